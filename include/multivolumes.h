@@ -1,0 +1,185 @@
+/*
+ * multivolumes.h -- C ABI of the MI355X-native cube-map-space volume ray-march path.
+ *
+ * This is the drop-in boundary for the path StarsX/MultiVolumes records in
+ *   MultiRayCaster::cullVolumes   (MultiVolumes/Content/MultiRayCaster.cpp:1249-1285)
+ *   MultiRayCaster::rayMarchL     (MultiRayCaster.cpp:1299-1327)
+ *   MultiRayCaster::rayMarchV     (MultiRayCaster.cpp:1329-1368)
+ *   cubeDepthPeel/renderCube/resolveOIT (MultiRayCaster.cpp:1440-1633)   [K-buffer OIT composite]
+ * i.e. "where the DX12 dispatch sits" (MultiRayCaster.cpp:1284, 1326, 1367).
+ *
+ * The reference has no FFI of its own: the path lives behind protected C++ methods that record
+ * D3D12 work.  Each entry point below names the reference method (file:line) whose effect it
+ * replaces.  Plain pointers and sizes only; 0 = success, negative = error; no exceptions cross
+ * the ABI.  The caller owns every host pointer; the context owns device memory unless a
+ * *_device entry point says the pointer is borrowed.
+ *
+ * Buffer layouts are the reference's (MultiRayCaster.cpp:23-56, 99-126, 455-549):
+ *   volume      RGBA16F  N^3      uint16[z][y][x][4]   (x fastest)
+ *   light map   R11G11B10F L^3    uint32[z][y][x]      (R bits 0-10, G 11-21, B 22-31)
+ *   depth map   R32F W*H          float[y][x]          (1.0 = far plane)
+ *   shadow map  D16_UNORM M*M     uint16[y][x]
+ *   cube map    RGBA16F (N>>mip)^2 x 6 faces: uint16[face][y][x][4]; faces +X,-X,+Y,-Y,+Z,-Z
+ *   cube depth  R32F, same shape: float[face][y][x]
+ *   PerObject   224 B per volume  {float4x4 WorldViewProj(T), float4x4 WorldViewProjI(T), float3x4 WorldI, float3x4 World}
+ *   CBPerFrame  212 B             {float4 EyePos, float4 Viewport, float4x4 ScreenToWorld(T), float4x4 ShadowViewProj(T),
+ *                                  float4 LightPos, float4 LightColor, float4 Ambient, uint FrameIdx}
+ *   VolumeDesc  u32               VolTexId:14 | NumMips:4 << 14 | CubeMapSize:14 << 18
+ *   VolumeInfo  4 x u16           {MipLevel, SmpCount, MaskBits (bit f = face f, bit 15 = cube-map scheme), VolTexId}
+ *
+ * Threading: one context per GPU; all work of a context is ordered on one hipStream_t;
+ * a context is not re-entrant; independent contexts may be driven from different threads.
+ */
+#ifndef MULTIVOLUMES_H
+#define MULTIVOLUMES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MV_NUM_CUBE_MIP 5			/* SharedConsts.h:6  NUM_CUBE_MIP */
+#define MV_NUM_OIT_LAYERS 8			/* SharedConsts.h:7  NUM_OIT_LAYERS */
+#define MV_PER_OBJECT_BYTES 224		/* MultiRayCaster.cpp:35-41 */
+#define MV_CB_PER_FRAME_BYTES 212	/* MultiRayCaster.cpp:23-33 */
+#define MV_CUBEMAP_RAYMARCH_BIT 0x8000u	/* Common.hlsli:11 */
+
+/* error codes */
+#define MV_OK 0
+#define MV_ERR_INVALID_ARG (-1)
+#define MV_ERR_HIP (-2)			/* a HIP runtime call failed; see mv_last_error() */
+#define MV_ERR_NO_DEVICE (-3)	/* no usable gfx950 device: the product has no CPU fallback */
+#define MV_ERR_OUT_OF_MEMORY (-4)
+#define MV_ERR_NOT_READY (-5)	/* an input the stage needs was never supplied */
+#define MV_ERR_RANGE (-6)
+
+/* mv_config.flags */
+#define MV_FLAG_NONE 0u
+#define MV_FLAG_FORCE_MIP0_ALL_FACES 1u	/* stress variant of SURVEY 8(d): cull forces mip 0, all 6 faces, cube-map scheme */
+
+typedef struct mv_ctx mv_ctx;
+
+typedef struct mv_config
+{
+	uint32_t struct_size;		/* = sizeof(mv_config) */
+	uint32_t grid_size;			/* N: volume edge and cube-map face edge (MultiRayCaster.cpp:103, 113, 478) */
+	uint32_t light_grid_size;	/* L (MultiRayCaster.cpp:123) */
+	uint32_t num_volumes;		/* V (MultiRayCaster.cpp:109-111) */
+	uint32_t num_volume_srcs;	/* S (MultiRayCaster.cpp:98) */
+	uint32_t viewport_w, viewport_h;	/* SetViewport (MultiRayCaster.cpp:226-241) */
+	uint32_t shadow_map_size;	/* M (ObjectRenderer.cpp:80-83; 1024 in the reference) */
+	int32_t device;				/* HIP device ordinal */
+	uint32_t flags;				/* MV_FLAG_* */
+	void* stream;				/* hipStream_t to order all work on; NULL = the context creates its own */
+	uint32_t shard_index;		/* multi-GPU: this context marches volumes v with v % shard_count == shard_index */
+	uint32_t shard_count;		/* 0 or 1 = unsharded */
+} mv_config;
+
+/* counters accumulated since the last mv_reset_stats (all device-side, exact) */
+typedef struct mv_stats
+{
+	uint64_t view_samples;		/* iterations of CSRayMarch.hlsl:117-153 that reach GetSample */
+	uint64_t lit_samples;		/* of those, alpha > 0.01 (light-map fetch, CSRayMarch.hlsl:128-130) */
+	uint64_t rays;				/* texels of visible faces whose ray hit the box */
+	uint64_t light_samples;		/* iterations of CastLightRay (RayMarch.hlsli:206-229) */
+	uint64_t composite_samples;	/* screen-space RayCast samples (RayCast.hlsli:62-102) */
+	uint64_t reserved[3];
+	double ms_cull, ms_march_light, ms_march_view, ms_composite;	/* HIP-event time per stage when profiling is on */
+	uint64_t n_cull, n_march_light, n_march_view, n_composite;		/* launches those sums cover */
+} mv_stats;
+
+const char* mv_error_string(int code);
+const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
+uint32_t mv_abi_version(void);
+
+/* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,
+ * zero-initialised), VolumeDesc[V] = {i % S, 5, N} (:471-479), VolumeInfo[V], visible / cube-map lists + counters. */
+int mv_create(const mv_config* cfg, mv_ctx** out);
+void mv_destroy(mv_ctx* ctx);
+
+/* Result of LoadVolumeData (MultiRayCaster.cpp:168-209): volume source `src` := N^3 RGBA16F texels from the host. */
+int mv_volume_upload_rgba16f(mv_ctx* ctx, uint32_t src, const uint16_t* rgba);
+/* Same, from a device pointer (copied, not borrowed). */
+int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgba);
+/* InitVolumeData (MultiRayCaster.cpp:243-264) = CSInitGridData.hlsl:10-27. */
+int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src);
+/* LoadVolumeData's compute pass = CSR32FToRGBA16F.hlsl:16-26 on a w x h x d R32F host array. */
+int mv_volume_load_r32f(mv_ctx* ctx, uint32_t src, const float* a, uint32_t w, uint32_t h, uint32_t d);
+/* createVolumeInfoBuffers (MultiRayCaster.cpp:471-488): replace the packed VolumeDesc[V]. */
+int mv_set_volume_descs(mv_ctx* ctx, const uint32_t* packed);
+
+/* SetRenderTargets (MultiRayCaster.cpp:211-224) hands the path DEPTH_MAP and SHADOW_MAP. Host copies: */
+int mv_set_depth_map(mv_ctx* ctx, const float* d32);		/* W x H */
+int mv_set_shadow_map(mv_ctx* ctx, const uint16_t* d16);	/* M x M */
+/* ...or borrowed device pointers, as the reference borrows ObjectRenderer's depth buffers (NULL = back to own copy) */
+int mv_set_depth_map_device(mv_ctx* ctx, const float* d_d32);
+int mv_set_shadow_map_device(mv_ctx* ctx, const uint16_t* d_d16);
+/* SetSH (MultiRayCaster.cpp:266-269): 9 x float3; NULL -> g_hasLightProbe = 0 (MultiRayCaster.cpp:1321). */
+int mv_set_sh(mv_ctx* ctx, const float* sh27);
+/* SetMaxSamples (MultiRayCaster.cpp:271-275). Defaults 256 / 96 (MultiRayCaster.cpp:65-66). */
+int mv_set_max_samples(mv_ctx* ctx, uint32_t maxRaySamples, uint32_t maxLightSamples);
+/* UpdateFrame (MultiRayCaster.cpp:316-353): the 212-byte CBPerFrame and V x 224-byte PerObject it writes. */
+int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject);
+
+/* cullVolumes (MultiRayCaster.cpp:1249-1285) = CSVolumeCull.hlsl:13-78. Lists come out in ascending volume order. */
+int mv_cull(mv_ctx* ctx);
+/* rayMarchL (MultiRayCaster.cpp:1299-1327) = CSRayMarchL.hlsl:20-121: relights ONE volume, visible[FrameIdx % count].
+ * Sharded contexts relight their own volume shard's member instead: owned_visible[FrameIdx % owned_count]. */
+int mv_march_light(mv_ctx* ctx);
+/* rayMarchV (MultiRayCaster.cpp:1329-1368) = CSRayMarch.hlsl:77-158 with _LIGHT_PASS_ (CSRayMarchV.hlsl). */
+int mv_march_view(mv_ctx* ctx);
+/* cubeDepthPeel + renderCube + resolveOIT (MultiRayCaster.cpp:1440-1492, 1544-1580, 1615-1633) over screen rows
+ * [row0, row1) of the W x H RGBA16F output (row1 = 0 -> H). Background = transparent black. */
+int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1);
+/* Render (MultiRayCaster.cpp:355-385), non-work-graph branch: cull -> marchL -> marchV [-> composite], then FrameIdx += 1 is the caller's job. */
+int mv_render(mv_ctx* ctx, int with_composite);
+
+/* CPU readback of the buffers the path emits (the reference's only "ReadBack" notion: XUSG.h:1614, 1860). */
+int mv_readback_volume_info(mv_ctx* ctx, uint16_t* dst /* V x 4 */);
+int mv_readback_visible_lists(mv_ctx* ctx, uint32_t* visible /* V */, uint32_t* visibleCount,
+	uint32_t* cubeMapVolumes /* V */, uint32_t* cubeMapCount);
+int mv_readback_volume(mv_ctx* ctx, uint32_t src, uint16_t* dst /* N^3 x 4 */);
+int mv_readback_light_map(mv_ctx* ctx, uint32_t volume, uint32_t* dst /* L^3 */);
+int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src /* L^3 */);	/* test/exchange hook */
+int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* dst /* 6 x d x d x 4 */);
+int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* dst /* 6 x d x d */);
+int mv_readback_composite(mv_ctx* ctx, uint16_t* dst /* W x H x 4 */);
+int mv_clear_cube_maps(mv_ctx* ctx);	/* zero every cube map / cube depth (creation state) */
+
+int mv_get_stats(mv_ctx* ctx, mv_stats* out);	/* synchronises the stream */
+int mv_reset_stats(mv_ctx* ctx);
+int mv_set_profiling(mv_ctx* ctx, int on);		/* record HIP events around every stage launch (adds host syncs in mv_get_stats only) */
+int mv_synchronize(mv_ctx* ctx);
+
+/* Raw handles for callers that keep data resident (torch / RCCL plumbing): */
+void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */
+/* device pointers + byte sizes of context-owned buffers; `which` = MV_BUF_* */
+#define MV_BUF_VOLUME 0			/* index = src */
+#define MV_BUF_LIGHT_MAP 1		/* index = volume */
+#define MV_BUF_CUBE_MAP 2		/* index = volume: whole 5-mip chain, uint16[chain][4] */
+#define MV_BUF_CUBE_DEPTH 3		/* index = volume */
+#define MV_BUF_VOLUME_INFO 4
+#define MV_BUF_COMPOSITE 5
+#define MV_BUF_DEPTH_MAP 6
+#define MV_BUF_SHADOW_MAP 7
+int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, size_t* bytes);
+
+/* texels (not bytes) of one volume's 5-mip cube chain and the offset of mip m inside it */
+uint64_t mv_cube_chain_texels(uint32_t N);
+uint64_t mv_cube_mip_offset(uint32_t N, uint32_t mip);
+
+/* ---- multi-GPU exchange: volumes shard v % shard_count; cube faces are all-gathered ---- */
+/* Bytes one rank contributes per frame: (V / shard_count) slots x slot_bytes, slot = 6 x d x d x (8 + 4) bytes with
+ * d = N >> min selected mip over all visible volumes (identical on every rank because cull is replicated). */
+int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size_t* shard_bytes);
+/* Pack this shard's selected-mip cube faces (colour then depth per slot) into d_dst (device, shard_bytes). */
+int mv_exchange_pack(mv_ctx* ctx, void* d_dst);
+/* Scatter an all-gathered buffer (shard_count x shard_bytes, rank-major) back into the cube maps / depths of every volume. */
+int mv_exchange_unpack(mv_ctx* ctx, const void* d_src);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

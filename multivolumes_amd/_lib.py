@@ -1,0 +1,158 @@
+"""ctypes loader for libmultivolumes_amd.so (the C ABI of include/multivolumes.h + include/multivolumes_host.h).
+
+The library is built in-tree by multivolumes_amd/csrc/build.sh (hipcc, gfx950 only).  There is no Python or CPU
+fallback for the device entry points: if the shared object is missing and cannot be built, importing fails loudly.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmultivolumes_amd.so")
+BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
+
+MV_OK = 0
+MV_ERR_INVALID_ARG = -1
+MV_ERR_HIP = -2
+MV_ERR_NO_DEVICE = -3
+MV_ERR_OUT_OF_MEMORY = -4
+MV_ERR_NOT_READY = -5
+MV_ERR_RANGE = -6
+
+MV_FLAG_FORCE_MIP0_ALL_FACES = 1
+
+MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
+MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7
+
+NUM_CUBE_MIP = 5
+PER_OBJECT_BYTES = 224
+CB_PER_FRAME_BYTES = 212
+
+
+class mv_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("grid_size", C.c_uint32), ("light_grid_size", C.c_uint32),
+        ("num_volumes", C.c_uint32), ("num_volume_srcs", C.c_uint32),
+        ("viewport_w", C.c_uint32), ("viewport_h", C.c_uint32), ("shadow_map_size", C.c_uint32),
+        ("device", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p),
+        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+    ]
+
+
+class mv_stats(C.Structure):
+    _fields_ = [
+        ("view_samples", C.c_uint64), ("lit_samples", C.c_uint64), ("rays", C.c_uint64),
+        ("light_samples", C.c_uint64), ("composite_samples", C.c_uint64), ("reserved", C.c_uint64 * 3),
+        ("ms_cull", C.c_double), ("ms_march_light", C.c_double), ("ms_march_view", C.c_double), ("ms_composite", C.c_double),
+        ("n_cull", C.c_uint64), ("n_march_light", C.c_uint64), ("n_march_view", C.c_uint64), ("n_composite", C.c_uint64),
+    ]
+
+
+_P = C.c_void_p
+_U32 = C.c_uint32
+_SZ = C.c_size_t
+
+# name -> (restype, argtypes).  Every symbol include/multivolumes.h and include/multivolumes_host.h declare.
+ABI = {
+    "mv_error_string": (C.c_char_p, [C.c_int]),
+    "mv_last_error": (C.c_char_p, [_P]),
+    "mv_abi_version": (_U32, []),
+    "mv_create": (C.c_int, [C.POINTER(mv_config), C.POINTER(_P)]),
+    "mv_destroy": (None, [_P]),
+    "mv_volume_upload_rgba16f": (C.c_int, [_P, _U32, _P]),
+    "mv_volume_upload_rgba16f_device": (C.c_int, [_P, _U32, _P]),
+    "mv_volume_init_procedural": (C.c_int, [_P, _U32]),
+    "mv_volume_load_r32f": (C.c_int, [_P, _U32, _P, _U32, _U32, _U32]),
+    "mv_set_volume_descs": (C.c_int, [_P, _P]),
+    "mv_set_depth_map": (C.c_int, [_P, _P]),
+    "mv_set_shadow_map": (C.c_int, [_P, _P]),
+    "mv_set_depth_map_device": (C.c_int, [_P, _P]),
+    "mv_set_shadow_map_device": (C.c_int, [_P, _P]),
+    "mv_set_sh": (C.c_int, [_P, _P]),
+    "mv_set_max_samples": (C.c_int, [_P, _U32, _U32]),
+    "mv_update_frame": (C.c_int, [_P, _P, _P]),
+    "mv_cull": (C.c_int, [_P]),
+    "mv_march_light": (C.c_int, [_P]),
+    "mv_march_view": (C.c_int, [_P]),
+    "mv_composite": (C.c_int, [_P, _U32, _U32]),
+    "mv_render": (C.c_int, [_P, C.c_int]),
+    "mv_readback_volume_info": (C.c_int, [_P, _P]),
+    "mv_readback_visible_lists": (C.c_int, [_P, _P, C.POINTER(_U32), _P, C.POINTER(_U32)]),
+    "mv_readback_volume": (C.c_int, [_P, _U32, _P]),
+    "mv_readback_light_map": (C.c_int, [_P, _U32, _P]),
+    "mv_upload_light_map": (C.c_int, [_P, _U32, _P]),
+    "mv_readback_cube_map": (C.c_int, [_P, _U32, _U32, _P]),
+    "mv_readback_cube_depth": (C.c_int, [_P, _U32, _U32, _P]),
+    "mv_readback_composite": (C.c_int, [_P, _P]),
+    "mv_clear_cube_maps": (C.c_int, [_P]),
+    "mv_get_stats": (C.c_int, [_P, C.POINTER(mv_stats)]),
+    "mv_reset_stats": (C.c_int, [_P]),
+    "mv_set_profiling": (C.c_int, [_P, C.c_int]),
+    "mv_synchronize": (C.c_int, [_P]),
+    "mv_get_stream": (_P, [_P]),
+    "mv_get_buffer": (C.c_int, [_P, _U32, _U32, C.POINTER(_P), C.POINTER(_SZ)]),
+    "mv_cube_chain_texels": (C.c_uint64, [_U32]),
+    "mv_cube_mip_offset": (C.c_uint64, [_U32, _U32]),
+    "mv_exchange_layout": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "mv_exchange_pack": (C.c_int, [_P, _P]),
+    "mv_exchange_unpack": (C.c_int, [_P, _P]),
+    # host helpers
+    "mvh_look_at_lh": (None, [_P, _P, _P, _P]),
+    "mvh_perspective_fov_lh": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "mvh_orthographic_lh": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _P]),
+    "mvh_multiply": (None, [_P, _P, _P]),
+    "mvh_inverse": (C.c_int, [_P, _P]),
+    "mvh_set_volume_world": (None, [C.c_float, _P, _P]),
+    "mvh_set_volumes_world": (None, [_U32, C.c_float, _P, _P]),
+    "mvh_shadow_view_proj": (None, [_P, C.c_float, _P]),
+    "mvh_update_frame": (None, [_U32, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _U32, _P, _P]),
+    "mvh_synth_volume": (None, [_U32, _U32, _P]),
+    "mvh_synth_sphere_depth": (None, [_U32, _U32, _P, _P, C.c_float, _P]),
+    "mvh_synth_sphere_shadow": (None, [_U32, _P, _P, C.c_float, _P]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
+    if force or not os.path.exists(LIB_PATH) or _stale():
+        subprocess.run(["bash", BUILD_SCRIPT], check=True)
+    return LIB_PATH
+
+
+def _stale():
+    try:
+        t = os.path.getmtime(LIB_PATH)
+        src = os.path.join(_HERE, "csrc")
+        inc = os.path.join(os.path.dirname(_HERE), "include")
+        for d in (src, inc):
+            for f in os.listdir(d):
+                if f.endswith((".hip", ".cpp", ".hpp", ".h")) and os.path.getmtime(os.path.join(d, f)) > t:
+                    return True
+    except OSError:
+        return True
+    return False
+
+
+def load():
+    """Load the shared library and set ctypes signatures; raises if it cannot be found or built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in ABI.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class MVError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        msg = load().mv_error_string(code).decode()
+        super().__init__(f"{where}: {msg} ({code})" + (f": {detail}" if detail else ""))

@@ -1,0 +1,664 @@
+// mv_api.cpp -- the C-ABI of include/multivolumes.h: context, device memory, stream-ordered stage launches.
+//
+// Host-side counterpart of MultiRayCaster (MultiVolumes/Content/MultiRayCaster.{h,cpp}): where the reference records
+// D3D12 dispatches into an XUSG command list, this layer launches the gfx950 kernels of mv_kernels.hip on one HIP stream.
+// Kernel order on the stream = the reference's barrier graph (cull -> marchL -> marchV -> composite).
+// There is no CPU fallback: without a gfx950 device every entry point fails.
+#include "../../include/multivolumes.h"
+#include "mv_kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <new>
+
+using mv::DeviceState;
+
+namespace
+{
+constexpr uint32_t kFrameSlices = 3;	// MultiRayCaster::FrameCount (MultiRayCaster.h:52): upload slices in flight
+constexpr uint32_t kNumCounters = 8;
+constexpr uint32_t kNumStats = 8;
+
+struct EventPair { hipEvent_t a, b; int stage; };
+}
+
+struct mv_ctx
+{
+	mv_config cfg;
+	hipStream_t stream = nullptr;
+	bool ownStream = false;
+	DeviceState st;
+
+	// owned device allocations
+	std::vector<uint2*> volumes;
+	uint2** dVolumePtrs = nullptr;
+	uint2* staging = nullptr;			// N^3 linear RGBA16F (upload / readback re-tiling)
+	size_t stagingBytes = 0;
+	float* ownDepth = nullptr;
+	uint16_t* ownShadow = nullptr;
+	void* dCb = nullptr;
+	void* dPerObject = nullptr;
+	uint32_t* dDescs = nullptr;
+	float* dSh = nullptr;
+	std::vector<void*> allocs;			// everything to hipFree
+
+	// pinned upload ring (the reference's upload-heap slices, MultiRayCaster.cpp:128-130, 461-467)
+	uint8_t* pinned = nullptr;
+	size_t sliceBytes = 0;
+	uint32_t slice = 0;
+	hipEvent_t sliceDone[kFrameSlices] = {};
+	uint64_t* pinnedStats = nullptr;
+	uint32_t* pinnedCounters = nullptr;
+
+	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
+	bool profiling = false;
+	std::vector<EventPair> pending;
+	std::vector<EventPair> freeEvents;
+	double msStage[4] = { 0, 0, 0, 0 };
+	uint64_t nStage[4] = { 0, 0, 0, 0 };
+	std::string lastError;
+};
+
+namespace
+{
+int fail(mv_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+	if (ctx)
+	{
+		char buf[512];
+		if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
+		else snprintf(buf, sizeof(buf), "%s", what);
+		ctx->lastError = buf;
+	}
+	return code;
+}
+
+#define MV_HIP(ctx, call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? MV_ERR_OUT_OF_MEMORY : MV_ERR_HIP, #call, e_); } while (0)
+#define MV_REQUIRE(ctx, cond, code, msg) do { if (!(cond)) return fail(ctx, code, msg); } while (0)
+
+template <typename T>
+int devAlloc(mv_ctx* ctx, T** out, size_t bytes, bool zero = true)
+{
+	void* p = nullptr;
+	MV_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
+	ctx->allocs.push_back(p);
+	if (zero) MV_HIP(ctx, hipMemsetAsync(p, 0, bytes ? bytes : 16, ctx->stream));
+	*out = reinterpret_cast<T*>(p);
+	return MV_OK;
+}
+
+void beginStage(mv_ctx* ctx, int stage, EventPair& ev)
+{
+	if (!ctx->profiling) return;
+	if (!ctx->freeEvents.empty()) { ev = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); }
+	else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+	ev.stage = stage;
+	(void)hipEventRecord(ev.a, ctx->stream);
+}
+
+void endStage(mv_ctx* ctx, EventPair& ev)
+{
+	if (!ctx->profiling) return;
+	(void)hipEventRecord(ev.b, ctx->stream);
+	ctx->pending.push_back(ev);
+}
+
+void foldEvents(mv_ctx* ctx)
+{
+	for (EventPair& ev : ctx->pending)
+	{
+		(void)hipEventSynchronize(ev.b);
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
+		{
+			ctx->msStage[ev.stage] += ms;
+			ctx->nStage[ev.stage] += 1;
+		}
+		ctx->freeEvents.push_back(ev);
+	}
+	ctx->pending.clear();
+}
+
+} // namespace
+
+extern "C" {
+
+const char* mv_error_string(int code)
+{
+	switch (code)
+	{
+	case MV_OK: return "ok";
+	case MV_ERR_INVALID_ARG: return "invalid argument";
+	case MV_ERR_HIP: return "HIP runtime error";
+	case MV_ERR_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
+	case MV_ERR_OUT_OF_MEMORY: return "out of device memory";
+	case MV_ERR_NOT_READY: return "a required input was never supplied";
+	case MV_ERR_RANGE: return "index out of range";
+	default: return "unknown error";
+	}
+}
+
+const char* mv_last_error(const mv_ctx* ctx) { return ctx ? ctx->lastError.c_str() : ""; }
+uint32_t mv_abi_version(void) { return 1u; }
+uint64_t mv_cube_chain_texels(uint32_t N) { return mv::cubeChainTexels(N); }
+uint64_t mv_cube_mip_offset(uint32_t N, uint32_t mip) { return mv::cubeMipOffset(N, mip); }
+
+int mv_create(const mv_config* cfg, mv_ctx** out)
+{
+	if (!cfg || !out || cfg->struct_size != sizeof(mv_config)) return MV_ERR_INVALID_ARG;
+	*out = nullptr;
+	if (cfg->grid_size < 2 || cfg->grid_size > 16383 || cfg->light_grid_size < 2 || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
+		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
+		return MV_ERR_INVALID_ARG;
+	if (cfg->shard_count > 1 && cfg->shard_index >= cfg->shard_count) return MV_ERR_INVALID_ARG;
+
+	int nDev = 0;
+	if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0 || cfg->device < 0 || cfg->device >= nDev) return MV_ERR_NO_DEVICE;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return MV_ERR_NO_DEVICE;
+	if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return MV_ERR_NO_DEVICE;	// kernels are built for gfx950 only
+	if (hipSetDevice(cfg->device) != hipSuccess) return MV_ERR_NO_DEVICE;
+
+	mv_ctx* ctx = new (std::nothrow) mv_ctx();
+	if (!ctx) return MV_ERR_OUT_OF_MEMORY;
+	ctx->cfg = *cfg;
+	memset(&ctx->st, 0, sizeof(ctx->st));
+
+	int rc = MV_OK;
+	auto bail = [&](int code) { *out = nullptr; mv_destroy(ctx); return code; };
+
+	if (cfg->stream) ctx->stream = reinterpret_cast<hipStream_t>(cfg->stream);
+	else
+	{
+		if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
+		ctx->ownStream = true;
+	}
+
+	DeviceState& st = ctx->st;
+	st.N = cfg->grid_size; st.bricks = (cfg->grid_size + 3u) >> 2; st.L = cfg->light_grid_size;
+	st.V = cfg->num_volumes; st.S = cfg->num_volume_srcs; st.W = cfg->viewport_w; st.H = cfg->viewport_h; st.M = cfg->shadow_map_size;
+	st.flags = cfg->flags; st.shardIndex = cfg->shard_count > 1 ? cfg->shard_index : 0u; st.shardCount = cfg->shard_count > 1 ? cfg->shard_count : 1u;
+	st.maxRaySamples = 256; st.maxLightSamples = 96;	// MultiRayCaster.cpp:65-66
+	st.hasLightProbe = 0;
+
+	const size_t brickedBytes = (size_t)st.bricks * st.bricks * st.bricks * 64 * sizeof(uint2);
+	const size_t chain = mv::cubeChainTexels(st.N);
+	const size_t L3 = (size_t)st.L * st.L * st.L;
+
+	// volumes[S] (MultiRayCaster.cpp:98-105)
+	ctx->volumes.resize(st.S, nullptr);
+	for (uint32_t i = 0; i < st.S; ++i)
+		if ((rc = devAlloc(ctx, &ctx->volumes[i], brickedBytes)) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->dVolumePtrs, st.S * sizeof(uint2*), false)) != MV_OK) return bail(rc);
+	if (hipMemcpyAsync(ctx->dVolumePtrs, ctx->volumes.data(), st.S * sizeof(uint2*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	st.volumes = ctx->dVolumePtrs;
+
+	ctx->stagingBytes = (size_t)st.N * st.N * st.N * sizeof(uint2);
+	if ((rc = devAlloc(ctx, &ctx->staging, ctx->stagingBytes, false)) != MV_OK) return bail(rc);
+
+	// lightMaps[V], cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-126), all zero-initialised
+	if ((rc = devAlloc(ctx, &st.lightMaps, (size_t)st.V * L3 * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->ownDepth, (size_t)st.W * st.H * sizeof(float))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->ownShadow, (size_t)st.M * st.M * sizeof(uint16_t))) != MV_OK) return bail(rc);
+	st.depthMap = ctx->ownDepth; st.shadowMap = ctx->ownShadow;
+
+	// createVolumeInfoBuffers (MultiRayCaster.cpp:455-549)
+	if ((rc = devAlloc(ctx, &ctx->dCb, 256)) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->dPerObject, (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->dDescs, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->dSh, 27 * sizeof(float))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.volumeInfo, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.visibleVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.cubeMapVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.counters, kNumCounters * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.workEntries, (size_t)st.V * 6 * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.workTileStart, ((size_t)st.V * 6 + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.cubeOffset, (size_t)st.V * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.stats, kNumStats * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	st.cbPerFrame = ctx->dCb; st.perObject = ctx->dPerObject; st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
+
+	// pinned upload ring + readback scratch
+	ctx->sliceBytes = 256 + (size_t)st.V * MV_PER_OBJECT_BYTES;
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kFrameSlices + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
+	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices);
+	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices + 128);
+	for (uint32_t i = 0; i < kFrameSlices; ++i)
+		if (hipEventCreateWithFlags(&ctx->sliceDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
+
+	// default VolumeDesc[V] = { i % S, NUM_CUBE_MIP, N } (MultiRayCaster.cpp:471-479)
+	{
+		std::vector<uint32_t> descs(st.V);
+		for (uint32_t i = 0; i < st.V; ++i) descs[i] = (i % st.S) | ((uint32_t)MV_NUM_CUBE_MIP << 14) | (st.N << 18);
+		if (hipMemcpyAsync(ctx->dDescs, descs.data(), descs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+		if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	}
+
+	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	*out = ctx;
+	return MV_OK;
+}
+
+void mv_destroy(mv_ctx* ctx)
+{
+	if (!ctx) return;
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	foldEvents(ctx);
+	for (EventPair& ev : ctx->freeEvents) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
+	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
+	for (void* p : ctx->allocs) (void)hipFree(p);
+	if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+	if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+int mv_volume_upload_rgba16f(mv_ctx* ctx, uint32_t src, const uint16_t* rgba)
+{
+	if (!ctx || !rgba) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	MV_HIP(ctx, hipMemcpyAsync(ctx->staging, rgba, ctx->stagingBytes, hipMemcpyHostToDevice, ctx->stream));
+	mv::launchRetile(ctx->stream, ctx->staging, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));	// the caller may reuse `rgba` and the staging buffer is shared
+	return MV_OK;
+}
+
+int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgba)
+{
+	if (!ctx || !d_rgba) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	mv::launchRetile(ctx->stream, reinterpret_cast<const uint2*>(d_rgba), ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	mv::launchInitGridData(ctx->stream, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+int mv_volume_load_r32f(mv_ctx* ctx, uint32_t src, const float* a, uint32_t w, uint32_t h, uint32_t d)
+{
+	if (!ctx || !a || !w || !h || !d) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	float* dSrc = nullptr;
+	const size_t bytes = (size_t)w * h * d * sizeof(float);
+	MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&dSrc), bytes));
+	hipError_t e = hipMemcpyAsync(dSrc, a, bytes, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess)
+	{
+		mv::launchR32FToRGBA16F(ctx->stream, dSrc, w, h, d, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+		e = hipGetLastError();
+	}
+	const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+	(void)hipFree(dSrc);
+	MV_HIP(ctx, e);
+	MV_HIP(ctx, e2);
+	return MV_OK;
+}
+
+int mv_set_volume_descs(mv_ctx* ctx, const uint32_t* packed)
+{
+	if (!ctx || !packed) return MV_ERR_INVALID_ARG;
+	for (uint32_t i = 0; i < ctx->st.V; ++i)
+	{
+		MV_REQUIRE(ctx, (packed[i] & 0x3fffu) < ctx->st.S, MV_ERR_RANGE, "VolumeDesc.VolTexId out of range");
+		MV_REQUIRE(ctx, (packed[i] >> 18) == ctx->st.N, MV_ERR_INVALID_ARG, "VolumeDesc.CubeMapSize must equal grid_size");
+		const uint32_t mips = (packed[i] >> 14) & 0xfu;
+		MV_REQUIRE(ctx, mips >= 1 && mips <= MV_NUM_CUBE_MIP, MV_ERR_INVALID_ARG, "VolumeDesc.NumMips must be 1..5");
+	}
+	MV_HIP(ctx, hipMemcpyAsync(ctx->dDescs, packed, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_set_depth_map(mv_ctx* ctx, const float* d32)
+{
+	if (!ctx || !d32) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipMemcpyAsync(ctx->ownDepth, d32, (size_t)ctx->st.W * ctx->st.H * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->st.depthMap = ctx->ownDepth;
+	ctx->haveDepth = true;
+	return MV_OK;
+}
+
+int mv_set_shadow_map(mv_ctx* ctx, const uint16_t* d16)
+{
+	if (!ctx || !d16) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipMemcpyAsync(ctx->ownShadow, d16, (size_t)ctx->st.M * ctx->st.M * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->st.shadowMap = ctx->ownShadow;
+	ctx->haveShadow = true;
+	return MV_OK;
+}
+
+int mv_set_depth_map_device(mv_ctx* ctx, const float* d_d32)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	ctx->st.depthMap = d_d32 ? d_d32 : ctx->ownDepth;
+	if (d_d32) ctx->haveDepth = true;
+	return MV_OK;
+}
+
+int mv_set_shadow_map_device(mv_ctx* ctx, const uint16_t* d_d16)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	ctx->st.shadowMap = d_d16 ? d_d16 : ctx->ownShadow;
+	if (d_d16) ctx->haveShadow = true;
+	return MV_OK;
+}
+
+int mv_set_sh(mv_ctx* ctx, const float* sh27)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	if (sh27)
+	{
+		MV_HIP(ctx, hipMemcpyAsync(ctx->dSh, sh27, 27 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+		MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	ctx->st.hasLightProbe = sh27 ? 1u : 0u;
+	return MV_OK;
+}
+
+int mv_set_max_samples(mv_ctx* ctx, uint32_t maxRaySamples, uint32_t maxLightSamples)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, maxRaySamples >= 1 && maxRaySamples <= 65535 && maxLightSamples >= 1 && maxLightSamples <= 65535, MV_ERR_INVALID_ARG,
+		"sample counts must fit the u16 VolumeInfo.SmpCount field");
+	ctx->st.maxRaySamples = maxRaySamples;
+	ctx->st.maxLightSamples = maxLightSamples;
+	return MV_OK;
+}
+
+int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
+{
+	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
+	const uint32_t k = ctx->slice;
+	ctx->slice = (k + 1) % kFrameSlices;
+	MV_HIP(ctx, hipEventSynchronize(ctx->sliceDone[k]));	// slice k was last used three frames ago
+	uint8_t* s = ctx->pinned + (size_t)k * ctx->sliceBytes;
+	memcpy(s, cbPerFrame, MV_CB_PER_FRAME_BYTES);
+	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
+	MV_HIP(ctx, hipMemcpyAsync(ctx->dCb, s, MV_CB_PER_FRAME_BYTES, hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipMemcpyAsync(ctx->dPerObject, s + 256, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES, hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->stream));
+	ctx->haveFrame = true;
+	return MV_OK;
+}
+
+int mv_cull(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->haveFrame, MV_ERR_NOT_READY, "mv_update_frame has not been called");
+	EventPair ev;
+	beginStage(ctx, 0, ev);
+	mv::launchCull(ctx->stream, ctx->st);
+	endStage(ctx, ev);
+	MV_HIP(ctx, hipGetLastError());
+	ctx->haveCull = true;
+	return MV_OK;
+}
+
+int mv_march_light(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
+	EventPair ev;
+	beginStage(ctx, 1, ev);
+	mv::launchMarchLight(ctx->stream, ctx->st);
+	endStage(ctx, ev);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+int mv_march_view(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
+	EventPair ev;
+	beginStage(ctx, 2, ev);
+	mv::launchMarchView(ctx->stream, ctx->st);
+	endStage(ctx, ev);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
+	if (row1 == 0 || row1 > ctx->st.H) row1 = ctx->st.H;
+	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
+	EventPair ev;
+	beginStage(ctx, 3, ev);
+	mv::launchComposite(ctx->stream, ctx->st, row0, row1);
+	endStage(ctx, ev);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+int mv_render(mv_ctx* ctx, int with_composite)
+{
+	int rc;
+	if ((rc = mv_cull(ctx)) != MV_OK) return rc;
+	if ((rc = mv_march_light(ctx)) != MV_OK) return rc;
+	if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
+	if (with_composite && (rc = mv_composite(ctx, 0, 0)) != MV_OK) return rc;
+	return MV_OK;
+}
+
+int mv_readback_volume_info(mv_ctx* ctx, uint16_t* dst)
+{
+	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.volumeInfo, (size_t)ctx->st.V * 4 * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_readback_visible_lists(mv_ctx* ctx, uint32_t* visible, uint32_t* visibleCount, uint32_t* cubeMapVolumes, uint32_t* cubeMapCount)
+{
+	if (!ctx || !visible || !visibleCount || !cubeMapVolumes || !cubeMapCount) return MV_ERR_INVALID_ARG;
+	uint32_t counters[kNumCounters];
+	MV_HIP(ctx, hipMemcpyAsync(counters, ctx->st.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipMemcpyAsync(visible, ctx->st.visibleVolumes, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipMemcpyAsync(cubeMapVolumes, ctx->st.cubeMapVolumes, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*visibleCount = counters[0];
+	*cubeMapCount = counters[1];
+	return MV_OK;
+}
+
+int mv_readback_volume(mv_ctx* ctx, uint32_t src, uint16_t* dst)
+{
+	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	mv::launchUntile(ctx->stream, ctx->volumes[src], ctx->staging, ctx->st.N, ctx->st.bricks);
+	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->staging, ctx->stagingBytes, hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_readback_light_map(mv_ctx* ctx, uint32_t volume, uint32_t* dst)
+{
+	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
+	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.lightMaps + volume * L3, L3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src)
+{
+	if (!ctx || !src) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
+	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
+	MV_HIP(ctx, hipMemcpyAsync(ctx->st.lightMaps + volume * L3, src, L3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* dst)
+{
+	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, volume < ctx->st.V && mip < MV_NUM_CUBE_MIP, MV_ERR_RANGE, "volume / mip out of range");
+	const size_t d = ctx->st.N >> mip;
+	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.cubeMaps + off, 6 * d * d * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* dst)
+{
+	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, volume < ctx->st.V && mip < MV_NUM_CUBE_MIP, MV_ERR_RANGE, "volume / mip out of range");
+	const size_t d = ctx->st.N >> mip;
+	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.cubeDepths + off, 6 * d * d * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_readback_composite(mv_ctx* ctx, uint16_t* dst)
+{
+	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.composite, (size_t)ctx->st.W * ctx->st.H * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_clear_cube_maps(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	const size_t chain = mv::cubeChainTexels(ctx->st.N);
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.cubeMaps, 0, (size_t)ctx->st.V * chain * sizeof(uint2), ctx->stream));
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.cubeDepths, 0, (size_t)ctx->st.V * chain * sizeof(float), ctx->stream));
+	return MV_OK;
+}
+
+int mv_get_stats(mv_ctx* ctx, mv_stats* out)
+{
+	if (!ctx || !out) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedStats, ctx->st.stats, kNumStats * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	foldEvents(ctx);
+	memset(out, 0, sizeof(*out));
+	out->view_samples = ctx->pinnedStats[0];
+	out->lit_samples = ctx->pinnedStats[1];
+	out->rays = ctx->pinnedStats[2];
+	out->light_samples = ctx->pinnedStats[3];
+	out->composite_samples = ctx->pinnedStats[4];
+	out->ms_cull = ctx->msStage[0]; out->ms_march_light = ctx->msStage[1]; out->ms_march_view = ctx->msStage[2]; out->ms_composite = ctx->msStage[3];
+	out->n_cull = ctx->nStage[0]; out->n_march_light = ctx->nStage[1]; out->n_march_view = ctx->nStage[2]; out->n_composite = ctx->nStage[3];
+	return MV_OK;
+}
+
+int mv_reset_stats(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	foldEvents(ctx);
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
+	for (int i = 0; i < 4; ++i) { ctx->msStage[i] = 0.0; ctx->nStage[i] = 0; }
+	return MV_OK;
+}
+
+int mv_set_profiling(mv_ctx* ctx, int on)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	ctx->profiling = on != 0;
+	return MV_OK;
+}
+
+int mv_synchronize(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+void* mv_get_stream(mv_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
+
+int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, size_t* bytes)
+{
+	if (!ctx || !d_ptr || !bytes) return MV_ERR_INVALID_ARG;
+	const DeviceState& st = ctx->st;
+	const size_t chain = mv::cubeChainTexels(st.N);
+	const size_t L3 = (size_t)st.L * st.L * st.L;
+	switch (which)
+	{
+	case MV_BUF_VOLUME:
+		MV_REQUIRE(ctx, index < st.S, MV_ERR_RANGE, "volume source index out of range");
+		*d_ptr = ctx->volumes[index]; *bytes = (size_t)st.bricks * st.bricks * st.bricks * 64 * sizeof(uint2); return MV_OK;
+	case MV_BUF_LIGHT_MAP:
+		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
+		*d_ptr = st.lightMaps + index * L3; *bytes = L3 * sizeof(uint32_t); return MV_OK;
+	case MV_BUF_CUBE_MAP:
+		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
+		*d_ptr = st.cubeMaps + index * chain; *bytes = chain * sizeof(uint2); return MV_OK;
+	case MV_BUF_CUBE_DEPTH:
+		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
+		*d_ptr = st.cubeDepths + index * chain; *bytes = chain * sizeof(float); return MV_OK;
+	case MV_BUF_VOLUME_INFO: *d_ptr = st.volumeInfo; *bytes = (size_t)st.V * 8; return MV_OK;
+	case MV_BUF_COMPOSITE: *d_ptr = st.composite; *bytes = (size_t)st.W * st.H * sizeof(uint2); return MV_OK;
+	case MV_BUF_DEPTH_MAP: *d_ptr = ctx->ownDepth; *bytes = (size_t)st.W * st.H * sizeof(float); return MV_OK;
+	case MV_BUF_SHADOW_MAP: *d_ptr = ctx->ownShadow; *bytes = (size_t)st.M * st.M * sizeof(uint16_t); return MV_OK;
+	default: return fail(ctx, MV_ERR_INVALID_ARG, "unknown buffer id");
+	}
+}
+
+int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size_t* shard_bytes)
+{
+	if (!ctx || !slot_dim || !slot_bytes || !shard_bytes) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedCounters, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t minMip = ctx->pinnedCounters[5] < MV_NUM_CUBE_MIP ? ctx->pinnedCounters[5] : 0u;
+	const uint32_t d = ctx->st.N >> minMip;
+	*slot_dim = d;
+	*slot_bytes = (size_t)6 * d * d * (sizeof(uint2) + sizeof(float));
+	const uint32_t sc = ctx->st.shardCount ? ctx->st.shardCount : 1u;
+	*shard_bytes = *slot_bytes * ((ctx->st.V + sc - 1u) / sc);
+	return MV_OK;
+}
+
+int mv_exchange_pack(mv_ctx* ctx, void* d_dst)
+{
+	if (!ctx || !d_dst) return MV_ERR_INVALID_ARG;
+	uint32_t d; size_t sb, tb;
+	const int rc = mv_exchange_layout(ctx, &d, &sb, &tb);
+	if (rc != MV_OK) return rc;
+	mv::launchExchangePack(ctx->stream, ctx->st, d, d_dst);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+int mv_exchange_unpack(mv_ctx* ctx, const void* d_src)
+{
+	if (!ctx || !d_src) return MV_ERR_INVALID_ARG;
+	uint32_t d; size_t sb, tb;
+	const int rc = mv_exchange_layout(ctx, &d, &sb, &tb);
+	if (rc != MV_OK) return rc;
+	mv::launchExchangeUnpack(ctx->stream, ctx->st, d, d_src);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,363 @@
+// mv_device.hpp -- device-side building blocks of the ray-march path (gfx950 only).
+//
+// CDNA has no texture units, so everything the reference leaves to the D3D12 fixed-function sampler
+// (MultiRayCaster.cpp:556-566: LINEAR_CLAMP, POINT_CLAMP, LINEAR_LESS_EQUAL) is written out here:
+// texel-centre addressing, clamp, fp16 / 11-11-10 decode, filter weights, comparison PCF.
+//
+// Numeric contract (DESIGN.md "Numerics"): fp32 arithmetic, fp16/packed formats only in storage;
+// compiled with -ffp-contract=off, a multiply-add is fused only where __builtin_fmaf is written
+// (lerp, ray-point evaluation); HLSL min/max = fminf/fmaxf (NaN-ignoring); normalize = v / sqrt(dot).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mv
+{
+constexpr float kMaxDist = 3.4641016151377544f;	// Sh/RayMarch.hlsli:17  2.0 * sqrt(3.0)
+constexpr float kAbsorption = 0.8f;				// Sh/RayMarch.hlsli:11
+constexpr float kZeroThreshold = 0.01f;			// Sh/RayMarch.hlsli:12
+constexpr float kPI = 3.1415926535897f;			// XUSG/Shaders/SHIrradiance.hlsli:5-7
+constexpr float kFltMax = 3.402823466e+38f;		// Sh/Common.hlsli:9
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kZNear = 1.0f, kZFar = 1000.0f;	// SharedConsts.h:9-10
+constexpr uint32_t kNumCubeMip = 5;				// SharedConsts.h:6
+constexpr uint32_t kNumOitLayers = 8;			// SharedConsts.h:7
+constexpr uint32_t kCubeMapRayMarchBit = 1u << 15;	// Sh/Common.hlsli:11
+
+struct vec3 { float x, y, z; };
+struct vec4 { float x, y, z, w; };
+
+__device__ __forceinline__ vec3 v3(float x, float y, float z) { vec3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ vec3 operator+(vec3 a, vec3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ vec3 operator-(vec3 a, vec3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ vec3 operator/(vec3 a, vec3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ float comp(const vec3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+__device__ __forceinline__ float dot3(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ vec3 normalize3(vec3 v) { const float l = __builtin_sqrtf(dot3(v, v)); return v3(v.x / l, v.y / l, v.z / l); }
+__device__ __forceinline__ float saturatef(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
+__device__ __forceinline__ float lerpf(float a, float b, float w) { return __builtin_fmaf(w, b - a, a); }
+__device__ __forceinline__ float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+__device__ __forceinline__ vec3 rayAt(vec3 o, vec3 d, float t) { return v3(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z)); }
+__device__ __forceinline__ bool outsideBox(vec3 p) { return __builtin_fabsf(p.x) > 1.0f || __builtin_fabsf(p.y) > 1.0f || __builtin_fabsf(p.z) > 1.0f; }
+
+__device__ __forceinline__ uint32_t f2u_sat(float x)	// D3D ftou
+{
+	if (!(x > 0.0f)) return 0u;
+	if (x >= 4294967296.0f) return 0xffffffffu;
+	return (uint32_t)x;
+}
+
+__device__ __forceinline__ int floor_to_int(float x)	// saturating floor for texel addressing; NaN -> 0
+{
+	if (!(x == x)) return 0;
+	const float f = __builtin_floorf(x);
+	if (f <= -2147483648.0f) return INT32_MIN;
+	if (f >= 2147483520.0f) return INT32_MAX - 127;
+	return (int)f;
+}
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- structured/constant buffer layouts (Sh/Common.hlsli:28-49; MultiRayCaster.cpp:23-41, 341-351) ----
+// float4x4 written transposed by the host and read column-major: M[r][c] = f[4*c + r]; float4x3 likewise, c < 3.
+struct PerObject
+{
+	float wvp[16], wvpI[16], worldI[12], world[12];
+};
+
+struct CBPerFrame
+{
+	float eyePos[4];
+	float viewport[4];
+	float screenToWorld[16];
+	float shadowViewProj[16];
+	float lightPos[4];
+	float lightColor[4];
+	float ambient[4];
+	uint32_t frameIdx;
+};
+
+static_assert(sizeof(PerObject) == 224, "PerObject must stay 224 bytes (MultiRayCaster.cpp:35-41)");
+static_assert(sizeof(CBPerFrame) == 212, "CBPerFrame must stay 212 bytes (MultiRayCaster.cpp:23-33)");
+
+__device__ __forceinline__ vec4 mul44(vec4 p, const float* m)	// mul(float4, float4x4)
+{
+	vec4 r;
+	r.x = p.x * m[0] + p.y * m[1] + p.z * m[2] + p.w * m[3];
+	r.y = p.x * m[4] + p.y * m[5] + p.z * m[6] + p.w * m[7];
+	r.z = p.x * m[8] + p.y * m[9] + p.z * m[10] + p.w * m[11];
+	r.w = p.x * m[12] + p.y * m[13] + p.z * m[14] + p.w * m[15];
+	return r;
+}
+
+__device__ __forceinline__ vec3 mul43(vec3 p, const float* m)	// mul(float4(p, 1), float4x3)
+{
+	return v3(p.x * m[0] + p.y * m[1] + p.z * m[2] + m[3],
+		p.x * m[4] + p.y * m[5] + p.z * m[6] + m[7],
+		p.x * m[8] + p.y * m[9] + p.z * m[10] + m[11]);
+}
+
+__device__ __forceinline__ vec3 mul33(vec3 p, const float* m)	// mul(float3, (float3x3)float4x3)
+{
+	return v3(p.x * m[0] + p.y * m[1] + p.z * m[2],
+		p.x * m[4] + p.y * m[5] + p.z * m[6],
+		p.x * m[8] + p.y * m[9] + p.z * m[10]);
+}
+
+// ---- formats ----
+__device__ __forceinline__ float half_bits_to_float(uint32_t h)
+{
+	return (float)__builtin_bit_cast(_Float16, (uint16_t)h);
+}
+
+__device__ __forceinline__ uint16_t float_to_half_bits(float f)	// RNE (v_cvt_f16_f32)
+{
+	return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+// R11G11B10_FLOAT texel -> fp32: 5-bit exponent fields line up with fp16 after a left shift.
+__device__ __forceinline__ vec3 unpack_r11g11b10f(uint32_t p)
+{
+	return v3(half_bits_to_float((p & 0x7ffu) << 4), half_bits_to_float(((p >> 11) & 0x7ffu) << 4), half_bits_to_float((p >> 22) << 5));
+}
+
+// fp32 magnitude bits -> unsigned small float with 5 exponent / MB mantissa bits, round to nearest even
+template <int MB>
+__device__ __forceinline__ uint32_t f32_to_small(uint32_t a)
+{
+	constexpr int SH = 23 - MB;
+	constexpr uint32_t INF = 31u << MB;
+	if (a > 0x7f800000u) return INF | (1u << (MB - 1));
+	if (a == 0x7f800000u) return INF;
+	const int e = (int)(a >> 23) - 127;
+	uint32_t m = a & 0x7fffffu;
+	if (e > 15) return INF;
+	if (e >= -14)
+	{
+		uint32_t v = ((uint32_t)(e + 15) << MB) | (m >> SH);
+		const uint32_t rem = m & ((1u << SH) - 1u), half = 1u << (SH - 1);
+		if (rem > half || (rem == half && (v & 1u))) ++v;
+		return v;
+	}
+	if (e < -14 - MB - 1) return 0u;
+	m |= 0x800000u;
+	const int shift = SH + (-14 - e);
+	if (shift > 31) return 0u;
+	uint32_t v = m >> shift;
+	const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+	if (rem > half || (rem == half && (v & 1u))) ++v;
+	return v;
+}
+
+__device__ __forceinline__ uint32_t pack_r11g11b10f(float r, float g, float b)	// negative -> 0, RNE
+{
+	const uint32_t ur = __float_as_uint(r), ug = __float_as_uint(g), ub = __float_as_uint(b);
+	const uint32_t R = ((ur & 0x80000000u) && (ur & 0x7fffffffu) <= 0x7f800000u) ? 0u : f32_to_small<6>(ur & 0x7fffffffu);
+	const uint32_t G = ((ug & 0x80000000u) && (ug & 0x7fffffffu) <= 0x7f800000u) ? 0u : f32_to_small<6>(ug & 0x7fffffffu);
+	const uint32_t B = ((ub & 0x80000000u) && (ub & 0x7fffffffu) <= 0x7f800000u) ? 0u : f32_to_small<5>(ub & 0x7fffffffu);
+	return (R & 0x7ffu) | ((G & 0x7ffu) << 11) | ((B & 0x3ffu) << 22);
+}
+
+// ---- sampler addressing: LINEAR + CLAMP on one axis ----
+struct Taps { int i0, i1; float f; };
+
+__device__ __forceinline__ Taps linearTaps(float coord01, uint32_t size, int off)
+{
+	const float c = coord01 * (float)size - 0.5f;
+	const float fl = __builtin_floorf(c);
+	Taps t;
+	t.f = c - fl;
+	const int i = floor_to_int(c) + off;	// |off| <= 1 and |i| <= 2^31 - 128: no overflow
+	t.i0 = clampi(i, 0, (int)size - 1);
+	t.i1 = clampi(i + 1, 0, (int)size - 1);
+	return t;
+}
+
+// ---- volume texel storage -------------------------------------------------------------------
+// Volumes live in HBM as 4x4x4-texel bricks of RGBA16F (64 texels x 8 B = 512 B = four 128-B lines), bricks in
+// x-fastest order.  A trilinear footprint (2x2x2 texels) then touches 1 brick 42 % of the time and at most 8,
+// instead of always 4 rows that are N*8 bytes (and N*N*8 bytes) apart in a linear layout.
+// Texel (x,y,z) -> element index (units of one RGBA16F texel):
+__device__ __forceinline__ size_t volTexelIndex(uint32_t x, uint32_t y, uint32_t z, uint32_t bricksPerAxis)
+{
+	const uint32_t bx = x >> 2, by = y >> 2, bz = z >> 2;
+	const size_t brick = ((size_t)bz * bricksPerAxis + by) * bricksPerAxis + bx;
+	return brick * 64 + ((z & 3u) << 4) + ((y & 3u) << 2) + (x & 3u);
+}
+
+struct VolumeView
+{
+	const uint2* texels;	// RGBA16F texel = 8 bytes = uint2 {rg, ba}
+	uint32_t N;				// texels per axis
+	uint32_t bricks;		// ceil(N / 4)
+};
+
+__device__ __forceinline__ uint2 loadTexel(const VolumeView& v, int x, int y, int z)
+{
+	return v.texels[volTexelIndex((uint32_t)x, (uint32_t)y, (uint32_t)z, v.bricks)];
+}
+
+__device__ __forceinline__ vec4 decodeTexel(uint2 t)
+{
+	vec4 c;
+	c.x = half_bits_to_float(t.x & 0xffffu);
+	c.y = half_bits_to_float(t.x >> 16);
+	c.z = half_bits_to_float(t.y & 0xffffu);
+	c.w = half_bits_to_float(t.y >> 16);
+	return c;
+}
+
+// Texture3D<float4>.SampleLevel(LINEAR_CLAMP, uvw, 0) on RGBA16F -- Sh/RayMarch.hlsli:44-50
+__device__ __forceinline__ vec4 sampleRGBA16F(const VolumeView& v, vec3 uvw)
+{
+	const Taps tx = linearTaps(uvw.x, v.N, 0), ty = linearTaps(uvw.y, v.N, 0), tz = linearTaps(uvw.z, v.N, 0);
+	const uint2 t000 = loadTexel(v, tx.i0, ty.i0, tz.i0), t100 = loadTexel(v, tx.i1, ty.i0, tz.i0);
+	const uint2 t010 = loadTexel(v, tx.i0, ty.i1, tz.i0), t110 = loadTexel(v, tx.i1, ty.i1, tz.i0);
+	const uint2 t001 = loadTexel(v, tx.i0, ty.i0, tz.i1), t101 = loadTexel(v, tx.i1, ty.i0, tz.i1);
+	const uint2 t011 = loadTexel(v, tx.i0, ty.i1, tz.i1), t111 = loadTexel(v, tx.i1, ty.i1, tz.i1);
+	const vec4 c000 = decodeTexel(t000), c100 = decodeTexel(t100), c010 = decodeTexel(t010), c110 = decodeTexel(t110);
+	const vec4 c001 = decodeTexel(t001), c101 = decodeTexel(t101), c011 = decodeTexel(t011), c111 = decodeTexel(t111);
+	vec4 r;
+#define MV_TRI(ch) lerpf(lerpf(lerpf(c000.ch, c100.ch, tx.f), lerpf(c010.ch, c110.ch, tx.f), ty.f), \
+	lerpf(lerpf(c001.ch, c101.ch, tx.f), lerpf(c011.ch, c111.ch, tx.f), ty.f), tz.f)
+	r.x = MV_TRI(x); r.y = MV_TRI(y); r.z = MV_TRI(z); r.w = MV_TRI(w);
+#undef MV_TRI
+	return r;
+}
+
+// alpha channel only (CastLightRay / density probes): same arithmetic as channel w above, with optional texel offset
+__device__ __forceinline__ float sampleAlpha16F(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
+{
+	const Taps tx = linearTaps(uvw.x, v.N, ox), ty = linearTaps(uvw.y, v.N, oy), tz = linearTaps(uvw.z, v.N, oz);
+	const uint16_t* h = reinterpret_cast<const uint16_t*>(v.texels);
+#define MV_A(i, j, k) half_bits_to_float(h[4 * volTexelIndex((uint32_t)(i), (uint32_t)(j), (uint32_t)(k), v.bricks) + 3])
+	const float c00 = lerpf(MV_A(tx.i0, ty.i0, tz.i0), MV_A(tx.i1, ty.i0, tz.i0), tx.f);
+	const float c10 = lerpf(MV_A(tx.i0, ty.i1, tz.i0), MV_A(tx.i1, ty.i1, tz.i0), tx.f);
+	const float c01 = lerpf(MV_A(tx.i0, ty.i0, tz.i1), MV_A(tx.i1, ty.i0, tz.i1), tx.f);
+	const float c11 = lerpf(MV_A(tx.i0, ty.i1, tz.i1), MV_A(tx.i1, ty.i1, tz.i1), tx.f);
+#undef MV_A
+	return lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+}
+
+// Texture3D<float3>.SampleLevel(LINEAR_CLAMP, uvw, 0) on R11G11B10F (light map, linear x-fastest) -- Sh/RayMarch.hlsli:235-240
+__device__ __forceinline__ vec3 sampleR11G11B10F(const uint32_t* tex, uint32_t L, vec3 uvw)
+{
+	const Taps tx = linearTaps(uvw.x, L, 0), ty = linearTaps(uvw.y, L, 0), tz = linearTaps(uvw.z, L, 0);
+	const uint32_t sy = L, sz = L * L;
+#define MV_L(i, j, k) unpack_r11g11b10f(tex[(uint32_t)(k) * sz + (uint32_t)(j) * sy + (uint32_t)(i)])
+	const vec3 c000 = MV_L(tx.i0, ty.i0, tz.i0), c100 = MV_L(tx.i1, ty.i0, tz.i0), c010 = MV_L(tx.i0, ty.i1, tz.i0), c110 = MV_L(tx.i1, ty.i1, tz.i0);
+	const vec3 c001 = MV_L(tx.i0, ty.i0, tz.i1), c101 = MV_L(tx.i1, ty.i0, tz.i1), c011 = MV_L(tx.i0, ty.i1, tz.i1), c111 = MV_L(tx.i1, ty.i1, tz.i1);
+#undef MV_L
+	vec3 r;
+#define MV_TRI(ch) lerpf(lerpf(lerpf(c000.ch, c100.ch, tx.f), lerpf(c010.ch, c110.ch, tx.f), ty.f), \
+	lerpf(lerpf(c001.ch, c101.ch, tx.f), lerpf(c011.ch, c111.ch, tx.f), ty.f), tz.f)
+	r.x = MV_TRI(x); r.y = MV_TRI(y); r.z = MV_TRI(z);
+#undef MV_TRI
+	return r;
+}
+
+// Texture2D<float>.SampleLevel(POINT_CLAMP, uv, 0) -- Sh/CSRayMarch.hlsl:68
+__device__ __forceinline__ float samplePointR32F(const float* tex, uint32_t W, uint32_t H, float u, float v)
+{
+	const int x = clampi(floor_to_int(u * (float)W), 0, (int)W - 1);
+	const int y = clampi(floor_to_int(v * (float)H), 0, (int)H - 1);
+	return tex[(size_t)y * W + x];
+}
+
+// Texture2D<float>.SampleCmpLevelZero(LINEAR_LESS_EQUAL, uv, ref) on D16_UNORM -- Sh/RayMarch.hlsli:109
+__device__ __forceinline__ float sampleCmpD16(const uint16_t* tex, uint32_t M, float u, float v, float ref)
+{
+	const Taps tx = linearTaps(u, M, 0), ty = linearTaps(v, M, 0);
+	const float r = saturatef(ref);
+	const float t00 = (float)tex[(size_t)ty.i0 * M + tx.i0] / 65535.0f;
+	const float t10 = (float)tex[(size_t)ty.i0 * M + tx.i1] / 65535.0f;
+	const float t01 = (float)tex[(size_t)ty.i1 * M + tx.i0] / 65535.0f;
+	const float t11 = (float)tex[(size_t)ty.i1 * M + tx.i1] / 65535.0f;
+	const float c00 = r <= t00 ? 1.0f : 0.0f, c10 = r <= t10 ? 1.0f : 0.0f;
+	const float c01 = r <= t01 ? 1.0f : 0.0f, c11 = r <= t11 ? 1.0f : 0.0f;
+	return lerpf(lerpf(c00, c10, tx.f), lerpf(c01, c11, tx.f), ty.f);
+}
+
+// ---- Sh/RayMarch.hlsli device functions ----
+__device__ __forceinline__ vec3 LocalToTex3DSpace(vec3 pos)	// :170-177, _TEXCOORD_INVERT_Y_ off
+{
+	return v3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f);
+}
+
+// :128-155
+__device__ __forceinline__ bool ComputeRayOrigin(vec3& rayOrigin, vec3 rayDir)
+{
+	if (__builtin_fabsf(rayOrigin.x) <= 1.0f && __builtin_fabsf(rayOrigin.y) <= 1.0f && __builtin_fabsf(rayOrigin.z) <= 1.0f) return true;
+
+	float U = kFltMax;
+	bool isHit = false;
+#pragma unroll
+	for (int i = 0; i < 3; ++i)
+	{
+		const int j = (i + 1) % 3, k = (i + 2) % 3;
+		const float di = comp(rayDir, i), oi = comp(rayOrigin, i);
+		const float u = (-signf(di) - oi) / di;
+		const bool skip = (u < 0.0f)
+			|| (__builtin_fabsf(comp(rayDir, j) * u + comp(rayOrigin, j)) > 1.0f)
+			|| (__builtin_fabsf(comp(rayDir, k) * u + comp(rayOrigin, k)) > 1.0f);
+		if (!skip && u < U)
+		{
+			U = u;
+			isHit = true;
+		}
+	}
+	rayOrigin = v3(clampf(rayDir.x * U + rayOrigin.x, -1.0f, 1.0f),
+		clampf(rayDir.y * U + rayOrigin.y, -1.0f, 1.0f),
+		clampf(rayDir.z * U + rayOrigin.z, -1.0f, 1.0f));
+	return isHit;
+}
+
+// :160-165
+__device__ __forceinline__ float ComputeTargetHit(vec3 rayOrigin, vec3 target, vec3 rayDir)
+{
+	const vec3 u = (target - rayOrigin) / rayDir;
+	return __builtin_fmaxf(__builtin_fmaxf(u.x, u.y), u.z);
+}
+
+// :82-97
+__device__ __forceinline__ float GetTMax(vec3 pos, vec3 rayOrigin, vec3 rayDir, const float* worldViewProjI)
+{
+	if (pos.z >= 1.0f) return kFltMax;
+	vec4 p; p.x = pos.x; p.y = pos.y; p.z = pos.z; p.w = 1.0f;
+	const vec4 hpos = mul44(p, worldViewProjI);
+	pos = v3(hpos.x / hpos.w, hpos.y / hpos.w, hpos.z / hpos.w);
+	const vec3 t = (pos - rayOrigin) / rayDir;
+	return __builtin_fmaxf(__builtin_fmaxf(t.x, t.y), t.z);
+}
+
+// :182-192
+__device__ __forceinline__ float GetStep(float dDensity, float transm, float density, float step)
+{
+	const float factorEv = __builtin_fminf(1.0f / 256.0f / __builtin_fabsf(dDensity), 2.0f);
+	const float factorUi = __builtin_fminf(1.0f - density, 1.0f);
+	const float factorTh = 1.0f - transm;
+	step *= __builtin_fmaxf(1.5f * factorEv * factorUi * factorTh, 1.0f);
+	return step;
+}
+
+// Sh/CSRayMarch.hlsl:28-53
+__device__ __forceinline__ vec3 GetLocalPos(float px, float py, uint32_t slice, float dims)
+{
+	const float x = (px + 0.5f) / dims * 2.0f - 1.0f;
+	float y = (py + 0.5f) / dims * 2.0f - 1.0f;
+	y = -y;
+	switch (slice)
+	{
+	case 0: return v3(1.0f, y, -x);
+	case 1: return v3(-1.0f, y, x);
+	case 2: return v3(x, 1.0f, -y);
+	case 3: return v3(x, -1.0f, y);
+	case 4: return v3(x, y, 1.0f);
+	case 5: return v3(-x, y, -1.0f);
+	default: return v3(0.0f, 0.0f, 0.0f);
+	}
+}
+
+} // namespace mv

@@ -1,0 +1,673 @@
+// mv_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the cube-map-space ray-march path.
+//
+//   cullKernel        = Sh/CSVolumeCull.hlsl:13-78 + Sh/VolumeCull.hlsli           (a1)
+//   marchLightKernel  = Sh/CSRayMarchL.hlsl:20-121                                 (a2)
+//   marchViewKernel   = Sh/CSRayMarch.hlsl:77-158 compiled as CSRayMarchV          (a3)
+//   initGridDataKernel / r32fToRGBA16FKernel = Sh/CSInitGridData.hlsl:10-27 / Sh/CSR32FToRGBA16F.hlsl:16-26 (a6)
+//
+// Wave64 throughout: one wavefront marches one 8x8 cube-face tile (the reference's thread-group tile,
+// CSRayMarch.hlsl:77), eight 8-lane clusters per wavefront cull eight volumes (the reference packs four
+// into a wave32, CSVolumeCull.hlsl:13-22).  No MFMA: the path is gather/stencil work bound by the memory system.
+#include "mv_device.hpp"
+#include "mv_kernels.hpp"
+
+namespace mv
+{
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t waveExclusiveScanU32(uint32_t v, uint32_t lane, uint32_t& total)
+{
+	uint32_t incl = v;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1)
+	{
+		const uint32_t n = __shfl_up(incl, o);
+		if (lane >= (uint32_t)o) incl += n;
+	}
+	total = __shfl(incl, 63);
+	return incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// volume producers / layout converters
+// ---------------------------------------------------------------------------------------------
+// One thread per texel of the BRICKED destination (coalesced 8-byte stores); reads are gathers from the linear source.
+__global__ __launch_bounds__(256) void retileKernel(const uint2* __restrict__ linear, uint2* __restrict__ bricked, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const size_t brick = i >> 6;
+		const uint32_t in = (uint32_t)(i & 63);
+		const uint32_t bx = (uint32_t)(brick % bricks), by = (uint32_t)((brick / bricks) % bricks), bz = (uint32_t)(brick / ((size_t)bricks * bricks));
+		const uint32_t x = bx * 4 + (in & 3), y = by * 4 + ((in >> 2) & 3), z = bz * 4 + (in >> 4);
+		uint2 t = make_uint2(0u, 0u);
+		if (x < N && y < N && z < N) t = linear[((size_t)z * N + y) * N + x];
+		bricked[i] = t;
+	}
+}
+
+__global__ __launch_bounds__(256) void untileKernel(const uint2* __restrict__ bricked, uint2* __restrict__ linear, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)N * N * N;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const uint32_t x = (uint32_t)(i % N), y = (uint32_t)((i / N) % N), z = (uint32_t)(i / ((size_t)N * N));
+		linear[i] = bricked[volTexelIndex(x, y, z, bricks)];
+	}
+}
+
+// Sh/CSInitGridData.hlsl:10-27
+__global__ __launch_bounds__(256) void initGridDataKernel(uint2* __restrict__ bricked, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	const float gridSize = (float)N;
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const size_t brick = i >> 6;
+		const uint32_t in = (uint32_t)(i & 63);
+		const uint32_t bx = (uint32_t)(brick % bricks), by = (uint32_t)((brick / bricks) % bricks), bz = (uint32_t)(brick / ((size_t)bricks * bricks));
+		const uint32_t x = bx * 4 + (in & 3), y = by * 4 + ((in >> 2) & 3), z = bz * 4 + (in >> 4);
+		uint2 t = make_uint2(0u, 0u);
+		if (x < N && y < N && z < N)
+		{
+			const vec3 pos = v3(((float)x + 0.5f) / gridSize * 2.0f - 1.0f, ((float)y + 0.5f) / gridSize * 2.0f - 1.0f, ((float)z + 0.5f) / gridSize * 2.0f - 1.0f);
+			const float r_sq = dot3(pos, pos);
+			float a = 1.0f - r_sq;
+			a *= a;
+			a = saturatef(a * a * 2.0f);
+			const float s = saturatef(pos.y * 0.5f + 0.2f);
+			// lerp(colorD, colorU, s): colorU = (1, .6, 0), colorD = (.5, .8, 1)
+			const float r = lerpf(0.5f, 1.0f, s), g = lerpf(0.8f, 0.6f, s), b = lerpf(1.0f, 0.0f, s);
+			t.x = (uint32_t)float_to_half_bits(r) | ((uint32_t)float_to_half_bits(g) << 16);
+			t.y = (uint32_t)float_to_half_bits(b) | ((uint32_t)float_to_half_bits(a) << 16);
+		}
+		bricked[i] = t;
+	}
+}
+
+// Sh/CSR32FToRGBA16F.hlsl:16-26
+__global__ __launch_bounds__(256) void r32fToRGBA16FKernel(const float* __restrict__ src, uint32_t w, uint32_t h, uint32_t d,
+	uint2* __restrict__ bricked, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	const float gridSize = (float)N;
+	const uint32_t one = float_to_half_bits(1.0f);
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const size_t brick = i >> 6;
+		const uint32_t in = (uint32_t)(i & 63);
+		const uint32_t bx = (uint32_t)(brick % bricks), by = (uint32_t)((brick / bricks) % bricks), bz = (uint32_t)(brick / ((size_t)bricks * bricks));
+		const uint32_t x = bx * 4 + (in & 3), y = by * 4 + ((in >> 2) & 3), z = bz * 4 + (in >> 4);
+		uint2 t = make_uint2(0u, 0u);
+		if (x < N && y < N && z < N)
+		{
+			const Taps tx = linearTaps(((float)x + 0.5f) / gridSize, w, 0), ty = linearTaps(((float)y + 0.5f) / gridSize, h, 0), tz = linearTaps(((float)z + 0.5f) / gridSize, d, 0);
+#define MV_SRC(i_, j_, k_) src[((size_t)(k_) * h + (j_)) * w + (i_)]
+			const float c00 = lerpf(MV_SRC(tx.i0, ty.i0, tz.i0), MV_SRC(tx.i1, ty.i0, tz.i0), tx.f);
+			const float c10 = lerpf(MV_SRC(tx.i0, ty.i1, tz.i0), MV_SRC(tx.i1, ty.i1, tz.i0), tx.f);
+			const float c01 = lerpf(MV_SRC(tx.i0, ty.i0, tz.i1), MV_SRC(tx.i1, ty.i0, tz.i1), tx.f);
+			const float c11 = lerpf(MV_SRC(tx.i0, ty.i1, tz.i1), MV_SRC(tx.i1, ty.i1, tz.i1), tx.f);
+#undef MV_SRC
+			const float a = lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+			t.x = one | (one << 16);
+			t.y = one | ((uint32_t)float_to_half_bits(a * 0.25f) << 16);
+		}
+		bricked[i] = t;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// a1: volume cull.  One workgroup of 8 wavefronts; each wavefront culls 8 volumes (8 lanes = 8 cube vertices each).
+// After the cull the first wavefront compacts the visible / cube-map lists in ascending volume order and builds the
+// march work list (one entry per visible face of every owned cube-map volume, prefix sums of 8x8 tiles), so that
+// marchViewKernel is sized like the reference's work-graph variant (Sh/LibRayMarch.hlsl:120-121) without a host round trip.
+// ---------------------------------------------------------------------------------------------
+__constant__ uint8_t kEdgeLanes[12][2] = { {0,1},{3,2},{1,3},{2,0},{6,7},{5,4},{4,6},{7,5},{4,0},{2,6},{7,3},{1,5} };	// VolumeCull.hlsli:119-138
+__constant__ uint8_t kFaceEdges[6][4] = { {8,3,9,6},{10,2,11,7},{0,8,5,11},{1,10,4,9},{0,2,1,3},{4,6,5,7} };			// VolumeCull.hlsli:213-223
+
+constexpr uint32_t kCullThreads = 512;
+
+__global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
+{
+	extern __shared__ uint32_t sInfo[];	// per volume: bit0 visible, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask
+
+	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	const float vpW = cb->viewport[0], vpH = cb->viewport[1];
+	const vec3 eyePt = v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]);
+
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t li = lane & 7u;			// wTid.x: cube vertex / edge-pair / face index
+	const uint32_t baseLane = lane & ~7u;	// 8 * wTid.y
+	const uint32_t l6 = li < 6u ? li : 5u;	// lanes 6-7 shadow lane 5 so that every shuffle is executed wave-wide
+
+	for (uint32_t base = 0; base < st.V; base += kCullThreads / 8)
+	{
+		const uint32_t volumeId = base + (threadIdx.x >> 3);
+		const bool valid = volumeId < st.V;
+		const PerObject& po = perObjects[valid ? volumeId : 0u];
+
+		// ProjectToViewport (VolumeCull.hlsli:27-41)
+		vec4 p;
+		p.x = (li & 1u) ? 1.0f : -1.0f;
+		p.y = ((li >> 1) & 1u) ? 1.0f : -1.0f;
+		p.z = (li >> 2) ? 1.0f : -1.0f;
+		p.w = 1.0f;
+		p = mul44(p, po.wvp);
+		p.x /= p.w; p.y /= p.w; p.z /= p.w;
+		p.x = p.x * 0.5f + 0.5f;
+		p.y = p.y * 0.5f + 0.5f;
+		p.y = 1.0f - p.y;
+		const float vx = p.x * vpW, vy = p.y * vpH, vz = p.z;
+
+		// CSVolumeCull.hlsl:32-38
+		const bool isInView = valid && (vx <= vpW && vy <= vpH && vx >= 0.0f && vy >= 0.0f) && vz > 0.0f && vz < 1.0f;
+		const uint32_t volumeVis = (uint32_t)(__ballot(isInView) >> baseLane) & 0xffu;
+
+		// GenVisibilityMask (VolumeCull.hlsli:46-66)
+		const vec3 localSpaceEyePt = mul43(eyePt, po.worldI);
+		const float viewComp = comp(localSpaceEyePt, (int)(l6 >> 1));
+		const bool faceVis = li < 6u && ((li & 1u) ? viewComp > -1.0f : viewComp < 1.0f);
+		uint32_t faceMask = (uint32_t)(__ballot(faceVis) >> baseLane) & 0xffu;
+
+		// GetCubeEdgePairPerLane (VolumeCull.hlsli:164-181): lane li < 6 holds edges 2 li and 2 li + 1
+		float ex[2], ey[2];
+#pragma unroll
+		for (uint32_t i = 0; i < 2; ++i)
+		{
+			const uint32_t e = 2u * l6 + i;
+			const int a = (int)(baseLane + kEdgeLanes[e][0]), b = (int)(baseLane + kEdgeLanes[e][1]);
+			const float v0x = __shfl(vx, a), v0y = __shfl(vy, a);
+			const float v1x = __shfl(vx, b), v1y = __shfl(vy, b);
+			ex[i] = v1x - v0x;
+			ey[i] = v1y - v0y;
+		}
+
+		// EstimateCubeMaxEdgeLength (VolumeCull.hlsli:248-262)
+		const float ms = __builtin_fmaxf(__builtin_sqrtf(ex[0] * ex[0] + ey[0] * ey[0]), __builtin_sqrtf(ex[1] * ex[1] + ey[1] * ey[1]));
+		float maxEdge = __shfl(ms, (int)baseLane);
+#pragma unroll
+		for (uint32_t k = 1; k < 6; ++k) maxEdge = __builtin_fmaxf(maxEdge, __shfl(ms, (int)(baseLane + k)));
+
+		// EstimateProjCoverage (VolumeCull.hlsli:299-322): face li gathers its four edges from the edge-pair lanes
+		float fx[4], fy[4];
+#pragma unroll
+		for (uint32_t k = 0; k < 4; ++k)
+		{
+			const uint32_t e = kFaceEdges[l6][k];
+			const int srcLane = (int)(baseLane + (e >> 1));
+			const float x0 = __shfl(ex[0], srcLane), y0 = __shfl(ey[0], srcLane);
+			const float x1 = __shfl(ex[1], srcLane), y1 = __shfl(ey[1], srcLane);
+			fx[k] = (e & 1u) ? x1 : x0;
+			fy[k] = (e & 1u) ? y1 : y0;
+		}
+		float faceArea = 0.0f;
+		if (li < 6u && (faceMask & (1u << li)))
+			faceArea = 0.5f * __builtin_fabsf(fx[0] * fy[1] - fy[0] * fx[1]) + 0.5f * __builtin_fabsf(fx[2] * fy[3] - fy[2] * fx[3]);
+		float projCov = __shfl(faceArea, (int)baseLane);	// WaveActiveSum, summed in lane order
+#pragma unroll
+		for (uint32_t k = 1; k < 6; ++k) projCov = projCov + __shfl(faceArea, (int)(baseLane + k));
+
+		if (li == 0u && valid)
+		{
+			uint32_t info = 0u;
+			if (volumeVis != 0u)
+			{
+				const uint32_t volumeIn = st.volumeDescs[volumeId];
+				uint32_t raySampleCount = st.maxRaySamples;
+
+				// EstimateCubeMapLOD (VolumeCull.hlsli:267-294)
+				const uint32_t cubeMapSize = volumeIn >> 18;
+				const uint32_t numMips = (volumeIn >> 14) & 0xfu;
+				float s = maxEdge / 2.0f;
+				float raySampleAmt = 2.0f * s / kSqrt3;
+				const uint32_t raySampleCnt = f2u_sat(__builtin_ceilf(raySampleAmt));
+				raySampleCount = raySampleCnt < raySampleCount ? raySampleCnt : raySampleCount;
+				raySampleAmt = __builtin_fminf(raySampleAmt, (float)raySampleCount);
+				s = raySampleAmt / 2.0f * kSqrt3;
+				const uint32_t level = f2u_sat(__builtin_fmaxf(log2f((float)cubeMapSize / s), 0.0f));
+				uint32_t mipLevel = level < numMips - 1u ? level : numMips - 1u;
+
+				// CSVolumeCull.hlsl:62-77
+				const uint32_t edgeLength = cubeMapSize >> mipLevel;
+				const float cubeMapPix = (float)(edgeLength * edgeLength) * (float)__popc(faceMask);
+				bool useCubeMap = cubeMapPix <= projCov;
+				if (st.flags & 1u)	// MV_FLAG_FORCE_MIP0_ALL_FACES (stress variant, not a reference mode)
+				{
+					mipLevel = 0u; faceMask = 0x3fu; useCubeMap = true; raySampleCount = st.maxRaySamples;
+				}
+				const uint32_t maskBits = useCubeMap ? (faceMask | kCubeMapRayMarchBit) : faceMask;
+				const uint32_t volTexId = volumeIn & 0x3fffu;
+
+				ushort4 out;
+				out.x = (uint16_t)mipLevel; out.y = (uint16_t)raySampleCount; out.z = (uint16_t)maskBits; out.w = (uint16_t)volTexId;
+				reinterpret_cast<ushort4*>(st.volumeInfo)[volumeId] = out;
+				info = 1u | (useCubeMap ? 2u : 0u) | (mipLevel << 2) | ((faceMask & 0x3fu) << 5);
+			}
+			sInfo[volumeId] = info;
+		}
+	}
+
+	__syncthreads();
+	if (threadIdx.x >= 64u) return;
+
+	// ---- list compaction + work list, first wavefront ----
+	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
+	const uint64_t chain = cubeChainTexels(st.N);
+	const uint64_t lower = (1ull << lane) - 1ull;
+	uint32_t nVis = 0, nCube = 0, nOwned = 0, nEntries = 0, nTiles = 0, minMip = 0xffffffffu;
+	for (uint32_t base = 0; base < st.V; base += 64)
+	{
+		const uint32_t v = base + lane;
+		const uint32_t info = v < st.V ? sInfo[v] : 0u;
+		if (v < st.V) st.volumeFlags[v] = info;
+		const bool vis = info & 1u, cube = info & 2u;
+		const bool owned = (v % shardCount) == st.shardIndex;
+		const uint32_t mip = (info >> 2) & 7u, mask = (info >> 5) & 0x3fu;
+		const uint64_t bVis = __ballot(vis), bCube = __ballot(cube), bOwn = __ballot(vis && owned);
+		if (vis)
+		{
+			st.visibleVolumes[nVis + __popcll(bVis & lower)] = v;
+			st.cubeOffset[v] = (uint64_t)v * chain + cubeMipOffset(st.N, mip);
+			minMip = mip < minMip ? mip : minMip;
+		}
+		if (cube) st.cubeMapVolumes[nCube + __popcll(bCube & lower)] = v;
+		if (vis && owned) st.ownedVisible[nOwned + __popcll(bOwn & lower)] = v;
+		nVis += __popcll(bVis); nCube += __popcll(bCube); nOwned += __popcll(bOwn);
+
+		const uint32_t dims = st.N >> mip;
+		const uint32_t tilesPerFace = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
+		const uint32_t myFaces = (cube && owned) ? (uint32_t)__popc(mask) : 0u;
+		uint32_t totFaces, totTiles;
+		const uint32_t eBase = nEntries + waveExclusiveScanU32(myFaces, lane, totFaces);
+		const uint32_t tBase = nTiles + waveExclusiveScanU32(myFaces * tilesPerFace, lane, totTiles);
+		uint32_t k = 0;
+		for (uint32_t f = 0; f < 6; ++f)
+			if (myFaces && (mask & (1u << f)))
+			{
+				st.workEntries[eBase + k] = v | (f << 16);
+				st.workTileStart[eBase + k] = tBase + k * tilesPerFace;
+				++k;
+			}
+		nEntries += totFaces; nTiles += totTiles;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(minMip, o); minMip = m < minMip ? m : minMip; }
+	if (lane == 0)
+	{
+		st.workTileStart[nEntries] = nTiles;
+		st.counters[0] = nVis; st.counters[1] = nCube; st.counters[2] = nEntries; st.counters[3] = nTiles;
+		st.counters[4] = nOwned; st.counters[5] = minMip == 0xffffffffu ? 0u : minMip;
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sh/RayMarch.hlsli:197-230  CastLightRay (mipLevel 0)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vol, vec3 rayOrigin, vec3 rayDir,
+	float stepScale, uint32_t numSamples, uint32_t& samples)
+{
+	float t = stepScale;
+	float step = stepScale;
+	float prevDensity = 0.0f;
+	for (uint32_t i = 0; i < numSamples; ++i)
+	{
+		const vec3 pos = rayAt(rayOrigin, rayDir, t);
+		if (outsideBox(pos)) break;
+		const vec3 uvw = LocalToTex3DSpace(pos);
+
+		const float density = sampleAlpha16F(vol, uvw);
+		++samples;
+
+		const float dDensity = density - prevDensity;
+		const float opacity = saturatef(density * step);
+		const float newStep = GetStep(dDensity, transm, opacity, stepScale);
+		prevDensity = density;	// (:219 `step = (step + newStep) * 0.5` is dead: overwritten at :227)
+
+		transm *= 1.0f - density * kAbsorption;
+		if (transm < kZeroThreshold) break;
+
+		step = newStep;
+		t += step;
+	}
+}
+
+// XUSG/Shaders/SHIrradianceTypeless.hlsli:15-36
+__device__ __forceinline__ vec3 EvaluateSHIrradiance(const float* sh, vec3 norm)
+{
+	const float c1 = 0.42904276540489171563379376569857f;
+	const float c2 = 0.51166335397324424423977581244463f;
+	const float c3 = 0.24770795610037568833406429782001f;
+	const float c4 = 0.88622692545275801364908374167057f;
+	const float x = -norm.x, y = -norm.y, z = norm.z;
+	float r[3];
+#pragma unroll
+	for (int ch = 0; ch < 3; ++ch)
+	{
+#define MV_SHC(i) sh[3 * (i) + ch]
+		const float v = (c1 * (x * x - y * y)) * MV_SHC(8)
+			+ (c3 * (3.0f * z * z - 1.0f)) * MV_SHC(6)
+			+ c4 * MV_SHC(0)
+			+ 2.0f * c1 * (MV_SHC(4) * x * y + MV_SHC(7) * x * z + MV_SHC(5) * y * z)
+			+ 2.0f * c2 * (MV_SHC(3) * x + MV_SHC(1) * y + MV_SHC(2) * z);
+#undef MV_SHC
+		r[ch] = __builtin_fmaxf(0.0f, v);
+	}
+	return v3(r[0], r[1], r[2]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2: light-space march.  One wavefront = one 4x4x4 block of light-map voxels (the reference's thread group).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
+{
+	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+
+	// CSRayMarchL.hlsl:29-33 (sharded contexts round-robin over their own visible volumes)
+	const uint32_t ownedCount = st.counters[4];
+	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
+	uint32_t volumeId;
+	if (ownedCount) volumeId = st.ownedVisible[cb->frameIdx % ownedCount];
+	else if (shardCount == 1u) volumeId = cb->frameIdx % st.V;
+	else
+	{
+		const uint32_t ownedTotal = (st.V - st.shardIndex + shardCount - 1u) / shardCount;
+		if (ownedTotal == 0u) return;
+		volumeId = st.shardIndex + shardCount * (cb->frameIdx % ownedTotal);
+	}
+	volumeId = __builtin_amdgcn_readfirstlane(volumeId);
+
+	const uint32_t L = st.L;
+	const uint32_t blocksPerAxis = (L + 3u) >> 2;
+	const uint32_t b = blockIdx.x;
+	const uint32_t bx = b % blocksPerAxis, by = (b / blocksPerAxis) % blocksPerAxis, bz = b / (blocksPerAxis * blocksPerAxis);
+	const uint32_t lane = threadIdx.x;
+	const uint32_t xx = bx * 4 + (lane & 3u), yy = by * 4 + ((lane >> 2) & 3u), zz = bz * 4 + (lane >> 4);
+	const bool inRange = xx < L && yy < L && zz < L;
+
+	uint32_t nS = 0;
+	if (inRange)
+	{
+		const float gridSize = (float)L;
+		const float gStep = kMaxDist / (float)st.maxLightSamples;	// RayMarch.hlsli:18
+		const uint32_t volTexId0 = st.volumeDescs[volumeId] & 0x3fffu;
+		const PerObject& po0 = perObjects[volumeId];
+		VolumeView vol0; vol0.texels = st.volumes[volTexId0]; vol0.N = st.N; vol0.bricks = st.bricks;
+
+		vec3 rayOrigin = v3(((float)xx + 0.5f) / gridSize * 2.0f - 1.0f, ((float)yy + 0.5f) / gridSize * 2.0f - 1.0f, ((float)zz + 0.5f) / gridSize * 2.0f - 1.0f);
+		const vec3 uvw = LocalToTex3DSpace(rayOrigin);
+		const float density = sampleAlpha16F(vol0, uvw);
+		const bool hasDensity = density >= kZeroThreshold;	// :46
+
+		rayOrigin = mul43(rayOrigin, po0.world);	// :47 light-map space to world space
+
+		// ShadowTest (RayMarch.hlsli:103-112)
+		float shadow;
+		{
+			vec4 p; p.x = rayOrigin.x; p.y = rayOrigin.y; p.z = rayOrigin.z; p.w = 1.0f;
+			const vec4 ls = mul44(p, cb->shadowViewProj);
+			const float su = ls.x * 0.5f + 0.5f;
+			float sv = ls.y * 0.5f + 0.5f;
+			sv = 1.0f - sv;
+			shadow = sampleCmpD16(st.shadowMap, st.M, su, sv, ls.z - 0.0027f);
+		}
+
+		float ao = 1.0f;
+		vec3 irradiance = v3(0.0f, 0.0f, 0.0f);
+
+		if (hasDensity)
+		{
+			vec3 aoRayDir = v3(0.0f, 0.0f, 0.0f);
+			if (st.hasLightProbe)
+			{
+				// GetDensityGradient (RayMarch.hlsli:55-77)
+				const float q0 = sampleAlpha16F(vol0, uvw, -1, 0, 0), q1 = sampleAlpha16F(vol0, uvw, 1, 0, 0);
+				const float q2 = sampleAlpha16F(vol0, uvw, 0, -1, 0), q3 = sampleAlpha16F(vol0, uvw, 0, 1, 0);
+				const float q4 = sampleAlpha16F(vol0, uvw, 0, 0, -1), q5 = sampleAlpha16F(vol0, uvw, 0, 0, 1);
+				aoRayDir = v3(-(q1 - q0), -(q3 - q2), -(q5 - q4));
+				const bool nz = __builtin_fabsf(aoRayDir.x) > 0.0f || __builtin_fabsf(aoRayDir.y) > 0.0f || __builtin_fabsf(aoRayDir.z) > 0.0f;
+				aoRayDir = nz ? aoRayDir : rayOrigin;	// :69 (rayOrigin is already world space here)
+				aoRayDir = mul33(aoRayDir, po0.world);
+				aoRayDir = normalize3(aoRayDir);
+				irradiance = EvaluateSHIrradiance(st.sh, normalize3(aoRayDir));	// GetIrradiance normalises again (RayMarch.hlsli:121)
+			}
+
+			for (uint32_t n = 0; n < st.V; ++n)	// :77-110
+			{
+				const uint32_t volTexId = st.volumeDescs[n] & 0x3fffu;
+				const PerObject& po = perObjects[n];
+				VolumeView vol; vol.texels = st.volumes[volTexId]; vol.N = st.N; vol.bricks = st.bricks;
+				vec3 localRayOrigin = mul43(rayOrigin, po.worldI);
+
+				if (shadow >= kZeroThreshold)
+				{
+					const vec3 localSpaceLightPt = mul33(v3(cb->lightPos[0], cb->lightPos[1], cb->lightPos[2]), po.worldI);
+					const vec3 rayDir = normalize3(localSpaceLightPt);
+					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
+					CastLightRay(shadow, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS);
+				}
+
+				if (st.hasLightProbe)
+				{
+					const vec3 rayDir = normalize3(mul33(aoRayDir, po.worldI));
+					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
+					float transm = 1.0f;
+					CastLightRay(transm, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS);
+					ao *= n == volumeId ? transm : __builtin_sqrtf(__builtin_sqrtf(saturatef(transm + 0.5f)));	// pow(x, 0.25)
+				}
+			}
+		}
+
+		const vec3 lightColor = v3(cb->lightColor[0] * cb->lightColor[3], cb->lightColor[1] * cb->lightColor[3], cb->lightColor[2] * cb->lightColor[3]);
+		vec3 ambient = v3(cb->ambient[0] * cb->ambient[3], cb->ambient[1] * cb->ambient[3], cb->ambient[2] * cb->ambient[3]);
+		if (st.hasLightProbe) ambient = v3(ao * irradiance.x, ao * irradiance.y, ao * irradiance.z);
+
+		const vec3 result = v3(shadow * lightColor.x + ambient.x, shadow * lightColor.y + ambient.y, shadow * lightColor.z + ambient.z);
+		st.lightMaps[(size_t)volumeId * L * L * L + ((size_t)zz * L + yy) * L + xx] = pack_r11g11b10f(result.x, result.y, result.z);
+	}
+
+	const uint32_t tot = waveSumU32(nS);
+	if (lane == 0 && tot) atomicAdd(reinterpret_cast<unsigned long long*>(st.stats + 3), (unsigned long long)tot);
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3: view-space march into cube faces.  One wavefront = one 8x8 tile of one face of one volume.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kMarchWaves = 4;	// independent wavefronts per workgroup
+
+__global__ __launch_bounds__(64 * kMarchWaves) void marchViewKernel(DeviceState st)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
+
+	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Give every XCD one contiguous eighth of
+	// the tile list so that neighbouring tiles -- which read neighbouring bricks -- share an L2.  Placement only
+	// affects speed: every tile is marched exactly once whatever the mapping.
+	const uint32_t nBlocks = (nTiles + kMarchWaves - 1u) / kMarchWaves;
+	const uint32_t perXcd = (nBlocks + 7u) >> 3;
+	const uint32_t xcd = blockIdx.x & 7u, idxInXcd = blockIdx.x >> 3;
+	if (idxInXcd >= perXcd) return;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane((xcd * perXcd + idxInXcd) * kMarchWaves + wave);
+	if (tile >= nTiles) return;
+
+	// find the work entry that owns this tile (wave-uniform)
+	uint32_t entry = 0;
+	for (uint32_t base = 0; base < nEntries; base += 64)
+	{
+		const uint32_t i = base + lane;
+		const bool hit = i < nEntries && st.workTileStart[i] <= tile && tile < st.workTileStart[i + 1];
+		const uint64_t b = __ballot(hit);
+		if (b) { entry = base + (uint32_t)__ffsll((unsigned long long)b) - 1u; break; }
+	}
+	entry = __builtin_amdgcn_readfirstlane(entry);
+	const uint32_t we = st.workEntries[entry];
+	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16;
+	const uint32_t localTile = tile - st.workTileStart[entry];
+
+	const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId];	// CSRayMarch.hlsl:81
+	const uint32_t mipLevel = vi.x, smpCount = vi.y, volTexId = vi.w;
+	const uint32_t dims = st.N >> mipLevel;
+	const uint32_t tilesX = (dims + 7u) >> 3;
+	const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
+
+	uint32_t nSamples = 0, nLit = 0, nRays = 0;
+	if (px < dims && py < dims)
+	{
+		const PerObject& po = reinterpret_cast<const PerObject*>(st.perObject)[volumeId];
+		const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+
+		vec3 rayOrigin = mul43(v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]), po.worldI);	// :89
+		const vec3 target = GetLocalPos((float)px, (float)py, faceId, (float)dims);
+		const vec3 rayDir = normalize3(target - rayOrigin);
+		if (ComputeRayOrigin(rayOrigin, rayDir))	// :96
+		{
+			float tMax = ComputeTargetHit(rayOrigin, target, rayDir);
+			const float stepScale = kMaxDist / (float)smpCount;
+			const size_t texel = (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
+
+			// GetClipPos (:59-71)
+			vec3 clip;
+			{
+				vec4 hPos;
+				hPos.x = __builtin_fmaf(0.01f, rayDir.x, rayOrigin.x);
+				hPos.y = __builtin_fmaf(0.01f, rayDir.y, rayOrigin.y);
+				hPos.z = __builtin_fmaf(0.01f, rayDir.z, rayOrigin.z);
+				hPos.w = 1.0f;
+				hPos = mul44(hPos, po.wvp);
+				const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
+				const float u = cx * 0.5f + 0.5f;
+				float v = cy * 0.5f + 0.5f;
+				v = 1.0f - v;
+				clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
+			}
+			st.cubeDepths[texel] = clip.z;	// :105
+			tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
+
+			VolumeView vol; vol.texels = st.volumes[volTexId]; vol.N = st.N; vol.bricks = st.bricks;
+			const uint32_t* lightMap = st.lightMaps + (size_t)volumeId * st.L * st.L * st.L;
+
+			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
+			float t = 0.0f;
+			float prevDensity = 0.0f;
+			for (uint32_t i = 0; i < smpCount; ++i)	// :117-153
+			{
+				const vec3 pos = rayAt(rayOrigin, rayDir, t);
+				if (outsideBox(pos)) break;
+				const vec3 uvw = LocalToTex3DSpace(pos);
+
+				vec4 color = sampleRGBA16F(vol, uvw);
+				++nSamples;
+				float newStep = stepScale;
+
+				if (color.w > kZeroThreshold)
+				{
+					const vec3 light = sampleR11G11B10F(lightMap, st.L, v3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f));
+					++nLit;
+
+					const float transm = 1.0f - scatter.w;
+					const float dDensity = color.w - prevDensity;
+					newStep = GetStep(dDensity, transm, color.w, stepScale);
+					prevDensity = color.w;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
+
+					color.x *= color.w; color.y *= color.w; color.z *= color.w;	// :140-142 not pre-multiplied
+					color.x *= light.x; color.y *= light.y; color.z *= light.z;
+					scatter.x += color.x * kAbsorption * transm;
+					scatter.y += color.y * kAbsorption * transm;
+					scatter.z += color.z * kAbsorption * transm;
+					scatter.w += color.w * kAbsorption * transm;
+
+					if (transm < kZeroThreshold) break;
+				}
+
+				t += newStep;
+				if (t > tMax) break;
+			}
+
+			const float twoPi = 2.0f * kPI;
+			scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;	// :155
+
+			uint2 o;
+			o.x = (uint32_t)float_to_half_bits(scatter.x) | ((uint32_t)float_to_half_bits(scatter.y) << 16);
+			o.y = (uint32_t)float_to_half_bits(scatter.z) | ((uint32_t)float_to_half_bits(scatter.w) << 16);
+			st.cubeMaps[texel] = o;	// :157
+			nRays = 1;
+		}
+	}
+
+	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays);
+	if (lane == 0)
+	{
+		unsigned long long* s = reinterpret_cast<unsigned long long*>(st.stats);
+		if (totS) atomicAdd(s + 0, (unsigned long long)totS);
+		if (totL) atomicAdd(s + 1, (unsigned long long)totL);
+		if (totR) atomicAdd(s + 2, (unsigned long long)totR);
+	}
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline uint32_t gridFor(size_t total, uint32_t block)
+{
+	const size_t g = (total + block - 1) / block;
+	return (uint32_t)(g < 8192 ? (g ? g : 1) : 8192);	// 256 CUs x 8 blocks x 4: grid-stride the rest
+}
+
+void launchRetile(hipStream_t s, const uint2* linear, uint2* bricked, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	hipLaunchKernelGGL(retileKernel, dim3(gridFor(total, 256)), dim3(256), 0, s, linear, bricked, N, bricks);
+}
+
+void launchUntile(hipStream_t s, const uint2* bricked, uint2* linear, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)N * N * N;
+	hipLaunchKernelGGL(untileKernel, dim3(gridFor(total, 256)), dim3(256), 0, s, bricked, linear, N, bricks);
+}
+
+void launchInitGridData(hipStream_t s, uint2* bricked, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	hipLaunchKernelGGL(initGridDataKernel, dim3(gridFor(total, 256)), dim3(256), 0, s, bricked, N, bricks);
+}
+
+void launchR32FToRGBA16F(hipStream_t s, const float* src, uint32_t w, uint32_t h, uint32_t d, uint2* bricked, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	hipLaunchKernelGGL(r32fToRGBA16FKernel, dim3(gridFor(total, 256)), dim3(256), 0, s, src, w, h, d, bricked, N, bricks);
+}
+
+void launchCull(hipStream_t s, const DeviceState& st)
+{
+	hipLaunchKernelGGL(cullKernel, dim3(1), dim3(kCullThreads), st.V * sizeof(uint32_t), s, st);
+}
+
+void launchMarchLight(hipStream_t s, const DeviceState& st)
+{
+	const uint32_t b = (st.L + 3u) >> 2;
+	hipLaunchKernelGGL(marchLightKernel, dim3(b * b * b), dim3(64), 0, s, st);
+}
+
+void launchMarchView(hipStream_t s, const DeviceState& st)
+{
+	// Upper bound of the tile count (the real count is on the device, written by cullKernel): every owned volume at mip 0 with 6 faces.
+	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
+	const uint32_t owned = (st.V + shardCount - 1u) / shardCount;
+	const uint32_t t = (st.N + 7u) >> 3;
+	const uint64_t maxTiles = (uint64_t)owned * 6u * t * t;
+	uint64_t blocks = (maxTiles + kMarchWaves - 1) / kMarchWaves;
+	blocks = ((blocks + 7) / 8) * 8;
+	hipLaunchKernelGGL(marchViewKernel, dim3((uint32_t)blocks), dim3(64 * kMarchWaves), 0, s, st);
+}
+} // namespace mv

@@ -1,0 +1,79 @@
+// mv_kernels.hpp -- launch interface between the C-ABI host layer (mv_api.cpp) and the gfx950 kernels (mv_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace mv
+{
+// Device-side state of one context. Every pointer is device memory; the struct is passed to kernels by value.
+struct DeviceState
+{
+	// geometry of the problem
+	uint32_t N;				// volume / cube-face edge
+	uint32_t bricks;		// ceil(N / 4): volumes are stored as 4x4x4 bricks
+	uint32_t L;				// light-map edge
+	uint32_t V;				// number of volumes
+	uint32_t S;				// number of volume sources
+	uint32_t W, H;			// viewport
+	uint32_t M;				// shadow-map edge
+	uint32_t flags;
+	uint32_t shardIndex, shardCount;
+	uint32_t maxRaySamples, maxLightSamples;
+	uint32_t hasLightProbe;
+
+	// per-frame constants (device copies of the reference's upload-heap slices)
+	const void* cbPerFrame;			// CBPerFrame, 212 B
+	const void* perObject;			// PerObject[V]
+	const uint32_t* volumeDescs;	// VolumeDesc[V]
+	const float* sh;				// 27 floats
+
+	// resources
+	const uint2* const* volumes;	// S pointers to bricked RGBA16F texels
+	uint32_t* lightMaps;			// V x L^3 R11G11B10F
+	const float* depthMap;			// W x H
+	const uint16_t* shadowMap;		// M x M D16
+	uint2* cubeMaps;				// V x chain RGBA16F texels
+	float* cubeDepths;				// V x chain
+	uint2* composite;				// W x H RGBA16F
+
+	// cull outputs
+	uint16_t* volumeInfo;			// V x 4
+	uint32_t* visibleVolumes;		// V
+	uint32_t* cubeMapVolumes;		// V
+	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
+									// [4] owned visible count, [5] min selected mip over visible volumes
+	uint32_t* ownedVisible;			// V: visible volumes of this shard, ascending
+	uint32_t* workEntries;			// 6 V: volume | face << 16
+	uint32_t* workTileStart;		// 6 V + 1 prefix sums of 8x8 tiles
+	uint64_t* cubeOffset;			// V: texel offset of the selected mip of volume v inside cubeMaps / cubeDepths
+	uint32_t* volumeFlags;			// V: bit0 visible this frame, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask
+
+	uint64_t* stats;				// [0] view samples, [1] lit samples, [2] rays, [3] light samples, [4] composite samples
+};
+
+__host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)
+{
+	uint64_t s = 0;
+	for (uint32_t m = 0; m < 5; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	return s;
+}
+
+__host__ __device__ inline uint64_t cubeMipOffset(uint32_t N, uint32_t mip)
+{
+	uint64_t s = 0;
+	for (uint32_t m = 0; m < mip; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	return s;
+}
+void launchRetile(hipStream_t s, const uint2* linear, uint2* bricked, uint32_t N, uint32_t bricks);
+void launchUntile(hipStream_t s, const uint2* bricked, uint2* linear, uint32_t N, uint32_t bricks);
+void launchInitGridData(hipStream_t s, uint2* bricked, uint32_t N, uint32_t bricks);
+void launchR32FToRGBA16F(hipStream_t s, const float* src, uint32_t w, uint32_t h, uint32_t d, uint2* bricked, uint32_t N, uint32_t bricks);
+void launchCull(hipStream_t s, const DeviceState& st);
+void launchMarchLight(hipStream_t s, const DeviceState& st);
+void launchMarchView(hipStream_t s, const DeviceState& st);
+void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1);
+void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, void* dst);
+void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim, const void* src);
+} // namespace mv

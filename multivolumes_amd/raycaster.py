@@ -1,0 +1,325 @@
+"""Python mirror of the reference's hot-path owner, MultiRayCaster (MultiVolumes/Content/MultiRayCaster.h:28-50),
+driving the gfx950 kernels through the C ABI of include/multivolumes.h.
+
+Method names, argument meaning and defaults follow the reference so that tests read like calls into it:
+Init -> __init__, LoadVolumeData / InitVolumeData, SetRenderTargets, SetSH, SetMaxSamples, SetVolumesWorld /
+SetVolumeWorld, SetLight, SetAmbient, UpdateFrame, Render.  Creation failures raise (the reference returns false,
+XUSG.h:12-15); stage launches are stream-ordered and asynchronous like the reference's command recording.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MVError, mv_config, mv_stats
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f32(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if n is not None and a.size != n:
+        raise ValueError(f"expected {n} floats, got {a.size}")
+    return a
+
+
+# ---- DirectXMath-convention helpers (row vectors, row-major 4x4), computed by libmultivolumes_amd's host code ----
+def look_at_lh(eye, focus, up=(0.0, 1.0, 0.0)):
+    out = np.empty(16, np.float32)
+    _lib.load().mvh_look_at_lh(_ptr(_f32(eye, 3)), _ptr(_f32(focus, 3)), _ptr(_f32(up, 3)), _ptr(out))
+    return out.reshape(4, 4)
+
+
+def perspective_fov_lh(fov_y, aspect, zn, zf):
+    out = np.empty(16, np.float32)
+    _lib.load().mvh_perspective_fov_lh(fov_y, aspect, zn, zf, _ptr(out))
+    return out.reshape(4, 4)
+
+
+def orthographic_lh(w, h, zn, zf):
+    out = np.empty(16, np.float32)
+    _lib.load().mvh_orthographic_lh(w, h, zn, zf, _ptr(out))
+    return out.reshape(4, 4)
+
+
+def multiply(a, b):
+    out = np.empty(16, np.float32)
+    _lib.load().mvh_multiply(_ptr(_f32(a, 16)), _ptr(_f32(b, 16)), _ptr(out))
+    return out.reshape(4, 4)
+
+
+def shadow_view_proj(light_pos, scene_size):
+    """ObjectRenderer.cpp:176-185; returned TRANSPOSED, as the reference stores m_shadowVP."""
+    out = np.empty(16, np.float32)
+    _lib.load().mvh_shadow_view_proj(_ptr(_f32(light_pos, 3)), scene_size, _ptr(out))
+    return out.reshape(4, 4)
+
+
+def synth_volume(N, k):
+    out = np.empty((N, N, N, 4), np.uint16)
+    _lib.load().mvh_synth_volume(N, k, _ptr(out))
+    return out
+
+
+def synth_sphere_depth(W, H, view_proj, center, radius):
+    out = np.empty((H, W), np.float32)
+    _lib.load().mvh_synth_sphere_depth(W, H, _ptr(_f32(view_proj, 16)), _ptr(_f32(center, 3)), radius, _ptr(out))
+    return out
+
+
+def synth_sphere_shadow(M, light_view_proj_t, center, radius):
+    out = np.empty((M, M), np.uint16)
+    _lib.load().mvh_synth_sphere_shadow(M, _ptr(_f32(light_view_proj_t, 16)), _ptr(_f32(center, 3)), radius, _ptr(out))
+    return out
+
+
+def cube_chain_texels(N):
+    return int(_lib.load().mv_cube_chain_texels(N))
+
+
+def cube_mip_offset(N, mip):
+    return int(_lib.load().mv_cube_mip_offset(N, mip))
+
+
+class MultiRayCaster:
+    FrameCount = 3  # MultiRayCaster.h:52
+
+    def __init__(self, gridSize, lightGridSize, numVolumes, numVolumeSrcs, viewport, shadowMapSize=1024,
+                 device=0, stream=None, flags=0, shard=(0, 1)):
+        """MultiRayCaster::Init (MultiRayCaster.cpp:79-166) + SetViewport (:226-241)."""
+        self._lib = _lib.load()
+        self._ctx = C.c_void_p()
+        self.gridSize, self.lightGridSize = int(gridSize), int(lightGridSize)
+        self.numVolumes, self.numVolumeSrcs = int(numVolumes), int(numVolumeSrcs)
+        self.viewport = (int(viewport[0]), int(viewport[1]))
+        self.shadowMapSize = int(shadowMapSize)
+        cfg = mv_config(C.sizeof(mv_config), self.gridSize, self.lightGridSize, self.numVolumes, self.numVolumeSrcs,
+                        self.viewport[0], self.viewport[1], self.shadowMapSize, int(device), int(flags),
+                        C.c_void_p(stream) if stream else None, int(shard[0]), int(shard[1]))
+        rc = self._lib.mv_create(C.byref(cfg), C.byref(self._ctx))
+        if rc != 0:
+            self._ctx = C.c_void_p()
+            raise MVError(rc, "mv_create")
+        # host-side state of the reference class (MultiRayCaster.cpp:58-72)
+        self.m_maxRaySamples, self.m_maxLightSamples = 256, 96
+        self.m_lightPt = np.array([75.0, 75.0, -75.0], np.float32)
+        self.m_lightColor = np.array([1.0, 0.7, 0.3, 1.0], np.float32)
+        self.m_ambient = np.array([0.0, 0.3, 1.0, 0.4], np.float32)
+        self.m_frameIdx = 0
+        self.m_volumeWorlds = np.zeros((self.numVolumes, 12), np.float32)
+        self.SetVolumesWorld(20.0, (0.0, 0.0, 0.0))  # MultiRayCaster.cpp:141
+        self.cbPerFrame = np.zeros(_lib.CB_PER_FRAME_BYTES, np.uint8)
+        self.perObject = np.zeros(self.numVolumes * _lib.PER_OBJECT_BYTES, np.uint8)
+
+    # ---- lifetime ----
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.mv_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, where):
+        if rc != 0:
+            raise MVError(rc, where, self._lib.mv_last_error(self._ctx).decode())
+
+    # ---- volume data ----
+    def LoadVolumeData(self, i, rgba16f):
+        """Result of LoadVolumeData (MultiRayCaster.cpp:168-209): N^3 x 4 halfs (uint16 bit patterns or float16)."""
+        a = np.ascontiguousarray(rgba16f)
+        if a.dtype == np.float16:
+            a = a.view(np.uint16)
+        N = self.gridSize
+        if a.dtype != np.uint16 or a.size != N * N * N * 4:
+            raise ValueError("volume must be N^3 x 4 uint16/float16")
+        self._check(self._lib.mv_volume_upload_rgba16f(self._ctx, i, _ptr(a)), "mv_volume_upload_rgba16f")
+
+    def LoadVolumeDataR32F(self, i, a):
+        """LoadVolumeData's CSR32FToRGBA16F pass on a (d, h, w) float32 array."""
+        a = np.ascontiguousarray(a, np.float32)
+        d, h, w = a.shape
+        self._check(self._lib.mv_volume_load_r32f(self._ctx, i, _ptr(a), w, h, d), "mv_volume_load_r32f")
+
+    def LoadVolumeDataDevice(self, i, device_ptr):
+        self._check(self._lib.mv_volume_upload_rgba16f_device(self._ctx, i, C.c_void_p(device_ptr)), "mv_volume_upload_rgba16f_device")
+
+    def InitVolumeData(self, i):
+        """InitVolumeData (MultiRayCaster.cpp:243-264)."""
+        self._check(self._lib.mv_volume_init_procedural(self._ctx, i), "mv_volume_init_procedural")
+
+    def SetVolumeDescs(self, packed):
+        a = np.ascontiguousarray(packed, np.uint32)
+        if a.size != self.numVolumes:
+            raise ValueError("need one VolumeDesc per volume")
+        self._check(self._lib.mv_set_volume_descs(self._ctx, _ptr(a)), "mv_set_volume_descs")
+
+    # ---- inputs ----
+    def SetRenderTargets(self, depthMap=None, shadowMap=None, depthMapDevice=None, shadowMapDevice=None):
+        """SetRenderTargets (MultiRayCaster.cpp:211-224): the DEPTH_MAP / SHADOW_MAP the path reads."""
+        W, H = self.viewport
+        if depthMap is not None:
+            a = np.ascontiguousarray(depthMap, np.float32)
+            if a.size != W * H:
+                raise ValueError("depth map must be H x W float32")
+            self._check(self._lib.mv_set_depth_map(self._ctx, _ptr(a)), "mv_set_depth_map")
+        if shadowMap is not None:
+            a = np.ascontiguousarray(shadowMap, np.uint16)
+            if a.size != self.shadowMapSize ** 2:
+                raise ValueError("shadow map must be M x M uint16")
+            self._check(self._lib.mv_set_shadow_map(self._ctx, _ptr(a)), "mv_set_shadow_map")
+        if depthMapDevice is not None:
+            self._check(self._lib.mv_set_depth_map_device(self._ctx, C.c_void_p(depthMapDevice)), "mv_set_depth_map_device")
+        if shadowMapDevice is not None:
+            self._check(self._lib.mv_set_shadow_map_device(self._ctx, C.c_void_p(shadowMapDevice)), "mv_set_shadow_map_device")
+
+    def SetSH(self, coeffSH):
+        a = None if coeffSH is None else _f32(coeffSH, 27)
+        self._check(self._lib.mv_set_sh(self._ctx, _ptr(a)), "mv_set_sh")
+
+    def SetMaxSamples(self, maxRaySamples, maxLightSamples):
+        self.m_maxRaySamples, self.m_maxLightSamples = int(maxRaySamples), int(maxLightSamples)
+        self._check(self._lib.mv_set_max_samples(self._ctx, self.m_maxRaySamples, self.m_maxLightSamples), "mv_set_max_samples")
+
+    def SetVolumesWorld(self, size, center):
+        self._lib.mvh_set_volumes_world(self.numVolumes, float(size), _ptr(_f32(center, 3)), _ptr(self.m_volumeWorlds))
+
+    def SetVolumeWorld(self, i, size, pos):
+        self._lib.mvh_set_volume_world(float(size), _ptr(_f32(pos, 3)), _ptr(self.m_volumeWorlds[i]))
+
+    def SetLight(self, pos, color, intensity):
+        self.m_lightPt = _f32(pos, 3)
+        self.m_lightColor = np.array([color[0], color[1], color[2], intensity], np.float32)
+
+    def SetAmbient(self, color, intensity):
+        self.m_ambient = np.array([color[0], color[1], color[2], intensity], np.float32)
+
+    def UpdateFrame(self, viewProj, shadowVP, eyePt):
+        """UpdateFrame (MultiRayCaster.cpp:316-353). shadowVP is the TRANSPOSED light view-projection (m_shadowVP)."""
+        W, H = self.viewport
+        self._lib.mvh_update_frame(self.numVolumes, _ptr(self.m_volumeWorlds), _ptr(_f32(viewProj, 16)), _ptr(_f32(shadowVP, 16)),
+                                   _ptr(_f32(eyePt, 3)), float(W), float(H), _ptr(self.m_lightPt), _ptr(self.m_lightColor),
+                                   _ptr(self.m_ambient), self.m_frameIdx, _ptr(self.cbPerFrame), _ptr(self.perObject))
+        self.UpdateFrameRaw(self.cbPerFrame, self.perObject)
+
+    def UpdateFrameRaw(self, cbPerFrame, perObject):
+        cb = np.ascontiguousarray(cbPerFrame).view(np.uint8)
+        po = np.ascontiguousarray(perObject).view(np.uint8)
+        if cb.size != _lib.CB_PER_FRAME_BYTES or po.size != self.numVolumes * _lib.PER_OBJECT_BYTES:
+            raise ValueError("CBPerFrame must be 212 bytes and PerObject V x 224 bytes")
+        self._check(self._lib.mv_update_frame(self._ctx, _ptr(cb), _ptr(po)), "mv_update_frame")
+
+    # ---- the path ----
+    def cullVolumes(self):
+        self._check(self._lib.mv_cull(self._ctx), "mv_cull")
+
+    def rayMarchL(self):
+        self._check(self._lib.mv_march_light(self._ctx), "mv_march_light")
+
+    def rayMarchV(self):
+        self._check(self._lib.mv_march_view(self._ctx), "mv_march_view")
+
+    def composite(self, row0=0, row1=0):
+        self._check(self._lib.mv_composite(self._ctx, row0, row1), "mv_composite")
+
+    def Render(self, composite=False):
+        """Render (MultiRayCaster.cpp:355-385), non-work-graph branch; increments m_frameIdx like :384."""
+        self._check(self._lib.mv_render(self._ctx, 1 if composite else 0), "mv_render")
+        self.m_frameIdx += 1
+
+    def synchronize(self):
+        self._check(self._lib.mv_synchronize(self._ctx), "mv_synchronize")
+
+    # ---- readback ----
+    def ReadBackVolumeInfo(self):
+        out = np.zeros((self.numVolumes, 4), np.uint16)
+        self._check(self._lib.mv_readback_volume_info(self._ctx, _ptr(out)), "mv_readback_volume_info")
+        return out
+
+    def ReadBackVisibleLists(self):
+        vis = np.zeros(self.numVolumes, np.uint32)
+        cube = np.zeros(self.numVolumes, np.uint32)
+        nv, nc = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.mv_readback_visible_lists(self._ctx, _ptr(vis), C.byref(nv), _ptr(cube), C.byref(nc)), "mv_readback_visible_lists")
+        return vis[:nv.value].copy(), cube[:nc.value].copy()
+
+    def ReadBackVolume(self, src):
+        N = self.gridSize
+        out = np.empty((N, N, N, 4), np.uint16)
+        self._check(self._lib.mv_readback_volume(self._ctx, src, _ptr(out)), "mv_readback_volume")
+        return out
+
+    def ReadBackLightMap(self, volume):
+        L = self.lightGridSize
+        out = np.empty((L, L, L), np.uint32)
+        self._check(self._lib.mv_readback_light_map(self._ctx, volume, _ptr(out)), "mv_readback_light_map")
+        return out
+
+    def UploadLightMap(self, volume, data):
+        a = np.ascontiguousarray(data, np.uint32)
+        if a.size != self.lightGridSize ** 3:
+            raise ValueError("light map must be L^3 uint32")
+        self._check(self._lib.mv_upload_light_map(self._ctx, volume, _ptr(a)), "mv_upload_light_map")
+
+    def ReadBackCubeMap(self, volume, mip):
+        d = self.gridSize >> mip
+        out = np.empty((6, d, d, 4), np.uint16)
+        self._check(self._lib.mv_readback_cube_map(self._ctx, volume, mip, _ptr(out)), "mv_readback_cube_map")
+        return out
+
+    def ReadBackCubeDepth(self, volume, mip):
+        d = self.gridSize >> mip
+        out = np.empty((6, d, d), np.float32)
+        self._check(self._lib.mv_readback_cube_depth(self._ctx, volume, mip, _ptr(out)), "mv_readback_cube_depth")
+        return out
+
+    def ReadBackComposite(self):
+        W, H = self.viewport
+        out = np.empty((H, W, 4), np.uint16)
+        self._check(self._lib.mv_readback_composite(self._ctx, _ptr(out)), "mv_readback_composite")
+        return out
+
+    def ClearCubeMaps(self):
+        self._check(self._lib.mv_clear_cube_maps(self._ctx), "mv_clear_cube_maps")
+
+    # ---- measurement / plumbing ----
+    def GetStats(self):
+        s = mv_stats()
+        self._check(self._lib.mv_get_stats(self._ctx, C.byref(s)), "mv_get_stats")
+        return {k: getattr(s, k) for k, _ in mv_stats._fields_ if k != "reserved"}
+
+    def ResetStats(self):
+        self._check(self._lib.mv_reset_stats(self._ctx), "mv_reset_stats")
+
+    def SetProfiling(self, on):
+        self._check(self._lib.mv_set_profiling(self._ctx, 1 if on else 0), "mv_set_profiling")
+
+    def GetStream(self):
+        return self._lib.mv_get_stream(self._ctx)
+
+    def GetBuffer(self, which, index=0):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._check(self._lib.mv_get_buffer(self._ctx, which, index, C.byref(p), C.byref(n)), "mv_get_buffer")
+        return p.value, n.value
+
+    def ExchangeLayout(self):
+        d, sb, tb = C.c_uint32(), C.c_size_t(), C.c_size_t()
+        self._check(self._lib.mv_exchange_layout(self._ctx, C.byref(d), C.byref(sb), C.byref(tb)), "mv_exchange_layout")
+        return d.value, sb.value, tb.value
+
+    def ExchangePack(self, device_ptr):
+        self._check(self._lib.mv_exchange_pack(self._ctx, C.c_void_p(device_ptr)), "mv_exchange_pack")
+
+    def ExchangeUnpack(self, device_ptr):
+        self._check(self._lib.mv_exchange_unpack(self._ctx, C.c_void_p(device_ptr)), "mv_exchange_unpack")

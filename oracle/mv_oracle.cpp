@@ -1,0 +1,980 @@
+/*
+ * mv_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code; see mv_oracle.h).
+ *
+ * PARITY UNPINNED: no reference test, golden vector or runnable reference exists for this path.
+ * Line-for-line scalar fp32 restatement of the reference HLSL:
+ *   Sh/Common.hlsli, SharedConsts.h, Sh/RayMarch.hlsli, Sh/CSRayMarch.hlsl (+CSRayMarchV.hlsl),
+ *   Sh/CSRayMarchL.hlsl, Sh/CSVolumeCull.hlsl, Sh/VolumeCull.hlsli,
+ *   XUSG/Shaders/SHIrradiance{,Typeless}.hlsli, Sh/CSInitGridData.hlsl, Sh/CSR32FToRGBA16F.hlsl,
+ *   Sh/VSCube.hlsl, Sh/PSDepthPeel.hlsl, Sh/PSCube.hlsl(i), Sh/RayCast.hlsli, Sh/PSResolveOIT.hlsl.
+ *
+ * Numeric conventions (documented in DESIGN.md, mirrored by the HIP kernels):
+ *   - `min16float` is a minimum-precision hint (SM6.3 without -enable-16bit-types): fp32 everywhere,
+ *     fp16 / 11-11-10 only in storage.
+ *   - build with -ffp-contract=off; a multiply-add is fused ONLY where fmaf() is written out
+ *     (lerp and ray-point evaluation -- the places a shader compiler emits `mad`).
+ *   - normalize(v) = v / sqrt(dot(v,v)); dot and mul() accumulate left to right.
+ *   - HLSL min/max return the non-NaN operand (fminf/fmaxf); saturate(NaN) = 0.
+ *   - float -> uint casts saturate (D3D ftou).
+ *   - pow(x, 0.25) is evaluated as sqrt(sqrt(x)) (correctly rounded steps, identical on CPU and GPU).
+ *   - sampler: texel centres at +0.5, clamp addressing, exact fp32 filter weights
+ *     (D3D hardware may quantise weights to >= 8 fractional bits; unpinned).
+ *   - fp32 -> fp16 and fp32 -> 11/11/10 stores round to nearest even; negative 11/10-bit values -> 0.
+ *   - D16 comparison sampler: reference clamped to [0,1], compared in fp32 against texel/65535,
+ *     LESS_EQUAL, bilinear blend of the four 0/1 results.
+ */
+#include "mv_oracle.h"
+
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace
+{
+const float kMaxDist = 3.4641016151377544f;	// RayMarch.hlsli:17   2.0 * sqrt(3.0)
+const float kAbsorption = 0.8f;				// RayMarch.hlsli:11
+const float kZeroThreshold = 0.01f;			// RayMarch.hlsli:12
+const float kPI = 3.1415926535897f;			// XUSG/Shaders/SHIrradiance.hlsli:5-7
+const float kFltMax = 3.402823466e+38f;		// Common.hlsli:9
+const float kSqrt3 = 1.7320508075688772f;
+const float kZNear = 1.0f, kZFar = 1000.0f;	// SharedConsts.h:9-10
+const uint32_t kCubeMapRayMarchBit = 1u << 15;	// Common.hlsli:11
+
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+
+inline float3 f3(float x, float y, float z) { float3 r = { x, y, z }; return r; }
+inline float3 operator+(float3 a, float3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+inline float3 operator-(float3 a, float3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+inline float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+inline float3 operator/(float3 a, float3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+inline float idx(const float3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+inline float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float3 normalize3(float3 v) { const float l = sqrtf(dot3(v, v)); return f3(v.x / l, v.y / l, v.z / l); }
+inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }	// NaN -> 0
+inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+inline float lerpf(float a, float b, float w) { return fmaf(w, b - a, a); }
+inline float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+inline float3 rayAt(float3 o, float3 d, float t) { return f3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)); }
+
+inline uint32_t f2u(float x)	// D3D ftou: NaN/negative -> 0, saturating
+{
+	if (!(x > 0.0f)) return 0u;
+	if (x >= 4294967296.0f) return 0xffffffffu;
+	return (uint32_t)x;
+}
+
+inline int32_t f2i_floor(float x)	// floor to int with saturation (texel addressing)
+{
+	if (!(x == x)) return 0;
+	const float f = floorf(x);
+	if (f <= -2147483648.0f) return INT32_MIN;
+	if (f >= 2147483520.0f) return INT32_MAX - 127;
+	return (int32_t)f;
+}
+
+inline int32_t clampi(int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+// ---- HLSL constant-buffer / structured-buffer decoding (Common.hlsli:28-49; MultiRayCaster.cpp:23-41, 341-351)
+// float4x4 stored transposed via XMStoreFloat4x4(XMMatrixTranspose(M)) and read column-major: M[r][c] = f[4*c + r].
+// float4x3 stored via XMStoreFloat3x4(M) and read column-major:                                M[r][c] = f[4*c + r], c < 3.
+struct PerObject
+{
+	float wvp[16], wvpI[16], worldI[12], world[12];
+};
+
+struct CBPerFrame
+{
+	float eyePos[4];
+	float viewport[4];
+	float screenToWorld[16];
+	float shadowViewProj[16];
+	float lightPos[4];
+	float lightColor[4];
+	float ambient[4];
+	uint32_t frameIdx;
+};
+
+static_assert(sizeof(PerObject) == MVO_PER_OBJECT_BYTES, "PerObject layout");
+static_assert(sizeof(CBPerFrame) == MVO_CB_PER_FRAME_BYTES, "CBPerFrame layout");
+
+inline float4 mul44(float4 p, const float* m)	// mul(float4, float4x4)
+{
+	float4 r;
+	r.x = p.x * m[0] + p.y * m[1] + p.z * m[2] + p.w * m[3];
+	r.y = p.x * m[4] + p.y * m[5] + p.z * m[6] + p.w * m[7];
+	r.z = p.x * m[8] + p.y * m[9] + p.z * m[10] + p.w * m[11];
+	r.w = p.x * m[12] + p.y * m[13] + p.z * m[14] + p.w * m[15];
+	return r;
+}
+
+inline float3 mul43(float3 p, const float* m)	// mul(float4(p, 1.0), float4x3)
+{
+	return f3(p.x * m[0] + p.y * m[1] + p.z * m[2] + m[3],
+		p.x * m[4] + p.y * m[5] + p.z * m[6] + m[7],
+		p.x * m[8] + p.y * m[9] + p.z * m[10] + m[11]);
+}
+
+inline float3 mul33(float3 p, const float* m)	// mul(float3, (float3x3)float4x3)
+{
+	return f3(p.x * m[0] + p.y * m[1] + p.z * m[2],
+		p.x * m[4] + p.y * m[5] + p.z * m[6],
+		p.x * m[8] + p.y * m[9] + p.z * m[10]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// formats
+// ---------------------------------------------------------------------------------------------
+inline uint32_t asuint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float asfloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+float h2f(uint16_t h)
+{
+	const uint32_t s = (uint32_t)(h & 0x8000u) << 16;
+	const uint32_t e = (h >> 10) & 0x1fu;
+	uint32_t m = h & 0x3ffu;
+	if (e == 0)
+	{
+		if (m == 0) return asfloat(s);
+		// denormal: m * 2^-24
+		const float v = (float)m * 5.9604644775390625e-08f;
+		return asfloat(asuint(v) | s);
+	}
+	if (e == 31) return asfloat(s | 0x7f800000u | (m << 13));
+	return asfloat(s | ((e + 112u) << 23) | (m << 13));
+}
+
+// Generic fp32 -> small float (EB exponent bits = 5, MB mantissa bits) RNE; returns magnitude bits (no sign).
+template <int MB>
+uint32_t f32_to_small(uint32_t absBits)
+{
+	const int SH = 23 - MB;
+	const uint32_t INF = 31u << MB;
+	if (absBits > 0x7f800000u) return INF | (1u << (MB - 1));	// NaN -> quiet NaN
+	if (absBits == 0x7f800000u) return INF;
+	const int32_t e = (int32_t)(absBits >> 23) - 127;
+	uint32_t m = absBits & 0x7fffffu;
+	if (e > 15)
+	{
+		// may still round to max finite? no: e >= 16 is already >= 65536 > max finite -> inf under RNE
+		return INF;
+	}
+	if (e >= -14)
+	{
+		// normal
+		uint32_t v = ((uint32_t)(e + 15) << MB) | (m >> SH);
+		const uint32_t rem = m & ((1u << SH) - 1);
+		const uint32_t half = 1u << (SH - 1);
+		if (rem > half || (rem == half && (v & 1u))) ++v;	// carry may roll into exponent (and to INF), which is correct
+		return v;
+	}
+	// denormal: value = 1.m * 2^e, target unit = 2^(-14 - MB)
+	if (e < -14 - MB - 1) return 0;
+	m |= 0x800000u;
+	const int shift = SH + (-14 - e);	// >= SH + 1
+	if (shift > 31) return 0;
+	uint32_t v = m >> shift;
+	const uint32_t rem = m & ((1u << shift) - 1);
+	const uint32_t half = 1u << (shift - 1);
+	if (rem > half || (rem == half && (v & 1u))) ++v;
+	return v;
+}
+
+uint16_t f2h(float f)
+{
+	const uint32_t u = asuint(f);
+	const uint32_t s = (u >> 16) & 0x8000u;
+	return (uint16_t)(s | f32_to_small<10>(u & 0x7fffffffu));
+}
+
+inline float small_to_f32(uint32_t bits, int MB)	// 5-bit exponent, MB mantissa bits, unsigned
+{
+	return h2f((uint16_t)(bits << (10 - MB)));
+}
+
+uint32_t pack_r11g11b10f(float r, float g, float b)
+{
+	// negative (incl. -0) -> 0 ; NaN keeps NaN ; RNE  (DirectXMath XMStoreFloat3PK semantics for sign; RNE assumed)
+	const uint32_t ur = asuint(r), ug = asuint(g), ub = asuint(b);
+	const uint32_t R = ((ur & 0x80000000u) && (ur & 0x7fffffffu) <= 0x7f800000u) ? 0u : f32_to_small<6>(ur & 0x7fffffffu);
+	const uint32_t G = ((ug & 0x80000000u) && (ug & 0x7fffffffu) <= 0x7f800000u) ? 0u : f32_to_small<6>(ug & 0x7fffffffu);
+	const uint32_t B = ((ub & 0x80000000u) && (ub & 0x7fffffffu) <= 0x7f800000u) ? 0u : f32_to_small<5>(ub & 0x7fffffffu);
+	return (R & 0x7ffu) | ((G & 0x7ffu) << 11) | ((B & 0x3ffu) << 22);
+}
+
+inline float3 unpack_r11g11b10f(uint32_t p)
+{
+	return f3(small_to_f32(p & 0x7ffu, 6), small_to_f32((p >> 11) & 0x7ffu, 6), small_to_f32(p >> 22, 5));
+}
+
+// ---------------------------------------------------------------------------------------------
+// a5: fixed-function sampler contract (samplers at MultiRayCaster.cpp:556-566)
+// ---------------------------------------------------------------------------------------------
+struct Taps { int32_t i0, i1; float f; };
+
+inline Taps linearTaps(float coord01, uint32_t size, int32_t off)
+{
+	// LINEAR + CLAMP: c = u * size - 0.5 ; taps floor(c) and floor(c) + 1 clamped to [0, size-1]
+	const float c = coord01 * (float)size - 0.5f;
+	const float fl = floorf(c);
+	Taps t;
+	t.f = c - fl;
+	const int32_t i = f2i_floor(c);
+	const int64_t a = (int64_t)i + off, b = a + 1;
+	t.i0 = (int32_t)std::min<int64_t>(std::max<int64_t>(a, 0), (int64_t)size - 1);
+	t.i1 = (int32_t)std::min<int64_t>(std::max<int64_t>(b, 0), (int64_t)size - 1);
+	return t;
+}
+
+// Texture3D<float4>.SampleLevel(LINEAR_CLAMP, uvw, 0, offset) on RGBA16F -- RayMarch.hlsli:44-50, 74
+float4 sampleRGBA16F(const uint16_t* tex, uint32_t N, float3 uvw, int ox = 0, int oy = 0, int oz = 0)
+{
+	const Taps tx = linearTaps(uvw.x, N, ox), ty = linearTaps(uvw.y, N, oy), tz = linearTaps(uvw.z, N, oz);
+	const size_t sy = (size_t)N, sz = (size_t)N * N;
+	const int32_t xs[2] = { tx.i0, tx.i1 }, ys[2] = { ty.i0, ty.i1 }, zs[2] = { tz.i0, tz.i1 };
+	float c[2][2][2][4];
+	for (int k = 0; k < 2; ++k)
+		for (int j = 0; j < 2; ++j)
+			for (int i = 0; i < 2; ++i)
+			{
+				const uint16_t* p = tex + 4 * ((size_t)zs[k] * sz + (size_t)ys[j] * sy + (size_t)xs[i]);
+				for (int ch = 0; ch < 4; ++ch) c[k][j][i][ch] = h2f(p[ch]);
+			}
+	float r[4];
+	for (int ch = 0; ch < 4; ++ch)
+	{
+		const float c00 = lerpf(c[0][0][0][ch], c[0][0][1][ch], tx.f);
+		const float c10 = lerpf(c[0][1][0][ch], c[0][1][1][ch], tx.f);
+		const float c01 = lerpf(c[1][0][0][ch], c[1][0][1][ch], tx.f);
+		const float c11 = lerpf(c[1][1][0][ch], c[1][1][1][ch], tx.f);
+		const float c0 = lerpf(c00, c10, ty.f);
+		const float c1 = lerpf(c01, c11, ty.f);
+		r[ch] = lerpf(c0, c1, tz.f);
+	}
+	float4 o = { r[0], r[1], r[2], r[3] };
+	return o;
+}
+
+// alpha only (same arithmetic as channel 3 above)
+float sampleAlpha16F(const uint16_t* tex, uint32_t N, float3 uvw, int ox = 0, int oy = 0, int oz = 0)
+{
+	const Taps tx = linearTaps(uvw.x, N, ox), ty = linearTaps(uvw.y, N, oy), tz = linearTaps(uvw.z, N, oz);
+	const size_t sy = (size_t)N, sz = (size_t)N * N;
+	const int32_t xs[2] = { tx.i0, tx.i1 }, ys[2] = { ty.i0, ty.i1 }, zs[2] = { tz.i0, tz.i1 };
+	float c[2][2][2];
+	for (int k = 0; k < 2; ++k)
+		for (int j = 0; j < 2; ++j)
+			for (int i = 0; i < 2; ++i)
+				c[k][j][i] = h2f(tex[4 * ((size_t)zs[k] * sz + (size_t)ys[j] * sy + (size_t)xs[i]) + 3]);
+	const float c00 = lerpf(c[0][0][0], c[0][0][1], tx.f);
+	const float c10 = lerpf(c[0][1][0], c[0][1][1], tx.f);
+	const float c01 = lerpf(c[1][0][0], c[1][0][1], tx.f);
+	const float c11 = lerpf(c[1][1][0], c[1][1][1], tx.f);
+	return lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+}
+
+// Texture3D<float3>.SampleLevel(LINEAR_CLAMP, uvw, 0) on R11G11B10F -- RayMarch.hlsli:235-240
+float3 sampleR11G11B10F(const uint32_t* tex, uint32_t L, float3 uvw)
+{
+	const Taps tx = linearTaps(uvw.x, L, 0), ty = linearTaps(uvw.y, L, 0), tz = linearTaps(uvw.z, L, 0);
+	const size_t sy = (size_t)L, sz = (size_t)L * L;
+	const int32_t xs[2] = { tx.i0, tx.i1 }, ys[2] = { ty.i0, ty.i1 }, zs[2] = { tz.i0, tz.i1 };
+	float3 c[2][2][2];
+	for (int k = 0; k < 2; ++k)
+		for (int j = 0; j < 2; ++j)
+			for (int i = 0; i < 2; ++i)
+				c[k][j][i] = unpack_r11g11b10f(tex[(size_t)zs[k] * sz + (size_t)ys[j] * sy + (size_t)xs[i]]);
+	float r[3];
+	for (int ch = 0; ch < 3; ++ch)
+	{
+		const float c00 = lerpf(idx(c[0][0][0], ch), idx(c[0][0][1], ch), tx.f);
+		const float c10 = lerpf(idx(c[0][1][0], ch), idx(c[0][1][1], ch), tx.f);
+		const float c01 = lerpf(idx(c[1][0][0], ch), idx(c[1][0][1], ch), tx.f);
+		const float c11 = lerpf(idx(c[1][1][0], ch), idx(c[1][1][1], ch), tx.f);
+		r[ch] = lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+	}
+	return f3(r[0], r[1], r[2]);
+}
+
+// Texture2D<float>.SampleLevel(POINT_CLAMP, uv, 0) -- CSRayMarch.hlsl:68
+float samplePointR32F(const float* tex, uint32_t W, uint32_t H, float u, float v)
+{
+	const int32_t x = clampi(f2i_floor(u * (float)W), 0, (int32_t)W - 1);
+	const int32_t y = clampi(f2i_floor(v * (float)H), 0, (int32_t)H - 1);
+	return tex[(size_t)y * W + x];
+}
+
+// Texture2D<float>.SampleCmpLevelZero(LINEAR_LESS_EQUAL, uv, ref) on D16_UNORM -- RayMarch.hlsli:109
+float sampleCmpD16(const uint16_t* tex, uint32_t M, float u, float v, float ref)
+{
+	const Taps tx = linearTaps(u, M, 0), ty = linearTaps(v, M, 0);
+	const float r = saturatef(ref);
+	const float t00 = (float)tex[(size_t)ty.i0 * M + tx.i0] / 65535.0f;
+	const float t10 = (float)tex[(size_t)ty.i0 * M + tx.i1] / 65535.0f;
+	const float t01 = (float)tex[(size_t)ty.i1 * M + tx.i0] / 65535.0f;
+	const float t11 = (float)tex[(size_t)ty.i1 * M + tx.i1] / 65535.0f;
+	const float c00 = r <= t00 ? 1.0f : 0.0f, c10 = r <= t10 ? 1.0f : 0.0f;
+	const float c01 = r <= t01 ? 1.0f : 0.0f, c11 = r <= t11 ? 1.0f : 0.0f;
+	return lerpf(lerpf(c00, c10, tx.f), lerpf(c01, c11, tx.f), ty.f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sh/RayMarch.hlsli device functions
+// ---------------------------------------------------------------------------------------------
+// RayMarch.hlsli:170-177 (_TEXCOORD_INVERT_Y_ undefined)
+inline float3 LocalToTex3DSpace(float3 pos) { return f3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f); }
+
+// RayMarch.hlsli:128-155
+bool ComputeRayOrigin(float3& rayOrigin, float3 rayDir)
+{
+	if (fabsf(rayOrigin.x) <= 1.0f && fabsf(rayOrigin.y) <= 1.0f && fabsf(rayOrigin.z) <= 1.0f) return true;
+
+	float U = kFltMax;
+	bool isHit = false;
+	for (int i = 0; i < 3; ++i)
+	{
+		const float u = (-signf(idx(rayDir, i)) - idx(rayOrigin, i)) / idx(rayDir, i);
+		if (u < 0.0f) continue;
+		const int j = (i + 1) % 3, k = (i + 2) % 3;
+		if (fabsf(idx(rayDir, j) * u + idx(rayOrigin, j)) > 1.0f) continue;
+		if (fabsf(idx(rayDir, k) * u + idx(rayOrigin, k)) > 1.0f) continue;
+		if (u < U)
+		{
+			U = u;
+			isHit = true;
+		}
+	}
+	rayOrigin = f3(clampf(rayDir.x * U + rayOrigin.x, -1.0f, 1.0f),
+		clampf(rayDir.y * U + rayOrigin.y, -1.0f, 1.0f),
+		clampf(rayDir.z * U + rayOrigin.z, -1.0f, 1.0f));
+	return isHit;
+}
+
+// RayMarch.hlsli:160-165
+inline float ComputeTargetHit(float3 rayOrigin, float3 target, float3 rayDir)
+{
+	const float3 u = (target - rayOrigin) / rayDir;
+	return fmaxf(fmaxf(u.x, u.y), u.z);
+}
+
+// RayMarch.hlsli:82-97
+float GetTMax(float3 pos, float3 rayOrigin, float3 rayDir, const float* worldViewProjI)
+{
+	if (pos.z >= 1.0f) return kFltMax;
+	float4 p = { pos.x, pos.y, pos.z, 1.0f };
+	const float4 hpos = mul44(p, worldViewProjI);
+	pos = f3(hpos.x / hpos.w, hpos.y / hpos.w, hpos.z / hpos.w);
+	const float3 t = (pos - rayOrigin) / rayDir;
+	return fmaxf(fmaxf(t.x, t.y), t.z);
+}
+
+// RayMarch.hlsli:182-192
+inline float GetStep(float dDensity, float transm, float density, float step)
+{
+	const float factorEv = fminf(1.0f / 256.0f / fabsf(dDensity), 2.0f);
+	const float factorUi = fminf(1.0f - density, 1.0f);
+	const float factorTh = 1.0f - transm;
+	step *= fmaxf(1.5f * factorEv * factorUi * factorTh, 1.0f);
+	return step;
+}
+
+// RayMarch.hlsli:197-230 (mipLevel = 0)
+void CastLightRay(float& transm, const uint16_t* tex, uint32_t N, float3 rayOrigin, float3 rayDir,
+	float stepScale, uint32_t numSamples, uint64_t& samples)
+{
+	float t = stepScale;
+	float step = stepScale;
+	float prevDensity = 0.0f;
+	for (uint32_t i = 0; i < numSamples; ++i)
+	{
+		const float3 pos = rayAt(rayOrigin, rayDir, t);
+		if (fabsf(pos.x) > 1.0f || fabsf(pos.y) > 1.0f || fabsf(pos.z) > 1.0f) break;
+		const float3 uvw = LocalToTex3DSpace(pos);
+
+		const float density = sampleAlpha16F(tex, N, uvw);
+		++samples;
+
+		const float dDensity = density - prevDensity;
+		const float opacity = saturatef(density * step);
+		const float newStep = GetStep(dDensity, transm, opacity, stepScale);
+		// step = (step + newStep) * 0.5;	-- :219, dead: overwritten at :227
+		prevDensity = density;
+
+		transm *= 1.0f - density * kAbsorption;
+		if (transm < kZeroThreshold) break;
+
+		step = newStep;
+		t += step;
+	}
+}
+
+// RayMarch.hlsli:55-77
+float3 GetDensityGradient(const uint16_t* tex, uint32_t N, float3 uvw)
+{
+	float q[6];
+	q[0] = sampleAlpha16F(tex, N, uvw, -1, 0, 0);
+	q[1] = sampleAlpha16F(tex, N, uvw, 1, 0, 0);
+	q[2] = sampleAlpha16F(tex, N, uvw, 0, -1, 0);
+	q[3] = sampleAlpha16F(tex, N, uvw, 0, 1, 0);
+	q[4] = sampleAlpha16F(tex, N, uvw, 0, 0, -1);
+	q[5] = sampleAlpha16F(tex, N, uvw, 0, 0, 1);
+	return f3(q[1] - q[0], q[3] - q[2], q[5] - q[4]);
+}
+
+// XUSG/Shaders/SHIrradianceTypeless.hlsli:15-36
+float3 EvaluateSHIrradiance(const float* sh /* 9 x float3 */, float3 norm)
+{
+	const float c1 = 0.42904276540489171563379376569857f;
+	const float c2 = 0.51166335397324424423977581244463f;
+	const float c3 = 0.24770795610037568833406429782001f;
+	const float c4 = 0.88622692545275801364908374167057f;
+	const float x = -norm.x, y = -norm.y, z = norm.z;
+	float r[3];
+	for (int ch = 0; ch < 3; ++ch)
+	{
+#define SHC(i) sh[3 * (i) + ch]
+		const float v = (c1 * (x * x - y * y)) * SHC(8)
+			+ (c3 * (3.0f * z * z - 1.0f)) * SHC(6)
+			+ c4 * SHC(0)
+			+ 2.0f * c1 * (SHC(4) * x * y + SHC(7) * x * z + SHC(5) * y * z)
+			+ 2.0f * c2 * (SHC(3) * x + SHC(1) * y + SHC(2) * z);
+#undef SHC
+		r[ch] = fmaxf(0.0f, v);
+	}
+	return f3(r[0], r[1], r[2]);
+}
+
+// CSRayMarch.hlsl:28-53
+float3 GetLocalPos(float px, float py, uint32_t slice, float dims)
+{
+	float x = (px + 0.5f) / dims * 2.0f - 1.0f;
+	float y = (py + 0.5f) / dims * 2.0f - 1.0f;
+	y = -y;
+	switch (slice)
+	{
+	case 0: return f3(1.0f, y, -x);
+	case 1: return f3(-1.0f, y, x);
+	case 2: return f3(x, 1.0f, -y);
+	case 3: return f3(x, -1.0f, y);
+	case 4: return f3(x, y, 1.0f);
+	case 5: return f3(-x, y, -1.0f);
+	default: return f3(0.0f, 0.0f, 0.0f);
+	}
+}
+
+inline uint64_t chainTexels(uint32_t N)
+{
+	uint64_t s = 0;
+	for (uint32_t m = 0; m < MVO_NUM_CUBE_MIP; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	return s;
+}
+
+inline uint64_t mipOffset(uint32_t N, uint32_t mip)
+{
+	uint64_t s = 0;
+	for (uint32_t m = 0; m < mip; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	return s;
+}
+
+// Shared body of CSRayMarch.hlsl:111-155 and RayCast.hlsli:56-104 (identical loops; RayCast has no ComputeTargetHit clamp)
+float4 marchLoop(const uint16_t* vol, uint32_t N, const uint32_t* lightMap, uint32_t L,
+	float3 rayOrigin, float3 rayDir, float tMax, uint32_t smpCount, uint64_t& nSamples, uint64_t& nLit)
+{
+	const float stepScale = kMaxDist / (float)smpCount;
+	float4 scatter = { 0.0f, 0.0f, 0.0f, 0.0f };
+
+	float t = 0.0f;
+	float step = stepScale;
+	float prevDensity = 0.0f;
+	for (uint32_t i = 0; i < smpCount; ++i)
+	{
+		const float3 pos = rayAt(rayOrigin, rayDir, t);
+		if (fabsf(pos.x) > 1.0f || fabsf(pos.y) > 1.0f || fabsf(pos.z) > 1.0f) break;
+		const float3 uvw = LocalToTex3DSpace(pos);
+
+		float4 color = sampleRGBA16F(vol, N, uvw);
+		++nSamples;
+		float newStep = stepScale;
+
+		if (color.w > kZeroThreshold)
+		{
+			const float3 light = sampleR11G11B10F(lightMap, L, f3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f));
+			++nLit;
+
+			const float transm = 1.0f - scatter.w;
+			const float dDensity = color.w - prevDensity;
+			newStep = GetStep(dDensity, transm, color.w, stepScale);
+			// step = (step + newStep) * 0.5;	-- CSRayMarch.hlsl:136, dead: overwritten at :150
+			prevDensity = color.w;
+
+			color.x *= color.w; color.y *= color.w; color.z *= color.w;	// not pre-multiplied (:140-142)
+			color.x *= light.x; color.y *= light.y; color.z *= light.z;
+			scatter.x += color.x * kAbsorption * transm;
+			scatter.y += color.y * kAbsorption * transm;
+			scatter.z += color.z * kAbsorption * transm;
+			scatter.w += color.w * kAbsorption * transm;
+
+			if (transm < kZeroThreshold) break;
+		}
+
+		step = newStep;
+		t += step;
+		if (t > tMax) break;
+	}
+	(void)step;
+
+	const float twoPi = 2.0f * kPI;
+	scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;
+	return scatter;
+}
+} // namespace
+
+// =============================================================================================
+// exported
+// =============================================================================================
+extern "C" {
+
+uint16_t mvo_f32_to_f16(float f) { return f2h(f); }
+float mvo_f16_to_f32(uint16_t h) { return h2f(h); }
+uint32_t mvo_pack_r11g11b10f(float r, float g, float b) { return pack_r11g11b10f(r, g, b); }
+void mvo_unpack_r11g11b10f(uint32_t p, float rgb[3]) { const float3 c = unpack_r11g11b10f(p); rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z; }
+uint64_t mvo_cube_chain_texels(uint32_t N) { return chainTexels(N); }
+uint64_t mvo_cube_mip_offset(uint32_t N, uint32_t mip) { return mipOffset(N, mip); }
+
+void mvo_sample_rgba16f(const uint16_t* tex, uint32_t N, const float uvw[3], const int32_t off[3], float out[4])
+{
+	const float4 c = sampleRGBA16F(tex, N, f3(uvw[0], uvw[1], uvw[2]), off ? off[0] : 0, off ? off[1] : 0, off ? off[2] : 0);
+	out[0] = c.x; out[1] = c.y; out[2] = c.z; out[3] = c.w;
+}
+
+void mvo_sample_r11g11b10f(const uint32_t* tex, uint32_t L, const float uvw[3], float out[3])
+{
+	const float3 c = sampleR11G11B10F(tex, L, f3(uvw[0], uvw[1], uvw[2]));
+	out[0] = c.x; out[1] = c.y; out[2] = c.z;
+}
+
+float mvo_sample_point_r32f(const float* tex, uint32_t W, uint32_t H, float u, float v) { return samplePointR32F(tex, W, H, u, v); }
+float mvo_sample_cmp_d16(const uint16_t* tex, uint32_t M, float u, float v, float ref) { return sampleCmpD16(tex, M, u, v, ref); }
+
+int mvo_compute_ray_origin(float origin[3], const float dir[3])
+{
+	float3 o = f3(origin[0], origin[1], origin[2]);
+	const bool hit = ComputeRayOrigin(o, f3(dir[0], dir[1], dir[2]));
+	origin[0] = o.x; origin[1] = o.y; origin[2] = o.z;
+	return hit ? 1 : 0;
+}
+
+float mvo_compute_target_hit(const float origin[3], const float target[3], const float dir[3])
+{
+	return ComputeTargetHit(f3(origin[0], origin[1], origin[2]), f3(target[0], target[1], target[2]), f3(dir[0], dir[1], dir[2]));
+}
+
+float mvo_get_step(float dDensity, float transm, float density, float step) { return GetStep(dDensity, transm, density, step); }
+
+void mvo_get_local_pos(float px, float py, uint32_t slice, uint32_t dims, float out[3])
+{
+	const float3 p = GetLocalPos(px, py, slice, (float)dims);
+	out[0] = p.x; out[1] = p.y; out[2] = p.z;
+}
+
+void mvo_cast_light_ray(float* transm, const uint16_t* tex, uint32_t N, const float origin[3],
+	const float dir[3], float stepScale, uint32_t numSamples, uint64_t* samples)
+{
+	uint64_t n = 0;
+	CastLightRay(*transm, tex, N, f3(origin[0], origin[1], origin[2]), f3(dir[0], dir[1], dir[2]), stepScale, numSamples, n);
+	if (samples) *samples = n;
+}
+
+void mvo_eval_sh_irradiance(const float sh27[27], const float norm[3], float out[3])
+{
+	const float3 r = EvaluateSHIrradiance(sh27, f3(norm[0], norm[1], norm[2]));
+	out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+
+int mvo_num_threads(void)
+{
+#ifdef _OPENMP
+	return omp_get_max_threads();
+#else
+	return 1;
+#endif
+}
+
+void mvo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+	if (n > 0) omp_set_num_threads(n);
+#else
+	(void)n;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// a6: CSInitGridData.hlsl:10-27
+// ---------------------------------------------------------------------------------------------
+void mvo_init_grid_data(uint32_t N, uint16_t* rgba)
+{
+	const float gridSize = (float)N;
+#pragma omp parallel for schedule(static)
+	for (int64_t z = 0; z < (int64_t)N; ++z)
+		for (uint32_t y = 0; y < N; ++y)
+			for (uint32_t x = 0; x < N; ++x)
+			{
+				const float3 pos = f3(((float)x + 0.5f) / gridSize * 2.0f - 1.0f,
+					((float)y + 0.5f) / gridSize * 2.0f - 1.0f,
+					((float)z + 0.5f) / gridSize * 2.0f - 1.0f);
+				const float r_sq = dot3(pos, pos);
+				float a = 1.0f - r_sq;
+				a *= a;
+				a = saturatef(a * a * 2.0f);
+
+				const float3 colorU = f3(1.0f, 0.6f, 0.0f);
+				const float3 colorD = f3(0.5f, 0.8f, 1.0f);
+				const float s = saturatef(pos.y * 0.5f + 0.2f);
+				// lerp(x, y, s) = x + s * (y - x)
+				const float3 color = f3(lerpf(colorD.x, colorU.x, s), lerpf(colorD.y, colorU.y, s), lerpf(colorD.z, colorU.z, s));
+
+				uint16_t* o = rgba + 4 * (((size_t)z * N + y) * N + x);
+				o[0] = f2h(color.x); o[1] = f2h(color.y); o[2] = f2h(color.z); o[3] = f2h(a);
+			}
+}
+
+// CSR32FToRGBA16F.hlsl:16-26 -- Texture3D<float>.SampleLevel(LINEAR_CLAMP) of a w x h x d R32F source
+void mvo_r32f_to_rgba16f(const float* src, uint32_t w, uint32_t h, uint32_t d, uint32_t N, uint16_t* rgba)
+{
+	const float gridSize = (float)N;
+	const uint16_t one = f2h(1.0f);
+#pragma omp parallel for schedule(static)
+	for (int64_t z = 0; z < (int64_t)N; ++z)
+		for (uint32_t y = 0; y < N; ++y)
+			for (uint32_t x = 0; x < N; ++x)
+			{
+				const float3 uvw = f3(((float)x + 0.5f) / gridSize, ((float)y + 0.5f) / gridSize, ((float)z + 0.5f) / gridSize);
+				const Taps tx = linearTaps(uvw.x, w, 0), ty = linearTaps(uvw.y, h, 0), tz = linearTaps(uvw.z, d, 0);
+#define SRC(i, j, k) src[((size_t)(k) * h + (j)) * w + (i)]
+				const float c00 = lerpf(SRC(tx.i0, ty.i0, tz.i0), SRC(tx.i1, ty.i0, tz.i0), tx.f);
+				const float c10 = lerpf(SRC(tx.i0, ty.i1, tz.i0), SRC(tx.i1, ty.i1, tz.i0), tx.f);
+				const float c01 = lerpf(SRC(tx.i0, ty.i0, tz.i1), SRC(tx.i1, ty.i0, tz.i1), tx.f);
+				const float c11 = lerpf(SRC(tx.i0, ty.i1, tz.i1), SRC(tx.i1, ty.i1, tz.i1), tx.f);
+#undef SRC
+				const float a = lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+				uint16_t* o = rgba + 4 * (((size_t)z * N + y) * N + x);
+				o[0] = one; o[1] = one; o[2] = one; o[3] = f2h(a * 0.25f);
+			}
+}
+
+// ---------------------------------------------------------------------------------------------
+// a1: CSVolumeCull.hlsl:13-78 + VolumeCull.hlsli
+// ---------------------------------------------------------------------------------------------
+void mvo_cull(uint32_t V, const void* perObjectBytes, const uint32_t* volumeDescs, const void* cbBytes,
+	uint32_t maxRaySamples, uint16_t* volumeInfo, uint32_t* visibleVolumes, uint32_t* visibleCount,
+	uint32_t* cubeMapVolumes, uint32_t* cubeMapCount)
+{
+	const PerObject* perObjects = (const PerObject*)perObjectBytes;
+	CBPerFrame cb;
+	memcpy(&cb, cbBytes, sizeof(cb));
+	const float vpW = cb.viewport[0], vpH = cb.viewport[1];
+	const float3 eyePt = f3(cb.eyePos[0], cb.eyePos[1], cb.eyePos[2]);
+
+	// VolumeCull.hlsli:119-138 edge -> vertex-lane table ; :213-223 face -> edge table
+	static const uint8_t edgeLanes[12][2] = { {0,1},{3,2},{1,3},{2,0},{6,7},{5,4},{4,6},{7,5},{4,0},{2,6},{7,3},{1,5} };
+	static const uint8_t faceEdges[6][4] = { {8,3,9,6},{10,2,11,7},{0,8,5,11},{1,10,4,9},{0,2,1,3},{4,6,5,7} };
+
+	uint32_t nVis = 0, nCube = 0;
+	for (uint32_t volumeId = 0; volumeId < V; ++volumeId)
+	{
+		const PerObject& po = perObjects[volumeId];
+
+		// ProjectToViewport (VolumeCull.hlsli:27-41), one vertex per lane
+		float vx[8], vy[8], vz[8];
+		bool anyInView = false;
+		for (uint32_t i = 0; i < 8; ++i)
+		{
+			float4 p;
+			p.x = (i & 1) ? 1.0f : -1.0f;
+			p.y = ((i >> 1) & 1) ? 1.0f : -1.0f;
+			p.z = (i >> 2) ? 1.0f : -1.0f;
+			p.w = 1.0f;
+			p = mul44(p, po.wvp);
+			p.x /= p.w; p.y /= p.w; p.z /= p.w;
+			p.x = p.x * 0.5f + 0.5f;
+			p.y = p.y * 0.5f + 0.5f;
+			p.y = 1.0f - p.y;
+			vx[i] = p.x * vpW; vy[i] = p.y * vpH; vz[i] = p.z;
+			// CSVolumeCull.hlsl:32
+			const bool isInView = (vx[i] <= vpW && vy[i] <= vpH && vx[i] >= 0.0f && vy[i] >= 0.0f) && vz[i] > 0.0f && vz[i] < 1.0f;
+			anyInView = anyInView || isInView;
+		}
+		if (!anyInView) continue;	// :38
+
+		const uint32_t volumeIn = volumeDescs[volumeId];
+		uint32_t raySampleCount = maxRaySamples;
+
+		// GenVisibilityMask (VolumeCull.hlsli:46-66)
+		const float3 localSpaceEyePt = mul43(eyePt, po.worldI);
+		uint32_t faceMask = 0;
+		for (uint32_t face = 0; face < 6; ++face)
+		{
+			const float viewComp = idx(localSpaceEyePt, (int)(face >> 1));
+			const bool vis = (face & 1) ? viewComp > -1.0f : viewComp < 1.0f;
+			if (vis) faceMask |= 1u << face;
+		}
+
+		// GetCubeEdgePairPerLane (:164-181)
+		float ex[12], ey[12];
+		for (uint32_t e = 0; e < 12; ++e)
+		{
+			const uint32_t a = edgeLanes[e][0], b = edgeLanes[e][1];
+			ex[e] = vx[b] - vx[a];
+			ey[e] = vy[b] - vy[a];
+		}
+
+		// EstimateCubeMaxEdgeLength (:248-262): WaveActiveMax over lanes 0-5 of max(|e0|, |e1|)
+		float maxEdge = 0.0f;
+		for (uint32_t lane = 0; lane < 6; ++lane)
+		{
+			const float l0 = sqrtf(ex[2 * lane] * ex[2 * lane] + ey[2 * lane] * ey[2 * lane]);
+			const float l1 = sqrtf(ex[2 * lane + 1] * ex[2 * lane + 1] + ey[2 * lane + 1] * ey[2 * lane + 1]);
+			const float ms = fmaxf(l0, l1);
+			maxEdge = lane == 0 ? ms : fmaxf(maxEdge, ms);
+		}
+
+		// EstimateCubeMapLOD (:267-294), upscale = 2, raySampleCountScale = 2
+		const uint32_t cubeMapSize = volumeIn >> 18;
+		const uint32_t numMips = (volumeIn >> 14) & 0xf;
+		float s = maxEdge / 2.0f;
+		float raySampleAmt = 2.0f * s / kSqrt3;
+		const uint32_t raySampleCnt = f2u(ceilf(raySampleAmt));
+		raySampleCount = std::min(raySampleCnt, raySampleCount);
+		raySampleAmt = fminf(raySampleAmt, (float)raySampleCount);
+		s = raySampleAmt / 2.0f * kSqrt3;
+		const uint32_t level = f2u(fmaxf(log2f((float)cubeMapSize / s), 0.0f));
+		const uint32_t mipLevel = std::min(level, numMips - 1);
+
+		// EstimateProjCoverage (:299-322): WaveActiveSum over lanes 0-5 (summed in lane order here)
+		float projCov = 0.0f;
+		for (uint32_t face = 0; face < 6; ++face)
+		{
+			float fx[4], fy[4];
+			for (uint32_t k = 0; k < 4; ++k) { fx[k] = ex[faceEdges[face][k]]; fy[k] = ey[faceEdges[face][k]]; }
+			float faceArea = 0.0f;
+			if (faceMask & (1u << face))
+				faceArea = 0.5f * fabsf(fx[0] * fy[1] - fy[0] * fx[1]) + 0.5f * fabsf(fx[2] * fy[3] - fy[2] * fx[3]);
+			projCov = face == 0 ? faceArea : projCov + faceArea;
+		}
+
+		// CSVolumeCull.hlsl:62-77
+		const uint32_t edgeLength = cubeMapSize >> mipLevel;
+		const float visibleFaceCount = (float)__builtin_popcount(faceMask);
+		const float cubeMapPix = (float)(edgeLength * edgeLength) * visibleFaceCount;
+		const bool useCubeMap = cubeMapPix <= projCov;
+		const uint32_t maskBits = useCubeMap ? (faceMask | kCubeMapRayMarchBit) : faceMask;
+		const uint32_t volTexId = volumeIn & 0x3fff;
+
+		if (useCubeMap) cubeMapVolumes[nCube++] = volumeId;
+		volumeInfo[4 * volumeId + 0] = (uint16_t)mipLevel;
+		volumeInfo[4 * volumeId + 1] = (uint16_t)raySampleCount;
+		volumeInfo[4 * volumeId + 2] = (uint16_t)maskBits;
+		volumeInfo[4 * volumeId + 3] = (uint16_t)volTexId;
+		visibleVolumes[nVis++] = volumeId;
+	}
+	*visibleCount = nVis;
+	*cubeMapCount = nCube;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a2: CSRayMarchL.hlsl:20-121
+// ---------------------------------------------------------------------------------------------
+uint32_t mvo_march_light(uint32_t V, uint32_t N, uint32_t L, uint32_t M,
+	const uint16_t* const* volumes, const uint32_t* volumeDescs,
+	const void* perObjectBytes, const void* cbBytes, const uint16_t* shadowMap,
+	const float* sh27, const uint32_t* visibleVolumes, uint32_t visibleCount,
+	uint32_t maxLightSamples, uint32_t* lightMaps, mvo_stats* stats)
+{
+	const PerObject* perObjects = (const PerObject*)perObjectBytes;
+	CBPerFrame cb;
+	memcpy(&cb, cbBytes, sizeof(cb));
+
+	// :29-33
+	uint32_t volumeId;
+	if (visibleCount) volumeId = visibleVolumes[cb.frameIdx % visibleCount];
+	else volumeId = cb.frameIdx % V;
+
+	const uint32_t hasLightProbe = sh27 ? 1u : 0u;
+	const float gStep = kMaxDist / (float)maxLightSamples;	// RayMarch.hlsli:18
+	const float gridSize = (float)L;
+	const uint32_t volTexId0 = volumeDescs[volumeId] & 0x3fff;
+	const PerObject& po0 = perObjects[volumeId];
+	uint32_t* out = lightMaps + (size_t)volumeId * L * L * L;
+	uint64_t totalSamples = 0;
+
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : totalSamples)
+	for (int64_t zz = 0; zz < (int64_t)L; ++zz)
+		for (uint32_t yy = 0; yy < L; ++yy)
+			for (uint32_t xx = 0; xx < L; ++xx)
+			{
+				uint64_t nS = 0;
+				float3 rayOrigin = f3(((float)xx + 0.5f) / gridSize * 2.0f - 1.0f,
+					((float)yy + 0.5f) / gridSize * 2.0f - 1.0f,
+					((float)zz + 0.5f) / gridSize * 2.0f - 1.0f);
+
+				const float3 uvw = LocalToTex3DSpace(rayOrigin);
+				const float density = sampleAlpha16F(volumes[volTexId0], N, uvw);
+				const bool hasDensity = density >= kZeroThreshold;	// :46
+
+				const float3 localPos = rayOrigin;
+				rayOrigin = mul43(rayOrigin, po0.world);	// light-map space to world space
+
+				// ShadowTest (RayMarch.hlsli:103-112): mul(float4(pos,1), g_shadowViewProj).xyz
+				float shadow;
+				{
+					const float4 p = { rayOrigin.x, rayOrigin.y, rayOrigin.z, 1.0f };
+					const float4 ls = mul44(p, cb.shadowViewProj);
+					float su = ls.x * 0.5f + 0.5f;
+					float sv = ls.y * 0.5f + 0.5f;
+					sv = 1.0f - sv;
+					shadow = sampleCmpD16(shadowMap, M, su, sv, ls.z - 0.0027f);
+				}
+
+				float ao = 1.0f;
+				float3 irradiance = f3(0.0f, 0.0f, 0.0f);
+
+				if (hasDensity)
+				{
+					float3 aoRayDir = f3(0.0f, 0.0f, 0.0f);
+					if (hasLightProbe)
+					{
+						aoRayDir = GetDensityGradient(volumes[volTexId0], N, uvw);
+						aoRayDir = f3(-aoRayDir.x, -aoRayDir.y, -aoRayDir.z);
+						const bool nz = fabsf(aoRayDir.x) > 0.0f || fabsf(aoRayDir.y) > 0.0f || fabsf(aoRayDir.z) > 0.0f;
+						// :69 falls back to rayOrigin.xyz, which at that point is already the WORLD-space position (:47)
+						aoRayDir = nz ? aoRayDir : rayOrigin;
+						aoRayDir = mul33(aoRayDir, po0.world);
+						aoRayDir = normalize3(aoRayDir);
+						irradiance = EvaluateSHIrradiance(sh27, normalize3(aoRayDir));	// GetIrradiance normalises again (RayMarch.hlsli:121)
+					}
+
+					for (uint32_t n = 0; n < V; ++n)	// :77-110
+					{
+						const uint32_t volTexId = volumeDescs[n] & 0x3fff;
+						const PerObject& po = perObjects[n];
+						float3 localRayOrigin = mul43(rayOrigin, po.worldI);
+
+						if (shadow >= kZeroThreshold)
+						{
+							const float3 localSpaceLightPt = mul33(f3(cb.lightPos[0], cb.lightPos[1], cb.lightPos[2]), po.worldI);
+							const float3 rayDir = normalize3(localSpaceLightPt);
+							if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
+							CastLightRay(shadow, volumes[volTexId], N, localRayOrigin, rayDir, gStep, maxLightSamples, nS);
+						}
+
+						if (hasLightProbe)
+						{
+							const float3 rayDir = normalize3(mul33(aoRayDir, po.worldI));
+							if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
+							float transm = 1.0f;
+							CastLightRay(transm, volumes[volTexId], N, localRayOrigin, rayDir, gStep, maxLightSamples, nS);
+							ao *= n == volumeId ? transm : sqrtf(sqrtf(saturatef(transm + 0.5f)));	// pow(x, 0.25)
+						}
+					}
+				}
+				(void)localPos;
+
+				const float3 lightColor = f3(cb.lightColor[0] * cb.lightColor[3], cb.lightColor[1] * cb.lightColor[3], cb.lightColor[2] * cb.lightColor[3]);
+				float3 ambient = f3(cb.ambient[0] * cb.ambient[3], cb.ambient[1] * cb.ambient[3], cb.ambient[2] * cb.ambient[3]);
+				if (hasLightProbe) ambient = f3(ao * irradiance.x, ao * irradiance.y, ao * irradiance.z);
+
+				const float3 result = f3(shadow * lightColor.x + ambient.x, shadow * lightColor.y + ambient.y, shadow * lightColor.z + ambient.z);
+				out[((size_t)zz * L + yy) * L + xx] = pack_r11g11b10f(result.x, result.y, result.z);
+				totalSamples += nS;
+			}
+
+	if (stats) stats->light_samples += totalSamples;
+	return volumeId;
+}
+
+// ---------------------------------------------------------------------------------------------
+// a3: CSRayMarch.hlsl:77-158 compiled as CSRayMarchV
+// ---------------------------------------------------------------------------------------------
+void mvo_march_view(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
+	const uint16_t* const* volumes, const uint32_t* lightMaps,
+	const float* depthMap, const void* perObjectBytes, const void* cbBytes,
+	const uint16_t* volumeInfo, const uint32_t* cubeMapVolumes, uint32_t cubeMapCount,
+	uint16_t* cubeMaps, float* cubeDepths, mvo_stats* stats)
+{
+	(void)V;
+	const PerObject* perObjects = (const PerObject*)perObjectBytes;
+	CBPerFrame cb;
+	memcpy(&cb, cbBytes, sizeof(cb));
+	const float3 eyePt = f3(cb.eyePos[0], cb.eyePos[1], cb.eyePos[2]);
+	const uint64_t chain = chainTexels(N);
+	uint64_t nSamples = 0, nLit = 0, nRays = 0;
+
+	for (uint32_t g = 0; g < cubeMapCount; ++g)
+	{
+		const uint32_t volumeId = cubeMapVolumes[g];	// :80
+		const uint32_t mipLevel = volumeInfo[4 * volumeId + 0];
+		const uint32_t smpCount = volumeInfo[4 * volumeId + 1];
+		const uint32_t maskBits = volumeInfo[4 * volumeId + 2];
+		const uint32_t volTexId = volumeInfo[4 * volumeId + 3];
+		const PerObject& po = perObjects[volumeId];
+		const uint32_t dims = N >> mipLevel;
+		uint16_t* cubeMap = cubeMaps + 4 * ((size_t)volumeId * chain + mipOffset(N, mipLevel));
+		float* cubeDepth = cubeDepths + ((size_t)volumeId * chain + mipOffset(N, mipLevel));
+		const uint16_t* vol = volumes[volTexId];
+		const uint32_t* lightMap = lightMaps + (size_t)volumeId * L * L * L;
+
+		for (uint32_t faceId = 0; faceId < 6; ++faceId)
+		{
+			if ((maskBits & (1u << faceId)) == 0) continue;	// :85
+
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : nSamples, nLit, nRays)
+			for (int64_t ty = 0; ty < (int64_t)dims; ++ty)
+				for (uint32_t tx = 0; tx < dims; ++tx)
+				{
+					float3 rayOrigin = mul43(eyePt, po.worldI);	// :89
+					const float3 target = GetLocalPos((float)tx, (float)ty, faceId, (float)dims);
+					const float3 rayDir = normalize3(target - rayOrigin);
+					if (!ComputeRayOrigin(rayOrigin, rayDir)) continue;	// :96
+
+					float tMax = ComputeTargetHit(rayOrigin, target, rayDir);
+					const size_t texel = ((size_t)faceId * dims + (size_t)ty) * dims + tx;
+
+					// GetClipPos (:59-71)
+					float3 clip;
+					{
+						float4 hPos = { fmaf(0.01f, rayDir.x, rayOrigin.x), fmaf(0.01f, rayDir.y, rayOrigin.y), fmaf(0.01f, rayDir.z, rayOrigin.z), 1.0f };
+						hPos = mul44(hPos, po.wvp);
+						const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
+						float u = cx * 0.5f + 0.5f;
+						float v = cy * 0.5f + 0.5f;
+						v = 1.0f - v;
+						const float z = samplePointR32F(depthMap, W, H, u, v);
+						clip = f3(cx, cy, z);
+					}
+					cubeDepth[texel] = clip.z;	// :105
+					tMax = fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
+
+					uint64_t s = 0, l = 0;
+					const float4 scatter = marchLoop(vol, N, lightMap, L, rayOrigin, rayDir, tMax, smpCount, s, l);
+					nSamples += s; nLit += l; ++nRays;
+
+					uint16_t* o = cubeMap + 4 * texel;
+					o[0] = f2h(scatter.x); o[1] = f2h(scatter.y); o[2] = f2h(scatter.z); o[3] = f2h(scatter.w);
+				}
+		}
+	}
+
+	if (stats)
+	{
+		stats->view_samples += nSamples;
+		stats->lit_samples += nLit;
+		stats->rays += nRays;
+	}
+}
+
+} // extern "C"

@@ -1,0 +1,156 @@
+"""ctypes wrapper of the CPU oracle (oracle/libmv_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
+the product package.  PARITY UNPINNED: see oracle/mv_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmv_oracle.so")
+NUM_CUBE_MIP = 5
+
+
+class mvo_stats(C.Structure):
+    _fields_ = [("view_samples", C.c_uint64), ("lit_samples", C.c_uint64), ("rays", C.c_uint64), ("light_samples", C.c_uint64)]
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("mv_oracle.cpp", "mv_oracle.h", "Makefile")]
+    if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libmv_oracle.so"], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+_P, _U32, _F = C.c_void_p, C.c_uint32, C.c_float
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    lib = C.CDLL(LIB_PATH)
+    sig = {
+        "mvo_f32_to_f16": (C.c_uint16, [_F]), "mvo_f16_to_f32": (_F, [C.c_uint16]),
+        "mvo_pack_r11g11b10f": (_U32, [_F, _F, _F]), "mvo_unpack_r11g11b10f": (None, [_U32, _P]),
+        "mvo_cube_chain_texels": (C.c_uint64, [_U32]), "mvo_cube_mip_offset": (C.c_uint64, [_U32, _U32]),
+        "mvo_sample_rgba16f": (None, [_P, _U32, _P, _P, _P]), "mvo_sample_r11g11b10f": (None, [_P, _U32, _P, _P]),
+        "mvo_sample_point_r32f": (_F, [_P, _U32, _U32, _F, _F]), "mvo_sample_cmp_d16": (_F, [_P, _U32, _F, _F, _F]),
+        "mvo_compute_ray_origin": (C.c_int, [_P, _P]), "mvo_compute_target_hit": (_F, [_P, _P, _P]),
+        "mvo_get_step": (_F, [_F, _F, _F, _F]), "mvo_get_local_pos": (None, [_F, _F, _U32, _U32, _P]),
+        "mvo_cast_light_ray": (None, [_P, _P, _U32, _P, _P, _F, _U32, _P]),
+        "mvo_eval_sh_irradiance": (None, [_P, _P, _P]),
+        "mvo_init_grid_data": (None, [_U32, _P]), "mvo_r32f_to_rgba16f": (None, [_P, _U32, _U32, _U32, _U32, _P]),
+        "mvo_cull": (None, [_U32, _P, _P, _P, _U32, _P, _P, _P, _P, _P]),
+        "mvo_march_light": (_U32, [_U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _U32, _P, _P]),
+        "mvo_march_view": (None, [_U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P]),
+        "mvo_num_threads": (C.c_int, []), "mvo_set_num_threads": (None, [C.c_int]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if hasattr(lib, "mvo_composite"):
+        lib.mvo_composite.restype = None
+        lib.mvo_composite.argtypes = [_U32, _U32, _U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _vol_ptrs(volumes):
+    vols = [np.ascontiguousarray(v).view(np.uint16) for v in volumes]
+    arr = (C.c_void_p * len(vols))(*[v.ctypes.data for v in vols])
+    return vols, arr
+
+
+def cube_chain_texels(N):
+    return int(load().mvo_cube_chain_texels(N))
+
+
+def cube_mip_offset(N, mip):
+    return int(load().mvo_cube_mip_offset(N, mip))
+
+
+def f16_to_f32(a):
+    """uint16 bit patterns -> float32 through the oracle's own decoder."""
+    lib = load()
+    a = np.asarray(a, np.uint16)
+    return np.array([lib.mvo_f16_to_f32(int(x)) for x in a.ravel()], np.float32).reshape(a.shape)
+
+
+def init_grid_data(N):
+    out = np.empty((N, N, N, 4), np.uint16)
+    load().mvo_init_grid_data(N, _ptr(out))
+    return out
+
+
+def r32f_to_rgba16f(src, N):
+    src = np.ascontiguousarray(src, np.float32)
+    d, h, w = src.shape
+    out = np.empty((N, N, N, 4), np.uint16)
+    load().mvo_r32f_to_rgba16f(_ptr(src), w, h, d, N, _ptr(out))
+    return out
+
+
+def cull(V, perObject, descs, cbPerFrame, maxRaySamples, volumeInfo=None):
+    """Returns (volumeInfo[V,4] u16, visible list, cube-map list). volumeInfo rows of culled volumes keep their input."""
+    info = np.zeros((V, 4), np.uint16) if volumeInfo is None else np.ascontiguousarray(volumeInfo, np.uint16).copy()
+    vis = np.zeros(V, np.uint32)
+    cube = np.zeros(V, np.uint32)
+    nv, nc = C.c_uint32(), C.c_uint32()
+    po = np.ascontiguousarray(perObject).view(np.uint8)
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8)
+    d = np.ascontiguousarray(descs, np.uint32)
+    load().mvo_cull(V, _ptr(po), _ptr(d), _ptr(cb), maxRaySamples, _ptr(info), _ptr(vis), C.byref(nv), _ptr(cube), C.byref(nc))
+    return info, vis[:nv.value].copy(), cube[:nc.value].copy()
+
+
+def march_light(V, N, L, M, volumes, descs, perObject, cbPerFrame, shadowMap, sh27, visible, maxLightSamples, lightMaps=None):
+    """Returns (volumeId, lightMaps[V, L,L,L] u32, light sample count)."""
+    vols, arr = _vol_ptrs(volumes)
+    lm = np.zeros((V, L, L, L), np.uint32) if lightMaps is None else np.ascontiguousarray(lightMaps, np.uint32).copy()
+    po = np.ascontiguousarray(perObject).view(np.uint8)
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8)
+    d = np.ascontiguousarray(descs, np.uint32)
+    sm = np.ascontiguousarray(shadowMap, np.uint16)
+    sh = None if sh27 is None else np.ascontiguousarray(sh27, np.float32)
+    vis = np.ascontiguousarray(visible, np.uint32)
+    st = mvo_stats()
+    vid = load().mvo_march_light(V, N, L, M, arr, _ptr(d), _ptr(po), _ptr(cb), _ptr(sm), _ptr(sh), _ptr(vis), len(vis),
+                                 maxLightSamples, _ptr(lm), C.byref(st))
+    return int(vid), lm, int(st.light_samples)
+
+
+def march_view(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame, volumeInfo, cubeMapVolumes,
+               cubeMaps=None, cubeDepths=None):
+    """Returns (cubeMaps[V, chain, 4] u16, cubeDepths[V, chain] f32, stats dict)."""
+    vols, arr = _vol_ptrs(volumes)
+    chain = cube_chain_texels(N)
+    cm = np.zeros((V, chain, 4), np.uint16) if cubeMaps is None else np.ascontiguousarray(cubeMaps, np.uint16).copy()
+    cd = np.zeros((V, chain), np.float32) if cubeDepths is None else np.ascontiguousarray(cubeDepths, np.float32).copy()
+    lm = np.ascontiguousarray(lightMaps, np.uint32)
+    dm = np.ascontiguousarray(depthMap, np.float32)
+    po = np.ascontiguousarray(perObject).view(np.uint8)
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8)
+    vi = np.ascontiguousarray(volumeInfo, np.uint16)
+    cl = np.ascontiguousarray(cubeMapVolumes, np.uint32)
+    st = mvo_stats()
+    load().mvo_march_view(V, N, L, W, H, arr, _ptr(lm), _ptr(dm), _ptr(po), _ptr(cb), _ptr(vi), _ptr(cl), len(cl),
+                          _ptr(cm), _ptr(cd), C.byref(st))
+    return cm, cd, dict(view_samples=int(st.view_samples), lit_samples=int(st.lit_samples), rays=int(st.rays))
+
+
+def cube_face_view(chain_array, N, mip):
+    """Slice mip `mip` out of a per-volume chain array: [chain, ...] -> [6, d, d, ...]."""
+    d = N >> mip
+    off = cube_mip_offset(N, mip)
+    a = chain_array[off:off + 6 * d * d]
+    return a.reshape((6, d, d) + a.shape[1:])

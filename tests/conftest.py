@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    # -m gpu on a box without a GPU must fail loudly, not skip: the product has no CPU fallback.
+    pass
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import mv_oracle
+    mv_oracle.load()
+    return mv_oracle
+
+
+@pytest.fixture(scope="session")
+def mvlib():
+    import multivolumes_amd
+    return multivolumes_amd.load()
+
+
+def half_to_float(a):
+    return np.asarray(a, np.uint16).view(np.float16).astype(np.float32)
