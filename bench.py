@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json: volume Msamples/s (+ frames/s) of the cube-map-space ray-march path
+at 1024^2 viewport, 16 x 256^3 volumes, 128 steps/ray + mesh-depth occlusion (config C3), on N MI355X GPUs.
+
+One "step" = one frame of the hot path exactly as MultiRayCaster::Render records it (MultiRayCaster.cpp:355-385):
+UpdateFrame upload -> cull -> marchL (one volume, round-robin) -> marchV [-> composite].  Inputs (volumes, depth,
+shadow map) are resident in HBM before the timed region.  With --gpus N > 1 the 16 volumes are sharded v % N across
+ranks (strong scaling, BASELINE config C4) and the selected-mip cube faces are all-gathered over RCCL every frame.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (marchViewKernel) with the algorithmic bytes of
+SURVEY.md 8(d): 64 B/view sample + 32 B/lit sample + 16 B/ray, divided by its HIP-event launch time.
+`cpu_baseline` is the CPU oracle (the reference has no Linux CPU path) timed on the same frame's marchV.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=30)
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--config", default="C3", help="C1/C2/C3/C5/T1/T2 (default C3 = the config the metric is quoted on)")
+    p.add_argument("--stress", action="store_true", help="C3-stress: force mip 0, all 6 faces (SURVEY 8d)")
+    p.add_argument("--composite", action="store_true", help="include the OIT composite in the step")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the ray-march path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+
+    from multivolumes_amd import MultiRayCaster, _lib, scene
+    from multivolumes_amd import raycaster as rc
+
+    cfg = dict(scene.CONFIGS[args.config])
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    M = 1024
+    flags = _lib.MV_FLAG_FORCE_MIP0_ALL_FACES if args.stress else 0
+    stream = torch.cuda.current_stream().cuda_stream
+    caster = MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=M, device=local_rank,
+                            stream=stream, flags=flags, shard=(rank, world))
+
+    # ---- synthetic inputs, resident in HBM before the timed region ----
+    t0 = time.time()
+    vols_host = {}
+    for k in range(V):
+        v = rc.synth_volume(N, k)
+        caster.LoadVolumeData(k, v)
+        if rank == 0 and not args.no_cpu_baseline:
+            vols_host[k] = v
+    fr = scene.setup_raycaster(caster, cfg)
+    t_setup = time.time() - t0
+
+    def frame(with_exchange=True):
+        caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        caster.Render(composite=False)
+        if world > 1 and with_exchange:
+            d, slot_bytes, shard_bytes = caster.ExchangeLayout()
+            send = torch.empty(shard_bytes, dtype=torch.uint8, device="cuda")
+            recv = torch.empty(shard_bytes * world, dtype=torch.uint8, device="cuda")
+            caster.ExchangePack(send.data_ptr())
+            dist.all_gather_into_tensor(recv, send)
+            caster.ExchangeUnpack(recv.data_ptr())
+        if args.composite:
+            H = cfg["H"]
+            r0, r1 = (H * rank) // world, (H * (rank + 1)) // world
+            caster.composite(r0, r1)
+
+    # relight every visible volume once so the light maps are real, then warm up
+    for _ in range(V):
+        frame(with_exchange=False)
+    for _ in range(args.warmup):
+        frame()
+    caster.synchronize()
+    caster.ResetStats()
+    caster.SetProfiling(True)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frame()
+    barrier()
+    dt = time.perf_counter() - t0
+    caster.SetProfiling(False)
+    st = caster.GetStats()
+
+    # max time over ranks, sum of samples over ranks
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        tot_view, tot_lit, tot_rays, tot_light = [int(x) for x in cnt.tolist()]
+    else:
+        tot_view, tot_lit, tot_rays, tot_light = st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"]
+
+    if rank == 0:
+        K = args.steps
+        info = caster.ReadBackVolumeInfo()
+        vis, cube = caster.ReadBackVisibleLists()
+        ms_v = st["ms_march_view"] / max(1, st["n_march_view"])
+        ms_l = st["ms_march_light"] / max(1, st["n_march_light"])
+        ms_c = st["ms_cull"] / max(1, st["n_cull"])
+        # rank-0 marchV launch: algorithmic bytes per launch / average launch duration
+        alg_bytes = (64 * st["view_samples"] + 32 * st["lit_samples"] + 16 * st["rays"]) / max(1, st["n_march_view"])
+        achieved = alg_bytes / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(f"{args.config}{'-stress' if args.stress else ''}", {}).get("marchViewKernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "volume_samples_per_sec", "value": tot_view / dt / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
+            "frames_per_s": K / dt, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.config}{'-stress' if args.stress else ''}: {V}x{N}^3 RGBA16F volumes, {cfg['W']}x{cfg['H']} viewport, "
+                            f"{cfg['maxRay']} steps/ray, light grid {L}^3 x {cfg['maxLight']} light steps"
+                            + (", mesh depth occlusion (analytic sphere)" if cfg["mesh"] else ""),
+                "visible_volumes": int(len(vis)), "cube_map_volumes": int(len(cube)),
+                "selected_mips": sorted(set(int(info[v, 0]) for v in vis)),
+                "samples_per_ray_cap": [int(info[v, 1]) for v in vis][:4],
+                "view_samples_per_frame": tot_view // K, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
+                "light_samples_per_frame": tot_light // K,
+                "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
+                "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+composite" if args.composite else ""),
+            },
+            "kernel_ms": {"cull": ms_c, "march_light": ms_l, "march_view": ms_v},
+            "light_msamples_per_s": tot_light / dt / 1e6,
+            "roofline": {"bound": "hbm", "kernel": "marchViewKernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": ms_v},
+            "setup_s": t_setup,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, cfg, caster, fr, info, cube, vols_host)
+        print(json.dumps(out))
+    caster.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
+    """Time the CPU oracle's marchV on (a bounded part of) the same frame, and check the GPU against it."""
+    from oracle import mv_oracle as o
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    # rank 0 owns cube[i] with i % world == 0 only when sharded; pick volumes whose cube maps this rank marched
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    mine = [int(v) for v in cube if int(v) % world == 0]
+    n = args.cpu_volumes or min(len(mine), 4)
+    sel = mine[:n]
+    if not sel:
+        return None
+    lms = np.zeros((V, L, L, L), np.uint32)
+    for v in sel:
+        lms[v] = caster.ReadBackLightMap(v)
+    vols = [vols_host.get(k, vols_host[sel[0]]) for k in range(V)]
+    t0 = time.perf_counter()
+    cm, cd, st = o.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel)
+    dt = time.perf_counter() - t0
+    worst = 0.0
+    for v in sel:
+        mip = int(info[v, 0])
+        exp = o.cube_face_view(cm[v], N, mip).view(np.float16).astype(np.float32)
+        got = caster.ReadBackCubeMap(v, mip).view(np.float16).astype(np.float32)
+        worst = max(worst, float(np.max(np.abs(exp - got))))
+    return {"value": st["view_samples"] / dt / 1e6, "unit": "Msamples/s", "cores": o.load().mvo_num_threads(), "kind": "port",
+            "sample": f"marchV of {len(sel)} of the {len(cube)} cube-map volumes of the same frame ({st['view_samples']} samples, {dt:.2f} s)",
+            "gpu_vs_oracle_max_abs_err": worst}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,296 @@
+"""Parity of the gfx950 kernels (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): cull outputs bit-exact; marched buffers within 1e-3 (fp16 storage) of the oracle,
+with the outlier count reported.  Kernel and oracle share the numeric contract (fp32, explicit fma only in
+lerp / ray-point evaluation, -ffp-contract=off), so in practice almost every texel matches bit for bit.
+"""
+import numpy as np
+import pytest
+
+from multivolumes_amd import MultiRayCaster, scene
+from multivolumes_amd import raycaster as rc
+from tests.conftest import half_to_float
+from tests.helpers import default_descs, oracle_pipeline
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3  # fp16 tolerance of the north star
+
+
+def make_caster(cfg, M, S=None, flags=0, shard=(0, 1)):
+    return MultiRayCaster(cfg["N"], cfg["L"], cfg["V"], S or cfg["V"], (cfg["W"], cfg["H"]), shadowMapSize=M, flags=flags, shard=shard)
+
+
+def run_gpu(caster, cfg, volumes, frames=None, use_sh=False, eye=None):
+    fr = scene.setup_raycaster(caster, cfg, volumes, use_sh=use_sh, eye=eye)
+    frames = cfg["V"] if frames is None else frames
+    for f in range(frames):
+        caster.m_frameIdx = f
+        caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        caster.cullVolumes()
+        caster.rayMarchL()
+    caster.rayMarchV()
+    caster.synchronize()
+    return fr
+
+
+def compare_cube(o, caster, ref, cfg, tol=TOL):
+    N = cfg["N"]
+    worst = 0.0
+    mism = 0
+    total = 0
+    for v in ref["cube"]:
+        mip = int(ref["info"][v, 0])
+        mask = int(ref["info"][v, 2])
+        got = half_to_float(caster.ReadBackCubeMap(int(v), mip))
+        exp = half_to_float(o.cube_face_view(ref["cubeMaps"][v], N, mip))
+        gotd = caster.ReadBackCubeDepth(int(v), mip)
+        expd = o.cube_face_view(ref["cubeDepths"][v], N, mip)
+        for f in range(6):
+            if not (mask >> f) & 1:
+                # invisible faces are never written (creation state = 0)
+                assert not got[f].any() and not gotd[f].any()
+                continue
+            diff = np.abs(got[f] - exp[f])
+            worst = max(worst, float(diff.max()))
+            mism += int((got[f] != exp[f]).sum())
+            total += diff.size
+            assert np.array_equal(gotd[f], expd[f]), f"cube depth differs (volume {v}, face {f})"
+    assert worst <= tol, f"max |gpu - oracle| = {worst}"
+    return worst, mism, total
+
+
+def compare_light(o, caster, ref, cfg, volumes_to_check, tol=TOL):
+    lib = o.load()
+    worst = 0.0
+    for v in volumes_to_check:
+        got = caster.ReadBackLightMap(int(v))
+        exp = ref["lightMaps"][v]
+        if np.array_equal(got, exp):
+            continue
+        idx = np.nonzero(got != exp)
+        g = np.zeros(3, np.float32)
+        e = np.zeros(3, np.float32)
+        for a, b in zip(got[idx][:2000], exp[idx][:2000]):
+            lib.mvo_unpack_r11g11b10f(int(a), rc._ptr(g))
+            lib.mvo_unpack_r11g11b10f(int(b), rc._ptr(e))
+            rel = np.max(np.abs(g - e) / np.maximum(np.abs(e), 1.0))
+            worst = max(worst, float(rel))
+        # 6-bit mantissas: one unit in the last place is 1/64 relative
+        assert worst <= 1.0 / 32, f"light map differs by more than one 11-bit ulp: {worst}"
+        assert len(idx[0]) <= 1e-3 * got.size, f"{len(idx[0])} light-map voxels differ"
+    return worst
+
+
+@pytest.mark.parametrize("name", ["C1", "T1"])
+def test_pipeline_parity(oracle, name):
+    cfg = scene.CONFIGS[name]
+    M = 256
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    ref = oracle_pipeline(oracle, cfg, vols, M)
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols)
+        info = c.ReadBackVolumeInfo()
+        vis, cube = c.ReadBackVisibleLists()
+        assert np.array_equal(info, ref["info"]), "VolumeInfo must be bit-exact"
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube, ref["cube"])
+        compare_light(oracle, c, ref, cfg, ref["vis"])
+        worst, mism, total = compare_cube(oracle, c, ref, cfg)
+        st = c.GetStats()
+        # sample counters: identical control flow => identical counts (allow the rare threshold flip)
+        assert abs(st["rays"] - ref["stats"]["rays"]) == 0
+        assert abs(st["view_samples"] - ref["stats"]["view_samples"]) <= 1e-4 * ref["stats"]["view_samples"] + 2
+        assert abs(st["lit_samples"] - ref["stats"]["lit_samples"]) <= 1e-4 * ref["stats"]["lit_samples"] + 2
+        assert abs(st["light_samples"] - ref["stats"]["light_samples"]) <= 1e-4 * ref["stats"]["light_samples"] + 2
+        print(f"{name}: max abs err {worst:.3g}, {mism}/{total} halfs differ")
+
+
+def test_pipeline_parity_16_volumes_with_sh(oracle):
+    """16 volumes (4 culled by the default camera), mesh depth + shadow, SH/AO path on."""
+    cfg = scene.CONFIGS["T2"]
+    M = 512
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    ref = oracle_pipeline(oracle, cfg, vols, M, sh=scene.DEFAULT_SH)
+    assert 0 < len(ref["vis"]) < cfg["V"]
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols, use_sh=True)
+        assert np.array_equal(c.ReadBackVolumeInfo(), ref["info"])
+        vis, cube = c.ReadBackVisibleLists()
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube, ref["cube"])
+        # frames 0..V-1 relight visible[f % count]: every visible volume got a light map
+        compare_light(oracle, c, ref, cfg, ref["vis"])
+        compare_cube(oracle, c, ref, cfg)
+
+
+def test_cull_bit_exact_many_cameras(oracle):
+    """VolumeInfo / lists bit-exact over a sweep of eye points, including eyes inside the grid and odd viewports."""
+    cfg = dict(scene.CONFIGS["T2"], W=640, H=360)
+    V, N = cfg["V"], cfg["N"]
+    M = 64
+    rng = np.random.default_rng(3)
+    eyes = [(4, 16, -80), (0, 0, -200), (30, 5, 10), (0, 60, 0.1), (-70, 20, 40), (5, 5, 5)] + [tuple(rng.uniform(-120, 120, 3)) for _ in range(24)]
+    from tests.helpers import host_frame
+    with make_caster(cfg, M, S=1) as c:
+        c.SetMaxSamples(cfg["maxRay"], cfg["maxLight"])
+        c.SetVolumesWorld(scene.VOLUME_SIZE, (0, 0, 0))
+        for eye in eyes:
+            _, vp, svp, cb, po = host_frame(cfg, 0, eye)
+            sentinel = np.zeros((V, 4), np.uint16)
+            # start both from the same VolumeInfo state: culled volumes keep stale rows (reference behaviour)
+            prev = c.ReadBackVolumeInfo()
+            info, vis, cube = oracle.cull(V, po, default_descs(V, 1, N), cb, cfg["maxRay"], prev)
+            c.UpdateFrameRaw(cb, po)
+            c.cullVolumes()
+            got = c.ReadBackVolumeInfo()
+            gvis, gcube = c.ReadBackVisibleLists()
+            assert np.array_equal(got[:, 2], info[:, 2]), f"MaskBits differ for eye {eye}"
+            assert np.array_equal(got, info), f"VolumeInfo differs for eye {eye}"
+            assert np.array_equal(gvis, vis) and np.array_equal(gcube, cube)
+            del sentinel
+
+
+def test_volume_producers(oracle):
+    N = 20  # not a multiple of the 4^3 brick: exercises the padded border bricks
+    cfg = dict(N=N, L=8, V=1, W=64, H=64)
+    with MultiRayCaster(N, 8, 1, 3, (64, 64), shadowMapSize=16) as c:
+        c.InitVolumeData(0)
+        assert np.array_equal(c.ReadBackVolume(0), oracle.init_grid_data(N)), "CSInitGridData must be bit-exact"
+        rng = np.random.default_rng(5)
+        src = rng.random((7, 9, 11), np.float32)
+        c.LoadVolumeDataR32F(1, src)
+        assert np.array_equal(c.ReadBackVolume(1), oracle.r32f_to_rgba16f(src, N)), "CSR32FToRGBA16F must be bit-exact"
+        raw = rng.integers(0, 0x7C00, (N, N, N, 4), dtype=np.uint16)
+        c.LoadVolumeData(2, raw)
+        assert np.array_equal(c.ReadBackVolume(2), raw), "upload -> brick -> readback round trip"
+    del cfg
+
+
+def test_edge_cases(oracle):
+    """Nothing visible, empty volume, single-texel faces (mip 4 of N=16), ragged sizes."""
+    from tests.helpers import host_frame
+    # camera looking away: nothing visible -> no work, stale buffers untouched, marchL falls back to frameIdx % V
+    cfg = dict(scene.CONFIGS["T1"])
+    M = 32
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    with make_caster(cfg, M) as c:
+        fr = scene.setup_raycaster(c, cfg, vols)
+        eye = np.array([0, 0, 300], np.float32)
+        view = rc.look_at_lh(eye, (0, 0, 600))
+        vp = rc.multiply(view, rc.perspective_fov_lh(scene.FOV_ANGLE_Y, 1.0, 1.0, 1000.0))
+        c.m_frameIdx = 5
+        c.UpdateFrame(vp, fr["shadowVP"], eye)
+        c.Render()
+        c.synchronize()
+        vis, cube = c.ReadBackVisibleLists()
+        assert len(vis) == 0 and len(cube) == 0
+        st = c.GetStats()
+        assert st["view_samples"] == 0 and st["rays"] == 0
+        for v in range(cfg["V"]):
+            assert not c.ReadBackCubeMap(v, 0).any()
+        # CSRayMarchL.hlsl:31: no visible volume -> volume frameIdx % V is relit
+        descs = default_descs(cfg["V"], cfg["V"], cfg["N"])
+        vid, lms, _ = oracle.march_light(cfg["V"], cfg["N"], cfg["L"], M, vols, descs, c.perObject, c.cbPerFrame, fr["shadow"], None, [], cfg["maxLight"])
+        assert vid == 5 % cfg["V"]
+        assert np.array_equal(c.ReadBackLightMap(vid), lms[vid])
+    # empty volume (alpha = 0): exact zeros, but rays are counted and cube depth is written
+    cfg = dict(scene.CONFIGS["C1"], N=16, L=8, maxRay=16, maxLight=8)
+    empty = np.zeros((16, 16, 16, 4), np.float16)
+    empty[..., :3] = 1.0
+    ref = oracle_pipeline(oracle, cfg, [empty.view(np.uint16)], M)
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, [empty.view(np.uint16)])
+        compare_cube(oracle, c, ref, cfg, tol=0.0)
+        st = c.GetStats()
+        assert st["lit_samples"] == 0 and st["rays"] == ref["stats"]["rays"] and st["view_samples"] == ref["stats"]["view_samples"]
+    # far camera: coarse mip, faces smaller than an 8x8 tile
+    cfg = dict(scene.CONFIGS["C1"], N=16, L=8, maxRay=16, maxLight=8)
+    vols = [rc.synth_volume(16, 1)]
+    eye = (40.0, 160.0, -800.0)
+    ref = oracle_pipeline(oracle, cfg, vols, M, eye=eye)
+    assert ref["info"][0, 0] >= 2
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols, eye=eye)
+        assert np.array_equal(c.ReadBackVolumeInfo(), ref["info"])
+        compare_cube(oracle, c, ref, cfg)
+    # ragged: N and L not multiples of the brick / block sizes
+    cfg = dict(scene.CONFIGS["C1"], N=22, L=10, maxRay=24, maxLight=12, W=300, H=200)
+    vols = [rc.synth_volume(22, 2)]
+    ref = oracle_pipeline(oracle, cfg, vols, M)
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols)
+        assert np.array_equal(c.ReadBackVolumeInfo(), ref["info"])
+        compare_light(oracle, c, ref, cfg, ref["vis"])
+        compare_cube(oracle, c, ref, cfg)
+
+
+def test_shared_volume_sources(oracle):
+    """VolumeDesc.VolTexId = i % numVolumeSrcs (MultiRayCaster.cpp:471-479): 4 volumes over 2 sources."""
+    cfg = scene.CONFIGS["T1"]
+    M = 64
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(2)]
+    ref = oracle_pipeline(oracle, cfg, vols, M)
+    assert list(ref["info"][:, 3]) == [0, 1, 0, 1]
+    with make_caster(cfg, M, S=2) as c:
+        run_gpu(c, cfg, vols)
+        assert np.array_equal(c.ReadBackVolumeInfo(), ref["info"])
+        compare_cube(oracle, c, ref, cfg)
+
+
+def test_error_behaviour():
+    """Creation failures return codes (the reference returns false, XUSG.h:12-15); stages need their inputs."""
+    from multivolumes_amd import MVError, _lib
+    with pytest.raises(MVError) as e:
+        MultiRayCaster(1, 8, 1, 1, (8, 8))
+    assert e.value.code == _lib.MV_ERR_INVALID_ARG
+    with MultiRayCaster(8, 8, 1, 1, (8, 8), shadowMapSize=8) as c:
+        with pytest.raises(MVError) as e:
+            c.cullVolumes()
+        assert e.value.code == _lib.MV_ERR_NOT_READY
+        with pytest.raises(MVError) as e:
+            c.InitVolumeData(3)
+        assert e.value.code == _lib.MV_ERR_RANGE
+        with pytest.raises(MVError) as e:
+            c.SetVolumeDescs([5 | (5 << 14) | (8 << 18)])
+        assert e.value.code == _lib.MV_ERR_RANGE
+
+
+@pytest.mark.parametrize("name", ["C2"])
+def test_full_size_properties(oracle, name):
+    """At BASELINE sizes the oracle is too slow for a full compare: size-independent properties instead.
+    idempotence (same frame twice => identical buffers), counters consistent with the cull, alpha in [0,1],
+    and an oracle spot check on one face row band."""
+    cfg = scene.CONFIGS[name]
+    M = 1024
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    with make_caster(cfg, M) as c:
+        fr = run_gpu(c, cfg, vols)
+        info = c.ReadBackVolumeInfo()
+        vis, cube = c.ReadBackVisibleLists()
+        st1 = c.GetStats()
+        first = {int(v): (c.ReadBackCubeMap(int(v), int(info[v, 0])), c.ReadBackCubeDepth(int(v), int(info[v, 0]))) for v in cube}
+        c.ResetStats()
+        c.rayMarchV()
+        c.synchronize()
+        st2 = c.GetStats()
+        expect_rays = 0
+        for v in cube:
+            cm, cd = first[int(v)]
+            assert np.array_equal(c.ReadBackCubeMap(int(v), int(info[v, 0])), cm), "marchV must be idempotent"
+            a = half_to_float(cm)[..., 3]
+            assert np.all((a >= 0) & (a <= 1.0))
+            assert np.all(np.isfinite(half_to_float(cm)))
+            d = cfg["N"] >> int(info[v, 0])
+            expect_rays += bin(int(info[v, 2]) & 0x3F).count("1") * d * d
+        # every texel of a visible face of a volume the eye is outside of hits the box
+        assert st2["rays"] == expect_rays
+        assert st2["view_samples"] == st1["view_samples"] and st2["lit_samples"] == st1["lit_samples"]
+        assert st2["view_samples"] <= expect_rays * cfg["maxRay"]
+        # oracle spot check: volume cube[0], all visible faces (64^2 texels each at C2) against the GPU's own light map
+        v = int(cube[0])
+        lms = np.zeros((cfg["V"], cfg["L"], cfg["L"], cfg["L"]), np.uint32)
+        lms[v] = c.ReadBackLightMap(v)
+        cm, cd, _ = oracle.march_view(cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"], vols, lms, fr["depth"], c.perObject, c.cbPerFrame, info, [v])
+        mip = int(info[v, 0])
+        exp = half_to_float(oracle.cube_face_view(cm[v], cfg["N"], mip))
+        got = half_to_float(first[v][0])
+        assert np.max(np.abs(exp - got)) <= TOL
