@@ -155,7 +155,7 @@ def main():
                 "visible_volumes": int(len(vis)), "cube_map_volumes": int(len(cube)),
                 "selected_mips": sorted(set(int(info[v, 0]) for v in vis)),
                 "samples_per_ray_cap": [int(info[v, 1]) for v in vis][:4],
-                "view_samples_per_frame": tot_view // K, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
+                "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+composite" if args.composite else ""),

@@ -150,7 +150,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 {
 	if (!cfg || !out || cfg->struct_size != sizeof(mv_config)) return MV_ERR_INVALID_ARG;
 	*out = nullptr;
-	if (cfg->grid_size < 2 || cfg->grid_size > 16383 || cfg->light_grid_size < 2 || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
+	if (cfg->grid_size < 2 || cfg->grid_size > 768 /* bricked volume must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
 		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
 		return MV_ERR_INVALID_ARG;
 	if (cfg->shard_count > 1 && cfg->shard_index >= cfg->shard_count) return MV_ERR_INVALID_ARG;
@@ -224,6 +224,12 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &st.cubeOffset, (size_t)st.V * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.stats, kNumStats * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	st.maxTiles = mv::marchViewMaxTiles(st.V, st.N, st.shardCount);
+	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
+	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
+	if ((rc = devAlloc(ctx, &st.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	st.cbPerFrame = ctx->dCb; st.perObject = ctx->dPerObject; st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
 
 	// pinned upload ring + readback scratch
@@ -556,6 +562,9 @@ int mv_clear_cube_maps(mv_ctx* ctx)
 int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 {
 	if (!ctx || !out) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
+	mv::launchReduceStats(ctx->stream, ctx->st);
+	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedStats, ctx->st.stats, kNumStats * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	foldEvents(ctx);
@@ -565,6 +574,7 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 	out->rays = ctx->pinnedStats[2];
 	out->light_samples = ctx->pinnedStats[3];
 	out->composite_samples = ctx->pinnedStats[4];
+	out->reserved[0] = ctx->pinnedStats[5];	// marchV lane slots (64 x longest ray per wavefront)
 	out->ms_cull = ctx->msStage[0]; out->ms_march_light = ctx->msStage[1]; out->ms_march_view = ctx->msStage[2]; out->ms_composite = ctx->msStage[3];
 	out->n_cull = ctx->nStage[0]; out->n_march_light = ctx->nStage[1]; out->n_march_view = ctx->nStage[2]; out->n_composite = ctx->nStage[3];
 	return MV_OK;
@@ -576,6 +586,9 @@ int mv_reset_stats(mv_ctx* ctx)
 	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	foldEvents(ctx);
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.lightStats, 0, (size_t)ctx->st.lightBlocks * sizeof(uint64_t), ctx->stream));
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.compositeStats, 0, (size_t)ctx->st.compositeSlots * sizeof(uint64_t), ctx->stream));
 	for (int i = 0; i < 4; ++i) { ctx->msStage[i] = 0.0; ctx->nStage[i] = 0; }
 	return MV_OK;
 }

@@ -49,15 +49,6 @@ __device__ __forceinline__ uint32_t f2u_sat(float x)	// D3D ftou
 	return (uint32_t)x;
 }
 
-__device__ __forceinline__ int floor_to_int(float x)	// saturating floor for texel addressing; NaN -> 0
-{
-	if (!(x == x)) return 0;
-	const float f = __builtin_floorf(x);
-	if (f <= -2147483648.0f) return INT32_MIN;
-	if (f >= 2147483520.0f) return INT32_MAX - 127;
-	return (int)f;
-}
-
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---- structured/constant buffer layouts (Sh/Common.hlsli:28-49; MultiRayCaster.cpp:23-41, 341-351) ----
@@ -169,7 +160,10 @@ __device__ __forceinline__ Taps linearTaps(float coord01, uint32_t size, int off
 	const float fl = __builtin_floorf(c);
 	Taps t;
 	t.f = c - fl;
-	const int i = floor_to_int(c) + off;	// |off| <= 1 and |i| <= 2^31 - 128: no overflow
+	// Clamp in float first (NaN -> -2) so the int conversion is always in range; after the integer clamp to
+	// [0, size-1] this equals a saturating floor-to-int for every finite coordinate (|off| <= 1).
+	const float flc = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), (float)size + 1.0f);
+	const int i = (int)flc + off;
 	t.i0 = clampi(i, 0, (int)size - 1);
 	t.i1 = clampi(i + 1, 0, (int)size - 1);
 	return t;
@@ -180,24 +174,49 @@ __device__ __forceinline__ Taps linearTaps(float coord01, uint32_t size, int off
 // x-fastest order.  A trilinear footprint (2x2x2 texels) then touches 1 brick 42 % of the time and at most 8,
 // instead of always 4 rows that are N*8 bytes (and N*N*8 bytes) apart in a linear layout.
 // Texel (x,y,z) -> element index (units of one RGBA16F texel):
-__device__ __forceinline__ size_t volTexelIndex(uint32_t x, uint32_t y, uint32_t z, uint32_t bricksPerAxis)
+__host__ __device__ __forceinline__ size_t volTexelIndex(uint32_t x, uint32_t y, uint32_t z, uint32_t bricksPerAxis)
 {
 	const uint32_t bx = x >> 2, by = y >> 2, bz = z >> 2;
 	const size_t brick = ((size_t)bz * bricksPerAxis + by) * bricksPerAxis + bx;
 	return brick * 64 + ((z & 3u) << 4) + ((y & 3u) << 2) + (x & 3u);
 }
 
+// Global-address-space views: loads through them are global_load (SGPR base + 32-bit VGPR byte offset), not flat_load.
+typedef const __attribute__((address_space(1))) uint8_t* GlobalBytes;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(1))) u32x2* GlobalUint2;
+typedef const __attribute__((address_space(1))) uint32_t* GlobalUint;
+typedef const __attribute__((address_space(1))) uint16_t* GlobalUshort;
+
 struct VolumeView
 {
-	const uint2* texels;	// RGBA16F texel = 8 bytes = uint2 {rg, ba}
+	GlobalBytes base;		// bricked RGBA16F texels (8 bytes each); the whole volume is < 4 GiB (mv_create enforces N <= 768)
 	uint32_t N;				// texels per axis
-	uint32_t bricks;		// ceil(N / 4)
+	uint32_t strideY;		// bytes between bricks along y = bricks * 512
+	uint32_t strideZ;		// bytes between bricks along z = bricks^2 * 512
 };
 
-__device__ __forceinline__ uint2 loadTexel(const VolumeView& v, int x, int y, int z)
+__device__ __forceinline__ VolumeView makeVolumeView(const uint2* texels, uint32_t N, uint32_t bricks)
 {
-	return v.texels[volTexelIndex((uint32_t)x, (uint32_t)y, (uint32_t)z, v.bricks)];
+	VolumeView v;
+	v.base = (GlobalBytes)texels;
+	v.N = N;
+	v.strideY = bricks * 512u;
+	v.strideZ = bricks * bricks * 512u;
+	return v;
 }
+
+// byte offsets contributed by one axis: brick part + in-brick part
+__device__ __forceinline__ uint32_t offX(int i) { return (((uint32_t)i >> 2) << 9) + (((uint32_t)i & 3u) << 3); }
+__device__ __forceinline__ uint32_t offY(int i, uint32_t strideY) { return ((uint32_t)i >> 2) * strideY + (((uint32_t)i & 3u) << 5); }
+__device__ __forceinline__ uint32_t offZ(int i, uint32_t strideZ) { return ((uint32_t)i >> 2) * strideZ + (((uint32_t)i & 3u) << 7); }
+
+__device__ __forceinline__ uint2 loadTexelAt(const VolumeView& v, uint32_t byteOff)
+{
+	const u32x2 t = *(GlobalUint2)(v.base + byteOff);	// global_load_dwordx2, SGPR base + VGPR offset
+	return make_uint2(t.x, t.y);
+}
+__device__ __forceinline__ float loadAlphaAt(const VolumeView& v, uint32_t byteOff) { return half_bits_to_float(*(GlobalUshort)(v.base + byteOff + 6u)); }
 
 __device__ __forceinline__ vec4 decodeTexel(uint2 t)
 {
@@ -209,21 +228,63 @@ __device__ __forceinline__ vec4 decodeTexel(uint2 t)
 	return c;
 }
 
+__device__ __forceinline__ float trilerp(float c000, float c100, float c010, float c110, float c001, float c101, float c011, float c111, float fx, float fy, float fz)
+{
+	return lerpf(lerpf(lerpf(c000, c100, fx), lerpf(c010, c110, fx), fy), lerpf(lerpf(c001, c101, fx), lerpf(c011, c111, fx), fy), fz);
+}
+
+// The eight raw texels of a trilinear footprint plus the filter weights; decode is split so that the march can test
+// alpha (Sh/CSRayMarch.hlsl:128) before paying for the colour channels.
+struct Footprint
+{
+	uint2 t000, t100, t010, t110, t001, t101, t011, t111;
+	float fx, fy, fz;
+};
+
+__device__ __forceinline__ Footprint fetchFootprint(const VolumeView& v, vec3 uvw)
+{
+	const Taps tx = linearTaps(uvw.x, v.N, 0), ty = linearTaps(uvw.y, v.N, 0), tz = linearTaps(uvw.z, v.N, 0);
+	const uint32_t x0 = offX(tx.i0), x1 = offX(tx.i1);
+	const uint32_t y0 = offY(ty.i0, v.strideY), y1 = offY(ty.i1, v.strideY);
+	const uint32_t z0 = offZ(tz.i0, v.strideZ), z1 = offZ(tz.i1, v.strideZ);
+	const uint32_t r00 = y0 + z0, r10 = y1 + z0, r01 = y0 + z1, r11 = y1 + z1;
+	Footprint f;
+	f.t000 = loadTexelAt(v, r00 + x0); f.t100 = loadTexelAt(v, r00 + x1);
+	f.t010 = loadTexelAt(v, r10 + x0); f.t110 = loadTexelAt(v, r10 + x1);
+	f.t001 = loadTexelAt(v, r01 + x0); f.t101 = loadTexelAt(v, r01 + x1);
+	f.t011 = loadTexelAt(v, r11 + x0); f.t111 = loadTexelAt(v, r11 + x1);
+	f.fx = tx.f; f.fy = ty.f; f.fz = tz.f;
+	return f;
+}
+
+__device__ __forceinline__ float footprintAlpha(const Footprint& f)
+{
+#define MV_W(t) half_bits_to_float((t).y >> 16)
+	return trilerp(MV_W(f.t000), MV_W(f.t100), MV_W(f.t010), MV_W(f.t110), MV_W(f.t001), MV_W(f.t101), MV_W(f.t011), MV_W(f.t111), f.fx, f.fy, f.fz);
+#undef MV_W
+}
+
+__device__ __forceinline__ vec3 footprintRGB(const Footprint& f)
+{
+	vec3 r;
+#define MV_R(t) half_bits_to_float((t).x & 0xffffu)
+#define MV_G(t) half_bits_to_float((t).x >> 16)
+#define MV_B(t) half_bits_to_float((t).y & 0xffffu)
+	r.x = trilerp(MV_R(f.t000), MV_R(f.t100), MV_R(f.t010), MV_R(f.t110), MV_R(f.t001), MV_R(f.t101), MV_R(f.t011), MV_R(f.t111), f.fx, f.fy, f.fz);
+	r.y = trilerp(MV_G(f.t000), MV_G(f.t100), MV_G(f.t010), MV_G(f.t110), MV_G(f.t001), MV_G(f.t101), MV_G(f.t011), MV_G(f.t111), f.fx, f.fy, f.fz);
+	r.z = trilerp(MV_B(f.t000), MV_B(f.t100), MV_B(f.t010), MV_B(f.t110), MV_B(f.t001), MV_B(f.t101), MV_B(f.t011), MV_B(f.t111), f.fx, f.fy, f.fz);
+#undef MV_R
+#undef MV_G
+#undef MV_B
+	return r;
+}
+
 // Texture3D<float4>.SampleLevel(LINEAR_CLAMP, uvw, 0) on RGBA16F -- Sh/RayMarch.hlsli:44-50
 __device__ __forceinline__ vec4 sampleRGBA16F(const VolumeView& v, vec3 uvw)
 {
-	const Taps tx = linearTaps(uvw.x, v.N, 0), ty = linearTaps(uvw.y, v.N, 0), tz = linearTaps(uvw.z, v.N, 0);
-	const uint2 t000 = loadTexel(v, tx.i0, ty.i0, tz.i0), t100 = loadTexel(v, tx.i1, ty.i0, tz.i0);
-	const uint2 t010 = loadTexel(v, tx.i0, ty.i1, tz.i0), t110 = loadTexel(v, tx.i1, ty.i1, tz.i0);
-	const uint2 t001 = loadTexel(v, tx.i0, ty.i0, tz.i1), t101 = loadTexel(v, tx.i1, ty.i0, tz.i1);
-	const uint2 t011 = loadTexel(v, tx.i0, ty.i1, tz.i1), t111 = loadTexel(v, tx.i1, ty.i1, tz.i1);
-	const vec4 c000 = decodeTexel(t000), c100 = decodeTexel(t100), c010 = decodeTexel(t010), c110 = decodeTexel(t110);
-	const vec4 c001 = decodeTexel(t001), c101 = decodeTexel(t101), c011 = decodeTexel(t011), c111 = decodeTexel(t111);
-	vec4 r;
-#define MV_TRI(ch) lerpf(lerpf(lerpf(c000.ch, c100.ch, tx.f), lerpf(c010.ch, c110.ch, tx.f), ty.f), \
-	lerpf(lerpf(c001.ch, c101.ch, tx.f), lerpf(c011.ch, c111.ch, tx.f), ty.f), tz.f)
-	r.x = MV_TRI(x); r.y = MV_TRI(y); r.z = MV_TRI(z); r.w = MV_TRI(w);
-#undef MV_TRI
+	const Footprint f = fetchFootprint(v, uvw);
+	const vec3 rgb = footprintRGB(f);
+	vec4 r; r.x = rgb.x; r.y = rgb.y; r.z = rgb.z; r.w = footprintAlpha(f);
 	return r;
 }
 
@@ -231,38 +292,61 @@ __device__ __forceinline__ vec4 sampleRGBA16F(const VolumeView& v, vec3 uvw)
 __device__ __forceinline__ float sampleAlpha16F(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
 {
 	const Taps tx = linearTaps(uvw.x, v.N, ox), ty = linearTaps(uvw.y, v.N, oy), tz = linearTaps(uvw.z, v.N, oz);
-	const uint16_t* h = reinterpret_cast<const uint16_t*>(v.texels);
-#define MV_A(i, j, k) half_bits_to_float(h[4 * volTexelIndex((uint32_t)(i), (uint32_t)(j), (uint32_t)(k), v.bricks) + 3])
-	const float c00 = lerpf(MV_A(tx.i0, ty.i0, tz.i0), MV_A(tx.i1, ty.i0, tz.i0), tx.f);
-	const float c10 = lerpf(MV_A(tx.i0, ty.i1, tz.i0), MV_A(tx.i1, ty.i1, tz.i0), tx.f);
-	const float c01 = lerpf(MV_A(tx.i0, ty.i0, tz.i1), MV_A(tx.i1, ty.i0, tz.i1), tx.f);
-	const float c11 = lerpf(MV_A(tx.i0, ty.i1, tz.i1), MV_A(tx.i1, ty.i1, tz.i1), tx.f);
-#undef MV_A
-	return lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+	const uint32_t x0 = offX(tx.i0), x1 = offX(tx.i1);
+	const uint32_t y0 = offY(ty.i0, v.strideY), y1 = offY(ty.i1, v.strideY);
+	const uint32_t z0 = offZ(tz.i0, v.strideZ), z1 = offZ(tz.i1, v.strideZ);
+	const uint32_t r00 = y0 + z0, r10 = y1 + z0, r01 = y0 + z1, r11 = y1 + z1;
+	return trilerp(loadAlphaAt(v, r00 + x0), loadAlphaAt(v, r00 + x1), loadAlphaAt(v, r10 + x0), loadAlphaAt(v, r10 + x1),
+		loadAlphaAt(v, r01 + x0), loadAlphaAt(v, r01 + x1), loadAlphaAt(v, r11 + x0), loadAlphaAt(v, r11 + x1), tx.f, ty.f, tz.f);
 }
 
 // Texture3D<float3>.SampleLevel(LINEAR_CLAMP, uvw, 0) on R11G11B10F (light map, linear x-fastest) -- Sh/RayMarch.hlsli:235-240
-__device__ __forceinline__ vec3 sampleR11G11B10F(const uint32_t* tex, uint32_t L, vec3 uvw)
+// Split into fetch (8 dword loads in flight) and resolve (decode + filter) so the march can overlap it with other loads.
+struct LightFootprint
+{
+	uint32_t p000, p100, p010, p110, p001, p101, p011, p111;
+	float fx, fy, fz;
+};
+
+__device__ __forceinline__ LightFootprint fetchLightFootprint(const uint32_t* tex, uint32_t L, vec3 uvw)
 {
 	const Taps tx = linearTaps(uvw.x, L, 0), ty = linearTaps(uvw.y, L, 0), tz = linearTaps(uvw.z, L, 0);
-	const uint32_t sy = L, sz = L * L;
-#define MV_L(i, j, k) unpack_r11g11b10f(tex[(uint32_t)(k) * sz + (uint32_t)(j) * sy + (uint32_t)(i)])
-	const vec3 c000 = MV_L(tx.i0, ty.i0, tz.i0), c100 = MV_L(tx.i1, ty.i0, tz.i0), c010 = MV_L(tx.i0, ty.i1, tz.i0), c110 = MV_L(tx.i1, ty.i1, tz.i0);
-	const vec3 c001 = MV_L(tx.i0, ty.i0, tz.i1), c101 = MV_L(tx.i1, ty.i0, tz.i1), c011 = MV_L(tx.i0, ty.i1, tz.i1), c111 = MV_L(tx.i1, ty.i1, tz.i1);
+	const GlobalBytes base = (GlobalBytes)tex;
+	const uint32_t x0 = (uint32_t)tx.i0 << 2, x1 = (uint32_t)tx.i1 << 2;
+	const uint32_t y0 = (uint32_t)ty.i0 * (L << 2), y1 = (uint32_t)ty.i1 * (L << 2);
+	const uint32_t z0 = (uint32_t)tz.i0 * (L * L << 2), z1 = (uint32_t)tz.i1 * (L * L << 2);
+	const uint32_t r00 = y0 + z0, r10 = y1 + z0, r01 = y0 + z1, r11 = y1 + z1;
+	LightFootprint f;
+#define MV_L(o) (*(GlobalUint)(base + (o)))
+	f.p000 = MV_L(r00 + x0); f.p100 = MV_L(r00 + x1); f.p010 = MV_L(r10 + x0); f.p110 = MV_L(r10 + x1);
+	f.p001 = MV_L(r01 + x0); f.p101 = MV_L(r01 + x1); f.p011 = MV_L(r11 + x0); f.p111 = MV_L(r11 + x1);
 #undef MV_L
+	f.fx = tx.f; f.fy = ty.f; f.fz = tz.f;
+	return f;
+}
+
+__device__ __forceinline__ vec3 resolveLight(const LightFootprint& f)
+{
+	const vec3 c000 = unpack_r11g11b10f(f.p000), c100 = unpack_r11g11b10f(f.p100), c010 = unpack_r11g11b10f(f.p010), c110 = unpack_r11g11b10f(f.p110);
+	const vec3 c001 = unpack_r11g11b10f(f.p001), c101 = unpack_r11g11b10f(f.p101), c011 = unpack_r11g11b10f(f.p011), c111 = unpack_r11g11b10f(f.p111);
 	vec3 r;
-#define MV_TRI(ch) lerpf(lerpf(lerpf(c000.ch, c100.ch, tx.f), lerpf(c010.ch, c110.ch, tx.f), ty.f), \
-	lerpf(lerpf(c001.ch, c101.ch, tx.f), lerpf(c011.ch, c111.ch, tx.f), ty.f), tz.f)
-	r.x = MV_TRI(x); r.y = MV_TRI(y); r.z = MV_TRI(z);
-#undef MV_TRI
+	r.x = trilerp(c000.x, c100.x, c010.x, c110.x, c001.x, c101.x, c011.x, c111.x, f.fx, f.fy, f.fz);
+	r.y = trilerp(c000.y, c100.y, c010.y, c110.y, c001.y, c101.y, c011.y, c111.y, f.fx, f.fy, f.fz);
+	r.z = trilerp(c000.z, c100.z, c010.z, c110.z, c001.z, c101.z, c011.z, c111.z, f.fx, f.fy, f.fz);
 	return r;
+}
+
+__device__ __forceinline__ vec3 sampleR11G11B10F(const uint32_t* tex, uint32_t L, vec3 uvw)
+{
+	return resolveLight(fetchLightFootprint(tex, L, uvw));
 }
 
 // Texture2D<float>.SampleLevel(POINT_CLAMP, uv, 0) -- Sh/CSRayMarch.hlsl:68
 __device__ __forceinline__ float samplePointR32F(const float* tex, uint32_t W, uint32_t H, float u, float v)
 {
-	const int x = clampi(floor_to_int(u * (float)W), 0, (int)W - 1);
-	const int y = clampi(floor_to_int(v * (float)H), 0, (int)H - 1);
+	// float clamp first (NaN -> 0), then the conversion is exact and in range
+	const int x = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(u * (float)W), 0.0f), (float)(W - 1u));
+	const int y = (int)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(v * (float)H), 0.0f), (float)(H - 1u));
 	return tex[(size_t)y * W + x];
 }
 
@@ -279,6 +363,7 @@ __device__ __forceinline__ float sampleCmpD16(const uint16_t* tex, uint32_t M, f
 	const float c01 = r <= t01 ? 1.0f : 0.0f, c11 = r <= t11 ? 1.0f : 0.0f;
 	return lerpf(lerpf(c00, c10, tx.f), lerpf(c01, c11, tx.f), ty.f);
 }
+
 
 // ---- Sh/RayMarch.hlsli device functions ----
 __device__ __forceinline__ vec3 LocalToTex3DSpace(vec3 pos)	// :170-177, _TEXCOORD_INVERT_Y_ off

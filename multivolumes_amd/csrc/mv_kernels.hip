@@ -11,6 +11,8 @@
 #include "mv_device.hpp"
 #include "mv_kernels.hpp"
 
+#include <stdlib.h>
+
 namespace mv
 {
 // ---------------------------------------------------------------------------------------------
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 		const float gStep = kMaxDist / (float)st.maxLightSamples;	// RayMarch.hlsli:18
 		const uint32_t volTexId0 = st.volumeDescs[volumeId] & 0x3fffu;
 		const PerObject& po0 = perObjects[volumeId];
-		VolumeView vol0; vol0.texels = st.volumes[volTexId0]; vol0.N = st.N; vol0.bricks = st.bricks;
+		const VolumeView vol0 = makeVolumeView(st.volumes[volTexId0], st.N, st.bricks);
 
 		vec3 rayOrigin = v3(((float)xx + 0.5f) / gridSize * 2.0f - 1.0f, ((float)yy + 0.5f) / gridSize * 2.0f - 1.0f, ((float)zz + 0.5f) / gridSize * 2.0f - 1.0f);
 		const vec3 uvw = LocalToTex3DSpace(rayOrigin);
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 			{
 				const uint32_t volTexId = st.volumeDescs[n] & 0x3fffu;
 				const PerObject& po = perObjects[n];
-				VolumeView vol; vol.texels = st.volumes[volTexId]; vol.N = st.N; vol.bricks = st.bricks;
+				const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.N, st.bricks);
 				vec3 localRayOrigin = mul43(rayOrigin, po.worldI);
 
 				if (shadow >= kZeroThreshold)
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 	}
 
 	const uint32_t tot = waveSumU32(nS);
-	if (lane == 0 && tot) atomicAdd(reinterpret_cast<unsigned long long*>(st.stats + 3), (unsigned long long)tot);
+	if (lane == 0 && tot) st.lightStats[blockIdx.x] += tot;	// this block's own slot: no atomics
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -485,7 +487,14 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kMarchWaves = 4;	// independent wavefronts per workgroup
 
-__global__ __launch_bounds__(64 * kMarchWaves) void marchViewKernel(DeviceState st)
+// X = 0 is the product kernel.  X != 0 are timing-only diagnostic variants (wrong results by construction) selected with
+// MV_EXPERIMENT=<X> to price one part of the loop: 1 = no light-map fetch, 2 = volume fetch from lane-coalesced fake
+// addresses, 3 = speculative prefetch of the next footprint (measured slower: +46 VGPRs cost a wave per SIMD), 4 = 1 + 2.
+#ifndef MV_MARCH_MIN_WAVES
+#define MV_MARCH_MIN_WAVES 5	// waves per SIMD the register allocator must leave room for (measured best)
+#endif
+template <int X>
+__global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchViewKernel(DeviceState st)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
@@ -554,44 +563,77 @@ __global__ __launch_bounds__(64 * kMarchWaves) void marchViewKernel(DeviceState 
 			st.cubeDepths[texel] = clip.z;	// :105
 			tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
 
-			VolumeView vol; vol.texels = st.volumes[volTexId]; vol.N = st.N; vol.bricks = st.bricks;
+			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.N, st.bricks);
 			const uint32_t* lightMap = st.lightMaps + (size_t)volumeId * st.L * st.L * st.L;
 
 			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
 			float t = 0.0f;
 			float prevDensity = 0.0f;
-			for (uint32_t i = 0; i < smpCount; ++i)	// :117-153
+			// The loop at :117-153.  Variant X = 3 additionally fetches the NEXT footprint speculatively at t + stepScale (GetStep returns exactly stepScale until
+			// the accumulated opacity is large); kept as a diagnostic because its register cost outweighs the overlap.
+			constexpr bool kSpeculate = (X == 3);
+			vec3 pos = rayAt(rayOrigin, rayDir, t);
+			bool alive = smpCount > 0u && !outsideBox(pos);
+			auto fetchVol = [&](vec3 p) -> Footprint
 			{
-				const vec3 pos = rayAt(rayOrigin, rayDir, t);
-				if (outsideBox(pos)) break;
+				if constexpr (X == 2 || X == 4)
+				{
+					Footprint f = fetchFootprint(vol, v3(0.0f, 0.0f, 0.0f));
+					const uint32_t o = lane * 8u + (__float_as_uint(p.x) & 0x3f000u);
+					f.t000 = loadTexelAt(vol, o); f.t100 = loadTexelAt(vol, o + 512u); f.t010 = loadTexelAt(vol, o + 1024u); f.t110 = loadTexelAt(vol, o + 1536u);
+					f.t001 = loadTexelAt(vol, o + 2048u); f.t101 = loadTexelAt(vol, o + 2560u); f.t011 = loadTexelAt(vol, o + 3072u); f.t111 = loadTexelAt(vol, o + 3584u);
+					return f;
+				}
+				else return fetchFootprint(vol, LocalToTex3DSpace(p));
+			};
+			Footprint cur;
+			if constexpr (kSpeculate) cur = fetchVol(pos);
+			for (uint32_t i = 0; alive; )
+			{
 				const vec3 uvw = LocalToTex3DSpace(pos);
+				if constexpr (!kSpeculate) cur = fetchVol(pos);
+				const float alpha = footprintAlpha(cur);	// GetSample (RayMarch.hlsli:44-50)
+				const bool lit = alpha > kZeroThreshold;	// :128
+				LightFootprint lf;
+				if (lit && X != 1 && X != 4) lf = fetchLightFootprint(lightMap, st.L, uvw);	// GetLight (RayMarch.hlsli:235-240), issued before the prefetch so its wait leaves the prefetch in flight
 
-				vec4 color = sampleRGBA16F(vol, uvw);
+				const float tSpec = t + stepScale;
+				Footprint nxt;
+				if constexpr (kSpeculate) nxt = fetchVol(rayAt(rayOrigin, rayDir, tSpec));
+
 				++nSamples;
 				float newStep = stepScale;
-
-				if (color.w > kZeroThreshold)
+				if (lit)
 				{
-					const vec3 light = sampleR11G11B10F(lightMap, st.L, v3(pos.x * 0.5f + 0.5f, pos.y * 0.5f + 0.5f, pos.z * 0.5f + 0.5f));
+					const vec3 light = (X == 1 || X == 4) ? v3(1.0f, 1.0f, 1.0f) : resolveLight(lf);
+					vec3 color = footprintRGB(cur);
 					++nLit;
 
 					const float transm = 1.0f - scatter.w;
-					const float dDensity = color.w - prevDensity;
-					newStep = GetStep(dDensity, transm, color.w, stepScale);
-					prevDensity = color.w;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
+					const float dDensity = alpha - prevDensity;
+					newStep = GetStep(dDensity, transm, alpha, stepScale);
+					prevDensity = alpha;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
 
-					color.x *= color.w; color.y *= color.w; color.z *= color.w;	// :140-142 not pre-multiplied
+					color.x *= alpha; color.y *= alpha; color.z *= alpha;	// :140-142 not pre-multiplied
 					color.x *= light.x; color.y *= light.y; color.z *= light.z;
 					scatter.x += color.x * kAbsorption * transm;
 					scatter.y += color.y * kAbsorption * transm;
 					scatter.z += color.z * kAbsorption * transm;
-					scatter.w += color.w * kAbsorption * transm;
+					scatter.w += alpha * kAbsorption * transm;
 
-					if (transm < kZeroThreshold) break;
+					if (transm < kZeroThreshold) break;	// :146
 				}
 
 				t += newStep;
-				if (t > tMax) break;
+				if (t > tMax) break;	// :152
+				if (++i >= smpCount) break;	// :117
+				pos = rayAt(rayOrigin, rayDir, t);
+				if (outsideBox(pos)) break;	// :120
+				if constexpr (kSpeculate)
+				{
+					if (newStep != stepScale) nxt = fetchVol(pos);	// mis-speculated step
+					cur = nxt;
+				}
 			}
 
 			const float twoPi = 2.0f * kPI;
@@ -606,13 +648,54 @@ __global__ __launch_bounds__(64 * kMarchWaves) void marchViewKernel(DeviceState 
 	}
 
 	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays);
-	if (lane == 0)
+	uint32_t maxS = nSamples;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
+	if (lane == 0 && tile < st.maxTiles)
 	{
-		unsigned long long* s = reinterpret_cast<unsigned long long*>(st.stats);
-		if (totS) atomicAdd(s + 0, (unsigned long long)totS);
-		if (totL) atomicAdd(s + 1, (unsigned long long)totL);
-		if (totR) atomicAdd(s + 2, (unsigned long long)totR);
+		// this tile slot belongs to this wavefront alone: plain read-modify-write, reduced by reduceStatsKernel on demand
+		ulonglong4* slot = reinterpret_cast<ulonglong4*>(st.tileStats) + tile;
+		ulonglong4 v = *slot;
+		v.x += totS; v.y += totL; v.z += totR;
+		v.w += (unsigned long long)maxS * 64ull;	// lane slots the wave occupied (utilisation = view samples / slots)
+		*slot = v;
 	}
+}
+
+// Sums the per-wavefront counter slots into st.stats (run by mv_get_stats, not per frame).
+__global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st)
+{
+	unsigned long long a[6] = { 0, 0, 0, 0, 0, 0 };
+	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
+	for (uint32_t i = tid; i < st.maxTiles; i += nThreads)
+	{
+		const ulonglong4 v = reinterpret_cast<const ulonglong4*>(st.tileStats)[i];
+		a[0] += v.x; a[1] += v.y; a[2] += v.z; a[5] += v.w;
+	}
+	for (uint32_t i = tid; i < st.lightBlocks; i += nThreads) a[3] += st.lightStats[i];
+	for (uint32_t i = tid; i < st.compositeSlots; i += nThreads) a[4] += st.compositeStats[i];
+#pragma unroll
+	for (int k = 0; k < 6; ++k)
+	{
+		unsigned long long v = a[k];
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+		if ((threadIdx.x & 63u) == 0u && v) atomicAdd(reinterpret_cast<unsigned long long*>(st.stats) + k, v);
+	}
+}
+
+uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount)
+{
+	// every owned volume at mip 0 with all 6 faces
+	const uint32_t sc = shardCount ? shardCount : 1u;
+	const uint32_t owned = (V + sc - 1u) / sc;
+	const uint32_t t = (N + 7u) >> 3;
+	return owned * 6u * t * t;
+}
+
+void launchReduceStats(hipStream_t s, const DeviceState& st)
+{
+	hipLaunchKernelGGL(reduceStatsKernel, dim3(64), dim3(256), 0, s, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -662,12 +745,18 @@ void launchMarchLight(hipStream_t s, const DeviceState& st)
 void launchMarchView(hipStream_t s, const DeviceState& st)
 {
 	// Upper bound of the tile count (the real count is on the device, written by cullKernel): every owned volume at mip 0 with 6 faces.
-	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
-	const uint32_t owned = (st.V + shardCount - 1u) / shardCount;
-	const uint32_t t = (st.N + 7u) >> 3;
-	const uint64_t maxTiles = (uint64_t)owned * 6u * t * t;
+	const uint64_t maxTiles = marchViewMaxTiles(st.V, st.N, st.shardCount);
 	uint64_t blocks = (maxTiles + kMarchWaves - 1) / kMarchWaves;
 	blocks = ((blocks + 7) / 8) * 8;
-	hipLaunchKernelGGL(marchViewKernel, dim3((uint32_t)blocks), dim3(64 * kMarchWaves), 0, s, st);
+	static const int experiment = []() { const char* e = getenv("MV_EXPERIMENT"); return e ? atoi(e) : 0; }();
+	const dim3 grid((uint32_t)blocks), block(64 * kMarchWaves);
+	switch (experiment)
+	{
+	case 1: hipLaunchKernelGGL(marchViewKernel<1>, grid, block, 0, s, st); break;
+	case 2: hipLaunchKernelGGL(marchViewKernel<2>, grid, block, 0, s, st); break;
+	case 3: hipLaunchKernelGGL(marchViewKernel<3>, grid, block, 0, s, st); break;
+	case 4: hipLaunchKernelGGL(marchViewKernel<4>, grid, block, 0, s, st); break;
+	default: hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st); break;
+	}
 }
 } // namespace mv

@@ -50,7 +50,14 @@ struct DeviceState
 	uint64_t* cubeOffset;			// V: texel offset of the selected mip of volume v inside cubeMaps / cubeDepths
 	uint32_t* volumeFlags;			// V: bit0 visible this frame, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask
 
-	uint64_t* stats;				// [0] view samples, [1] lit samples, [2] rays, [3] light samples, [4] composite samples
+	// Counters.  Every wavefront owns one slot and updates it with a plain read-modify-write (launches are stream
+	// ordered), because tens of thousands of same-address atomics per launch cost more than the march itself.
+	uint64_t* stats;				// totals, filled by launchReduceStats: [0] view samples, [1] lit samples, [2] rays,
+									// [3] light samples, [4] composite samples, [5] marchV lane slots
+	uint64_t* tileStats;			// maxTiles x 4: {view samples, lit samples, rays, lane slots} per marchV tile slot
+	uint64_t* lightStats;			// ceil(L/4)^3: light samples per marchL block
+	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
+	uint32_t maxTiles, lightBlocks, compositeSlots;
 };
 
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)
@@ -73,6 +80,8 @@ void launchR32FToRGBA16F(hipStream_t s, const float* src, uint32_t w, uint32_t h
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);
+void launchReduceStats(hipStream_t s, const DeviceState& st);
+uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
 void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1);
 void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, void* dst);
 void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim, const void* src);

@@ -297,7 +297,9 @@ class MultiRayCaster:
     def GetStats(self):
         s = mv_stats()
         self._check(self._lib.mv_get_stats(self._ctx, C.byref(s)), "mv_get_stats")
-        return {k: getattr(s, k) for k, _ in mv_stats._fields_ if k != "reserved"}
+        d = {k: getattr(s, k) for k, _ in mv_stats._fields_ if k != "reserved"}
+        d["reserved0"] = s.reserved[0]  # marchV lane slots (64 x longest ray per wavefront)
+        return d
 
     def ResetStats(self):
         self._check(self._lib.mv_reset_stats(self._ctx), "mv_reset_stats")
