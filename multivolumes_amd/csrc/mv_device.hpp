@@ -445,4 +445,53 @@ __device__ __forceinline__ vec3 GetLocalPos(float px, float py, uint32_t slice, 
 	}
 }
 
+
+// Shared body of the view march (Sh/CSRayMarch.hlsl:111-155) and of the screen-space RayCast (Sh/RayCast.hlsli:56-104):
+// front-to-back accumulation with the adaptive step of GetStep.  Returns scatter (rgb already divided by 2 pi).
+__device__ __forceinline__ vec4 marchRay(const VolumeView& vol, const uint32_t* lightMap, uint32_t L, vec3 rayOrigin, vec3 rayDir,
+	float tMax, uint32_t smpCount, uint32_t& nSamples, uint32_t& nLit)
+{
+	const float stepScale = kMaxDist / (float)smpCount;
+	vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
+	float t = 0.0f;
+	float prevDensity = 0.0f;
+	for (uint32_t i = 0; i < smpCount; ++i)
+	{
+		const vec3 pos = rayAt(rayOrigin, rayDir, t);
+		if (outsideBox(pos)) break;
+		const vec3 uvw = LocalToTex3DSpace(pos);
+
+		const Footprint fp = fetchFootprint(vol, uvw);
+		const float alpha = footprintAlpha(fp);
+		++nSamples;
+		float newStep = stepScale;
+
+		if (alpha > kZeroThreshold)
+		{
+			const vec3 light = sampleR11G11B10F(lightMap, L, uvw);
+			vec3 color = footprintRGB(fp);
+			++nLit;
+
+			const float transm = 1.0f - scatter.w;
+			const float dDensity = alpha - prevDensity;
+			newStep = GetStep(dDensity, transm, alpha, stepScale);
+			prevDensity = alpha;
+
+			color.x *= alpha; color.y *= alpha; color.z *= alpha;
+			color.x *= light.x; color.y *= light.y; color.z *= light.z;
+			scatter.x += color.x * kAbsorption * transm;
+			scatter.y += color.y * kAbsorption * transm;
+			scatter.z += color.z * kAbsorption * transm;
+			scatter.w += alpha * kAbsorption * transm;
+
+			if (transm < kZeroThreshold) break;
+		}
+
+		t += newStep;
+		if (t > tMax) break;
+	}
+	const float twoPi = 2.0f * kPI;
+	scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;
+	return scatter;
+}
 } // namespace mv

@@ -978,3 +978,236 @@ void mvo_march_view(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// a7: K-buffer OIT composite -- VSCube.hlsl:51-76, PSDepthPeel.hlsl:12-24, PSCube.hlsl:30-60, PSCube.hlsli:21-108,
+// RayCast.hlsli:43-108, PSResolveOIT.hlsl:12-26.
+// The reference rasterises each visible volume's cube with front-face culling (MultiRayCaster.cpp:868, 897), no depth
+// test (:869, :898): a pixel gets one fragment per volume, at the point where the pixel's view ray EXITS the cube.
+// Here that fragment is found analytically (slab test) instead of by rasterisation; fragment depth = clip z/w of the
+// exit point; fragments outside 0 <= z < 1 or with w <= 0 are clipped.  The 8 nearest fragments (PSDepthPeel) are
+// shaded (CubeCast when MaskBits has CUBEMAP_RAYMARCH_BIT, else the screen-space RayCast), stored as RGBA16F
+// (kColors format, MultiRayCaster.cpp:236) and resolved front to back.
+// TextureCube Gather across a face edge takes the texel the out-of-face texel centre re-projects to (D3D leaves
+// edge/corner filtering implementation-defined: unpinned).
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+struct CubeCoord { uint32_t face; float s, t; };
+
+inline CubeCoord cubeFaceCoords(float3 d)	// D3D cube-map face selection, consistent with GetLocalPos (CSRayMarch.hlsl:36-52)
+{
+	const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+	CubeCoord c;
+	float sc, tc, ma;
+	if (ax >= ay && ax >= az) { c.face = d.x > 0.0f ? 0u : 1u; sc = d.x > 0.0f ? -d.z : d.z; tc = -d.y; ma = ax; }
+	else if (ay >= az) { c.face = d.y > 0.0f ? 2u : 3u; sc = d.x; tc = d.y > 0.0f ? d.z : -d.z; ma = ay; }
+	else { c.face = d.z > 0.0f ? 4u : 5u; sc = d.z > 0.0f ? d.x : -d.x; tc = -d.y; ma = az; }
+	c.s = (sc / ma + 1.0f) * 0.5f;
+	c.t = (tc / ma + 1.0f) * 0.5f;
+	return c;
+}
+
+inline size_t cubeTexelIndex(uint32_t face, int32_t i, int32_t j, int32_t d)
+{
+	if (i < 0 || j < 0 || i >= d || j >= d)
+	{
+		const float a = ((float)i + 0.5f) / (float)d * 2.0f - 1.0f, b = ((float)j + 0.5f) / (float)d * 2.0f - 1.0f;
+		float3 dir;
+		switch (face)
+		{
+		case 0: dir = f3(1.0f, -b, -a); break;
+		case 1: dir = f3(-1.0f, -b, a); break;
+		case 2: dir = f3(a, 1.0f, b); break;
+		case 3: dir = f3(a, -1.0f, -b); break;
+		case 4: dir = f3(a, -b, 1.0f); break;
+		default: dir = f3(-a, -b, -1.0f); break;
+		}
+		const CubeCoord c = cubeFaceCoords(dir);
+		face = c.face;
+		i = clampi(f2i_floor(c.s * (float)d), 0, d - 1);
+		j = clampi(f2i_floor(c.t * (float)d), 0, d - 1);
+	}
+	return ((size_t)face * d + (size_t)j) * d + (size_t)i;
+}
+
+inline float UnprojectZ(float depth)	// PSCube.hlsli:21-26
+{
+	return (kZNear * kZFar) / (depth * (kZNear - kZFar) + kZFar);
+}
+
+// CubeCast (PSCube.hlsli:51-108) + GetDomain (:31-46)
+float4 CubeCast(const uint16_t* cubeMap, const float* cubeDepth, int32_t d, float depthPix, float3 pos, float3 rayDir)
+{
+	const CubeCoord cc = cubeFaceCoords(pos);
+	const float gridSize = (float)d;
+
+	// gather footprint
+	const float u = cc.s * gridSize - 0.5f, v = cc.t * gridSize - 0.5f;
+	const int32_t i0 = f2i_floor(u), j0 = f2i_floor(v);
+	const float fx = u - floorf(u), fy = v - floorf(v);
+	const size_t idx[4] = { cubeTexelIndex(cc.face, i0, j0 + 1, d), cubeTexelIndex(cc.face, i0 + 1, j0 + 1, d),
+		cubeTexelIndex(cc.face, i0 + 1, j0, d), cubeTexelIndex(cc.face, i0, j0, d) };
+	float smp[4][4], z[4];
+	for (int k = 0; k < 4; ++k)
+	{
+		for (int ch = 0; ch < 4; ++ch) smp[k][ch] = h2f(cubeMap[4 * idx[k] + ch]);
+		z[k] = cubeDepth[idx[k]];
+	}
+
+	// SampleLevel fallback colour: plain bilinear over the same footprint
+	const float wl[4] = { (1.0f - fx) * fy, fx * fy, fx * (1.0f - fy), (1.0f - fx) * (1.0f - fy) };
+	float color[4];
+	for (int ch = 0; ch < 4; ++ch) color[ch] = smp[0][ch] * wl[0] + smp[1][ch] * wl[1] + smp[2][ch] * wl[2] + smp[3][ch] * wl[3];
+
+	// GetDomain
+	float uvx = cc.s * gridSize, uvy = cc.t * gridSize;
+	float domx = (uvx + 0.5f) - floorf(uvx + 0.5f), domy = (uvy + 0.5f) - floorf(uvy + 0.5f);
+	const float bound = gridSize - 1.0f;
+	const float3 axes = f3(pos.x * gridSize, pos.y * gridSize, pos.z * gridSize);
+	if ((fabsf(axes.x) > bound && axes.x * rayDir.x < 0.0f) || (fabsf(axes.y) > bound && axes.y * rayDir.y < 0.0f) || (fabsf(axes.z) > bound && axes.z * rayDir.z < 0.0f))
+	{
+		uvx = fminf(uvx, gridSize - 0.5f); uvy = fminf(uvy, gridSize - 0.5f);
+		domx = uvx < 0.5f ? 1.0f : 0.0f; domy = uvy < 0.5f ? 1.0f : 0.0f;
+	}
+	const float dix = 1.0f - domx, diy = 1.0f - domy;
+	const float wb[4] = { dix * domy, domx * domy, domx * diy, dix * diy };
+
+	const float depth = UnprojectZ(depthPix);
+	float result[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+	float ws = 0.0f;
+	for (int k = 0; k < 4; ++k)
+	{
+		const float zi = UnprojectZ(z[k]);
+		float w = fmaxf(1.0f - 0.5f * fabsf(depth - zi), 0.0f);
+		w *= wb[k];
+		for (int ch = 0; ch < 4; ++ch) result[ch] += smp[k][ch] * w;
+		ws += w;
+	}
+	float4 r;
+	if (ws > 0.0f) { r.x = result[0] / ws; r.y = result[1] / ws; r.z = result[2] / ws; r.w = result[3] / ws; }
+	else { r.x = color[0]; r.y = color[1]; r.z = color[2]; r.w = color[3]; }
+	return r;
+}
+
+struct Fragment { uint32_t zbits; uint32_t volume; float3 lpt; };
+} // namespace
+
+extern "C" void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+	const uint16_t* const* volumes, const uint32_t* lightMaps, const float* depthMap, const void* perObjectBytes, const void* cbBytes,
+	const uint16_t* volumeInfo, const uint32_t* visibleVolumes, uint32_t visibleCount,
+	const uint16_t* cubeMaps, const float* cubeDepths, uint16_t* outRGBA, mvo_stats* stats)
+{
+	(void)V;
+	const PerObject* perObjects = (const PerObject*)perObjectBytes;
+	CBPerFrame cb;
+	memcpy(&cb, cbBytes, sizeof(cb));
+	const float3 eyePt = f3(cb.eyePos[0], cb.eyePos[1], cb.eyePos[2]);
+	const uint64_t chain = chainTexels(N);
+	uint64_t nSamples = 0;
+	if (y1 > H) y1 = H;
+
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : nSamples)
+	for (int64_t py = y0; py < (int64_t)y1; ++py)
+		for (uint32_t px = 0; px < W; ++px)
+		{
+			// PSCube.hlsl:37-39
+			float nx = ((float)px + 0.5f) / (float)W, ny = ((float)py + 0.5f) / (float)H;
+			nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
+			const float depthPix = depthMap[(size_t)py * W + px];
+
+			Fragment frags[MVO_NUM_OIT_LAYERS];
+			uint32_t nFrags = 0;
+			for (uint32_t k = 0; k < visibleCount; ++k)
+			{
+				const uint32_t v = visibleVolumes[k];
+				const PerObject& po = perObjects[v];
+				const float3 o = mul43(eyePt, po.worldI);
+				float4 c0 = { nx, ny, 0.0f, 1.0f }, c1 = { nx, ny, 1.0f, 1.0f };
+				const float4 h0 = mul44(c0, po.wvpI), h1 = mul44(c1, po.wvpI);
+				const float3 p0 = f3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w), p1 = f3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w);
+				const float3 d = p1 - p0;
+
+				// slab test from the eye along d
+				float tNear = -kFltMax, tFar = kFltMax;
+				int farAxis = -1;
+				bool miss = false;
+				for (int a = 0; a < 3; ++a)
+				{
+					const float da = idx(d, a), oa = idx(o, a);
+					if (da == 0.0f) { if (fabsf(oa) > 1.0f) miss = true; continue; }
+					const float sgn = da > 0.0f ? 1.0f : -1.0f;
+					const float tn = (-sgn - oa) / da, tf = (sgn - oa) / da;
+					if (tn > tNear) tNear = tn;
+					if (tf < tFar) { tFar = tf; farAxis = a; }
+				}
+				if (miss || farAxis < 0 || !(tFar > 0.0f) || !(tNear <= tFar)) continue;
+
+				float3 lpt = f3(fmaf(d.x, tFar, o.x), fmaf(d.y, tFar, o.y), fmaf(d.z, tFar, o.z));
+				lpt = f3(clampf(lpt.x, -1.0f, 1.0f), clampf(lpt.y, -1.0f, 1.0f), clampf(lpt.z, -1.0f, 1.0f));
+				const float snap = idx(d, farAxis) > 0.0f ? 1.0f : -1.0f;
+				if (farAxis == 0) lpt.x = snap; else if (farAxis == 1) lpt.y = snap; else lpt.z = snap;
+
+				float4 lp = { lpt.x, lpt.y, lpt.z, 1.0f };
+				const float4 clip = mul44(lp, po.wvp);
+				if (!(clip.w > 0.0f)) continue;
+				const float z = clip.z / clip.w;
+				if (!(z >= 0.0f && z < 1.0f)) continue;
+
+				// PSDepthPeel.hlsl:12-24: keep the NUM_OIT_LAYERS smallest depths, ascending
+				Fragment f; f.zbits = asuint(z); f.volume = v; f.lpt = lpt;
+				uint32_t pos = nFrags;
+				while (pos > 0 && frags[pos - 1].zbits > f.zbits) --pos;
+				if (pos >= MVO_NUM_OIT_LAYERS) continue;
+				const uint32_t last = nFrags < MVO_NUM_OIT_LAYERS ? nFrags : MVO_NUM_OIT_LAYERS - 1;
+				for (uint32_t m = last; m > pos; --m) frags[m] = frags[m - 1];
+				frags[pos] = f;
+				if (nFrags < MVO_NUM_OIT_LAYERS) ++nFrags;
+			}
+
+			// PSCube.hlsl:30-60 per layer, PSResolveOIT.hlsl:12-26
+			float4 result = { 0.0f, 0.0f, 0.0f, 0.0f };
+			for (uint32_t k = 0; k < nFrags; ++k)
+			{
+				const uint32_t v = frags[k].volume;
+				const PerObject& po = perObjects[v];
+				const uint32_t mipLevel = volumeInfo[4 * v + 0], smpCount = volumeInfo[4 * v + 1];
+				const uint32_t maskBits = volumeInfo[4 * v + 2], volTexId = volumeInfo[4 * v + 3];
+				const float3 localSpaceEyePt = mul43(eyePt, po.worldI);
+				const float3 rayDir = frags[k].lpt - localSpaceEyePt;
+				float4 color;
+				if (!(maskBits & kCubeMapRayMarchBit))
+				{
+					// RayCast (RayCast.hlsli:43-108)
+					float3 ro = localSpaceEyePt;
+					const float3 rd = normalize3(rayDir);
+					if (!ComputeRayOrigin(ro, rd)) { color.x = color.y = color.z = color.w = 0.0f; }
+					else
+					{
+						const float tMax = GetTMax(f3(nx, ny, depthPix), ro, rd, po.wvpI);
+						uint64_t s = 0, l = 0;
+						color = marchLoop(volumes[volTexId], N, lightMaps + (size_t)v * L * L * L, L, ro, rd, tMax, smpCount, s, l);
+						nSamples += s;
+					}
+				}
+				else
+				{
+					const int32_t d = (int32_t)(N >> mipLevel);
+					const size_t off = (size_t)v * chain + mipOffset(N, mipLevel);
+					color = CubeCast(cubeMaps + 4 * off, cubeDepths + off, d, depthPix, frags[k].lpt, rayDir);
+				}
+				if (color.w > 0.0f && color.w <= 1.0f)
+				{
+					// kColors is RGBA16F
+					const float cr = h2f(f2h(color.x)), cg = h2f(f2h(color.y)), cbb = h2f(f2h(color.z)), ca = h2f(f2h(color.w));
+					const float it = 1.0f - result.w;
+					result.x += cr * it; result.y += cg * it; result.z += cbb * it; result.w += ca * it;
+				}
+			}
+			result.w = fminf(result.w, 0.9997f);
+			uint16_t* o = outRGBA + 4 * ((size_t)py * W + px);
+			o[0] = f2h(result.x); o[1] = f2h(result.y); o[2] = f2h(result.z); o[3] = f2h(result.w);
+		}
+	if (stats) stats->view_samples += nSamples;
+}
+

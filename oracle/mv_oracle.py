@@ -154,3 +154,23 @@ def cube_face_view(chain_array, N, mip):
     off = cube_mip_offset(N, mip)
     a = chain_array[off:off + 6 * d * d]
     return a.reshape((6, d, d) + a.shape[1:])
+
+
+def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame, volumeInfo, visible, cubeMaps, cubeDepths,
+              y0=0, y1=None, out=None):
+    """K-buffer OIT composite over rows [y0, y1). Returns (out[H, W, 4] u16, RayCast sample count)."""
+    vols, arr = _vol_ptrs(volumes)
+    y1 = H if y1 is None else y1
+    o = np.zeros((H, W, 4), np.uint16) if out is None else out
+    lm = np.ascontiguousarray(lightMaps, np.uint32)
+    dm = np.ascontiguousarray(depthMap, np.float32)
+    po = np.ascontiguousarray(perObject).view(np.uint8)
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8)
+    vi = np.ascontiguousarray(volumeInfo, np.uint16)
+    vl = np.ascontiguousarray(visible, np.uint32)
+    cm = np.ascontiguousarray(cubeMaps, np.uint16)
+    cd = np.ascontiguousarray(cubeDepths, np.float32)
+    st = mvo_stats()
+    load().mvo_composite(V, N, L, W, H, y0, y1, arr, _ptr(lm), _ptr(dm), _ptr(po), _ptr(cb), _ptr(vi), _ptr(vl), len(vl),
+                         _ptr(cm), _ptr(cd), _ptr(o), C.byref(st))
+    return o, int(st.view_samples)

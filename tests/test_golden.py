@@ -1,0 +1,77 @@
+"""Golden fixture tests/golden/small.npz (made by tests/golden/make_golden.py from the oracle):
+CPU leg: the oracle still reproduces it bit for bit.  GPU leg: the HIP path matches it without the oracle present."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.conftest import half_to_float
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "small.npz")
+
+
+def load():
+    g = np.load(GOLDEN)
+    N, L, V, W, H, maxRay, maxLight, M = [int(x) for x in g["cfg"]]
+    return g, dict(N=N, L=L, V=V, W=W, H=H, maxRay=maxRay, maxLight=maxLight, M=M)
+
+
+def cb_for_frame(cb, f):
+    c = np.array(cb, np.uint8).copy()
+    c[208:212] = np.frombuffer(np.uint32(f).tobytes(), np.uint8)
+    return c
+
+
+def test_oracle_reproduces_golden(oracle):
+    g, c = load()
+    V, N, L, M = c["V"], c["N"], c["L"], c["M"]
+    vols = [g["volumes"][k] for k in range(V)]
+    info, vis, cube = oracle.cull(V, g["po"], g["descs"], g["cb"], c["maxRay"])
+    assert np.array_equal(info, g["info"]) and np.array_equal(vis, g["vis"]) and np.array_equal(cube, g["cube"])
+    lms, nls = None, 0
+    for f in range(V):
+        _, lms, n = oracle.march_light(V, N, L, M, vols, g["descs"], g["po"], cb_for_frame(g["cb"], f), g["shadow"], g["sh"], vis, c["maxLight"], lms)
+        nls += n
+    assert np.array_equal(lms, g["lightMaps"])
+    cm, cd, st = oracle.march_view(V, N, L, c["W"], c["H"], vols, lms, g["depth"], g["po"], g["cb"], info, cube)
+    assert np.array_equal(cm, g["cubeMaps"]) and np.array_equal(cd, g["cubeDepths"])
+    img, ns = oracle.composite(V, N, L, c["W"], c["H"], vols, lms, g["depth"], g["po"], g["cb"], info, vis, cm, cd)
+    assert np.array_equal(img, g["composite"])
+    assert [st["view_samples"], st["lit_samples"], st["rays"], nls, ns] == [int(x) for x in g["stats"]]
+
+
+@pytest.mark.gpu
+def test_gpu_matches_golden():
+    from multivolumes_amd import MultiRayCaster
+    g, c = load()
+    V, N, L = c["V"], c["N"], c["L"]
+    with MultiRayCaster(N, L, V, V, (c["W"], c["H"]), shadowMapSize=c["M"]) as mc:
+        for k in range(V):
+            mc.LoadVolumeData(k, g["volumes"][k])
+        mc.SetRenderTargets(g["depth"], g["shadow"])
+        mc.SetSH(g["sh"])
+        mc.SetMaxSamples(c["maxRay"], c["maxLight"])
+        for f in range(V):
+            mc.UpdateFrameRaw(cb_for_frame(g["cb"], f), g["po"])
+            mc.cullVolumes()
+            mc.rayMarchL()
+        mc.rayMarchV()
+        mc.composite()
+        assert np.array_equal(mc.ReadBackVolumeInfo(), g["info"])
+        vis, cube = mc.ReadBackVisibleLists()
+        assert np.array_equal(vis, g["vis"]) and np.array_equal(cube, g["cube"])
+        for v in vis:
+            lm = mc.ReadBackLightMap(int(v))
+            assert (lm != g["lightMaps"][v]).sum() <= 1e-3 * lm.size
+        from multivolumes_amd.raycaster import cube_mip_offset
+        for v in cube:
+            mip = int(g["info"][v, 0])
+            d = N >> mip
+            off = cube_mip_offset(N, mip)
+            exp = half_to_float(g["cubeMaps"][v][off:off + 6 * d * d].reshape(6, d, d, 4))
+            got = half_to_float(mc.ReadBackCubeMap(int(v), mip))
+            assert np.abs(exp - got).max() <= 1e-3
+            assert np.array_equal(mc.ReadBackCubeDepth(int(v), mip), g["cubeDepths"][v][off:off + 6 * d * d].reshape(6, d, d))
+        assert np.abs(half_to_float(mc.ReadBackComposite()) - half_to_float(g["composite"])).max() <= 1e-3
+        st = mc.GetStats()
+        assert [st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"], st["composite_samples"]] == [int(x) for x in g["stats"]]
