@@ -32,7 +32,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--config", default="C3", help="C1/C2/C3/C5/T1/T2 (default C3 = the config the metric is quoted on)")
     p.add_argument("--stress", action="store_true", help="C3-stress: force mip 0, all 6 faces (SURVEY 8d)")
-    p.add_argument("--composite", action="store_true", help="include the OIT composite in the step")
+    p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
     return p.parse_args()
@@ -76,21 +76,29 @@ def main():
             vols_host[k] = v
     fr = scene.setup_raycaster(caster, cfg)
     t_setup = time.time() - t0
+    do_composite = not args.no_composite
+
+    from multivolumes_amd import distributed as D
+    cube_xchg = D.CubeFaceExchange(caster) if world > 1 else None
+    light_xchg = D.LightMapExchange(caster) if world > 1 and do_composite else None
+    H, W = cfg["H"], cfg["W"]
+    band = D.row_range(H, rank, world)
+    xbytes = [0]
 
     def frame(with_exchange=True):
+        frame_idx = caster.m_frameIdx
         caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
-        caster.Render(composite=False)
+        caster.Render(composite=False)  # cull -> marchL -> marchV, stream ordered
         if world > 1 and with_exchange:
-            d, slot_bytes, shard_bytes = caster.ExchangeLayout()
-            send = torch.empty(shard_bytes, dtype=torch.uint8, device="cuda")
-            recv = torch.empty(shard_bytes * world, dtype=torch.uint8, device="cuda")
-            caster.ExchangePack(send.data_ptr())
-            dist.all_gather_into_tensor(recv, send)
-            caster.ExchangeUnpack(recv.data_ptr())
-        if args.composite:
-            H = cfg["H"]
-            r0, r1 = (H * rank) // world, (H * (rank + 1)) // world
-            caster.composite(r0, r1)
+            xbytes[0] += cube_xchg.run()  # pack -> RCCL all-gather -> unpack
+            if light_xchg is not None:
+                info_h = caster.ReadBackVolumeInfo()
+                vis_h, _ = caster.ReadBackVisibleLists()
+                xbytes[0] += light_xchg.run(info_h, vis_h, frame_idx)
+        if do_composite:
+            caster.composite(band[0], band[1])
+            if world > 1 and with_exchange:
+                xbytes[0] += D.gather_composite_rows(caster, H, W, rank, world)
 
     # relight every visible volume once so the light maps are real, then warm up
     for _ in range(V):
@@ -158,9 +166,11 @@ def main():
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
-                "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+composite" if args.composite else ""),
+                "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
+                "exchange_bytes_per_frame": xbytes[0] // max(1, K + args.warmup),
             },
-            "kernel_ms": {"cull": ms_c, "march_light": ms_l, "march_view": ms_v},
+            "kernel_ms": {"cull": ms_c, "march_light": ms_l, "march_view": ms_v, "composite": st["ms_composite"] / max(1, st["n_composite"])},
+            "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,
             "light_msamples_per_s": tot_light / dt / 1e6,
             "roofline": {"bound": "hbm", "kernel": "marchViewKernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -183,7 +193,7 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     # rank 0 owns cube[i] with i % world == 0 only when sharded; pick volumes whose cube maps this rank marched
     world = int(os.environ.get("WORLD_SIZE", "1"))
     mine = [int(v) for v in cube if int(v) % world == 0]
-    n = args.cpu_volumes or min(len(mine), 4)
+    n = args.cpu_volumes or len(mine)
     sel = mine[:n]
     if not sel:
         return None
@@ -191,8 +201,12 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     for v in sel:
         lms[v] = caster.ReadBackLightMap(v)
     vols = [vols_host.get(k, vols_host[sel[0]]) for k in range(V)]
+    chain = o.cube_chain_texels(N)
+    cm = np.zeros((V, chain, 4), np.uint16)
+    cd = np.zeros((V, chain), np.float32)
+    o.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel[:1], cm, cd, inplace=True)  # warm caches / thread pool
     t0 = time.perf_counter()
-    cm, cd, st = o.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel)
+    _, _, st = o.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel, cm, cd, inplace=True)
     dt = time.perf_counter() - t0
     worst = 0.0
     for v in sel:

@@ -812,7 +812,7 @@ uint32_t mvo_march_light(uint32_t V, uint32_t N, uint32_t L, uint32_t M,
 	uint32_t* out = lightMaps + (size_t)volumeId * L * L * L;
 	uint64_t totalSamples = 0;
 
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : totalSamples)
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) reduction(+ : totalSamples)
 	for (int64_t zz = 0; zz < (int64_t)L; ++zz)
 		for (uint32_t yy = 0; yy < L; ++yy)
 			for (uint32_t xx = 0; xx < L; ++xx)
@@ -932,7 +932,7 @@ void mvo_march_view(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
 		{
 			if ((maskBits & (1u << faceId)) == 0) continue;	// :85
 
-#pragma omp parallel for schedule(dynamic, 4) reduction(+ : nSamples, nLit, nRays)
+#pragma omp parallel for collapse(2) schedule(dynamic, 16) reduction(+ : nSamples, nLit, nRays)
 			for (int64_t ty = 0; ty < (int64_t)dims; ++ty)
 				for (uint32_t tx = 0; tx < dims; ++tx)
 				{
@@ -1107,7 +1107,7 @@ extern "C" void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, ui
 	uint64_t nSamples = 0;
 	if (y1 > H) y1 = H;
 
-#pragma omp parallel for schedule(dynamic, 1) reduction(+ : nSamples)
+#pragma omp parallel for schedule(dynamic, 2) reduction(+ : nSamples)
 	for (int64_t py = y0; py < (int64_t)y1; ++py)
 		for (uint32_t px = 0; px < W; ++px)
 		{

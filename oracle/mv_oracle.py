@@ -130,12 +130,16 @@ def march_light(V, N, L, M, volumes, descs, perObject, cbPerFrame, shadowMap, sh
 
 
 def march_view(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame, volumeInfo, cubeMapVolumes,
-               cubeMaps=None, cubeDepths=None):
-    """Returns (cubeMaps[V, chain, 4] u16, cubeDepths[V, chain] f32, stats dict)."""
+               cubeMaps=None, cubeDepths=None, inplace=False):
+    """Returns (cubeMaps[V, chain, 4] u16, cubeDepths[V, chain] f32, stats dict). inplace=True writes into the given arrays."""
     vols, arr = _vol_ptrs(volumes)
     chain = cube_chain_texels(N)
-    cm = np.zeros((V, chain, 4), np.uint16) if cubeMaps is None else np.ascontiguousarray(cubeMaps, np.uint16).copy()
-    cd = np.zeros((V, chain), np.float32) if cubeDepths is None else np.ascontiguousarray(cubeDepths, np.float32).copy()
+    if inplace:
+        cm, cd = cubeMaps, cubeDepths
+        assert cm.dtype == np.uint16 and cd.dtype == np.float32 and cm.flags.c_contiguous and cd.flags.c_contiguous
+    else:
+        cm = np.zeros((V, chain, 4), np.uint16) if cubeMaps is None else np.ascontiguousarray(cubeMaps, np.uint16).copy()
+        cd = np.zeros((V, chain), np.float32) if cubeDepths is None else np.ascontiguousarray(cubeDepths, np.float32).copy()
     lm = np.ascontiguousarray(lightMaps, np.uint32)
     dm = np.ascontiguousarray(depthMap, np.float32)
     po = np.ascontiguousarray(perObject).view(np.uint8)

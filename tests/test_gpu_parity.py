@@ -331,3 +331,99 @@ def test_composite_parity(oracle, name, W, H):
         c3 = c.ReadBackComposite()
         assert np.array_equal(c2, c3), "re-compositing a row band must reproduce the same pixels"
         print(f"composite {name} {W}x{H}: max abs err {diff.max():.3g}, {(got != exp).sum()} halfs differ")
+
+
+def test_sharded_contexts_reproduce_unsharded_frame(oracle):
+    """Two sharded contexts on one GPU (shard 0/2 and 1/2) + the exchange kernels = the unsharded frame.
+    The all-gather itself is emulated by concatenating the two packed shards in rank order (what
+    all_gather_into_tensor produces); tests/test_distributed_cpu.py covers the collective over gloo."""
+    import torch
+    from multivolumes_amd import distributed as D
+    cfg = dict(scene.CONFIGS["T2"], W=256, H=160)
+    V, N, H = cfg["V"], cfg["N"], cfg["H"]
+    M = 64
+    world = 2
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    with make_caster(cfg, M) as full:
+        fr = run_gpu(full, cfg, vols)
+        full.composite()
+        info = full.ReadBackVolumeInfo()
+        vis, cube = full.ReadBackVisibleLists()
+        ref_img = full.ReadBackComposite()
+        ref_cm = {int(v): full.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube}
+        ref_cd = {int(v): full.ReadBackCubeDepth(int(v), int(info[v, 0])) for v in cube}
+        ref_lm = {int(v): full.ReadBackLightMap(int(v)) for v in vis}
+        ref_stats = full.GetStats()
+    shards = [make_caster(cfg, M, shard=(r, world)) for r in range(world)]
+    try:
+        packed = []
+        tot_samples = tot_rays = 0
+        for r, c in enumerate(shards):
+            scene.setup_raycaster(c, cfg, vols)
+            owned_vis = [int(v) for v in vis if int(v) % world == r]
+            for f in range(len(owned_vis)):  # sharded contexts relight owned_visible[f % count]
+                c.m_frameIdx = f
+                c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+                c.cullVolumes()
+                c.rayMarchL()
+            c.rayMarchV()
+            assert np.array_equal(c.ReadBackVolumeInfo(), info), "cull is replicated"
+            for v in owned_vis:
+                assert np.array_equal(c.ReadBackLightMap(v), ref_lm[v])
+            d, slot_bytes, shard_bytes = c.ExchangeLayout()
+            assert (d, slot_bytes, shard_bytes) == D.exchange_layout(N, info, vis, V, world)
+            buf = torch.zeros(shard_bytes, dtype=torch.uint8, device="cuda")
+            c.ExchangePack(buf.data_ptr())
+            c.synchronize()
+            packed.append(buf)
+            st = c.GetStats()
+            tot_samples += st["view_samples"]
+            tot_rays += st["rays"]
+            # a rank marches only its own volumes
+            for v in cube:
+                got = c.ReadBackCubeMap(int(v), int(info[v, 0]))
+                if int(v) % world == r:
+                    assert np.array_equal(got, ref_cm[int(v)])
+                else:
+                    assert not got.any()
+        assert tot_samples == ref_stats["view_samples"] and tot_rays == ref_stats["rays"]
+        gathered = torch.cat(packed)
+        for r, c in enumerate(shards):
+            c.ExchangeUnpack(gathered.data_ptr())
+            # light maps of the other rank's volumes (needed by screen-space RayCast layers)
+            for v in vis:
+                if int(v) % world != r:
+                    c.UploadLightMap(int(v), ref_lm[int(v)])
+            for v in cube:
+                assert np.array_equal(c.ReadBackCubeMap(int(v), int(info[v, 0])), ref_cm[int(v)])
+                assert np.array_equal(c.ReadBackCubeDepth(int(v), int(info[v, 0])), ref_cd[int(v)])
+            r0, r1 = D.row_range(H, r, world)
+            c.composite(r0, r1)
+            img = c.ReadBackComposite()
+            assert np.array_equal(img[r0:r1], ref_img[r0:r1]), "row band must match the unsharded composite"
+    finally:
+        for c in shards:
+            c.close()
+
+
+def test_device_views_alias_context_buffers():
+    """distributed._device_view wraps a context-owned buffer as a torch tensor without copying (RCCL plumbing)."""
+    import torch
+    from multivolumes_amd import distributed as D
+    cfg = dict(scene.CONFIGS["T1"], W=64, H=48)
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    with make_caster(cfg, 32) as c:
+        run_gpu(c, cfg, vols, frames=1)
+        c.composite()
+        c.synchronize()
+        ptr, n = c.GetBuffer(5)
+        view = D._device_view(ptr, n)
+        torch.cuda.synchronize()
+        assert np.array_equal(view.cpu().numpy().view(np.uint16).reshape(48, 64, 4), c.ReadBackComposite())
+        view.zero_()
+        torch.cuda.synchronize()
+        assert not c.ReadBackComposite().any()
+        ptr, n = c.GetBuffer(1, 0)
+        assert n == cfg["L"] ** 3 * 4
+        lm = D._device_view(ptr, n).cpu().numpy().view(np.uint32).reshape(cfg["L"], cfg["L"], cfg["L"])
+        assert np.array_equal(lm, c.ReadBackLightMap(0))
