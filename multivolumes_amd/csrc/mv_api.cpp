@@ -34,7 +34,10 @@ struct mv_ctx
 
 	// owned device allocations
 	std::vector<uint2*> volumes;
+	std::vector<uint4*> cells;
 	uint2** dVolumePtrs = nullptr;
+	uint4** dCellPtrs = nullptr;
+	uint32_t* lightStaging = nullptr;	// L^3 plain R11G11B10F (readback / upload conversion)
 	uint2* staging = nullptr;			// N^3 linear RGBA16F (upload / readback re-tiling)
 	size_t stagingBytes = 0;
 	float* ownDepth = nullptr;
@@ -150,7 +153,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 {
 	if (!cfg || !out || cfg->struct_size != sizeof(mv_config)) return MV_ERR_INVALID_ARG;
 	*out = nullptr;
-	if (cfg->grid_size < 2 || cfg->grid_size > 768 /* bricked volume must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
+	if (cfg->grid_size < 2 || cfg->grid_size > 640 /* bricked alpha cells (16 B/texel) must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
 		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
 		return MV_ERR_INVALID_ARG;
 	if (cfg->shard_count > 1 && cfg->shard_index >= cfg->shard_count) return MV_ERR_INVALID_ARG;
@@ -196,12 +199,21 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipMemcpyAsync(ctx->dVolumePtrs, ctx->volumes.data(), st.S * sizeof(uint2*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 	st.volumes = ctx->dVolumePtrs;
+	// alpha-cell companions (mv_device.hpp, VolumeView): 16 bytes per texel, bricked like the texels
+	ctx->cells.resize(st.S, nullptr);
+	for (uint32_t i = 0; i < st.S; ++i)
+		if ((rc = devAlloc(ctx, &ctx->cells[i], 2 * brickedBytes)) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->dCellPtrs, st.S * sizeof(uint4*), false)) != MV_OK) return bail(rc);
+	if (hipMemcpyAsync(ctx->dCellPtrs, ctx->cells.data(), st.S * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	st.alphaCells = ctx->dCellPtrs;
 
 	ctx->stagingBytes = (size_t)st.N * st.N * st.N * sizeof(uint2);
 	if ((rc = devAlloc(ctx, &ctx->staging, ctx->stagingBytes, false)) != MV_OK) return bail(rc);
 
 	// lightMaps[V], cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-126), all zero-initialised
-	if ((rc = devAlloc(ctx, &st.lightMaps, (size_t)st.V * L3 * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.lightMaps, (size_t)st.V * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &ctx->lightStaging, L3 * sizeof(uint32_t), false)) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
@@ -272,6 +284,7 @@ int mv_volume_upload_rgba16f(mv_ctx* ctx, uint32_t src, const uint16_t* rgba)
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	MV_HIP(ctx, hipMemcpyAsync(ctx->staging, rgba, ctx->stagingBytes, hipMemcpyHostToDevice, ctx->stream));
 	mv::launchRetile(ctx->stream, ctx->staging, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));	// the caller may reuse `rgba` and the staging buffer is shared
 	return MV_OK;
@@ -282,6 +295,7 @@ int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgb
 	if (!ctx || !d_rgba) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	mv::launchRetile(ctx->stream, reinterpret_cast<const uint2*>(d_rgba), ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
 	return MV_OK;
 }
@@ -291,6 +305,7 @@ int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	mv::launchInitGridData(ctx->stream, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
 	return MV_OK;
 }
@@ -306,6 +321,7 @@ int mv_volume_load_r32f(mv_ctx* ctx, uint32_t src, const float* a, uint32_t w, u
 	if (e == hipSuccess)
 	{
 		mv::launchR32FToRGBA16F(ctx->stream, dSrc, w, h, d, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
+		mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 		e = hipGetLastError();
 	}
 	const hipError_t e2 = hipStreamSynchronize(ctx->stream);
@@ -505,7 +521,9 @@ int mv_readback_light_map(mv_ctx* ctx, uint32_t volume, uint32_t* dst)
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
 	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
-	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.lightMaps + volume * L3, L3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	mv::launchLightFromQuads(ctx->stream, ctx->st.lightMaps + volume * L3, ctx->lightStaging, ctx->st.L);
+	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->lightStaging, L3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MV_OK;
 }
@@ -515,7 +533,9 @@ int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src)
 	if (!ctx || !src) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
 	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
-	MV_HIP(ctx, hipMemcpyAsync(ctx->st.lightMaps + volume * L3, src, L3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipMemcpyAsync(ctx->lightStaging, src, L3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	mv::launchLightToQuads(ctx->stream, ctx->lightStaging, ctx->st.lightMaps + volume * L3, ctx->st.L);
+	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return MV_OK;
 }
@@ -622,7 +642,7 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 		*d_ptr = ctx->volumes[index]; *bytes = (size_t)st.bricks * st.bricks * st.bricks * 64 * sizeof(uint2); return MV_OK;
 	case MV_BUF_LIGHT_MAP:
 		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
-		*d_ptr = st.lightMaps + index * L3; *bytes = L3 * sizeof(uint32_t); return MV_OK;
+		*d_ptr = st.lightMaps + index * L3; *bytes = L3 * sizeof(uint4); return MV_OK;
 	case MV_BUF_CUBE_MAP:
 		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
 		*d_ptr = st.cubeMaps + index * chain; *bytes = chain * sizeof(uint2); return MV_OK;

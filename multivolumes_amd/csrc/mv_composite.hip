@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void compositeKernel(DeviceState st, uint32_t r
 				if (ComputeRayOrigin(ro, rd))
 				{
 					const float tMax = GetTMax(v3(nx, ny, depthPix), ro, rd, po.wvpI);
-					const VolumeView vol = makeVolumeView(st.volumes[vi.w], st.N, st.bricks);
+					const VolumeView vol = makeVolumeView(st.volumes[vi.w], st.alphaCells[vi.w], st.N, st.bricks);
 					color = marchRay(vol, st.lightMaps + (size_t)v * st.L * st.L * st.L, st.L, ro, rd, tMax, vi.y, nSamples, nLit);
 				}
 			}

@@ -184,29 +184,38 @@ __host__ __device__ __forceinline__ size_t volTexelIndex(uint32_t x, uint32_t y,
 // Global-address-space views: loads through them are global_load (SGPR base + 32-bit VGPR byte offset), not flat_load.
 typedef const __attribute__((address_space(1))) uint8_t* GlobalBytes;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x2* GlobalUint2;
+typedef const __attribute__((address_space(1))) u32x4* GlobalUint4;
 typedef const __attribute__((address_space(1))) uint32_t* GlobalUint;
-typedef const __attribute__((address_space(1))) uint16_t* GlobalUshort;
 
+// Besides the RGBA16F bricks every volume source has an ALPHA-CELL companion: for every texel (x,y,z) the eight
+// alphas of the 2x2x2 footprint that starts there, a(x..x+1, y..y+1, z..z+1) with the +1 neighbours clamped, as 8 halfs
+// = one 16-byte aligned cell, cells bricked exactly like the texels (so cell offset = 2 x texel offset).  A density
+// sample (CastLightRay, the alpha test of the view march, the gradient taps) is then ONE aligned 16-byte load instead of
+// eight 2-byte gathers: these kernels are bound by L1 tag lookups (one per distinct line per load instruction), and
+// 288 GB of HBM make the 8x replication of a 2-byte channel (16 B/texel next to the 8 B/texel RGBA) affordable.
 struct VolumeView
 {
-	GlobalBytes base;		// bricked RGBA16F texels (8 bytes each); the whole volume is < 4 GiB (mv_create enforces N <= 768)
+	GlobalBytes base;		// bricked RGBA16F texels (8 bytes each)
+	GlobalBytes cells;		// bricked alpha cells (16 bytes each); both stay < 4 GiB (mv_create enforces N <= 640)
 	uint32_t N;				// texels per axis
-	uint32_t strideY;		// bytes between bricks along y = bricks * 512
-	uint32_t strideZ;		// bytes between bricks along z = bricks^2 * 512
+	uint32_t strideY;		// texel bytes between bricks along y = bricks * 512
+	uint32_t strideZ;		// texel bytes between bricks along z = bricks^2 * 512
 };
 
-__device__ __forceinline__ VolumeView makeVolumeView(const uint2* texels, uint32_t N, uint32_t bricks)
+__device__ __forceinline__ VolumeView makeVolumeView(const uint2* texels, const uint4* cells, uint32_t N, uint32_t bricks)
 {
 	VolumeView v;
 	v.base = (GlobalBytes)texels;
+	v.cells = (GlobalBytes)cells;
 	v.N = N;
 	v.strideY = bricks * 512u;
 	v.strideZ = bricks * bricks * 512u;
 	return v;
 }
 
-// byte offsets contributed by one axis: brick part + in-brick part
+// texel byte offsets contributed by one axis: brick part + in-brick part
 __device__ __forceinline__ uint32_t offX(int i) { return (((uint32_t)i >> 2) << 9) + (((uint32_t)i & 3u) << 3); }
 __device__ __forceinline__ uint32_t offY(int i, uint32_t strideY) { return ((uint32_t)i >> 2) * strideY + (((uint32_t)i & 3u) << 5); }
 __device__ __forceinline__ uint32_t offZ(int i, uint32_t strideZ) { return ((uint32_t)i >> 2) * strideZ + (((uint32_t)i & 3u) << 7); }
@@ -216,7 +225,6 @@ __device__ __forceinline__ uint2 loadTexelAt(const VolumeView& v, uint32_t byteO
 	const u32x2 t = *(GlobalUint2)(v.base + byteOff);	// global_load_dwordx2, SGPR base + VGPR offset
 	return make_uint2(t.x, t.y);
 }
-__device__ __forceinline__ float loadAlphaAt(const VolumeView& v, uint32_t byteOff) { return half_bits_to_float(*(GlobalUshort)(v.base + byteOff + 6u)); }
 
 __device__ __forceinline__ vec4 decodeTexel(uint2 t)
 {
@@ -233,38 +241,70 @@ __device__ __forceinline__ float trilerp(float c000, float c100, float c010, flo
 	return lerpf(lerpf(lerpf(c000, c100, fx), lerpf(c010, c110, fx), fy), lerpf(lerpf(c001, c101, fx), lerpf(c011, c111, fx), fy), fz);
 }
 
-// The eight raw texels of a trilinear footprint plus the filter weights; decode is split so that the march can test
-// alpha (Sh/CSRayMarch.hlsl:128) before paying for the colour channels.
-struct Footprint
+// Footprint addressing shared by the density and the colour fetch of one sample.
+struct FootprintAddr
 {
-	uint2 t000, t100, t010, t110, t001, t101, t011, t111;
-	float fx, fy, fz;
+	uint32_t x0, x1, r00, r10, r01, r11;	// texel byte offsets: x taps and the four (y, z) rows
+	float fx, fy, fz;						// filter weights
+	float cx, cy, cz;						// weights for a CELL fetch: 0 where the two taps of an axis coincide (see fetchAlphaCell)
 };
 
-__device__ __forceinline__ Footprint fetchFootprint(const VolumeView& v, vec3 uvw)
+__device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
 {
-	const Taps tx = linearTaps(uvw.x, v.N, 0), ty = linearTaps(uvw.y, v.N, 0), tz = linearTaps(uvw.z, v.N, 0);
-	const uint32_t x0 = offX(tx.i0), x1 = offX(tx.i1);
+	const Taps tx = linearTaps(uvw.x, v.N, ox), ty = linearTaps(uvw.y, v.N, oy), tz = linearTaps(uvw.z, v.N, oz);
+	FootprintAddr a;
+	a.x0 = offX(tx.i0); a.x1 = offX(tx.i1);
 	const uint32_t y0 = offY(ty.i0, v.strideY), y1 = offY(ty.i1, v.strideY);
 	const uint32_t z0 = offZ(tz.i0, v.strideZ), z1 = offZ(tz.i1, v.strideZ);
-	const uint32_t r00 = y0 + z0, r10 = y1 + z0, r01 = y0 + z1, r11 = y1 + z1;
-	Footprint f;
-	f.t000 = loadTexelAt(v, r00 + x0); f.t100 = loadTexelAt(v, r00 + x1);
-	f.t010 = loadTexelAt(v, r10 + x0); f.t110 = loadTexelAt(v, r10 + x1);
-	f.t001 = loadTexelAt(v, r01 + x0); f.t101 = loadTexelAt(v, r01 + x1);
-	f.t011 = loadTexelAt(v, r11 + x0); f.t111 = loadTexelAt(v, r11 + x1);
-	f.fx = tx.f; f.fy = ty.f; f.fz = tz.f;
+	a.r00 = y0 + z0; a.r10 = y1 + z0; a.r01 = y0 + z1; a.r11 = y1 + z1;
+	a.fx = tx.f; a.fy = ty.f; a.fz = tz.f;
+	// A cell holds the clamped +1 neighbours of its own texel.  They are the sampler's second taps except when both
+	// taps of an axis are the SAME texel (coordinate below the first texel centre: taps (0,0) but the cell holds (0,1));
+	// there lerp(a, a, f) == a exactly, which is lerp(a, b, 0): zero the weight instead of fetching differently.
+	a.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; a.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; a.cz = tz.i1 == tz.i0 ? 0.0f : tz.f;
+	return a;
+}
+
+// density of the footprint: one aligned 16-byte load of the alpha cell at (x0, y0, z0)
+struct AlphaFootprint { u32x4 cell; float cx, cy, cz; };
+
+__device__ __forceinline__ AlphaFootprint fetchAlphaCell(const VolumeView& v, const FootprintAddr& a)
+{
+	AlphaFootprint f;
+	f.cell = *(GlobalUint4)(v.cells + 2u * (a.r00 + a.x0));
+	f.cx = a.cx; f.cy = a.cy; f.cz = a.cz;
 	return f;
 }
 
-__device__ __forceinline__ float footprintAlpha(const Footprint& f)
+// cell halfs are ordered x fastest, then y, then z: {a000,a100 | a010,a110 | a001,a101 | a011,a111}
+__device__ __forceinline__ float resolveAlpha(const AlphaFootprint& f)
 {
-#define MV_W(t) half_bits_to_float((t).y >> 16)
-	return trilerp(MV_W(f.t000), MV_W(f.t100), MV_W(f.t010), MV_W(f.t110), MV_W(f.t001), MV_W(f.t101), MV_W(f.t011), MV_W(f.t111), f.fx, f.fy, f.fz);
-#undef MV_W
+	return trilerp(half_bits_to_float(f.cell.x & 0xffffu), half_bits_to_float(f.cell.x >> 16), half_bits_to_float(f.cell.y & 0xffffu), half_bits_to_float(f.cell.y >> 16),
+		half_bits_to_float(f.cell.z & 0xffffu), half_bits_to_float(f.cell.z >> 16), half_bits_to_float(f.cell.w & 0xffffu), half_bits_to_float(f.cell.w >> 16),
+		f.cx, f.cy, f.cz);
 }
 
-__device__ __forceinline__ vec3 footprintRGB(const Footprint& f)
+// Texture3D<float4>.SampleLevel(LINEAR_CLAMP, uvw, 0, offset).w -- Sh/RayMarch.hlsli:44-50, 74
+__device__ __forceinline__ float sampleAlpha16F(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
+{
+	return resolveAlpha(fetchAlphaCell(v, footprintAddr(v, uvw, ox, oy, oz)));
+}
+
+// colour of the footprint: the eight RGBA16F texels (only fetched for samples that pass the alpha test)
+struct ColourFootprint { uint2 t000, t100, t010, t110, t001, t101, t011, t111; float fx, fy, fz; };
+
+__device__ __forceinline__ ColourFootprint fetchColour(const VolumeView& v, const FootprintAddr& a)
+{
+	ColourFootprint f;
+	f.t000 = loadTexelAt(v, a.r00 + a.x0); f.t100 = loadTexelAt(v, a.r00 + a.x1);
+	f.t010 = loadTexelAt(v, a.r10 + a.x0); f.t110 = loadTexelAt(v, a.r10 + a.x1);
+	f.t001 = loadTexelAt(v, a.r01 + a.x0); f.t101 = loadTexelAt(v, a.r01 + a.x1);
+	f.t011 = loadTexelAt(v, a.r11 + a.x0); f.t111 = loadTexelAt(v, a.r11 + a.x1);
+	f.fx = a.fx; f.fy = a.fy; f.fz = a.fz;
+	return f;
+}
+
+__device__ __forceinline__ vec3 resolveRGB(const ColourFootprint& f)
 {
 	vec3 r;
 #define MV_R(t) half_bits_to_float((t).x & 0xffffu)
@@ -279,66 +319,49 @@ __device__ __forceinline__ vec3 footprintRGB(const Footprint& f)
 	return r;
 }
 
-// Texture3D<float4>.SampleLevel(LINEAR_CLAMP, uvw, 0) on RGBA16F -- Sh/RayMarch.hlsli:44-50
-__device__ __forceinline__ vec4 sampleRGBA16F(const VolumeView& v, vec3 uvw)
+// alpha through the texels themselves (used by diagnostics and by the alpha-cell builder's self check)
+__device__ __forceinline__ float resolveAlphaFromTexels(const ColourFootprint& f)
 {
-	const Footprint f = fetchFootprint(v, uvw);
-	const vec3 rgb = footprintRGB(f);
-	vec4 r; r.x = rgb.x; r.y = rgb.y; r.z = rgb.z; r.w = footprintAlpha(f);
-	return r;
+#define MV_W(t) half_bits_to_float((t).y >> 16)
+	return trilerp(MV_W(f.t000), MV_W(f.t100), MV_W(f.t010), MV_W(f.t110), MV_W(f.t001), MV_W(f.t101), MV_W(f.t011), MV_W(f.t111), f.fx, f.fy, f.fz);
+#undef MV_W
 }
 
-// alpha channel only (CastLightRay / density probes): same arithmetic as channel w above, with optional texel offset
-__device__ __forceinline__ float sampleAlpha16F(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
-{
-	const Taps tx = linearTaps(uvw.x, v.N, ox), ty = linearTaps(uvw.y, v.N, oy), tz = linearTaps(uvw.z, v.N, oz);
-	const uint32_t x0 = offX(tx.i0), x1 = offX(tx.i1);
-	const uint32_t y0 = offY(ty.i0, v.strideY), y1 = offY(ty.i1, v.strideY);
-	const uint32_t z0 = offZ(tz.i0, v.strideZ), z1 = offZ(tz.i1, v.strideZ);
-	const uint32_t r00 = y0 + z0, r10 = y1 + z0, r01 = y0 + z1, r11 = y1 + z1;
-	return trilerp(loadAlphaAt(v, r00 + x0), loadAlphaAt(v, r00 + x1), loadAlphaAt(v, r10 + x0), loadAlphaAt(v, r10 + x1),
-		loadAlphaAt(v, r01 + x0), loadAlphaAt(v, r01 + x1), loadAlphaAt(v, r11 + x0), loadAlphaAt(v, r11 + x1), tx.f, ty.f, tz.f);
-}
+// ---- light maps ---------------------------------------------------------------------------------
+// Light maps are stored QUAD-replicated: element (x,y,z) is a 16-byte cell {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)} of
+// slice z (+1 neighbours clamped), elements in plain [z][y][x] order.  Texture3D<float3>.SampleLevel(LINEAR_CLAMP)
+// (GetLight, Sh/RayMarch.hlsli:235-240) is then two aligned 16-byte loads (slices z0 and z1) instead of eight 4-byte
+// gathers.  The same coincident-tap rule as for alpha cells applies to x and y.  (Assumes finite light-map texels:
+// an 11/10-bit float only reaches inf above 65024, far beyond lightColor + ambient.)
+struct LightFootprint { u32x4 q0, q1; float cx, cy, fz; };
 
-// Texture3D<float3>.SampleLevel(LINEAR_CLAMP, uvw, 0) on R11G11B10F (light map, linear x-fastest) -- Sh/RayMarch.hlsli:235-240
-// Split into fetch (8 dword loads in flight) and resolve (decode + filter) so the march can overlap it with other loads.
-struct LightFootprint
-{
-	uint32_t p000, p100, p010, p110, p001, p101, p011, p111;
-	float fx, fy, fz;
-};
-
-__device__ __forceinline__ LightFootprint fetchLightFootprint(const uint32_t* tex, uint32_t L, vec3 uvw)
+__device__ __forceinline__ LightFootprint fetchLightFootprint(const uint4* quads, uint32_t L, vec3 uvw)
 {
 	const Taps tx = linearTaps(uvw.x, L, 0), ty = linearTaps(uvw.y, L, 0), tz = linearTaps(uvw.z, L, 0);
-	const GlobalBytes base = (GlobalBytes)tex;
-	const uint32_t x0 = (uint32_t)tx.i0 << 2, x1 = (uint32_t)tx.i1 << 2;
-	const uint32_t y0 = (uint32_t)ty.i0 * (L << 2), y1 = (uint32_t)ty.i1 * (L << 2);
-	const uint32_t z0 = (uint32_t)tz.i0 * (L * L << 2), z1 = (uint32_t)tz.i1 * (L * L << 2);
-	const uint32_t r00 = y0 + z0, r10 = y1 + z0, r01 = y0 + z1, r11 = y1 + z1;
+	const GlobalBytes base = (GlobalBytes)quads;
+	const uint32_t row = ((uint32_t)ty.i0 * L + (uint32_t)tx.i0) << 4;
+	const uint32_t slice = (L * L) << 4;
 	LightFootprint f;
-#define MV_L(o) (*(GlobalUint)(base + (o)))
-	f.p000 = MV_L(r00 + x0); f.p100 = MV_L(r00 + x1); f.p010 = MV_L(r10 + x0); f.p110 = MV_L(r10 + x1);
-	f.p001 = MV_L(r01 + x0); f.p101 = MV_L(r01 + x1); f.p011 = MV_L(r11 + x0); f.p111 = MV_L(r11 + x1);
-#undef MV_L
-	f.fx = tx.f; f.fy = ty.f; f.fz = tz.f;
+	f.q0 = *(GlobalUint4)(base + ((uint32_t)tz.i0 * slice + row));
+	f.q1 = *(GlobalUint4)(base + ((uint32_t)tz.i1 * slice + row));
+	f.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; f.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; f.fz = tz.f;
 	return f;
 }
 
 __device__ __forceinline__ vec3 resolveLight(const LightFootprint& f)
 {
-	const vec3 c000 = unpack_r11g11b10f(f.p000), c100 = unpack_r11g11b10f(f.p100), c010 = unpack_r11g11b10f(f.p010), c110 = unpack_r11g11b10f(f.p110);
-	const vec3 c001 = unpack_r11g11b10f(f.p001), c101 = unpack_r11g11b10f(f.p101), c011 = unpack_r11g11b10f(f.p011), c111 = unpack_r11g11b10f(f.p111);
+	const vec3 c000 = unpack_r11g11b10f(f.q0.x), c100 = unpack_r11g11b10f(f.q0.y), c010 = unpack_r11g11b10f(f.q0.z), c110 = unpack_r11g11b10f(f.q0.w);
+	const vec3 c001 = unpack_r11g11b10f(f.q1.x), c101 = unpack_r11g11b10f(f.q1.y), c011 = unpack_r11g11b10f(f.q1.z), c111 = unpack_r11g11b10f(f.q1.w);
 	vec3 r;
-	r.x = trilerp(c000.x, c100.x, c010.x, c110.x, c001.x, c101.x, c011.x, c111.x, f.fx, f.fy, f.fz);
-	r.y = trilerp(c000.y, c100.y, c010.y, c110.y, c001.y, c101.y, c011.y, c111.y, f.fx, f.fy, f.fz);
-	r.z = trilerp(c000.z, c100.z, c010.z, c110.z, c001.z, c101.z, c011.z, c111.z, f.fx, f.fy, f.fz);
+	r.x = trilerp(c000.x, c100.x, c010.x, c110.x, c001.x, c101.x, c011.x, c111.x, f.cx, f.cy, f.fz);
+	r.y = trilerp(c000.y, c100.y, c010.y, c110.y, c001.y, c101.y, c011.y, c111.y, f.cx, f.cy, f.fz);
+	r.z = trilerp(c000.z, c100.z, c010.z, c110.z, c001.z, c101.z, c011.z, c111.z, f.cx, f.cy, f.fz);
 	return r;
 }
 
-__device__ __forceinline__ vec3 sampleR11G11B10F(const uint32_t* tex, uint32_t L, vec3 uvw)
+__device__ __forceinline__ vec3 sampleR11G11B10F(const uint4* quads, uint32_t L, vec3 uvw)
 {
-	return resolveLight(fetchLightFootprint(tex, L, uvw));
+	return resolveLight(fetchLightFootprint(quads, L, uvw));
 }
 
 // Texture2D<float>.SampleLevel(POINT_CLAMP, uv, 0) -- Sh/CSRayMarch.hlsl:68
@@ -448,7 +471,8 @@ __device__ __forceinline__ vec3 GetLocalPos(float px, float py, uint32_t slice, 
 
 // Shared body of the view march (Sh/CSRayMarch.hlsl:111-155) and of the screen-space RayCast (Sh/RayCast.hlsli:56-104):
 // front-to-back accumulation with the adaptive step of GetStep.  Returns scatter (rgb already divided by 2 pi).
-__device__ __forceinline__ vec4 marchRay(const VolumeView& vol, const uint32_t* lightMap, uint32_t L, vec3 rayOrigin, vec3 rayDir,
+// Per sample: one alpha-cell load decides :128; only lit samples fetch the 8 RGBA texels and the 2 light-map quads.
+__device__ __forceinline__ vec4 marchRay(const VolumeView& vol, const uint4* lightQuads, uint32_t L, vec3 rayOrigin, vec3 rayDir,
 	float tMax, uint32_t smpCount, uint32_t& nSamples, uint32_t& nLit)
 {
 	const float stepScale = kMaxDist / (float)smpCount;
@@ -461,23 +485,25 @@ __device__ __forceinline__ vec4 marchRay(const VolumeView& vol, const uint32_t* 
 		if (outsideBox(pos)) break;
 		const vec3 uvw = LocalToTex3DSpace(pos);
 
-		const Footprint fp = fetchFootprint(vol, uvw);
-		const float alpha = footprintAlpha(fp);
+		const FootprintAddr fa = footprintAddr(vol, uvw);
+		const float alpha = resolveAlpha(fetchAlphaCell(vol, fa));	// GetSample(...).w
 		++nSamples;
 		float newStep = stepScale;
 
 		if (alpha > kZeroThreshold)
 		{
-			const vec3 light = sampleR11G11B10F(lightMap, L, uvw);
-			vec3 color = footprintRGB(fp);
+			const LightFootprint lf = fetchLightFootprint(lightQuads, L, uvw);	// GetLight: same pos * 0.5 + 0.5
+			const ColourFootprint cf = fetchColour(vol, fa);
+			const vec3 light = resolveLight(lf);
+			vec3 color = resolveRGB(cf);
 			++nLit;
 
 			const float transm = 1.0f - scatter.w;
 			const float dDensity = alpha - prevDensity;
 			newStep = GetStep(dDensity, transm, alpha, stepScale);
-			prevDensity = alpha;
+			prevDensity = alpha;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
 
-			color.x *= alpha; color.y *= alpha; color.z *= alpha;
+			color.x *= alpha; color.y *= alpha; color.z *= alpha;	// :140-142 not pre-multiplied
 			color.x *= light.x; color.y *= light.y; color.z *= light.z;
 			scatter.x += color.x * kAbsorption * transm;
 			scatter.y += color.y * kAbsorption * transm;

@@ -127,6 +127,52 @@ __global__ __launch_bounds__(256) void r32fToRGBA16FKernel(const float* __restri
 	}
 }
 
+// Alpha-cell companion of a bricked volume (mv_device.hpp, VolumeView): cell i holds the eight alphas of the 2x2x2
+// footprint that starts at texel i, +1 neighbours clamped to N-1.  Runs after every volume producer.
+__global__ __launch_bounds__(256) void buildAlphaCellsKernel(const uint2* __restrict__ bricked, uint4* __restrict__ cells, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	const uint16_t* h = reinterpret_cast<const uint16_t*>(bricked);
+	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+	{
+		const size_t brick = i >> 6;
+		const uint32_t in = (uint32_t)(i & 63);
+		const uint32_t bx = (uint32_t)(brick % bricks), by = (uint32_t)((brick / bricks) % bricks), bz = (uint32_t)(brick / ((size_t)bricks * bricks));
+		const uint32_t x = bx * 4 + (in & 3), y = by * 4 + ((in >> 2) & 3), z = bz * 4 + (in >> 4);
+		uint4 c = make_uint4(0u, 0u, 0u, 0u);
+		if (x < N && y < N && z < N)
+		{
+			const uint32_t x1 = x + 1 < N ? x + 1 : N - 1, y1 = y + 1 < N ? y + 1 : N - 1, z1 = z + 1 < N ? z + 1 : N - 1;
+#define MV_A(xx_, yy_, zz_) ((uint32_t)h[4 * volTexelIndex(xx_, yy_, zz_, bricks) + 3])
+			c.x = MV_A(x, y, z) | (MV_A(x1, y, z) << 16);
+			c.y = MV_A(x, y1, z) | (MV_A(x1, y1, z) << 16);
+			c.z = MV_A(x, y, z1) | (MV_A(x1, y, z1) << 16);
+			c.w = MV_A(x, y1, z1) | (MV_A(x1, y1, z1) << 16);
+#undef MV_A
+		}
+		cells[i] = c;
+	}
+}
+
+// light map: plain R11G11B10F [z][y][x] (the reference / ABI layout) <-> quad-replicated cells (device layout)
+__global__ __launch_bounds__(256) void lightToQuadsKernel(const uint32_t* __restrict__ linear, uint4* __restrict__ quads, uint32_t L)
+{
+	const uint32_t total = L * L * L;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+	{
+		const uint32_t x = i % L, y = (i / L) % L, z = i / (L * L);
+		const uint32_t x1 = x + 1 < L ? x + 1 : L - 1, y1 = y + 1 < L ? y + 1 : L - 1;
+		const uint32_t* s = linear + (size_t)z * L * L;
+		quads[i] = make_uint4(s[y * L + x], s[y * L + x1], s[y1 * L + x], s[y1 * L + x1]);
+	}
+}
+
+__global__ __launch_bounds__(256) void lightFromQuadsKernel(const uint4* __restrict__ quads, uint32_t* __restrict__ linear, uint32_t L)
+{
+	const uint32_t total = L * L * L;
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) linear[i] = quads[i].x;
+}
+
 // ---------------------------------------------------------------------------------------------
 // a1: volume cull.  One workgroup of 8 wavefronts; each wavefront culls 8 volumes (8 lanes = 8 cube vertices each).
 // After the cull the first wavefront compacts the visible / cube-map lists in ascending volume order and builds the
@@ -315,12 +361,46 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 // ---------------------------------------------------------------------------------------------
 // Sh/RayMarch.hlsli:197-230  CastLightRay (mipLevel 0)
 // ---------------------------------------------------------------------------------------------
+#ifndef MV_LIGHT_SPECULATE
+#define MV_LIGHT_SPECULATE 1
+#endif
 __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vol, vec3 rayOrigin, vec3 rayDir,
 	float stepScale, uint32_t numSamples, uint32_t& samples)
 {
 	float t = stepScale;
 	float step = stepScale;
 	float prevDensity = 0.0f;
+#if MV_LIGHT_SPECULATE
+	// Same loop, software pipelined: the alpha footprint of the next sample is fetched at t + stepScale while the
+	// current one is resolved.  GetStep returns exactly stepScale until the light is noticeably attenuated
+	// (1.5 * factorEv * factorUi * (1 - transm) <= 1), so the guess is right for most of a ray and consecutive
+	// samples' memory latencies overlap; a wrong guess costs one re-fetch.  Arithmetic and order are the reference's.
+	vec3 pos = rayAt(rayOrigin, rayDir, t);
+	if (numSamples == 0u || outsideBox(pos)) return;
+	AlphaFootprint cur = fetchAlphaCell(vol, footprintAddr(vol, LocalToTex3DSpace(pos)));
+	for (uint32_t i = 0;;)
+	{
+		const AlphaFootprint nxt = fetchAlphaCell(vol, footprintAddr(vol, LocalToTex3DSpace(rayAt(rayOrigin, rayDir, t + stepScale))));
+		const float density = resolveAlpha(cur);
+		++samples;
+
+		const float dDensity = density - prevDensity;
+		const float opacity = saturatef(density * step);
+		const float newStep = GetStep(dDensity, transm, opacity, stepScale);
+		prevDensity = density;	// (:219 `step = (step + newStep) * 0.5` is dead: overwritten at :227)
+
+		transm *= 1.0f - density * kAbsorption;
+		if (transm < kZeroThreshold) break;
+
+		step = newStep;
+		t += step;
+		if (++i >= numSamples) break;
+		pos = rayAt(rayOrigin, rayDir, t);
+		if (outsideBox(pos)) break;
+		cur = nxt;
+		if (newStep != stepScale) cur = fetchAlphaCell(vol, footprintAddr(vol, LocalToTex3DSpace(pos)));
+	}
+#else
 	for (uint32_t i = 0; i < numSamples; ++i)
 	{
 		const vec3 pos = rayAt(rayOrigin, rayDir, t);
@@ -341,6 +421,7 @@ __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vo
 		step = newStep;
 		t += step;
 	}
+#endif
 }
 
 // XUSG/Shaders/SHIrradianceTypeless.hlsli:15-36
@@ -404,7 +485,7 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 		const float gStep = kMaxDist / (float)st.maxLightSamples;	// RayMarch.hlsli:18
 		const uint32_t volTexId0 = st.volumeDescs[volumeId] & 0x3fffu;
 		const PerObject& po0 = perObjects[volumeId];
-		const VolumeView vol0 = makeVolumeView(st.volumes[volTexId0], st.N, st.bricks);
+		const VolumeView vol0 = makeVolumeView(st.volumes[volTexId0], st.alphaCells[volTexId0], st.N, st.bricks);
 
 		vec3 rayOrigin = v3(((float)xx + 0.5f) / gridSize * 2.0f - 1.0f, ((float)yy + 0.5f) / gridSize * 2.0f - 1.0f, ((float)zz + 0.5f) / gridSize * 2.0f - 1.0f);
 		const vec3 uvw = LocalToTex3DSpace(rayOrigin);
@@ -438,7 +519,7 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 				const float q4 = sampleAlpha16F(vol0, uvw, 0, 0, -1), q5 = sampleAlpha16F(vol0, uvw, 0, 0, 1);
 				aoRayDir = v3(-(q1 - q0), -(q3 - q2), -(q5 - q4));
 				const bool nz = __builtin_fabsf(aoRayDir.x) > 0.0f || __builtin_fabsf(aoRayDir.y) > 0.0f || __builtin_fabsf(aoRayDir.z) > 0.0f;
-				aoRayDir = nz ? aoRayDir : rayOrigin;	// :69 (rayOrigin is already world space here)
+				aoRayDir = v3(nz ? aoRayDir.x : rayOrigin.x, nz ? aoRayDir.y : rayOrigin.y, nz ? aoRayDir.z : rayOrigin.z);	// :69 (rayOrigin is already world space here)
 				aoRayDir = mul33(aoRayDir, po0.world);
 				aoRayDir = normalize3(aoRayDir);
 				irradiance = EvaluateSHIrradiance(st.sh, normalize3(aoRayDir));	// GetIrradiance normalises again (RayMarch.hlsli:121)
@@ -448,7 +529,7 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 			{
 				const uint32_t volTexId = st.volumeDescs[n] & 0x3fffu;
 				const PerObject& po = perObjects[n];
-				const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.N, st.bricks);
+				const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
 				vec3 localRayOrigin = mul43(rayOrigin, po.worldI);
 
 				if (shadow >= kZeroThreshold)
@@ -475,7 +556,20 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 		if (st.hasLightProbe) ambient = v3(ao * irradiance.x, ao * irradiance.y, ao * irradiance.z);
 
 		const vec3 result = v3(shadow * lightColor.x + ambient.x, shadow * lightColor.y + ambient.y, shadow * lightColor.z + ambient.z);
-		st.lightMaps[(size_t)volumeId * L * L * L + ((size_t)zz * L + yy) * L + xx] = pack_r11g11b10f(result.x, result.y, result.z);
+		// quad-replicated store (see mv_device.hpp "light maps"): texel (x, y) is slot (sx, sy) of every cell (cx, cy)
+		// with min(cx + sx, L-1) == x and min(cy + sy, L-1) == y
+		const uint32_t packed = pack_r11g11b10f(result.x, result.y, result.z);
+		uint32_t* quads = reinterpret_cast<uint32_t*>(st.lightMaps + (size_t)volumeId * L * L * L);
+		const uint32_t cxs[3] = { xx, xx - 1u, xx }, sxs[3] = { 0u, 1u, 1u };
+		const bool vx[3] = { true, xx >= 1u, xx == L - 1u };
+		const uint32_t cys[3] = { yy, yy - 1u, yy };
+		const bool vy[3] = { true, yy >= 1u, yy == L - 1u };
+#pragma unroll
+		for (int b = 0; b < 3; ++b)
+#pragma unroll
+			for (int a = 0; a < 3; ++a)
+				if (vx[a] && vy[b])
+					quads[((((size_t)zz * L + cys[b]) * L + cxs[a]) << 2) + sxs[a] + 2u * sxs[b]] = packed;
 	}
 
 	const uint32_t tot = waveSumU32(nS);
@@ -488,13 +582,18 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 constexpr uint32_t kMarchWaves = 4;	// independent wavefronts per workgroup
 
 // X = 0 is the product kernel.  X != 0 are timing-only diagnostic variants (wrong results by construction) selected with
-// MV_EXPERIMENT=<X> to price one part of the loop: 1 = no light-map fetch, 2 = volume fetch from lane-coalesced fake
-// addresses, 3 = speculative prefetch of the next footprint (measured slower: +46 VGPRs cost a wave per SIMD), 4 = 1 + 2.
+// MV_EXPERIMENT=<X> to price one part of the loop: 1 = no light-map fetch, 2 = no colour fetch.
+#ifndef MV_ALPHA_FROM_TEXELS
+#define MV_ALPHA_FROM_TEXELS 1	// measured: 0.39 vs 0.44 ms at C3, 0.98 vs 0.99 ms at C3-stress (the alpha-cell form adds an HBM round trip to lit samples)
+#endif
+#ifndef MV_PREDICT_LIT
+#define MV_PREDICT_LIT 1
+#endif
 #ifndef MV_MARCH_MIN_WAVES
 #define MV_MARCH_MIN_WAVES 5	// waves per SIMD the register allocator must leave room for (measured best)
 #endif
 template <int X>
-__global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchViewKernel(DeviceState st)
+__global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchViewKernel(DeviceState st, uint32_t mapMode)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
@@ -507,8 +606,10 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 	const uint32_t perXcd = (nBlocks + 7u) >> 3;
 	const uint32_t xcd = blockIdx.x & 7u, idxInXcd = blockIdx.x >> 3;
 	if (idxInXcd >= perXcd) return;
-	const uint32_t tile = __builtin_amdgcn_readfirstlane((xcd * perXcd + idxInXcd) * kMarchWaves + wave);
+	uint32_t tile = __builtin_amdgcn_readfirstlane((xcd * perXcd + idxInXcd) * kMarchWaves + wave);
+	if (mapMode == 1u) tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kMarchWaves + wave);	// diagnostic: dispatch order
 	if (tile >= nTiles) return;
+	if (mapMode == 2u) tile = nTiles - 1u - tile;	// diagnostic: reversed list
 
 	// find the work entry that owns this tile (wave-uniform)
 	uint32_t entry = 0;
@@ -563,50 +664,66 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 			st.cubeDepths[texel] = clip.z;	// :105
 			tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
 
-			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.N, st.bricks);
-			const uint32_t* lightMap = st.lightMaps + (size_t)volumeId * st.L * st.L * st.L;
+			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
+			const uint4* lightQuads = st.lightMaps + (size_t)volumeId * st.L * st.L * st.L;
 
 			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
 			float t = 0.0f;
 			float prevDensity = 0.0f;
-			// The loop at :117-153.  Variant X = 3 additionally fetches the NEXT footprint speculatively at t + stepScale (GetStep returns exactly stepScale until
-			// the accumulated opacity is large); kept as a diagnostic because its register cost outweighs the overlap.
-			constexpr bool kSpeculate = (X == 3);
-			vec3 pos = rayAt(rayOrigin, rayDir, t);
-			bool alive = smpCount > 0u && !outsideBox(pos);
-			auto fetchVol = [&](vec3 p) -> Footprint
+			// The loop at :117-153.  One aligned 16-byte alpha-cell load decides the alpha test (:128); only lit samples
+			// fetch the eight RGBA16F texels and the two light-map quads (issued together: one round trip).
+			bool prevLit = false;
+			for (uint32_t i = 0; i < smpCount; ++i)
 			{
-				if constexpr (X == 2 || X == 4)
-				{
-					Footprint f = fetchFootprint(vol, v3(0.0f, 0.0f, 0.0f));
-					const uint32_t o = lane * 8u + (__float_as_uint(p.x) & 0x3f000u);
-					f.t000 = loadTexelAt(vol, o); f.t100 = loadTexelAt(vol, o + 512u); f.t010 = loadTexelAt(vol, o + 1024u); f.t110 = loadTexelAt(vol, o + 1536u);
-					f.t001 = loadTexelAt(vol, o + 2048u); f.t101 = loadTexelAt(vol, o + 2560u); f.t011 = loadTexelAt(vol, o + 3072u); f.t111 = loadTexelAt(vol, o + 3584u);
-					return f;
-				}
-				else return fetchFootprint(vol, LocalToTex3DSpace(p));
-			};
-			Footprint cur;
-			if constexpr (kSpeculate) cur = fetchVol(pos);
-			for (uint32_t i = 0; alive; )
-			{
+				const vec3 pos = rayAt(rayOrigin, rayDir, t);
+				if (outsideBox(pos)) break;	// :120
 				const vec3 uvw = LocalToTex3DSpace(pos);
-				if constexpr (!kSpeculate) cur = fetchVol(pos);
-				const float alpha = footprintAlpha(cur);	// GetSample (RayMarch.hlsli:44-50)
-				const bool lit = alpha > kZeroThreshold;	// :128
+
+				const FootprintAddr fa = footprintAddr(vol, uvw);
+#if MV_ALPHA_FROM_TEXELS
+				// latency-oriented form: the eight RGBA texels are fetched unconditionally and alpha comes from them
+				ColourFootprint cf = fetchColour(vol, fa);
 				LightFootprint lf;
-				if (lit && X != 1 && X != 4) lf = fetchLightFootprint(lightMap, st.L, uvw);	// GetLight (RayMarch.hlsli:235-240), issued before the prefetch so its wait leaves the prefetch in flight
-
-				const float tSpec = t + stepScale;
-				Footprint nxt;
-				if constexpr (kSpeculate) nxt = fetchVol(rayAt(rayOrigin, rayDir, tSpec));
-
+				const bool early = MV_PREDICT_LIT && prevLit;
+				if (early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+				const float alpha = resolveAlphaFromTexels(cf);
 				++nSamples;
 				float newStep = stepScale;
+				const bool lit = alpha > kZeroThreshold;	// :128
+				prevLit = lit;
 				if (lit)
 				{
-					const vec3 light = (X == 1 || X == 4) ? v3(1.0f, 1.0f, 1.0f) : resolveLight(lf);
-					vec3 color = footprintRGB(cur);
+					if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+#else
+				const AlphaFootprint ac = fetchAlphaCell(vol, fa);
+				// A ray's samples are a dependent chain, so its time is made of memory round trips.  Lit samples come in runs:
+				// when the previous sample was lit, the colour texels and the light quads are requested together with the alpha
+				// cell (one round trip for the whole sample); otherwise only the 16-byte cell is read and empty space costs one
+				// load per sample.  Prediction only changes which loads are issued, never the arithmetic.
+				LightFootprint lf;
+				ColourFootprint cf;
+				const bool early = MV_PREDICT_LIT && prevLit;
+				if (early)
+				{
+					if constexpr (X != 1) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+					if constexpr (X != 2) cf = fetchColour(vol, fa);
+				}
+				const float alpha = resolveAlpha(ac);	// GetSample(...).w (RayMarch.hlsli:44-50)
+				++nSamples;
+				float newStep = stepScale;
+				const bool lit = alpha > kZeroThreshold;	// :128
+				prevLit = lit;
+
+				if (lit)
+				{
+					if (!early)
+					{
+						if constexpr (X != 1) lf = fetchLightFootprint(lightQuads, st.L, uvw);	// GetLight (RayMarch.hlsli:235-240): same pos * 0.5 + 0.5
+						if constexpr (X != 2) cf = fetchColour(vol, fa);
+					}
+#endif
+					const vec3 light = X == 1 ? v3(1.0f, 1.0f, 1.0f) : resolveLight(lf);
+					vec3 color = X == 2 ? v3(0.5f, 0.5f, 0.5f) : resolveRGB(cf);
 					++nLit;
 
 					const float transm = 1.0f - scatter.w;
@@ -626,14 +743,6 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 
 				t += newStep;
 				if (t > tMax) break;	// :152
-				if (++i >= smpCount) break;	// :117
-				pos = rayAt(rayOrigin, rayDir, t);
-				if (outsideBox(pos)) break;	// :120
-				if constexpr (kSpeculate)
-				{
-					if (newStep != stepScale) nxt = fetchVol(pos);	// mis-speculated step
-					cur = nxt;
-				}
 			}
 
 			const float twoPi = 2.0f * kPI;
@@ -731,6 +840,22 @@ void launchR32FToRGBA16F(hipStream_t s, const float* src, uint32_t w, uint32_t h
 	hipLaunchKernelGGL(r32fToRGBA16FKernel, dim3(gridFor(total, 256)), dim3(256), 0, s, src, w, h, d, bricked, N, bricks);
 }
 
+void launchBuildAlphaCells(hipStream_t s, const uint2* bricked, uint4* cells, uint32_t N, uint32_t bricks)
+{
+	const size_t total = (size_t)bricks * bricks * bricks * 64;
+	hipLaunchKernelGGL(buildAlphaCellsKernel, dim3(gridFor(total, 256)), dim3(256), 0, s, bricked, cells, N, bricks);
+}
+
+void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uint32_t L)
+{
+	hipLaunchKernelGGL(lightToQuadsKernel, dim3(gridFor((size_t)L * L * L, 256)), dim3(256), 0, s, linear, quads, L);
+}
+
+void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L)
+{
+	hipLaunchKernelGGL(lightFromQuadsKernel, dim3(gridFor((size_t)L * L * L, 256)), dim3(256), 0, s, quads, linear, L);
+}
+
 void launchCull(hipStream_t s, const DeviceState& st)
 {
 	hipLaunchKernelGGL(cullKernel, dim3(1), dim3(kCullThreads), st.V * sizeof(uint32_t), s, st);
@@ -749,14 +874,13 @@ void launchMarchView(hipStream_t s, const DeviceState& st)
 	uint64_t blocks = (maxTiles + kMarchWaves - 1) / kMarchWaves;
 	blocks = ((blocks + 7) / 8) * 8;
 	static const int experiment = []() { const char* e = getenv("MV_EXPERIMENT"); return e ? atoi(e) : 0; }();
+	static const uint32_t mapMode = []() { const char* e = getenv("MV_TILE_MAP"); return e ? (uint32_t)atoi(e) : 0u; }();
 	const dim3 grid((uint32_t)blocks), block(64 * kMarchWaves);
 	switch (experiment)
 	{
-	case 1: hipLaunchKernelGGL(marchViewKernel<1>, grid, block, 0, s, st); break;
-	case 2: hipLaunchKernelGGL(marchViewKernel<2>, grid, block, 0, s, st); break;
-	case 3: hipLaunchKernelGGL(marchViewKernel<3>, grid, block, 0, s, st); break;
-	case 4: hipLaunchKernelGGL(marchViewKernel<4>, grid, block, 0, s, st); break;
-	default: hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st); break;
+	case 1: hipLaunchKernelGGL(marchViewKernel<1>, grid, block, 0, s, st, mapMode); break;
+	case 2: hipLaunchKernelGGL(marchViewKernel<2>, grid, block, 0, s, st, mapMode); break;
+	default: hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st, mapMode); break;
 	}
 }
 } // namespace mv

@@ -31,7 +31,8 @@ struct DeviceState
 
 	// resources
 	const uint2* const* volumes;	// S pointers to bricked RGBA16F texels
-	uint32_t* lightMaps;			// V x L^3 R11G11B10F
+	const uint4* const* alphaCells;	// S pointers to the bricked alpha cells (8 halfs per texel: its 2x2x2 footprint)
+	uint4* lightMaps;				// V x L^3 quad-replicated R11G11B10F cells {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)}
 	const float* depthMap;			// W x H
 	const uint16_t* shadowMap;		// M x M D16
 	uint2* cubeMaps;				// V x chain RGBA16F texels
@@ -77,6 +78,9 @@ void launchRetile(hipStream_t s, const uint2* linear, uint2* bricked, uint32_t N
 void launchUntile(hipStream_t s, const uint2* bricked, uint2* linear, uint32_t N, uint32_t bricks);
 void launchInitGridData(hipStream_t s, uint2* bricked, uint32_t N, uint32_t bricks);
 void launchR32FToRGBA16F(hipStream_t s, const float* src, uint32_t w, uint32_t h, uint32_t d, uint2* bricked, uint32_t N, uint32_t bricks);
+void launchBuildAlphaCells(hipStream_t s, const uint2* bricked, uint4* cells, uint32_t N, uint32_t bricks);
+void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uint32_t L);
+void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);

@@ -117,7 +117,7 @@ class LightMapExchange:
         self.caster, self.group = caster, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.nbytes = caster.lightGridSize ** 3 * 4
+        self.nbytes = caster.GetBuffer(1, 0)[1]  # MV_BUF_LIGHT_MAP: device layout (quad-replicated cells, 16 B per texel)
         self.send = self.recv = None
 
     def relit_volume(self, visible, frame_idx, rank):

@@ -424,6 +424,15 @@ def test_device_views_alias_context_buffers():
         torch.cuda.synchronize()
         assert not c.ReadBackComposite().any()
         ptr, n = c.GetBuffer(1, 0)
-        assert n == cfg["L"] ** 3 * 4
-        lm = D._device_view(ptr, n).cpu().numpy().view(np.uint32).reshape(cfg["L"], cfg["L"], cfg["L"])
-        assert np.array_equal(lm, c.ReadBackLightMap(0))
+        # device layout of a light map: quad-replicated cells {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)}, +1 clamped
+        L = cfg["L"]
+        assert n == L ** 3 * 16
+        q = D._device_view(ptr, n).cpu().numpy().view(np.uint32).reshape(L, L, L, 4)
+        lm = c.ReadBackLightMap(0)
+        x1 = np.minimum(np.arange(L) + 1, L - 1)
+        assert np.array_equal(q[..., 0], lm) and np.array_equal(q[..., 1], lm[:, :, x1])
+        assert np.array_equal(q[..., 2], lm[:, x1, :]) and np.array_equal(q[..., 3], lm[:, x1, :][:, :, x1])
+        # upload path rebuilds the same cells
+        c.UploadLightMap(1, lm)
+        ptr1, _ = c.GetBuffer(1, 1)
+        assert np.array_equal(D._device_view(ptr1, n).cpu().numpy().view(np.uint32).reshape(L, L, L, 4), q)
