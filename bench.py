@@ -142,7 +142,9 @@ def main():
         ms_l = st["ms_march_light"] / max(1, st["n_march_light"])
         ms_c = st["ms_cull"] / max(1, st["n_cull"])
         # rank-0 marchV launch: algorithmic bytes per launch / average launch duration
-        alg_bytes = (64 * st["view_samples"] + 32 * st["lit_samples"] + 16 * st["rays"]) / max(1, st["n_march_view"])
+        # the view-march launch also marches the screen-space RayCast tiles (composite_samples) on single-GPU contexts
+        fused = st["composite_samples"] if world == 1 else 0
+        alg_bytes = (64 * (st["view_samples"] + fused) + 32 * (st["lit_samples"] + (st["fused_raycast_lit"] if world == 1 else 0)) + 16 * st["rays"]) / max(1, st["n_march_view"])
         achieved = alg_bytes / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")

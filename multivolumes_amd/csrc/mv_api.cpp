@@ -231,10 +231,18 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &st.cubeMapVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.counters, kNumCounters * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.workEntries, (size_t)st.V * 6 * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.workTileStart, ((size_t)st.V * 6 + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	// RayCast layers of screen-space-scheme volumes are marched inside the view-march launch (single-GPU contexts) into
+	// fp32 RGBA layers; volumes beyond the slot capacity fall back to marching inside the composite.
+	st.screenSlots = st.shardCount > 1 ? 0u : (st.V < 8u ? st.V : 8u);
+	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
+	if ((rc = devAlloc(ctx, &st.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.screenSlot, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.workEntries, ((size_t)st.V * 6 + st.screenSlots) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.workTileStart, ((size_t)st.V * 6 + st.screenSlots + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.cubeOffset, (size_t)st.V * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.stats, kNumStats * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	st.maxTiles = mv::marchViewMaxTiles(st.V, st.N, st.shardCount);
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
@@ -595,6 +603,7 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 	out->light_samples = ctx->pinnedStats[3];
 	out->composite_samples = ctx->pinnedStats[4];
 	out->reserved[0] = ctx->pinnedStats[5];	// marchV lane slots (64 x longest ray per wavefront)
+	out->reserved[1] = ctx->pinnedStats[6];	// lit samples among composite_samples that were marched inside the view-march launch
 	out->ms_cull = ctx->msStage[0]; out->ms_march_light = ctx->msStage[1]; out->ms_march_view = ctx->msStage[2]; out->ms_composite = ctx->msStage[3];
 	out->n_cull = ctx->nStage[0]; out->n_march_light = ctx->nStage[1]; out->n_march_view = ctx->nStage[2]; out->n_composite = ctx->nStage[3];
 	return MV_OK;
@@ -609,6 +618,7 @@ int mv_reset_stats(mv_ctx* ctx)
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.lightStats, 0, (size_t)ctx->st.lightBlocks * sizeof(uint64_t), ctx->stream));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.compositeStats, 0, (size_t)ctx->st.compositeSlots * sizeof(uint64_t), ctx->stream));
+	MV_HIP(ctx, hipMemsetAsync(ctx->st.screenStats, 0, ((size_t)ctx->st.maxScreenTiles + 1) * 2 * sizeof(uint64_t), ctx->stream));
 	for (int i = 0; i < 4; ++i) { ctx->msStage[i] = 0.0; ctx->nStage[i] = 0; }
 	return MV_OK;
 }

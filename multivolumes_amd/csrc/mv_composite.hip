@@ -184,8 +184,8 @@ __global__ __launch_bounds__(64) void compositeKernel(DeviceState st, uint32_t r
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t tilesX = (st.W + 7u) >> 3;
-	const uint32_t px = (blockIdx.x % tilesX) * 8u + (lane & 7u);
-	const uint32_t py = row0 + (blockIdx.x / tilesX) * 8u + (lane >> 3);
+	const uint32_t tileX0 = (blockIdx.x % tilesX) * 8u, tileY0 = row0 + (blockIdx.x / tilesX) * 8u;
+	const uint32_t px = tileX0 + (lane & 7u), py = tileY0 + (lane >> 3);
 	uint32_t nSamples = 0, nLit = 0;
 
 	if (px < st.W && py < row1)
@@ -199,8 +199,9 @@ __global__ __launch_bounds__(64) void compositeKernel(DeviceState st, uint32_t r
 		float nx = ((float)px + 0.5f) / (float)st.W, ny = ((float)py + 0.5f) / (float)st.H;
 		nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
 		const float depthPix = st.depthMap[(size_t)py * st.W + px];
+		const vec3 dirW = pixelRayWorld(cb, nx, ny);
 
-		// PSDepthPeel.hlsl:12-24: the NUM_OIT_LAYERS nearest fragments, ascending depth; key = depth bits : volume slot
+		// PSDepthPeel.hlsl:12-24: the NUM_OIT_LAYERS nearest fragments, ascending depth; key = depth bits : list index
 		unsigned long long keys[kNumOitLayers];
 #pragma unroll
 		for (uint32_t m = 0; m < kNumOitLayers; ++m) keys[m] = ~0ull;
@@ -208,39 +209,13 @@ __global__ __launch_bounds__(64) void compositeKernel(DeviceState st, uint32_t r
 		for (uint32_t k = 0; k < visibleCount; ++k)
 		{
 			const uint32_t v = st.visibleVolumes[k];
+			// volumes whose screen rectangle misses this 8x8 tile cannot produce a fragment here (wave-uniform skip)
+			const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[v];
+			if (tileX0 + 7u < rect.x || tileX0 > rect.z || tileY0 + 7u < rect.y || tileY0 > rect.w) continue;
 			const PerObject& po = perObjects[v];
-			const vec3 o = mul43(eyePt, po.worldI);
-			vec4 c0; c0.x = nx; c0.y = ny; c0.z = 0.0f; c0.w = 1.0f;
-			vec4 c1 = c0; c1.z = 1.0f;
-			const vec4 h0 = mul44(c0, po.wvpI), h1 = mul44(c1, po.wvpI);
-			const vec3 p0 = v3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w), p1 = v3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w);
-			const vec3 d = p1 - p0;
-
-			float tNear = -kFltMax, tFar = kFltMax;
-			int farAxis = -1;
-			bool miss = false;
-#pragma unroll
-			for (int a = 0; a < 3; ++a)
-			{
-				const float da = comp(d, a), oa = comp(o, a);
-				if (da == 0.0f) { if (__builtin_fabsf(oa) > 1.0f) miss = true; continue; }
-				const float sgn = da > 0.0f ? 1.0f : -1.0f;
-				const float tn = (-sgn - oa) / da, tf = (sgn - oa) / da;
-				if (tn > tNear) tNear = tn;
-				if (tf < tFar) { tFar = tf; farAxis = a; }
-			}
-			if (miss || farAxis < 0 || !(tFar > 0.0f) || !(tNear <= tFar)) continue;
-
-			vec3 lpt = rayAt(o, d, tFar);
-			lpt = v3(clampf(lpt.x, -1.0f, 1.0f), clampf(lpt.y, -1.0f, 1.0f), clampf(lpt.z, -1.0f, 1.0f));
-			const float snap = comp(d, farAxis) > 0.0f ? 1.0f : -1.0f;
-			if (farAxis == 0) lpt.x = snap; else if (farAxis == 1) lpt.y = snap; else lpt.z = snap;
-
-			vec4 lp; lp.x = lpt.x; lp.y = lpt.y; lp.z = lpt.z; lp.w = 1.0f;
-			const vec4 clip = mul44(lp, po.wvp);
-			if (!(clip.w > 0.0f)) continue;
-			const float z = clip.z / clip.w;
-			if (!(z >= 0.0f && z < 1.0f)) continue;
+			vec3 lpt;
+			float z;
+			if (!findExitFragment(po, mul43(eyePt, po.worldI), dirW, lpt, z)) continue;
 
 			// sorted insert (stable for equal depths: the list index k is the low word)
 			unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | k;
@@ -266,48 +241,40 @@ __global__ __launch_bounds__(64) void compositeKernel(DeviceState st, uint32_t r
 			const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[v];
 			const vec3 localSpaceEyePt = mul43(eyePt, po.worldI);
 
-			// recompute the exit point exactly as in the peel loop (cheaper than keeping 8 float3 in registers)
-			vec4 c0; c0.x = nx; c0.y = ny; c0.z = 0.0f; c0.w = 1.0f;
-			vec4 c1 = c0; c1.z = 1.0f;
-			const vec4 h0 = mul44(c0, po.wvpI), h1 = mul44(c1, po.wvpI);
-			const vec3 p0 = v3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w), p1 = v3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w);
-			const vec3 d = p1 - p0;
-			float tFar = kFltMax;
-			int farAxis = 0;
-#pragma unroll
-			for (int a = 0; a < 3; ++a)
-			{
-				const float da = comp(d, a), oa = comp(localSpaceEyePt, a);
-				if (da == 0.0f) continue;
-				const float sgn = da > 0.0f ? 1.0f : -1.0f;
-				const float tf = (sgn - oa) / da;
-				if (tf < tFar) { tFar = tf; farAxis = a; }
-			}
-			vec3 lpt = rayAt(localSpaceEyePt, d, tFar);
-			lpt = v3(clampf(lpt.x, -1.0f, 1.0f), clampf(lpt.y, -1.0f, 1.0f), clampf(lpt.z, -1.0f, 1.0f));
-			const float snap = comp(d, farAxis) > 0.0f ? 1.0f : -1.0f;
-			if (farAxis == 0) lpt.x = snap; else if (farAxis == 1) lpt.y = snap; else lpt.z = snap;
-			const vec3 rayDir = lpt - localSpaceEyePt;
-
 			vec4 color;
-			if (!(vi.z & kCubeMapRayMarchBit))
+			const uint32_t slot = (vi.z & kCubeMapRayMarchBit) ? 0xffffffffu : st.screenSlot[v];
+			if (!(vi.z & kCubeMapRayMarchBit) && slot != 0xffffffffu)
 			{
-				// RayCast (RayCast.hlsli:43-108)
-				vec3 ro = localSpaceEyePt;
-				const vec3 rd = normalize3(rayDir);
-				color.x = color.y = color.z = color.w = 0.0f;
-				if (ComputeRayOrigin(ro, rd))
-				{
-					const float tMax = GetTMax(v3(nx, ny, depthPix), ro, rd, po.wvpI);
-					const VolumeView vol = makeVolumeView(st.volumes[vi.w], st.alphaCells[vi.w], st.N, st.bricks);
-					color = marchRay(vol, st.lightMaps + (size_t)v * st.L * st.L * st.L, st.L, ro, rd, tMax, vi.y, nSamples, nLit);
-				}
+				// RayCast (RayCast.hlsli:43-108) already marched for this pixel by marchViewKernel's screen tiles
+				const float4 c = st.screenLayers[((size_t)slot * st.H + py) * st.W + px];
+				color.x = c.x; color.y = c.y; color.z = c.z; color.w = c.w;
 			}
 			else
 			{
-				const int dims = (int)(st.N >> vi.x);
-				const size_t off = (size_t)v * chain + cubeMipOffset(st.N, vi.x);
-				color = CubeCast(st.cubeMaps + off, st.cubeDepths + off, dims, depthPix, lpt, rayDir);
+				// recompute the exit point exactly as in the peel loop (cheaper than keeping 8 float3 in registers)
+				vec3 lpt;
+				float z;
+				findExitFragment(po, localSpaceEyePt, dirW, lpt, z);
+				const vec3 rayDir = lpt - localSpaceEyePt;
+				if (!(vi.z & kCubeMapRayMarchBit))
+				{
+					// RayCast (RayCast.hlsli:43-108), inline fallback (sharded contexts, or more screen-space volumes than slots)
+					vec3 ro = localSpaceEyePt;
+					const vec3 rd = normalize3(rayDir);
+					color.x = color.y = color.z = color.w = 0.0f;
+					if (ComputeRayOrigin(ro, rd))
+					{
+						const float tMax = GetTMax(v3(nx, ny, depthPix), ro, rd, po.wvpI);
+						const VolumeView vol = makeVolumeView(st.volumes[vi.w], st.alphaCells[vi.w], st.N, st.bricks);
+						color = marchRay(vol, st.lightMaps + (size_t)v * st.L * st.L * st.L, st.L, ro, rd, tMax, vi.y, nSamples, nLit);
+					}
+				}
+				else
+				{
+					const int dims = (int)(st.N >> vi.x);
+					const size_t off = (size_t)v * chain + cubeMipOffset(st.N, vi.x);
+					color = CubeCast(st.cubeMaps + off, st.cubeDepths + off, dims, depthPix, lpt, rayDir);
+				}
 			}
 			if (color.w > 0.0f && color.w <= 1.0f)
 			{

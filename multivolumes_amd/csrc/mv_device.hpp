@@ -469,6 +469,49 @@ __device__ __forceinline__ vec3 GetLocalPos(float px, float py, uint32_t slice, 
 }
 
 
+// The fragment the reference's rasteriser produces for one volume at one pixel (VSCube.hlsl:51-76 with front-face
+// culling, MultiRayCaster.cpp:868, 897): the point where the pixel's view ray EXITS the cube, found analytically.
+// dirW = the pixel's world-space ray direction (from g_screenToWorld).  Returns false if the ray misses the cube or the
+// fragment would be clipped (w <= 0 or z outside [0, 1)).  Used by the composite and by the fused screen-space RayCast.
+__device__ __forceinline__ bool findExitFragment(const PerObject& po, vec3 eyeLocal, vec3 dirW, vec3& lpt, float& z)
+{
+	const vec3 d = mul33(dirW, po.worldI);
+	float tNear = -kFltMax, tFar = kFltMax;
+	int farAxis = -1;
+	bool miss = false;
+#pragma unroll
+	for (int a = 0; a < 3; ++a)
+	{
+		const float da = comp(d, a), oa = comp(eyeLocal, a);
+		if (da == 0.0f) { if (__builtin_fabsf(oa) > 1.0f) miss = true; continue; }
+		const float sgn = da > 0.0f ? 1.0f : -1.0f;
+		const float tn = (-sgn - oa) / da, tf = (sgn - oa) / da;
+		if (tn > tNear) tNear = tn;
+		if (tf < tFar) { tFar = tf; farAxis = a; }
+	}
+	if (miss || farAxis < 0 || !(tFar > 0.0f) || !(tNear <= tFar)) return false;
+
+	lpt = rayAt(eyeLocal, d, tFar);
+	lpt = v3(clampf(lpt.x, -1.0f, 1.0f), clampf(lpt.y, -1.0f, 1.0f), clampf(lpt.z, -1.0f, 1.0f));
+	const float snap = comp(d, farAxis) > 0.0f ? 1.0f : -1.0f;
+	if (farAxis == 0) lpt.x = snap; else if (farAxis == 1) lpt.y = snap; else lpt.z = snap;
+
+	vec4 lp; lp.x = lpt.x; lp.y = lpt.y; lp.z = lpt.z; lp.w = 1.0f;
+	const vec4 clip = mul44(lp, po.wvp);
+	if (!(clip.w > 0.0f)) return false;
+	z = clip.z / clip.w;
+	return z >= 0.0f && z < 1.0f;
+}
+
+// world-space direction of the view ray through NDC (nx, ny): unproject the near and far points with g_screenToWorld
+__device__ __forceinline__ vec3 pixelRayWorld(const CBPerFrame* cb, float nx, float ny)
+{
+	vec4 c0; c0.x = nx; c0.y = ny; c0.z = 0.0f; c0.w = 1.0f;
+	vec4 c1 = c0; c1.z = 1.0f;
+	const vec4 h0 = mul44(c0, cb->screenToWorld), h1 = mul44(c1, cb->screenToWorld);
+	return v3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w) - v3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w);
+}
+
 // Shared body of the view march (Sh/CSRayMarch.hlsl:111-155) and of the screen-space RayCast (Sh/RayCast.hlsli:56-104):
 // front-to-back accumulation with the adaptive step of GetStep.  Returns scatter (rgb already divided by 2 pi).
 // Per sample: one alpha-cell load decides :128; only lit samples fetch the 8 RGBA texels and the 2 light-map quads.

@@ -186,7 +186,8 @@ constexpr uint32_t kCullThreads = 512;
 
 __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 {
-	extern __shared__ uint32_t sInfo[];	// per volume: bit0 visible, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask
+	extern __shared__ uint32_t sInfo[];	// per volume: bit0 visible, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask; then V x 2 words of screen rectangle
+	uint32_t* sRect = sInfo + st.V;
 
 	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
@@ -265,8 +266,30 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 #pragma unroll
 		for (uint32_t k = 1; k < 6; ++k) projCov = projCov + __shfl(faceArea, (int)(baseLane + k));
 
+		// Conservative screen rectangle of the cube for the composite's per-tile volume skip: bounding box of the eight
+		// projected vertices, grown by one pixel; the whole viewport if any vertex is at or behind the eye plane.
+		float bx0 = vx, bx1 = vx, by0 = vy, by1 = vy, wMin = p.w;
+#pragma unroll
+		for (int o = 1; o < 8; o <<= 1)
+		{
+			bx0 = __builtin_fminf(bx0, __shfl_xor(bx0, o)); bx1 = __builtin_fmaxf(bx1, __shfl_xor(bx1, o));
+			by0 = __builtin_fminf(by0, __shfl_xor(by0, o)); by1 = __builtin_fmaxf(by1, __shfl_xor(by1, o));
+			wMin = __builtin_fminf(wMin, __shfl_xor(wMin, o));
+		}
+
 		if (li == 0u && valid)
 		{
+			ushort4 rect;
+			if (wMin > 1e-3f && bx0 == bx0 && by0 == by0)
+			{
+				rect.x = (uint16_t)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(bx0) - 1.0f, 0.0f), 65535.0f);
+				rect.y = (uint16_t)__builtin_fminf(__builtin_fmaxf(__builtin_floorf(by0) - 1.0f, 0.0f), 65535.0f);
+				rect.z = (uint16_t)__builtin_fminf(__builtin_fmaxf(__builtin_ceilf(bx1) + 1.0f, 0.0f), 65535.0f);
+				rect.w = (uint16_t)__builtin_fminf(__builtin_fmaxf(__builtin_ceilf(by1) + 1.0f, 0.0f), 65535.0f);
+			}
+			else { rect.x = 0; rect.y = 0; rect.z = 65535; rect.w = 65535; }
+			reinterpret_cast<ushort4*>(st.volumeRects)[volumeId] = rect;
+			sRect[2 * volumeId] = (uint32_t)rect.x | ((uint32_t)rect.y << 16); sRect[2 * volumeId + 1] = (uint32_t)rect.z | ((uint32_t)rect.w << 16);
 			uint32_t info = 0u;
 			if (volumeVis != 0u)
 			{
@@ -350,11 +373,45 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(minMip, o); minMip = m < minMip ? m : minMip; }
+
+	// Screen-space-scheme volumes (visible, cubeMapPix > projCov): their RayCast (RayCast.hlsli:43-108) is a march like
+	// any other, so it joins the same launch as extra 8x8 PIXEL tiles over the volume's screen rectangle and leaves its
+	// result in an fp32 layer the composite reads.  One slot per volume, up to st.screenSlots; the rest stay inline.
+	const uint32_t nCubeTiles = nTiles;
+	uint32_t nScreen = 0;
+	for (uint32_t base = 0; base < st.V; base += 64)
+	{
+		const uint32_t v = base + lane;
+		const uint32_t info = v < st.V ? sInfo[v] : 0u;
+		const bool scr = (info & 1u) && !(info & 2u);
+		const uint64_t bScr = __ballot(scr);
+		const uint32_t slot = nScreen + (uint32_t)__popcll(bScr & lower);
+		const bool take = scr && slot < st.screenSlots;
+		if (v < st.V) st.screenSlot[v] = take ? slot : 0xffffffffu;
+		uint32_t tiles = 0;
+		if (take)
+		{
+			const uint32_t r0 = sRect[2 * v], r1 = sRect[2 * v + 1];
+			const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16;
+			uint32_t x1 = r1 & 0xffffu, y1 = r1 >> 16;
+			x1 = x1 < st.W - 1u ? x1 : st.W - 1u; y1 = y1 < st.H - 1u ? y1 : st.H - 1u;
+			if (x0 <= x1 && y0 <= y1) tiles = ((x1 >> 3) - (x0 >> 3) + 1u) * ((y1 >> 3) - (y0 >> 3) + 1u);
+		}
+		uint32_t totE, totT;
+		const uint32_t eBase = nEntries + waveExclusiveScanU32(take ? 1u : 0u, lane, totE);
+		const uint32_t tBase = nTiles + waveExclusiveScanU32(tiles, lane, totT);
+		if (take)
+		{
+			st.workEntries[eBase] = v | (7u << 16);
+			st.workTileStart[eBase] = tBase;
+		}
+		nEntries += totE; nTiles += totT; nScreen += (uint32_t)__popcll(bScr);
+	}
 	if (lane == 0)
 	{
 		st.workTileStart[nEntries] = nTiles;
 		st.counters[0] = nVis; st.counters[1] = nCube; st.counters[2] = nEntries; st.counters[3] = nTiles;
-		st.counters[4] = nOwned; st.counters[5] = minMip == 0xffffffffu ? 0u : minMip;
+		st.counters[4] = nOwned; st.counters[5] = minMip == 0xffffffffu ? 0u : minMip; st.counters[6] = nCubeTiles;
 	}
 }
 
@@ -627,43 +684,87 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 
 	const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId];	// CSRayMarch.hlsl:81
 	const uint32_t mipLevel = vi.x, smpCount = vi.y, volTexId = vi.w;
-	const uint32_t dims = st.N >> mipLevel;
-	const uint32_t tilesX = (dims + 7u) >> 3;
-	const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
+	const PerObject& po = reinterpret_cast<const PerObject*>(st.perObject)[volumeId];
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	const bool screenTile = faceId == 7u;	// wave-uniform
 
+	// ---- ray setup: a cube-face texel (CSRayMarch.hlsl:84-107) or a screen pixel of a RayCast volume (RayCast.hlsli:43-54)
 	uint32_t nSamples = 0, nLit = 0, nRays = 0;
-	if (px < dims && py < dims)
+	bool valid = false;
+	vec3 rayOrigin = mul43(v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]), po.worldI);	// :89
+	vec3 rayDir = v3(0.0f, 0.0f, 1.0f);
+	float tMax = 0.0f;
+	size_t outIndex = 0;
+	if (!screenTile)
 	{
-		const PerObject& po = reinterpret_cast<const PerObject*>(st.perObject)[volumeId];
-		const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
-
-		vec3 rayOrigin = mul43(v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]), po.worldI);	// :89
-		const vec3 target = GetLocalPos((float)px, (float)py, faceId, (float)dims);
-		const vec3 rayDir = normalize3(target - rayOrigin);
-		if (ComputeRayOrigin(rayOrigin, rayDir))	// :96
+		const uint32_t dims = st.N >> mipLevel;
+		const uint32_t tilesX = (dims + 7u) >> 3;
+		const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
+		if (px < dims && py < dims)
 		{
-			float tMax = ComputeTargetHit(rayOrigin, target, rayDir);
-			const float stepScale = kMaxDist / (float)smpCount;
-			const size_t texel = (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
-
-			// GetClipPos (:59-71)
-			vec3 clip;
+			const vec3 target = GetLocalPos((float)px, (float)py, faceId, (float)dims);
+			rayDir = normalize3(target - rayOrigin);
+			if (ComputeRayOrigin(rayOrigin, rayDir))	// :96
 			{
-				vec4 hPos;
-				hPos.x = __builtin_fmaf(0.01f, rayDir.x, rayOrigin.x);
-				hPos.y = __builtin_fmaf(0.01f, rayDir.y, rayOrigin.y);
-				hPos.z = __builtin_fmaf(0.01f, rayDir.z, rayOrigin.z);
-				hPos.w = 1.0f;
-				hPos = mul44(hPos, po.wvp);
-				const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
-				const float u = cx * 0.5f + 0.5f;
-				float v = cy * 0.5f + 0.5f;
-				v = 1.0f - v;
-				clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
-			}
-			st.cubeDepths[texel] = clip.z;	// :105
-			tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
+				tMax = ComputeTargetHit(rayOrigin, target, rayDir);
+				outIndex = (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
 
+				// GetClipPos (:59-71)
+				vec3 clip;
+				{
+					vec4 hPos;
+					hPos.x = __builtin_fmaf(0.01f, rayDir.x, rayOrigin.x);
+					hPos.y = __builtin_fmaf(0.01f, rayDir.y, rayOrigin.y);
+					hPos.z = __builtin_fmaf(0.01f, rayDir.z, rayOrigin.z);
+					hPos.w = 1.0f;
+					hPos = mul44(hPos, po.wvp);
+					const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
+					const float u = cx * 0.5f + 0.5f;
+					float v = cy * 0.5f + 0.5f;
+					v = 1.0f - v;
+					clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
+				}
+				st.cubeDepths[outIndex] = clip.z;	// :105
+				tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
+				valid = true;
+				nRays = 1;
+			}
+		}
+	}
+	else
+	{
+		// screen rectangle of the volume, clipped to the viewport, in 8x8 pixel tiles
+		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
+		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
+		const uint32_t tx0 = rect.x >> 3, ty0 = rect.y >> 3, tw = (x1 >> 3) - tx0 + 1u;
+		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (ty0 + localTile / tw) * 8u + (lane >> 3);
+		if (px < st.W && py < st.H)
+		{
+			// PSCube.hlsl:37-39, then the fragment the rasteriser would have produced for this volume at this pixel
+			float nx = ((float)px + 0.5f) / (float)st.W, ny = ((float)py + 0.5f) / (float)st.H;
+			nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
+			vec3 lpt;
+			float z;
+			outIndex = ((size_t)st.screenSlot[volumeId] * st.H + py) * st.W + px;
+			if (findExitFragment(po, rayOrigin, pixelRayWorld(cb, nx, ny), lpt, z))
+			{
+				rayDir = normalize3(lpt - rayOrigin);	// PSCube.hlsl:33, 50: normalize(input.LPt - localSpaceEyePt)
+				float4 zero; zero.x = zero.y = zero.z = zero.w = 0.0f;
+				st.screenLayers[outIndex] = zero;	// RayCast returns 0 on a miss (RayCast.hlsli:46)
+				if (ComputeRayOrigin(rayOrigin, rayDir))
+				{
+					const float depthPix = st.depthMap[(size_t)py * st.W + px];
+					tMax = GetTMax(v3(nx, ny, depthPix), rayOrigin, rayDir, po.wvpI);	// RayCast.hlsli:50-51 (no ComputeTargetHit clamp)
+					valid = true;
+				}
+			}
+		}
+	}
+
+	if (valid)
+	{
+		{
+			const float stepScale = kMaxDist / (float)smpCount;
 			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
 			const uint4* lightQuads = st.lightMaps + (size_t)volumeId * st.L * st.L * st.L;
 
@@ -748,11 +849,18 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 			const float twoPi = 2.0f * kPI;
 			scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;	// :155
 
-			uint2 o;
-			o.x = (uint32_t)float_to_half_bits(scatter.x) | ((uint32_t)float_to_half_bits(scatter.y) << 16);
-			o.y = (uint32_t)float_to_half_bits(scatter.z) | ((uint32_t)float_to_half_bits(scatter.w) << 16);
-			st.cubeMaps[texel] = o;	// :157
-			nRays = 1;
+			if (!screenTile)
+			{
+				uint2 o;
+				o.x = (uint32_t)float_to_half_bits(scatter.x) | ((uint32_t)float_to_half_bits(scatter.y) << 16);
+				o.y = (uint32_t)float_to_half_bits(scatter.z) | ((uint32_t)float_to_half_bits(scatter.w) << 16);
+				st.cubeMaps[outIndex] = o;	// :157
+			}
+			else
+			{
+				float4 o; o.x = scatter.x; o.y = scatter.y; o.z = scatter.z; o.w = scatter.w;
+				st.screenLayers[outIndex] = o;	// what RayCast returns (RayCast.hlsli:107); the composite applies PSCube.hlsl:56
+			}
 		}
 	}
 
@@ -760,7 +868,13 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 	uint32_t maxS = nSamples;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
-	if (lane == 0 && tile < st.maxTiles)
+	const uint32_t nCubeTiles = st.counters[6];
+	if (lane == 0 && screenTile)
+	{
+		const uint32_t sIdx = tile - nCubeTiles;
+		if (sIdx < st.maxScreenTiles) { st.screenStats[2 * sIdx] += totS; st.screenStats[2 * sIdx + 1] += totL; }
+	}
+	else if (lane == 0 && tile < st.maxTiles)
 	{
 		// this tile slot belongs to this wavefront alone: plain read-modify-write, reduced by reduceStatsKernel on demand
 		ulonglong4* slot = reinterpret_cast<ulonglong4*>(st.tileStats) + tile;
@@ -774,7 +888,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 // Sums the per-wavefront counter slots into st.stats (run by mv_get_stats, not per frame).
 __global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st)
 {
-	unsigned long long a[6] = { 0, 0, 0, 0, 0, 0 };
+	unsigned long long a[7] = { 0, 0, 0, 0, 0, 0, 0 };	// [6] = lit samples of the fused RayCast tiles
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
 	for (uint32_t i = tid; i < st.maxTiles; i += nThreads)
 	{
@@ -783,8 +897,9 @@ __global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st)
 	}
 	for (uint32_t i = tid; i < st.lightBlocks; i += nThreads) a[3] += st.lightStats[i];
 	for (uint32_t i = tid; i < st.compositeSlots; i += nThreads) a[4] += st.compositeStats[i];
+	for (uint32_t i = tid; i < st.maxScreenTiles; i += nThreads) { a[4] += st.screenStats[2 * i]; a[6] += st.screenStats[2 * i + 1]; }
 #pragma unroll
-	for (int k = 0; k < 6; ++k)
+	for (int k = 0; k < 7; ++k)
 	{
 		unsigned long long v = a[k];
 #pragma unroll
@@ -858,7 +973,7 @@ void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, u
 
 void launchCull(hipStream_t s, const DeviceState& st)
 {
-	hipLaunchKernelGGL(cullKernel, dim3(1), dim3(kCullThreads), st.V * sizeof(uint32_t), s, st);
+	hipLaunchKernelGGL(cullKernel, dim3(1), dim3(kCullThreads), st.V * 3 * sizeof(uint32_t), s, st);
 }
 
 void launchMarchLight(hipStream_t s, const DeviceState& st)
@@ -870,7 +985,7 @@ void launchMarchLight(hipStream_t s, const DeviceState& st)
 void launchMarchView(hipStream_t s, const DeviceState& st)
 {
 	// Upper bound of the tile count (the real count is on the device, written by cullKernel): every owned volume at mip 0 with 6 faces.
-	const uint64_t maxTiles = marchViewMaxTiles(st.V, st.N, st.shardCount);
+	const uint64_t maxTiles = (uint64_t)marchViewMaxTiles(st.V, st.N, st.shardCount) + st.maxScreenTiles;
 	uint64_t blocks = (maxTiles + kMarchWaves - 1) / kMarchWaves;
 	blocks = ((blocks + 7) / 8) * 8;
 	static const int experiment = []() { const char* e = getenv("MV_EXPERIMENT"); return e ? atoi(e) : 0; }();

@@ -38,17 +38,21 @@ struct DeviceState
 	uint2* cubeMaps;				// V x chain RGBA16F texels
 	float* cubeDepths;				// V x chain
 	uint2* composite;				// W x H RGBA16F
+	float4* screenLayers;			// screenSlots x W x H fp32 RGBA: RayCast results of screen-space-scheme volumes (marched inside marchViewKernel)
+	uint32_t* screenSlot;			// V: slot of volume v in screenLayers, or 0xffffffff (composite then marches it inline)
+	uint32_t screenSlots;			// capacity
 
 	// cull outputs
 	uint16_t* volumeInfo;			// V x 4
 	uint32_t* visibleVolumes;		// V
 	uint32_t* cubeMapVolumes;		// V
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
-									// [4] owned visible count, [5] min selected mip over visible volumes
+									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow)
 	uint32_t* ownedVisible;			// V: visible volumes of this shard, ascending
-	uint32_t* workEntries;			// 6 V: volume | face << 16
-	uint32_t* workTileStart;		// 6 V + 1 prefix sums of 8x8 tiles
+	uint32_t* workEntries;			// 6 V + screenSlots: volume | face << 16 (face 7 = screen-space RayCast entry)
+	uint32_t* workTileStart;		// entries + 1 prefix sums of 8x8 tiles
 	uint64_t* cubeOffset;			// V: texel offset of the selected mip of volume v inside cubeMaps / cubeDepths
+	uint16_t* volumeRects;			// V x 4: conservative screen rectangle {x0, y0, x1, y1} (pixels, inclusive) of a visible volume
 	uint32_t* volumeFlags;			// V: bit0 visible this frame, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask
 
 	// Counters.  Every wavefront owns one slot and updates it with a plain read-modify-write (launches are stream
@@ -58,7 +62,8 @@ struct DeviceState
 	uint64_t* tileStats;			// maxTiles x 4: {view samples, lit samples, rays, lane slots} per marchV tile slot
 	uint64_t* lightStats;			// ceil(L/4)^3: light samples per marchL block
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
-	uint32_t maxTiles, lightBlocks, compositeSlots;
+	uint64_t* screenStats;			// maxScreenTiles x 2: {RayCast samples, lit} per screen tile marched by marchViewKernel
+	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles;
 };
 
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)

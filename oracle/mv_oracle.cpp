@@ -1115,6 +1115,13 @@ extern "C" void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, ui
 			float nx = ((float)px + 0.5f) / (float)W, ny = ((float)py + 0.5f) / (float)H;
 			nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
 			const float depthPix = depthMap[(size_t)py * W + px];
+			// the pixel's view ray in world space: unproject its near and far points with g_screenToWorld (Common.hlsli:43)
+			float3 dirW;
+			{
+				float4 c0 = { nx, ny, 0.0f, 1.0f }, c1 = { nx, ny, 1.0f, 1.0f };
+				const float4 h0 = mul44(c0, cb.screenToWorld), h1 = mul44(c1, cb.screenToWorld);
+				dirW = f3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w) - f3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w);
+			}
 
 			Fragment frags[MVO_NUM_OIT_LAYERS];
 			uint32_t nFrags = 0;
@@ -1123,10 +1130,7 @@ extern "C" void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, ui
 				const uint32_t v = visibleVolumes[k];
 				const PerObject& po = perObjects[v];
 				const float3 o = mul43(eyePt, po.worldI);
-				float4 c0 = { nx, ny, 0.0f, 1.0f }, c1 = { nx, ny, 1.0f, 1.0f };
-				const float4 h0 = mul44(c0, po.wvpI), h1 = mul44(c1, po.wvpI);
-				const float3 p0 = f3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w), p1 = f3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w);
-				const float3 d = p1 - p0;
+				const float3 d = mul33(dirW, po.worldI);	// the pixel's world-space ray direction in volume space
 
 				// slab test from the eye along d
 				float tNear = -kFltMax, tFar = kFltMax;

@@ -316,8 +316,7 @@ def test_composite_parity(oracle, name, W, H):
         assert exp_samples > 0
     with make_caster(cfg, M) as c:
         run_gpu(c, cfg, vols)
-        c.ResetStats()
-        c.composite()
+        c.composite()  # (the RayCast layers were marched by rayMarchV's screen tiles; composite_samples counts both places)
         got = c.ReadBackComposite()
         g, e = half_to_float(got), half_to_float(exp)
         diff = np.abs(g - e)
