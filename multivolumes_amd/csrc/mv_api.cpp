@@ -6,6 +6,7 @@
 // There is no CPU fallback: without a gfx950 device every entry point fails.
 #include "../../include/multivolumes.h"
 #include "mv_kernels.hpp"
+#include "mv_device.hpp"
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -38,6 +39,7 @@ struct mv_ctx
 	uint2** dVolumePtrs = nullptr;
 	uint4** dCellPtrs = nullptr;
 	uint32_t* lightStaging = nullptr;	// L^3 plain R11G11B10F (readback / upload conversion)
+	uint32_t* tileOrderBuf = nullptr;
 	uint2* staging = nullptr;			// N^3 linear RGBA16F (upload / readback re-tiling)
 	size_t stagingBytes = 0;
 	float* ownDepth = nullptr;
@@ -187,7 +189,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.maxRaySamples = 256; st.maxLightSamples = 96;	// MultiRayCaster.cpp:65-66
 	st.hasLightProbe = 0;
 
-	const size_t brickedBytes = (size_t)st.bricks * st.bricks * st.bricks * 64 * sizeof(uint2);
+	const size_t brickedBytes = mv::volBrickCount(st.bricks) * 64 * sizeof(uint2);	// padded brick pitches (mv_device.hpp)
 	const size_t chain = mv::cubeChainTexels(st.N);
 	const size_t L3 = (size_t)st.L * st.L * st.L;
 
@@ -247,6 +249,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.maxTiles = mv::marchViewMaxTiles(st.V, st.N, st.shardCount);
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
 	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
+	if ((rc = devAlloc(ctx, &ctx->tileOrderBuf, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.tileCost, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
@@ -649,7 +653,7 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 	{
 	case MV_BUF_VOLUME:
 		MV_REQUIRE(ctx, index < st.S, MV_ERR_RANGE, "volume source index out of range");
-		*d_ptr = ctx->volumes[index]; *bytes = (size_t)st.bricks * st.bricks * st.bricks * 64 * sizeof(uint2); return MV_OK;
+		*d_ptr = ctx->volumes[index]; *bytes = mv::volBrickCount(st.bricks) * 64 * sizeof(uint2); return MV_OK;
 	case MV_BUF_LIGHT_MAP:
 		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
 		*d_ptr = st.lightMaps + index * L3; *bytes = L3 * sizeof(uint4); return MV_OK;
@@ -665,6 +669,30 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 	case MV_BUF_SHADOW_MAP: *d_ptr = ctx->ownShadow; *bytes = (size_t)st.M * st.M * sizeof(uint16_t); return MV_OK;
 	default: return fail(ctx, MV_ERR_INVALID_ARG, "unknown buffer id");
 	}
+}
+
+/* diagnostic hooks (not part of the reference surface): read the per-tile cost of the last view march, set a dispatch order */
+int mv_debug_tile_costs(mv_ctx* ctx, uint16_t* dst, uint32_t* numTiles)
+{
+	if (!ctx || !dst || !numTiles) return MV_ERR_INVALID_ARG;
+	uint32_t counters[kNumCounters];
+	MV_HIP(ctx, hipMemcpyAsync(counters, ctx->st.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	*numTiles = counters[3];
+	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.tileCost, (size_t)counters[3] * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return MV_OK;
+}
+
+int mv_debug_set_tile_order(mv_ctx* ctx, const uint32_t* order, uint32_t n)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	if (!order) { ctx->st.tileOrder = nullptr; return MV_OK; }
+	MV_REQUIRE(ctx, n <= ctx->st.maxTiles + ctx->st.maxScreenTiles, MV_ERR_RANGE, "too many tiles");
+	MV_HIP(ctx, hipMemcpyAsync(ctx->tileOrderBuf, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->st.tileOrder = ctx->tileOrderBuf;
+	return MV_OK;
 }
 
 int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size_t* shard_bytes)

@@ -174,11 +174,22 @@ __device__ __forceinline__ Taps linearTaps(float coord01, uint32_t size, int off
 // x-fastest order.  A trilinear footprint (2x2x2 texels) then touches 1 brick 42 % of the time and at most 8,
 // instead of always 4 rows that are N*8 bytes (and N*N*8 bytes) apart in a linear layout.
 // Texel (x,y,z) -> element index (units of one RGBA16F texel):
+// Brick pitches are padded (row of bricks + 1, plane + 17 bricks): with power-of-two pitches the bricks one x-slab of a
+// march front touches are exactly 512 * bricks bytes apart and alias onto a few HBM channels (measured: a random tile
+// order ran 11 % faster than list order before the padding).
+#ifndef MV_BRICK_PAD
+#define MV_BRICK_PAD 1
+#endif
+__host__ __device__ __forceinline__ uint32_t brickPitchY(uint32_t bricks) { return MV_BRICK_PAD ? bricks + 1u : bricks; }
+__host__ __device__ __forceinline__ uint32_t brickPitchZ(uint32_t bricks) { return MV_BRICK_PAD ? bricks * (bricks + 1u) + 17u : bricks * bricks; }
+__host__ __device__ __forceinline__ size_t volBrickCount(uint32_t bricks) { return (size_t)bricks * brickPitchZ(bricks); }	// allocation, in bricks
+__host__ __device__ __forceinline__ size_t volBrickIndex(uint32_t bx, uint32_t by, uint32_t bz, uint32_t bricks)
+{
+	return (size_t)bz * brickPitchZ(bricks) + (size_t)by * brickPitchY(bricks) + bx;
+}
 __host__ __device__ __forceinline__ size_t volTexelIndex(uint32_t x, uint32_t y, uint32_t z, uint32_t bricksPerAxis)
 {
-	const uint32_t bx = x >> 2, by = y >> 2, bz = z >> 2;
-	const size_t brick = ((size_t)bz * bricksPerAxis + by) * bricksPerAxis + bx;
-	return brick * 64 + ((z & 3u) << 4) + ((y & 3u) << 2) + (x & 3u);
+	return volBrickIndex(x >> 2, y >> 2, z >> 2, bricksPerAxis) * 64 + ((z & 3u) << 4) + ((y & 3u) << 2) + (x & 3u);
 }
 
 // Global-address-space views: loads through them are global_load (SGPR base + 32-bit VGPR byte offset), not flat_load.
@@ -210,8 +221,8 @@ __device__ __forceinline__ VolumeView makeVolumeView(const uint2* texels, const 
 	v.base = (GlobalBytes)texels;
 	v.cells = (GlobalBytes)cells;
 	v.N = N;
-	v.strideY = bricks * 512u;
-	v.strideZ = bricks * bricks * 512u;
+	v.strideY = brickPitchY(bricks) * 512u;
+	v.strideZ = brickPitchZ(bricks) * 512u;
 	return v;
 }
 

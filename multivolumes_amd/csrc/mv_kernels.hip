@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void retileKernel(const uint2* __restrict__ li
 		const uint32_t x = bx * 4 + (in & 3), y = by * 4 + ((in >> 2) & 3), z = bz * 4 + (in >> 4);
 		uint2 t = make_uint2(0u, 0u);
 		if (x < N && y < N && z < N) t = linear[((size_t)z * N + y) * N + x];
-		bricked[i] = t;
+		bricked[volBrickIndex(bx, by, bz, bricks) * 64 + in] = t;
 	}
 }
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void initGridDataKernel(uint2* __restrict__ br
 			t.x = (uint32_t)float_to_half_bits(r) | ((uint32_t)float_to_half_bits(g) << 16);
 			t.y = (uint32_t)float_to_half_bits(b) | ((uint32_t)float_to_half_bits(a) << 16);
 		}
-		bricked[i] = t;
+		bricked[volBrickIndex(bx, by, bz, bricks) * 64 + in] = t;
 	}
 }
 
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void r32fToRGBA16FKernel(const float* __restri
 			t.x = one | (one << 16);
 			t.y = one | ((uint32_t)float_to_half_bits(a * 0.25f) << 16);
 		}
-		bricked[i] = t;
+		bricked[volBrickIndex(bx, by, bz, bricks) * 64 + in] = t;
 	}
 }
 
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void buildAlphaCellsKernel(const uint2* __rest
 			c.w = MV_A(x, y1, z1) | (MV_A(x1, y1, z1) << 16);
 #undef MV_A
 		}
-		cells[i] = c;
+		cells[volBrickIndex(bx, by, bz, bricks) * 64 + in] = c;
 	}
 }
 
@@ -412,6 +412,16 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		st.workTileStart[nEntries] = nTiles;
 		st.counters[0] = nVis; st.counters[1] = nCube; st.counters[2] = nEntries; st.counters[3] = nTiles;
 		st.counters[4] = nOwned; st.counters[5] = minMip == 0xffffffffu ? 0u : minMip; st.counters[6] = nCubeTiles;
+		// stride of the dispatch permutation slot -> tile = slot * stride mod nTiles: about nTiles / golden ratio, coprime with nTiles
+		uint32_t stride = (uint32_t)(((uint64_t)nTiles * 2654435769ull) >> 32) | 1u;
+		for (;;)
+		{
+			uint32_t a = stride, b = nTiles;
+			while (b) { const uint32_t r = a % b; a = b; b = r; }
+			if (a == 1u || nTiles < 2u) break;
+			stride += 2u;
+		}
+		st.counters[7] = nTiles < 2u ? 1u : stride;
 	}
 }
 
@@ -656,17 +666,24 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 	const uint32_t wave = threadIdx.x >> 6;
 	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
 
-	// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Give every XCD one contiguous eighth of
-	// the tile list so that neighbouring tiles -- which read neighbouring bricks -- share an L2.  Placement only
-	// affects speed: every tile is marched exactly once whatever the mapping.
-	const uint32_t nBlocks = (nTiles + kMarchWaves - 1u) / kMarchWaves;
-	const uint32_t perXcd = (nBlocks + 7u) >> 3;
-	const uint32_t xcd = blockIdx.x & 7u, idxInXcd = blockIdx.x >> 3;
-	if (idxInXcd >= perXcd) return;
-	uint32_t tile = __builtin_amdgcn_readfirstlane((xcd * perXcd + idxInXcd) * kMarchWaves + wave);
-	if (mapMode == 1u) tile = __builtin_amdgcn_readfirstlane(blockIdx.x * kMarchWaves + wave);	// diagnostic: dispatch order
-	if (tile >= nTiles) return;
-	if (mapMode == 2u) tile = nTiles - 1u - tile;	// diagnostic: reversed list
+	// Dispatch slot -> tile: plain list order (workgroups are dealt round-robin over the 8 XCDs, so every XCD sees an even
+	// mix of volumes and of cube / screen tiles).  Measured alternatives, kept as diagnostics (MV_TILE_MAP): 1 = golden-ratio
+	// stride permutation (equal at C3, 28 % slower at C3-stress: it gives up the L2 reuse between neighbouring tiles),
+	// 2 = one contiguous eighth of the list per XCD (17 % slower at C3: whole volumes, and all screen tiles, land on one XCD).
+	// Placement only affects speed: every tile is marched exactly once whatever the mapping.
+	const uint32_t slot = blockIdx.x * kMarchWaves + wave;
+	if (slot >= nTiles) return;
+	uint32_t tile = slot;
+	if (mapMode == 1u) tile = (uint32_t)(((uint64_t)slot * st.counters[7]) % nTiles);
+	else if (mapMode == 2u)
+	{
+		const uint32_t nBlocks = (nTiles + kMarchWaves - 1u) / kMarchWaves;
+		const uint32_t perXcd = (nBlocks + 7u) >> 3;
+		tile = ((blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3)) * kMarchWaves + wave;
+		if ((blockIdx.x >> 3) >= perXcd || tile >= nTiles) return;
+	}
+	tile = __builtin_amdgcn_readfirstlane(tile);
+	if (st.tileOrder) tile = __builtin_amdgcn_readfirstlane(st.tileOrder[slot]);
 
 	// find the work entry that owns this tile (wave-uniform)
 	uint32_t entry = 0;
@@ -868,6 +885,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 	uint32_t maxS = nSamples;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
+	if (lane == 0 && st.tileCost) st.tileCost[tile] = (uint16_t)(maxS > 65535u ? 65535u : maxS);
 	const uint32_t nCubeTiles = st.counters[6];
 	if (lane == 0 && screenTile)
 	{

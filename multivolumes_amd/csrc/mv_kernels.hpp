@@ -64,6 +64,8 @@ struct DeviceState
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
 	uint64_t* screenStats;			// maxScreenTiles x 2: {RayCast samples, lit} per screen tile marched by marchViewKernel
 	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles;
+	const uint32_t* tileOrder;		// optional permutation of the tile list (dispatch slot -> tile), longest tiles first; NULL = list order
+	uint16_t* tileCost;				// per tile: samples of its longest ray in the last launch (feeds the next frame's order)
 };
 
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)
