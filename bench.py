@@ -48,10 +48,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the ray-march path has no CPU fallback")
+    # MV_BENCH_SHARE_GPU=1 is a functional test mode for boxes with fewer GPUs than ranks: every rank uses cuda:0 and the
+    # collectives go through gloo (RCCL refuses two ranks on one device). Never used for reported numbers.
+    share_gpu = os.environ.get("MV_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if args.gpus != world and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
 
@@ -90,10 +98,9 @@ def main():
         caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
         caster.Render(composite=False)  # cull -> marchL -> marchV, stream ordered
         if world > 1 and with_exchange:
-            xbytes[0] += cube_xchg.run()  # pack -> RCCL all-gather -> unpack
+            info_h, vis_h, _, _ = caster.ReadBackCull()  # the one host sync of the frame: the exchange sizes depend on the cull
+            xbytes[0] += cube_xchg.run(info_h, vis_h)  # pack -> RCCL all-gather -> unpack
             if light_xchg is not None:
-                info_h = caster.ReadBackVolumeInfo()
-                vis_h, _ = caster.ReadBackVisibleLists()
                 xbytes[0] += light_xchg.run(info_h, vis_h, frame_idx)
         if do_composite:
             caster.composite(band[0], band[1])

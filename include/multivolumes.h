@@ -138,6 +138,10 @@ int mv_render(mv_ctx* ctx, int with_composite);
 
 /* CPU readback of the buffers the path emits (the reference's only "ReadBack" notion: XUSG.h:1614, 1860). */
 int mv_readback_volume_info(mv_ctx* ctx, uint16_t* dst /* V x 4 */);
+/* Everything the cull produced in ONE stream synchronisation (what a multi-GPU driver needs per frame): VolumeInfo[V],
+ * both lists with their counts, and the minimum selected mip over the visible volumes (the exchange slot size). */
+int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info /* V x 4 */, uint32_t* visible /* V */, uint32_t* visibleCount,
+	uint32_t* cubeMapVolumes /* V */, uint32_t* cubeMapCount, uint32_t* minMip);
 int mv_readback_visible_lists(mv_ctx* ctx, uint32_t* visible /* V */, uint32_t* visibleCount,
 	uint32_t* cubeMapVolumes /* V */, uint32_t* cubeMapCount);
 int mv_readback_volume(mv_ctx* ctx, uint32_t src, uint16_t* dst /* N^3 x 4 */);
@@ -172,12 +176,13 @@ uint64_t mv_cube_mip_offset(uint32_t N, uint32_t mip);
 
 /* ---- multi-GPU exchange: volumes shard v % shard_count; cube faces are all-gathered ---- */
 /* Bytes one rank contributes per frame: (V / shard_count) slots x slot_bytes, slot = 6 x d x d x (8 + 4) bytes with
- * d = N >> min selected mip over all visible volumes (identical on every rank because cull is replicated). */
+ * d = N >> min selected mip over all visible volumes (identical on every rank because cull is replicated).
+ * mv_exchange_layout synchronises the stream; pack / unpack take slot_dim from it (or from mv_readback_cull) and do not. */
 int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size_t* shard_bytes);
 /* Pack this shard's selected-mip cube faces (colour then depth per slot) into d_dst (device, shard_bytes). */
-int mv_exchange_pack(mv_ctx* ctx, void* d_dst);
+int mv_exchange_pack(mv_ctx* ctx, void* d_dst, uint32_t slot_dim);
 /* Scatter an all-gathered buffer (shard_count x shard_bytes, rank-major) back into the cube maps / depths of every volume. */
-int mv_exchange_unpack(mv_ctx* ctx, const void* d_src);
+int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim);
 
 #ifdef __cplusplus
 }

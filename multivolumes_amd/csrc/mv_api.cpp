@@ -57,6 +57,7 @@ struct mv_ctx
 	hipEvent_t sliceDone[kFrameSlices] = {};
 	uint64_t* pinnedStats = nullptr;
 	uint32_t* pinnedCounters = nullptr;
+	uint8_t* pinnedCull = nullptr;		// counters + VolumeInfo + both lists, one readback
 
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
 	bool profiling = false;
@@ -261,6 +262,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kFrameSlices + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices);
 	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices + 128);
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 16, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	for (uint32_t i = 0; i < kFrameSlices; ++i)
 		if (hipEventCreateWithFlags(&ctx->sliceDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 
@@ -286,6 +288,7 @@ void mv_destroy(mv_ctx* ctx)
 	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
 	for (void* p : ctx->allocs) (void)hipFree(p);
 	if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+	if (ctx->pinnedCull) (void)hipHostFree(ctx->pinnedCull);
 	if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -710,25 +713,43 @@ int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size
 	return MV_OK;
 }
 
-int mv_exchange_pack(mv_ctx* ctx, void* d_dst)
+int mv_exchange_pack(mv_ctx* ctx, void* d_dst, uint32_t slot_dim)
 {
 	if (!ctx || !d_dst) return MV_ERR_INVALID_ARG;
-	uint32_t d; size_t sb, tb;
-	const int rc = mv_exchange_layout(ctx, &d, &sb, &tb);
-	if (rc != MV_OK) return rc;
-	mv::launchExchangePack(ctx->stream, ctx->st, d, d_dst);
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	MV_REQUIRE(ctx, slot_dim >= 1 && slot_dim <= ctx->st.N, MV_ERR_RANGE, "slot_dim out of range");
+	mv::launchExchangePack(ctx->stream, ctx->st, slot_dim, d_dst);
 	MV_HIP(ctx, hipGetLastError());
 	return MV_OK;
 }
 
-int mv_exchange_unpack(mv_ctx* ctx, const void* d_src)
+int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim)
 {
 	if (!ctx || !d_src) return MV_ERR_INVALID_ARG;
-	uint32_t d; size_t sb, tb;
-	const int rc = mv_exchange_layout(ctx, &d, &sb, &tb);
-	if (rc != MV_OK) return rc;
-	mv::launchExchangeUnpack(ctx->stream, ctx->st, d, d_src);
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	MV_REQUIRE(ctx, slot_dim >= 1 && slot_dim <= ctx->st.N, MV_ERR_RANGE, "slot_dim out of range");
+	mv::launchExchangeUnpack(ctx->stream, ctx->st, slot_dim, d_src);
 	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+
+int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info, uint32_t* visible, uint32_t* visibleCount,
+	uint32_t* cubeMapVolumes, uint32_t* cubeMapCount, uint32_t* minMip)
+{
+	if (!ctx || !volume_info || !visible || !visibleCount || !cubeMapVolumes || !cubeMapCount || !minMip) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	const size_t V = ctx->st.V;
+	uint8_t* p = ctx->pinnedCull;
+	MV_HIP(ctx, hipMemcpyAsync(p, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipMemcpyAsync(p + 64, ctx->st.volumeInfo, V * 8, hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 8, ctx->st.visibleVolumes, V * 4, hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 12, ctx->st.cubeMapVolumes, V * 4, hipMemcpyDeviceToHost, ctx->stream));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	const uint32_t* counters = reinterpret_cast<const uint32_t*>(p);
+	*visibleCount = counters[0]; *cubeMapCount = counters[1]; *minMip = counters[5];
+	memcpy(volume_info, p + 64, V * 8);
+	memcpy(visible, p + 64 + V * 8, V * 4);
+	memcpy(cubeMapVolumes, p + 64 + V * 12, V * 4);
 	return MV_OK;
 }
 

@@ -90,17 +90,19 @@ class CubeFaceExchange:
         self._bytes = None
         self.send = self.recv = None
 
-    def run(self):
+    def run(self, volume_info, visible):
+        """volume_info / visible: this frame's (replicated) cull results, e.g. from caster.ReadBackCull()."""
         if self.world == 1:
             return 0
-        d, slot_bytes, shard_bytes = self.caster.ExchangeLayout()
+        c = self.caster
+        d, slot_bytes, shard_bytes = exchange_layout(c.gridSize, volume_info, visible, c.numVolumes, self.world)
         if shard_bytes != self._bytes:
             self.send = self.torch.empty(shard_bytes, dtype=self.torch.uint8, device="cuda")
             self.recv = self.torch.empty(shard_bytes * self.world, dtype=self.torch.uint8, device="cuda")
             self._bytes = shard_bytes
-        self.caster.ExchangePack(self.send.data_ptr())
+        c.ExchangePack(self.send.data_ptr(), d)
         self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        self.caster.ExchangeUnpack(self.recv.data_ptr())
+        c.ExchangeUnpack(self.recv.data_ptr(), d)
         return shard_bytes * self.world
 
 

@@ -321,8 +321,17 @@ class MultiRayCaster:
         self._check(self._lib.mv_exchange_layout(self._ctx, C.byref(d), C.byref(sb), C.byref(tb)), "mv_exchange_layout")
         return d.value, sb.value, tb.value
 
-    def ExchangePack(self, device_ptr):
-        self._check(self._lib.mv_exchange_pack(self._ctx, C.c_void_p(device_ptr)), "mv_exchange_pack")
+    def ExchangePack(self, device_ptr, slot_dim):
+        self._check(self._lib.mv_exchange_pack(self._ctx, C.c_void_p(device_ptr), slot_dim), "mv_exchange_pack")
 
-    def ExchangeUnpack(self, device_ptr):
-        self._check(self._lib.mv_exchange_unpack(self._ctx, C.c_void_p(device_ptr)), "mv_exchange_unpack")
+    def ExchangeUnpack(self, device_ptr, slot_dim):
+        self._check(self._lib.mv_exchange_unpack(self._ctx, C.c_void_p(device_ptr), slot_dim), "mv_exchange_unpack")
+
+    def ReadBackCull(self):
+        """(VolumeInfo[V,4], visible list, cube-map list, min selected mip) with a single stream synchronisation."""
+        info = np.zeros((self.numVolumes, 4), np.uint16)
+        vis = np.zeros(self.numVolumes, np.uint32)
+        cube = np.zeros(self.numVolumes, np.uint32)
+        nv, nc, mm = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self._lib.mv_readback_cull(self._ctx, _ptr(info), _ptr(vis), C.byref(nv), _ptr(cube), C.byref(nc), C.byref(mm)), "mv_readback_cull")
+        return info, vis[:nv.value].copy(), cube[:nc.value].copy(), mm.value

@@ -372,7 +372,9 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
             d, slot_bytes, shard_bytes = c.ExchangeLayout()
             assert (d, slot_bytes, shard_bytes) == D.exchange_layout(N, info, vis, V, world)
             buf = torch.zeros(shard_bytes, dtype=torch.uint8, device="cuda")
-            c.ExchangePack(buf.data_ptr())
+            c.ExchangePack(buf.data_ptr(), d)
+            info2, vis2, cube2, min_mip = c.ReadBackCull()
+            assert np.array_equal(info2, info) and np.array_equal(vis2, vis) and np.array_equal(cube2, cube) and (N >> min_mip) == d
             c.synchronize()
             packed.append(buf)
             st = c.GetStats()
@@ -388,7 +390,7 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
         assert tot_samples == ref_stats["view_samples"] and tot_rays == ref_stats["rays"]
         gathered = torch.cat(packed)
         for r, c in enumerate(shards):
-            c.ExchangeUnpack(gathered.data_ptr())
+            c.ExchangeUnpack(gathered.data_ptr(), d)
             # light maps of the other rank's volumes (needed by screen-space RayCast layers)
             for v in vis:
                 if int(v) % world != r:
