@@ -180,7 +180,10 @@ __device__ __forceinline__ vec4 CubeCast(const uint2* cubeMap, const float* cube
 	return color;
 }
 
-__global__ __launch_bounds__(64) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1)
+#ifndef MV_COMPOSITE_MIN_WAVES
+#define MV_COMPOSITE_MIN_WAVES 4
+#endif
+__global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t tilesX = (st.W + 7u) >> 3;

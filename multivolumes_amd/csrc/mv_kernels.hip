@@ -518,7 +518,10 @@ __device__ __forceinline__ vec3 EvaluateSHIrradiance(const float* sh, vec3 norm)
 // ---------------------------------------------------------------------------------------------
 // a2: light-space march.  One wavefront = one 4x4x4 block of light-map voxels (the reference's thread group).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
+#ifndef MV_LIGHT_MIN_WAVES
+#define MV_LIGHT_MIN_WAVES 4	// measured: 8 -> 0.150 ms, 6/4 -> 0.144 ms
+#endif
+__global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st)
 {
 	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
@@ -646,7 +649,10 @@ __global__ __launch_bounds__(64) void marchLightKernel(DeviceState st)
 // ---------------------------------------------------------------------------------------------
 // a3: view-space march into cube faces.  One wavefront = one 8x8 tile of one face of one volume.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kMarchWaves = 4;	// independent wavefronts per workgroup
+#ifndef MV_MARCH_WAVES
+#define MV_MARCH_WAVES 2	// measured at C3: 1 -> 0.357 ms, 2 -> 0.352, 4 -> 0.364, 8 -> 0.416
+#endif
+constexpr uint32_t kMarchWaves = MV_MARCH_WAVES;	// independent wavefronts per workgroup
 
 // X = 0 is the product kernel.  X != 0 are timing-only diagnostic variants (wrong results by construction) selected with
 // MV_EXPERIMENT=<X> to price one part of the loop: 1 = no light-map fetch, 2 = no colour fetch.
@@ -657,7 +663,8 @@ constexpr uint32_t kMarchWaves = 4;	// independent wavefronts per workgroup
 #define MV_PREDICT_LIT 1
 #endif
 #ifndef MV_MARCH_MIN_WAVES
-#define MV_MARCH_MIN_WAVES 5	// waves per SIMD the register allocator must leave room for (measured best)
+#define MV_MARCH_MIN_WAVES 3	// occupancy bound given to the register allocator / scheduler. Measured at C3 (same box): 3 -> 0.360 ms,
+								// 5 -> 0.395, 6 -> 0.414, 7 -> 0.46, 8 -> 0.60 (spills); all of 1..5 allocate 88 VGPRs, the looser bound schedules loads earlier
 #endif
 template <int X>
 __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchViewKernel(DeviceState st, uint32_t mapMode)
