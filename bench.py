@@ -33,6 +33,7 @@ def parse():
     p.add_argument("--config", default="C3", help="C1/C2/C3/C5/T1/T2 (default C3 = the config the metric is quoted on)")
     p.add_argument("--stress", action="store_true", help="C3-stress: force mip 0, all 6 faces (SURVEY 8d)")
     p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
+    p.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of frame i+1's light march with frame i's view march")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
     return p.parse_args()
@@ -70,6 +71,9 @@ def main():
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
     M = 1024
     flags = _lib.MV_FLAG_FORCE_MIP0_ALL_FACES if args.stress else 0
+    pipelined = world == 1 and not args.no_pipeline
+    if pipelined:
+        flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # two frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
     stream = torch.cuda.current_stream().cuda_stream
     caster = MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=M, device=local_rank,
                             stream=stream, flags=flags, shard=(rank, world))
@@ -175,6 +179,7 @@ def main():
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
+                "frames_in_flight": 2 if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes[0] // max(1, K + args.warmup),
             },

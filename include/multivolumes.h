@@ -58,6 +58,9 @@ extern "C" {
 /* mv_config.flags */
 #define MV_FLAG_NONE 0u
 #define MV_FLAG_FORCE_MIP0_ALL_FACES 1u	/* stress variant of SURVEY 8(d): cull forces mip 0, all 6 faces, cube-map scheme */
+#define MV_FLAG_PIPELINE_FRAMES 2u		/* two frames in flight (the reference keeps FrameCount = 3, MultiRayCaster.h:52): constant upload, cull and
+										   light march of frame i+1 run on a second stream while frame i's view march / composite finish.
+										   Results are identical; only readbacks (which synchronise both streams) observe the difference. */
 
 typedef struct mv_ctx mv_ctx;
 

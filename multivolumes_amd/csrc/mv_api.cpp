@@ -26,12 +26,33 @@ constexpr uint32_t kNumStats = 8;
 struct EventPair { hipEvent_t a, b; int stage; };
 }
 
+// Buffers that exist once per frame parity (constants + everything the cull writes): frame i+1's upload / cull / light march
+// (stream A) may then run while frame i's view march / composite (stream B) still read frame i's copies.
+struct FrameBufs
+{
+	void* dCb = nullptr;
+	void* dPerObject = nullptr;
+	uint16_t* volumeInfo = nullptr;
+	uint32_t *visibleVolumes = nullptr, *cubeMapVolumes = nullptr, *counters = nullptr, *ownedVisible = nullptr;
+	uint32_t *workEntries = nullptr, *workTileStart = nullptr;
+	uint64_t* cubeOffset = nullptr;
+	uint32_t* volumeFlags = nullptr;
+	uint16_t* volumeRects = nullptr;
+	uint32_t* screenSlot = nullptr;
+	uint4** lightTable = nullptr;
+};
+
 struct mv_ctx
 {
 	mv_config cfg;
-	hipStream_t stream = nullptr;
-	bool ownStream = false;
-	DeviceState st;
+	hipStream_t stream = nullptr;		// stream B: view march, composite, exchange, producers, readbacks
+	hipStream_t streamA = nullptr;		// stream A: constant upload, cull, light march (== stream unless MV_FLAG_PIPELINE_FRAMES)
+	bool ownStream = false, ownStreamA = false;
+	DeviceState st;						// always holds the CURRENT parity's pointers (applyParity)
+	FrameBufs fb[2];
+	uint32_t parity = 0;
+	hipEvent_t evStageA[2] = {}, evMainDone[2] = {}, evProducers = nullptr;
+	bool producersDirty = false;
 
 	// owned device allocations
 	std::vector<uint2*> volumes;
@@ -44,8 +65,6 @@ struct mv_ctx
 	size_t stagingBytes = 0;
 	float* ownDepth = nullptr;
 	uint16_t* ownShadow = nullptr;
-	void* dCb = nullptr;
-	void* dPerObject = nullptr;
 	uint32_t* dDescs = nullptr;
 	float* dSh = nullptr;
 	std::vector<void*> allocs;			// everything to hipFree
@@ -96,19 +115,47 @@ int devAlloc(mv_ctx* ctx, T** out, size_t bytes, bool zero = true)
 	return MV_OK;
 }
 
-void beginStage(mv_ctx* ctx, int stage, EventPair& ev)
+void applyParity(mv_ctx* ctx)
+{
+	const FrameBufs& f = ctx->fb[ctx->parity];
+	const FrameBufs& q = ctx->fb[ctx->parity ^ 1u];
+	DeviceState& st = ctx->st;
+	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
+	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
+	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
+	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot;
+	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo;
+}
+
+int syncAll(mv_ctx* ctx)
+{
+	if (ctx->streamA != ctx->stream)
+	{
+		const hipError_t e = hipStreamSynchronize(ctx->streamA);
+		if (e != hipSuccess) return (int)e;
+	}
+	return (int)hipStreamSynchronize(ctx->stream);
+}
+
+// stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
+void stageADone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evStageA[ctx->parity], ctx->streamA); }
+void stageBBegin(mv_ctx* ctx) { (void)hipStreamWaitEvent(ctx->stream, ctx->evStageA[ctx->parity], 0); }
+// stage of stream B finished being enqueued: the next user of this parity's buffers (two frames on) waits for it
+void stageBDone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evMainDone[ctx->parity], ctx->stream); }
+
+void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
 {
 	if (!ctx->profiling) return;
 	if (!ctx->freeEvents.empty()) { ev = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); }
 	else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
 	ev.stage = stage;
-	(void)hipEventRecord(ev.a, ctx->stream);
+	(void)hipEventRecord(ev.a, stream);
 }
 
-void endStage(mv_ctx* ctx, EventPair& ev)
+void endStage(mv_ctx* ctx, EventPair& ev, hipStream_t stream)
 {
 	if (!ctx->profiling) return;
-	(void)hipEventRecord(ev.b, ctx->stream);
+	(void)hipEventRecord(ev.b, stream);
 	ctx->pending.push_back(ev);
 }
 
@@ -183,6 +230,20 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		ctx->ownStream = true;
 	}
 
+	ctx->streamA = ctx->stream;
+	if (cfg->flags & MV_FLAG_PIPELINE_FRAMES)
+	{
+		// highest priority: stream A's short kernels (cull = one workgroup, light march) must not queue behind the
+		// thousands of view-march workgroups of the previous frame, or the overlap is lost
+		int prLow = 0, prHigh = 0;
+		(void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
+		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
+		ctx->ownStreamA = true;
+	}
+	for (int i = 0; i < 2; ++i)
+		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
+	if (hipEventCreateWithFlags(&ctx->evProducers, hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
+
 	DeviceState& st = ctx->st;
 	st.N = cfg->grid_size; st.bricks = (cfg->grid_size + 3u) >> 2; st.L = cfg->light_grid_size;
 	st.V = cfg->num_volumes; st.S = cfg->num_volume_srcs; st.W = cfg->viewport_w; st.H = cfg->viewport_h; st.M = cfg->shadow_map_size;
@@ -215,7 +276,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &ctx->staging, ctx->stagingBytes, false)) != MV_OK) return bail(rc);
 
 	// lightMaps[V], cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-126), all zero-initialised
-	if ((rc = devAlloc(ctx, &st.lightMaps, (size_t)st.V * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * 2 * L3 * sizeof(uint4))) != MV_OK) return bail(rc);	// two buffers per volume
 	if ((rc = devAlloc(ctx, &ctx->lightStaging, L3 * sizeof(uint32_t), false)) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
@@ -225,27 +286,39 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.depthMap = ctx->ownDepth; st.shadowMap = ctx->ownShadow;
 
 	// createVolumeInfoBuffers (MultiRayCaster.cpp:455-549)
-	if ((rc = devAlloc(ctx, &ctx->dCb, 256)) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &ctx->dPerObject, (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->dDescs, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->dSh, 27 * sizeof(float))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.volumeInfo, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.visibleVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.cubeMapVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.counters, kNumCounters * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	// RayCast layers of screen-space-scheme volumes are marched inside the view-march launch (single-GPU contexts) into
 	// fp32 RGBA layers; volumes beyond the slot capacity fall back to marching inside the composite.
 	st.screenSlots = st.shardCount > 1 ? 0u : (st.V < 8u ? st.V : 8u);
 	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
 	if ((rc = devAlloc(ctx, &st.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.screenSlot, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.workEntries, ((size_t)st.V * 6 + st.screenSlots) * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.workTileStart, ((size_t)st.V * 6 + st.screenSlots + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.cubeOffset, (size_t)st.V * sizeof(uint64_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
+	// constants + cull outputs, once per frame parity (FrameBufs)
+	{
+		std::vector<uint4*> table(st.V);
+		for (uint32_t v = 0; v < st.V; ++v) table[v] = st.lightBuffers + (size_t)(2u * v) * L3;
+		for (int p = 0; p < 2; ++p)
+		{
+			FrameBufs& f = ctx->fb[p];
+			if ((rc = devAlloc(ctx, &f.dCb, 256)) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.dPerObject, (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.volumeInfo, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.visibleVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.cubeMapVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.counters, kNumCounters * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.screenSlot, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.workEntries, ((size_t)st.V * 6 + st.screenSlots) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.workTileStart, ((size_t)st.V * 6 + st.screenSlots + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.cubeOffset, (size_t)st.V * sizeof(uint64_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.lightTable, (size_t)st.V * sizeof(uint4*), false)) != MV_OK) return bail(rc);
+			if (hipMemcpyAsync(f.lightTable, table.data(), (size_t)st.V * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+		}
+		if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	}
 	if ((rc = devAlloc(ctx, &st.stats, kNumStats * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	st.maxTiles = mv::marchViewMaxTiles(st.V, st.N, st.shardCount);
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
@@ -255,7 +328,9 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &st.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
-	st.cbPerFrame = ctx->dCb; st.perObject = ctx->dPerObject; st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
+	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
+	ctx->parity = 0;
+	applyParity(ctx);
 
 	// pinned upload ring + readback scratch
 	ctx->sliceBytes = 256 + (size_t)st.V * MV_PER_OBJECT_BYTES;
@@ -282,8 +357,11 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 void mv_destroy(mv_ctx* ctx)
 {
 	if (!ctx) return;
-	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx->stream) (void)syncAll(ctx);
 	foldEvents(ctx);
+	for (int i = 0; i < 2; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); }
+	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
+	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
 	for (EventPair& ev : ctx->freeEvents) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
 	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
 	for (void* p : ctx->allocs) (void)hipFree(p);
@@ -301,7 +379,7 @@ int mv_volume_upload_rgba16f(mv_ctx* ctx, uint32_t src, const uint16_t* rgba)
 	mv::launchRetile(ctx->stream, ctx->staging, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));	// the caller may reuse `rgba` and the staging buffer is shared
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the caller may reuse `rgba` and the staging buffer is shared
 	return MV_OK;
 }
 
@@ -312,6 +390,8 @@ int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgb
 	mv::launchRetile(ctx->stream, reinterpret_cast<const uint2*>(d_rgba), ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, hipEventRecord(ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
+	ctx->producersDirty = true;
 	return MV_OK;
 }
 
@@ -322,6 +402,8 @@ int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src)
 	mv::launchInitGridData(ctx->stream, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, hipEventRecord(ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
+	ctx->producersDirty = true;
 	return MV_OK;
 }
 
@@ -357,7 +439,7 @@ int mv_set_volume_descs(mv_ctx* ctx, const uint32_t* packed)
 		MV_REQUIRE(ctx, mips >= 1 && mips <= MV_NUM_CUBE_MIP, MV_ERR_INVALID_ARG, "VolumeDesc.NumMips must be 1..5");
 	}
 	MV_HIP(ctx, hipMemcpyAsync(ctx->dDescs, packed, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -365,7 +447,7 @@ int mv_set_depth_map(mv_ctx* ctx, const float* d32)
 {
 	if (!ctx || !d32) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, hipMemcpyAsync(ctx->ownDepth, d32, (size_t)ctx->st.W * ctx->st.H * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	ctx->st.depthMap = ctx->ownDepth;
 	ctx->haveDepth = true;
 	return MV_OK;
@@ -375,7 +457,7 @@ int mv_set_shadow_map(mv_ctx* ctx, const uint16_t* d16)
 {
 	if (!ctx || !d16) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, hipMemcpyAsync(ctx->ownShadow, d16, (size_t)ctx->st.M * ctx->st.M * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	ctx->st.shadowMap = ctx->ownShadow;
 	ctx->haveShadow = true;
 	return MV_OK;
@@ -403,7 +485,7 @@ int mv_set_sh(mv_ctx* ctx, const float* sh27)
 	if (sh27)
 	{
 		MV_HIP(ctx, hipMemcpyAsync(ctx->dSh, sh27, 27 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-		MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	}
 	ctx->st.hasLightProbe = sh27 ? 1u : 0u;
 	return MV_OK;
@@ -422,15 +504,23 @@ int mv_set_max_samples(mv_ctx* ctx, uint32_t maxRaySamples, uint32_t maxLightSam
 int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 {
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
+	// a new frame: switch to the other parity's constants / cull buffers
+	ctx->parity ^= 1u;
+	applyParity(ctx);
+	// its previous user (two frames ago) must be done with them; volume producers on stream B must have finished
+	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->parity], 0));
+	if (ctx->producersDirty) { MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evProducers, 0)); ctx->producersDirty = false; }
 	const uint32_t k = ctx->slice;
 	ctx->slice = (k + 1) % kFrameSlices;
 	MV_HIP(ctx, hipEventSynchronize(ctx->sliceDone[k]));	// slice k was last used three frames ago
 	uint8_t* s = ctx->pinned + (size_t)k * ctx->sliceBytes;
 	memcpy(s, cbPerFrame, MV_CB_PER_FRAME_BYTES);
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
-	MV_HIP(ctx, hipMemcpyAsync(ctx->dCb, s, MV_CB_PER_FRAME_BYTES, hipMemcpyHostToDevice, ctx->stream));
-	MV_HIP(ctx, hipMemcpyAsync(ctx->dPerObject, s + 256, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES, hipMemcpyHostToDevice, ctx->stream));
-	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->stream));
+	const FrameBufs& f = ctx->fb[ctx->parity];
+	MV_HIP(ctx, hipMemcpyAsync(f.dCb, s, MV_CB_PER_FRAME_BYTES, hipMemcpyHostToDevice, ctx->streamA));
+	MV_HIP(ctx, hipMemcpyAsync(f.dPerObject, s + 256, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES, hipMemcpyHostToDevice, ctx->streamA));
+	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->streamA));
+	stageADone(ctx);
 	ctx->haveFrame = true;
 	return MV_OK;
 }
@@ -440,10 +530,11 @@ int mv_cull(mv_ctx* ctx)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveFrame, MV_ERR_NOT_READY, "mv_update_frame has not been called");
 	EventPair ev;
-	beginStage(ctx, 0, ev);
-	mv::launchCull(ctx->stream, ctx->st);
-	endStage(ctx, ev);
+	beginStage(ctx, 0, ev, ctx->streamA);
+	mv::launchCull(ctx->streamA, ctx->st);
+	endStage(ctx, ev, ctx->streamA);
 	MV_HIP(ctx, hipGetLastError());
+	stageADone(ctx);
 	ctx->haveCull = true;
 	return MV_OK;
 }
@@ -454,10 +545,11 @@ int mv_march_light(mv_ctx* ctx)
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
 	EventPair ev;
-	beginStage(ctx, 1, ev);
-	mv::launchMarchLight(ctx->stream, ctx->st);
-	endStage(ctx, ev);
+	beginStage(ctx, 1, ev, ctx->streamA);
+	mv::launchMarchLight(ctx->streamA, ctx->st);
+	endStage(ctx, ev, ctx->streamA);
 	MV_HIP(ctx, hipGetLastError());
+	stageADone(ctx);
 	return MV_OK;
 }
 
@@ -466,11 +558,13 @@ int mv_march_view(mv_ctx* ctx)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
+	stageBBegin(ctx);
 	EventPair ev;
-	beginStage(ctx, 2, ev);
+	beginStage(ctx, 2, ev, ctx->stream);
 	mv::launchMarchView(ctx->stream, ctx->st);
-	endStage(ctx, ev);
+	endStage(ctx, ev, ctx->stream);
 	MV_HIP(ctx, hipGetLastError());
+	stageBDone(ctx);
 	return MV_OK;
 }
 
@@ -481,11 +575,13 @@ int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
 	if (row1 == 0 || row1 > ctx->st.H) row1 = ctx->st.H;
 	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
+	stageBBegin(ctx);
 	EventPair ev;
-	beginStage(ctx, 3, ev);
+	beginStage(ctx, 3, ev, ctx->stream);
 	mv::launchComposite(ctx->stream, ctx->st, row0, row1);
-	endStage(ctx, ev);
+	endStage(ctx, ev, ctx->stream);
 	MV_HIP(ctx, hipGetLastError());
+	stageBDone(ctx);
 	return MV_OK;
 }
 
@@ -502,19 +598,21 @@ int mv_render(mv_ctx* ctx, int with_composite)
 int mv_readback_volume_info(mv_ctx* ctx, uint16_t* dst)
 {
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.volumeInfo, (size_t)ctx->st.V * 4 * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
 int mv_readback_visible_lists(mv_ctx* ctx, uint32_t* visible, uint32_t* visibleCount, uint32_t* cubeMapVolumes, uint32_t* cubeMapCount)
 {
 	if (!ctx || !visible || !visibleCount || !cubeMapVolumes || !cubeMapCount) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	uint32_t counters[kNumCounters];
 	MV_HIP(ctx, hipMemcpyAsync(counters, ctx->st.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, hipMemcpyAsync(visible, ctx->st.visibleVolumes, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, hipMemcpyAsync(cubeMapVolumes, ctx->st.cubeMapVolumes, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	*visibleCount = counters[0];
 	*cubeMapCount = counters[1];
 	return MV_OK;
@@ -527,7 +625,14 @@ int mv_readback_volume(mv_ctx* ctx, uint32_t src, uint16_t* dst)
 	mv::launchUntile(ctx->stream, ctx->volumes[src], ctx->staging, ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->staging, ctx->stagingBytes, hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	return MV_OK;
+}
+
+static int currentLightBuffer(mv_ctx* ctx, uint32_t volume, uint4** out)
+{
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	MV_HIP(ctx, hipMemcpy(out, ctx->st.lightTable + volume, sizeof(uint4*), hipMemcpyDeviceToHost));
 	return MV_OK;
 }
 
@@ -536,10 +641,13 @@ int mv_readback_light_map(mv_ctx* ctx, uint32_t volume, uint32_t* dst)
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
 	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
-	mv::launchLightFromQuads(ctx->stream, ctx->st.lightMaps + volume * L3, ctx->lightStaging, ctx->st.L);
+	uint4* buf = nullptr;
+	const int rc = currentLightBuffer(ctx, volume, &buf);
+	if (rc != MV_OK) return rc;
+	mv::launchLightFromQuads(ctx->stream, buf, ctx->lightStaging, ctx->st.L);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->lightStaging, L3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -548,10 +656,13 @@ int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src)
 	if (!ctx || !src) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
 	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
+	uint4* buf = nullptr;
+	const int rc = currentLightBuffer(ctx, volume, &buf);
+	if (rc != MV_OK) return rc;
 	MV_HIP(ctx, hipMemcpyAsync(ctx->lightStaging, src, L3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	mv::launchLightToQuads(ctx->stream, ctx->lightStaging, ctx->st.lightMaps + volume * L3, ctx->st.L);
+	mv::launchLightToQuads(ctx->stream, ctx->lightStaging, buf, ctx->st.L);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -562,7 +673,7 @@ int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* d
 	const size_t d = ctx->st.N >> mip;
 	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.cubeMaps + off, 6 * d * d * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -573,7 +684,7 @@ int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* ds
 	const size_t d = ctx->st.N >> mip;
 	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.cubeDepths + off, 6 * d * d * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -581,7 +692,7 @@ int mv_readback_composite(mv_ctx* ctx, uint16_t* dst)
 {
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.composite, (size_t)ctx->st.W * ctx->st.H * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -597,11 +708,12 @@ int mv_clear_cube_maps(mv_ctx* ctx)
 int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 {
 	if (!ctx || !out) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
 	mv::launchReduceStats(ctx->stream, ctx->st);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedStats, ctx->st.stats, kNumStats * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	foldEvents(ctx);
 	memset(out, 0, sizeof(*out));
 	out->view_samples = ctx->pinnedStats[0];
@@ -619,7 +731,8 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 int mv_reset_stats(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	foldEvents(ctx);
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
@@ -640,7 +753,7 @@ int mv_set_profiling(mv_ctx* ctx, int on)
 int mv_synchronize(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -659,7 +772,12 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 		*d_ptr = ctx->volumes[index]; *bytes = mv::volBrickCount(st.bricks) * 64 * sizeof(uint2); return MV_OK;
 	case MV_BUF_LIGHT_MAP:
 		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
-		*d_ptr = st.lightMaps + index * L3; *bytes = L3 * sizeof(uint4); return MV_OK;
+		{
+			uint4* buf = nullptr;
+			const int rc = currentLightBuffer(ctx, index, &buf);	// the buffer the current frame reads (synchronises)
+			if (rc != MV_OK) return rc;
+			*d_ptr = buf; *bytes = L3 * sizeof(uint4); return MV_OK;
+		}
 	case MV_BUF_CUBE_MAP:
 		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
 		*d_ptr = st.cubeMaps + index * chain; *bytes = chain * sizeof(uint2); return MV_OK;
@@ -680,10 +798,10 @@ int mv_debug_tile_costs(mv_ctx* ctx, uint16_t* dst, uint32_t* numTiles)
 	if (!ctx || !dst || !numTiles) return MV_ERR_INVALID_ARG;
 	uint32_t counters[kNumCounters];
 	MV_HIP(ctx, hipMemcpyAsync(counters, ctx->st.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	*numTiles = counters[3];
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.tileCost, (size_t)counters[3] * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -693,7 +811,7 @@ int mv_debug_set_tile_order(mv_ctx* ctx, const uint32_t* order, uint32_t n)
 	if (!order) { ctx->st.tileOrder = nullptr; return MV_OK; }
 	MV_REQUIRE(ctx, n <= ctx->st.maxTiles + ctx->st.maxScreenTiles, MV_ERR_RANGE, "too many tiles");
 	MV_HIP(ctx, hipMemcpyAsync(ctx->tileOrderBuf, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	ctx->st.tileOrder = ctx->tileOrderBuf;
 	return MV_OK;
 }
@@ -702,8 +820,9 @@ int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size
 {
 	if (!ctx || !slot_dim || !slot_bytes || !shard_bytes) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	stageBBegin(ctx);
 	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedCounters, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	const uint32_t minMip = ctx->pinnedCounters[5] < MV_NUM_CUBE_MIP ? ctx->pinnedCounters[5] : 0u;
 	const uint32_t d = ctx->st.N >> minMip;
 	*slot_dim = d;
@@ -738,13 +857,14 @@ int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info, uint32_t* visible, uint
 {
 	if (!ctx || !volume_info || !visible || !visibleCount || !cubeMapVolumes || !cubeMapCount || !minMip) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	stageBBegin(ctx);	// the copies below run on stream B and read what stream A's cull wrote
 	const size_t V = ctx->st.V;
 	uint8_t* p = ctx->pinnedCull;
 	MV_HIP(ctx, hipMemcpyAsync(p, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, hipMemcpyAsync(p + 64, ctx->st.volumeInfo, V * 8, hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 8, ctx->st.visibleVolumes, V * 4, hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 12, ctx->st.cubeMapVolumes, V * 4, hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	const uint32_t* counters = reinterpret_cast<const uint32_t*>(p);
 	*visibleCount = counters[0]; *cubeMapCount = counters[1]; *minMip = counters[5];
 	memcpy(volume_info, p + 64, V * 8);

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 					{
 						const float tMax = GetTMax(v3(nx, ny, depthPix), ro, rd, po.wvpI);
 						const VolumeView vol = makeVolumeView(st.volumes[vi.w], st.alphaCells[vi.w], st.N, st.bricks);
-						color = marchRay(vol, st.lightMaps + (size_t)v * st.L * st.L * st.L, st.L, ro, rd, tMax, vi.y, nSamples, nLit);
+						color = marchRay(vol, st.lightTable[v], st.L, ro, rd, tMax, vi.y, nSamples, nLit);
 					}
 				}
 				else

@@ -173,6 +173,18 @@ __global__ __launch_bounds__(256) void lightFromQuadsKernel(const uint4* __restr
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) linear[i] = quads[i].x;
 }
 
+// The volume CSRayMarchL.hlsl:29-33 relights this frame: visible[frameIdx % visibleCount], else frameIdx % V.
+// Sharded contexts round-robin over their OWN visible volumes (and own volumes when nothing is visible).
+__device__ __forceinline__ uint32_t relitVolume(const DeviceState& st, uint32_t frameIdx, uint32_t ownedCount, const uint32_t* ownedVisible)
+{
+	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
+	if (ownedCount) return ownedVisible[frameIdx % ownedCount];
+	if (shardCount == 1u) return frameIdx % st.V;
+	const uint32_t ownedTotal = st.V > st.shardIndex ? (st.V - st.shardIndex + shardCount - 1u) / shardCount : 0u;
+	if (ownedTotal == 0u) return 0xffffffffu;
+	return st.shardIndex + shardCount * (frameIdx % ownedTotal);
+}
+
 // ---------------------------------------------------------------------------------------------
 // a1: volume cull.  One workgroup of 8 wavefronts; each wavefront culls 8 volumes (8 lanes = 8 cube vertices each).
 // After the cull the first wavefront compacts the visible / cube-map lists in ascending volume order and builds the
@@ -324,6 +336,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 				reinterpret_cast<ushort4*>(st.volumeInfo)[volumeId] = out;
 				info = 1u | (useCubeMap ? 2u : 0u) | (mipLevel << 2) | ((faceMask & 0x3fu) << 5);
 			}
+			else reinterpret_cast<ushort4*>(st.volumeInfo)[volumeId] = reinterpret_cast<const ushort4*>(st.volumeInfoPrev)[volumeId];	// CSVolumeCull.hlsl:38 returns without writing
 			sInfo[volumeId] = info;
 		}
 	}
@@ -373,6 +386,36 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(minMip, o); minMip = m < minMip ? m : minMip; }
+
+	// This frame's light-map table = last frame's, with the volume about to be relit switched to its other buffer.
+	{
+		uint32_t relit;
+		const uint32_t sc = st.shardCount ? st.shardCount : 1u;
+		if (nOwned)
+		{
+			// the (frameIdx % nOwned)-th owned visible volume, found in the flags (the list itself was written by other lanes)
+			const uint32_t want = cb->frameIdx % nOwned;
+			uint32_t seen = 0; relit = 0xffffffffu;
+			for (uint32_t base = 0; base < st.V; base += 64)
+			{
+				const uint32_t v = base + lane;
+				const bool ov = v < st.V && (sInfo[v] & 1u) && (v % sc) == st.shardIndex;
+				const uint64_t b = __ballot(ov);
+				const uint32_t rank = seen + (uint32_t)__popcll(b & lower);
+				const uint64_t hit = __ballot(ov && rank == want);
+				if (hit) { relit = base + (uint32_t)__ffsll((unsigned long long)hit) - 1u; break; }
+				seen += (uint32_t)__popcll(b);
+			}
+		}
+		else relit = relitVolume(st, cb->frameIdx, 0u, nullptr);
+		const size_t L3 = (size_t)st.L * st.L * st.L;
+		for (uint32_t v = lane; v < st.V; v += 64)
+		{
+			uint4* p = st.lightTablePrev[v];
+			if (v == relit) p = (p == st.lightBuffers + (size_t)(2u * v) * L3) ? st.lightBuffers + (size_t)(2u * v + 1u) * L3 : st.lightBuffers + (size_t)(2u * v) * L3;
+			st.lightTable[v] = p;
+		}
+	}
 
 	// Screen-space-scheme volumes (visible, cubeMapPix > projCov): their RayCast (RayCast.hlsli:43-108) is a march like
 	// any other, so it joins the same launch as extra 8x8 PIXEL tiles over the volume's screen rectangle and leaves its
@@ -527,17 +570,8 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 
 	// CSRayMarchL.hlsl:29-33 (sharded contexts round-robin over their own visible volumes)
-	const uint32_t ownedCount = st.counters[4];
-	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
-	uint32_t volumeId;
-	if (ownedCount) volumeId = st.ownedVisible[cb->frameIdx % ownedCount];
-	else if (shardCount == 1u) volumeId = cb->frameIdx % st.V;
-	else
-	{
-		const uint32_t ownedTotal = (st.V - st.shardIndex + shardCount - 1u) / shardCount;
-		if (ownedTotal == 0u) return;
-		volumeId = st.shardIndex + shardCount * (cb->frameIdx % ownedTotal);
-	}
+	uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[4], st.ownedVisible);
+	if (volumeId == 0xffffffffu) return;
 	volumeId = __builtin_amdgcn_readfirstlane(volumeId);
 
 	const uint32_t L = st.L;
@@ -629,7 +663,7 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 		// quad-replicated store (see mv_device.hpp "light maps"): texel (x, y) is slot (sx, sy) of every cell (cx, cy)
 		// with min(cx + sx, L-1) == x and min(cy + sy, L-1) == y
 		const uint32_t packed = pack_r11g11b10f(result.x, result.y, result.z);
-		uint32_t* quads = reinterpret_cast<uint32_t*>(st.lightMaps + (size_t)volumeId * L * L * L);
+		uint32_t* quads = reinterpret_cast<uint32_t*>(st.lightTable[volumeId]);
 		const uint32_t cxs[3] = { xx, xx - 1u, xx }, sxs[3] = { 0u, 1u, 1u };
 		const bool vx[3] = { true, xx >= 1u, xx == L - 1u };
 		const uint32_t cys[3] = { yy, yy - 1u, yy };
@@ -790,7 +824,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 		{
 			const float stepScale = kMaxDist / (float)smpCount;
 			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
-			const uint4* lightQuads = st.lightMaps + (size_t)volumeId * st.L * st.L * st.L;
+			const uint4* lightQuads = st.lightTable[volumeId];
 
 			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
 			float t = 0.0f;

@@ -437,3 +437,44 @@ def test_device_views_alias_context_buffers():
         c.UploadLightMap(1, lm)
         ptr1, _ = c.GetBuffer(1, 1)
         assert np.array_equal(D._device_view(ptr1, n).cpu().numpy().view(np.uint32).reshape(L, L, L, 4), q)
+
+
+def test_pipelined_frames_match_sequential():
+    """MV_FLAG_PIPELINE_FRAMES (frame i+1's upload / cull / light march on a second stream while frame i's view march and
+    composite run) must not change a single bit: same Render() sequence on a pipelined and on a plain context."""
+    from multivolumes_amd import _lib
+    cfg = dict(scene.CONFIGS["T2"], W=256, H=192)
+    V = cfg["V"]
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+    outs = []
+    for flags in (0, _lib.MV_FLAG_PIPELINE_FRAMES):
+        with make_caster(cfg, 64, flags=flags) as c:
+            fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
+            eye = np.array(fr["eye"], np.float32)
+            frames = []
+            for f in range(V + 5):
+                # move the camera a little every frame so that cull results, light maps and cube maps all change
+                e = eye + np.array([0.7 * f, -0.3 * f, 1.1 * f], np.float32)
+                view = rc.look_at_lh(e, (0, 0, 0))
+                vp = rc.multiply(view, rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0))
+                c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+                c.UpdateFrame(vp, fr["shadowVP"], e)
+                c.Render(composite=True)
+                if f % 4 == 3 or f == V + 4:
+                    frames.append((c.ReadBackComposite(), c.ReadBackVolumeInfo()))
+            info = c.ReadBackVolumeInfo()
+            vis, cube = c.ReadBackVisibleLists()
+            lms = [c.ReadBackLightMap(v) for v in range(V)]
+            cms = [c.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube]
+            st = c.GetStats()
+            outs.append((frames, info, vis, cube, lms, cms, {k: st[k] for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples")}))
+    a, b = outs
+    assert a[6] == b[6]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+    for x, y in zip(a[0], b[0]):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+    for x, y in zip(a[4], b[4]):
+        assert np.array_equal(x, y)
+    for x, y in zip(a[5], b[5]):
+        assert np.array_equal(x, y)
+    assert sum(int(l.any()) for l in a[4]) >= len(a[2]), "every visible volume has been relit at least once"
