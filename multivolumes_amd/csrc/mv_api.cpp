@@ -40,6 +40,14 @@ struct FrameBufs
 	uint16_t* volumeRects = nullptr;
 	uint32_t* screenSlot = nullptr;
 	uint4** lightTable = nullptr;
+	// outputs of the view march / composite and their counters (distinct per parity only with MV_FLAG_PIPELINE_FRAMES, so that
+	// the view marches of two consecutive frames may overlap on the GPU)
+	uint2* cubeMaps = nullptr;
+	float* cubeDepths = nullptr;
+	uint2* composite = nullptr;
+	float4* screenLayers = nullptr;
+	uint64_t *tileStats = nullptr, *screenStats = nullptr, *compositeStats = nullptr;
+	uint16_t* tileCost = nullptr;
 };
 
 struct mv_ctx
@@ -47,7 +55,8 @@ struct mv_ctx
 	mv_config cfg;
 	hipStream_t stream = nullptr;		// stream B: view march, composite, exchange, producers, readbacks
 	hipStream_t streamA = nullptr;		// stream A: constant upload, cull, light march (== stream unless MV_FLAG_PIPELINE_FRAMES)
-	bool ownStream = false, ownStreamA = false;
+	hipStream_t streamB[2] = {};		// view march + composite of even / odd frames ([0] == stream; [1] == stream unless pipelined)
+	bool ownStream = false, ownStreamA = false, ownStreamB1 = false;
 	DeviceState st;						// always holds the CURRENT parity's pointers (applyParity)
 	FrameBufs fb[2];
 	uint32_t parity = 0;
@@ -125,6 +134,8 @@ void applyParity(mv_ctx* ctx)
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo;
+	st.cubeMaps = f.cubeMaps; st.cubeDepths = f.cubeDepths; st.composite = f.composite; st.screenLayers = f.screenLayers;
+	st.tileStats = f.tileStats; st.screenStats = f.screenStats; st.compositeStats = f.compositeStats; st.tileCost = f.tileCost;
 }
 
 int syncAll(mv_ctx* ctx)
@@ -134,14 +145,20 @@ int syncAll(mv_ctx* ctx)
 		const hipError_t e = hipStreamSynchronize(ctx->streamA);
 		if (e != hipSuccess) return (int)e;
 	}
+	if (ctx->streamB[1] && ctx->streamB[1] != ctx->stream)
+	{
+		const hipError_t e = hipStreamSynchronize(ctx->streamB[1]);
+		if (e != hipSuccess) return (int)e;
+	}
 	return (int)hipStreamSynchronize(ctx->stream);
 }
 
 // stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
 void stageADone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evStageA[ctx->parity], ctx->streamA); }
-void stageBBegin(mv_ctx* ctx) { (void)hipStreamWaitEvent(ctx->stream, ctx->evStageA[ctx->parity], 0); }
+hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->parity]; }
+void stageBBegin(mv_ctx* ctx) { (void)hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->parity], 0); }
 // stage of stream B finished being enqueued: the next user of this parity's buffers (two frames on) waits for it
-void stageBDone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evMainDone[ctx->parity], ctx->stream); }
+void stageBDone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evMainDone[ctx->parity], streamB(ctx)); }
 
 void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
 {
@@ -231,6 +248,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	}
 
 	ctx->streamA = ctx->stream;
+	ctx->streamB[0] = ctx->streamB[1] = ctx->stream;
 	if (cfg->flags & MV_FLAG_PIPELINE_FRAMES)
 	{
 		// highest priority: stream A's short kernels (cull = one workgroup, light march) must not queue behind the
@@ -239,6 +257,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		(void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
 		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamA = true;
+		if (hipStreamCreateWithFlags(&ctx->streamB[1], hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
+		ctx->ownStreamB1 = true;
 	}
 	for (int i = 0; i < 2; ++i)
 		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
@@ -278,9 +298,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	// lightMaps[V], cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-126), all zero-initialised
 	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * 2 * L3 * sizeof(uint4))) != MV_OK) return bail(rc);	// two buffers per volume
 	if ((rc = devAlloc(ctx, &ctx->lightStaging, L3 * sizeof(uint32_t), false)) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownDepth, (size_t)st.W * st.H * sizeof(float))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownShadow, (size_t)st.M * st.M * sizeof(uint16_t))) != MV_OK) return bail(rc);
 	st.depthMap = ctx->ownDepth; st.shadowMap = ctx->ownShadow;
@@ -292,8 +309,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	// fp32 RGBA layers; volumes beyond the slot capacity fall back to marching inside the composite.
 	st.screenSlots = st.shardCount > 1 ? 0u : (st.V < 8u ? st.V : 8u);
 	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
-	if ((rc = devAlloc(ctx, &st.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	// constants + cull outputs, once per frame parity (FrameBufs)
 	{
 		std::vector<uint4*> table(st.V);
@@ -324,10 +339,27 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
 	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
 	if ((rc = devAlloc(ctx, &ctx->tileOrderBuf, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.tileCost, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
-	if ((rc = devAlloc(ctx, &st.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	for (int p = 0; p < 2; ++p)
+	{
+		FrameBufs& f = ctx->fb[p];
+		if (p == 1 && !(cfg->flags & MV_FLAG_PIPELINE_FRAMES))
+		{
+			const FrameBufs& g = ctx->fb[0];	// one frame in flight: both parities share the outputs
+			f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
+			f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost;
+			break;
+		}
+		// cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-121), zero-initialised
+		if ((rc = devAlloc(ctx, &f.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.tileCost, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
+	}
 	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
 	ctx->parity = 0;
 	applyParity(ctx);
@@ -362,6 +394,7 @@ void mv_destroy(mv_ctx* ctx)
 	for (int i = 0; i < 2; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); }
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
 	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
+	if (ctx->ownStreamB1 && ctx->streamB[1]) (void)hipStreamDestroy(ctx->streamB[1]);
 	for (EventPair& ev : ctx->freeEvents) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
 	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
 	for (void* p : ctx->allocs) (void)hipFree(p);
@@ -560,9 +593,9 @@ int mv_march_view(mv_ctx* ctx)
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
 	stageBBegin(ctx);
 	EventPair ev;
-	beginStage(ctx, 2, ev, ctx->stream);
-	mv::launchMarchView(ctx->stream, ctx->st);
-	endStage(ctx, ev, ctx->stream);
+	beginStage(ctx, 2, ev, streamB(ctx));
+	mv::launchMarchView(streamB(ctx), ctx->st);
+	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
 	stageBDone(ctx);
 	return MV_OK;
@@ -577,9 +610,9 @@ int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
 	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
 	stageBBegin(ctx);
 	EventPair ev;
-	beginStage(ctx, 3, ev, ctx->stream);
-	mv::launchComposite(ctx->stream, ctx->st, row0, row1);
-	endStage(ctx, ev, ctx->stream);
+	beginStage(ctx, 3, ev, streamB(ctx));
+	mv::launchComposite(streamB(ctx), ctx->st, row0, row1);
+	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
 	stageBDone(ctx);
 	return MV_OK;
@@ -621,6 +654,7 @@ int mv_readback_visible_lists(mv_ctx* ctx, uint32_t* visible, uint32_t* visibleC
 int mv_readback_volume(mv_ctx* ctx, uint32_t src, uint16_t* dst)
 {
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the producing frame may have run on another stream
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	mv::launchUntile(ctx->stream, ctx->volumes[src], ctx->staging, ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
@@ -669,6 +703,7 @@ int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src)
 int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* dst)
 {
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the producing frame may have run on another stream
 	MV_REQUIRE(ctx, volume < ctx->st.V && mip < MV_NUM_CUBE_MIP, MV_ERR_RANGE, "volume / mip out of range");
 	const size_t d = ctx->st.N >> mip;
 	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
@@ -680,6 +715,7 @@ int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* d
 int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* dst)
 {
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the producing frame may have run on another stream
 	MV_REQUIRE(ctx, volume < ctx->st.V && mip < MV_NUM_CUBE_MIP, MV_ERR_RANGE, "volume / mip out of range");
 	const size_t d = ctx->st.N >> mip;
 	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
@@ -691,6 +727,7 @@ int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* ds
 int mv_readback_composite(mv_ctx* ctx, uint16_t* dst)
 {
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the producing frame may have run on another stream
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.composite, (size_t)ctx->st.W * ctx->st.H * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
@@ -700,8 +737,13 @@ int mv_clear_cube_maps(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	const size_t chain = mv::cubeChainTexels(ctx->st.N);
-	MV_HIP(ctx, hipMemsetAsync(ctx->st.cubeMaps, 0, (size_t)ctx->st.V * chain * sizeof(uint2), ctx->stream));
-	MV_HIP(ctx, hipMemsetAsync(ctx->st.cubeDepths, 0, (size_t)ctx->st.V * chain * sizeof(float), ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	for (int p = 0; p < 2; ++p)
+	{
+		MV_HIP(ctx, hipMemsetAsync(ctx->fb[p].cubeMaps, 0, (size_t)ctx->st.V * chain * sizeof(uint2), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(ctx->fb[p].cubeDepths, 0, (size_t)ctx->st.V * chain * sizeof(float), ctx->stream));
+	}
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
 
@@ -710,7 +752,14 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 	if (!ctx || !out) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
-	mv::launchReduceStats(ctx->stream, ctx->st);
+	mv::launchReduceStats(ctx->stream, ctx->st, 1);
+	if (ctx->fb[0].tileStats != ctx->fb[1].tileStats)
+	{
+		DeviceState other = ctx->st;
+		const FrameBufs& q = ctx->fb[ctx->parity ^ 1u];
+		other.tileStats = q.tileStats; other.screenStats = q.screenStats; other.compositeStats = q.compositeStats;
+		mv::launchReduceStats(ctx->stream, other, 0);
+	}
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedStats, ctx->st.stats, kNumStats * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
@@ -735,10 +784,14 @@ int mv_reset_stats(mv_ctx* ctx)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	foldEvents(ctx);
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
-	MV_HIP(ctx, hipMemsetAsync(ctx->st.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.lightStats, 0, (size_t)ctx->st.lightBlocks * sizeof(uint64_t), ctx->stream));
-	MV_HIP(ctx, hipMemsetAsync(ctx->st.compositeStats, 0, (size_t)ctx->st.compositeSlots * sizeof(uint64_t), ctx->stream));
-	MV_HIP(ctx, hipMemsetAsync(ctx->st.screenStats, 0, ((size_t)ctx->st.maxScreenTiles + 1) * 2 * sizeof(uint64_t), ctx->stream));
+	for (int p = 0; p < 2; ++p)
+	{
+		const FrameBufs& f = ctx->fb[p];
+		MV_HIP(ctx, hipMemsetAsync(f.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(f.compositeStats, 0, (size_t)ctx->st.compositeSlots * sizeof(uint64_t), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(f.screenStats, 0, ((size_t)ctx->st.maxScreenTiles + 1) * 2 * sizeof(uint64_t), ctx->stream));
+	}
 	for (int i = 0; i < 4; ++i) { ctx->msStage[i] = 0.0; ctx->nStage[i] = 0; }
 	return MV_OK;
 }
@@ -762,6 +815,7 @@ void* mv_get_stream(mv_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->str
 int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, size_t* bytes)
 {
 	if (!ctx || !d_ptr || !bytes) return MV_ERR_INVALID_ARG;
+	// pointers of the CURRENT frame parity (with MV_FLAG_PIPELINE_FRAMES the outputs alternate between two buffers)
 	const DeviceState& st = ctx->st;
 	const size_t chain = mv::cubeChainTexels(st.N);
 	const size_t L3 = (size_t)st.L * st.L * st.L;
@@ -837,7 +891,7 @@ int mv_exchange_pack(mv_ctx* ctx, void* d_dst, uint32_t slot_dim)
 	if (!ctx || !d_dst) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, slot_dim >= 1 && slot_dim <= ctx->st.N, MV_ERR_RANGE, "slot_dim out of range");
-	mv::launchExchangePack(ctx->stream, ctx->st, slot_dim, d_dst);
+	mv::launchExchangePack(streamB(ctx), ctx->st, slot_dim, d_dst);
 	MV_HIP(ctx, hipGetLastError());
 	return MV_OK;
 }
@@ -847,7 +901,7 @@ int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim)
 	if (!ctx || !d_src) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, slot_dim >= 1 && slot_dim <= ctx->st.N, MV_ERR_RANGE, "slot_dim out of range");
-	mv::launchExchangeUnpack(ctx->stream, ctx->st, slot_dim, d_src);
+	mv::launchExchangeUnpack(streamB(ctx), ctx->st, slot_dim, d_src);
 	MV_HIP(ctx, hipGetLastError());
 	return MV_OK;
 }

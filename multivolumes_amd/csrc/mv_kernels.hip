@@ -945,7 +945,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 }
 
 // Sums the per-wavefront counter slots into st.stats (run by mv_get_stats, not per frame).
-__global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st)
+__global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st, int includeLight)
 {
 	unsigned long long a[7] = { 0, 0, 0, 0, 0, 0, 0 };	// [6] = lit samples of the fused RayCast tiles
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
@@ -954,7 +954,7 @@ __global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st)
 		const ulonglong4 v = reinterpret_cast<const ulonglong4*>(st.tileStats)[i];
 		a[0] += v.x; a[1] += v.y; a[2] += v.z; a[5] += v.w;
 	}
-	for (uint32_t i = tid; i < st.lightBlocks; i += nThreads) a[3] += st.lightStats[i];
+	if (includeLight) for (uint32_t i = tid; i < st.lightBlocks; i += nThreads) a[3] += st.lightStats[i];
 	for (uint32_t i = tid; i < st.compositeSlots; i += nThreads) a[4] += st.compositeStats[i];
 	for (uint32_t i = tid; i < st.maxScreenTiles; i += nThreads) { a[4] += st.screenStats[2 * i]; a[6] += st.screenStats[2 * i + 1]; }
 #pragma unroll
@@ -976,9 +976,9 @@ uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount)
 	return owned * 6u * t * t;
 }
 
-void launchReduceStats(hipStream_t s, const DeviceState& st)
+void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight)
 {
-	hipLaunchKernelGGL(reduceStatsKernel, dim3(64), dim3(256), 0, s, st);
+	hipLaunchKernelGGL(reduceStatsKernel, dim3(64), dim3(256), 0, s, st, includeLight);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -98,7 +98,7 @@ void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, u
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);
-void launchReduceStats(hipStream_t s, const DeviceState& st);
+void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight);
 uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
 void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1);
 void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, void* dst);
