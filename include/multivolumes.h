@@ -126,6 +126,20 @@ int mv_set_max_samples(mv_ctx* ctx, uint32_t maxRaySamples, uint32_t maxLightSam
 /* UpdateFrame (MultiRayCaster.cpp:316-353): the 212-byte CBPerFrame and V x 224-byte PerObject it writes. */
 int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject);
 
+/* ---- mesh depth / shadow producer: what ObjectRenderer hands the path through SetRenderTargets ----
+ * ObjectRenderer::RenderShadow / Render (ObjectRenderer.cpp:209-262, VSDepth.hlsl:24-27, VSBasePass.hlsl:44-60) rasterise the
+ * mesh into SHADOW_MAP (D16, M x M) and DEPTH_MAP (D32F, viewport).  Here a gfx950 kernel rasterises the indexed triangle
+ * list straight into the context's own depth / shadow maps (LESS test, cleared to 1.0; 1/256-pixel snapping, top-left rule).
+ * Triangles with a vertex at or behind the eye plane (w <= 0) are dropped: the mesh is assumed in front of the camera. */
+int mv_mesh_upload(mv_ctx* ctx, const float* positions /* numVerts x 3 */, uint32_t numVerts, const uint32_t* indices /* numTris x 3 */, uint32_t numTris);
+/* worldViewProjT: the transposed 4x4 the reference stores in cbPerObject (ObjectRenderer.cpp:195-199); projBias: the Halton
+ * TAA jitter of VSBasePass.hlsl:57 (NULL = none).  Makes the context's own depth map current (like mv_set_depth_map). */
+int mv_mesh_render_depth(mv_ctx* ctx, const float worldViewProjT[16], const float projBias[2]);
+/* shadowWVPT: world * lightViewProj, transposed (ObjectRenderer.cpp:186).  Makes the own shadow map current. */
+int mv_mesh_render_shadow(mv_ctx* ctx, const float shadowWVPT[16]);
+int mv_readback_depth_map(mv_ctx* ctx, float* dst /* W x H */);
+int mv_readback_shadow_map(mv_ctx* ctx, uint16_t* dst /* M x M */);
+
 /* cullVolumes (MultiRayCaster.cpp:1249-1285) = CSVolumeCull.hlsl:13-78. Lists come out in ascending volume order. */
 int mv_cull(mv_ctx* ctx);
 /* rayMarchL (MultiRayCaster.cpp:1299-1327) = CSRayMarchL.hlsl:20-121: relights ONE volume, visible[FrameIdx % count].

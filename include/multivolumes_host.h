@@ -43,6 +43,16 @@ void mvh_synth_sphere_depth(uint32_t W, uint32_t H, const float viewProj[16], co
 /* D16 depth of the same sphere through an orthographic light view-projection given TRANSPOSED (as mvh_shadow_view_proj returns it). */
 void mvh_synth_sphere_shadow(uint32_t M, const float lightViewProjT[16], const float center[3], float radius, uint16_t* d16);
 
+/* Wavefront OBJ positions + triangles (the subset of XUSG/Optional/XUSGObjLoader.cpp the depth passes need): `v x y z`,
+ * `f a b c ...` with a, a/b, a//c or a/b/c references, negative (relative) indices, polygons fan-triangulated.
+ * Arrays are malloc'ed; release with mvh_free.  Returns 0, or -1 if the file cannot be read / has no faces. */
+int mvh_load_obj(const char* path, float** positions, uint32_t* numVerts, uint32_t** indices, uint32_t* numTris, float aabbMin[3], float aabbMax[3]);
+void mvh_free(void* p);
+/* ObjectRenderer::SetWorld (ObjectRenderer.cpp:147-154, no rotation): Scale(scale) * Translate(pos), row-major 4x4 */
+void mvh_mesh_world(float scale, const float pos[3], float world[16]);
+/* transposed store of a row-major 4x4 (XMStoreFloat4x4(XMMatrixTranspose(M))) */
+void mvh_transpose(const float m[16], float outT[16]);
+
 #ifdef __cplusplus
 }
 #endif

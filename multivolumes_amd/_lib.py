@@ -98,7 +98,16 @@ ABI = {
     "mv_exchange_pack": (C.c_int, [_P, _P, _U32]),
     "mv_exchange_unpack": (C.c_int, [_P, _P, _U32]),
     "mv_readback_cull": (C.c_int, [_P, _P, _P, C.POINTER(_U32), _P, C.POINTER(_U32), C.POINTER(_U32)]),
+    "mv_mesh_upload": (C.c_int, [_P, _P, _U32, _P, _U32]),
+    "mv_mesh_render_depth": (C.c_int, [_P, _P, _P]),
+    "mv_mesh_render_shadow": (C.c_int, [_P, _P]),
+    "mv_readback_depth_map": (C.c_int, [_P, _P]),
+    "mv_readback_shadow_map": (C.c_int, [_P, _P]),
     # host helpers
+    "mvh_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(_U32), C.POINTER(_P), C.POINTER(_U32), _P, _P]),
+    "mvh_free": (None, [_P]),
+    "mvh_mesh_world": (None, [C.c_float, _P, _P]),
+    "mvh_transpose": (None, [_P, _P]),
     "mvh_look_at_lh": (None, [_P, _P, _P, _P]),
     "mvh_perspective_fov_lh": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _P]),
     "mvh_orthographic_lh": (None, [C.c_float, C.c_float, C.c_float, C.c_float, _P]),

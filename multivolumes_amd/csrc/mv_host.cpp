@@ -4,6 +4,8 @@
 #include "../../include/multivolumes_host.h"
 
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
 #include <vector>
@@ -367,5 +369,72 @@ void mvh_synth_sphere_shadow(uint32_t M, const float lightViewProjT[16], const f
 		}
 	});
 }
+
+int mvh_load_obj(const char* path, float** positions, uint32_t* numVerts, uint32_t** indices, uint32_t* numTris, float aabbMin[3], float aabbMax[3])
+{
+	if (!path || !positions || !numVerts || !indices || !numTris) return -1;
+	FILE* f = fopen(path, "r");
+	if (!f) return -1;
+	std::vector<float> v;
+	std::vector<uint32_t> idx;
+	char line[1024];
+	while (fgets(line, sizeof(line), f))
+	{
+		if (line[0] == 'v' && (line[1] == ' ' || line[1] == '\t'))
+		{
+			float x, y, z;
+			if (sscanf(line + 1, "%f %f %f", &x, &y, &z) == 3) { v.push_back(x); v.push_back(y); v.push_back(z); }
+		}
+		else if (line[0] == 'f' && (line[1] == ' ' || line[1] == '\t'))
+		{
+			std::vector<uint32_t> poly;
+			const char* p = line + 1;
+			for (;;)
+			{
+				while (*p == ' ' || *p == '\t') ++p;
+				if (*p == 0 || *p == '\n' || *p == '\r') break;
+				char* end = nullptr;
+				const long a = strtol(p, &end, 10);
+				if (end == p) break;
+				const long nv = (long)(v.size() / 3);
+				const long i = a > 0 ? a - 1 : nv + a;	// 1-based, or relative to the vertices read so far
+				if (i < 0 || i >= nv) { fclose(f); return -1; }
+				poly.push_back((uint32_t)i);
+				p = end;
+				while (*p && *p != ' ' && *p != '\t' && *p != '\n' && *p != '\r') ++p;	// skip /vt/vn
+			}
+			for (size_t k = 2; k < poly.size(); ++k) { idx.push_back(poly[0]); idx.push_back(poly[k - 1]); idx.push_back(poly[k]); }
+		}
+	}
+	fclose(f);
+	if (v.empty() || idx.empty()) return -1;
+	*numVerts = (uint32_t)(v.size() / 3);
+	*numTris = (uint32_t)(idx.size() / 3);
+	*positions = static_cast<float*>(malloc(v.size() * sizeof(float)));
+	*indices = static_cast<uint32_t*>(malloc(idx.size() * sizeof(uint32_t)));
+	if (!*positions || !*indices) { free(*positions); free(*indices); return -1; }
+	memcpy(*positions, v.data(), v.size() * sizeof(float));
+	memcpy(*indices, idx.data(), idx.size() * sizeof(uint32_t));
+	if (aabbMin && aabbMax)
+		for (int c = 0; c < 3; ++c)
+		{
+			float lo = v[c], hi = v[c];
+			for (size_t i = c; i < v.size(); i += 3) { lo = fminf(lo, v[i]); hi = fmaxf(hi, v[i]); }
+			aabbMin[c] = lo; aabbMax[c] = hi;
+		}
+	return 0;
+}
+
+void mvh_free(void* p) { free(p); }
+
+void mvh_mesh_world(float scale, const float pos[3], float world[16])
+{
+	M4 m; memset(&m, 0, sizeof(m));
+	m.m[0][0] = m.m[1][1] = m.m[2][2] = scale;
+	m.m[3][0] = pos[0]; m.m[3][1] = pos[1]; m.m[3][2] = pos[2]; m.m[3][3] = 1.0;
+	store(m, world);
+}
+
+void mvh_transpose(const float m[16], float outT[16]) { storeT(load(m), outT, 4); }
 
 } // extern "C"

@@ -75,6 +75,36 @@ def synth_sphere_shadow(M, light_view_proj_t, center, radius):
     return out
 
 
+def load_obj(path):
+    """(positions[n,3] float32, indices[m,3] uint32, aabb_min[3], aabb_max[3]) of a Wavefront OBJ (mvh_load_obj)."""
+    lib = _lib.load()
+    pos, idx = C.c_void_p(), C.c_void_p()
+    nv, nt = C.c_uint32(), C.c_uint32()
+    lo, hi = np.zeros(3, np.float32), np.zeros(3, np.float32)
+    if lib.mvh_load_obj(str(path).encode(), C.byref(pos), C.byref(nv), C.byref(idx), C.byref(nt), _ptr(lo), _ptr(hi)) != 0:
+        raise IOError(f"cannot load OBJ {path}")
+    try:
+        p = np.ctypeslib.as_array(C.cast(pos, C.POINTER(C.c_float)), (nv.value, 3)).copy()
+        i = np.ctypeslib.as_array(C.cast(idx, C.POINTER(C.c_uint32)), (nt.value, 3)).copy()
+    finally:
+        lib.mvh_free(pos)
+        lib.mvh_free(idx)
+    return p, i, lo, hi
+
+
+def mesh_world(scale, pos):
+    """ObjectRenderer::SetWorld (ObjectRenderer.cpp:147-154): Scale * Translate, row-major 4x4."""
+    out = np.empty(16, np.float32)
+    _lib.load().mvh_mesh_world(float(scale), _ptr(_f32(pos, 3)), _ptr(out))
+    return out.reshape(4, 4)
+
+
+def transpose_store(m):
+    out = np.empty(16, np.float32)
+    _lib.load().mvh_transpose(_ptr(_f32(m, 16)), _ptr(out))
+    return out.reshape(4, 4)
+
+
 def cube_chain_texels(N):
     return int(_lib.load().mv_cube_chain_texels(N))
 
@@ -183,6 +213,35 @@ class MultiRayCaster:
             self._check(self._lib.mv_set_depth_map_device(self._ctx, C.c_void_p(depthMapDevice)), "mv_set_depth_map_device")
         if shadowMapDevice is not None:
             self._check(self._lib.mv_set_shadow_map_device(self._ctx, C.c_void_p(shadowMapDevice)), "mv_set_shadow_map_device")
+
+    # ---- mesh depth / shadow producer (what ObjectRenderer hands to SetRenderTargets) ----
+    def SetMesh(self, positions, indices):
+        p = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+        i = np.ascontiguousarray(indices, np.uint32).reshape(-1, 3)
+        self._check(self._lib.mv_mesh_upload(self._ctx, _ptr(p), len(p), _ptr(i), len(i)), "mv_mesh_upload")
+
+    def RenderMeshDepth(self, worldViewProj, projBias=None):
+        """ObjectRenderer::Render's depth output (VSBasePass.hlsl:44-60). worldViewProj: row-major world * view * proj."""
+        t = transpose_store(worldViewProj)
+        b = None if projBias is None else _f32(projBias, 2)
+        self._check(self._lib.mv_mesh_render_depth(self._ctx, _ptr(t), _ptr(b)), "mv_mesh_render_depth")
+
+    def RenderMeshShadow(self, shadowWVP):
+        """ObjectRenderer::RenderShadow (VSDepth.hlsl:24-27). shadowWVP: row-major world * lightView * lightProj."""
+        t = transpose_store(shadowWVP)
+        self._check(self._lib.mv_mesh_render_shadow(self._ctx, _ptr(t)), "mv_mesh_render_shadow")
+
+    def ReadBackDepthMap(self):
+        W, H = self.viewport
+        out = np.empty((H, W), np.float32)
+        self._check(self._lib.mv_readback_depth_map(self._ctx, _ptr(out)), "mv_readback_depth_map")
+        return out
+
+    def ReadBackShadowMap(self):
+        M = self.shadowMapSize
+        out = np.empty((M, M), np.uint16)
+        self._check(self._lib.mv_readback_shadow_map(self._ctx, _ptr(out)), "mv_readback_shadow_map")
+        return out
 
     def SetSH(self, coeffSH):
         a = None if coeffSH is None else _f32(coeffSH, 27)

@@ -178,3 +178,26 @@ def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame
     load().mvo_composite(V, N, L, W, H, y0, y1, arr, _ptr(lm), _ptr(dm), _ptr(po), _ptr(cb), _ptr(vi), _ptr(vl), len(vl),
                          _ptr(cm), _ptr(cd), _ptr(o), C.byref(st))
     return o, int(st.view_samples)
+
+
+def raster_depth(positions, indices, wvp_t, W, H, bias=(0.0, 0.0)):
+    """CPU oracle of the mesh depth rasteriser: returns float32[H, W] (1.0 where nothing was drawn)."""
+    lib = load()
+    lib.mvo_raster_depth.restype = None
+    lib.mvo_raster_depth.argtypes = [_P, _P, _U32, _P, _F, _F, _U32, _U32, _P]
+    p = np.ascontiguousarray(positions, np.float32)
+    i = np.ascontiguousarray(indices, np.uint32)
+    m = np.ascontiguousarray(wvp_t, np.float32)
+    out = np.ones((H, W), np.float32)
+    lib.mvo_raster_depth(_ptr(p), _ptr(i), i.size // 3, _ptr(m), bias[0], bias[1], W, H, _ptr(out))
+    return out
+
+
+def depth_to_d16(depth):
+    lib = load()
+    lib.mvo_depth_to_d16.restype = None
+    lib.mvo_depth_to_d16.argtypes = [_P, C.c_size_t, _P]
+    d = np.ascontiguousarray(depth, np.float32)
+    out = np.empty(d.shape, np.uint16)
+    lib.mvo_depth_to_d16(_ptr(d), d.size, _ptr(out))
+    return out
