@@ -51,6 +51,7 @@ struct FrameBufs
 	float4* screenLayers = nullptr;
 	uint64_t *tileStats = nullptr, *screenStats = nullptr, *compositeStats = nullptr;
 	uint16_t* tileCost = nullptr;
+	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per parity
 };
 
 struct mv_ctx
@@ -72,7 +73,7 @@ struct mv_ctx
 	uint2** dVolumePtrs = nullptr;
 	uint4** dCellPtrs = nullptr;
 	uint32_t* lightStaging = nullptr;	// L^3 plain R11G11B10F (readback / upload conversion)
-	uint32_t* tileOrderBuf = nullptr;
+	bool orderTiles = true;				// MV_TILE_ORDER=0 in the environment: list-order dispatch (A/B measurements)
 	// mesh depth / shadow producer (mv_mesh_*)
 	float* meshPositions = nullptr;
 	uint32_t* meshIndices = nullptr;
@@ -145,6 +146,7 @@ void applyParity(mv_ctx* ctx)
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo;
 	st.cubeMaps = f.cubeMaps; st.cubeDepths = f.cubeDepths; st.composite = f.composite; st.screenLayers = f.screenLayers;
 	st.tileStats = f.tileStats; st.screenStats = f.screenStats; st.compositeStats = f.compositeStats; st.tileCost = f.tileCost;
+	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
 }
 
 int syncAll(mv_ctx* ctx)
@@ -347,7 +349,12 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.maxTiles = mv::marchViewMaxTiles(st.V, st.N, st.shardCount);
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
 	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
-	if ((rc = devAlloc(ctx, &ctx->tileOrderBuf, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	{ const char* e = getenv("MV_TILE_ORDER"); ctx->orderTiles = !(e && e[0] == '0'); }
+	for (int p = 0; p < 2; ++p)
+	{
+		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 256 * 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	}
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	for (int p = 0; p < 2; ++p)
 	{
@@ -365,7 +372,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.tileCost, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.tileCost, ((size_t)st.V * 6 * ((st.N + 7u) >> 3) * ((st.N + 7u) >> 3) + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	}
@@ -581,6 +588,13 @@ int mv_cull(mv_ctx* ctx)
 	endStage(ctx, ev, ctx->streamA);
 	MV_HIP(ctx, hipGetLastError());
 	stageADone(ctx);
+	if (ctx->orderTiles)
+	{
+		// dispatch order of this frame's view march, on ITS stream: it runs beside the light march and only needs the cull
+		stageBBegin(ctx);
+		mv::launchTileOrder(streamB(ctx), ctx->st, ctx->fb[ctx->parity].binCounts, ctx->fb[ctx->parity].tileOrder);
+		MV_HIP(ctx, hipGetLastError());
+	}
 	ctx->haveCull = true;
 	return MV_OK;
 }
@@ -931,30 +945,6 @@ int mv_readback_shadow_map(mv_ctx* ctx, uint16_t* dst)
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemcpy(dst, ctx->st.shadowMap, (size_t)ctx->st.M * ctx->st.M * sizeof(uint16_t), hipMemcpyDeviceToHost));
-	return MV_OK;
-}
-
-/* diagnostic hooks (not part of the reference surface): read the per-tile cost of the last view march, set a dispatch order */
-int mv_debug_tile_costs(mv_ctx* ctx, uint16_t* dst, uint32_t* numTiles)
-{
-	if (!ctx || !dst || !numTiles) return MV_ERR_INVALID_ARG;
-	uint32_t counters[kNumCounters];
-	MV_HIP(ctx, hipMemcpyAsync(counters, ctx->st.counters, sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	*numTiles = counters[3];
-	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.tileCost, (size_t)counters[3] * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	return MV_OK;
-}
-
-int mv_debug_set_tile_order(mv_ctx* ctx, const uint32_t* order, uint32_t n)
-{
-	if (!ctx) return MV_ERR_INVALID_ARG;
-	if (!order) { ctx->st.tileOrder = nullptr; return MV_OK; }
-	MV_REQUIRE(ctx, n <= ctx->st.maxTiles + ctx->st.maxScreenTiles, MV_ERR_RANGE, "too many tiles");
-	MV_HIP(ctx, hipMemcpyAsync(ctx->tileOrderBuf, order, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	ctx->st.tileOrder = ctx->tileOrderBuf;
 	return MV_OK;
 }
 

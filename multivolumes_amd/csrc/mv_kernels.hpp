@@ -71,8 +71,8 @@ struct DeviceState
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
 	uint64_t* screenStats;			// maxScreenTiles x 2: {RayCast samples, lit} per screen tile marched by marchViewKernel
 	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles;
-	const uint32_t* tileOrder;		// optional permutation of the tile list (dispatch slot -> tile), longest tiles first; NULL = list order
-	uint16_t* tileCost;				// per tile: samples of its longest ray in the last launch (feeds the next frame's order)
+	const uint32_t* tileOrder;		// permutation of the tile list (dispatch slot -> tile), longest bins first (launchTileOrder); NULL = list order
+	uint16_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch, by stable tile key
 };
 
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)
@@ -98,6 +98,7 @@ void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, u
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);
+void launchTileOrder(hipStream_t s, const DeviceState& st, uint32_t* binCounts, uint32_t* order);	// binCounts: 256 x 8 scratch; order: maxTiles + maxScreenTiles
 void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight);
 uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
 void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1);
