@@ -8,8 +8,14 @@ shadow map) are resident in HBM before the timed region.  With --gpus N > 1 the 
 ranks (strong scaling, BASELINE config C4) and the selected-mip cube faces are all-gathered over RCCL every frame.
 
 Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (marchViewKernel) with the algorithmic bytes of
-SURVEY.md 8(d): 64 B/view sample + 32 B/lit sample + 16 B/ray, divided by its HIP-event launch time.
+SURVEY.md 8(d): 64 B/view sample + 32 B/lit sample + 16 B/ray, divided by its HIP-event launch time.  On one GPU the
+timed region keeps several frames in flight, so two view-march launches share the GPU and a launch's event-to-event time
+(`launch_ms_in_flight`) is not the kernel's own speed; `launch_ms` therefore comes from a second pass of the same frames
+run one at a time (synchronise after every frame), still HIP events inside this process.
 `cpu_baseline` is the CPU oracle (the reference has no Linux CPU path) timed on the same frame's marchV.
+
+Defaults: 150 warm-up + 300 timed frames (about 0.2 s of GPU time).  The warm-up is that long because the HIP runtime
+stalls once for 30-50 ms around the 140th frame of a process (its command / signal pools grow); measured, one-time.
 """
 import argparse
 import json
@@ -28,13 +34,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=30)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=300)
+    p.add_argument("--warmup", type=int, default=150)
     p.add_argument("--config", default="C3", help="C1/C2/C3/C5/T1/T2 (default C3 = the config the metric is quoted on)")
     p.add_argument("--stress", action="store_true", help="C3-stress: force mip 0, all 6 faces (SURVEY 8d)")
     p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
     p.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of frame i+1's light march with frame i's view march")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
+    p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
     return p.parse_args()
 
@@ -74,6 +82,10 @@ def main():
     pipelined = world == 1 and not args.no_pipeline
     if pipelined:
         flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # two frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
+    # a real (non-blocking) torch stream, made current so that the RCCL collectives of the multi-GPU path are ordered on it too:
+    # torch's default is the legacy null stream, whose implicit synchronisation rules cost the pipelined frame ~20 %
+    if os.environ.get("MV_BENCH_NULL_STREAM", "0") != "1":
+        torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
     stream = torch.cuda.current_stream().cuda_stream
     caster = MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=M, device=local_rank,
                             stream=stream, flags=flags, shard=(rank, world))
@@ -127,12 +139,30 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    trace = [] if os.environ.get("MV_BENCH_TRACE") else None
+    for i in range(args.steps):
+        caster.SetProfiling(i % args.profile_every == 0)  # HIP-event pairs around the launches of a sample of the timed frames
         frame()
+        if trace is not None:
+            trace.append(time.perf_counter())
     barrier()
+    if trace:
+        d = sorted(((b - a) * 1e3, i + 1) for i, (a, b) in enumerate(zip(trace, trace[1:])))
+        print("host ms per frame: median %.3f, largest %s" % (d[len(d) // 2][0], [(round(x, 2), i) for x, i in d[-6:]]), file=sys.stderr)
     dt = time.perf_counter() - t0
     caster.SetProfiling(False)
     st = caster.GetStats()
+
+    # roofline pass: the same frames, one at a time, so that a launch's HIP-event duration is the kernel's own time
+    st_iso = None
+    if pipelined and args.roofline_frames > 0:
+        caster.ResetStats()
+        caster.SetProfiling(True)
+        for _ in range(args.roofline_frames):
+            frame()
+            caster.synchronize()
+        caster.SetProfiling(False)
+        st_iso = caster.GetStats()
 
     # max time over ranks, sum of samples over ranks
     if world > 1:
@@ -149,13 +179,16 @@ def main():
         K = args.steps
         info = caster.ReadBackVolumeInfo()
         vis, cube = caster.ReadBackVisibleLists()
-        ms_v = st["ms_march_view"] / max(1, st["n_march_view"])
-        ms_l = st["ms_march_light"] / max(1, st["n_march_light"])
-        ms_c = st["ms_cull"] / max(1, st["n_cull"])
-        # rank-0 marchV launch: algorithmic bytes per launch / average launch duration
+        def kernel_ms(s_):
+            return {"cull": s_["ms_cull"] / max(1, s_["n_cull"]), "march_light": s_["ms_march_light"] / max(1, s_["n_march_light"]),
+                    "march_view": s_["ms_march_view"] / max(1, s_["n_march_view"]), "composite": s_["ms_composite"] / max(1, s_["n_composite"])}
+        k_in_flight = kernel_ms(st)
+        k_alone = kernel_ms(st_iso) if st_iso else k_in_flight
+        ms_v = k_alone["march_view"]
+        # rank-0 marchV launch: algorithmic bytes per launch (the counters cover every timed frame) / average launch duration
         # the view-march launch also marches the screen-space RayCast tiles (composite_samples) on single-GPU contexts
         fused = st["composite_samples"] if world == 1 else 0
-        alg_bytes = (64 * (st["view_samples"] + fused) + 32 * (st["lit_samples"] + (st["fused_raycast_lit"] if world == 1 else 0)) + 16 * st["rays"]) / max(1, st["n_march_view"])
+        alg_bytes = (64 * (st["view_samples"] + fused) + 32 * (st["lit_samples"] + (st["fused_raycast_lit"] if world == 1 else 0)) + 16 * st["rays"]) / K
         achieved = alg_bytes / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -179,16 +212,19 @@ def main():
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
-                "frames_in_flight": 2 if pipelined else 1,
+                "frames_in_flight": "up to 3 (constants / cull 4 slots, march outputs 2, light maps 3 buffers per volume)" if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes[0] // max(1, K + args.warmup),
             },
-            "kernel_ms": {"cull": ms_c, "march_light": ms_l, "march_view": ms_v, "composite": st["ms_composite"] / max(1, st["n_composite"])},
+            "kernel_ms": k_alone, "kernel_ms_in_flight": k_in_flight,
             "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,
             "light_msamples_per_s": tot_light / dt / 1e6,
             "roofline": {"bound": "hbm", "kernel": "marchViewKernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": ms_v},
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": ms_v,
+                         "launch_ms_in_flight": k_in_flight["march_view"],
+                         "launch_ms_from": (f"{args.roofline_frames} frames run one at a time after the timed region (HIP events)" if st_iso
+                                            else f"every {args.profile_every}th frame of the timed region (HIP events)")},
             "setup_s": t_setup,
         }
         if not args.no_cpu_baseline:

@@ -22,14 +22,15 @@ using mv::DeviceState;
 
 namespace
 {
+constexpr uint32_t kFrameSlots = 4;	// constants + cull outputs in flight: the cull of frame i+2 may run while frame i is still marching
 constexpr uint32_t kFrameSlices = 3;	// MultiRayCaster::FrameCount (MultiRayCaster.h:52): upload slices in flight
-constexpr uint32_t kNumCounters = 8;
+constexpr uint32_t kNumCounters = 8;	// read back; counters[8] (the cull's ticket) is device-only
 constexpr uint32_t kNumStats = 8;
 
 struct EventPair { hipEvent_t a, b; int stage; };
 }
 
-// Buffers that exist once per frame parity (constants + everything the cull writes): frame i+1's upload / cull / light march
+// Buffers that exist once per frame slot (constants + everything the cull writes): frame i+1's upload / cull / light march
 // (stream A) may then run while frame i's view march / composite (stream B) still read frame i's copies.
 struct FrameBufs
 {
@@ -51,20 +52,21 @@ struct FrameBufs
 	float4* screenLayers = nullptr;
 	uint64_t *tileStats = nullptr, *screenStats = nullptr, *compositeStats = nullptr;
 	uint16_t* tileCost = nullptr;
-	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per parity
+	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per slot
 };
 
 struct mv_ctx
 {
 	mv_config cfg;
 	hipStream_t stream = nullptr;		// stream B: view march, composite, exchange, producers, readbacks
-	hipStream_t streamA = nullptr;		// stream A: constant upload, cull, light march (== stream unless MV_FLAG_PIPELINE_FRAMES)
+	hipStream_t streamA = nullptr;		// stream A: constant upload, cull (== stream unless MV_FLAG_PIPELINE_FRAMES); may run frames ahead
+	hipStream_t streamL = nullptr;		// stream L: light march (== stream unless MV_FLAG_PIPELINE_FRAMES)
 	hipStream_t streamB[2] = {};		// view march + composite of even / odd frames ([0] == stream; [1] == stream unless pipelined)
 	bool ownStream = false, ownStreamA = false, ownStreamB1 = false;
-	DeviceState st;						// always holds the CURRENT parity's pointers (applyParity)
-	FrameBufs fb[2];
-	uint32_t parity = 0;
-	hipEvent_t evStageA[2] = {}, evMainDone[2] = {}, evProducers = nullptr;
+	DeviceState st;						// always holds the CURRENT frame slot's pointers (applyParity)
+	FrameBufs fb[kFrameSlots];			// constants + cull outputs per slot; march / composite outputs per PARITY (slot & 1), aliased
+	uint32_t slot = 0;					// frame counter mod kFrameSlots
+	hipEvent_t evStageA[kFrameSlots] = {}, evLight[kFrameSlots] = {}, evMainDone[kFrameSlots] = {}, evProducers = nullptr;
 	bool producersDirty = false;
 
 	// owned device allocations
@@ -136,8 +138,8 @@ int devAlloc(mv_ctx* ctx, T** out, size_t bytes, bool zero = true)
 
 void applyParity(mv_ctx* ctx)
 {
-	const FrameBufs& f = ctx->fb[ctx->parity];
-	const FrameBufs& q = ctx->fb[ctx->parity ^ 1u];
+	const FrameBufs& f = ctx->fb[ctx->slot];
+	const FrameBufs& q = ctx->fb[(ctx->slot + kFrameSlots - 1u) % kFrameSlots];	// the previous frame's
 	DeviceState& st = ctx->st;
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
@@ -156,6 +158,11 @@ int syncAll(mv_ctx* ctx)
 		const hipError_t e = hipStreamSynchronize(ctx->streamA);
 		if (e != hipSuccess) return (int)e;
 	}
+	if (ctx->streamL && ctx->streamL != ctx->stream)
+	{
+		const hipError_t e = hipStreamSynchronize(ctx->streamL);
+		if (e != hipSuccess) return (int)e;
+	}
 	if (ctx->streamB[1] && ctx->streamB[1] != ctx->stream)
 	{
 		const hipError_t e = hipStreamSynchronize(ctx->streamB[1]);
@@ -165,11 +172,15 @@ int syncAll(mv_ctx* ctx)
 }
 
 // stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
-void stageADone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evStageA[ctx->parity], ctx->streamA); }
-hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->parity]; }
-void stageBBegin(mv_ctx* ctx) { (void)hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->parity], 0); }
-// stage of stream B finished being enqueued: the next user of this parity's buffers (two frames on) waits for it
-void stageBDone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evMainDone[ctx->parity], streamB(ctx)); }
+void stageADone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evStageA[ctx->slot], ctx->streamA); }
+hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->slot & 1u]; }
+void stageBBegin(mv_ctx* ctx)
+{
+	(void)hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->slot], 0);
+	(void)hipStreamWaitEvent(streamB(ctx), ctx->evLight[ctx->slot], 0);	// this frame's light march, if one has been enqueued
+}
+// stage of stream B finished being enqueued: the next user of this slot's buffers (kFrameSlots frames on) and the light march two frames on wait for it
+void stageBDone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evMainDone[ctx->slot], streamB(ctx)); }
 
 void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
 {
@@ -259,6 +270,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	}
 
 	ctx->streamA = ctx->stream;
+	ctx->streamL = ctx->stream;
 	ctx->streamB[0] = ctx->streamB[1] = ctx->stream;
 	if (cfg->flags & MV_FLAG_PIPELINE_FRAMES)
 	{
@@ -267,12 +279,14 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		int prLow = 0, prHigh = 0;
 		(void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
 		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
+		if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamA = true;
 		if (hipStreamCreateWithFlags(&ctx->streamB[1], hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamB1 = true;
 	}
-	for (int i = 0; i < 2; ++i)
-		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
+	for (uint32_t i = 0; i < kFrameSlots; ++i)
+		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess
+			|| hipEventCreateWithFlags(&ctx->evLight[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->evProducers, hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 
 	DeviceState& st = ctx->st;
@@ -307,7 +321,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &ctx->staging, ctx->stagingBytes, false)) != MV_OK) return bail(rc);
 
 	// lightMaps[V], cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-126), all zero-initialised
-	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * 2 * L3 * sizeof(uint4))) != MV_OK) return bail(rc);	// two buffers per volume
+	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * mv::kLightBuffers * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->lightStaging, L3 * sizeof(uint32_t), false)) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownDepth, (size_t)st.W * st.H * sizeof(float))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownShadow, (size_t)st.M * st.M * sizeof(uint16_t))) != MV_OK) return bail(rc);
@@ -320,20 +334,20 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	// fp32 RGBA layers; volumes beyond the slot capacity fall back to marching inside the composite.
 	st.screenSlots = st.shardCount > 1 ? 0u : (st.V < 8u ? st.V : 8u);
 	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
-	// constants + cull outputs, once per frame parity (FrameBufs)
+	// constants + cull outputs, once per frame slot (FrameBufs)
 	{
 		std::vector<uint4*> table(st.V);
-		for (uint32_t v = 0; v < st.V; ++v) table[v] = st.lightBuffers + (size_t)(2u * v) * L3;
-		for (int p = 0; p < 2; ++p)
+		for (uint32_t v = 0; v < st.V; ++v) table[v] = st.lightBuffers + (size_t)(mv::kLightBuffers * v) * L3;
+		for (uint32_t p = 0; p < kFrameSlots; ++p)
 		{
 			FrameBufs& f = ctx->fb[p];
-			if ((rc = devAlloc(ctx, &f.dCb, 256)) != MV_OK) return bail(rc);
-			if ((rc = devAlloc(ctx, &f.dPerObject, (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.dCb, 256 + (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);	// one upload: CBPerFrame, then PerObject[V]
+			f.dPerObject = static_cast<uint8_t*>(f.dCb) + 256;
 			if ((rc = devAlloc(ctx, &f.volumeInfo, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.visibleVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.cubeMapVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
-			if ((rc = devAlloc(ctx, &f.counters, kNumCounters * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.counters, (kNumCounters + 8) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.screenSlot, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.workEntries, ((size_t)st.V * 6 + st.screenSlots) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.workTileStart, ((size_t)st.V * 6 + st.screenSlots + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
@@ -350,7 +364,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
 	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
 	{ const char* e = getenv("MV_TILE_ORDER"); ctx->orderTiles = !(e && e[0] == '0'); }
-	for (int p = 0; p < 2; ++p)
+	for (uint32_t p = 0; p < kFrameSlots; ++p)
 	{
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 256 * 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
@@ -376,8 +390,15 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	}
+	for (uint32_t p = 2; p < kFrameSlots; ++p)
+	{
+		FrameBufs& f = ctx->fb[p];
+		const FrameBufs& g = ctx->fb[p & 1u];	// outputs exist per parity
+		f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
+		f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost;
+	}
 	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
-	ctx->parity = 0;
+	ctx->slot = 0;
 	applyParity(ctx);
 
 	// pinned upload ring + readback scratch
@@ -407,9 +428,10 @@ void mv_destroy(mv_ctx* ctx)
 	if (!ctx) return;
 	if (ctx->stream) (void)syncAll(ctx);
 	foldEvents(ctx);
-	for (int i = 0; i < 2; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); }
+	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); if (ctx->evLight[i]) (void)hipEventDestroy(ctx->evLight[i]); }
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
 	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
+	if (ctx->ownStreamA && ctx->streamL && ctx->streamL != ctx->stream) (void)hipStreamDestroy(ctx->streamL);
 	if (ctx->ownStreamB1 && ctx->streamB[1]) (void)hipStreamDestroy(ctx->streamB[1]);
 	for (EventPair& ev : ctx->freeEvents) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
 	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
@@ -557,11 +579,12 @@ int mv_set_max_samples(mv_ctx* ctx, uint32_t maxRaySamples, uint32_t maxLightSam
 int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 {
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
-	// a new frame: switch to the other parity's constants / cull buffers
-	ctx->parity ^= 1u;
+	// a new frame: the next slot of constants / cull buffers (and the other parity's march outputs)
+	ctx->slot = (ctx->slot + 1u) % kFrameSlots;
 	applyParity(ctx);
-	// its previous user (two frames ago) must be done with them; volume producers on stream B must have finished
-	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->parity], 0));
+	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
+	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->slot], 0));
+	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evLight[ctx->slot], 0));
 	if (ctx->producersDirty) { MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evProducers, 0)); ctx->producersDirty = false; }
 	const uint32_t k = ctx->slice;
 	ctx->slice = (k + 1) % kFrameSlices;
@@ -569,9 +592,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	uint8_t* s = ctx->pinned + (size_t)k * ctx->sliceBytes;
 	memcpy(s, cbPerFrame, MV_CB_PER_FRAME_BYTES);
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
-	const FrameBufs& f = ctx->fb[ctx->parity];
-	MV_HIP(ctx, hipMemcpyAsync(f.dCb, s, MV_CB_PER_FRAME_BYTES, hipMemcpyHostToDevice, ctx->streamA));
-	MV_HIP(ctx, hipMemcpyAsync(f.dPerObject, s + 256, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES, hipMemcpyHostToDevice, ctx->streamA));
+	MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));
 	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->streamA));
 	stageADone(ctx);
 	ctx->haveFrame = true;
@@ -592,7 +613,7 @@ int mv_cull(mv_ctx* ctx)
 	{
 		// dispatch order of this frame's view march, on ITS stream: it runs beside the light march and only needs the cull
 		stageBBegin(ctx);
-		mv::launchTileOrder(streamB(ctx), ctx->st, ctx->fb[ctx->parity].binCounts, ctx->fb[ctx->parity].tileOrder);
+		mv::launchTileOrder(streamB(ctx), ctx->st, ctx->fb[ctx->slot].binCounts, ctx->fb[ctx->slot].tileOrder);
 		MV_HIP(ctx, hipGetLastError());
 	}
 	ctx->haveCull = true;
@@ -604,12 +625,17 @@ int mv_march_light(mv_ctx* ctx)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
+	// The light buffer this launch writes was last read by a frame at least kLightBuffers (3) frames back (the relit volume's
+	// table entry has rotated since): that frame's view march / composite must be over.  Older ones are, by stream order.
+	static_assert(mv::kLightBuffers == 3 && kFrameSlots == 4, "the wait below names frame i - 3");
+	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamL, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));
+	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamL, ctx->evStageA[ctx->slot], 0));	// this frame's upload + cull
 	EventPair ev;
-	beginStage(ctx, 1, ev, ctx->streamA);
-	mv::launchMarchLight(ctx->streamA, ctx->st);
-	endStage(ctx, ev, ctx->streamA);
+	beginStage(ctx, 1, ev, ctx->streamL);
+	mv::launchMarchLight(ctx->streamL, ctx->st);
+	endStage(ctx, ev, ctx->streamL);
 	MV_HIP(ctx, hipGetLastError());
-	stageADone(ctx);
+	MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], ctx->streamL));
 	return MV_OK;
 }
 
@@ -783,7 +809,7 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 	if (ctx->fb[0].tileStats != ctx->fb[1].tileStats)
 	{
 		DeviceState other = ctx->st;
-		const FrameBufs& q = ctx->fb[ctx->parity ^ 1u];
+		const FrameBufs& q = ctx->fb[(ctx->slot & 1u) ^ 1u];
 		other.tileStats = q.tileStats; other.screenStats = q.screenStats; other.compositeStats = q.compositeStats;
 		mv::launchReduceStats(ctx->stream, other, 0);
 	}

@@ -186,15 +186,18 @@ __device__ __forceinline__ uint32_t relitVolume(const DeviceState& st, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// a1: volume cull.  One workgroup of 8 wavefronts; each wavefront culls 8 volumes (8 lanes = 8 cube vertices each).
-// After the cull the first wavefront compacts the visible / cube-map lists in ascending volume order and builds the
-// march work list (one entry per visible face of every owned cube-map volume, prefix sums of 8x8 tiles), so that
-// marchViewKernel is sized like the reference's work-graph variant (Sh/LibRayMarch.hlsl:120-121) without a host round trip.
+// a1: volume cull.  ceil(V / 8) single-wavefront workgroups; each culls 8 volumes (8 lanes = 8 cube vertices each).
+// The wavefront that finishes last (a ticket in counters[8]) compacts the visible / cube-map lists in ascending volume
+// order and builds the march work list (one entry per visible face of every owned cube-map volume, prefix sums of 8x8
+// tiles), so that marchViewKernel is sized like the reference's work-graph variant (Sh/LibRayMarch.hlsl:120-121) without a
+// host round trip.  Single-wave workgroups on purpose: with frames in flight the cull is dispatched while the previous
+// frame's view march fills every CU, and a 512-thread workgroup (the first version) waited 200-600 us for one CU to free
+// eight wave slots at once; a lone wave takes the first slot that retires.
 // ---------------------------------------------------------------------------------------------
 __constant__ uint8_t kEdgeLanes[12][2] = { {0,1},{3,2},{1,3},{2,0},{6,7},{5,4},{4,6},{7,5},{4,0},{2,6},{7,3},{1,5} };	// VolumeCull.hlsli:119-138
 __constant__ uint8_t kFaceEdges[6][4] = { {8,3,9,6},{10,2,11,7},{0,8,5,11},{1,10,4,9},{0,2,1,3},{4,6,5,7} };			// VolumeCull.hlsli:213-223
 
-constexpr uint32_t kCullThreads = 512;
+constexpr uint32_t kCullThreads = 64;
 
 __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 {
@@ -211,9 +214,8 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	const uint32_t baseLane = lane & ~7u;	// 8 * wTid.y
 	const uint32_t l6 = li < 6u ? li : 5u;	// lanes 6-7 shadow lane 5 so that every shuffle is executed wave-wide
 
-	for (uint32_t base = 0; base < st.V; base += kCullThreads / 8)
 	{
-		const uint32_t volumeId = base + (threadIdx.x >> 3);
+		const uint32_t volumeId = blockIdx.x * (kCullThreads / 8) + (threadIdx.x >> 3);
 		const bool valid = volumeId < st.V;
 		const PerObject& po = perObjects[valid ? volumeId : 0u];
 
@@ -301,7 +303,6 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			}
 			else { rect.x = 0; rect.y = 0; rect.z = 65535; rect.w = 65535; }
 			reinterpret_cast<ushort4*>(st.volumeRects)[volumeId] = rect;
-			sRect[2 * volumeId] = (uint32_t)rect.x | ((uint32_t)rect.y << 16); sRect[2 * volumeId + 1] = (uint32_t)rect.z | ((uint32_t)rect.w << 16);
 			uint32_t info = 0u;
 			if (volumeVis != 0u)
 			{
@@ -337,12 +338,25 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 				info = 1u | (useCubeMap ? 2u : 0u) | (mipLevel << 2) | ((faceMask & 0x3fu) << 5);
 			}
 			else reinterpret_cast<ushort4*>(st.volumeInfo)[volumeId] = reinterpret_cast<const ushort4*>(st.volumeInfoPrev)[volumeId];	// CSVolumeCull.hlsl:38 returns without writing
-			sInfo[volumeId] = info;
+			st.volumeFlags[volumeId] = info;
 		}
 	}
 
+	// last wavefront to get here builds the lists from everybody's flags and rectangles
+	__threadfence();
+	uint32_t ticket = 0;
+	if (lane == 0) ticket = atomicAdd(&st.counters[8], 1u);
+	ticket = __shfl(ticket, 0);
+	if (ticket != gridDim.x - 1u) return;
+	__threadfence();
+	for (uint32_t v = lane; v < st.V; v += 64)
+	{
+		sInfo[v] = __hip_atomic_load(st.volumeFlags + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t* rects = reinterpret_cast<const uint32_t*>(st.volumeRects);
+		sRect[2 * v] = __hip_atomic_load(rects + 2 * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);		// x0 | y0 << 16
+		sRect[2 * v + 1] = __hip_atomic_load(rects + 2 * v + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// x1 | y1 << 16
+	}
 	__syncthreads();
-	if (threadIdx.x >= 64u) return;
 
 	// ---- list compaction + work list, first wavefront ----
 	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
@@ -353,7 +367,6 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	{
 		const uint32_t v = base + lane;
 		const uint32_t info = v < st.V ? sInfo[v] : 0u;
-		if (v < st.V) st.volumeFlags[v] = info;
 		const bool vis = info & 1u, cube = info & 2u;
 		const bool owned = (v % shardCount) == st.shardIndex;
 		const uint32_t mip = (info >> 2) & 7u, mask = (info >> 5) & 0x3fu;
@@ -412,7 +425,13 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		for (uint32_t v = lane; v < st.V; v += 64)
 		{
 			uint4* p = st.lightTablePrev[v];
-			if (v == relit) p = (p == st.lightBuffers + (size_t)(2u * v) * L3) ? st.lightBuffers + (size_t)(2u * v + 1u) * L3 : st.lightBuffers + (size_t)(2u * v) * L3;
+			if (v == relit)
+			{
+				// next of the volume's kLightBuffers buffers, in rotation
+				uint4* first = st.lightBuffers + (size_t)(kLightBuffers * v) * L3;
+				const uint32_t k = (uint32_t)((size_t)(p - first) / L3);
+				p = first + (size_t)((k + 1u) % kLightBuffers) * L3;
+			}
 			st.lightTable[v] = p;
 		}
 	}
@@ -465,6 +484,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			stride += 2u;
 		}
 		st.counters[7] = nTiles < 2u ? 1u : stride;
+		st.counters[8] = 0u;	// the ticket, for the next cull that uses this slot
 	}
 }
 
@@ -1145,7 +1165,7 @@ void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, u
 
 void launchCull(hipStream_t s, const DeviceState& st)
 {
-	hipLaunchKernelGGL(cullKernel, dim3(1), dim3(kCullThreads), st.V * 3 * sizeof(uint32_t), s, st);
+	hipLaunchKernelGGL(cullKernel, dim3((st.V + 7u) / 8u), dim3(kCullThreads), st.V * 3 * sizeof(uint32_t), s, st);
 }
 
 void launchMarchLight(hipStream_t s, const DeviceState& st)

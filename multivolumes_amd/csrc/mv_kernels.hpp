@@ -7,6 +7,10 @@
 
 namespace mv
 {
+// Light-map buffers per volume.  The light march of frame i writes the buffer the relit volume's table entry held
+// kLightBuffers relights ago, which no frame after i - kLightBuffers can still be reading.
+constexpr uint32_t kLightBuffers = 3;
+
 // Device-side state of one context. Every pointer is device memory; the struct is passed to kernels by value.
 struct DeviceState
 {
@@ -33,10 +37,10 @@ struct DeviceState
 	const uint2* const* volumes;	// S pointers to bricked RGBA16F texels
 	const uint4* const* alphaCells;	// S pointers to the bricked alpha cells (8 halfs per texel: its 2x2x2 footprint)
 	// Light maps: L^3 quad-replicated R11G11B10F cells {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)} per volume.  Every volume
-	// has TWO buffers; lightTable[v] is the one this frame reads (and, for the volume relit this frame, writes).  The cull
-	// derives it from the previous frame's table and flips the relit volume, so that the light march of frame i+1 can
-	// run on a second stream while the view march / composite of frame i still read frame i's light maps.
-	uint4* lightBuffers;			// 2 V x L^3 cells: buffer k of volume v at index 2 v + k
+	// has kLightBuffers buffers; lightTable[v] is the one this frame reads (and, for the volume relit this frame, writes).
+	// The cull derives it from the previous frame's table and rotates the relit volume's entry, so that the light march
+	// of frames i+1, i+2 can run while the view march / composite of frame i still read frame i's light maps.
+	uint4* lightBuffers;			// kLightBuffers V x L^3 cells: buffer k of volume v at index kLightBuffers v + k
 	uint4** lightTable;				// V pointers (this frame)
 	uint4* const* lightTablePrev;	// V pointers (previous frame)
 	const uint16_t* volumeInfoPrev;	// previous frame's VolumeInfo (rows of culled volumes are carried over: the reference never clears them)

@@ -1,0 +1,42 @@
+"""Summarise a rocprofv3 --kernel-trace CSV: per-kernel durations, how the streams overlap, and the idle gaps of the GPU.
+usage: python scripts/timeline.py <dir with *_kernel_trace.csv> [skip_frames]"""
+import csv, glob, sys, collections
+d = sys.argv[1]
+f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].replace("mv::", ""), r.get("Queue_Id", "?")) for r in rows)
+# keep the steady state: from the (skip)th marchViewKernel on
+mv = [i for i, e in enumerate(ev) if e[2].startswith("marchViewKernel")]
+lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.34
+hi = float(sys.argv[3]) if len(sys.argv) > 3 else 0.99
+ev = ev[mv[int(lo * len(mv))]:mv[min(len(mv) - 2, int(hi * len(mv)))]]
+t0, t1 = ev[0][0], max(e[1] for e in ev)
+n = sum(1 for e in ev if e[2].startswith("marchViewKernel"))
+print("frames %d  span %.3f ms  -> %.4f ms/frame" % (n, (t1 - t0) / 1e6, (t1 - t0) / 1e6 / n))
+dur = collections.defaultdict(list)
+for s, e, k, q in ev: dur[(k, q)].append(e - s)
+for (k, q), v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    print("  %-28s queue %-3s n %5d  avg %8.1f us  per-frame %7.1f us" % (k, q, len(v), sum(v) / len(v) / 1e3, sum(v) / n / 1e3))
+# coverage: time with 0, 1, 2+ kernels running
+pts = []
+for s, e, k, q in ev: pts += [(s, 1), (e, -1)]
+pts.sort()
+cov = collections.Counter(); cur = 0; last = pts[0][0]
+for t, dlt in pts:
+    cov[min(cur, 3)] += t - last; last = t; cur += dlt
+tot = sum(cov.values())
+print("  concurrency: " + "  ".join("%d kernels: %.1f%% (%.1f us/frame)" % (k, 100.0 * v / tot, v / n / 1e3) for k, v in sorted(cov.items())))
+# a sample of the steady-state schedule
+base = ev[len(ev) // 2][0]
+for s, e, k, q in ev[len(ev) // 2: len(ev) // 2 + 24]:
+    print("   %9.1f .. %9.1f us  q%-3s %s" % ((s - base) / 1e3, (e - base) / 1e3, q, k))
+# the largest idle gaps (no kernel running) of the window
+gaps = []; cur = 0; last = None
+for t, dlt in pts:
+    if cur == 0 and last is not None and t - last > 30000: gaps.append((t - last, last))
+    cur += dlt
+    if cur == 0: last = t
+print("  idle gaps > 30 us: %d, total %.1f us/frame" % (len(gaps), sum(g for g, _ in gaps) / n / 1e3))
+for g, at in sorted(gaps, reverse=True)[:8]:
+    prev = [e for e in ev if e[1] <= at][-3:]; nxt = [e for e in ev if e[0] >= at + g][:2]
+    print("   gap %.1f us at %.1f us after %s before %s" % (g / 1e3, (at - t0) / 1e3, [p[2] for p in prev], [q[2] for q in nxt]))
