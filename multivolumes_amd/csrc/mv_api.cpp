@@ -74,6 +74,8 @@ struct mv_ctx
 	std::vector<uint4*> cells;
 	uint2** dVolumePtrs = nullptr;
 	uint4** dCellPtrs = nullptr;
+	std::vector<uint64_t*> occupancy;	// brick occupancy words per volume source
+	uint64_t** dOccPtrs = nullptr;
 	uint32_t* lightStaging = nullptr;	// L^3 plain R11G11B10F (readback / upload conversion)
 	bool orderTiles = true;				// MV_TILE_ORDER=0 in the environment: list-order dispatch (A/B measurements)
 	// mesh depth / shadow producer (mv_mesh_*)
@@ -316,6 +318,16 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipMemcpyAsync(ctx->dCellPtrs, ctx->cells.data(), st.S * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 	st.alphaCells = ctx->dCellPtrs;
+	{
+		const size_t regions = mv::occupancyRegions(st.bricks);
+		ctx->occupancy.resize(st.S, nullptr);
+		for (uint32_t i = 0; i < st.S; ++i)
+			if ((rc = devAlloc(ctx, &ctx->occupancy[i], regions * regions * regions * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &ctx->dOccPtrs, st.S * sizeof(uint64_t*), false)) != MV_OK) return bail(rc);
+		if (hipMemcpyAsync(ctx->dOccPtrs, ctx->occupancy.data(), st.S * sizeof(uint64_t*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+		if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+		st.occupancy = ctx->dOccPtrs;
+	}
 
 	ctx->stagingBytes = (size_t)st.N * st.N * st.N * sizeof(uint2);
 	if ((rc = devAlloc(ctx, &ctx->staging, ctx->stagingBytes, false)) != MV_OK) return bail(rc);
@@ -453,6 +465,7 @@ int mv_volume_upload_rgba16f(mv_ctx* ctx, uint32_t src, const uint16_t* rgba)
 	MV_HIP(ctx, hipMemcpyAsync(ctx->staging, rgba, ctx->stagingBytes, hipMemcpyHostToDevice, ctx->stream));
 	mv::launchRetile(ctx->stream, ctx->staging, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
+	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the caller may reuse `rgba` and the staging buffer is shared
 	return MV_OK;
@@ -464,6 +477,7 @@ int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgb
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	mv::launchRetile(ctx->stream, reinterpret_cast<const uint2*>(d_rgba), ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
+	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipEventRecord(ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
 	ctx->producersDirty = true;
@@ -476,6 +490,7 @@ int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src)
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	mv::launchInitGridData(ctx->stream, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
+	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipEventRecord(ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
 	ctx->producersDirty = true;
@@ -494,6 +509,7 @@ int mv_volume_load_r32f(mv_ctx* ctx, uint32_t src, const float* a, uint32_t w, u
 	{
 		mv::launchR32FToRGBA16F(ctx->stream, dSrc, w, h, d, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 		mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
+		mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
 		e = hipGetLastError();
 	}
 	const hipError_t e2 = hipStreamSynchronize(ctx->stream);

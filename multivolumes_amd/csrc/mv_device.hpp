@@ -258,6 +258,7 @@ struct FootprintAddr
 	uint32_t x0, x1, r00, r10, r01, r11;	// texel byte offsets: x taps and the four (y, z) rows
 	float fx, fy, fz;						// filter weights
 	float cx, cy, cz;						// weights for a CELL fetch: 0 where the two taps of an axis coincide (see fetchAlphaCell)
+	uint32_t ix, iy, iz;					// first tap of every axis (the footprint is {i, min(i + 1, N - 1)}^3)
 };
 
 __device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
@@ -269,6 +270,7 @@ __device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3
 	const uint32_t z0 = offZ(tz.i0, v.strideZ), z1 = offZ(tz.i1, v.strideZ);
 	a.r00 = y0 + z0; a.r10 = y1 + z0; a.r01 = y0 + z1; a.r11 = y1 + z1;
 	a.fx = tx.f; a.fy = ty.f; a.fz = tz.f;
+	a.ix = (uint32_t)tx.i0; a.iy = (uint32_t)ty.i0; a.iz = (uint32_t)tz.i0;
 	// A cell holds the clamped +1 neighbours of its own texel.  They are the sampler's second taps except when both
 	// taps of an axis are the SAME texel (coordinate below the first texel centre: taps (0,0) but the cell holds (0,1));
 	// there lerp(a, a, f) == a exactly, which is lerp(a, b, 0): zero the weight instead of fetching differently.
@@ -276,7 +278,51 @@ __device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3
 	return a;
 }
 
+// ---- brick occupancy ---------------------------------------------------------------------------
+// One bit per 4x4x4 brick: set when ANY texel of the brick or of its +1 halo (the texels a trilinear footprint whose first
+// taps lie in the brick can read) has alpha above kOccupancyLimit.  A clear bit proves that the interpolated alpha of such a
+// sample cannot exceed ZERO_THRESHOLD (a convex combination of values <= limit, evaluated with three roundings of relative
+// size 6e-8, against a limit 1e-3 below the threshold: the largest fp16 below 0.01 is 0.0099945), i.e. that the reference's
+// loop does nothing for it but advance t -- so the eight texel loads, and the HBM lines behind them, are skipped.
+// 64 bricks (a 16^3-texel region) share one 64-bit word: bit = bx & 3 | (by & 3) << 2 | (bz & 3) << 4.
+constexpr float kOccupancyLimit = 0.00999f;
+__host__ __device__ inline uint32_t occupancyRegions(uint32_t bricks) { return (bricks + 3u) >> 2; }
+__device__ __forceinline__ uint32_t occupancyWord(uint32_t ix, uint32_t iy, uint32_t iz, uint32_t regions)
+{
+	return ((iz >> 4) * regions + (iy >> 4)) * regions + (ix >> 4);
+}
+__device__ __forceinline__ uint32_t occupancyBit(uint32_t ix, uint32_t iy, uint32_t iz)
+{
+	return ((ix >> 2) & 3u) | (((iy >> 2) & 3u) << 2) | (((iz >> 2) & 3u) << 4);
+}
+
 // density of the footprint: one aligned 16-byte load of the alpha cell at (x0, y0, z0)
+#ifndef MV_ALPHA_QUADS
+#define MV_ALPHA_QUADS 1
+#endif
+#if MV_ALPHA_QUADS
+// Quad form (default): the companion holds 8 bytes per texel -- {a(x,y,z), a(x+1,y,z), a(x,y,z+1), a(x+1,y,z+1)}, +1 neighbours
+// clamped -- in the texels' own brick layout, and a footprint is the quads of its two y rows (32 bytes apart inside one
+// 128-byte line three times out of four).  Half the bytes of the 16-byte cell form behind every sample: the light march
+// reads this structure almost completely every launch and is bound by HBM bandwidth (589 MB per launch with cells).
+struct AlphaFootprint { u32x2 row0, row1; float cx, cy, cz; };
+
+__device__ __forceinline__ AlphaFootprint fetchAlphaCell(const VolumeView& v, const FootprintAddr& a)
+{
+	AlphaFootprint f;
+	f.row0 = *(GlobalUint2)(v.cells + (a.r00 + a.x0));
+	f.row1 = *(GlobalUint2)(v.cells + (a.r10 + a.x0));
+	f.cx = a.cx; f.cy = a.fy; f.cz = a.cz;	// the y taps are the sampler's own: its own weight
+	return f;
+}
+
+__device__ __forceinline__ float resolveAlpha(const AlphaFootprint& f)
+{
+	return trilerp(half_bits_to_float(f.row0.x & 0xffffu), half_bits_to_float(f.row0.x >> 16), half_bits_to_float(f.row1.x & 0xffffu), half_bits_to_float(f.row1.x >> 16),
+		half_bits_to_float(f.row0.y & 0xffffu), half_bits_to_float(f.row0.y >> 16), half_bits_to_float(f.row1.y & 0xffffu), half_bits_to_float(f.row1.y >> 16),
+		f.cx, f.cy, f.cz);
+}
+#else
 struct AlphaFootprint { u32x4 cell; float cx, cy, cz; };
 
 __device__ __forceinline__ AlphaFootprint fetchAlphaCell(const VolumeView& v, const FootprintAddr& a)
@@ -294,6 +340,7 @@ __device__ __forceinline__ float resolveAlpha(const AlphaFootprint& f)
 		half_bits_to_float(f.cell.z & 0xffffu), half_bits_to_float(f.cell.z >> 16), half_bits_to_float(f.cell.w & 0xffffu), half_bits_to_float(f.cell.w >> 16),
 		f.cx, f.cy, f.cz);
 }
+#endif
 
 // Texture3D<float4>.SampleLevel(LINEAR_CLAMP, uvw, 0, offset).w -- Sh/RayMarch.hlsli:44-50, 74
 __device__ __forceinline__ float sampleAlpha16F(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)

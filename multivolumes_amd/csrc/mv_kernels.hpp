@@ -36,6 +36,7 @@ struct DeviceState
 	// resources
 	const uint2* const* volumes;	// S pointers to bricked RGBA16F texels
 	const uint4* const* alphaCells;	// S pointers to the bricked alpha cells (8 halfs per texel: its 2x2x2 footprint)
+	const uint64_t* const* occupancy;	// S pointers to the brick occupancy words (mv_device.hpp), ceil(bricks / 4)^3 each
 	// Light maps: L^3 quad-replicated R11G11B10F cells {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)} per volume.  Every volume
 	// has kLightBuffers buffers; lightTable[v] is the one this frame reads (and, for the volume relit this frame, writes).
 	// The cull derives it from the previous frame's table and rotates the relit volume's entry, so that the light march
@@ -97,6 +98,7 @@ void launchUntile(hipStream_t s, const uint2* bricked, uint2* linear, uint32_t N
 void launchInitGridData(hipStream_t s, uint2* bricked, uint32_t N, uint32_t bricks);
 void launchR32FToRGBA16F(hipStream_t s, const float* src, uint32_t w, uint32_t h, uint32_t d, uint2* bricked, uint32_t N, uint32_t bricks);
 void launchBuildAlphaCells(hipStream_t s, const uint2* bricked, uint4* cells, uint32_t N, uint32_t bricks);
+void launchBuildOccupancy(hipStream_t s, const uint2* bricked, uint64_t* words, uint32_t N, uint32_t bricks);
 void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uint32_t L);
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);

@@ -1,9 +1,10 @@
-# usage: exp_flag.sh MACRO v1 v2 ...   -> rebuilds with -DMACRO=v and prints C3 / stress kernel times
-M=$1; shift
-for w in "$@"; do
-  ./multivolumes_amd/csrc/build.sh -D$M=$w -Rpass-analysis=kernel-resource-usage 2>&1 | grep -A3 "marchViewKernelILi0" | grep VGPRs | sed 's/.*remark: *//'
-  for a in "" "--stress"; do
-  timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline $a 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$M=$w $a', d['kernel_ms'], d['roofline']['frac'])"
+#!/bin/bash
+# usage: scripts/exp_flag.sh "<bench args>" -DFLAG=a -DFLAG=b ...   (rebuilds the library per flag set and prints the bench summary)
+args="$1"; shift
+for f in "$@"; do
+  ./multivolumes_amd/csrc/build.sh $f > /dev/null 2>&1 || { echo "build failed: $f"; continue; }
+  for i in 1 2; do
+    python bench.py --no-cpu-baseline $args 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$f', round(d['ms_per_step'],4), {k: round(v,4) for k,v in d['kernel_ms'].items()})"
   done
 done
-timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+./multivolumes_amd/csrc/build.sh > /dev/null 2>&1
