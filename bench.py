@@ -211,6 +211,7 @@ def main():
                 "samples_per_ray_cap": [int(info[v, 1]) for v in vis][:4],
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
+                "fetch_free_samples_per_frame": st.get("fetch_free_samples", 0) // K,
                 "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
                 "frames_in_flight": "up to 3 (constants / cull 4 slots, march outputs 2, light maps 3 buffers per volume)" if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
@@ -222,6 +223,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "marchViewKernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": ms_v,
+                         "requested_bytes_per_launch": alg_bytes - 64 * st.get("fetch_free_samples", 0) / K,
                          "launch_ms_in_flight": k_in_flight["march_view"],
                          "launch_ms_from": (f"{args.roofline_frames} frames run one at a time after the timed region (HIP events)" if st_iso
                                             else f"every {args.profile_every}th frame of the timed region (HIP events)")},

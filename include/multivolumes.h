@@ -88,7 +88,9 @@ typedef struct mv_stats
 	uint64_t rays;				/* texels of visible faces whose ray hit the box */
 	uint64_t light_samples;		/* iterations of CastLightRay (RayMarch.hlsli:206-229) */
 	uint64_t composite_samples;	/* screen-space RayCast samples (RayCast.hlsli:62-102) */
-	uint64_t reserved[3];
+	uint64_t reserved[3];		/* [0] view-march lane slots (64 x longest ray of every wavefront), [1] lit samples among composite_samples that were
+								   marched inside the view-march launch, [2] view / RayCast samples counted above whose eight texel loads were
+								   not issued because their brick's occupancy bit proved alpha <= ZERO_THRESHOLD (results are unaffected) */
 	double ms_cull, ms_march_light, ms_march_view, ms_composite;	/* HIP-event time per stage when profiling is on */
 	uint64_t n_cull, n_march_light, n_march_view, n_composite;		/* launches those sums cover */
 } mv_stats;

@@ -50,7 +50,7 @@ struct FrameBufs
 	float* cubeDepths = nullptr;
 	uint2* composite = nullptr;
 	float4* screenLayers = nullptr;
-	uint64_t *tileStats = nullptr, *screenStats = nullptr, *compositeStats = nullptr;
+	uint64_t *tileStats = nullptr, *screenStats = nullptr, *compositeStats = nullptr, *tileSkipped = nullptr;
 	uint16_t* tileCost = nullptr;
 	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per slot
 };
@@ -149,7 +149,7 @@ void applyParity(mv_ctx* ctx)
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo;
 	st.cubeMaps = f.cubeMaps; st.cubeDepths = f.cubeDepths; st.composite = f.composite; st.screenLayers = f.screenLayers;
-	st.tileStats = f.tileStats; st.screenStats = f.screenStats; st.compositeStats = f.compositeStats; st.tileCost = f.tileCost;
+	st.tileStats = f.tileStats; st.screenStats = f.screenStats; st.compositeStats = f.compositeStats; st.tileCost = f.tileCost; st.tileSkipped = f.tileSkipped;
 	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
 }
 
@@ -389,7 +389,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		{
 			const FrameBufs& g = ctx->fb[0];	// one frame in flight: both parities share the outputs
 			f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
-			f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost;
+			f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost; f.tileSkipped = g.tileSkipped;
 			break;
 		}
 		// cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-121), zero-initialised
@@ -400,6 +400,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.tileCost, ((size_t)st.V * 6 * ((st.N + 7u) >> 3) * ((st.N + 7u) >> 3) + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.tileSkipped, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	}
 	for (uint32_t p = 2; p < kFrameSlots; ++p)
@@ -407,7 +408,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		FrameBufs& f = ctx->fb[p];
 		const FrameBufs& g = ctx->fb[p & 1u];	// outputs exist per parity
 		f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
-		f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost;
+		f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost; f.tileSkipped = g.tileSkipped;
 	}
 	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
 	ctx->slot = 0;
@@ -826,7 +827,7 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 	{
 		DeviceState other = ctx->st;
 		const FrameBufs& q = ctx->fb[(ctx->slot & 1u) ^ 1u];
-		other.tileStats = q.tileStats; other.screenStats = q.screenStats; other.compositeStats = q.compositeStats;
+		other.tileStats = q.tileStats; other.screenStats = q.screenStats; other.compositeStats = q.compositeStats; other.tileSkipped = q.tileSkipped;
 		mv::launchReduceStats(ctx->stream, other, 0);
 	}
 	MV_HIP(ctx, hipGetLastError());
@@ -840,6 +841,7 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 	out->light_samples = ctx->pinnedStats[3];
 	out->composite_samples = ctx->pinnedStats[4];
 	out->reserved[0] = ctx->pinnedStats[5];	// marchV lane slots (64 x longest ray per wavefront)
+	out->reserved[2] = ctx->pinnedStats[7];	// view / RayCast samples marched without a texel fetch (their brick's occupancy bit was clear)
 	out->reserved[1] = ctx->pinnedStats[6];	// lit samples among composite_samples that were marched inside the view-march launch
 	out->ms_cull = ctx->msStage[0]; out->ms_march_light = ctx->msStage[1]; out->ms_march_view = ctx->msStage[2]; out->ms_composite = ctx->msStage[3];
 	out->n_cull = ctx->nStage[0]; out->n_march_light = ctx->nStage[1]; out->n_march_view = ctx->nStage[2]; out->n_composite = ctx->nStage[3];
@@ -858,6 +860,7 @@ int mv_reset_stats(mv_ctx* ctx)
 	{
 		const FrameBufs& f = ctx->fb[p];
 		MV_HIP(ctx, hipMemsetAsync(f.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(f.tileSkipped, 0, ((size_t)ctx->st.maxTiles + ctx->st.maxScreenTiles + 1) * sizeof(uint64_t), ctx->stream));
 		MV_HIP(ctx, hipMemsetAsync(f.compositeStats, 0, (size_t)ctx->st.compositeSlots * sizeof(uint64_t), ctx->stream));
 		MV_HIP(ctx, hipMemsetAsync(f.screenStats, 0, ((size_t)ctx->st.maxScreenTiles + 1) * 2 * sizeof(uint64_t), ctx->stream));
 	}

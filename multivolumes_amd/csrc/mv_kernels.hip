@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 	const bool screenTile = faceId == 7u;	// wave-uniform
 
 	// ---- ray setup: a cube-face texel (CSRayMarch.hlsl:84-107) or a screen pixel of a RayCast volume (RayCast.hlsli:43-54)
-	uint32_t nSamples = 0, nLit = 0, nRays = 0;
+	uint32_t nSamples = 0, nLit = 0, nRays = 0, nSkipped = 0;
 	bool valid = false;
 	vec3 rayOrigin = mul43(v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]), po.worldI);	// :89
 	vec3 rayDir = v3(0.0f, 0.0f, 1.0f);
@@ -940,6 +940,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 					if (!((occWord >> occupancyBit(fa.ix, fa.iy, fa.iz)) & 1ull))
 					{
 						++nSamples;
+						++nSkipped;
 						prevLit = false;
 						t += stepScale;
 						if (t > tMax) break;	// :152
@@ -1030,12 +1031,13 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 		}
 	}
 
-	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays);
+	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays), totK = waveSumU32(nSkipped);
 	uint32_t maxS = nSamples;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
 	const uint32_t nCubeTiles = st.counters[6];
 	if (lane == 0) st.tileCost[tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles)] = (uint16_t)(maxS > 65535u ? 65535u : maxS);
+	if (lane == 0 && totK && tile < st.maxTiles + st.maxScreenTiles) st.tileSkipped[tile] += totK;	// samples whose fetch the occupancy bits saved
 	if (lane == 0 && screenTile)
 	{
 		const uint32_t sIdx = tile - nCubeTiles;
@@ -1153,7 +1155,7 @@ void launchTileOrder(hipStream_t s, const DeviceState& st, uint32_t* binCounts, 
 // Sums the per-wavefront counter slots into st.stats (run by mv_get_stats, not per frame).
 __global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st, int includeLight)
 {
-	unsigned long long a[7] = { 0, 0, 0, 0, 0, 0, 0 };	// [6] = lit samples of the fused RayCast tiles
+	unsigned long long a[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };	// [6] = lit samples of the fused RayCast tiles, [7] = samples marched without a texel fetch
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
 	for (uint32_t i = tid; i < st.maxTiles; i += nThreads)
 	{
@@ -1164,7 +1166,9 @@ __global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st, int inc
 	for (uint32_t i = tid; i < st.compositeSlots; i += nThreads) a[4] += st.compositeStats[i];
 	for (uint32_t i = tid; i < st.maxScreenTiles; i += nThreads) { a[4] += st.screenStats[2 * i]; a[6] += st.screenStats[2 * i + 1]; }
 #pragma unroll
-	for (int k = 0; k < 7; ++k)
+	for (uint32_t i = tid; i < st.maxTiles + st.maxScreenTiles; i += nThreads) a[7] += st.tileSkipped[i];
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
 	{
 		unsigned long long v = a[k];
 #pragma unroll

@@ -70,8 +70,9 @@ struct DeviceState
 	// Counters.  Every wavefront owns one slot and updates it with a plain read-modify-write (launches are stream
 	// ordered), because tens of thousands of same-address atomics per launch cost more than the march itself.
 	uint64_t* stats;				// totals, filled by launchReduceStats: [0] view samples, [1] lit samples, [2] rays,
-									// [3] light samples, [4] composite samples, [5] marchV lane slots
+									// [3] light samples, [4] composite samples, [5] marchV lane slots, [6] fused RayCast lit samples, [7] fetch-free samples
 	uint64_t* tileStats;			// maxTiles x 4: {view samples, lit samples, rays, lane slots} per marchV tile slot
+	uint64_t* tileSkipped;			// maxTiles + maxScreenTiles: view / RayCast samples marched without a texel fetch (occupancy bit clear)
 	uint64_t* lightStats;			// ceil(L/4)^3: light samples per marchL block
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
 	uint64_t* screenStats;			// maxScreenTiles x 2: {RayCast samples, lit} per screen tile marched by marchViewKernel

@@ -358,6 +358,7 @@ class MultiRayCaster:
         self._check(self._lib.mv_get_stats(self._ctx, C.byref(s)), "mv_get_stats")
         d = {k: getattr(s, k) for k, _ in mv_stats._fields_ if k != "reserved"}
         d["reserved0"] = s.reserved[0]  # marchV lane slots (64 x longest ray per wavefront)
+        d["fetch_free_samples"] = s.reserved[2]  # view / RayCast samples whose texel fetch the brick occupancy bits saved
         d["fused_raycast_lit"] = s.reserved[1]  # lit samples of the RayCast tiles marched inside the view-march launch
         return d
 

@@ -1,0 +1,79 @@
+"""Brick occupancy bits (view march / RayCast): a clear bit skips the eight texel loads of a sample, never the sample.
+
+The skip is legal only if it cannot change a bit of the output or a counter, so every case here is compared with the
+oracle (which has no such structure) bit for bit, on volumes built to sit on the edges of the rule: alpha uniformly at the
+two fp16 values around ZERO_THRESHOLD, a single lit texel at a brick corner (footprints that reach it start in the
+neighbouring bricks), sparse random bricks, and a ragged N that leaves partial bricks and regions.
+"""
+import numpy as np
+import pytest
+
+from multivolumes_amd import scene
+from multivolumes_amd import raycaster as rc
+from tests.helpers import oracle_pipeline
+from tests.test_gpu_parity import compare_cube, compare_light, make_caster, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def uniform(N, alpha):
+    v = np.empty((N, N, N, 4), np.float16)
+    v[..., 0], v[..., 1], v[..., 2], v[..., 3] = 0.9, 0.5, 0.25, alpha
+    return v.view(np.uint16)
+
+
+def check(oracle, cfg, vols, M=64):
+    ref = oracle_pipeline(oracle, cfg, vols, M)
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols)
+        assert np.array_equal(c.ReadBackVolumeInfo(), ref["info"])
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        worst, mism, _ = compare_cube(oracle, c, ref, cfg, tol=0.0)
+        assert mism == 0
+        st = c.GetStats()
+    for k in ("rays", "view_samples", "lit_samples", "light_samples"):
+        assert st[k] == ref["stats"][k], k
+    assert st["rays"] > 0 and st["view_samples"] > 0
+    return st
+
+
+BELOW = float(np.float16(0.01))            # 0.010002: the fp16 nearest 0.01 is ABOVE the fp32 threshold 0.01f
+JUST_BELOW = float(np.nextafter(np.float16(0.01), np.float16(0)))  # 0.0099945, the largest fp16 below it
+
+
+def test_uniform_alpha_around_the_threshold(oracle):
+    cfg = dict(scene.CONFIGS["C1"], N=24, L=12, maxRay=24, maxLight=12)
+    assert BELOW > 0.01 > JUST_BELOW > 0.00999
+    for alpha, lit, skipped in ((0.0, False, True), (0.005, False, True), (JUST_BELOW, False, False), (BELOW, True, False), (0.02, True, False)):
+        st = check(oracle, cfg, [uniform(cfg["N"], alpha)])
+        assert (st["lit_samples"] > 0) == lit, alpha
+        if skipped:
+            assert st["fetch_free_samples"] == st["view_samples"] + st["composite_samples"], alpha
+        else:
+            assert st["fetch_free_samples"] == 0, alpha
+
+
+@pytest.mark.parametrize("N", [24, 22])
+def test_single_texels_at_brick_corners(oracle, N):
+    """A lone opaque texel at (4i, 4j, 4k): the footprints that read it start at (4i-1, ...) in the PREVIOUS bricks (the +1 halo)."""
+    cfg = dict(scene.CONFIGS["C1"], N=N, L=12, maxRay=48, maxLight=12)
+    v = uniform(N, 0.0).view(np.float16)
+    for p in ((4, 4, 4), (8, 12, 16), (N - 1, N - 1, N - 1), (0, 0, 0), (16, 3, 7), (20, 20, 0)):
+        v[p[2], p[1], p[0], 3] = 1.0
+    st = check(oracle, cfg, [v.view(np.uint16)])
+    assert 0 < st["fetch_free_samples"] < st["view_samples"] + st["composite_samples"] and st["lit_samples"] > 0
+
+
+def test_sparse_random_bricks(oracle):
+    cfg = dict(scene.CONFIGS["T1"], N=36, W=200, H=150)
+    rng = np.random.default_rng(11)
+    vols = []
+    for k in range(cfg["V"]):
+        N = cfg["N"]
+        v = rc.synth_volume(N, k).view(np.float16).copy()
+        keep = rng.random((N // 4, N // 4, N // 4)) < 0.35  # 35 % of the bricks keep their content, the rest become empty
+        mask = np.repeat(np.repeat(np.repeat(keep, 4, 0), 4, 1), 4, 2)
+        v[..., 3] = np.where(mask, v[..., 3], np.float16(rng.choice([0.0, 0.004, JUST_BELOW])))
+        vols.append(v.view(np.uint16))
+    st = check(oracle, cfg, vols)
+    assert 0 < st["fetch_free_samples"] < st["view_samples"] + st["composite_samples"]
