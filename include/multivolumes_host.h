@@ -48,6 +48,12 @@ void mvh_synth_sphere_shadow(uint32_t M, const float lightViewProjT[16], const f
  * Arrays are malloc'ed; release with mvh_free.  Returns 0, or -1 if the file cannot be read / has no faces. */
 int mvh_load_obj(const char* path, float** positions, uint32_t* numVerts, uint32_t** indices, uint32_t* numTris, float aabbMin[3], float aabbMax[3]);
 void mvh_free(void* p);
+/* Volume texture of a .dds file as float32 [depth][height][width] (mip 0 only): what DDS::Loader hands CSR32FToRGBA16F as g_txSrc
+ * (MultiRayCaster.cpp:168-180; the shader samples .x, CSR32FToRGBA16F.hlsl:16-26).  Reads DDS_HEADER volumes (DDSD_DEPTH /
+ * DDSCAPS2_VOLUME) and DX10-extended 3D textures; channel 0 of R32_FLOAT, R16_FLOAT, R8_UNORM, R16_UNORM, R32G32B32A32_FLOAT,
+ * R16G16B16A16_FLOAT, R8G8B8A8_UNORM (DX10 DXGI_FORMAT or the legacy D3DFMT four-CC / bit-mask equivalents).  malloc'ed; release
+ * with mvh_free.  Returns 0, -1 unreadable / not a DDS, -2 not a volume texture, -3 unsupported pixel format, -4 truncated. */
+int mvh_load_dds_volume(const char* path, float** texels, uint32_t* width, uint32_t* height, uint32_t* depth);
 /* ObjectRenderer::SetWorld (ObjectRenderer.cpp:147-154, no rotation): Scale(scale) * Translate(pos), row-major 4x4 */
 void mvh_mesh_world(float scale, const float pos[3], float world[16]);
 /* transposed store of a row-major 4x4 (XMStoreFloat4x4(XMMatrixTranspose(M))) */

@@ -106,6 +106,7 @@ ABI = {
     # host helpers
     "mvh_load_obj": (C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(_U32), C.POINTER(_P), C.POINTER(_U32), _P, _P]),
     "mvh_free": (None, [_P]),
+    "mvh_load_dds_volume": (C.c_int, [C.c_char_p, C.POINTER(_P), C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
     "mvh_mesh_world": (None, [C.c_float, _P, _P]),
     "mvh_transpose": (None, [_P, _P]),
     "mvh_look_at_lh": (None, [_P, _P, _P, _P]),

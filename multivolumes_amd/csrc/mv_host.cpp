@@ -438,3 +438,103 @@ void mvh_mesh_world(float scale, const float pos[3], float world[16])
 void mvh_transpose(const float m[16], float outT[16]) { storeT(load(m), outT, 4); }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Minimal DDS volume reader (the front end of LoadVolumeData, MultiRayCaster.cpp:168-180).  Layout per the public DDS
+// specification: magic "DDS ", DDS_HEADER (124 bytes), optional DDS_HEADER_DXT10 (20 bytes) when the four-CC is "DX10".
+// ---------------------------------------------------------------------------------------------
+namespace
+{
+float halfToFloat(uint16_t h)
+{
+	const uint32_t s = (uint32_t)(h >> 15) << 31, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+	uint32_t bits;
+	if (e == 0)
+	{
+		if (m == 0) bits = s;
+		else
+		{
+			int sh = 0; uint32_t mm = m;
+			while (!(mm & 0x400u)) { mm <<= 1; ++sh; }
+			bits = s | ((uint32_t)(127 - 15 + 1 - sh) << 23) | ((mm & 0x3ffu) << 13);
+		}
+	}
+	else if (e == 31) bits = s | 0x7f800000u | (m << 13);
+	else bits = s | ((e + 127 - 15) << 23) | (m << 13);
+	float f; memcpy(&f, &bits, 4);
+	return f;
+}
+
+enum class DdsChannel { F32, F16, U8, U16 };
+}
+
+int mvh_load_dds_volume(const char* path, float** texels, uint32_t* width, uint32_t* height, uint32_t* depth)
+{
+	if (!path || !texels || !width || !height || !depth) return -1;
+	FILE* f = fopen(path, "rb");
+	if (!f) return -1;
+	uint32_t hdr[32];	// magic + DDS_HEADER
+	if (fread(hdr, 4, 32, f) != 32 || hdr[0] != 0x20534444u /* "DDS " */ || hdr[1] != 124u) { fclose(f); return -1; }
+	const uint32_t flags = hdr[2], h = hdr[3], w = hdr[4], d = hdr[6];
+	const uint32_t pfFlags = hdr[20], fourCC = hdr[21], rgbBits = hdr[22], rMask = hdr[23], caps2 = hdr[28];
+	bool isVolume = (flags & 0x800000u /* DDSD_DEPTH */) || (caps2 & 0x200000u /* DDSCAPS2_VOLUME */);
+	DdsChannel ch = DdsChannel::F32;
+	uint32_t stride = 0;	// bytes per texel; channel 0 is at offset 0
+	auto dxgi = [&](uint32_t fmt) -> bool
+	{
+		switch (fmt)
+		{
+		case 41: ch = DdsChannel::F32; stride = 4; return true;		// R32_FLOAT
+		case 54: ch = DdsChannel::F16; stride = 2; return true;		// R16_FLOAT
+		case 61: ch = DdsChannel::U8; stride = 1; return true;		// R8_UNORM
+		case 56: ch = DdsChannel::U16; stride = 2; return true;		// R16_UNORM
+		case 2: ch = DdsChannel::F32; stride = 16; return true;		// R32G32B32A32_FLOAT
+		case 10: ch = DdsChannel::F16; stride = 8; return true;		// R16G16B16A16_FLOAT
+		case 28: ch = DdsChannel::U8; stride = 4; return true;		// R8G8B8A8_UNORM
+		default: return false;
+		}
+	};
+	bool ok = false;
+	if ((pfFlags & 0x4u /* DDPF_FOURCC */) && fourCC == 0x30315844u /* "DX10" */)
+	{
+		uint32_t dx10[5];
+		if (fread(dx10, 4, 5, f) != 5) { fclose(f); return -4; }
+		isVolume = dx10[1] == 4u /* D3D10_RESOURCE_DIMENSION_TEXTURE3D */;
+		ok = dxgi(dx10[0]);
+	}
+	else if (pfFlags & 0x4u)
+	{
+		switch (fourCC)	// legacy D3DFMT codes stored as four-CC
+		{
+		case 114: ok = dxgi(41); break;	// D3DFMT_R32F
+		case 111: ok = dxgi(54); break;	// D3DFMT_R16F
+		case 116: ok = dxgi(2); break;	// D3DFMT_A32B32G32R32F
+		case 113: ok = dxgi(10); break;	// D3DFMT_A16B16G16R16F
+		default: ok = false;
+		}
+	}
+	else if ((pfFlags & 0x20000u /* DDPF_LUMINANCE */) && rgbBits == 8) ok = dxgi(61);
+	else if ((pfFlags & 0x20000u) && rgbBits == 16) ok = dxgi(56);
+	else if ((pfFlags & 0x40u /* DDPF_RGB */) && rgbBits == 32 && rMask == 0xffu) ok = dxgi(28);	// A8B8G8R8: red is byte 0
+	if (!isVolume || w == 0 || h == 0 || d == 0) { fclose(f); return -2; }
+	if (!ok) { fclose(f); return -3; }
+	const size_t n = (size_t)w * h * d;
+	std::vector<uint8_t> raw(n * stride);
+	if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); return -4; }
+	fclose(f);
+	float* out = static_cast<float*>(malloc(n * sizeof(float)));
+	if (!out) return -1;
+	for (size_t i = 0; i < n; ++i)
+	{
+		const uint8_t* p = raw.data() + i * stride;
+		switch (ch)
+		{
+		case DdsChannel::F32: memcpy(&out[i], p, 4); break;
+		case DdsChannel::F16: { uint16_t v; memcpy(&v, p, 2); out[i] = halfToFloat(v); break; }
+		case DdsChannel::U8: out[i] = (float)p[0] / 255.0f; break;
+		case DdsChannel::U16: { uint16_t v; memcpy(&v, p, 2); out[i] = (float)v / 65535.0f; break; }
+		}
+	}
+	*texels = out; *width = w; *height = h; *depth = d;
+	return 0;
+}

@@ -1165,7 +1165,6 @@ __global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st, int inc
 	if (includeLight) for (uint32_t i = tid; i < st.lightBlocks; i += nThreads) a[3] += st.lightStats[i];
 	for (uint32_t i = tid; i < st.compositeSlots; i += nThreads) a[4] += st.compositeStats[i];
 	for (uint32_t i = tid; i < st.maxScreenTiles; i += nThreads) { a[4] += st.screenStats[2 * i]; a[6] += st.screenStats[2 * i + 1]; }
-#pragma unroll
 	for (uint32_t i = tid; i < st.maxTiles + st.maxScreenTiles; i += nThreads) a[7] += st.tileSkipped[i];
 #pragma unroll
 	for (int k = 0; k < 8; ++k)

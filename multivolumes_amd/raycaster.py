@@ -92,6 +92,20 @@ def load_obj(path):
     return p, i, lo, hi
 
 
+def load_dds_volume(path):
+    """float32 [depth, height, width] of the volume texture in a .dds file (mvh_load_dds_volume)."""
+    lib = _lib.load()
+    tex = C.c_void_p()
+    w, h, d = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc_ = lib.mvh_load_dds_volume(str(path).encode(), C.byref(tex), C.byref(w), C.byref(h), C.byref(d))
+    if rc_ != 0:
+        raise IOError(f"cannot load DDS volume {path}: " + {-1: "unreadable or not a DDS file", -2: "not a volume texture", -3: "unsupported pixel format", -4: "truncated"}.get(rc_, str(rc_)))
+    try:
+        return np.ctypeslib.as_array(C.cast(tex, C.POINTER(C.c_float)), (d.value, h.value, w.value)).copy()
+    finally:
+        lib.mvh_free(tex)
+
+
 def mesh_world(scale, pos):
     """ObjectRenderer::SetWorld (ObjectRenderer.cpp:147-154): Scale * Translate, row-major 4x4."""
     out = np.empty(16, np.float32)
@@ -175,6 +189,10 @@ class MultiRayCaster:
         if a.dtype != np.uint16 or a.size != N * N * N * 4:
             raise ValueError("volume must be N^3 x 4 uint16/float16")
         self._check(self._lib.mv_volume_upload_rgba16f(self._ctx, i, _ptr(a)), "mv_volume_upload_rgba16f")
+
+    def LoadVolumeFile(self, i, fileName):
+        """LoadVolumeData(pCommandList, i, fileName, ...) (MultiRayCaster.cpp:168-209): DDS volume -> CSR32FToRGBA16F."""
+        self.LoadVolumeDataR32F(i, load_dds_volume(fileName))
 
     def LoadVolumeDataR32F(self, i, a):
         """LoadVolumeData's CSR32FToRGBA16F pass on a (d, h, w) float32 array."""
