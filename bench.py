@@ -169,11 +169,11 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        cnt = torch.tensor([st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"]], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"], st["fetch_free_samples"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-        tot_view, tot_lit, tot_rays, tot_light = [int(x) for x in cnt.tolist()]
+        tot_view, tot_lit, tot_rays, tot_light, tot_free = [int(x) for x in cnt.tolist()]
     else:
-        tot_view, tot_lit, tot_rays, tot_light = st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"]
+        tot_view, tot_lit, tot_rays, tot_light, tot_free = st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"], st["fetch_free_samples"]
 
     if rank == 0:
         K = args.steps
@@ -211,7 +211,7 @@ def main():
                 "samples_per_ray_cap": [int(info[v, 1]) for v in vis][:4],
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
-                "fetch_free_samples_per_frame": st.get("fetch_free_samples", 0) // K,
+                "fetch_free_samples_per_frame": tot_free // K,
                 "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
                 "frames_in_flight": "up to 3 (constants / cull 4 slots, march outputs 2, light maps 3 buffers per volume)" if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),

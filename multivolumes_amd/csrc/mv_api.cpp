@@ -244,7 +244,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 {
 	if (!cfg || !out || cfg->struct_size != sizeof(mv_config)) return MV_ERR_INVALID_ARG;
 	*out = nullptr;
-	if (cfg->grid_size < 2 || cfg->grid_size > 640 /* bricked alpha cells (16 B/texel) must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
+	if (cfg->grid_size < 2 || cfg->grid_size > 640 /* bricked alpha cells (16 B/texel) must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->light_grid_size > 640 /* 32-bit offsets into the 16 B/texel light quads */ || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
 		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
 		return MV_ERR_INVALID_ARG;
 	if (cfg->shard_count > 1 && cfg->shard_index >= cfg->shard_count) return MV_ERR_INVALID_ARG;
@@ -380,6 +380,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	{
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 256 * 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
+		// per-tile cost table, one per slot: the view march of frame i writes it, the tile order of frame i + 4 reads it
+		if ((rc = devAlloc(ctx, &ctx->fb[p].tileCost, ((size_t)st.V * 6 * ((st.N + 7u) >> 3) * ((st.N + 7u) >> 3) + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
 	}
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	for (int p = 0; p < 2; ++p)
@@ -389,7 +391,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		{
 			const FrameBufs& g = ctx->fb[0];	// one frame in flight: both parities share the outputs
 			f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
-			f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost; f.tileSkipped = g.tileSkipped;
+			f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileSkipped = g.tileSkipped;
 			break;
 		}
 		// cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-121), zero-initialised
@@ -398,7 +400,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.tileCost, ((size_t)st.V * 6 * ((st.N + 7u) >> 3) * ((st.N + 7u) >> 3) + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.tileSkipped, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
@@ -408,7 +409,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		FrameBufs& f = ctx->fb[p];
 		const FrameBufs& g = ctx->fb[p & 1u];	// outputs exist per parity
 		f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
-		f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileCost = g.tileCost; f.tileSkipped = g.tileSkipped;
+		f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileSkipped = g.tileSkipped;
 	}
 	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
 	ctx->slot = 0;
@@ -628,10 +629,11 @@ int mv_cull(mv_ctx* ctx)
 	stageADone(ctx);
 	if (ctx->orderTiles)
 	{
-		// dispatch order of this frame's view march, on ITS stream: it runs beside the light march and only needs the cull
-		stageBBegin(ctx);
-		mv::launchTileOrder(streamB(ctx), ctx->st, ctx->fb[ctx->slot].binCounts, ctx->fb[ctx->slot].tileOrder);
+		// Dispatch order of this frame's view march, right behind the cull on stream A (which runs frames ahead), from the cost
+		// table the view march of the slot's previous user wrote (mv_update_frame already made stream A wait for that frame).
+		mv::launchTileOrder(ctx->streamA, ctx->st, ctx->fb[ctx->slot].binCounts, ctx->fb[ctx->slot].tileOrder);
 		MV_HIP(ctx, hipGetLastError());
+		stageADone(ctx);
 	}
 	ctx->haveCull = true;
 	return MV_OK;

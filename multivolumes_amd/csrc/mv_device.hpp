@@ -228,8 +228,10 @@ __device__ __forceinline__ VolumeView makeVolumeView(const uint2* texels, const 
 
 // texel byte offsets contributed by one axis: brick part + in-brick part
 __device__ __forceinline__ uint32_t offX(int i) { return (((uint32_t)i >> 2) << 9) + (((uint32_t)i & 3u) << 3); }
-__device__ __forceinline__ uint32_t offY(int i, uint32_t strideY) { return ((uint32_t)i >> 2) * strideY + (((uint32_t)i & 3u) << 5); }
-__device__ __forceinline__ uint32_t offZ(int i, uint32_t strideZ) { return ((uint32_t)i >> 2) * strideZ + (((uint32_t)i & 3u) << 7); }
+// 24-bit multiplies (v_mul_u32_u24, full rate; v_mul_lo_u32 is quarter rate): brick indices are < 2^8 and the strides < 2^24
+// for every N <= 640 (pitchZ * 512 = 13.2 M at N = 640), which mv_create enforces.
+__device__ __forceinline__ uint32_t offY(int i, uint32_t strideY) { return __umul24((uint32_t)i >> 2, strideY) + (((uint32_t)i & 3u) << 5); }
+__device__ __forceinline__ uint32_t offZ(int i, uint32_t strideZ) { return __umul24((uint32_t)i >> 2, strideZ) + (((uint32_t)i & 3u) << 7); }
 
 __device__ __forceinline__ uint2 loadTexelAt(const VolumeView& v, uint32_t byteOff)
 {
@@ -289,7 +291,7 @@ constexpr float kOccupancyLimit = 0.00999f;
 __host__ __device__ inline uint32_t occupancyRegions(uint32_t bricks) { return (bricks + 3u) >> 2; }
 __device__ __forceinline__ uint32_t occupancyWord(uint32_t ix, uint32_t iy, uint32_t iz, uint32_t regions)
 {
-	return ((iz >> 4) * regions + (iy >> 4)) * regions + (ix >> 4);
+	return __umul24(__umul24(iz >> 4, regions) + (iy >> 4), regions) + (ix >> 4);
 }
 __device__ __forceinline__ uint32_t occupancyBit(uint32_t ix, uint32_t iy, uint32_t iz)
 {
@@ -397,11 +399,12 @@ __device__ __forceinline__ LightFootprint fetchLightFootprint(const uint4* quads
 {
 	const Taps tx = linearTaps(uvw.x, L, 0), ty = linearTaps(uvw.y, L, 0), tz = linearTaps(uvw.z, L, 0);
 	const GlobalBytes base = (GlobalBytes)quads;
-	const uint32_t row = ((uint32_t)ty.i0 * L + (uint32_t)tx.i0) << 4;
+	// 32-bit byte offsets and 24-bit multiplies: L <= 640 (mv_create), so L^2 * 16 < 2^24 and L^3 * 16 < 2^32
+	const uint32_t row = (__umul24((uint32_t)ty.i0, L) + (uint32_t)tx.i0) << 4;
 	const uint32_t slice = (L * L) << 4;
 	LightFootprint f;
-	f.q0 = *(GlobalUint4)(base + ((uint32_t)tz.i0 * slice + row));
-	f.q1 = *(GlobalUint4)(base + ((uint32_t)tz.i1 * slice + row));
+	f.q0 = *(GlobalUint4)(base + (__umul24((uint32_t)tz.i0, slice) + row));
+	f.q1 = *(GlobalUint4)(base + (__umul24((uint32_t)tz.i1, slice) + row));
 	f.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; f.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; f.fz = tz.f;
 	return f;
 }
