@@ -478,3 +478,25 @@ def test_pipelined_frames_match_sequential():
     for x, y in zip(a[5], b[5]):
         assert np.array_equal(x, y)
     assert sum(int(l.any()) for l in a[4]) >= len(a[2]), "every visible volume has been relit at least once"
+
+
+def test_headline_config_c3_matches_oracle_at_full_size(oracle):
+    """BASELINE.json configs[2] -- 16 x 256^3, 1024^2, 128 steps/ray, mesh depth -- cull, 16 light marches and the view march
+    of the whole frame against the oracle, bit for bit (the sizes the metric is quoted on, not a reduced stand-in)."""
+    cfg = scene.CONFIGS["C3"]
+    M = 1024
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    ref = oracle_pipeline(oracle, cfg, vols, M)
+    assert len(ref["vis"]) >= 10 and len(ref["cube"]) >= 8
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols)
+        assert np.array_equal(c.ReadBackVolumeInfo(), ref["info"])
+        vis, cube = c.ReadBackVisibleLists()
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube, ref["cube"])
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        worst, mism, total = compare_cube(oracle, c, ref, cfg, tol=0.0)
+        assert mism == 0 and total > 1_500_000
+        st = c.GetStats()
+        for k in ("rays", "view_samples", "lit_samples", "light_samples"):
+            assert st[k] == ref["stats"][k], k
+        assert st["view_samples"] > 15_000_000 and 0 < st["fetch_free_samples"] < st["view_samples"]
