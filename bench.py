@@ -104,20 +104,28 @@ def main():
 
     from multivolumes_amd import distributed as D
     cube_xchg = D.CubeFaceExchange(caster) if world > 1 else None
-    light_xchg = D.LightMapExchange(caster) if world > 1 and do_composite else None
+    light_xchg = D.LightMapExchange(caster) if world > 1 else None
     H, W = cfg["H"], cfg["W"]
     band = D.row_range(H, rank, world)
+    assert band == caster.ShardRows()
     xbytes = [0]
 
     def frame(with_exchange=True):
         frame_idx = caster.m_frameIdx
         caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
-        caster.Render(composite=False)  # cull -> marchL -> marchV, stream ordered
-        if world > 1 and with_exchange:
-            info_h, vis_h, _, _ = caster.ReadBackCull()  # the one host sync of the frame: the exchange sizes depend on the cull
-            xbytes[0] += cube_xchg.run(info_h, vis_h)  # pack -> RCCL all-gather -> unpack
-            if light_xchg is not None:
-                xbytes[0] += light_xchg.run(info_h, vis_h, frame_idx)
+        if world == 1:
+            caster.Render(composite=False)  # cull -> marchL -> marchV, stream ordered
+        else:
+            caster.cullVolumes()
+            info_h, vis_h, _, _ = caster.ReadBackCull()  # host sync on the cull alone: the exchange sizes depend on it
+            caster.rayMarchL()
+            # a light map relit this frame by another rank is needed here if its volume is on the screen-space scheme:
+            # every rank marches its own rows of every such volume inside the view march
+            xbytes[0] += light_xchg.run(info_h, vis_h, frame_idx)
+            caster.rayMarchV()
+            caster.m_frameIdx += 1  # what Render() does (MultiRayCaster.cpp:384)
+            if with_exchange:
+                xbytes[0] += cube_xchg.run(info_h, vis_h)  # pack -> RCCL all-gather -> unpack
         if do_composite:
             caster.composite(band[0], band[1])
             if world > 1 and with_exchange:
@@ -187,8 +195,8 @@ def main():
         ms_v = k_alone["march_view"]
         # rank-0 marchV launch: algorithmic bytes per launch (the counters cover every timed frame) / average launch duration
         # the view-march launch also marches the screen-space RayCast tiles (composite_samples) on single-GPU contexts
-        fused = st["composite_samples"] if world == 1 else 0
-        alg_bytes = (64 * (st["view_samples"] + fused) + 32 * (st["lit_samples"] + (st["fused_raycast_lit"] if world == 1 else 0)) + 16 * st["rays"]) / K
+        fused = st["composite_samples"]  # the screen-space RayCast samples of this rank's rows, marched by the same launch
+        alg_bytes = (64 * (st["view_samples"] + fused) + 32 * (st["lit_samples"] + st["fused_raycast_lit"]) + 16 * st["rays"]) / K
         achieved = alg_bytes / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")

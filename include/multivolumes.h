@@ -198,6 +198,11 @@ uint64_t mv_cube_mip_offset(uint32_t N, uint32_t mip);
  * d = N >> min selected mip over all visible volumes (identical on every rank because cull is replicated).
  * mv_exchange_layout synchronises the stream; pack / unpack take slot_dim from it (or from mv_readback_cull) and do not. */
 int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size_t* shard_bytes);
+/* Screen rows [row0, row1) of this shard (whole 8-row tiles split evenly over shard_count; the whole screen when unsharded).
+ * The shard composites these rows (mv_composite(ctx, row0, row1)), and its view march also marches, for these rows only, the
+ * screen-space RayCast (Sh/RayCast.hlsli:43-108) of EVERY volume on that scheme -- so the light maps of such volumes owned by
+ * other shards must be current (mv_upload_light_map / a device-to-device copy into MV_BUF_LIGHT_MAP) before mv_march_view. */
+int mv_shard_rows(mv_ctx* ctx, uint32_t* row0, uint32_t* row1);
 /* Pack this shard's selected-mip cube faces (colour then depth per slot) into d_dst (device, shard_bytes). */
 int mv_exchange_pack(mv_ctx* ctx, void* d_dst, uint32_t slot_dim);
 /* Scatter an all-gathered buffer (shard_count x shard_bytes, rank-major) back into the cube maps / depths of every volume. */

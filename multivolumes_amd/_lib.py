@@ -95,6 +95,7 @@ ABI = {
     "mv_cube_chain_texels": (C.c_uint64, [_U32]),
     "mv_cube_mip_offset": (C.c_uint64, [_U32, _U32]),
     "mv_exchange_layout": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_SZ), C.POINTER(_SZ)]),
+    "mv_shard_rows": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_U32)]),
     "mv_exchange_pack": (C.c_int, [_P, _P, _U32]),
     "mv_exchange_unpack": (C.c_int, [_P, _P, _U32]),
     "mv_readback_cull": (C.c_int, [_P, _P, _P, C.POINTER(_U32), _P, C.POINTER(_U32), C.POINTER(_U32)]),

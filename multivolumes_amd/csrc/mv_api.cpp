@@ -342,10 +342,18 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	// createVolumeInfoBuffers (MultiRayCaster.cpp:455-549)
 	if ((rc = devAlloc(ctx, &ctx->dDescs, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->dSh, 27 * sizeof(float))) != MV_OK) return bail(rc);
-	// RayCast layers of screen-space-scheme volumes are marched inside the view-march launch (single-GPU contexts) into
-	// fp32 RGBA layers; volumes beyond the slot capacity fall back to marching inside the composite.
-	st.screenSlots = st.shardCount > 1 ? 0u : (st.V < 8u ? st.V : 8u);
-	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
+	// RayCast layers of screen-space-scheme volumes are marched inside the view-march launch into fp32 RGBA layers; volumes
+	// beyond the slot capacity fall back to marching inside the composite.
+	// Rows this shard composites (multivolumes_amd/distributed.py::row_range states the same rule): whole 8-row tiles, split evenly.
+	{
+		const uint32_t tiles = (st.H + 7u) >> 3;
+		const uint32_t t0 = (uint32_t)(((uint64_t)tiles * st.shardIndex) / st.shardCount), t1 = (uint32_t)(((uint64_t)tiles * (st.shardIndex + 1u)) / st.shardCount);
+		st.bandRow0 = t0 * 8u < st.H ? t0 * 8u : st.H;
+		st.bandRow1 = t1 * 8u < st.H ? t1 * 8u : st.H;
+	}
+	// Screen-space-scheme volumes are marched inside the view-march launch (up to 8 of them), by every shard for ITS rows
+	st.screenSlots = st.V < 8u ? st.V : 8u;
+	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.bandRow1 - st.bandRow0 + 7u) >> 3);
 	// constants + cull outputs, once per frame slot (FrameBufs)
 	{
 		std::vector<uint4*> table(st.V);
@@ -992,6 +1000,13 @@ int mv_readback_shadow_map(mv_ctx* ctx, uint16_t* dst)
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemcpy(dst, ctx->st.shadowMap, (size_t)ctx->st.M * ctx->st.M * sizeof(uint16_t), hipMemcpyDeviceToHost));
+	return MV_OK;
+}
+
+int mv_shard_rows(mv_ctx* ctx, uint32_t* row0, uint32_t* row1)
+{
+	if (!ctx || !row0 || !row1) return MV_ERR_INVALID_ARG;
+	*row0 = ctx->st.bandRow0; *row1 = ctx->st.bandRow1;
 	return MV_OK;
 }
 

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 
 			vec4 color;
 			const uint32_t slot = (vi.z & kCubeMapRayMarchBit) ? 0xffffffffu : st.screenSlot[v];
-			if (!(vi.z & kCubeMapRayMarchBit) && slot != 0xffffffffu)
+			if (!(vi.z & kCubeMapRayMarchBit) && slot != 0xffffffffu && py >= st.bandRow0 && py < st.bandRow1)
 			{
 				// RayCast (RayCast.hlsli:43-108) already marched for this pixel by marchViewKernel's screen tiles
 				const float4 c = st.screenLayers[((size_t)slot * st.H + py) * st.W + px];

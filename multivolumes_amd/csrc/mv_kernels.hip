@@ -487,7 +487,9 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16;
 			uint32_t x1 = r1 & 0xffffu, y1 = r1 >> 16;
 			x1 = x1 < st.W - 1u ? x1 : st.W - 1u; y1 = y1 < st.H - 1u ? y1 : st.H - 1u;
-			if (x0 <= x1 && y0 <= y1) tiles = ((x1 >> 3) - (x0 >> 3) + 1u) * ((y1 >> 3) - (y0 >> 3) + 1u);
+			const uint32_t yb0 = y0 > st.bandRow0 ? y0 : st.bandRow0;	// this shard's rows only
+			const uint32_t yb1 = st.bandRow1 ? (y1 < st.bandRow1 - 1u ? y1 : st.bandRow1 - 1u) : 0u;
+			if (x0 <= x1 && yb0 <= yb1 && st.bandRow1 > st.bandRow0) tiles = ((x1 >> 3) - (x0 >> 3) + 1u) * ((yb1 >> 3) - (yb0 >> 3) + 1u);
 		}
 		uint32_t totE, totT;
 		const uint32_t eBase = nEntries + waveExclusiveScanU32(take ? 1u : 0u, lane, totE);
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 		// screen rectangle of the volume, clipped to the viewport, in 8x8 pixel tiles
 		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
 		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
-		const uint32_t tx0 = rect.x >> 3, ty0 = rect.y >> 3, tw = (x1 >> 3) - tx0 + 1u;
+		const uint32_t tx0 = rect.x >> 3, ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3, tw = (x1 >> 3) - tx0 + 1u;
 		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (ty0 + localTile / tw) * 8u + (lane >> 3);
 		if (px < st.W && py < st.H)
 		{

@@ -24,6 +24,8 @@ struct DeviceState
 	uint32_t M;				// shadow-map edge
 	uint32_t flags;
 	uint32_t shardIndex, shardCount;
+	uint32_t bandRow0, bandRow1;	// screen rows [bandRow0, bandRow1) this shard composites (8-row aligned; the whole screen when unsharded):
+									// the screen tiles of the fused RayCast are marched for these rows only, for EVERY screen-space-scheme volume
 	uint32_t maxRaySamples, maxLightSamples;
 	uint32_t hasLightProbe;
 

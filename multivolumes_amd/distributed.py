@@ -157,6 +157,10 @@ def gather_composite_rows(caster, H, W, rank, world, group=None):
     row_bytes = W * 8
     r0, r1 = bands[rank]
     frame = _device_view(ptr, nbytes)  # aliases the context's buffer, no copy
+    if all(b[1] - b[0] == max_rows for b in bands) and dist.get_backend(group) == "nccl":
+        # equal bands: the frame buffer IS the all-gather output and this rank's band its input, in place (no staging copies)
+        dist.all_gather_into_tensor(frame[:world * max_rows * row_bytes], frame[r0 * row_bytes:r1 * row_bytes], group=group)
+        return world * max_rows * row_bytes
     send = torch.zeros(max_rows * row_bytes, dtype=torch.uint8, device="cuda")
     send[:(r1 - r0) * row_bytes].copy_(frame[r0 * row_bytes:r1 * row_bytes])
     recv = torch.empty(world * max_rows * row_bytes, dtype=torch.uint8, device="cuda")

@@ -394,6 +394,12 @@ class MultiRayCaster:
         self._check(self._lib.mv_get_buffer(self._ctx, which, index, C.byref(p), C.byref(n)), "mv_get_buffer")
         return p.value, n.value
 
+    def ShardRows(self):
+        """Screen rows [row0, row1) this shard composites and marches screen-space RayCast tiles for (mv_shard_rows)."""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self._lib.mv_shard_rows(self._ctx, C.byref(a), C.byref(b)), "mv_shard_rows")
+        return a.value, b.value
+
     def ExchangeLayout(self):
         d, sb, tb = C.c_uint32(), C.c_size_t(), C.c_size_t()
         self._check(self._lib.mv_exchange_layout(self._ctx, C.byref(d), C.byref(sb), C.byref(tb)), "mv_exchange_layout")

@@ -356,7 +356,7 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
     shards = [make_caster(cfg, M, shard=(r, world)) for r in range(world)]
     try:
         packed = []
-        tot_samples = tot_rays = 0
+        tot_samples = tot_rays = tot_raycast = 0
         for r, c in enumerate(shards):
             scene.setup_raycaster(c, cfg, vols)
             owned_vis = [int(v) for v in vis if int(v) % world == r]
@@ -365,6 +365,12 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
                 c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
                 c.cullVolumes()
                 c.rayMarchL()
+            # the light-map exchange: the view march also marches this rank's rows of EVERY screen-space volume (RayCast reads
+            # that volume's light map), so the maps the other rank relit must be here before it
+            for v in vis:
+                if int(v) % world != r:
+                    c.UploadLightMap(int(v), ref_lm[int(v)])
+            assert c.ShardRows() == D.row_range(H, r, world)
             c.rayMarchV()
             assert np.array_equal(c.ReadBackVolumeInfo(), info), "cull is replicated"
             for v in owned_vis:
@@ -380,6 +386,7 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
             st = c.GetStats()
             tot_samples += st["view_samples"]
             tot_rays += st["rays"]
+            tot_raycast += st["composite_samples"]
             # a rank marches only its own volumes
             for v in cube:
                 got = c.ReadBackCubeMap(int(v), int(info[v, 0]))
@@ -388,13 +395,10 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
                 else:
                     assert not got.any()
         assert tot_samples == ref_stats["view_samples"] and tot_rays == ref_stats["rays"]
+        assert tot_raycast == ref_stats["composite_samples"] > 0, "the RayCast pixels are split by rows, none marched twice"
         gathered = torch.cat(packed)
         for r, c in enumerate(shards):
             c.ExchangeUnpack(gathered.data_ptr(), d)
-            # light maps of the other rank's volumes (needed by screen-space RayCast layers)
-            for v in vis:
-                if int(v) % world != r:
-                    c.UploadLightMap(int(v), ref_lm[int(v)])
             for v in cube:
                 assert np.array_equal(c.ReadBackCubeMap(int(v), int(info[v, 0])), ref_cm[int(v)])
                 assert np.array_equal(c.ReadBackCubeDepth(int(v), int(info[v, 0])), ref_cd[int(v)])
