@@ -79,9 +79,13 @@ def main():
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
     M = 1024
     flags = _lib.MV_FLAG_FORCE_MIP0_ALL_FACES if args.stress else 0
-    pipelined = world == 1 and not args.no_pipeline
+    pipelined = not args.no_pipeline
     if pipelined:
-        flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # two frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
+        flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
+        if world > 1:
+            # the RCCL collectives are ordered on the context's (= torch's current) stream between the view march and the composite:
+            # only upload, cull and light march run ahead
+            flags |= _lib.MV_FLAG_SINGLE_VIEW_STREAM
     # a real (non-blocking) torch stream, made current so that the RCCL collectives of the multi-GPU path are ordered on it too:
     # torch's default is the legacy null stream, whose implicit synchronisation rules cost the pipelined frame ~20 %
     if os.environ.get("MV_BENCH_NULL_STREAM", "0") != "1":
@@ -221,7 +225,8 @@ def main():
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
                 "parallelism": f"volumes sharded v%{world}, RCCL all-gather of cube faces" if world > 1 else "single GPU",
-                "frames_in_flight": "up to 3 (constants / cull 4 slots, march outputs 2, light maps 3 buffers per volume)" if pipelined else 1,
+                "frames_in_flight": ("up to 3 (constants / cull 4 slots, march outputs 2, light maps 3 buffers per volume)" if world == 1
+                                     else "upload + cull + light march ahead of the view march / exchange / composite stream") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes[0] // max(1, K + args.warmup),
             },

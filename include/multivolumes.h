@@ -58,9 +58,13 @@ extern "C" {
 /* mv_config.flags */
 #define MV_FLAG_NONE 0u
 #define MV_FLAG_FORCE_MIP0_ALL_FACES 1u	/* stress variant of SURVEY 8(d): cull forces mip 0, all 6 faces, cube-map scheme */
-#define MV_FLAG_PIPELINE_FRAMES 2u		/* two frames in flight (the reference keeps FrameCount = 3, MultiRayCaster.h:52): constant upload, cull and
-										   light march of frame i+1 run on a second stream while frame i's view march / composite finish.
-										   Results are identical; only readbacks (which synchronise both streams) observe the difference. */
+#define MV_FLAG_PIPELINE_FRAMES 2u			/* frames in flight (the reference keeps FrameCount = 3, MultiRayCaster.h:52): constant upload + cull, the light march,
+										   and the view march + composite of even / odd frames run on internal streams with 4 slots of cull outputs,
+										   3 light buffers per volume and 2 output sets.  Results are identical; calls stay asynchronous and every
+										   readback / mv_get_stats / producer synchronises first. */
+#define MV_FLAG_SINGLE_VIEW_STREAM 4u		/* with MV_FLAG_PIPELINE_FRAMES: keep the view march, exchange and composite of EVERY frame on the context's
+										   stream (only upload, cull and light march run ahead on internal streams) -- for callers that order their own
+										   work, e.g. RCCL collectives, on that stream between mv_march_view and mv_composite */
 
 typedef struct mv_ctx mv_ctx;
 

@@ -99,7 +99,9 @@ struct mv_ctx
 	hipEvent_t sliceDone[kFrameSlices] = {};
 	uint64_t* pinnedStats = nullptr;
 	uint32_t* pinnedCounters = nullptr;
-	uint8_t* pinnedCull = nullptr;		// counters + VolumeInfo + both lists, one readback
+	uint8_t* pinnedCull = nullptr;		// counters + VolumeInfo + both lists + light table, one readback
+	uint64_t frame = 0;					// frames begun (mv_update_frame)
+	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
 
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
 	bool profiling = false;
@@ -283,8 +285,11 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamA = true;
-		if (hipStreamCreateWithFlags(&ctx->streamB[1], hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
-		ctx->ownStreamB1 = true;
+		if (!(cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM))
+		{
+			if (hipStreamCreateWithFlags(&ctx->streamB[1], hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
+			ctx->ownStreamB1 = true;
+		}
 	}
 	for (uint32_t i = 0; i < kFrameSlots; ++i)
 		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess
@@ -428,7 +433,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kFrameSlices + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices);
 	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices + 128);
-	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 16, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	for (uint32_t i = 0; i < kFrameSlices; ++i)
 		if (hipEventCreateWithFlags(&ctx->sliceDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 
@@ -607,6 +612,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
 	// a new frame: the next slot of constants / cull buffers (and the other parity's march outputs)
 	ctx->slot = (ctx->slot + 1u) % kFrameSlots;
+	++ctx->frame;
 	applyParity(ctx);
 	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->slot], 0));
@@ -745,6 +751,15 @@ int mv_readback_volume(mv_ctx* ctx, uint32_t src, uint16_t* dst)
 
 static int currentLightBuffer(mv_ctx* ctx, uint32_t volume, uint4** out)
 {
+	if (ctx->lightTableFrame == ctx->frame)
+	{
+		// this frame's table came back with mv_readback_cull: no host synchronisation, the context's stream waits for the
+		// frame's light march instead (work the caller orders on that stream then sees the relit map)
+		*out = reinterpret_cast<uint4* const*>(ctx->pinnedCull + 64 + (size_t)ctx->st.V * 16)[volume];
+		MV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evStageA[ctx->slot], 0));
+		MV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLight[ctx->slot], 0));
+		return MV_OK;
+	}
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemcpy(out, ctx->st.lightTable + volume, sizeof(uint4*), hipMemcpyDeviceToHost));
 	return MV_OK;
@@ -1051,14 +1066,17 @@ int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info, uint32_t* visible, uint
 {
 	if (!ctx || !volume_info || !visible || !visibleCount || !cubeMapVolumes || !cubeMapCount || !minMip) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
-	stageBBegin(ctx);	// the copies below run on stream B and read what stream A's cull wrote
+	// The copies run behind the cull on stream A and only that stream is waited for: with frames in flight the host then
+	// waits for this frame's cull (which runs ahead), not for the marches of the frames before it.
 	const size_t V = ctx->st.V;
 	uint8_t* p = ctx->pinnedCull;
-	MV_HIP(ctx, hipMemcpyAsync(p, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipMemcpyAsync(p + 64, ctx->st.volumeInfo, V * 8, hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 8, ctx->st.visibleVolumes, V * 4, hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 12, ctx->st.cubeMapVolumes, V * 4, hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	MV_HIP(ctx, hipMemcpyAsync(p, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->streamA));
+	MV_HIP(ctx, hipMemcpyAsync(p + 64, ctx->st.volumeInfo, V * 8, hipMemcpyDeviceToHost, ctx->streamA));
+	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 8, ctx->st.visibleVolumes, V * 4, hipMemcpyDeviceToHost, ctx->streamA));
+	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 12, ctx->st.cubeMapVolumes, V * 4, hipMemcpyDeviceToHost, ctx->streamA));
+	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 16, ctx->st.lightTable, V * sizeof(uint4*), hipMemcpyDeviceToHost, ctx->streamA));
+	MV_HIP(ctx, hipStreamSynchronize(ctx->streamA));
+	ctx->lightTableFrame = ctx->frame;
 	const uint32_t* counters = reinterpret_cast<const uint32_t*>(p);
 	*visibleCount = counters[0]; *cubeMapCount = counters[1]; *minMip = counters[5];
 	memcpy(volume_info, p + 64, V * 8);

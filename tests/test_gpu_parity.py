@@ -451,7 +451,7 @@ def test_pipelined_frames_match_sequential():
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
     outs = []
-    for flags in (0, _lib.MV_FLAG_PIPELINE_FRAMES):
+    for flags in (0, _lib.MV_FLAG_PIPELINE_FRAMES, _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM):
         with make_caster(cfg, 64, flags=flags) as c:
             fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
             eye = np.array(fr["eye"], np.float32)
@@ -463,7 +463,19 @@ def test_pipelined_frames_match_sequential():
                 vp = rc.multiply(view, rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0))
                 c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
                 c.UpdateFrame(vp, fr["shadowVP"], e)
-                c.Render(composite=True)
+                if f % 3 == 1:
+                    # the multi-GPU call order: cull, cull readback (waits for the cull only), light march, light-map pointer
+                    # (no host wait: the context's stream waits for the light march), view march, composite
+                    c.cullVolumes()
+                    info_f, vis_f, _, _ = c.ReadBackCull()
+                    c.rayMarchL()
+                    if len(vis_f):
+                        c.GetBuffer(1, int(vis_f[0]))
+                    c.rayMarchV()
+                    c.composite()
+                    c.m_frameIdx += 1
+                else:
+                    c.Render(composite=True)
                 if f % 4 == 3 or f == V + 4:
                     frames.append((c.ReadBackComposite(), c.ReadBackVolumeInfo()))
             info = c.ReadBackVolumeInfo()
@@ -472,15 +484,16 @@ def test_pipelined_frames_match_sequential():
             cms = [c.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube]
             st = c.GetStats()
             outs.append((frames, info, vis, cube, lms, cms, {k: st[k] for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples")}))
-    a, b = outs
-    assert a[6] == b[6]
-    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
-    for x, y in zip(a[0], b[0]):
-        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
-    for x, y in zip(a[4], b[4]):
-        assert np.array_equal(x, y)
-    for x, y in zip(a[5], b[5]):
-        assert np.array_equal(x, y)
+    a = outs[0]
+    for b in outs[1:]:
+        assert a[6] == b[6]
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+        for x, y in zip(a[0], b[0]):
+            assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1])
+        for x, y in zip(a[4], b[4]):
+            assert np.array_equal(x, y)
+        for x, y in zip(a[5], b[5]):
+            assert np.array_equal(x, y)
     assert sum(int(l.any()) for l in a[4]) >= len(a[2]), "every visible volume has been relit at least once"
 
 
