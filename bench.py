@@ -14,7 +14,7 @@ timed region keeps several frames in flight, so two view-march launches share th
 run one at a time (synchronise after every frame), still HIP events inside this process.
 `cpu_baseline` is the CPU oracle (the reference has no Linux CPU path) timed on the same frame's marchV.
 
-Defaults: 150 warm-up + 300 timed frames (about 0.2 s of GPU time).  The warm-up is that long because the HIP runtime
+Defaults: 200 warm-up + 1000 timed frames (about 0.5 s of GPU time).  The warm-up is that long because the HIP runtime
 stalls once for 30-50 ms around the 140th frame of a process (its command / signal pools grow); measured, one-time.
 """
 import argparse
@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=300)
-    p.add_argument("--warmup", type=int, default=150)
+    p.add_argument("--steps", type=int, default=1000)
+    p.add_argument("--warmup", type=int, default=200)
     p.add_argument("--config", default="C3", help="C1/C2/C3/C5/T1/T2 (default C3 = the config the metric is quoted on)")
     p.add_argument("--stress", action="store_true", help="C3-stress: force mip 0, all 6 faces (SURVEY 8d)")
     p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
