@@ -42,6 +42,7 @@ struct FrameBufs
 	uint64_t* cubeOffset = nullptr;
 	uint32_t* volumeFlags = nullptr;
 	uint16_t* volumeRects = nullptr;
+	float4* lightDirs = nullptr;
 	uint32_t* screenSlot = nullptr;
 	uint4** lightTable = nullptr;
 	// outputs of the view march / composite and their counters (distinct per parity only with MV_FLAG_PIPELINE_FRAMES, so that
@@ -148,7 +149,7 @@ void applyParity(mv_ctx* ctx)
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
-	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot;
+	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.lightDirs = f.lightDirs;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo;
 	st.cubeMaps = f.cubeMaps; st.cubeDepths = f.cubeDepths; st.composite = f.composite; st.screenLayers = f.screenLayers;
 	st.tileStats = f.tileStats; st.screenStats = f.screenStats; st.compositeStats = f.compositeStats; st.tileCost = f.tileCost; st.tileSkipped = f.tileSkipped;
@@ -379,6 +380,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			if ((rc = devAlloc(ctx, &f.cubeOffset, (size_t)st.V * sizeof(uint64_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.lightDirs, (size_t)st.V * sizeof(float4))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.lightTable, (size_t)st.V * sizeof(uint4*), false)) != MV_OK) return bail(rc);
 			if (hipMemcpyAsync(f.lightTable, table.data(), (size_t)st.V * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 		}

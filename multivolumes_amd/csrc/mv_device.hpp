@@ -483,6 +483,18 @@ __device__ __forceinline__ bool ComputeRayOrigin(vec3& rayOrigin, vec3 rayDir)
 	return isHit;
 }
 
+// Conservative rejection in front of ComputeRayOrigin for the light march, where a voxel's ray is tested against every
+// volume and misses nearly all of them: a ray whose LINE stays outside the sphere of radius^2 3.1 (the box's circumscribed
+// sphere is radius^2 3, a 3 % margin, plus 1e-4 |o|^2 for the cancellation in |o|^2 - (o.d)^2 when the origin is far)
+// cannot pass ComputeRayOrigin's tests, which accept only points within 1 + a few ulp of the box -- and an origin inside
+// the box has |o|^2 <= 3.  rayDir is unit length (normalize3); NaNs compare false and fall through to the exact test.
+__device__ __forceinline__ bool missesUnitBox(vec3 o, vec3 d)
+{
+	const float oo = o.x * o.x + o.y * o.y + o.z * o.z;
+	const float od = o.x * d.x + o.y * d.y + o.z * d.z;
+	return oo - od * od > 3.1f + 1e-4f * oo;
+}
+
 // :160-165
 __device__ __forceinline__ float ComputeTargetHit(vec3 rayOrigin, vec3 target, vec3 rayDir)
 {

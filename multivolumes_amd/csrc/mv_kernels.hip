@@ -323,6 +323,12 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 
 		if (li == 0u && valid)
 		{
+			// the light direction in this volume's space: the light march needs it for every (voxel, volume) pair
+			{
+				const vec3 ld = normalize3(mul33(v3(cb->lightPos[0], cb->lightPos[1], cb->lightPos[2]), po.worldI));
+				float4 o; o.x = ld.x; o.y = ld.y; o.z = ld.z; o.w = 0.0f;
+				st.lightDirs[volumeId] = o;
+			}
 			ushort4 rect;
 			if (wMin > 1e-3f && bx0 == bx0 && by0 == by0)
 			{
@@ -706,8 +712,9 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 
 				if (shadow >= kZeroThreshold)
 				{
-					const vec3 localSpaceLightPt = mul33(v3(cb->lightPos[0], cb->lightPos[1], cb->lightPos[2]), po.worldI);
-					const vec3 rayDir = normalize3(localSpaceLightPt);
+					const float4 ld = st.lightDirs[n];	// = normalize(mul(lightPos, (float3x3)WorldI_n)), :88-89, evaluated once by the cull
+					const vec3 rayDir = v3(ld.x, ld.y, ld.z);
+					if (missesUnitBox(localRayOrigin, rayDir)) continue;	// what ComputeRayOrigin would conclude, at a fifth of the cost
 					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
 					CastLightRay(shadow, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS);
 				}
@@ -715,6 +722,7 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 				if (st.hasLightProbe)
 				{
 					const vec3 rayDir = normalize3(mul33(aoRayDir, po.worldI));
+					if (missesUnitBox(localRayOrigin, rayDir)) continue;
 					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
 					float transm = 1.0f;
 					CastLightRay(transm, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS);
@@ -1058,13 +1066,13 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 
 // ---------------------------------------------------------------------------------------------
 // Dispatch order of the view march: tiles binned by the length of their longest ray in the last launch that used this
-// frame parity's buffers, longest bins first, list order inside a bin (a stable counting sort, so neighbouring tiles
+// frame slot (four frames back: the cost table lives with the cull outputs), longest bins first, list order inside a bin (a stable counting sort, so neighbouring tiles
 // still follow each other and share L2 lines).  The tail of the launch is then made of short tiles instead of whichever
 // long ones the list happened to end with: 0.362 -> 0.326 ms at C3.  A full sort by cost is SLOWER than list order
 // (0.378 ms): it destroys the locality between neighbouring tiles; two bins give half the gain.  The order only decides
 // which wavefront marches which tile -- every tile is marched exactly once whatever the costs say, so a stale or empty
 // cost table (first frame, moved camera, changed mip) only costs speed.
-// Two launches of kOrderWaves single-wave workgroups, each owning a contiguous chunk of the tile list:
+// Two launches of kOrderWaves single-wave workgroups right behind the cull, each owning a contiguous chunk of the tile list:
 // count (per-wave bin histogram) and scatter (every wave re-derives its 8 bases from the 256 x 8 histogram).
 // ---------------------------------------------------------------------------------------------
 __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sStart, const uint32_t* sEntry, uint32_t nEntries, uint32_t nCubeTiles, uint32_t tile)

@@ -67,6 +67,7 @@ struct DeviceState
 	uint32_t* workTileStart;		// entries + 1 prefix sums of 8x8 tiles
 	uint64_t* cubeOffset;			// V: texel offset of the selected mip of volume v inside cubeMaps / cubeDepths
 	uint16_t* volumeRects;			// V x 4: conservative screen rectangle {x0, y0, x1, y1} (pixels, inclusive) of a visible volume
+	float4* lightDirs;				// V: normalize(mul(lightPos, (float3x3)WorldI_v)) -- CSRayMarchL.hlsl:88-89 evaluates it per voxel, it only depends on v
 	uint32_t* volumeFlags;			// V: bit0 visible this frame, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask
 
 	// Counters.  Every wavefront owns one slot and updates it with a plain read-modify-write (launches are stream
