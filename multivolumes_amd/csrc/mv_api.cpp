@@ -10,6 +10,7 @@
 #include "mv_mesh.hpp"
 
 #include <algorithm>
+#include <chrono>
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -22,6 +23,7 @@ using mv::DeviceState;
 
 namespace
 {
+constexpr uint32_t kMaxScreenSlots = 32;	// screen-space-scheme volumes whose RayCast joins the view-march launch (16 B x W x H of layer each, per output set)
 constexpr uint32_t kFrameSlots = 4;	// constants + cull outputs in flight: the cull of frame i+2 may run while frame i is still marching
 constexpr uint32_t kFrameSlices = 3;	// MultiRayCaster::FrameCount (MultiRayCaster.h:52): upload slices in flight
 constexpr uint32_t kNumCounters = 8;	// read back; counters[8] (the cull's ticket) is device-only
@@ -100,6 +102,7 @@ struct mv_ctx
 	hipEvent_t sliceDone[kFrameSlices] = {};
 	uint64_t* pinnedStats = nullptr;
 	uint32_t* pinnedCounters = nullptr;
+	unsigned long long* pinnedTiles = nullptr;	// written by the cull kernel: {frame tag : tile count} of the most recent cull that has run
 	uint8_t* pinnedCull = nullptr;		// counters + VolumeInfo + both lists + light table, one readback
 	uint64_t frame = 0;					// frames begun (mv_update_frame)
 	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
@@ -357,8 +360,12 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		st.bandRow0 = t0 * 8u < st.H ? t0 * 8u : st.H;
 		st.bandRow1 = t1 * 8u < st.H ? t1 * 8u : st.H;
 	}
-	// Screen-space-scheme volumes are marched inside the view-march launch (up to 8 of them), by every shard for ITS rows
-	st.screenSlots = st.V < 8u ? st.V : 8u;
+	// Screen-space-scheme volumes are marched inside the view-march launch (up to kMaxScreenSlots of them), by every shard for ITS rows
+	{
+		const char* e = getenv("MV_SCREEN_SLOTS");	// A/B measurements only
+		const uint32_t cap = e ? (uint32_t)atoi(e) : kMaxScreenSlots;
+		st.screenSlots = st.V < cap ? st.V : cap;
+	}
 	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.bandRow1 - st.bandRow0 + 7u) >> 3);
 	// constants + cull outputs, once per frame slot (FrameBufs)
 	{
@@ -438,6 +445,9 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	for (uint32_t i = 0; i < kFrameSlices; ++i)
 		if (hipEventCreateWithFlags(&ctx->sliceDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedTiles), 64, hipHostMallocCoherent) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
+	*ctx->pinnedTiles = ~0ull;
+	st.tilesReport = ctx->pinnedTiles;
 
 	// default VolumeDesc[V] = { i % S, NUM_CUBE_MIP, N } (MultiRayCaster.cpp:471-479)
 	{
@@ -471,6 +481,7 @@ void mv_destroy(mv_ctx* ctx)
 	if (ctx->dMeshMatrix) (void)hipFree(ctx->dMeshMatrix);
 	if (ctx->pinned) (void)hipHostFree(ctx->pinned);
 	if (ctx->pinnedCull) (void)hipHostFree(ctx->pinnedCull);
+	if (ctx->pinnedTiles) (void)hipHostFree(ctx->pinnedTiles);
 	if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -615,6 +626,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	// a new frame: the next slot of constants / cull buffers (and the other parity's march outputs)
 	ctx->slot = (ctx->slot + 1u) % kFrameSlots;
 	++ctx->frame;
+	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);
 	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->slot], 0));
@@ -674,6 +686,22 @@ int mv_march_light(mv_ctx* ctx)
 	return MV_OK;
 }
 
+// With frames in flight the cull of this frame runs ahead on stream A and reports its tile count to pinned memory; waiting for
+// that report (normally already there; bounded spin otherwise) lets the view-march grid be exact.  On one stream the host would
+// stall for the cull instead, and there the surplus workgroups of an upper-bound grid cost nothing: no wait.
+static uint32_t exactTileCount(mv_ctx* ctx)
+{
+	if (!(ctx->cfg.flags & MV_FLAG_PIPELINE_FRAMES) || !ctx->pinnedTiles) return 0xffffffffu;
+	const volatile unsigned long long* report = ctx->pinnedTiles;
+	const auto t0 = std::chrono::steady_clock::now();
+	for (uint32_t spins = 0;; ++spins)
+	{
+		const unsigned long long v = *report;
+		if ((uint32_t)(v >> 32) == (uint32_t)ctx->frame) return (uint32_t)v;
+		if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return 0xffffffffu;	// far beyond any frame in flight: give up, the upper bound is always correct
+	}
+}
+
 int mv_march_view(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
@@ -682,7 +710,7 @@ int mv_march_view(mv_ctx* ctx)
 	stageBBegin(ctx);
 	EventPair ev;
 	beginStage(ctx, 2, ev, streamB(ctx));
-	mv::launchMarchView(streamB(ctx), ctx->st);
+	mv::launchMarchView(streamB(ctx), ctx->st, exactTileCount(ctx));
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
 	stageBDone(ctx);

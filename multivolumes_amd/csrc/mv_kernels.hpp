@@ -60,6 +60,8 @@ struct DeviceState
 	uint16_t* volumeInfo;			// V x 4
 	uint32_t* visibleVolumes;		// V
 	uint32_t* cubeMapVolumes;		// V
+	unsigned long long* tilesReport;	// pinned host memory (may be NULL): the cull stores {frameTag : tile count} here
+	uint32_t frameTag;				// low 32 bits of the context's frame counter
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
 									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow)
 	uint32_t* ownedVisible;			// V: visible volumes of this shard, ascending
@@ -107,7 +109,7 @@ void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uin
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
-void launchMarchView(hipStream_t s, const DeviceState& st);
+void launchMarchView(hipStream_t s, const DeviceState& st, uint32_t exactTiles);
 void launchTileOrder(hipStream_t s, const DeviceState& st, uint32_t* binCounts, uint32_t* order);	// binCounts: 256 x 8 scratch; order: maxTiles + maxScreenTiles
 void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight);
 uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
