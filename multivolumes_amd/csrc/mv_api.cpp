@@ -642,6 +642,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->streamA));
 	stageADone(ctx);
 	ctx->haveFrame = true;
+	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
 	return MV_OK;
 }
 

@@ -252,6 +252,21 @@ def test_error_behaviour():
         with pytest.raises(MVError) as e:
             c.SetVolumeDescs([5 | (5 << 14) | (8 << 18)])
         assert e.value.code == _lib.MV_ERR_RANGE
+        # a frame's marches need THAT frame's cull (its slot holds the outputs of four frames ago until then)
+        cfg = dict(scene.CONFIGS["C1"], N=8, L=8, W=8, H=8)
+        fr = scene.setup_raycaster(c, cfg, [rc.synth_volume(8, 0)])
+        c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        c.Render()
+        c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        for stage in (c.rayMarchL, c.rayMarchV, c.composite, c.ReadBackCull):
+            with pytest.raises(MVError) as e:
+                stage()
+            assert e.value.code == _lib.MV_ERR_NOT_READY
+        c.cullVolumes()
+        c.rayMarchL(); c.rayMarchV(); c.composite(); c.synchronize()
+        with pytest.raises(MVError) as e:
+            MultiRayCaster(8, 700, 1, 1, (8, 8))  # light grid beyond the 32-bit offsets of the quad-replicated layout
+        assert e.value.code == _lib.MV_ERR_INVALID_ARG
 
 
 @pytest.mark.parametrize("name", ["C2"])
