@@ -49,7 +49,8 @@ __device__ __forceinline__ uint32_t f2u_sat(float x)	// D3D ftou
 	return (uint32_t)x;
 }
 
-__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// min(max(v, lo), hi): the form the compiler turns into one v_med3_i32 (the ?: chain became min + compare + select)
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { const int m = v > lo ? v : lo; return m < hi ? m : hi; }
 
 // ---- structured/constant buffer layouts (Sh/Common.hlsli:28-49; MultiRayCaster.cpp:23-41, 341-351) ----
 // float4x4 written transposed by the host and read column-major: M[r][c] = f[4*c + r]; float4x3 likewise, c < 3.
