@@ -146,7 +146,8 @@ int mv_mesh_render_shadow(mv_ctx* ctx, const float shadowWVPT[16]);
 int mv_readback_depth_map(mv_ctx* ctx, float* dst /* W x H */);
 int mv_readback_shadow_map(mv_ctx* ctx, uint16_t* dst /* M x M */);
 
-/* cullVolumes (MultiRayCaster.cpp:1249-1285) = CSVolumeCull.hlsl:13-78. Lists come out in ascending volume order. */
+/* cullVolumes (MultiRayCaster.cpp:1249-1285) = CSVolumeCull.hlsl:13-78. Lists come out in ascending volume order.
+ * The three marches below need THIS frame's cull (the frame that the last mv_update_frame began): MV_ERR_NOT_READY otherwise. */
 int mv_cull(mv_ctx* ctx);
 /* rayMarchL (MultiRayCaster.cpp:1299-1327) = CSRayMarchL.hlsl:20-121: relights ONE volume, visible[FrameIdx % count].
  * Sharded contexts relight their own volume shard's member instead: owned_visible[FrameIdx % owned_count]. */
@@ -156,13 +157,15 @@ int mv_march_view(mv_ctx* ctx);
 /* cubeDepthPeel + renderCube + resolveOIT (MultiRayCaster.cpp:1440-1492, 1544-1580, 1615-1633) over screen rows
  * [row0, row1) of the W x H RGBA16F output (row1 = 0 -> H). Background = transparent black. */
 int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1);
-/* Render (MultiRayCaster.cpp:355-385), non-work-graph branch: cull -> marchL -> marchV [-> composite], then FrameIdx += 1 is the caller's job. */
+/* Render (MultiRayCaster.cpp:355-385), non-work-graph branch: cull -> marchL -> marchV [-> composite]; FrameIdx += 1 is the caller's job. */
 int mv_render(mv_ctx* ctx, int with_composite);
 
 /* CPU readback of the buffers the path emits (the reference's only "ReadBack" notion: XUSG.h:1614, 1860). */
 int mv_readback_volume_info(mv_ctx* ctx, uint16_t* dst /* V x 4 */);
-/* Everything the cull produced in ONE stream synchronisation (what a multi-GPU driver needs per frame): VolumeInfo[V],
- * both lists with their counts, and the minimum selected mip over the visible volumes (the exchange slot size). */
+/* Everything the cull produced in ONE host wait (what a multi-GPU driver needs per frame): VolumeInfo[V], both lists with their
+ * counts, and the minimum selected mip over the visible volumes (the exchange slot size).  Waits for the cull only: with frames
+ * in flight the marches of earlier frames keep running.  It also brings back this frame's light-map table, so that
+ * mv_get_buffer(MV_BUF_LIGHT_MAP) afterwards needs no host wait (the context's stream waits for the frame's light march). */
 int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info /* V x 4 */, uint32_t* visible /* V */, uint32_t* visibleCount,
 	uint32_t* cubeMapVolumes /* V */, uint32_t* cubeMapCount, uint32_t* minMip);
 int mv_readback_visible_lists(mv_ctx* ctx, uint32_t* visible /* V */, uint32_t* visibleCount,
@@ -184,7 +187,7 @@ int mv_synchronize(mv_ctx* ctx);
 void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */
 /* device pointers + byte sizes of context-owned buffers; `which` = MV_BUF_* */
 #define MV_BUF_VOLUME 0			/* index = src */
-#define MV_BUF_LIGHT_MAP 1		/* index = volume */
+#define MV_BUF_LIGHT_MAP 1		/* index = volume: the buffer this frame reads (device layout: L^3 cells of 16 B) */
 #define MV_BUF_CUBE_MAP 2		/* index = volume: whole 5-mip chain, uint16[chain][4] */
 #define MV_BUF_CUBE_DEPTH 3		/* index = volume */
 #define MV_BUF_VOLUME_INFO 4
