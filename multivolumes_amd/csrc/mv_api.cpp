@@ -38,6 +38,7 @@ struct FrameBufs
 {
 	void* dCb = nullptr;
 	void* dPerObject = nullptr;
+	uint8_t* cullBlock = nullptr;		// counters | VolumeInfo | visible | cube-map list | light table, contiguous
 	uint16_t* volumeInfo = nullptr;
 	uint32_t *visibleVolumes = nullptr, *cubeMapVolumes = nullptr, *counters = nullptr, *ownedVisible = nullptr;
 	uint32_t *workEntries = nullptr, *workTileStart = nullptr;
@@ -376,11 +377,19 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			FrameBufs& f = ctx->fb[p];
 			if ((rc = devAlloc(ctx, &f.dCb, 256 + (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);	// one upload: CBPerFrame, then PerObject[V]
 			f.dPerObject = static_cast<uint8_t*>(f.dCb) + 256;
-			if ((rc = devAlloc(ctx, &f.volumeInfo, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
-			if ((rc = devAlloc(ctx, &f.visibleVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
-			if ((rc = devAlloc(ctx, &f.cubeMapVolumes, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			// what mv_readback_cull brings back sits in ONE block, in the order of its pinned copy: counters (64 B), VolumeInfo[V],
+			// visible[V], cube-map list[V], light table[V]
+			{
+				uint8_t* block = nullptr;
+				if ((rc = devAlloc(ctx, &block, 64 + (size_t)st.V * 24)) != MV_OK) return bail(rc);
+				f.cullBlock = block;
+				f.counters = reinterpret_cast<uint32_t*>(block);	// kNumCounters read back + the cull's ticket at [8]
+				f.volumeInfo = reinterpret_cast<uint16_t*>(block + 64);
+				f.visibleVolumes = reinterpret_cast<uint32_t*>(block + 64 + (size_t)st.V * 8);
+				f.cubeMapVolumes = reinterpret_cast<uint32_t*>(block + 64 + (size_t)st.V * 12);
+				f.lightTable = reinterpret_cast<uint4**>(block + 64 + (size_t)st.V * 16);
+			}
 			if ((rc = devAlloc(ctx, &f.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
-			if ((rc = devAlloc(ctx, &f.counters, (kNumCounters + 8) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.screenSlot, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.workEntries, ((size_t)st.V * 6 + st.screenSlots) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.workTileStart, ((size_t)st.V * 6 + st.screenSlots + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
@@ -388,7 +397,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			if ((rc = devAlloc(ctx, &f.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.lightDirs, (size_t)st.V * sizeof(float4))) != MV_OK) return bail(rc);
-			if ((rc = devAlloc(ctx, &f.lightTable, (size_t)st.V * sizeof(uint4*), false)) != MV_OK) return bail(rc);
 			if (hipMemcpyAsync(f.lightTable, table.data(), (size_t)st.V * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 		}
 		if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
@@ -1101,11 +1109,7 @@ int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info, uint32_t* visible, uint
 	// waits for this frame's cull (which runs ahead), not for the marches of the frames before it.
 	const size_t V = ctx->st.V;
 	uint8_t* p = ctx->pinnedCull;
-	MV_HIP(ctx, hipMemcpyAsync(p, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->streamA));
-	MV_HIP(ctx, hipMemcpyAsync(p + 64, ctx->st.volumeInfo, V * 8, hipMemcpyDeviceToHost, ctx->streamA));
-	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 8, ctx->st.visibleVolumes, V * 4, hipMemcpyDeviceToHost, ctx->streamA));
-	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 12, ctx->st.cubeMapVolumes, V * 4, hipMemcpyDeviceToHost, ctx->streamA));
-	MV_HIP(ctx, hipMemcpyAsync(p + 64 + V * 16, ctx->st.lightTable, V * sizeof(uint4*), hipMemcpyDeviceToHost, ctx->streamA));
+	MV_HIP(ctx, hipMemcpyAsync(p, ctx->fb[ctx->slot].cullBlock, 64 + V * 24, hipMemcpyDeviceToHost, ctx->streamA));	// one copy (FrameBufs::cullBlock)
 	MV_HIP(ctx, hipStreamSynchronize(ctx->streamA));
 	ctx->lightTableFrame = ctx->frame;
 	const uint32_t* counters = reinterpret_cast<const uint32_t*>(p);
