@@ -147,6 +147,9 @@ class LightMapExchange:
         return self.nbytes * self.world
 
 
+_IN_PLACE_REFUSED = []  # set once if torch rejects the in-place all-gather (argument checks raise before anything is enqueued)
+
+
 def gather_composite_rows(caster, H, W, rank, world, group=None):
     """After every rank composited its row band: all-gather the bands so every rank's composite buffer holds the frame."""
     import torch
@@ -157,10 +160,14 @@ def gather_composite_rows(caster, H, W, rank, world, group=None):
     row_bytes = W * 8
     r0, r1 = bands[rank]
     frame = _device_view(ptr, nbytes)  # aliases the context's buffer, no copy
-    if all(b[1] - b[0] == max_rows for b in bands) and dist.get_backend(group) == "nccl":
-        # equal bands: the frame buffer IS the all-gather output and this rank's band its input, in place (no staging copies)
-        dist.all_gather_into_tensor(frame[:world * max_rows * row_bytes], frame[r0 * row_bytes:r1 * row_bytes], group=group)
-        return world * max_rows * row_bytes
+    if all(b[1] - b[0] == max_rows for b in bands) and dist.get_backend(group) == "nccl" and not _IN_PLACE_REFUSED:
+        # equal bands: the frame buffer IS the all-gather output and this rank's band its input, in place (no staging copies);
+        # NCCL / RCCL define that (sendbuff == recvbuff + rank * count) -- if this torch build objects to the overlap, stage instead
+        try:
+            dist.all_gather_into_tensor(frame[:world * max_rows * row_bytes], frame[r0 * row_bytes:r1 * row_bytes], group=group)
+            return world * max_rows * row_bytes
+        except (RuntimeError, ValueError):
+            _IN_PLACE_REFUSED.append(True)
     send = torch.zeros(max_rows * row_bytes, dtype=torch.uint8, device="cuda")
     send[:(r1 - r0) * row_bytes].copy_(frame[r0 * row_bytes:r1 * row_bytes])
     recv = torch.empty(world * max_rows * row_bytes, dtype=torch.uint8, device="cuda")
