@@ -1,0 +1,56 @@
+"""Randomised parity sweep: the whole path (cull, V light marches, view march, composite inputs) against the oracle on
+seeded random scenes -- ragged grid sizes, random eyes (outside, inside and between the volumes), sparse / dense / noisy
+volumes, SH on and off, with and without mesh depth.  Everything must match bit for bit, counters included."""
+import numpy as np
+import pytest
+
+from multivolumes_amd import scene
+from multivolumes_amd import raycaster as rc
+from tests.helpers import oracle_pipeline
+from tests.test_gpu_parity import compare_cube, compare_light, make_caster, run_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+def random_volume(rng, N, kind):
+    v = rc.synth_volume(N, int(rng.integers(0, 6))).view(np.float16).copy()
+    if kind == "sparse":
+        keep = rng.random((-(-N // 4),) * 3) < rng.uniform(0.1, 0.6)
+        mask = np.repeat(np.repeat(np.repeat(keep, 4, 0), 4, 1), 4, 2)[:N, :N, :N]
+        v[..., 3] = np.where(mask, v[..., 3], np.float16(0))
+    elif kind == "noise":
+        v[..., 3] = (rng.random((N, N, N)) ** 3).astype(np.float16)
+        v[..., :3] = rng.random((N, N, N, 3)).astype(np.float16)
+    elif kind == "thin":
+        v[..., 3] = np.where(rng.random((N, N, N)) < 0.02, np.float16(1.0), np.float16(0.004))
+    return v.view(np.uint16)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scene(oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([12, 17, 20, 24, 30, 36, 40]))
+    L = int(rng.choice([6, 9, 12, 16]))
+    V = int(rng.choice([1, 2, 4, 9]))
+    W, H = int(rng.choice([96, 130, 200])), int(rng.choice([64, 100, 160]))
+    cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([16, 40, 100])), maxLight=int(rng.choice([8, 20, 48])), mesh=bool(rng.integers(0, 2)))
+    kinds = rng.choice(["plain", "sparse", "noise", "thin"], size=V)
+    vols = [random_volume(rng, N, k) for k in kinds]
+    r = rng.uniform(8, 140)
+    d = rng.normal(size=3)
+    eye = tuple((d / np.linalg.norm(d) * r).astype(np.float32))
+    use_sh = bool(rng.integers(0, 2))
+    M = 64
+    ref = oracle_pipeline(oracle, cfg, vols, M, sh=scene.DEFAULT_SH if use_sh else None, eye=eye)
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols, use_sh=use_sh, eye=eye)
+        assert np.array_equal(c.ReadBackVolumeInfo()[ref["vis"]], ref["info"][ref["vis"]]), "VolumeInfo of the visible volumes"
+        vis, cube = c.ReadBackVisibleLists()
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube, ref["cube"])
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        if len(ref["cube"]):
+            worst, mism, total = compare_cube(oracle, c, ref, cfg, tol=0.0)
+            assert mism == 0
+        st = c.GetStats()
+    for k in ("rays", "view_samples", "lit_samples", "light_samples"):
+        assert st[k] == ref["stats"][k], (k, cfg, kinds, eye)
