@@ -1,4 +1,4 @@
-"""Randomised parity sweep: the whole path (cull, V light marches, view march, composite inputs) against the oracle on
+"""Randomised parity sweep: the whole path (cull, V light marches, view march, composite) against the oracle on
 seeded random scenes -- ragged grid sizes, random eyes (outside, inside and between the volumes), sparse / dense / noisy
 volumes, SH on and off, with and without mesh depth.  Everything must match bit for bit, counters included."""
 import numpy as np
@@ -7,7 +7,7 @@ import pytest
 from multivolumes_amd import scene
 from multivolumes_amd import raycaster as rc
 from tests.helpers import oracle_pipeline
-from tests.test_gpu_parity import compare_cube, compare_light, make_caster, run_gpu
+from tests.test_gpu_parity import compare_cube, compare_light, make_caster, oracle_composite, run_gpu
 
 pytestmark = pytest.mark.gpu
 
@@ -51,6 +51,14 @@ def test_random_scene(oracle, seed):
         if len(ref["cube"]):
             worst, mism, total = compare_cube(oracle, c, ref, cfg, tol=0.0)
             assert mism == 0
+        # the K-buffer OIT composite of the same frame (CubeCast layers + screen-space RayCast layers)
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref)
+        c.composite()
+        got = c.ReadBackComposite()
+        gf, ef = got.view(np.float16), np.asarray(exp).view(np.float16)
+        assert np.array_equal(np.isnan(gf), np.isnan(ef))
+        assert np.array_equal(np.where(np.isnan(gf), 0, got), np.where(np.isnan(ef), 0, np.asarray(exp))), (cfg, kinds, eye)
         st = c.GetStats()
+    assert st["composite_samples"] == exp_samples
     for k in ("rays", "view_samples", "lit_samples", "light_samples"):
         assert st[k] == ref["stats"][k], (k, cfg, kinds, eye)
