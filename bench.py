@@ -14,8 +14,9 @@ timed region keeps several frames in flight, so two view-march launches share th
 run one at a time (synchronise after every frame), still HIP events inside this process.
 `cpu_baseline` is the CPU oracle (the reference has no Linux CPU path) timed on the same frame's marchV.
 
-Defaults: 200 warm-up + 1000 timed frames (about 0.5 s of GPU time).  The warm-up is that long because the HIP runtime
-stalls once for 30-50 ms around the 140th frame of a process (its command / signal pools grow); measured, one-time.
+Defaults: 200 warm-up + 1000 timed frames (about 0.5 s of GPU time).  The HIP runtime stalls once for 30-50 ms around the
+140th frame of a process (its command / signal pools grow; measured, one-time): the setup phase below runs 176 frames for
+that reason, before the caller's warm-up.
 """
 import argparse
 import json
@@ -135,8 +136,9 @@ def main():
             if world > 1 and with_exchange:
                 xbytes[0] += D.gather_composite_rows(caster, H, W, rank, world)
 
-    # relight every visible volume once so the light maps are real, then warm up
-    for _ in range(V):
+    # Setup frames: relight every visible volume at least once so the light maps are real -- and get past the HIP runtime's
+    # one-time 30-50 ms stall around the 140th frame of a process (see the module docstring) whatever --warmup the caller gives.
+    for _ in range(max(V, 176)):
         frame(with_exchange=False)
     for _ in range(args.warmup):
         frame()
