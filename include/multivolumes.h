@@ -150,7 +150,8 @@ int mv_readback_shadow_map(mv_ctx* ctx, uint16_t* dst /* M x M */);
  * The three marches below need THIS frame's cull (the frame that the last mv_update_frame began): MV_ERR_NOT_READY otherwise. */
 int mv_cull(mv_ctx* ctx);
 /* rayMarchL (MultiRayCaster.cpp:1299-1327) = CSRayMarchL.hlsl:20-121: relights ONE volume, visible[FrameIdx % count].
- * Sharded contexts relight their own volume shard's member instead: owned_visible[FrameIdx % owned_count]. */
+ * On sharded contexts only the shard that owns that volume marches (the others return at once): the light maps evolve frame
+ * by frame exactly as on one GPU. */
 int mv_march_light(mv_ctx* ctx);
 /* rayMarchV (MultiRayCaster.cpp:1329-1368) = CSRayMarch.hlsl:77-158 with _LIGHT_PASS_ (CSRayMarchV.hlsl). */
 int mv_march_view(mv_ctx* ctx);

@@ -203,16 +203,17 @@ __global__ __launch_bounds__(256) void lightFromQuadsKernel(const uint4* __restr
 	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) linear[i] = quads[i].x;
 }
 
-// The volume CSRayMarchL.hlsl:29-33 relights this frame: visible[frameIdx % visibleCount], else frameIdx % V.
-// Sharded contexts round-robin over their OWN visible volumes (and own volumes when nothing is visible).
-__device__ __forceinline__ uint32_t relitVolume(const DeviceState& st, uint32_t frameIdx, uint32_t ownedCount, const uint32_t* ownedVisible)
+// The volume CSRayMarchL.hlsl:29-33 relights this frame: visible[frameIdx % visibleCount], else frameIdx % V -- ONE volume per
+// frame whatever the number of shards (the lists are in ascending volume order on every shard: the cull is replicated).
+// The shard that owns it (v % shardCount == shardIndex) marches its light map; the others do nothing that frame.
+__device__ __forceinline__ uint32_t relitVolume(const DeviceState& st, uint32_t frameIdx, uint32_t visibleCount, const uint32_t* visibleVolumes)
+{
+	return visibleCount ? visibleVolumes[frameIdx % visibleCount] : frameIdx % st.V;
+}
+__device__ __forceinline__ bool ownsVolume(const DeviceState& st, uint32_t v)
 {
 	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
-	if (ownedCount) return ownedVisible[frameIdx % ownedCount];
-	if (shardCount == 1u) return frameIdx % st.V;
-	const uint32_t ownedTotal = st.V > st.shardIndex ? (st.V - st.shardIndex + shardCount - 1u) / shardCount : 0u;
-	if (ownedTotal == 0u) return 0xffffffffu;
-	return st.shardIndex + shardCount * (frameIdx % ownedTotal);
+	return v % shardCount == st.shardIndex;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,19 +437,18 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(minMip, o); minMip = m < minMip ? m : minMip; }
 
-	// This frame's light-map table = last frame's, with the volume about to be relit switched to its other buffer.
+	// This frame's light-map table = last frame's, with the volume this shard is about to relight switched to its next buffer.
 	{
 		uint32_t relit;
-		const uint32_t sc = st.shardCount ? st.shardCount : 1u;
-		if (nOwned)
+		if (nVis)
 		{
-			// the (frameIdx % nOwned)-th owned visible volume, found in the flags (the list itself was written by other lanes)
-			const uint32_t want = cb->frameIdx % nOwned;
+			// the (frameIdx % nVis)-th visible volume, found in the flags (the list itself was written by other lanes)
+			const uint32_t want = cb->frameIdx % nVis;
 			uint32_t seen = 0; relit = 0xffffffffu;
 			for (uint32_t base = 0; base < st.V; base += 64)
 			{
 				const uint32_t v = base + lane;
-				const bool ov = v < st.V && (sInfo[v] & 1u) && (v % sc) == st.shardIndex;
+				const bool ov = v < st.V && (sInfo[v] & 1u);
 				const uint64_t b = __ballot(ov);
 				const uint32_t rank = seen + (uint32_t)__popcll(b & lower);
 				const uint64_t hit = __ballot(ov && rank == want);
@@ -457,6 +457,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			}
 		}
 		else relit = relitVolume(st, cb->frameIdx, 0u, nullptr);
+		if (!ownsVolume(st, relit)) relit = 0xffffffffu;	// another shard's: nothing rotates here (its map, if needed, arrives by exchange)
 		const size_t L3 = (size_t)st.L * st.L * st.L;
 		for (uint32_t v = lane; v < st.V; v += 64)
 		{
@@ -645,10 +646,10 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 
-	// CSRayMarchL.hlsl:29-33 (sharded contexts round-robin over their own visible volumes)
-	uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[4], st.ownedVisible);
-	if (volumeId == 0xffffffffu) return;
+	// CSRayMarchL.hlsl:29-33; on a sharded context only the owner of that volume marches
+	uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
 	volumeId = __builtin_amdgcn_readfirstlane(volumeId);
+	if (!ownsVolume(st, volumeId)) return;
 
 	const uint32_t L = st.L;
 	const uint32_t blocksPerAxis = (L + 3u) >> 2;

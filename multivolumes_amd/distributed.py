@@ -107,10 +107,11 @@ class CubeFaceExchange:
 
 
 class LightMapExchange:
-    """Screen-space (RayCast) layers of the composite read the light map of their volume (RayCast.hlsli:76), which only
-    the owning rank relights.  Light maps change one volume per rank per frame (CSRayMarchL.hlsl:29-33), so per frame each
-    rank contributes at most the ONE light map it just relit, and only if that volume is on the screen-space scheme
-    (known everywhere: the cull is replicated).  Frames whose relit volumes are all on the cube-map scheme move nothing."""
+    """Screen-space (RayCast) layers read the light map of their volume (RayCast.hlsli:76), and every rank marches its own rows
+    of every such volume inside the view march.  ONE volume is relit per frame -- visible[frameIdx % count], by the rank that
+    owns it (CSRayMarchL.hlsl:29-33; the cull is replicated, so every rank knows which) -- so per frame at most that one light
+    map has to travel, and only if its volume is on the screen-space scheme: a broadcast from its owner before the view march.
+    Frames whose relit volume is on the cube-map scheme move nothing."""
 
     def __init__(self, caster, group=None):
         import torch
@@ -119,32 +120,21 @@ class LightMapExchange:
         self.caster, self.group = caster, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.nbytes = caster.GetBuffer(1, 0)[1]  # MV_BUF_LIGHT_MAP: device layout (quad-replicated cells, 16 B per texel)
-        self.send = self.recv = None
 
-    def relit_volume(self, visible, frame_idx, rank):
-        ov = [int(v) for v in visible if int(v) % self.world == rank]
-        return ov[frame_idx % len(ov)] if ov else None
+    @staticmethod
+    def relit_volume(visible, frame_idx, V):
+        """The volume this frame relights (the same on every rank)."""
+        return int(visible[frame_idx % len(visible)]) if len(visible) else frame_idx % V
 
     def run(self, volume_info, visible, frame_idx):
         if self.world == 1:
             return 0
-        relit = [self.relit_volume(visible, frame_idx, r) for r in range(self.world)]
-        need = [v is not None and not (int(volume_info[v][2]) & 0x8000) for v in relit]
-        if not any(need):
-            return 0
-        if self.send is None:
-            self.send = self.torch.zeros(self.nbytes, dtype=self.torch.uint8, device="cuda")
-            self.recv = self.torch.empty(self.nbytes * self.world, dtype=self.torch.uint8, device="cuda")
-        if need[self.rank]:
-            ptr, n = self.caster.GetBuffer(1, relit[self.rank])  # MV_BUF_LIGHT_MAP
-            self.send.copy_(_device_view(ptr, n))
-        self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        for r in range(self.world):
-            if r != self.rank and need[r]:
-                ptr, n = self.caster.GetBuffer(1, relit[r])
-                _device_view(ptr, n).copy_(self.recv[r * self.nbytes:(r + 1) * self.nbytes])
-        return self.nbytes * self.world
+        v = self.relit_volume(visible, frame_idx, self.caster.numVolumes)
+        if not len(visible) or (int(volume_info[v][2]) & 0x8000):
+            return 0  # on the cube-map scheme (or nothing visible): only its owner's view march reads that light map
+        ptr, n = self.caster.GetBuffer(1, v)  # MV_BUF_LIGHT_MAP (device layout); the context's stream waits for the light march
+        self.dist.broadcast(_device_view(ptr, n), src=v % self.world, group=self.group)
+        return n
 
 
 _IN_PLACE_REFUSED = []  # set once if torch rejects the in-place all-gather (argument checks raise before anything is enqueued)

@@ -62,12 +62,13 @@ def _worker(rank, world, port, out_path):
         depth, shadow = scene.depth_and_shadow(cfg, vp, svp, M)
         info, vis, cube = o.cull(V, po, descs, cb, cfg["maxRay"])  # replicated cull
         mine = [v for v in D.owned_volumes(V, rank, world)]
-        # marchL for owned visible volumes only: owned_visible[f % count]
-        owned_vis = [int(v) for v in vis if int(v) in mine]
+        # frame f relights visible[f % count] (CSRayMarchL.hlsl:29-33) on the rank that owns that volume; the others skip the light march
         lms = None
-        for f in range(len(owned_vis)):
+        for f in range(len(vis)):
+            if D.LightMapExchange.relit_volume(vis, f, V) not in mine:
+                continue
             _, _, _, cbf, _ = host_frame(cfg, f)
-            _, lms, _ = o.march_light(V, N, L, M, vols, descs, po, cbf, shadow, None, owned_vis, cfg["maxLight"], lms)
+            _, lms, _ = o.march_light(V, N, L, M, vols, descs, po, cbf, shadow, None, vis, cfg["maxLight"], lms)
         if lms is None:
             lms = np.zeros((V, L, L, L), np.uint32)
         own_cube = [int(v) for v in cube if int(v) in mine]
@@ -112,7 +113,7 @@ def test_two_rank_gloo_pipeline_matches_single_process(oracle, tmp_path):
     out_path = str(tmp_path / "rank0.npz")
     mp.spawn(_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
     got = np.load(out_path)
-    # single-process reference; its marchL round-robin differs (visible[f % count] over all volumes), so relight all
+    # single-process reference: the same frames, every one relit by the one process
     cfg = dict(scene.CONFIGS["T1"], W=96, H=80)
     vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
     ref = oracle_pipeline(oracle, cfg, vols, 32)

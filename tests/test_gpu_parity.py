@@ -379,7 +379,7 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
         for r, c in enumerate(shards):
             scene.setup_raycaster(c, cfg, vols)
             owned_vis = [int(v) for v in vis if int(v) % world == r]
-            for f in range(len(owned_vis)):  # sharded contexts relight owned_visible[f % count]
+            for f in range(len(vis)):  # every context runs every frame; frame f relights visible[f % count] on the shard that owns it
                 c.m_frameIdx = f
                 c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
                 c.cullVolumes()
