@@ -536,3 +536,22 @@ def test_headline_config_c3_matches_oracle_at_full_size(oracle):
         for k in ("rays", "view_samples", "lit_samples", "light_samples"):
             assert st[k] == ref["stats"][k], k
         assert st["view_samples"] > 15_000_000 and 0 < st["fetch_free_samples"] < st["view_samples"]
+
+
+def test_large_grid_offsets(oracle):
+    """N = 512 (1 GiB of texels per volume): the 32-bit byte offsets and 24-bit stride multiplies of the bricked layout near
+    their upper range, against the oracle."""
+    cfg = dict(scene.CONFIGS["C1"], N=512, L=16, W=640, H=640, maxRay=40, maxLight=24)
+    vols = [rc.synth_volume(cfg["N"], 1)]
+    ref = oracle_pipeline(oracle, cfg, vols, 64)
+    with make_caster(cfg, 64) as c:
+        run_gpu(c, cfg, vols)
+        assert np.array_equal(c.ReadBackVolumeInfo(), ref["info"])
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        worst, mism, total = compare_cube(oracle, c, ref, cfg, tol=0.0)
+        assert mism == 0 and total > 0
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref)
+        c.composite()
+        assert np.array_equal(c.ReadBackComposite(), exp)
+        st = c.GetStats()
+        assert st["view_samples"] == ref["stats"]["view_samples"] > 0 and st["composite_samples"] == exp_samples
