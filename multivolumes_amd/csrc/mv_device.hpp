@@ -365,9 +365,45 @@ __device__ __forceinline__ ColourFootprint fetchColour(const VolumeView& v, cons
 	return f;
 }
 
+#ifndef MV_FMA_MIX
+#define MV_FMA_MIX 1
+#endif
+#if MV_FMA_MIX
+// lerp(a, b, w) = fma(w, b - a, a) with a, b fp16 halves of 32-bit registers, through v_fma_mix_f32: the conversions ride on
+// the two FMAs instead of being instructions of their own.  b - a is fma(b, 1.0, -a): b * 1.0 is exact, so the one rounding is
+// that of the fp32 subtraction the plain form performs; the second FMA is the same operation with a converted on the fly.
+// HI selects the upper half of the register that holds the texel channel.
+template <int HI_A, int HI_B>
+__device__ __forceinline__ float lerpHalves(uint32_t regA, uint32_t regB, float w)
+{
+	float d, r;
+	if constexpr (HI_A == 0 && HI_B == 0) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(regB), "v"(regA));
+	else if constexpr (HI_A == 1 && HI_B == 1) asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(regB), "v"(regA));
+	else static_assert(HI_A == HI_B, "both halves come from the same channel position");
+	if constexpr (HI_A == 0) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(w), "v"(d), "v"(regA));
+	else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(w), "v"(d), "v"(regA));
+	return r;
+}
+// channel C of the eight texels (0 = R: low half of .x, 1 = G: high half of .x, 2 = B: low half of .y, 3 = A: high half of .y)
+template <int C>
+__device__ __forceinline__ float trilerpChannel(const ColourFootprint& f)
+{
+	constexpr int HI = C & 1;
+#define MV_REG(t) ((C >> 1) ? (t).y : (t).x)
+	const float x00 = lerpHalves<HI, HI>(MV_REG(f.t000), MV_REG(f.t100), f.fx), x10 = lerpHalves<HI, HI>(MV_REG(f.t010), MV_REG(f.t110), f.fx);
+	const float x01 = lerpHalves<HI, HI>(MV_REG(f.t001), MV_REG(f.t101), f.fx), x11 = lerpHalves<HI, HI>(MV_REG(f.t011), MV_REG(f.t111), f.fx);
+#undef MV_REG
+	return lerpf(lerpf(x00, x10, f.fy), lerpf(x01, x11, f.fy), f.fz);
+}
+#endif
+
 __device__ __forceinline__ vec3 resolveRGB(const ColourFootprint& f)
 {
 	vec3 r;
+#if MV_FMA_MIX
+	r.x = trilerpChannel<0>(f); r.y = trilerpChannel<1>(f); r.z = trilerpChannel<2>(f);
+	return r;
+#endif
 #define MV_R(t) half_bits_to_float((t).x & 0xffffu)
 #define MV_G(t) half_bits_to_float((t).x >> 16)
 #define MV_B(t) half_bits_to_float((t).y & 0xffffu)
@@ -383,6 +419,9 @@ __device__ __forceinline__ vec3 resolveRGB(const ColourFootprint& f)
 // alpha through the texels themselves (used by diagnostics and by the alpha-cell builder's self check)
 __device__ __forceinline__ float resolveAlphaFromTexels(const ColourFootprint& f)
 {
+#if MV_FMA_MIX
+	return trilerpChannel<3>(f);
+#endif
 #define MV_W(t) half_bits_to_float((t).y >> 16)
 	return trilerp(MV_W(f.t000), MV_W(f.t100), MV_W(f.t010), MV_W(f.t110), MV_W(f.t001), MV_W(f.t101), MV_W(f.t011), MV_W(f.t111), f.fx, f.fy, f.fz);
 #undef MV_W
