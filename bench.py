@@ -213,6 +213,24 @@ def main():
                 traffic = json.load(open(tf)).get(f"{args.config}{'-stress' if args.stress else ''}", {}).get("marchViewKernel_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        # SURVEY 8(d) asks for two more reference points beside the spec peak: what a plain device copy reaches on this box, and the
+        # compulsory footprint of the frame (every visible volume and light map read once, outputs written once)
+        copy_gbs = None
+        try:
+            a = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+            b = torch.empty_like(a)
+            b.copy_(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(8):
+                b.copy_(a)
+            e1.record()
+            e1.synchronize()
+            copy_gbs = 8 * 2 * a.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9  # bytes read + bytes written
+            del a, b
+        except Exception:
+            pass
+        compulsory = len(vis) * (8 * N ** 3 + 4 * L ** 3) + 12 * (tot_rays // K) + 4 * cfg["W"] * cfg["H"]
         out = {
             "metric": "volume_samples_per_sec", "value": tot_view / dt / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
@@ -241,6 +259,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": ms_v,
                          "requested_bytes_per_launch": alg_bytes - 64 * st.get("fetch_free_samples", 0) / K,
+                         "compulsory_footprint_bytes": compulsory, "device_copy_measured": copy_gbs, "device_copy_unit": "GB/s (read + write)",
                          "launch_ms_in_flight": k_in_flight["march_view"],
                          "launch_ms_from": (f"{args.roofline_frames} frames run one at a time after the timed region (HIP events)" if st_iso
                                             else f"every {args.profile_every}th frame of the timed region (HIP events)")},
