@@ -319,11 +319,33 @@ __device__ __forceinline__ AlphaFootprint fetchAlphaCell(const VolumeView& v, co
 	return f;
 }
 
+#ifndef MV_FMA_MIX
+#define MV_FMA_MIX 1
+#endif
+#if MV_FMA_MIX
+// lerp(lo, hi, w) of the two fp16 halves of ONE register through v_fma_mix_f32 (see lerpHalves below: same arithmetic as
+// converting both and computing fma(w, hi - lo, lo), without the conversions as separate instructions)
+__device__ __forceinline__ float lerpRegisterHalves(uint32_t reg, float w)
+{
+	float d, r;
+	asm("v_fma_mix_f32 %0, %1, 1.0, -%1 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(reg));
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(w), "v"(d), "v"(reg));
+	return r;
+}
+#endif
+
 __device__ __forceinline__ float resolveAlpha(const AlphaFootprint& f)
 {
+#if MV_FMA_MIX
+	// x taps are the two halves of each quad word: {a000,a100 | a001,a101} in row0, {a010,a110 | a011,a111} in row1
+	const float x00 = lerpRegisterHalves(f.row0.x, f.cx), x10 = lerpRegisterHalves(f.row1.x, f.cx);
+	const float x01 = lerpRegisterHalves(f.row0.y, f.cx), x11 = lerpRegisterHalves(f.row1.y, f.cx);
+	return lerpf(lerpf(x00, x10, f.cy), lerpf(x01, x11, f.cy), f.cz);
+#else
 	return trilerp(half_bits_to_float(f.row0.x & 0xffffu), half_bits_to_float(f.row0.x >> 16), half_bits_to_float(f.row1.x & 0xffffu), half_bits_to_float(f.row1.x >> 16),
 		half_bits_to_float(f.row0.y & 0xffffu), half_bits_to_float(f.row0.y >> 16), half_bits_to_float(f.row1.y & 0xffffu), half_bits_to_float(f.row1.y >> 16),
 		f.cx, f.cy, f.cz);
+#endif
 }
 #else
 struct AlphaFootprint { u32x4 cell; float cx, cy, cz; };
