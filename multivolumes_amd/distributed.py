@@ -6,6 +6,8 @@ torch.distributed is plumbing here: it moves the bytes the C ABI packs (mv_excha
 The pure functions (owned_volumes, exchange_layout, row_range) mirror the device-side layout so that CPU tests can
 check the protocol over gloo without a GPU.
 """
+import os
+
 import numpy as np
 
 NUM_CUBE_MIP = 5
@@ -120,6 +122,7 @@ class LightMapExchange:
         self.caster, self.group = caster, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.stage = None
 
     @staticmethod
     def relit_volume(visible, frame_idx, V):
@@ -133,7 +136,16 @@ class LightMapExchange:
         if not len(visible) or (int(volume_info[v][2]) & 0x8000):
             return 0  # on the cube-map scheme (or nothing visible): only its owner's view march reads that light map
         ptr, n = self.caster.GetBuffer(1, v)  # MV_BUF_LIGHT_MAP (device layout); the context's stream waits for the light march
-        self.dist.broadcast(_device_view(ptr, n), src=v % self.world, group=self.group)
+        view = _device_view(ptr, n)
+        # the collective runs on a torch-owned staging tensor (context buffers are only copied from / to)
+        if self.stage is None or self.stage.numel() != n:
+            self.stage = self.torch.empty(n, dtype=self.torch.uint8, device="cuda")
+        owner = v % self.world
+        if self.rank == owner:
+            self.stage.copy_(view)
+        self.dist.broadcast(self.stage, src=owner, group=self.group)
+        if self.rank != owner:
+            view.copy_(self.stage)
         return n
 
 
@@ -150,7 +162,7 @@ def gather_composite_rows(caster, H, W, rank, world, group=None):
     row_bytes = W * 8
     r0, r1 = bands[rank]
     frame = _device_view(ptr, nbytes)  # aliases the context's buffer, no copy
-    if all(b[1] - b[0] == max_rows for b in bands) and dist.get_backend(group) == "nccl" and not _IN_PLACE_REFUSED:
+    if os.environ.get("MV_INPLACE_GATHER") == "1" and all(b[1] - b[0] == max_rows for b in bands) and dist.get_backend(group) == "nccl" and not _IN_PLACE_REFUSED:
         # equal bands: the frame buffer IS the all-gather output and this rank's band its input, in place (no staging copies);
         # NCCL / RCCL define that (sendbuff == recvbuff + rank * count) -- if this torch build objects to the overlap, stage instead
         try:
