@@ -60,8 +60,10 @@ extern "C" {
 #define MV_FLAG_FORCE_MIP0_ALL_FACES 1u	/* stress variant of SURVEY 8(d): cull forces mip 0, all 6 faces, cube-map scheme */
 #define MV_FLAG_PIPELINE_FRAMES 2u			/* frames in flight (the reference keeps FrameCount = 3, MultiRayCaster.h:52): constant upload + cull, the light march,
 										   and the view march + composite of even / odd frames run on internal streams with 4 slots of cull outputs,
-										   3 light buffers per volume and 2 output sets.  Results are identical; calls stay asynchronous and every
-										   readback / mv_get_stats / producer synchronises first. */
+										   3 light buffers per volume and 2 output sets.  Everything a frame WRITES is identical; cube-map texels a frame
+										   does not write (faces not marched that frame) hold what frame i - 2 left there instead of frame i - 1, which a
+										   CubeCast gather across a cube edge can touch.  Calls stay asynchronous; every readback / mv_get_stats /
+										   producer synchronises first. */
 #define MV_FLAG_SINGLE_VIEW_STREAM 4u		/* with MV_FLAG_PIPELINE_FRAMES: keep the view march, exchange and composite of EVERY frame on the context's
 										   stream (only upload, cull and light march run ahead on internal streams) -- for callers that order their own
 										   work, e.g. RCCL collectives, on that stream between mv_march_view and mv_composite */

@@ -417,7 +417,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	for (int p = 0; p < 2; ++p)
 	{
 		FrameBufs& f = ctx->fb[p];
-		if (p == 1 && !(cfg->flags & MV_FLAG_PIPELINE_FRAMES))
+		// (MV_FORCE_TWO_SETS: validation only -- a one-stream context that alternates output sets like a pipelined one, see scripts/soak.py)
+		if (p == 1 && !(cfg->flags & MV_FLAG_PIPELINE_FRAMES) && !getenv("MV_FORCE_TWO_SETS"))
 		{
 			const FrameBufs& g = ctx->fb[0];	// one frame in flight: both parities share the outputs
 			f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
