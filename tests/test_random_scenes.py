@@ -62,3 +62,31 @@ def test_random_scene(oracle, seed):
     assert st["composite_samples"] == exp_samples
     for k in ("rays", "view_samples", "lit_samples", "light_samples"):
         assert st[k] == ref["stats"][k], (k, cfg, kinds, eye)
+
+
+def test_sixty_four_volumes(oracle):
+    """V = 64 (eight cull workgroups + the ticket, an 8 x 8 grid of volumes): with a small viewport most volumes are on the
+    screen-space scheme, more than the 32 whose RayCast joins the view-march launch, so the composite's inline fallback runs
+    beside the pre-marched layers; everything against the oracle."""
+    cfg = dict(N=16, L=8, V=64, W=192, H=128, maxRay=24, maxLight=8, mesh=True)
+    vols = [rc.synth_volume(cfg["N"], k % 7) for k in range(cfg["V"])]
+    eye = (16.0, 64.0, -320.0)  # the default eye scaled by rowLength / 4 (MultiVolumes.cpp:264-279), pulled back a little
+    M = 64
+    ref = oracle_pipeline(oracle, cfg, vols, M, frames=8, eye=eye)
+    scr = [v for v in ref["vis"] if not (int(ref["info"][v, 2]) & 0x8000)]
+    assert len(ref["vis"]) >= 48 and len(scr) > 32, (len(ref["vis"]), len(scr))
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols, frames=8, eye=eye)
+        assert np.array_equal(c.ReadBackVolumeInfo()[ref["vis"]], ref["info"][ref["vis"]])
+        vis, cube = c.ReadBackVisibleLists()
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube, ref["cube"])
+        compare_light(oracle, c, ref, cfg, [v for v in ref["vis"] if ref["lightMaps"][v].any()], tol=0.0)
+        if len(ref["cube"]):
+            assert compare_cube(oracle, c, ref, cfg, tol=0.0)[1] == 0
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref)
+        c.composite()
+        got = c.ReadBackComposite()
+        gf, ef = got.view(np.float16), np.asarray(exp).view(np.float16)
+        assert np.array_equal(np.isnan(gf), np.isnan(ef))
+        assert np.array_equal(np.where(np.isnan(gf), 0, got), np.where(np.isnan(ef), 0, np.asarray(exp)))
+        assert c.GetStats()["composite_samples"] == exp_samples > 0
