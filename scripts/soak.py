@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from multivolumes_amd import MultiRayCaster, scene, _lib
 from multivolumes_amd import raycaster as rc
-cfg = dict(scene.CONFIGS["T2"], W=320, H=200)
+cfg = dict(scene.CONFIGS[os.environ.get("MV_SOAK_CONFIG", "T2")]) if os.environ.get("MV_SOAK_CONFIG") else dict(scene.CONFIGS["T2"], W=320, H=200)
 V, N = cfg["V"], cfg["N"]
 vols = [rc.synth_volume(N, k) for k in range(V)]
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
