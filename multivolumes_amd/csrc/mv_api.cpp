@@ -48,15 +48,21 @@ struct FrameBufs
 	float4* lightDirs = nullptr;
 	uint32_t* screenSlot = nullptr;
 	uint4** lightTable = nullptr;
-	// outputs of the view march / composite and their counters (distinct per parity only with MV_FLAG_PIPELINE_FRAMES, so that
-	// the view marches of two consecutive frames may overlap on the GPU)
+	uint16_t* tileCost = nullptr;
+	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per slot
+};
+
+// Outputs of the view march / composite and their counters: one set, or kMaxOutSets-or-fewer rotating sets with
+// MV_FLAG_PIPELINE_FRAMES (frame i uses set i % numOutSets and view stream i % numOutSets), so that the view marches of
+// consecutive frames may overlap on the GPU.
+constexpr uint32_t kMaxOutSets = 3;
+struct OutBufs
+{
 	uint2* cubeMaps = nullptr;
 	float* cubeDepths = nullptr;
 	uint2* composite = nullptr;
 	float4* screenLayers = nullptr;
 	uint64_t *tileStats = nullptr, *screenStats = nullptr, *compositeStats = nullptr, *tileSkipped = nullptr;
-	uint16_t* tileCost = nullptr;
-	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per slot
 };
 
 struct mv_ctx
@@ -65,7 +71,10 @@ struct mv_ctx
 	hipStream_t stream = nullptr;		// stream B: view march, composite, exchange, producers, readbacks
 	hipStream_t streamA = nullptr;		// stream A: constant upload, cull (== stream unless MV_FLAG_PIPELINE_FRAMES); may run frames ahead
 	hipStream_t streamL = nullptr;		// stream L: light march (== stream unless MV_FLAG_PIPELINE_FRAMES)
-	hipStream_t streamB[2] = {};		// view march + composite of even / odd frames ([0] == stream; [1] == stream unless pipelined)
+	hipStream_t streamB[kMaxOutSets] = {};	// view march + composite of frame i on streamB[i % numOutSets] ([0] == stream; the others == stream unless pipelined)
+	OutBufs ob[kMaxOutSets];
+	uint32_t numOutSets = 1, numViewStreams = 1;
+	uint32_t set = 0;
 	bool ownStream = false, ownStreamA = false, ownStreamB1 = false;
 	DeviceState st;						// always holds the CURRENT frame slot's pointers (applyParity)
 	FrameBufs fb[kFrameSlots];			// constants + cull outputs per slot; march / composite outputs per PARITY (slot & 1), aliased
@@ -155,8 +164,9 @@ void applyParity(mv_ctx* ctx)
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.lightDirs = f.lightDirs;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo;
-	st.cubeMaps = f.cubeMaps; st.cubeDepths = f.cubeDepths; st.composite = f.composite; st.screenLayers = f.screenLayers;
-	st.tileStats = f.tileStats; st.screenStats = f.screenStats; st.compositeStats = f.compositeStats; st.tileCost = f.tileCost; st.tileSkipped = f.tileSkipped;
+	const OutBufs& o = ctx->ob[ctx->set];
+	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers;
+	st.tileStats = o.tileStats; st.screenStats = o.screenStats; st.compositeStats = o.compositeStats; st.tileCost = f.tileCost; st.tileSkipped = o.tileSkipped;
 	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
 }
 
@@ -172,17 +182,18 @@ int syncAll(mv_ctx* ctx)
 		const hipError_t e = hipStreamSynchronize(ctx->streamL);
 		if (e != hipSuccess) return (int)e;
 	}
-	if (ctx->streamB[1] && ctx->streamB[1] != ctx->stream)
-	{
-		const hipError_t e = hipStreamSynchronize(ctx->streamB[1]);
-		if (e != hipSuccess) return (int)e;
-	}
+	for (uint32_t i = 1; i < kMaxOutSets; ++i)
+		if (ctx->streamB[i] && ctx->streamB[i] != ctx->stream)
+		{
+			const hipError_t e = hipStreamSynchronize(ctx->streamB[i]);
+			if (e != hipSuccess) return (int)e;
+		}
 	return (int)hipStreamSynchronize(ctx->stream);
 }
 
 // stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
 void stageADone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evStageA[ctx->slot], ctx->streamA); }
-hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->slot & 1u]; }
+hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->frame % ctx->numViewStreams]; }
 void stageBBegin(mv_ctx* ctx)
 {
 	(void)hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->slot], 0);
@@ -280,7 +291,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 
 	ctx->streamA = ctx->stream;
 	ctx->streamL = ctx->stream;
-	ctx->streamB[0] = ctx->streamB[1] = ctx->stream;
+	for (uint32_t i = 0; i < kMaxOutSets; ++i) ctx->streamB[i] = ctx->stream;
 	if (cfg->flags & MV_FLAG_PIPELINE_FRAMES)
 	{
 		// highest priority: stream A's short kernels (cull = one workgroup, light march) must not queue behind the
@@ -290,9 +301,12 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamA = true;
+		{ const char* e = getenv("MV_OUT_SETS"); ctx->numOutSets = e ? (uint32_t)atoi(e) : 2u; if (ctx->numOutSets < 2u || ctx->numOutSets > kMaxOutSets) ctx->numOutSets = 2u; }
 		if (!(cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM))
 		{
-			if (hipStreamCreateWithFlags(&ctx->streamB[1], hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
+			ctx->numViewStreams = ctx->numOutSets;
+			for (uint32_t i = 1; i < ctx->numViewStreams; ++i)
+				if (hipStreamCreateWithFlags(&ctx->streamB[i], hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
 			ctx->ownStreamB1 = true;
 		}
 	}
@@ -414,17 +428,11 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileCost, ((size_t)st.V * 6 * ((st.N + 7u) >> 3) * ((st.N + 7u) >> 3) + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
 	}
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
-	for (int p = 0; p < 2; ++p)
+	// (MV_FORCE_TWO_SETS: validation only -- a one-stream context that alternates output sets like a pipelined one, see scripts/soak.py)
+	if (!(cfg->flags & MV_FLAG_PIPELINE_FRAMES) && getenv("MV_FORCE_TWO_SETS")) ctx->numOutSets = 2;
+	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
 	{
-		FrameBufs& f = ctx->fb[p];
-		// (MV_FORCE_TWO_SETS: validation only -- a one-stream context that alternates output sets like a pipelined one, see scripts/soak.py)
-		if (p == 1 && !(cfg->flags & MV_FLAG_PIPELINE_FRAMES) && !getenv("MV_FORCE_TWO_SETS"))
-		{
-			const FrameBufs& g = ctx->fb[0];	// one frame in flight: both parities share the outputs
-			f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
-			f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileSkipped = g.tileSkipped;
-			break;
-		}
+		OutBufs& f = ctx->ob[p];
 		// cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-121), zero-initialised
 		if ((rc = devAlloc(ctx, &f.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
@@ -435,15 +443,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.tileSkipped, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	}
-	for (uint32_t p = 2; p < kFrameSlots; ++p)
-	{
-		FrameBufs& f = ctx->fb[p];
-		const FrameBufs& g = ctx->fb[p & 1u];	// outputs exist per parity
-		f.cubeMaps = g.cubeMaps; f.cubeDepths = g.cubeDepths; f.composite = g.composite; f.screenLayers = g.screenLayers;
-		f.tileStats = g.tileStats; f.screenStats = g.screenStats; f.compositeStats = g.compositeStats; f.tileSkipped = g.tileSkipped;
-	}
 	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
-	ctx->slot = 0;
+	ctx->slot = 0; ctx->set = 0;
 	applyParity(ctx);
 
 	// pinned upload ring + readback scratch
@@ -480,7 +481,7 @@ void mv_destroy(mv_ctx* ctx)
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
 	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
 	if (ctx->ownStreamA && ctx->streamL && ctx->streamL != ctx->stream) (void)hipStreamDestroy(ctx->streamL);
-	if (ctx->ownStreamB1 && ctx->streamB[1]) (void)hipStreamDestroy(ctx->streamB[1]);
+	for (uint32_t i = 1; i < kMaxOutSets; ++i) if (ctx->ownStreamB1 && ctx->streamB[i] && ctx->streamB[i] != ctx->stream) (void)hipStreamDestroy(ctx->streamB[i]);
 	for (EventPair& ev : ctx->freeEvents) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
 	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
 	for (void* p : ctx->allocs) (void)hipFree(p);
@@ -635,6 +636,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	// a new frame: the next slot of constants / cull buffers (and the other parity's march outputs)
 	ctx->slot = (ctx->slot + 1u) % kFrameSlots;
 	++ctx->frame;
+	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
 	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);
 	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
@@ -718,6 +720,8 @@ int mv_march_view(mv_ctx* ctx)
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
 	stageBBegin(ctx);
+	// the previous user of this output set is frame i - numOutSets; with SINGLE_VIEW_STREAM / one stream it is on this stream anyway
+	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (ctx->numOutSets % kFrameSlots)) % kFrameSlots], 0));
 	EventPair ev;
 	beginStage(ctx, 2, ev, streamB(ctx));
 	mv::launchMarchView(streamB(ctx), ctx->st, exactTileCount(ctx));
@@ -873,10 +877,10 @@ int mv_clear_cube_maps(mv_ctx* ctx)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	const size_t chain = mv::cubeChainTexels(ctx->st.N);
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	for (int p = 0; p < 2; ++p)
+	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
 	{
-		MV_HIP(ctx, hipMemsetAsync(ctx->fb[p].cubeMaps, 0, (size_t)ctx->st.V * chain * sizeof(uint2), ctx->stream));
-		MV_HIP(ctx, hipMemsetAsync(ctx->fb[p].cubeDepths, 0, (size_t)ctx->st.V * chain * sizeof(float), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(ctx->ob[p].cubeMaps, 0, (size_t)ctx->st.V * chain * sizeof(uint2), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(ctx->ob[p].cubeDepths, 0, (size_t)ctx->st.V * chain * sizeof(float), ctx->stream));
 	}
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
@@ -888,10 +892,11 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
 	mv::launchReduceStats(ctx->stream, ctx->st, 1);
-	if (ctx->fb[0].tileStats != ctx->fb[1].tileStats)
+	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
 	{
+		if (p == ctx->set) continue;
 		DeviceState other = ctx->st;
-		const FrameBufs& q = ctx->fb[(ctx->slot & 1u) ^ 1u];
+		const OutBufs& q = ctx->ob[p];
 		other.tileStats = q.tileStats; other.screenStats = q.screenStats; other.compositeStats = q.compositeStats; other.tileSkipped = q.tileSkipped;
 		mv::launchReduceStats(ctx->stream, other, 0);
 	}
@@ -921,9 +926,9 @@ int mv_reset_stats(mv_ctx* ctx)
 	foldEvents(ctx);
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.stats, 0, kNumStats * sizeof(uint64_t), ctx->stream));
 	MV_HIP(ctx, hipMemsetAsync(ctx->st.lightStats, 0, (size_t)ctx->st.lightBlocks * sizeof(uint64_t), ctx->stream));
-	for (int p = 0; p < 2; ++p)
+	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
 	{
-		const FrameBufs& f = ctx->fb[p];
+		const OutBufs& f = ctx->ob[p];
 		MV_HIP(ctx, hipMemsetAsync(f.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
 		MV_HIP(ctx, hipMemsetAsync(f.tileSkipped, 0, ((size_t)ctx->st.maxTiles + ctx->st.maxScreenTiles + 1) * sizeof(uint64_t), ctx->stream));
 		MV_HIP(ctx, hipMemsetAsync(f.compositeStats, 0, (size_t)ctx->st.compositeSlots * sizeof(uint64_t), ctx->stream));
