@@ -45,6 +45,7 @@ extern "C" {
 #define MV_PER_OBJECT_BYTES 224		/* MultiRayCaster.cpp:35-41 */
 #define MV_CB_PER_FRAME_BYTES 212	/* MultiRayCaster.cpp:23-33 */
 #define MV_CUBEMAP_RAYMARCH_BIT 0x8000u	/* Common.hlsli:11 */
+#define MV_MAX_VOLUMES 1024u		/* mv_config.num_volumes limit (the reference's scenes use 2..64, Bin/all64.bat); volume sources: 16383 (VolTexId:14) */
 
 /* error codes */
 #define MV_OK 0

@@ -128,33 +128,50 @@ ABI = {
 _lib = None
 
 
-def build(force=False):
-    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950)."""
-    if force or not os.path.exists(LIB_PATH) or _stale():
-        subprocess.run(["bash", BUILD_SCRIPT], check=True)
-    return LIB_PATH
+def _source_hash():
+    """Content hash of everything the library is built from (mtimes do not survive the copy to the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(_HERE, "csrc")
+    inc = os.path.join(os.path.dirname(_HERE), "include")
+    for d in (src, inc):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".cpp", ".hpp", ".h", ".sh")):
+                h.update(f.encode())
+                with open(os.path.join(d, f), "rb") as fh:
+                    h.update(fh.read())
+    return h.hexdigest()
+
+
+HASH_PATH = LIB_PATH + ".srchash"
 
 
 def _stale():
+    """True when the shared object was not built from the sources that are in the tree now."""
     try:
-        t = os.path.getmtime(LIB_PATH)
-        src = os.path.join(_HERE, "csrc")
-        inc = os.path.join(os.path.dirname(_HERE), "include")
-        for d in (src, inc):
-            for f in os.listdir(d):
-                if f.endswith((".hip", ".cpp", ".hpp", ".h")) and os.path.getmtime(os.path.join(d, f)) > t:
-                    return True
+        with open(HASH_PATH) as fh:
+            return fh.read().strip() != _source_hash()
     except OSError:
         return True
-    return False
+
+
+def build(force=False):
+    """Compile the HIP extension in-tree (hipcc --offload-arch=gfx950).  One builder at a time (ranks / xdist workers share the tree)."""
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or not os.path.exists(LIB_PATH) or _stale():
+            subprocess.run(["bash", BUILD_SCRIPT], check=True)  # writes HASH_PATH itself
+    return LIB_PATH
 
 
 def load():
-    """Load the shared library and set ctypes signatures; raises if it cannot be found or built."""
+    """Load the shared library and set ctypes signatures; rebuilds it first if it is missing or older than its sources,
+    raises if that fails (there is no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or _stale():
         build()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in ABI.items():

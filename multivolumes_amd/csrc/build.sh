@@ -1,15 +1,35 @@
 #!/bin/bash
-# Builds libmultivolumes_amd.so (gfx950 only) in-tree.  Usage: build.sh [extra hipcc flags]
+# Builds libmultivolumes_amd.so (gfx950 only) in-tree.  Usage: build.sh [extra hipcc flags, e.g. -DMV_DIAGNOSTICS]
+# Objects go to a directory of their own per flag set (obj/<hash of the flags>), are rebuilt from scratch on every call, and
+# every compile job's exit status is checked: a translation unit that fails can never be replaced by a stale object.
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
-OUT=../libmultivolumes_amd.so
-$HIPCC $FLAGS -c mv_kernels.hip -o mv_kernels.o "$@" &
-$HIPCC $FLAGS -c mv_composite.hip -o mv_composite.o "$@" &
-$HIPCC $FLAGS -c mv_mesh.hip -o mv_mesh.o "$@" &
-$HIPCC $FLAGS -c mv_api.cpp -o mv_api.o "$@" &
-g++ -O2 -std=c++17 -fPIC -Wall -c mv_host.cpp -o mv_host.o &
-wait
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o $OUT mv_kernels.o mv_composite.o mv_mesh.o mv_api.o mv_host.o -lpthread
+OUT=${MV_OUT:-../libmultivolumes_amd.so}
+TAG=$(printf '%s' "$FLAGS $*" | md5sum | cut -c1-12)
+OBJ=obj/$TAG
+rm -rf "$OBJ"
+mkdir -p "$OBJ"
+pids=()
+$HIPCC $FLAGS -c mv_kernels.hip -o $OBJ/mv_kernels.o "$@" & pids+=($!)
+$HIPCC $FLAGS -c mv_composite.hip -o $OBJ/mv_composite.o "$@" & pids+=($!)
+$HIPCC $FLAGS -c mv_mesh.hip -o $OBJ/mv_mesh.o "$@" & pids+=($!)
+$HIPCC $FLAGS -c mv_api.cpp -o $OBJ/mv_api.o "$@" & pids+=($!)
+g++ -O2 -std=c++17 -fPIC -Wall -c mv_host.cpp -o $OBJ/mv_host.o & pids+=($!)
+rc=0
+for p in "${pids[@]}"; do wait "$p" || rc=1; done
+if [ $rc -ne 0 ]; then echo "build.sh: a compile job failed" >&2; rm -rf "$OBJ"; exit 1; fi
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT.tmp" $OBJ/mv_kernels.o $OBJ/mv_composite.o $OBJ/mv_mesh.o $OBJ/mv_api.o $OBJ/mv_host.o -lpthread
+mv -f "$OUT.tmp" "$OUT"
+# content hash of the sources this library was built from (multivolumes_amd/_lib.py::_source_hash computes the same):
+# the loader rebuilds when the tree no longer matches it
+srchash() {
+	for d in . ../../include; do
+		for f in $(cd "$d" && LC_ALL=C ls | grep -E '\.(hip|cpp|hpp|h|sh)$'); do printf '%s' "$f"; cat "$d/$f"; done
+	done | sha256sum | cut -d' ' -f1
+}
+srchash > "$OUT.srchash"
+rm -rf "$OBJ"
+rmdir obj 2>/dev/null || true
 echo "built $(realpath $OUT)"

@@ -90,7 +90,7 @@ struct mv_ctx
 	std::vector<uint64_t*> occupancy;	// brick occupancy words per volume source
 	uint64_t** dOccPtrs = nullptr;
 	uint32_t* lightStaging = nullptr;	// L^3 plain R11G11B10F (readback / upload conversion)
-	bool orderTiles = true;				// MV_TILE_ORDER=0 in the environment: list-order dispatch (A/B measurements)
+	bool orderTiles = true;				// (-DMV_DIAGNOSTICS builds: MV_TILE_ORDER=0 in the environment selects list-order dispatch)
 	// mesh depth / shadow producer (mv_mesh_*)
 	float* meshPositions = nullptr;
 	uint32_t* meshIndices = nullptr;
@@ -192,29 +192,33 @@ int syncAll(mv_ctx* ctx)
 }
 
 // stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
-void stageADone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evStageA[ctx->slot], ctx->streamA); }
+// (every one of these orders streams against each other: a failure must reach the caller, or a later stage reads unfinished data)
+hipError_t stageADone(mv_ctx* ctx) { return hipEventRecord(ctx->evStageA[ctx->slot], ctx->streamA); }
 hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->frame % ctx->numViewStreams]; }
-void stageBBegin(mv_ctx* ctx)
+hipError_t stageBBegin(mv_ctx* ctx)
 {
-	(void)hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->slot], 0);
-	(void)hipStreamWaitEvent(streamB(ctx), ctx->evLight[ctx->slot], 0);	// this frame's light march, if one has been enqueued
+	const hipError_t e = hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->slot], 0);
+	if (e != hipSuccess) return e;
+	return hipStreamWaitEvent(streamB(ctx), ctx->evLight[ctx->slot], 0);	// this frame's light march, if one has been enqueued
 }
 // stage of stream B finished being enqueued: the next user of this slot's buffers (kFrameSlots frames on) and the light march two frames on wait for it
-void stageBDone(mv_ctx* ctx) { (void)hipEventRecord(ctx->evMainDone[ctx->slot], streamB(ctx)); }
+hipError_t stageBDone(mv_ctx* ctx) { return hipEventRecord(ctx->evMainDone[ctx->slot], streamB(ctx)); }
 
 void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
 {
 	if (!ctx->profiling) return;
+	// timing events only (never used for ordering): a failure here loses one timing sample, nothing else
+	ev.a = ev.b = nullptr;
 	if (!ctx->freeEvents.empty()) { ev = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); }
-	else { (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b); }
+	else if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { ev.a = ev.b = nullptr; return; }
 	ev.stage = stage;
-	(void)hipEventRecord(ev.a, stream);
+	if (hipEventRecord(ev.a, stream) != hipSuccess) { ctx->freeEvents.push_back(ev); ev.a = ev.b = nullptr; }
 }
 
 void endStage(mv_ctx* ctx, EventPair& ev, hipStream_t stream)
 {
-	if (!ctx->profiling) return;
-	(void)hipEventRecord(ev.b, stream);
+	if (!ctx->profiling || !ev.a) return;
+	if (hipEventRecord(ev.b, stream) != hipSuccess) { ctx->freeEvents.push_back(ev); return; }
 	ctx->pending.push_back(ev);
 }
 
@@ -262,7 +266,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 {
 	if (!cfg || !out || cfg->struct_size != sizeof(mv_config)) return MV_ERR_INVALID_ARG;
 	*out = nullptr;
-	if (cfg->grid_size < 2 || cfg->grid_size > 640 /* bricked alpha cells (16 B/texel) must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->light_grid_size > 640 /* 32-bit offsets into the 16 B/texel light quads */ || cfg->num_volumes < 1 || cfg->num_volumes > 16383 ||
+	if (cfg->grid_size < 2 || cfg->grid_size > 640 /* bricked alpha cells (16 B/texel) must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->light_grid_size > 640 /* 32-bit offsets into the 16 B/texel light quads */ || cfg->num_volumes < 1 || cfg->num_volumes > MV_MAX_VOLUMES /* the cull and the tile order keep per-volume tables in LDS (12 V and 48 V + 132 bytes of the 64 KiB a launch gets by default) */ ||
 		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
 		return MV_ERR_INVALID_ARG;
 	if (cfg->shard_count > 1 && cfg->shard_index >= cfg->shard_count) return MV_ERR_INVALID_ARG;
@@ -301,7 +305,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamA = true;
-		{ const char* e = getenv("MV_OUT_SETS"); ctx->numOutSets = e ? (uint32_t)atoi(e) : 2u; if (ctx->numOutSets < 2u || ctx->numOutSets > kMaxOutSets) ctx->numOutSets = 2u; }
+		ctx->numOutSets = 2u;
+#ifdef MV_DIAGNOSTICS	// A/B measurements only (csrc/build.sh -DMV_DIAGNOSTICS); the shipped library reads no environment variable
+		{ const char* e = getenv("MV_OUT_SETS"); if (e) ctx->numOutSets = (uint32_t)atoi(e); if (ctx->numOutSets < 2u || ctx->numOutSets > kMaxOutSets) ctx->numOutSets = 2u; }
+#endif
 		if (!(cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM))
 		{
 			ctx->numViewStreams = ctx->numOutSets;
@@ -377,8 +384,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	}
 	// Screen-space-scheme volumes are marched inside the view-march launch (up to kMaxScreenSlots of them), by every shard for ITS rows
 	{
-		const char* e = getenv("MV_SCREEN_SLOTS");	// A/B measurements only
-		const uint32_t cap = e ? (uint32_t)atoi(e) : kMaxScreenSlots;
+		uint32_t cap = kMaxScreenSlots;
+#ifdef MV_DIAGNOSTICS
+		{ const char* e = getenv("MV_SCREEN_SLOTS"); if (e) cap = (uint32_t)atoi(e); }
+#endif
 		st.screenSlots = st.V < cap ? st.V : cap;
 	}
 	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.bandRow1 - st.bandRow0 + 7u) >> 3);
@@ -419,7 +428,9 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.maxTiles = mv::marchViewMaxTiles(st.V, st.N, st.shardCount);
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
 	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
+#ifdef MV_DIAGNOSTICS
 	{ const char* e = getenv("MV_TILE_ORDER"); ctx->orderTiles = !(e && e[0] == '0'); }
+#endif
 	for (uint32_t p = 0; p < kFrameSlots; ++p)
 	{
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
@@ -429,7 +440,9 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	}
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	// (MV_FORCE_TWO_SETS: validation only -- a one-stream context that alternates output sets like a pipelined one, see scripts/soak.py)
+#ifdef MV_DIAGNOSTICS
 	if (!(cfg->flags & MV_FLAG_PIPELINE_FRAMES) && getenv("MV_FORCE_TWO_SETS")) ctx->numOutSets = 2;
+#endif
 	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
 	{
 		OutBufs& f = ctx->ob[p];
@@ -500,6 +513,7 @@ int mv_volume_upload_rgba16f(mv_ctx* ctx, uint32_t src, const uint16_t* rgba)
 {
 	if (!ctx || !rgba) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight on the internal streams may still read this volume and the staging buffer
 	MV_HIP(ctx, hipMemcpyAsync(ctx->staging, rgba, ctx->stagingBytes, hipMemcpyHostToDevice, ctx->stream));
 	mv::launchRetile(ctx->stream, ctx->staging, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
@@ -513,6 +527,7 @@ int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgb
 {
 	if (!ctx || !d_rgba) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may still read this volume
 	mv::launchRetile(ctx->stream, reinterpret_cast<const uint2*>(d_rgba), ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
@@ -526,6 +541,7 @@ int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may still read this volume
 	mv::launchInitGridData(ctx->stream, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
@@ -541,6 +557,7 @@ int mv_volume_load_r32f(mv_ctx* ctx, uint32_t src, const float* a, uint32_t w, u
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	float* dSrc = nullptr;
 	const size_t bytes = (size_t)w * h * d * sizeof(float);
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may still read this volume
 	MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&dSrc), bytes));
 	hipError_t e = hipMemcpyAsync(dSrc, a, bytes, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess)
@@ -567,6 +584,7 @@ int mv_set_volume_descs(mv_ctx* ctx, const uint32_t* packed)
 		const uint32_t mips = (packed[i] >> 14) & 0xfu;
 		MV_REQUIRE(ctx, mips >= 1 && mips <= MV_NUM_CUBE_MIP, MV_ERR_INVALID_ARG, "VolumeDesc.NumMips must be 1..5");
 	}
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the cull / marches of frames in flight read VolumeDesc[V]
 	MV_HIP(ctx, hipMemcpyAsync(ctx->dDescs, packed, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
@@ -575,6 +593,10 @@ int mv_set_volume_descs(mv_ctx* ctx, const uint32_t* packed)
 int mv_set_depth_map(mv_ctx* ctx, const float* d32)
 {
 	if (!ctx || !d32) return MV_ERR_INVALID_ARG;
+	// Frames in flight (view march / composite on the internal streams) still read the depth map: wait for them BEFORE the
+	// copy overwrites it.  Callers that change the depth every frame and want to keep frames in flight hand over a device
+	// pointer per frame instead (mv_set_depth_map_device: borrowed, never written by the context).
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	MV_HIP(ctx, hipMemcpyAsync(ctx->ownDepth, d32, (size_t)ctx->st.W * ctx->st.H * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	ctx->st.depthMap = ctx->ownDepth;
@@ -585,6 +607,7 @@ int mv_set_depth_map(mv_ctx* ctx, const float* d32)
 int mv_set_shadow_map(mv_ctx* ctx, const uint16_t* d16)
 {
 	if (!ctx || !d16) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the light march of a frame in flight may still read the shadow map
 	MV_HIP(ctx, hipMemcpyAsync(ctx->ownShadow, d16, (size_t)ctx->st.M * ctx->st.M * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	ctx->st.shadowMap = ctx->ownShadow;
@@ -613,6 +636,7 @@ int mv_set_sh(mv_ctx* ctx, const float* sh27)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	if (sh27)
 	{
+		MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the light march of a frame in flight may still read the coefficients
 		MV_HIP(ctx, hipMemcpyAsync(ctx->dSh, sh27, 27 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
 		MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	}
@@ -651,7 +675,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
 	MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));
 	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->streamA));
-	stageADone(ctx);
+	MV_HIP(ctx, stageADone(ctx));
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
 	return MV_OK;
@@ -661,19 +685,19 @@ int mv_cull(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveFrame, MV_ERR_NOT_READY, "mv_update_frame has not been called");
-	EventPair ev;
+	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 0, ev, ctx->streamA);
 	mv::launchCull(ctx->streamA, ctx->st);
 	endStage(ctx, ev, ctx->streamA);
 	MV_HIP(ctx, hipGetLastError());
-	stageADone(ctx);
+	MV_HIP(ctx, stageADone(ctx));
 	if (ctx->orderTiles)
 	{
 		// Dispatch order of this frame's view march, right behind the cull on stream A (which runs frames ahead), from the cost
 		// table the view march of the slot's previous user wrote (mv_update_frame already made stream A wait for that frame).
 		mv::launchTileOrder(ctx->streamA, ctx->st, ctx->fb[ctx->slot].binCounts, ctx->fb[ctx->slot].tileOrder);
 		MV_HIP(ctx, hipGetLastError());
-		stageADone(ctx);
+		MV_HIP(ctx, stageADone(ctx));
 	}
 	ctx->haveCull = true;
 	return MV_OK;
@@ -689,7 +713,7 @@ int mv_march_light(mv_ctx* ctx)
 	static_assert(mv::kLightBuffers == 3 && kFrameSlots == 4, "the wait below names frame i - 3");
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamL, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamL, ctx->evStageA[ctx->slot], 0));	// this frame's upload + cull
-	EventPair ev;
+	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 1, ev, ctx->streamL);
 	mv::launchMarchLight(ctx->streamL, ctx->st);
 	endStage(ctx, ev, ctx->streamL);
@@ -719,15 +743,15 @@ int mv_march_view(mv_ctx* ctx)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
-	stageBBegin(ctx);
+	MV_HIP(ctx, stageBBegin(ctx));
 	// the previous user of this output set is frame i - numOutSets; with SINGLE_VIEW_STREAM / one stream it is on this stream anyway
 	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (ctx->numOutSets % kFrameSlots)) % kFrameSlots], 0));
-	EventPair ev;
+	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 2, ev, streamB(ctx));
 	mv::launchMarchView(streamB(ctx), ctx->st, exactTileCount(ctx));
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
-	stageBDone(ctx);
+	MV_HIP(ctx, stageBDone(ctx));
 	return MV_OK;
 }
 
@@ -738,13 +762,13 @@ int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
 	if (row1 == 0 || row1 > ctx->st.H) row1 = ctx->st.H;
 	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
-	stageBBegin(ctx);
-	EventPair ev;
+	MV_HIP(ctx, stageBBegin(ctx));
+	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 3, ev, streamB(ctx));
 	mv::launchComposite(streamB(ctx), ctx->st, row0, row1);
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
-	stageBDone(ctx);
+	MV_HIP(ctx, stageBDone(ctx));
 	return MV_OK;
 }
 
@@ -830,6 +854,7 @@ int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src)
 	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
 	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
 	uint4* buf = nullptr;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may read this buffer (and the shared staging buffer)
 	const int rc = currentLightBuffer(ctx, volume, &buf);
 	if (rc != MV_OK) return rc;
 	MV_HIP(ctx, hipMemcpyAsync(ctx->lightStaging, src, L3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1074,7 +1099,7 @@ int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size
 {
 	if (!ctx || !slot_dim || !slot_bytes || !shard_bytes) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
-	stageBBegin(ctx);
+	MV_HIP(ctx, stageBBegin(ctx));
 	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedCounters, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	const uint32_t minMip = ctx->pinnedCounters[5] < MV_NUM_CUBE_MIP ? ctx->pinnedCounters[5] : 0u;

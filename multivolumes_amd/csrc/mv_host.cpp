@@ -518,12 +518,23 @@ int mvh_load_dds_volume(const char* path, float** texels, uint32_t* width, uint3
 	else if ((pfFlags & 0x40u /* DDPF_RGB */) && rgbBits == 32 && rMask == 0xffu) ok = dxgi(28);	// A8B8G8R8: red is byte 0
 	if (!isVolume || w == 0 || h == 0 || d == 0) { fclose(f); return -2; }
 	if (!ok) { fclose(f); return -3; }
-	const size_t n = (size_t)w * h * d;
-	std::vector<uint8_t> raw(n * stride);
-	if (fread(raw.data(), 1, raw.size(), f) != raw.size()) { fclose(f); return -4; }
-	fclose(f);
+	// The header is untrusted input: bound every extent (D3D12 caps 3D textures at 2048 per axis), so that w*h*d*stride
+	// cannot wrap, and check the payload against what the file really holds before allocating anything.
+	if (w > 2048u || h > 2048u || d > 2048u) { fclose(f); return -2; }
+	const size_t n = (size_t)w * h * d;	// <= 2^33
+	const size_t rawBytes = n * stride;	// <= 2^37
+	{
+		const long here = ftell(f);
+		if (here < 0 || fseek(f, 0, SEEK_END) != 0) { fclose(f); return -4; }
+		const long end = ftell(f);
+		if (end < 0 || (size_t)(end - here) < rawBytes || fseek(f, here, SEEK_SET) != 0) { fclose(f); return -4; }	// truncated file
+	}
+	uint8_t* rawBuf = static_cast<uint8_t*>(malloc(rawBytes ? rawBytes : 1));	// no exception may cross the extern "C" boundary
 	float* out = static_cast<float*>(malloc(n * sizeof(float)));
-	if (!out) return -1;
+	if (!rawBuf || !out) { free(rawBuf); free(out); fclose(f); return -1; }
+	if (fread(rawBuf, 1, rawBytes, f) != rawBytes) { free(rawBuf); free(out); fclose(f); return -4; }
+	fclose(f);
+	struct RawHolder { uint8_t* p; ~RawHolder() { free(p); } uint8_t* data() const { return p; } } raw = { rawBuf };
 	for (size_t i = 0; i < n; ++i)
 	{
 		const uint8_t* p = raw.data() + i * stride;

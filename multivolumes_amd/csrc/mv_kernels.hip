@@ -1278,14 +1278,15 @@ void launchMarchView(hipStream_t s, const DeviceState& st, uint32_t exactTiles)
 	const uint64_t tiles = exactTiles < maxTiles ? (exactTiles ? exactTiles : 1u) : maxTiles;
 	uint64_t blocks = (tiles + kMarchWaves - 1) / kMarchWaves;
 	blocks = ((blocks + 7) / 8) * 8;
+	const dim3 grid((uint32_t)blocks), block(64 * kMarchWaves);
+#ifdef MV_DIAGNOSTICS	// timing-only variants (wrong results by construction) exist in diagnostic builds only
 	static const int experiment = []() { const char* e = getenv("MV_EXPERIMENT"); return e ? atoi(e) : 0; }();
 	static const uint32_t mapMode = []() { const char* e = getenv("MV_TILE_MAP"); return e ? (uint32_t)atoi(e) : 0u; }();
-	const dim3 grid((uint32_t)blocks), block(64 * kMarchWaves);
-	switch (experiment)
-	{
-	case 1: hipLaunchKernelGGL(marchViewKernel<1>, grid, block, 0, s, st, mapMode); break;
-	case 2: hipLaunchKernelGGL(marchViewKernel<2>, grid, block, 0, s, st, mapMode); break;
-	default: hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st, mapMode); break;
-	}
+	if (experiment == 1) { hipLaunchKernelGGL(marchViewKernel<1>, grid, block, 0, s, st, mapMode); return; }
+	if (experiment == 2) { hipLaunchKernelGGL(marchViewKernel<2>, grid, block, 0, s, st, mapMode); return; }
+	hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st, mapMode);
+#else
+	hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st, 0u);
+#endif
 }
 } // namespace mv
