@@ -118,6 +118,7 @@ struct mv_ctx
 	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
 
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
+	bool lightMarched = false, lightTableKept = false;	// this frame: mv_march_light ran / the frame keeps the previous frame's light table (see keepLightTable)
 	bool profiling = false;
 	std::vector<EventPair> pending;
 	std::vector<EventPair> freeEvents;
@@ -654,6 +655,21 @@ int mv_set_max_samples(mv_ctx* ctx, uint32_t maxRaySamples, uint32_t maxLightSam
 	return MV_OK;
 }
 
+// The cull rotates the light-table entry of the volume this frame relights to that volume's next buffer, expecting the
+// frame's light march to fill it.  A caller may leave mv_march_light out of a frame (the reference then simply keeps its light
+// maps): the first stage of such a frame that reads light maps puts the previous frame's table back, so the frame -- and the
+// frames after it, which derive their table from this one -- read the maps that were last written.
+static int keepLightTable(mv_ctx* ctx)
+{
+	if (ctx->lightMarched || ctx->lightTableKept) return MV_OK;
+	const FrameBufs& f = ctx->fb[ctx->slot];
+	const FrameBufs& q = ctx->fb[(ctx->slot + kFrameSlots - 1u) % kFrameSlots];
+	MV_HIP(ctx, hipMemcpyAsync(f.lightTable, q.lightTable, (size_t)ctx->st.V * sizeof(uint4*), hipMemcpyDeviceToDevice, ctx->streamA));
+	MV_HIP(ctx, stageADone(ctx));
+	ctx->lightTableKept = true;
+	return MV_OK;
+}
+
 int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 {
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
@@ -678,6 +694,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	MV_HIP(ctx, stageADone(ctx));
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
+	ctx->lightMarched = false; ctx->lightTableKept = false;
 	return MV_OK;
 }
 
@@ -708,6 +725,7 @@ int mv_march_light(mv_ctx* ctx)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
+	MV_REQUIRE(ctx, !ctx->lightTableKept, MV_ERR_NOT_READY, "mv_march_light must come before the frame's mv_march_view / mv_composite");
 	// The light buffer this launch writes was last read by a frame at least kLightBuffers (3) frames back (the relit volume's
 	// table entry has rotated since): that frame's view march / composite must be over.  Older ones are, by stream order.
 	static_assert(mv::kLightBuffers == 3 && kFrameSlots == 4, "the wait below names frame i - 3");
@@ -719,6 +737,7 @@ int mv_march_light(mv_ctx* ctx)
 	endStage(ctx, ev, ctx->streamL);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], ctx->streamL));
+	ctx->lightMarched = true;
 	return MV_OK;
 }
 
@@ -743,6 +762,7 @@ int mv_march_view(mv_ctx* ctx)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
+	{ const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, stageBBegin(ctx));
 	// the previous user of this output set is frame i - numOutSets; with SINGLE_VIEW_STREAM / one stream it is on this stream anyway
 	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (ctx->numOutSets % kFrameSlots)) % kFrameSlots], 0));
@@ -762,6 +782,7 @@ int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
 	if (row1 == 0 || row1 > ctx->st.H) row1 = ctx->st.H;
 	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
+	{ const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, stageBBegin(ctx));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 3, ev, streamB(ctx));

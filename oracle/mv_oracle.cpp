@@ -216,10 +216,25 @@ inline float3 unpack_r11g11b10f(uint32_t p)
 // ---------------------------------------------------------------------------------------------
 struct Taps { int32_t i0, i1; float f; };
 
+// Optional modes (mvo_set_options; both off by default and off in every parity run):
+//  * g_weightBits = b > 0: the scaled texel coordinate is snapped to b fractional bits (round to nearest) before the taps
+//    and the filter weight are taken from it -- what the D3D11.3 functional spec allows a fixed-function sampler to do
+//    ("at least 8 bits of fraction").  The reference's GPU may therefore differ from the exact-fp32 weights used here by up
+//    to this mode's deviation; tests/test_oracle_kat.py and scripts/weight_bits_deviation.py report it.
+//  * g_libRayMarch: the view march as the work-graph variant states it (LibRayMarch.hlsl:205-287): tMax = GetTMax only, no
+//    ComputeTargetHit clamp (CSRayMarch.hlsl:102-106 has it).
+int g_weightBits = 0;
+bool g_libRayMarch = false;
+
 inline Taps linearTaps(float coord01, uint32_t size, int32_t off)
 {
 	// LINEAR + CLAMP: c = u * size - 0.5 ; taps floor(c) and floor(c) + 1 clamped to [0, size-1]
-	const float c = coord01 * (float)size - 0.5f;
+	float c = coord01 * (float)size - 0.5f;
+	if (g_weightBits > 0)
+	{
+		const float q = (float)(1u << g_weightBits);
+		c = nearbyintf(c * q) / q;
+	}
 	const float fl = floorf(c);
 	Taps t;
 	t.f = c - fl;
@@ -941,7 +956,7 @@ void mvo_march_view(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
 					const float3 rayDir = normalize3(target - rayOrigin);
 					if (!ComputeRayOrigin(rayOrigin, rayDir)) continue;	// :96
 
-					float tMax = ComputeTargetHit(rayOrigin, target, rayDir);
+					float tMax = g_libRayMarch ? kFltMax : ComputeTargetHit(rayOrigin, target, rayDir);	// CSRayMarch.hlsl:102; absent from LibRayMarch.hlsl:222-232
 					const size_t texel = ((size_t)faceId * dims + (size_t)ty) * dims + tx;
 
 					// GetClipPos (:59-71)
@@ -1092,6 +1107,31 @@ float4 CubeCast(const uint16_t* cubeMap, const float* cubeDepth, int32_t d, floa
 
 struct Fragment { uint32_t zbits; uint32_t volume; float3 lpt; };
 } // namespace
+
+extern "C" {
+float mvo_unproject_z(float depth) { return UnprojectZ(depth); }
+
+// CubeCast on one cube map / cube depth of edge d (layout uint16[6][d][d][4] / float[6][d][d]) for the KATs
+void mvo_cube_cast(const uint16_t* cubeMap, const float* cubeDepth, uint32_t d, float depthPix, const float pos[3], const float rayDir[3], float out[4])
+{
+	const float4 r = CubeCast(cubeMap, cubeDepth, (int32_t)d, depthPix, f3(pos[0], pos[1], pos[2]), f3(rayDir[0], rayDir[1], rayDir[2]));
+	out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+// face / (s, t) of a direction and the texel a Gather tap (possibly outside the face) resolves to
+void mvo_cube_face_coords(const float dir[3], uint32_t* face, float st[2])
+{
+	const CubeCoord c = cubeFaceCoords(f3(dir[0], dir[1], dir[2]));
+	*face = c.face; st[0] = c.s; st[1] = c.t;
+}
+uint64_t mvo_cube_texel_index(uint32_t face, int32_t i, int32_t j, uint32_t d) { return cubeTexelIndex(face, i, j, (int32_t)d); }
+
+void mvo_set_options(int weightBits, int libRayMarch)
+{
+	g_weightBits = weightBits < 0 ? 0 : (weightBits > 23 ? 23 : weightBits);
+	g_libRayMarch = libRayMarch != 0;
+}
+}
 
 extern "C" void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
 	const uint16_t* const* volumes, const uint32_t* lightMaps, const float* depthMap, const void* perObjectBytes, const void* cbBytes,

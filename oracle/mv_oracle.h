@@ -106,6 +106,16 @@ void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
 	uint16_t* outRGBA /* W x H x 4 halfs, rows outside [y0,y1) untouched */, mvo_stats* stats);
 
 /* number of OpenMP threads the march functions will use (1 if built without OpenMP) */
+/* composite building blocks, exported for the known-answer tests */
+float mvo_unproject_z(float depth);                                                /* Sh/PSCube.hlsli:21-26 */
+void  mvo_cube_cast(const uint16_t* cubeMap, const float* cubeDepth, uint32_t d, float depthPix,
+	const float pos[3], const float rayDir[3], float out[4]);                       /* Sh/PSCube.hlsli:31-108 */
+void  mvo_cube_face_coords(const float dir[3], uint32_t* face, float st[2]);       /* D3D TextureCube face selection */
+uint64_t mvo_cube_texel_index(uint32_t face, int32_t i, int32_t j, uint32_t d);    /* Gather tap -> texel, across face edges */
+/* optional modes, off by default: filter weights snapped to `weightBits` fractional bits (0 = exact fp32); the view march as
+ * Sh/LibRayMarch.hlsl:205-287 states it (no ComputeTargetHit clamp) */
+void  mvo_set_options(int weightBits, int libRayMarch);
+
 int mvo_num_threads(void);
 void mvo_set_num_threads(int n);
 

@@ -19,7 +19,7 @@ class mvo_stats(C.Structure):
 
 
 def build(force=False):
-    src = [os.path.join(_HERE, f) for f in ("mv_oracle.cpp", "mv_oracle.h", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("mv_oracle.cpp", "mv_oracle_mesh.cpp", "mv_oracle.h", "Makefile")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src):
         subprocess.run(["make", "-C", _HERE, "-B", "libmv_oracle.so"], check=True, stdout=subprocess.DEVNULL)
     return LIB_PATH
@@ -50,6 +50,9 @@ def load():
         "mvo_march_light": (_U32, [_U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _U32, _P, _P]),
         "mvo_march_view": (None, [_U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P]),
         "mvo_num_threads": (C.c_int, []), "mvo_set_num_threads": (None, [C.c_int]),
+        "mvo_unproject_z": (_F, [_F]), "mvo_cube_cast": (None, [_P, _P, _U32, _F, _P, _P, _P]),
+        "mvo_cube_face_coords": (None, [_P, C.POINTER(_U32), _P]), "mvo_cube_texel_index": (C.c_uint64, [_U32, C.c_int32, C.c_int32, _U32]),
+        "mvo_set_options": (None, [C.c_int, C.c_int]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

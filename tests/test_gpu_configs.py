@@ -1,0 +1,266 @@
+"""BASELINE.json configs at their FULL sizes on the GPU box: C5 (64 x 256^3, 2048^2, 256 steps/ray -- Bin/all64.bat:1)
+and the C4 shape (C3's 16 x 256^3 frame sharded over 4 contexts on one GPU, bit for bit against the unsharded frame),
+plus the moving-depth-map schedule of frames in flight at C3 size.
+
+The oracle cannot march a whole C5 frame in seconds, so C5 is checked through size-independent properties (idempotence,
+counters against the cull, finite alpha in [0, 1]) and an oracle spot check of one volume and one composite row band.
+"""
+import numpy as np
+import pytest
+
+from multivolumes_amd import MultiRayCaster, _lib, scene
+from multivolumes_amd import distributed as D
+from multivolumes_amd import raycaster as rc
+from tests.conftest import half_to_float
+
+pytestmark = pytest.mark.gpu
+
+
+def make_caster(cfg, M, flags=0, shard=(0, 1)):
+    return MultiRayCaster(cfg["N"], cfg["L"], cfg["V"], cfg["V"], (cfg["W"], cfg["H"]), shadowMapSize=M, flags=flags, shard=shard)
+
+
+def relight_all(c, fr, frames):
+    for f in range(frames):
+        c.m_frameIdx = f
+        c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        c.cullVolumes()
+        c.rayMarchL()
+
+
+def test_c5_full_size_properties(oracle):
+    """BASELINE.json configs[4]: 64 volumes of 256^3, 2048^2 viewport, 256 steps/ray, early termination + OIT composite."""
+    cfg = scene.CONFIGS["C5"]
+    V, N, L, W, H = cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"]
+    M = 1024
+    with make_caster(cfg, M) as c:
+        for k in range(V):
+            c.LoadVolumeData(k, rc.synth_volume(N, k))
+        fr = scene.setup_raycaster(c, cfg)
+        c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        c.cullVolumes()
+        vis, cube = c.ReadBackVisibleLists()
+        assert len(vis) >= 32 and len(cube) >= 16, "the default C5 camera sees most of the 8 x 8 grid"
+        relight_all(c, fr, len(vis))  # every visible volume relit once
+        c.ResetStats()
+        c.rayMarchV()
+        c.composite()
+        c.synchronize()
+        info = c.ReadBackVolumeInfo()
+        st1 = c.GetStats()
+        img1 = c.ReadBackComposite()
+        first = {int(v): (c.ReadBackCubeMap(int(v), int(info[v, 0])), c.ReadBackCubeDepth(int(v), int(info[v, 0]))) for v in cube}
+
+        # idempotence: the same frame again writes the same bits and counts the same samples
+        c.ResetStats()
+        c.rayMarchV()
+        c.composite()
+        c.synchronize()
+        st2 = c.GetStats()
+        assert np.array_equal(c.ReadBackComposite(), img1)
+        expect_rays = 0
+        for v in cube:
+            cm, cd = first[int(v)]
+            mip = int(info[v, 0])
+            assert np.array_equal(c.ReadBackCubeMap(int(v), mip), cm) and np.array_equal(c.ReadBackCubeDepth(int(v), mip), cd)
+            f = half_to_float(cm)
+            assert np.all(np.isfinite(f)) and np.all((f[..., 3] >= 0) & (f[..., 3] <= 1.0))
+            d = N >> mip
+            expect_rays += bin(int(info[v, 2]) & 0x3F).count("1") * d * d
+        for k in ("view_samples", "lit_samples", "rays", "composite_samples"):
+            assert st1[k] == st2[k], k
+        # the eye is outside every volume: every texel of a visible face hits its box -- up to the odd ray that grazes a cube edge
+        # and fails ComputeRayOrigin's |p| <= 1 tests by an ulp (RayMarch.hlsli:141-146; such a texel is simply not written)
+        assert expect_rays - 16 <= st1["rays"] <= expect_rays
+        assert 0 < st1["lit_samples"] <= st1["view_samples"] <= expect_rays * cfg["maxRay"]
+        assert all(int(info[v, 1]) <= cfg["maxRay"] for v in vis)
+        a = half_to_float(img1)
+        assert np.all(np.isfinite(a)) and np.all((a[..., 3] >= 0) & (a[..., 3] <= 1.0)) and (a[..., 3] > 0).mean() > 0.2
+
+        # oracle spot checks, bit for bit: the largest cube-map volume's view march, then a band of the composite
+        # (the oracle composites from the GPU's own cube maps / light maps: it checks compositeKernel at 64 volumes, 2048^2)
+        vols = [rc.synth_volume(N, k) for k in range(V)]
+        v = int(max(cube, key=lambda u: -int(info[u, 0])))
+        lms = np.zeros((V, L, L, L), np.uint32)
+        for u in vis:
+            lms[u] = c.ReadBackLightMap(int(u))
+        cm, cd, _ = oracle.march_view(V, N, L, W, H, vols, lms, fr["depth"], c.perObject, c.cbPerFrame, info, [v])
+        mip = int(info[v, 0])
+        assert np.array_equal(oracle.cube_face_view(cm[v], N, mip), first[v][0])
+        assert np.array_equal(oracle.cube_face_view(cd[v], N, mip), first[v][1])
+        chain = oracle.cube_chain_texels(N)
+        cms = np.zeros((V, chain, 4), np.uint16)
+        cds = np.zeros((V, chain), np.float32)
+        for u in cube:
+            m = int(info[u, 0])
+            off, n = oracle.cube_mip_offset(N, m), 6 * (N >> m) ** 2
+            cms[u, off:off + n] = first[int(u)][0].reshape(n, 4)
+            cds[u, off:off + n] = first[int(u)][1].reshape(n)
+        y0, y1 = H // 2 - 16, H // 2 + 16
+        exp, _ = oracle.composite(V, N, L, W, H, vols, lms, fr["depth"], c.perObject, c.cbPerFrame, info, vis, cms, cds, y0, y1)
+        assert np.array_equal(exp[y0:y1], img1[y0:y1]), "composite band differs from the oracle"
+        print(f"C5: {len(vis)} visible / {len(cube)} cube-map volumes, {st1['view_samples']} view samples, {st1['composite_samples']} RayCast samples")
+
+
+def check_sharded(cfg, M, world):
+    """`world` sharded contexts on one GPU + the exchange kernels reproduce the unsharded frame bit for bit (cube maps,
+    cube depths, light maps of the owners, row-split RayCast, composite bands).  The all-gather is the concatenation of
+    the packed shards in rank order (what ncclAllGather produces)."""
+    import torch
+    V, N, H = cfg["V"], cfg["N"], cfg["H"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    with make_caster(cfg, M) as full:
+        fr = scene.setup_raycaster(full, cfg, vols)
+        relight_all(full, fr, V)
+        full.rayMarchV()
+        full.composite()
+        info = full.ReadBackVolumeInfo()
+        vis, cube = full.ReadBackVisibleLists()
+        ref_img = full.ReadBackComposite()
+        ref_cm = {int(v): full.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube}
+        ref_cd = {int(v): full.ReadBackCubeDepth(int(v), int(info[v, 0])) for v in cube}
+        ref_lm = {int(v): full.ReadBackLightMap(int(v)) for v in vis}
+        ref_stats = full.GetStats()
+    shards = []
+    try:
+        packed = []
+        tot = dict(view_samples=0, rays=0, composite_samples=0, light_samples=0)
+        for r in range(world):
+            c = make_caster(cfg, M, shard=(r, world))
+            shards.append(c)
+            scene.setup_raycaster(c, cfg, vols)
+            relight_all(c, fr, V)  # frame f relights visible[f % count] on the shard that owns it
+            for v in vis:
+                if int(v) % world != r:
+                    c.UploadLightMap(int(v), ref_lm[int(v)])  # the light-map exchange (RayCast rows read every such map)
+                else:
+                    assert np.array_equal(c.ReadBackLightMap(int(v)), ref_lm[int(v)])
+            assert c.ShardRows() == D.row_range(H, r, world)
+            c.rayMarchV()  # (same frame as the last light march, like the unsharded run above)
+            assert np.array_equal(c.ReadBackVolumeInfo(), info), "cull is replicated"
+            d, slot_bytes, shard_bytes = c.ExchangeLayout()
+            assert (d, slot_bytes, shard_bytes) == D.exchange_layout(N, info, vis, V, world)
+            buf = torch.zeros(shard_bytes, dtype=torch.uint8, device="cuda")
+            c.ExchangePack(buf.data_ptr(), d)
+            c.synchronize()
+            packed.append(buf)
+            st = c.GetStats()
+            for k in tot:
+                tot[k] += st[k]
+            for v in cube:
+                got = c.ReadBackCubeMap(int(v), int(info[v, 0]))
+                if int(v) % world == r:
+                    assert np.array_equal(got, ref_cm[int(v)])
+                else:
+                    assert not got.any(), "a shard marches only its own volumes"
+        assert tot["view_samples"] == ref_stats["view_samples"] and tot["rays"] == ref_stats["rays"]
+        assert tot["composite_samples"] == ref_stats["composite_samples"], "RayCast pixels are split by rows, none marched twice"
+        assert tot["light_samples"] == ref_stats["light_samples"], "every light march ran on exactly one shard"
+        gathered = torch.cat(packed)
+        for r, c in enumerate(shards):
+            c.ExchangeUnpack(gathered.data_ptr(), d)
+            for v in cube:
+                assert np.array_equal(c.ReadBackCubeMap(int(v), int(info[v, 0])), ref_cm[int(v)])
+                assert np.array_equal(c.ReadBackCubeDepth(int(v), int(info[v, 0])), ref_cd[int(v)])
+            r0, r1 = D.row_range(H, r, world)
+            c.composite(r0, r1)
+            img = c.ReadBackComposite()
+            assert np.array_equal(img[r0:r1], ref_img[r0:r1]), f"row band of shard {r} differs from the unsharded composite"
+        return dict(visible=len(vis), cube=len(cube), exchange_bytes=int(gathered.numel()), raycast=ref_stats["composite_samples"])
+    finally:
+        for c in shards:
+            c.close()
+
+
+def test_c4_shape_four_shards_of_c3_match_unsharded_frame():
+    """BASELINE.json configs[3] on the hardware at hand: the full-size C3 frame (16 x 256^3, 1024^2, 128 steps) split over
+    FOUR sharded contexts (4 volumes each) on one GPU -- the partitioning, pack / unpack and row-band composite of the 8-GPU
+    run, every byte compared with the unsharded frame.  (8 physical GPUs are the driver's to launch.)"""
+    r = check_sharded(scene.CONFIGS["C3"], 1024, 4)
+    assert r["visible"] >= 10 and r["cube"] >= 8 and r["raycast"] > 0
+    print("C4 shape:", r)
+
+
+def test_three_shards_uneven_split():
+    """V = 16 over 3 shards (6 / 5 / 5 volumes, uneven row bands): padding slots and ragged bands."""
+    check_sharded(dict(scene.CONFIGS["T2"], W=200, H=136), 64, 3)
+
+
+@pytest.mark.parametrize("route", ["host_copy", "device_pointer"])
+def test_frames_in_flight_with_a_new_depth_map_every_frame_c3(route):
+    """C3-sized frames with a DIFFERENT depth map every frame (a moving camera): frames in flight must give the one-stream
+    result.  `host_copy` = mv_set_depth_map per frame (the setter waits for the frames that still read the old map);
+    `device_pointer` = a borrowed device buffer per frame (mv_set_depth_map_device), which keeps frames in flight."""
+    import torch
+    cfg = scene.CONFIGS["C3"]
+    V, N, W, H = cfg["V"], cfg["N"], cfg["W"], cfg["H"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    frames = 12
+    cams = []
+    eye0 = np.array(scene.camera(cfg)[0], np.float32)
+    for f in range(frames):
+        e = eye0 + np.array([1.5 * f, -0.4 * f, 2.0 * f], np.float32)
+        vp = rc.multiply(rc.look_at_lh(e, (0, 0, 0)), rc.perspective_fov_lh(scene.FOV_ANGLE_Y, W / H, 1.0, 1000.0))
+        # the occluder moves too, so that consecutive depth maps differ over many pixels
+        cams.append((e, vp, rc.synth_sphere_depth(W, H, vp, (0.6 * f, 0.0, 0.0), scene.SPHERE_RADIUS)))
+    outs = []
+    for flags in (0, _lib.MV_FLAG_PIPELINE_FRAMES):
+        with make_caster(cfg, 1024, flags=flags) as c:
+            fr = scene.setup_raycaster(c, cfg, vols)
+            dev = [torch.from_numpy(d).cuda() for (_, _, d) in cams] if route == "device_pointer" else None
+            torch.cuda.synchronize()
+            imgs = []
+            for f, (e, vp, depth) in enumerate(cams):
+                if route == "host_copy":
+                    c.SetRenderTargets(depth)
+                else:
+                    c.SetRenderTargets(depthMapDevice=dev[f].data_ptr())
+                c.UpdateFrame(vp, fr["shadowVP"], e)
+                c.Render(composite=True)
+                if f % 4 == 3:
+                    imgs.append(c.ReadBackComposite())
+            info = c.ReadBackVolumeInfo()
+            vis, cube = c.ReadBackVisibleLists()
+            cms = [c.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube]
+            cds = [c.ReadBackCubeDepth(int(v), int(info[v, 0])) for v in cube]
+            st = c.GetStats()
+            outs.append((imgs, info, cms, cds, {k: st[k] for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples")}))
+    a, b = outs
+    assert a[4] == b[4]
+    assert np.array_equal(a[1], b[1])
+    for x, y in zip(a[0] + a[2] + a[3], b[0] + b[2] + b[3]):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("flags", [0, _lib.MV_FLAG_PIPELINE_FRAMES])
+def test_a_frame_without_light_march_keeps_the_light_maps(flags):
+    """The reference's light maps simply keep their contents when rayMarchL is not recorded in a frame.  Here every volume has
+    rotating light buffers and the cull pre-selects the relit volume's next one: a frame that leaves mv_march_light out must
+    still read the maps that were last written."""
+    cfg = dict(scene.CONFIGS["T2"], W=128, H=96)
+    V = cfg["V"]
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+    with make_caster(cfg, 64, flags=flags) as c:
+        fr = scene.setup_raycaster(c, cfg, vols)
+        relight_all(c, fr, V)
+        c.rayMarchV()
+        c.composite()
+        info = c.ReadBackVolumeInfo()
+        vis, cube = c.ReadBackVisibleLists()
+        ref = [c.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube]
+        ref_lm = [c.ReadBackLightMap(int(v)) for v in vis]
+        ref_img = c.ReadBackComposite()
+        for f in range(2 * len(vis) + 1):  # frameIdx sweeps every visible volume: each would have been "relit" once or twice
+            c.m_frameIdx = f
+            c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+            c.cullVolumes()
+            c.rayMarchV()
+            c.composite()
+        for v, a in zip(cube, ref):
+            assert np.array_equal(c.ReadBackCubeMap(int(v), int(info[v, 0])), a)
+        assert np.array_equal(c.ReadBackComposite(), ref_img)
+        for v, a in zip(vis, ref_lm):
+            assert np.array_equal(c.ReadBackLightMap(int(v)), a)
+        from multivolumes_amd._lib import MVError
+        with pytest.raises(MVError):
+            c.rayMarchL()  # after the frame's view march: refused (the frame already reads the kept maps)
