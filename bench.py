@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
     p.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of frame i+1's light march with frame i's view march")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-light", action="store_true", help="DIAGNOSTIC (not a valid bench line): leave the light march out of the timed frames, to price it")
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
     p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
@@ -114,11 +115,16 @@ def main():
     band = D.row_range(H, rank, world)
     assert band == caster.ShardRows()
     xbytes = [0]
+    skip_light = [False]
 
     def frame(with_exchange=True):
         frame_idx = caster.m_frameIdx
         caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
-        if world == 1:
+        if world == 1 and skip_light[0]:
+            caster.cullVolumes()
+            caster.rayMarchV()
+            caster.m_frameIdx += 1
+        elif world == 1:
             caster.Render(composite=False)  # cull -> marchL -> marchV, stream ordered
         else:
             caster.cullVolumes()
@@ -140,6 +146,7 @@ def main():
     # one-time 30-50 ms stall around the 140th frame of a process (see the module docstring) whatever --warmup the caller gives.
     for _ in range(max(V, 176)):
         frame(with_exchange=False)
+    skip_light[0] = args.no_light
     for _ in range(args.warmup):
         frame()
     caster.synchronize()
@@ -265,6 +272,8 @@ def main():
                                             else f"every {args.profile_every}th frame of the timed region (HIP events)")},
             "setup_s": t_setup,
         }
+        if args.no_light:
+            out["INVALID"] = "--no-light: the light march was left out of the timed frames (diagnostic run)"
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, cfg, caster, fr, info, cube, vols_host)
         print(json.dumps(out))

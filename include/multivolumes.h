@@ -69,6 +69,9 @@ extern "C" {
 										   stream (only upload, cull and light march run ahead on internal streams) -- for callers that order their own
 										   work, e.g. RCCL collectives, on that stream between mv_march_view and mv_composite */
 
+#define MV_FLAG_LIST_ORDER 8u				/* march the tiles in list order instead of the cost-binned order (longest rays first).  The order only
+										   decides which wavefront marches which ray and when: results are bit-identical either way (tests, A/B timing) */
+
 typedef struct mv_ctx mv_ctx;
 
 typedef struct mv_config
@@ -198,6 +201,7 @@ void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */
 #define MV_BUF_COMPOSITE 5
 #define MV_BUF_DEPTH_MAP 6
 #define MV_BUF_SHADOW_MAP 7
+#define MV_BUF_MARCH_TIMELINE 8	/* 8 x uint64 per march wavefront; only diagnostic builds (-DMV_TIMELINE) fill it (scripts/march_timeline.py) */
 int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, size_t* bytes);
 
 /* texels (not bytes) of one volume's 5-mip cube chain and the offset of mip m inside it */

@@ -22,6 +22,7 @@ MV_ERR_RANGE = -6
 MV_FLAG_FORCE_MIP0_ALL_FACES = 1
 MV_FLAG_PIPELINE_FRAMES = 2
 MV_FLAG_SINGLE_VIEW_STREAM = 4
+MV_FLAG_LIST_ORDER = 8
 
 MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
 MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7
@@ -171,9 +172,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH) or _stale():
-        build()
-    lib = C.CDLL(LIB_PATH)
+    alt = os.environ.get("MV_LIB_PATH")  # A/B measurements: a library built with other switches (scripts/exp_build.sh)
+    if alt:
+        lib = C.CDLL(alt)
+    else:
+        if not os.path.exists(LIB_PATH) or _stale():
+            build()
+        lib = C.CDLL(LIB_PATH)
     for name, (res, args) in ABI.items():
         fn = getattr(lib, name)  # AttributeError if the ABI symbol is missing: fail loudly
         fn.restype = res

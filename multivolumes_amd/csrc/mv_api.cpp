@@ -10,7 +10,6 @@
 #include "mv_mesh.hpp"
 
 #include <algorithm>
-#include <chrono>
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -48,8 +47,10 @@ struct FrameBufs
 	float4* lightDirs = nullptr;
 	uint32_t* screenSlot = nullptr;
 	uint4** lightTable = nullptr;
-	uint16_t* tileCost = nullptr;
+	uint32_t* tileCost = nullptr;
 	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per slot
+	mv::VolumeConsts* volConsts = nullptr;
+	uint32_t* queueHeads = nullptr;
 };
 
 // Outputs of the view march / composite and their counters: one set, or kMaxOutSets-or-fewer rotating sets with
@@ -62,7 +63,9 @@ struct OutBufs
 	float* cubeDepths = nullptr;
 	uint2* composite = nullptr;
 	float4* screenLayers = nullptr;
-	uint64_t *tileStats = nullptr, *screenStats = nullptr, *compositeStats = nullptr, *tileSkipped = nullptr;
+	uint64_t *waveStats = nullptr, *compositeStats = nullptr;
+	mv::RayRecord* rayRecords = nullptr;	// the view march's ray queue (mv_march.hip)
+	mv::TileInfo* tileInfo = nullptr;
 };
 
 struct mv_ctx
@@ -83,14 +86,16 @@ struct mv_ctx
 	bool producersDirty = false;
 
 	// owned device allocations
-	std::vector<uint2*> volumes;
+	std::vector<uint2*> volumes;		// volumes[i] = volPool + i * volStride: ONE allocation (the march addresses it as base + 32-bit offset)
+	uint8_t* volPool = nullptr;
+	uint64_t* occPool = nullptr;
 	std::vector<uint4*> cells;
 	uint2** dVolumePtrs = nullptr;
 	uint4** dCellPtrs = nullptr;
 	std::vector<uint64_t*> occupancy;	// brick occupancy words per volume source
 	uint64_t** dOccPtrs = nullptr;
 	uint32_t* lightStaging = nullptr;	// L^3 plain R11G11B10F (readback / upload conversion)
-	bool orderTiles = true;				// (-DMV_DIAGNOSTICS builds: MV_TILE_ORDER=0 in the environment selects list-order dispatch)
+	bool orderTiles = true;				// false with MV_FLAG_LIST_ORDER
 	// mesh depth / shadow producer (mv_mesh_*)
 	float* meshPositions = nullptr;
 	uint32_t* meshIndices = nullptr;
@@ -112,7 +117,6 @@ struct mv_ctx
 	hipEvent_t sliceDone[kFrameSlices] = {};
 	uint64_t* pinnedStats = nullptr;
 	uint32_t* pinnedCounters = nullptr;
-	unsigned long long* pinnedTiles = nullptr;	// written by the cull kernel: {frame tag : tile count} of the most recent cull that has run
 	uint8_t* pinnedCull = nullptr;		// counters + VolumeInfo + both lists + light table, one readback
 	uint64_t frame = 0;					// frames begun (mv_update_frame)
 	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
@@ -164,10 +168,11 @@ void applyParity(mv_ctx* ctx)
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.lightDirs = f.lightDirs;
-	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo;
+	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
 	const OutBufs& o = ctx->ob[ctx->set];
 	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers;
-	st.tileStats = o.tileStats; st.screenStats = o.screenStats; st.compositeStats = o.compositeStats; st.tileCost = f.tileCost; st.tileSkipped = o.tileSkipped;
+	st.waveStats = o.waveStats; st.compositeStats = o.compositeStats; st.tileCost = f.tileCost;
+	st.rayRecords = o.rayRecords; st.tileInfo = o.tileInfo;
 	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
 }
 
@@ -336,8 +341,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 
 	// volumes[S] (MultiRayCaster.cpp:98-105)
 	ctx->volumes.resize(st.S, nullptr);
-	for (uint32_t i = 0; i < st.S; ++i)
-		if ((rc = devAlloc(ctx, &ctx->volumes[i], brickedBytes)) != MV_OK) return bail(rc);
+	st.volStride = (brickedBytes + 511u) & ~(size_t)511u;
+	if ((rc = devAlloc(ctx, &ctx->volPool, (size_t)st.S * st.volStride)) != MV_OK) return bail(rc);
+	for (uint32_t i = 0; i < st.S; ++i) ctx->volumes[i] = reinterpret_cast<uint2*>(ctx->volPool + (size_t)i * st.volStride);
+	st.volPool = ctx->volPool;
 	if ((rc = devAlloc(ctx, &ctx->dVolumePtrs, st.S * sizeof(uint2*), false)) != MV_OK) return bail(rc);
 	if (hipMemcpyAsync(ctx->dVolumePtrs, ctx->volumes.data(), st.S * sizeof(uint2*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
@@ -353,8 +360,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	{
 		const size_t regions = mv::occupancyRegions(st.bricks);
 		ctx->occupancy.resize(st.S, nullptr);
-		for (uint32_t i = 0; i < st.S; ++i)
-			if ((rc = devAlloc(ctx, &ctx->occupancy[i], regions * regions * regions * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		st.occStride = (uint32_t)(regions * regions * regions);
+		if ((rc = devAlloc(ctx, &ctx->occPool, (size_t)st.S * st.occStride * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		for (uint32_t i = 0; i < st.S; ++i) ctx->occupancy[i] = ctx->occPool + (size_t)i * st.occStride;
+		st.occPool = ctx->occPool;
 		if ((rc = devAlloc(ctx, &ctx->dOccPtrs, st.S * sizeof(uint64_t*), false)) != MV_OK) return bail(rc);
 		if (hipMemcpyAsync(ctx->dOccPtrs, ctx->occupancy.data(), st.S * sizeof(uint64_t*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 		if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
@@ -421,23 +430,37 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			if ((rc = devAlloc(ctx, &f.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.lightDirs, (size_t)st.V * sizeof(float4))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.volConsts, (size_t)st.V * sizeof(mv::VolumeConsts))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.queueHeads, (size_t)mv::kRayQueues * mv::kRayQueueStride * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if (hipMemcpyAsync(f.lightTable, table.data(), (size_t)st.V * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 		}
 		if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
 	}
 	if ((rc = devAlloc(ctx, &st.stats, kNumStats * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	st.maxTiles = mv::marchViewMaxTiles(st.V, st.N, st.shardCount);
+	// RayRecord.out is a 31-bit element index into the cube chains / the screen layers
+	if ((uint64_t)st.V * mv::cubeChainTexels(st.N) >= (1ull << 31) || (uint64_t)st.screenSlots * st.W * st.H >= (1ull << 31)) return bail(MV_ERR_INVALID_ARG);
+	// The march is a persistent launch: as many wavefronts as the device holds at once.  With frames in flight it leaves a share of the
+	// wave slots to the kernels of the other streams (the next frame's cull and light march, the previous frame's composite), which
+	// could not start before its tail otherwise.
+	{
+		const uint32_t resident = mv::marchViewResidentWaves(cfg->device, (uint64_t)st.S * st.volStride > 0xffffffffull);
+		uint32_t share = (cfg->flags & MV_FLAG_PIPELINE_FRAMES) ? 80u : 100u;
+#ifdef MV_DIAGNOSTICS
+		{ const char* e = getenv("MV_MARCH_SHARE"); if (e) share = (uint32_t)atoi(e); }
+#endif
+		st.marchWaves = (uint32_t)((uint64_t)resident * share / 100u);
+		if (st.marchWaves < 64u) st.marchWaves = 64u;
+	}
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
 	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
-#ifdef MV_DIAGNOSTICS
-	{ const char* e = getenv("MV_TILE_ORDER"); ctx->orderTiles = !(e && e[0] == '0'); }
-#endif
+	ctx->orderTiles = !(cfg->flags & MV_FLAG_LIST_ORDER);
 	for (uint32_t p = 0; p < kFrameSlots; ++p)
 	{
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 256 * 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		// per-tile cost table, one per slot: the view march of frame i writes it, the tile order of frame i + 4 reads it
-		if ((rc = devAlloc(ctx, &ctx->fb[p].tileCost, ((size_t)st.V * 6 * ((st.N + 7u) >> 3) * ((st.N + 7u) >> 3) + st.maxScreenTiles + 1) * sizeof(uint16_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &ctx->fb[p].tileCost, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	}
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	// (MV_FORCE_TWO_SETS: validation only -- a one-stream context that alternates output sets like a pipelined one, see scripts/soak.py)
@@ -452,9 +475,11 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.screenStats, ((size_t)st.maxScreenTiles + 1) * 2 * sizeof(uint64_t))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.tileStats, (size_t)st.maxTiles * 4 * sizeof(uint64_t))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.tileSkipped, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.waveStats, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		if (p == 0 && (rc = devAlloc(ctx, &st.timeline, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		// the ray queue: 64 records per tile of the largest frame (every owned volume at mip 0 with 6 faces + every screen tile); never cleared
+		if ((rc = devAlloc(ctx, &f.rayRecords, ((size_t)st.maxTiles + st.maxScreenTiles) * 64 * sizeof(mv::RayRecord), false)) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.tileInfo, ((size_t)st.maxTiles + st.maxScreenTiles) * sizeof(mv::TileInfo), false)) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	}
 	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
@@ -469,9 +494,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	for (uint32_t i = 0; i < kFrameSlices; ++i)
 		if (hipEventCreateWithFlags(&ctx->sliceDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
-	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedTiles), 64, hipHostMallocCoherent) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
-	*ctx->pinnedTiles = ~0ull;
-	st.tilesReport = ctx->pinnedTiles;
 
 	// default VolumeDesc[V] = { i % S, NUM_CUBE_MIP, N } (MultiRayCaster.cpp:471-479)
 	{
@@ -505,7 +527,6 @@ void mv_destroy(mv_ctx* ctx)
 	if (ctx->dMeshMatrix) (void)hipFree(ctx->dMeshMatrix);
 	if (ctx->pinned) (void)hipHostFree(ctx->pinned);
 	if (ctx->pinnedCull) (void)hipHostFree(ctx->pinnedCull);
-	if (ctx->pinnedTiles) (void)hipHostFree(ctx->pinnedTiles);
 	if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -677,7 +698,6 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	ctx->slot = (ctx->slot + 1u) % kFrameSlots;
 	++ctx->frame;
 	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
-	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);
 	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->slot], 0));
@@ -741,22 +761,6 @@ int mv_march_light(mv_ctx* ctx)
 	return MV_OK;
 }
 
-// With frames in flight the cull of this frame runs ahead on stream A and reports its tile count to pinned memory; waiting for
-// that report (normally already there; bounded spin otherwise) lets the view-march grid be exact.  On one stream the host would
-// stall for the cull instead, and there the surplus workgroups of an upper-bound grid cost nothing: no wait.
-static uint32_t exactTileCount(mv_ctx* ctx)
-{
-	if (!(ctx->cfg.flags & MV_FLAG_PIPELINE_FRAMES) || !ctx->pinnedTiles) return 0xffffffffu;
-	const volatile unsigned long long* report = ctx->pinnedTiles;
-	const auto t0 = std::chrono::steady_clock::now();
-	for (uint32_t spins = 0;; ++spins)
-	{
-		const unsigned long long v = *report;
-		if ((uint32_t)(v >> 32) == (uint32_t)ctx->frame) return (uint32_t)v;
-		if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) return 0xffffffffu;	// far beyond any frame in flight: give up, the upper bound is always correct
-	}
-}
-
 int mv_march_view(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
@@ -768,7 +772,10 @@ int mv_march_view(mv_ctx* ctx)
 	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (ctx->numOutSets % kFrameSlots)) % kFrameSlots], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 2, ev, streamB(ctx));
-	mv::launchMarchView(streamB(ctx), ctx->st, exactTileCount(ctx));
+	// ray setup -> march, both with fixed grids that read the tile count on the device: nothing between the cull and the march
+	// waits for the host (the shape of the work-graph variant, Sh/LibRayMarch.hlsl:39-134)
+	mv::launchRaySetup(streamB(ctx), ctx->st);
+	mv::launchMarchView(streamB(ctx), ctx->st);
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, stageBDone(ctx));
@@ -943,7 +950,7 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out)
 		if (p == ctx->set) continue;
 		DeviceState other = ctx->st;
 		const OutBufs& q = ctx->ob[p];
-		other.tileStats = q.tileStats; other.screenStats = q.screenStats; other.compositeStats = q.compositeStats; other.tileSkipped = q.tileSkipped;
+		other.waveStats = q.waveStats; other.compositeStats = q.compositeStats;
 		mv::launchReduceStats(ctx->stream, other, 0);
 	}
 	MV_HIP(ctx, hipGetLastError());
@@ -975,10 +982,8 @@ int mv_reset_stats(mv_ctx* ctx)
 	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
 	{
 		const OutBufs& f = ctx->ob[p];
-		MV_HIP(ctx, hipMemsetAsync(f.tileStats, 0, (size_t)ctx->st.maxTiles * 4 * sizeof(uint64_t), ctx->stream));
-		MV_HIP(ctx, hipMemsetAsync(f.tileSkipped, 0, ((size_t)ctx->st.maxTiles + ctx->st.maxScreenTiles + 1) * sizeof(uint64_t), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(f.waveStats, 0, (size_t)ctx->st.marchWaves * 8 * sizeof(uint64_t), ctx->stream));
 		MV_HIP(ctx, hipMemsetAsync(f.compositeStats, 0, (size_t)ctx->st.compositeSlots * sizeof(uint64_t), ctx->stream));
-		MV_HIP(ctx, hipMemsetAsync(f.screenStats, 0, ((size_t)ctx->st.maxScreenTiles + 1) * 2 * sizeof(uint64_t), ctx->stream));
 	}
 	for (int i = 0; i < 4; ++i) { ctx->msStage[i] = 0.0; ctx->nStage[i] = 0; }
 	return MV_OK;
@@ -1030,6 +1035,7 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 	case MV_BUF_COMPOSITE: *d_ptr = st.composite; *bytes = (size_t)st.W * st.H * sizeof(uint2); return MV_OK;
 	case MV_BUF_DEPTH_MAP: *d_ptr = ctx->ownDepth; *bytes = (size_t)st.W * st.H * sizeof(float); return MV_OK;
 	case MV_BUF_SHADOW_MAP: *d_ptr = ctx->ownShadow; *bytes = (size_t)st.M * st.M * sizeof(uint16_t); return MV_OK;
+	case MV_BUF_MARCH_TIMELINE: *d_ptr = st.timeline; *bytes = (size_t)st.marchWaves * 8 * sizeof(uint64_t); return MV_OK;
 	default: return fail(ctx, MV_ERR_INVALID_ARG, "unknown buffer id");
 	}
 }

@@ -200,6 +200,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x2* GlobalUint2;
 typedef const __attribute__((address_space(1))) u32x4* GlobalUint4;
 typedef const __attribute__((address_space(1))) uint32_t* GlobalUint;
+typedef const __attribute__((address_space(1))) uint64_t* GlobalUint64;
 
 // Besides the RGBA16F bricks every volume source has an ALPHA-CELL companion: for every texel (x,y,z) the eight
 // alphas of the 2x2x2 footprint that starts there, a(x..x+1, y..y+1, z..z+1) with the +1 neighbours clamped, as 8 halfs
@@ -264,13 +265,13 @@ struct FootprintAddr
 	uint32_t ix, iy, iz;					// first tap of every axis (the footprint is {i, min(i + 1, N - 1)}^3)
 };
 
-__device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
+__device__ __forceinline__ FootprintAddr footprintAddr(uint32_t N, uint32_t strideY, uint32_t strideZ, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
 {
-	const Taps tx = linearTaps(uvw.x, v.N, ox), ty = linearTaps(uvw.y, v.N, oy), tz = linearTaps(uvw.z, v.N, oz);
+	const Taps tx = linearTaps(uvw.x, N, ox), ty = linearTaps(uvw.y, N, oy), tz = linearTaps(uvw.z, N, oz);
 	FootprintAddr a;
 	a.x0 = offX(tx.i0); a.x1 = offX(tx.i1);
-	const uint32_t y0 = offY(ty.i0, v.strideY), y1 = offY(ty.i1, v.strideY);
-	const uint32_t z0 = offZ(tz.i0, v.strideZ), z1 = offZ(tz.i1, v.strideZ);
+	const uint32_t y0 = offY(ty.i0, strideY), y1 = offY(ty.i1, strideY);
+	const uint32_t z0 = offZ(tz.i0, strideZ), z1 = offZ(tz.i1, strideZ);
 	a.r00 = y0 + z0; a.r10 = y1 + z0; a.r01 = y0 + z1; a.r11 = y1 + z1;
 	a.fx = tx.f; a.fy = ty.f; a.fz = tz.f;
 	a.ix = (uint32_t)tx.i0; a.iy = (uint32_t)ty.i0; a.iz = (uint32_t)tz.i0;
@@ -279,6 +280,11 @@ __device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3
 	// there lerp(a, a, f) == a exactly, which is lerp(a, b, 0): zero the weight instead of fetching differently.
 	a.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; a.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; a.cz = tz.i1 == tz.i0 ? 0.0f : tz.f;
 	return a;
+}
+
+__device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3 uvw, int ox = 0, int oy = 0, int oz = 0)
+{
+	return footprintAddr(v.N, v.strideY, v.strideZ, uvw, ox, oy, oz);
 }
 
 // ---- brick occupancy ---------------------------------------------------------------------------
@@ -376,16 +382,26 @@ __device__ __forceinline__ float sampleAlpha16F(const VolumeView& v, vec3 uvw, i
 // colour of the footprint: the eight RGBA16F texels (only fetched for samples that pass the alpha test)
 struct ColourFootprint { uint2 t000, t100, t010, t110, t001, t101, t011, t111; float fx, fy, fz; };
 
-__device__ __forceinline__ ColourFootprint fetchColour(const VolumeView& v, const FootprintAddr& a)
+// `base` is either wave-uniform (SGPR base + VGPR byte offset: the offsets then carry the volume's offset inside the pool) or a
+// per-lane pointer to the volume
+__device__ __forceinline__ uint2 loadTexelFrom(GlobalBytes base, uint32_t byteOff)
+{
+	const u32x2 t = *(GlobalUint2)(base + byteOff);
+	return make_uint2(t.x, t.y);
+}
+
+__device__ __forceinline__ ColourFootprint fetchColourAt(GlobalBytes base, const FootprintAddr& a)
 {
 	ColourFootprint f;
-	f.t000 = loadTexelAt(v, a.r00 + a.x0); f.t100 = loadTexelAt(v, a.r00 + a.x1);
-	f.t010 = loadTexelAt(v, a.r10 + a.x0); f.t110 = loadTexelAt(v, a.r10 + a.x1);
-	f.t001 = loadTexelAt(v, a.r01 + a.x0); f.t101 = loadTexelAt(v, a.r01 + a.x1);
-	f.t011 = loadTexelAt(v, a.r11 + a.x0); f.t111 = loadTexelAt(v, a.r11 + a.x1);
+	f.t000 = loadTexelFrom(base, a.r00 + a.x0); f.t100 = loadTexelFrom(base, a.r00 + a.x1);
+	f.t010 = loadTexelFrom(base, a.r10 + a.x0); f.t110 = loadTexelFrom(base, a.r10 + a.x1);
+	f.t001 = loadTexelFrom(base, a.r01 + a.x0); f.t101 = loadTexelFrom(base, a.r01 + a.x1);
+	f.t011 = loadTexelFrom(base, a.r11 + a.x0); f.t111 = loadTexelFrom(base, a.r11 + a.x1);
 	f.fx = a.fx; f.fy = a.fy; f.fz = a.fz;
 	return f;
 }
+
+__device__ __forceinline__ ColourFootprint fetchColour(const VolumeView& v, const FootprintAddr& a) { return fetchColourAt(v.base, a); }
 
 #ifndef MV_FMA_MIX
 #define MV_FMA_MIX 1
@@ -457,18 +473,23 @@ __device__ __forceinline__ float resolveAlphaFromTexels(const ColourFootprint& f
 // an 11/10-bit float only reaches inf above 65024, far beyond lightColor + ambient.)
 struct LightFootprint { u32x4 q0, q1; float cx, cy, fz; };
 
-__device__ __forceinline__ LightFootprint fetchLightFootprint(const uint4* quads, uint32_t L, vec3 uvw)
+// `pool` + `mapOff`: the light map starts mapOff bytes into a (wave-uniform) pool; mapOff may differ from lane to lane
+__device__ __forceinline__ LightFootprint fetchLightFootprintAt(GlobalBytes pool, uint32_t mapOff, uint32_t L, vec3 uvw)
 {
 	const Taps tx = linearTaps(uvw.x, L, 0), ty = linearTaps(uvw.y, L, 0), tz = linearTaps(uvw.z, L, 0);
-	const GlobalBytes base = (GlobalBytes)quads;
 	// 32-bit byte offsets and 24-bit multiplies: L <= 640 (mv_create), so L^2 * 16 < 2^24 and L^3 * 16 < 2^32
-	const uint32_t row = (__umul24((uint32_t)ty.i0, L) + (uint32_t)tx.i0) << 4;
+	const uint32_t row = ((__umul24((uint32_t)ty.i0, L) + (uint32_t)tx.i0) << 4) + mapOff;
 	const uint32_t slice = (L * L) << 4;
 	LightFootprint f;
-	f.q0 = *(GlobalUint4)(base + (__umul24((uint32_t)tz.i0, slice) + row));
-	f.q1 = *(GlobalUint4)(base + (__umul24((uint32_t)tz.i1, slice) + row));
+	f.q0 = *(GlobalUint4)(pool + (__umul24((uint32_t)tz.i0, slice) + row));
+	f.q1 = *(GlobalUint4)(pool + (__umul24((uint32_t)tz.i1, slice) + row));
 	f.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; f.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; f.fz = tz.f;
 	return f;
+}
+
+__device__ __forceinline__ LightFootprint fetchLightFootprint(const uint4* quads, uint32_t L, vec3 uvw)
+{
+	return fetchLightFootprintAt((GlobalBytes)quads, 0u, L, uvw);
 }
 
 __device__ __forceinline__ vec3 resolveLight(const LightFootprint& f)

@@ -470,6 +470,19 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 				p = first + (size_t)((k + 1u) % kLightBuffers) * L3;
 			}
 			st.lightTable[v] = p;
+
+			// what a ray of volume v needs besides its record (mv_march.hip): where its texels, its light map (this frame's
+			// buffer) and its occupancy words are, SmpCount and the step (CSRayMarch.hlsl:109 g_maxDist / SmpCount)
+			const unsigned long long infoBits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(st.volumeInfo) + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t smpCount = (uint32_t)(infoBits >> 16) & 0xffffu, volTexId = st.volumeDescs[v] & 0x3fffu;
+			VolumeConsts vc;
+			vc.texelOff = (uint64_t)volTexId * st.volStride;
+			vc.lightOff = 0u;	// (the ray setup takes it from lightTable)
+			vc.occOff = volTexId * st.occStride;
+			vc.smpCount = smpCount;
+			vc.stepScale = kMaxDist / (float)smpCount;
+			vc.pad[0] = vc.pad[1] = 0u;
+			st.volConsts[v] = vc;
 		}
 	}
 
@@ -524,8 +537,6 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		}
 		st.counters[7] = nTiles < 2u ? 1u : stride;
 		st.counters[8] = 0u;	// the ticket, for the next cull that uses this slot
-		// host-visible {frame tag : tile count}: with frames in flight the host sizes this frame's view-march grid exactly (mv_api.cpp)
-		if (st.tilesReport) *st.tilesReport = ((unsigned long long)st.frameTag << 32) | nTiles;
 	}
 }
 
@@ -759,313 +770,7 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 	if (lane == 0 && tot) st.lightStats[blockIdx.x] += tot;	// this block's own slot: no atomics
 }
 
-// ---------------------------------------------------------------------------------------------
-// a3: view-space march into cube faces.  One wavefront = one 8x8 tile of one face of one volume.
-// ---------------------------------------------------------------------------------------------
-#ifndef MV_MARCH_WAVES
-#define MV_MARCH_WAVES 2	// measured at C3: 1 -> 0.357 ms, 2 -> 0.352, 4 -> 0.364, 8 -> 0.416
-#endif
-constexpr uint32_t kMarchWaves = MV_MARCH_WAVES;	// independent wavefronts per workgroup
-
-// Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
-// their position among this frame's screen tiles.  A key that names another tile after a mip / visibility change only
-// misorders the dispatch.
 constexpr uint32_t kOrderBins = 8, kOrderWaves = 256;
-__device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
-{
-	const uint32_t t = (st.N + 7u) >> 3;
-	if (faceId == 7u)
-	{
-		const uint32_t sIdx = tile - nCubeTiles;
-		return st.V * 6u * t * t + (sIdx < st.maxScreenTiles ? sIdx : st.maxScreenTiles);
-	}
-	return (volumeId * 6u + faceId) * t * t + localTile;
-}
-
-// X = 0 is the product kernel.  X != 0 are timing-only diagnostic variants (wrong results by construction) selected with
-// MV_EXPERIMENT=<X> to price one part of the loop: 1 = no light-map fetch, 2 = no colour fetch.
-#ifndef MV_ALPHA_FROM_TEXELS
-#define MV_ALPHA_FROM_TEXELS 1	// measured: 0.39 vs 0.44 ms at C3, 0.98 vs 0.99 ms at C3-stress (the alpha-cell form adds an HBM round trip to lit samples)
-#endif
-#ifndef MV_OCCUPANCY
-#define MV_OCCUPANCY 1	// skip the texel fetch of samples whose brick occupancy bit is clear (results unchanged by construction)
-#endif
-#ifndef MV_PREDICT_LIT
-#define MV_PREDICT_LIT 1
-#endif
-#ifndef MV_MARCH_MIN_WAVES
-#define MV_MARCH_MIN_WAVES 3	// occupancy bound given to the register allocator / scheduler. Measured at C3 (same box): 3 -> 0.360 ms,
-								// 5 -> 0.395, 6 -> 0.414, 7 -> 0.46, 8 -> 0.60 (spills); all of 1..5 allocate 88 VGPRs, the looser bound schedules loads earlier
-#endif
-template <int X>
-__global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchViewKernel(DeviceState st, uint32_t mapMode)
-{
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t wave = threadIdx.x >> 6;
-	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
-
-	// Dispatch slot -> tile: plain list order (workgroups are dealt round-robin over the 8 XCDs, so every XCD sees an even
-	// mix of volumes and of cube / screen tiles).  Measured alternatives, kept as diagnostics (MV_TILE_MAP): 1 = golden-ratio
-	// stride permutation (equal at C3, 28 % slower at C3-stress: it gives up the L2 reuse between neighbouring tiles),
-	// 2 = one contiguous eighth of the list per XCD (17 % slower at C3: whole volumes, and all screen tiles, land on one XCD).
-	// Placement only affects speed: every tile is marched exactly once whatever the mapping.
-	const uint32_t slot = blockIdx.x * kMarchWaves + wave;
-	if (slot >= nTiles) return;
-	uint32_t tile = slot;
-	if (mapMode == 1u) tile = (uint32_t)(((uint64_t)slot * st.counters[7]) % nTiles);
-	else if (mapMode == 2u)
-	{
-		const uint32_t nBlocks = (nTiles + kMarchWaves - 1u) / kMarchWaves;
-		const uint32_t perXcd = (nBlocks + 7u) >> 3;
-		tile = ((blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3)) * kMarchWaves + wave;
-		if ((blockIdx.x >> 3) >= perXcd || tile >= nTiles) return;
-	}
-	tile = __builtin_amdgcn_readfirstlane(tile);
-	if (st.tileOrder) tile = __builtin_amdgcn_readfirstlane(st.tileOrder[slot]);
-
-	// find the work entry that owns this tile (wave-uniform)
-	uint32_t entry = 0;
-	for (uint32_t base = 0; base < nEntries; base += 64)
-	{
-		const uint32_t i = base + lane;
-		const bool hit = i < nEntries && st.workTileStart[i] <= tile && tile < st.workTileStart[i + 1];
-		const uint64_t b = __ballot(hit);
-		if (b) { entry = base + (uint32_t)__ffsll((unsigned long long)b) - 1u; break; }
-	}
-	entry = __builtin_amdgcn_readfirstlane(entry);
-	const uint32_t we = st.workEntries[entry];
-	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16;
-	const uint32_t localTile = tile - st.workTileStart[entry];
-
-	const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId];	// CSRayMarch.hlsl:81
-	const uint32_t mipLevel = vi.x, smpCount = vi.y, volTexId = vi.w;
-	const PerObject& po = reinterpret_cast<const PerObject*>(st.perObject)[volumeId];
-	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
-	const bool screenTile = faceId == 7u;	// wave-uniform
-
-	// ---- ray setup: a cube-face texel (CSRayMarch.hlsl:84-107) or a screen pixel of a RayCast volume (RayCast.hlsli:43-54)
-	uint32_t nSamples = 0, nLit = 0, nRays = 0, nSkipped = 0;
-	bool valid = false;
-	vec3 rayOrigin = mul43(v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]), po.worldI);	// :89
-	vec3 rayDir = v3(0.0f, 0.0f, 1.0f);
-	float tMax = 0.0f;
-	size_t outIndex = 0;
-	if (!screenTile)
-	{
-		const uint32_t dims = st.N >> mipLevel;
-		const uint32_t tilesX = (dims + 7u) >> 3;
-		const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
-		if (px < dims && py < dims)
-		{
-			const vec3 target = GetLocalPos((float)px, (float)py, faceId, (float)dims);
-			rayDir = normalize3(target - rayOrigin);
-			if (ComputeRayOrigin(rayOrigin, rayDir))	// :96
-			{
-				tMax = ComputeTargetHit(rayOrigin, target, rayDir);
-				outIndex = (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
-
-				// GetClipPos (:59-71)
-				vec3 clip;
-				{
-					vec4 hPos;
-					hPos.x = __builtin_fmaf(0.01f, rayDir.x, rayOrigin.x);
-					hPos.y = __builtin_fmaf(0.01f, rayDir.y, rayOrigin.y);
-					hPos.z = __builtin_fmaf(0.01f, rayDir.z, rayOrigin.z);
-					hPos.w = 1.0f;
-					hPos = mul44(hPos, po.wvp);
-					const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
-					const float u = cx * 0.5f + 0.5f;
-					float v = cy * 0.5f + 0.5f;
-					v = 1.0f - v;
-					clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
-				}
-				st.cubeDepths[outIndex] = clip.z;	// :105
-				tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
-				valid = true;
-				nRays = 1;
-			}
-		}
-	}
-	else
-	{
-		// screen rectangle of the volume, clipped to the viewport, in 8x8 pixel tiles
-		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
-		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
-		const uint32_t tx0 = rect.x >> 3, ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3, tw = (x1 >> 3) - tx0 + 1u;
-		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (ty0 + localTile / tw) * 8u + (lane >> 3);
-		if (px < st.W && py < st.H)
-		{
-			// PSCube.hlsl:37-39, then the fragment the rasteriser would have produced for this volume at this pixel
-			float nx = ((float)px + 0.5f) / (float)st.W, ny = ((float)py + 0.5f) / (float)st.H;
-			nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
-			vec3 lpt;
-			float z;
-			outIndex = ((size_t)st.screenSlot[volumeId] * st.H + py) * st.W + px;
-			if (findExitFragment(po, rayOrigin, pixelRayWorld(cb, nx, ny), lpt, z))
-			{
-				rayDir = normalize3(lpt - rayOrigin);	// PSCube.hlsl:33, 50: normalize(input.LPt - localSpaceEyePt)
-				float4 zero; zero.x = zero.y = zero.z = zero.w = 0.0f;
-				st.screenLayers[outIndex] = zero;	// RayCast returns 0 on a miss (RayCast.hlsli:46)
-				if (ComputeRayOrigin(rayOrigin, rayDir))
-				{
-					const float depthPix = st.depthMap[(size_t)py * st.W + px];
-					tMax = GetTMax(v3(nx, ny, depthPix), rayOrigin, rayDir, po.wvpI);	// RayCast.hlsli:50-51 (no ComputeTargetHit clamp)
-					valid = true;
-				}
-			}
-		}
-	}
-
-	if (valid)
-	{
-		{
-			const float stepScale = kMaxDist / (float)smpCount;
-			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
-			const uint4* lightQuads = st.lightTable[volumeId];
-
-			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
-			float t = 0.0f;
-			float prevDensity = 0.0f;
-			// The loop at :117-153.  One aligned 16-byte alpha-cell load decides the alpha test (:128); only lit samples
-			// fetch the eight RGBA16F texels and the two light-map quads (issued together: one round trip).
-			bool prevLit = false;
-#if MV_OCCUPANCY
-			const uint64_t* occupancy = st.occupancy[volTexId];
-			const uint32_t regions = occupancyRegions(st.bricks);
-			uint32_t occIndex = 0xffffffffu;
-			uint64_t occWord = 0;
-#endif
-			for (uint32_t i = 0; i < smpCount; ++i)
-			{
-				const vec3 pos = rayAt(rayOrigin, rayDir, t);
-				if (outsideBox(pos)) break;	// :120
-				const vec3 uvw = LocalToTex3DSpace(pos);
-
-				const FootprintAddr fa = footprintAddr(vol, uvw);
-#if MV_OCCUPANCY
-				// Empty space: a clear occupancy bit proves alpha <= ZERO_THRESHOLD, for which the loop below only advances t.
-				// At C3 this skips the fetch of 44 % of the samples (87 % of the unlit ones): 0.325 -> 0.258 ms, HBM traffic
-				// 1.66 -> 1.24 GB per launch.  One 64-bit word covers a 16^3-texel region and is reloaded (an L2 hit) when the
-				// ray enters another one; requesting the next region's word ahead of time was measured slower (0.289 ms).
-				{
-					const uint32_t w = occupancyWord(fa.ix, fa.iy, fa.iz, regions);
-					if (w != occIndex) { occWord = occupancy[w]; occIndex = w; }
-					if (!((occWord >> occupancyBit(fa.ix, fa.iy, fa.iz)) & 1ull))
-					{
-						++nSamples;
-						++nSkipped;
-						prevLit = false;
-						t += stepScale;
-						if (t > tMax) break;	// :152
-						continue;
-					}
-				}
-#endif
-#if MV_ALPHA_FROM_TEXELS
-				// latency-oriented form: the eight RGBA texels are fetched unconditionally and alpha comes from them
-				ColourFootprint cf = fetchColour(vol, fa);
-				LightFootprint lf;
-				const bool early = MV_PREDICT_LIT && prevLit;
-				if (early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
-				const float alpha = resolveAlphaFromTexels(cf);
-				++nSamples;
-				float newStep = stepScale;
-				const bool lit = alpha > kZeroThreshold;	// :128
-				prevLit = lit;
-				if (lit)
-				{
-					if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
-#else
-				const AlphaFootprint ac = fetchAlphaCell(vol, fa);
-				// A ray's samples are a dependent chain, so its time is made of memory round trips.  Lit samples come in runs:
-				// when the previous sample was lit, the colour texels and the light quads are requested together with the alpha
-				// cell (one round trip for the whole sample); otherwise only the 16-byte cell is read and empty space costs one
-				// load per sample.  Prediction only changes which loads are issued, never the arithmetic.
-				LightFootprint lf;
-				ColourFootprint cf;
-				const bool early = MV_PREDICT_LIT && prevLit;
-				if (early)
-				{
-					if constexpr (X != 1) lf = fetchLightFootprint(lightQuads, st.L, uvw);
-					if constexpr (X != 2) cf = fetchColour(vol, fa);
-				}
-				const float alpha = resolveAlpha(ac);	// GetSample(...).w (RayMarch.hlsli:44-50)
-				++nSamples;
-				float newStep = stepScale;
-				const bool lit = alpha > kZeroThreshold;	// :128
-				prevLit = lit;
-
-				if (lit)
-				{
-					if (!early)
-					{
-						if constexpr (X != 1) lf = fetchLightFootprint(lightQuads, st.L, uvw);	// GetLight (RayMarch.hlsli:235-240): same pos * 0.5 + 0.5
-						if constexpr (X != 2) cf = fetchColour(vol, fa);
-					}
-#endif
-					const vec3 light = X == 1 ? v3(1.0f, 1.0f, 1.0f) : resolveLight(lf);
-					vec3 color = X == 2 ? v3(0.5f, 0.5f, 0.5f) : resolveRGB(cf);
-					++nLit;
-
-					const float transm = 1.0f - scatter.w;
-					const float dDensity = alpha - prevDensity;
-					newStep = GetStep(dDensity, transm, alpha, stepScale);
-					prevDensity = alpha;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
-
-					color.x *= alpha; color.y *= alpha; color.z *= alpha;	// :140-142 not pre-multiplied
-					color.x *= light.x; color.y *= light.y; color.z *= light.z;
-					scatter.x += color.x * kAbsorption * transm;
-					scatter.y += color.y * kAbsorption * transm;
-					scatter.z += color.z * kAbsorption * transm;
-					scatter.w += alpha * kAbsorption * transm;
-
-					if (transm < kZeroThreshold) break;	// :146
-				}
-
-				t += newStep;
-				if (t > tMax) break;	// :152
-			}
-
-			const float twoPi = 2.0f * kPI;
-			scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;	// :155
-
-			if (!screenTile)
-			{
-				uint2 o;
-				o.x = (uint32_t)float_to_half_bits(scatter.x) | ((uint32_t)float_to_half_bits(scatter.y) << 16);
-				o.y = (uint32_t)float_to_half_bits(scatter.z) | ((uint32_t)float_to_half_bits(scatter.w) << 16);
-				st.cubeMaps[outIndex] = o;	// :157
-			}
-			else
-			{
-				float4 o; o.x = scatter.x; o.y = scatter.y; o.z = scatter.z; o.w = scatter.w;
-				st.screenLayers[outIndex] = o;	// what RayCast returns (RayCast.hlsli:107); the composite applies PSCube.hlsl:56
-			}
-		}
-	}
-
-	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays), totK = waveSumU32(nSkipped);
-	uint32_t maxS = nSamples;
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
-	const uint32_t nCubeTiles = st.counters[6];
-	if (lane == 0) st.tileCost[tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles)] = (uint16_t)(maxS > 65535u ? 65535u : maxS);
-	if (lane == 0 && totK && tile < st.maxTiles + st.maxScreenTiles) st.tileSkipped[tile] += totK;	// samples whose fetch the occupancy bits saved
-	if (lane == 0 && screenTile)
-	{
-		const uint32_t sIdx = tile - nCubeTiles;
-		if (sIdx < st.maxScreenTiles) { st.screenStats[2 * sIdx] += totS; st.screenStats[2 * sIdx + 1] += totL; }
-	}
-	else if (lane == 0 && tile < st.maxTiles)
-	{
-		// this tile slot belongs to this wavefront alone: plain read-modify-write, reduced by reduceStatsKernel on demand
-		ulonglong4* slot = reinterpret_cast<ulonglong4*>(st.tileStats) + tile;
-		ulonglong4 v = *slot;
-		v.x += totS; v.y += totL; v.z += totR;
-		v.w += (unsigned long long)maxS * 64ull;	// lane slots the wave occupied (utilisation = view samples / slots)
-		*slot = v;
-	}
-}
 
 // ---------------------------------------------------------------------------------------------
 // Dispatch order of the view march: tiles binned by the length of their longest ray in the last launch that used this
@@ -1090,7 +795,7 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 	const uint32_t we = sEntry[lo];
 	const uint32_t key = tileCostKey(st, we & 0xffffu, we >> 16, tile - sStart[lo], tile, nCubeTiles);
 	const uint32_t width = st.maxRaySamples >= kOrderBins ? st.maxRaySamples / kOrderBins : 1u;
-	const uint32_t b = (uint32_t)st.tileCost[key] / width;
+	const uint32_t b = st.tileCost[key] / width;
 	return kOrderBins - 1u - (b < kOrderBins - 1u ? b : kOrderBins - 1u);
 }
 
@@ -1170,15 +875,13 @@ __global__ __launch_bounds__(256) void reduceStatsKernel(DeviceState st, int inc
 {
 	unsigned long long a[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };	// [6] = lit samples of the fused RayCast tiles, [7] = samples marched without a texel fetch
 	const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, nThreads = gridDim.x * blockDim.x;
-	for (uint32_t i = tid; i < st.maxTiles; i += nThreads)
+	for (uint32_t i = tid; i < st.marchWaves; i += nThreads)
 	{
-		const ulonglong4 v = reinterpret_cast<const ulonglong4*>(st.tileStats)[i];
-		a[0] += v.x; a[1] += v.y; a[2] += v.z; a[5] += v.w;
+		const uint64_t* w = st.waveStats + (size_t)i * 8u;
+		a[0] += w[0]; a[1] += w[1]; a[2] += w[2]; a[5] += w[3]; a[4] += w[4]; a[6] += w[5]; a[7] += w[6];
 	}
 	if (includeLight) for (uint32_t i = tid; i < st.lightBlocks; i += nThreads) a[3] += st.lightStats[i];
 	for (uint32_t i = tid; i < st.compositeSlots; i += nThreads) a[4] += st.compositeStats[i];
-	for (uint32_t i = tid; i < st.maxScreenTiles; i += nThreads) { a[4] += st.screenStats[2 * i]; a[6] += st.screenStats[2 * i + 1]; }
-	for (uint32_t i = tid; i < st.maxTiles + st.maxScreenTiles; i += nThreads) a[7] += st.tileSkipped[i];
 #pragma unroll
 	for (int k = 0; k < 8; ++k)
 	{
@@ -1269,24 +972,4 @@ void launchMarchLight(hipStream_t s, const DeviceState& st)
 	hipLaunchKernelGGL(marchLightKernel, dim3(b * b * b), dim3(64), 0, s, st);
 }
 
-void launchMarchView(hipStream_t s, const DeviceState& st, uint32_t exactTiles)
-{
-	// exactTiles: this frame's tile count if the host already has it (0xffffffff otherwise).  Without it the grid is the upper
-	// bound -- every owned volume at mip 0 with 6 faces + every screen tile -- and the surplus workgroups exit at once: free
-	// when the launch is alone on the GPU (< 1 us per 100 k workgroups), 4 % of the frame per 130 k when two launches overlap.
-	const uint64_t maxTiles = (uint64_t)marchViewMaxTiles(st.V, st.N, st.shardCount) + st.maxScreenTiles;
-	const uint64_t tiles = exactTiles < maxTiles ? (exactTiles ? exactTiles : 1u) : maxTiles;
-	uint64_t blocks = (tiles + kMarchWaves - 1) / kMarchWaves;
-	blocks = ((blocks + 7) / 8) * 8;
-	const dim3 grid((uint32_t)blocks), block(64 * kMarchWaves);
-#ifdef MV_DIAGNOSTICS	// timing-only variants (wrong results by construction) exist in diagnostic builds only
-	static const int experiment = []() { const char* e = getenv("MV_EXPERIMENT"); return e ? atoi(e) : 0; }();
-	static const uint32_t mapMode = []() { const char* e = getenv("MV_TILE_MAP"); return e ? (uint32_t)atoi(e) : 0u; }();
-	if (experiment == 1) { hipLaunchKernelGGL(marchViewKernel<1>, grid, block, 0, s, st, mapMode); return; }
-	if (experiment == 2) { hipLaunchKernelGGL(marchViewKernel<2>, grid, block, 0, s, st, mapMode); return; }
-	hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st, mapMode);
-#else
-	hipLaunchKernelGGL(marchViewKernel<0>, grid, block, 0, s, st, 0u);
-#endif
-}
 } // namespace mv

@@ -11,6 +11,47 @@ namespace mv
 // kLightBuffers relights ago, which no frame after i - kLightBuffers can still be reading.
 constexpr uint32_t kLightBuffers = 3;
 
+// One ray of the view march, ready to be marched: the record the ray-setup stage emits and the march stage consumes -- the
+// counterpart of the work-graph variant's RayMarchRecord (Sh/LibRayMarch.hlsl:39-134), at ray instead of tile granularity.
+struct RayRecord
+{
+	float ox, oy, oz;		// origin in volume space, after ComputeRayOrigin (CSRayMarch.hlsl:96)
+	float dx, dy, dz;		// unit direction
+	float tMax;				// min(ComputeTargetHit, GetTMax) for a cube-face texel, GetTMax for a RayCast pixel
+	uint32_t out;			// element index of the result: cubeMaps[out], or screenLayers[out & 0x7fffffff] when bit 31 is set; kNoRay = slot without a ray
+};
+static_assert(sizeof(RayRecord) == 32, "two 16-byte stores / loads per lane");
+constexpr uint32_t kNoRay = 0xffffffffu, kScreenRayBit = 0x80000000u;
+// The ray queue is dealt over kRayQueues heads (dispatch slot s belongs to queue s % kRayQueues): one head word serves about 88
+// returning atomics per microsecond chip-wide, which 5000 wavefronts pulling 10^4 tiles would spend a third of the launch on.
+constexpr uint32_t kRayQueues = 64, kRayQueueStride = 32;	// stride in uint32: every head on a 128-byte line of its own
+
+// what the 64 records of one dispatch slot (one 8x8 tile) have in common: the tile's key in the cost table and a copy of its
+// volume's constants, so that a lane taking a record needs ONE round trip (record + tile info are independent loads)
+struct TileInfo
+{
+	uint64_t texelOff;		// byte offset of the volume's bricked texels inside volPool
+	uint32_t lightOff;		// byte offset of the light map this frame reads inside lightBuffers
+	uint32_t occOff;		// index of the volume's first occupancy word inside occPool
+	uint32_t smpCount;		// VolumeInfo.SmpCount
+	float stepScale;		// g_maxDist / SmpCount (CSRayMarch.hlsl:109)
+	uint32_t costKey;
+	uint32_t volume;
+};
+static_assert(sizeof(TileInfo) == 32, "two 16-byte loads");
+
+// per-volume constants of the march, written by the cull every frame (everything a ray needs besides its record)
+struct VolumeConsts
+{
+	uint64_t texelOff;		// byte offset of the volume's bricked texels inside volPool
+	uint32_t lightOff;		// byte offset of the light map this frame reads inside lightBuffers
+	uint32_t occOff;		// index of the volume's first occupancy word inside occPool
+	uint32_t smpCount;		// VolumeInfo.SmpCount
+	float stepScale;		// g_maxDist / SmpCount (CSRayMarch.hlsl:109)
+	uint32_t pad[2];
+};
+static_assert(sizeof(VolumeConsts) == 32, "two 16-byte loads");
+
 // Device-side state of one context. Every pointer is device memory; the struct is passed to kernels by value.
 struct DeviceState
 {
@@ -36,6 +77,10 @@ struct DeviceState
 	const float* sh;				// 27 floats
 
 	// resources
+	const uint8_t* volPool;			// all S bricked volumes in ONE allocation, volStride bytes apart (volumes[i] = volPool + i volStride):
+	uint64_t volStride;				//   the march addresses texels as pool base (SGPR) + 32-bit offset whatever the ray's volume
+	const uint64_t* occPool;		// all S occupancy arrays, occStride words apart
+	uint32_t occStride;
 	const uint2* const* volumes;	// S pointers to bricked RGBA16F texels
 	const uint4* const* alphaCells;	// S pointers to the bricked alpha cells (8 halfs per texel: its 2x2x2 footprint)
 	const uint64_t* const* occupancy;	// S pointers to the brick occupancy words (mv_device.hpp), ceil(bricks / 4)^3 each
@@ -60,10 +105,11 @@ struct DeviceState
 	uint16_t* volumeInfo;			// V x 4
 	uint32_t* visibleVolumes;		// V
 	uint32_t* cubeMapVolumes;		// V
-	unsigned long long* tilesReport;	// pinned host memory (may be NULL): the cull stores {frameTag : tile count} here
-	uint32_t frameTag;				// low 32 bits of the context's frame counter
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
-									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow)
+									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow),
+									// [8] the cull's ticket, [9] head of the march's ray queue (device-only)
+	VolumeConsts* volConsts;		// V (written by the cull)
+	uint32_t* queueHeads;			// kRayQueues heads of the march's ray queue, one per 128-byte line (zeroed by the ray setup)
 	uint32_t* ownedVisible;			// V: visible volumes of this shard, ascending
 	uint32_t* workEntries;			// 6 V + screenSlots: volume | face << 16 (face 7 = screen-space RayCast entry)
 	uint32_t* workTileStart;		// entries + 1 prefix sums of 8x8 tiles
@@ -76,15 +122,36 @@ struct DeviceState
 	// ordered), because tens of thousands of same-address atomics per launch cost more than the march itself.
 	uint64_t* stats;				// totals, filled by launchReduceStats: [0] view samples, [1] lit samples, [2] rays,
 									// [3] light samples, [4] composite samples, [5] marchV lane slots, [6] fused RayCast lit samples, [7] fetch-free samples
-	uint64_t* tileStats;			// maxTiles x 4: {view samples, lit samples, rays, lane slots} per marchV tile slot
-	uint64_t* tileSkipped;			// maxTiles + maxScreenTiles: view / RayCast samples marched without a texel fetch (occupancy bit clear)
+	uint64_t* timeline;				// marchWaves x 8 (filled by -DMV_TIMELINE builds only): per-wavefront stamps of the last march
+	uint64_t* waveStats;			// marchWaves x 8: {view samples, lit, rays, lane slots, RayCast samples, RayCast lit, fetch-free samples, -} per march wavefront
 	uint64_t* lightStats;			// ceil(L/4)^3: light samples per marchL block
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
-	uint64_t* screenStats;			// maxScreenTiles x 2: {RayCast samples, lit} per screen tile marched by marchViewKernel
-	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles;
+	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles, marchWaves;
 	const uint32_t* tileOrder;		// permutation of the tile list (dispatch slot -> tile), longest bins first (launchTileOrder); NULL = list order
-	uint16_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch, by stable tile key
+	uint32_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch, by stable tile key
+	// ray queue of the view march (per output set: two frames may be between setup and march at the same time)
+	RayRecord* rayRecords;			// (maxTiles + maxScreenTiles) x 64, in dispatch order: slot s holds the rays of tile tileOrder[s]
+	TileInfo* tileInfo;				// maxTiles + maxScreenTiles
 };
+
+// Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
+// their position among this frame's screen tiles.  A key that names another tile after a mip / visibility change only
+// misorders the dispatch.
+__host__ __device__ inline uint32_t tileCostKeyCount(uint32_t V, uint32_t N, uint32_t maxScreenTiles)
+{
+	const uint32_t t = (N + 7u) >> 3;
+	return V * 6u * t * t + maxScreenTiles + 1u;
+}
+__host__ __device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
+{
+	const uint32_t t = (st.N + 7u) >> 3;
+	if (faceId == 7u)
+	{
+		const uint32_t sIdx = tile - nCubeTiles;
+		return st.V * 6u * t * t + (sIdx < st.maxScreenTiles ? sIdx : st.maxScreenTiles);
+	}
+	return (volumeId * 6u + faceId) * t * t + localTile;
+}
 
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)
 {
@@ -109,7 +176,9 @@ void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uin
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
-void launchMarchView(hipStream_t s, const DeviceState& st, uint32_t exactTiles);
+void launchRaySetup(hipStream_t s, const DeviceState& st);
+void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
+uint32_t marchViewResidentWaves(int device, bool wideAddressing);	// wavefronts of the march kernel the device holds at once (occupancy query)
 void launchTileOrder(hipStream_t s, const DeviceState& st, uint32_t* binCounts, uint32_t* order);	// binCounts: 256 x 8 scratch; order: maxTiles + maxScreenTiles
 void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight);
 uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);

@@ -1,30 +1,21 @@
 """Dispatch order of the view march (launchTileOrder): it may only change WHICH wavefront marches a tile, never the result.
 
-Same moving-camera frame sequence on a context with the cost-binned order and on one with list order (MV_TILE_ORDER=0, read
-at mv_create); the cube maps are cleared before every frame, so a tile the order skipped (or marched with another tile's
+Same moving-camera frame sequence on a context with the cost-binned order and on one with list order (MV_FLAG_LIST_ORDER);
+the cube maps are cleared before every frame, so a tile the order skipped (or marched with another tile's
 parameters) would show up as zeros / wrong texels, and the sample counters would differ.
 """
-import os
-
 import numpy as np
 import pytest
 
-from multivolumes_amd import MultiRayCaster, scene
+from multivolumes_amd import MultiRayCaster, _lib, scene
 from multivolumes_amd import raycaster as rc
 
 pytestmark = pytest.mark.gpu
 
 
 def sequence(cfg, vols, ordered, frames):
-    old = os.environ.pop("MV_TILE_ORDER", None)
-    if not ordered:
-        os.environ["MV_TILE_ORDER"] = "0"
-    try:
-        c = MultiRayCaster(cfg["N"], cfg["L"], cfg["V"], cfg["V"], (cfg["W"], cfg["H"]), shadowMapSize=64)
-    finally:
-        os.environ.pop("MV_TILE_ORDER", None)
-        if old is not None:
-            os.environ["MV_TILE_ORDER"] = old
+    c = MultiRayCaster(cfg["N"], cfg["L"], cfg["V"], cfg["V"], (cfg["W"], cfg["H"]), shadowMapSize=64,
+                       flags=0 if ordered else _lib.MV_FLAG_LIST_ORDER)
     out = []
     with c:
         fr = scene.setup_raycaster(c, cfg, vols)
