@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
     p.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of frame i+1's light march with frame i's view march")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--ray-queue", action="store_true", help="MV_FLAG_RAY_QUEUE: the two-stage ray-queue march instead of one wavefront per tile")
     p.add_argument("--no-light", action="store_true", help="DIAGNOSTIC (not a valid bench line): leave the light march out of the timed frames, to price it")
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
     p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
@@ -81,6 +82,8 @@ def main():
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
     M = 1024
     flags = _lib.MV_FLAG_FORCE_MIP0_ALL_FACES if args.stress else 0
+    if args.ray_queue:
+        flags |= _lib.MV_FLAG_RAY_QUEUE
     pipelined = not args.no_pipeline
     if pipelined:
         flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # frames in flight, like the reference's upload ring (MultiRayCaster.h:52)

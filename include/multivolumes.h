@@ -72,6 +72,10 @@ extern "C" {
 #define MV_FLAG_LIST_ORDER 8u				/* march the tiles in list order instead of the cost-binned order (longest rays first).  The order only
 										   decides which wavefront marches which ray and when: results are bit-identical either way (tests, A/B timing) */
 
+#define MV_FLAG_RAY_QUEUE 16u				/* view march as the two-stage device-side pipeline (ray setup -> persistent march that refills finished lanes from
+										   a ray queue: ballot compaction) instead of one wavefront per 8x8 tile.  Same results bit for bit; it pays when
+										   a frame has many rays per lane of the GPU */
+
 typedef struct mv_ctx mv_ctx;
 
 typedef struct mv_config

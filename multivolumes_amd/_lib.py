@@ -23,6 +23,7 @@ MV_FLAG_FORCE_MIP0_ALL_FACES = 1
 MV_FLAG_PIPELINE_FRAMES = 2
 MV_FLAG_SINGLE_VIEW_STREAM = 4
 MV_FLAG_LIST_ORDER = 8
+MV_FLAG_RAY_QUEUE = 16
 
 MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
 MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7

@@ -117,6 +117,8 @@ struct mv_ctx
 	hipEvent_t sliceDone[kFrameSlices] = {};
 	uint64_t* pinnedStats = nullptr;
 	uint32_t* pinnedCounters = nullptr;
+	unsigned long long* pinnedTiles = nullptr;	// written by the cull kernel: {frame tag : tile count} of the most recent cull that has run (a hint, never waited for)
+	bool rayQueue = false;				// MV_FLAG_RAY_QUEUE: the two-stage ray-queue march (mv_march.hip) instead of one wavefront per tile
 	uint8_t* pinnedCull = nullptr;		// counters + VolumeInfo + both lists + light table, one readback
 	uint64_t frame = 0;					// frames begun (mv_update_frame)
 	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
@@ -491,6 +493,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kFrameSlices + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices);
 	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices + 128);
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedTiles), 64, hipHostMallocCoherent) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
+	*ctx->pinnedTiles = ~0ull;
+	st.tilesReport = ctx->pinnedTiles;
+	ctx->rayQueue = (cfg->flags & MV_FLAG_RAY_QUEUE) != 0;
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	for (uint32_t i = 0; i < kFrameSlices; ++i)
 		if (hipEventCreateWithFlags(&ctx->sliceDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
@@ -527,6 +533,7 @@ void mv_destroy(mv_ctx* ctx)
 	if (ctx->dMeshMatrix) (void)hipFree(ctx->dMeshMatrix);
 	if (ctx->pinned) (void)hipHostFree(ctx->pinned);
 	if (ctx->pinnedCull) (void)hipHostFree(ctx->pinnedCull);
+	if (ctx->pinnedTiles) (void)hipHostFree(ctx->pinnedTiles);
 	if (ctx->ownStream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -698,6 +705,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	ctx->slot = (ctx->slot + 1u) % kFrameSlots;
 	++ctx->frame;
 	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
+	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);
 	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->slot], 0));
@@ -772,10 +780,31 @@ int mv_march_view(mv_ctx* ctx)
 	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (ctx->numOutSets % kFrameSlots)) % kFrameSlots], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 2, ev, streamB(ctx));
-	// ray setup -> march, both with fixed grids that read the tile count on the device: nothing between the cull and the march
-	// waits for the host (the shape of the work-graph variant, Sh/LibRayMarch.hlsl:39-134)
-	mv::launchRaySetup(streamB(ctx), ctx->st);
-	mv::launchMarchView(streamB(ctx), ctx->st);
+	// Nothing between the cull and the march waits for the host (the shape of the work-graph variant, Sh/LibRayMarch.hlsl:39-134).
+	if (ctx->rayQueue)
+	{
+		// ray setup -> persistent march: fixed grids that read the tile count on the device
+		mv::launchRaySetup(streamB(ctx), ctx->st);
+		mv::launchMarchView(streamB(ctx), ctx->st);
+	}
+	else
+	{
+		// One wavefront per tile.  Every cull leaves {frame : tile count} in pinned memory; the grid is sized from the most recent
+		// report there is -- this frame's, or the one or two frames older one if this frame's cull has not run yet -- plus a margin,
+		// with one plain read and no wait.  Tile counts move slowly from frame to frame; when one jumps past the margin (a volume
+		// changing scheme) the overflow launch inside launchMarchTiles marches the rest, so the estimate only affects speed.
+		uint32_t tiles = 0xffffffffu;
+		if (ctx->pinnedTiles)
+		{
+			const unsigned long long v = *reinterpret_cast<const volatile unsigned long long*>(ctx->pinnedTiles);
+			if (v != ~0ull)
+			{
+				const uint32_t count = (uint32_t)v;
+				tiles = (uint32_t)(v >> 32) == (uint32_t)ctx->frame ? count : count + count / 4u + 256u;
+			}
+		}
+		mv::launchMarchTiles(streamB(ctx), ctx->st, tiles);
+	}
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, stageBDone(ctx));

@@ -105,6 +105,9 @@ struct DeviceState
 	uint16_t* volumeInfo;			// V x 4
 	uint32_t* visibleVolumes;		// V
 	uint32_t* cubeMapVolumes;		// V
+	unsigned long long* tilesReport;	// pinned host memory (may be NULL): the cull stores {frameTag : tile count} here -- a HINT for the host's
+									// next grid sizes, read without ever waiting for it
+	uint32_t frameTag;				// low 32 bits of the context's frame counter
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
 									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow),
 									// [8] the cull's ticket, [9] head of the march's ray queue (device-only)
@@ -176,6 +179,8 @@ void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uin
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
+void launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// one wavefront per tile (mv_march_tiles.hip)
+uint32_t marchTilesResidentWaves(int device);
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
 uint32_t marchViewResidentWaves(int device, bool wideAddressing);	// wavefronts of the march kernel the device holds at once (occupancy query)

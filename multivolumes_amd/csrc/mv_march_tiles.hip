@@ -1,0 +1,319 @@
+// mv_march_tiles.hip -- a3 (+ the fused screen-space RayCast) as one wavefront per 8x8 tile: the reference's thread-group tile
+// (Sh/CSRayMarch.hlsl:77), ray setup and sample loop in one kernel, wavefronts dispatched by the hardware in the cost-binned
+// tile order.  This is the form the context uses when a frame has only a few rays per lane of the GPU (C3: 0.66 M rays on
+// 0.33 M resident lanes), where a wavefront's whole life is two or three tiles and the ray queue of mv_march.hip cannot pay for
+// its record traffic and refills ("tiles or ray queue").  Same arithmetic, same results, bit for bit.
+#include "mv_device.hpp"
+#include "mv_kernels.hpp"
+
+namespace mv
+{
+#ifndef MV_TILE_WAVES
+#define MV_TILE_WAVES 2	// independent wavefronts per workgroup. Measured at C3: 1 -> 0.357 ms, 2 -> 0.352, 4 -> 0.364, 8 -> 0.416
+#endif
+constexpr uint32_t kTileWaves = MV_TILE_WAVES;
+#ifndef MV_ALPHA_FROM_TEXELS
+#define MV_ALPHA_FROM_TEXELS 1	// measured: 0.39 vs 0.44 ms at C3, 0.98 vs 0.99 ms at C3-stress (the alpha-cell form adds an HBM round trip to lit samples)
+#endif
+#ifndef MV_OCCUPANCY
+#define MV_OCCUPANCY 1	// skip the texel fetch of samples whose brick occupancy bit is clear (results unchanged by construction)
+#endif
+#ifndef MV_PREDICT_LIT
+#define MV_PREDICT_LIT 1
+#endif
+#ifndef MV_TILE_MIN_WAVES
+#define MV_TILE_MIN_WAVES 3	// occupancy bound given to the register allocator / scheduler. Measured at C3: 3 -> 0.360 ms, 5 -> 0.395, 6 -> 0.414,
+							// 7 -> 0.46, 8 -> 0.60 (spills); all of 1..5 allocate about 90 VGPRs, the looser bound schedules loads earlier
+#endif
+
+static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+	return v;
+}
+
+// OVERFLOW = false: the main launch, wavefront w marches dispatch slot w.  OVERFLOW = true: a small second launch that marches every
+// slot from `firstSlot` on, a grid apart (the loop costs 20 VGPRs, i.e. one wavefront per SIMD, which is why the main launch has none).
+template <bool OVERFLOW>
+__global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesKernel(DeviceState st, uint32_t firstSlot)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
+
+	// Dispatch slot -> tile: list order or the cost-binned order (tileOrderKernel).  Workgroups are dealt round-robin over the 8
+	// XCDs, so every XCD sees an even mix of volumes and of cube / screen tiles; placement only affects speed.
+	// The host sizes the main grid from the most recent tile count the cull has reported (plus a margin) without ever waiting for
+	// this frame's: wavefronts beyond the real count exit at once, and if the count grew past the grid the overflow launch that
+	// follows marches the rest.
+	for (uint32_t slot = firstSlot + blockIdx.x * kTileWaves + wave; slot < nTiles; slot += OVERFLOW ? gridDim.x * kTileWaves : 0xffffffffu - slot)
+	{
+	uint32_t tile = slot;
+	tile = __builtin_amdgcn_readfirstlane(tile);
+	if (st.tileOrder) tile = __builtin_amdgcn_readfirstlane(st.tileOrder[slot]);
+
+	// find the work entry that owns this tile (wave-uniform)
+	uint32_t entry = 0;
+	for (uint32_t base = 0; base < nEntries; base += 64)
+	{
+		const uint32_t i = base + lane;
+		const bool hit = i < nEntries && st.workTileStart[i] <= tile && tile < st.workTileStart[i + 1];
+		const uint64_t b = __ballot(hit);
+		if (b) { entry = base + (uint32_t)__ffsll((unsigned long long)b) - 1u; break; }
+	}
+	entry = __builtin_amdgcn_readfirstlane(entry);
+	const uint32_t we = st.workEntries[entry];
+	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16;
+	const uint32_t localTile = tile - st.workTileStart[entry];
+
+	const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId];	// CSRayMarch.hlsl:81
+	const uint32_t mipLevel = vi.x, smpCount = vi.y, volTexId = vi.w;
+	const PerObject& po = reinterpret_cast<const PerObject*>(st.perObject)[volumeId];
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	const bool screenTile = faceId == 7u;	// wave-uniform
+
+	// ---- ray setup: a cube-face texel (CSRayMarch.hlsl:84-107) or a screen pixel of a RayCast volume (RayCast.hlsli:43-54)
+	uint32_t nSamples = 0, nLit = 0, nRays = 0, nSkipped = 0;
+	bool valid = false;
+	vec3 rayOrigin = mul43(v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]), po.worldI);	// :89
+	vec3 rayDir = v3(0.0f, 0.0f, 1.0f);
+	float tMax = 0.0f;
+	size_t outIndex = 0;
+	if (!screenTile)
+	{
+		const uint32_t dims = st.N >> mipLevel;
+		const uint32_t tilesX = (dims + 7u) >> 3;
+		const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
+		if (px < dims && py < dims)
+		{
+			const vec3 target = GetLocalPos((float)px, (float)py, faceId, (float)dims);
+			rayDir = normalize3(target - rayOrigin);
+			if (ComputeRayOrigin(rayOrigin, rayDir))	// :96
+			{
+				tMax = ComputeTargetHit(rayOrigin, target, rayDir);
+				outIndex = (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
+
+				// GetClipPos (:59-71)
+				vec3 clip;
+				{
+					vec4 hPos;
+					hPos.x = __builtin_fmaf(0.01f, rayDir.x, rayOrigin.x);
+					hPos.y = __builtin_fmaf(0.01f, rayDir.y, rayOrigin.y);
+					hPos.z = __builtin_fmaf(0.01f, rayDir.z, rayOrigin.z);
+					hPos.w = 1.0f;
+					hPos = mul44(hPos, po.wvp);
+					const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
+					const float u = cx * 0.5f + 0.5f;
+					float v = cy * 0.5f + 0.5f;
+					v = 1.0f - v;
+					clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
+				}
+				st.cubeDepths[outIndex] = clip.z;	// :105
+				tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
+				valid = true;
+				nRays = 1;
+			}
+		}
+	}
+	else
+	{
+		// screen rectangle of the volume, clipped to the viewport, in 8x8 pixel tiles
+		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
+		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
+		const uint32_t tx0 = rect.x >> 3, ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3, tw = (x1 >> 3) - tx0 + 1u;
+		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (ty0 + localTile / tw) * 8u + (lane >> 3);
+		if (px < st.W && py < st.H)
+		{
+			// PSCube.hlsl:37-39, then the fragment the rasteriser would have produced for this volume at this pixel
+			float nx = ((float)px + 0.5f) / (float)st.W, ny = ((float)py + 0.5f) / (float)st.H;
+			nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
+			vec3 lpt;
+			float z;
+			outIndex = ((size_t)st.screenSlot[volumeId] * st.H + py) * st.W + px;
+			if (findExitFragment(po, rayOrigin, pixelRayWorld(cb, nx, ny), lpt, z))
+			{
+				rayDir = normalize3(lpt - rayOrigin);	// PSCube.hlsl:33, 50: normalize(input.LPt - localSpaceEyePt)
+				float4 zero; zero.x = zero.y = zero.z = zero.w = 0.0f;
+				st.screenLayers[outIndex] = zero;	// RayCast returns 0 on a miss (RayCast.hlsli:46)
+				if (ComputeRayOrigin(rayOrigin, rayDir))
+				{
+					const float depthPix = st.depthMap[(size_t)py * st.W + px];
+					tMax = GetTMax(v3(nx, ny, depthPix), rayOrigin, rayDir, po.wvpI);	// RayCast.hlsli:50-51 (no ComputeTargetHit clamp)
+					valid = true;
+				}
+			}
+		}
+	}
+
+	if (valid)
+	{
+		{
+			const float stepScale = kMaxDist / (float)smpCount;
+			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
+			const uint4* lightQuads = st.lightTable[volumeId];
+
+			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
+			float t = 0.0f;
+			float prevDensity = 0.0f;
+			// The loop at :117-153.  One aligned 16-byte alpha-cell load decides the alpha test (:128); only lit samples
+			// fetch the eight RGBA16F texels and the two light-map quads (issued together: one round trip).
+			bool prevLit = false;
+#if MV_OCCUPANCY
+			const uint64_t* occupancy = st.occupancy[volTexId];
+			const uint32_t regions = occupancyRegions(st.bricks);
+			uint32_t occIndex = 0xffffffffu;
+			uint64_t occWord = 0;
+#endif
+			for (uint32_t i = 0; i < smpCount; ++i)
+			{
+				const vec3 pos = rayAt(rayOrigin, rayDir, t);
+				if (outsideBox(pos)) break;	// :120
+				const vec3 uvw = LocalToTex3DSpace(pos);
+
+				const FootprintAddr fa = footprintAddr(vol, uvw);
+#if MV_OCCUPANCY
+				// Empty space: a clear occupancy bit proves alpha <= ZERO_THRESHOLD, for which the loop below only advances t.
+				// At C3 this skips the fetch of 44 % of the samples (87 % of the unlit ones): 0.325 -> 0.258 ms, HBM traffic
+				// 1.66 -> 1.24 GB per launch.  One 64-bit word covers a 16^3-texel region and is reloaded (an L2 hit) when the
+				// ray enters another one; requesting the next region's word ahead of time was measured slower (0.289 ms).
+				{
+					const uint32_t w = occupancyWord(fa.ix, fa.iy, fa.iz, regions);
+					if (w != occIndex) { occWord = occupancy[w]; occIndex = w; }
+					if (!((occWord >> occupancyBit(fa.ix, fa.iy, fa.iz)) & 1ull))
+					{
+						++nSamples;
+						++nSkipped;
+						prevLit = false;
+						t += stepScale;
+						if (t > tMax) break;	// :152
+						continue;
+					}
+				}
+#endif
+#if MV_ALPHA_FROM_TEXELS
+				// latency-oriented form: the eight RGBA texels are fetched unconditionally and alpha comes from them
+				ColourFootprint cf = fetchColour(vol, fa);
+				LightFootprint lf;
+				const bool early = MV_PREDICT_LIT && prevLit;
+				if (early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+				const float alpha = resolveAlphaFromTexels(cf);
+				++nSamples;
+				float newStep = stepScale;
+				const bool lit = alpha > kZeroThreshold;	// :128
+				prevLit = lit;
+				if (lit)
+				{
+					if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+#else
+				const AlphaFootprint ac = fetchAlphaCell(vol, fa);
+				// A ray's samples are a dependent chain, so its time is made of memory round trips.  Lit samples come in runs:
+				// when the previous sample was lit, the colour texels and the light quads are requested together with the alpha
+				// cell (one round trip for the whole sample); otherwise only the 16-byte cell is read and empty space costs one
+				// load per sample.  Prediction only changes which loads are issued, never the arithmetic.
+				LightFootprint lf;
+				ColourFootprint cf;
+				const bool early = MV_PREDICT_LIT && prevLit;
+				if (early)
+				{
+					if constexpr (X != 1) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+					if constexpr (X != 2) cf = fetchColour(vol, fa);
+				}
+				const float alpha = resolveAlpha(ac);	// GetSample(...).w (RayMarch.hlsli:44-50)
+				++nSamples;
+				float newStep = stepScale;
+				const bool lit = alpha > kZeroThreshold;	// :128
+				prevLit = lit;
+
+				if (lit)
+				{
+					if (!early)
+					{
+						lf = fetchLightFootprint(lightQuads, st.L, uvw);	// GetLight (RayMarch.hlsli:235-240): same pos * 0.5 + 0.5
+						cf = fetchColour(vol, fa);
+					}
+#endif
+					const vec3 light = resolveLight(lf);
+					vec3 color = resolveRGB(cf);
+					++nLit;
+
+					const float transm = 1.0f - scatter.w;
+					const float dDensity = alpha - prevDensity;
+					newStep = GetStep(dDensity, transm, alpha, stepScale);
+					prevDensity = alpha;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
+
+					color.x *= alpha; color.y *= alpha; color.z *= alpha;	// :140-142 not pre-multiplied
+					color.x *= light.x; color.y *= light.y; color.z *= light.z;
+					scatter.x += color.x * kAbsorption * transm;
+					scatter.y += color.y * kAbsorption * transm;
+					scatter.z += color.z * kAbsorption * transm;
+					scatter.w += alpha * kAbsorption * transm;
+
+					if (transm < kZeroThreshold) break;	// :146
+				}
+
+				t += newStep;
+				if (t > tMax) break;	// :152
+			}
+
+			const float twoPi = 2.0f * kPI;
+			scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;	// :155
+
+			if (!screenTile)
+			{
+				uint2 o;
+				o.x = (uint32_t)float_to_half_bits(scatter.x) | ((uint32_t)float_to_half_bits(scatter.y) << 16);
+				o.y = (uint32_t)float_to_half_bits(scatter.z) | ((uint32_t)float_to_half_bits(scatter.w) << 16);
+				st.cubeMaps[outIndex] = o;	// :157
+			}
+			else
+			{
+				float4 o; o.x = scatter.x; o.y = scatter.y; o.z = scatter.z; o.w = scatter.w;
+				st.screenLayers[outIndex] = o;	// what RayCast returns (RayCast.hlsli:107); the composite applies PSCube.hlsl:56
+			}
+		}
+	}
+
+	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays), totK = waveSumU32(nSkipped);
+	uint32_t maxS = nSamples;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
+	const uint32_t nCubeTiles = st.counters[6];
+	if (lane == 0)
+	{
+		st.tileCost[tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles)] = maxS;
+		// counters: a slot of the wave-stats table shared by the tiles that map to it (no-return atomics, once per tile)
+		unsigned long long* s = reinterpret_cast<unsigned long long*>(st.waveStats) + (size_t)(slot % st.marchWaves) * 8u;
+		if (!screenTile)
+		{
+			atomicAdd(s + 0, (unsigned long long)totS); atomicAdd(s + 1, (unsigned long long)totL); atomicAdd(s + 2, (unsigned long long)totR);
+			atomicAdd(s + 3, (unsigned long long)maxS * 64ull);	// lane slots the wave occupied (utilisation = view samples / slots)
+		}
+		else { atomicAdd(s + 4, (unsigned long long)totS); atomicAdd(s + 5, (unsigned long long)totL); }
+		if (totK) atomicAdd(s + 6, (unsigned long long)totK);
+	}
+	if (!OVERFLOW) break;
+	}
+}
+
+uint32_t marchTilesResidentWaves(int device)
+{
+	int perCu = 0, cus = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, marchTilesKernel<false>, 64 * kTileWaves, 0) != hipSuccess || perCu <= 0) perCu = 8;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+	return (uint32_t)perCu * (uint32_t)cus * kTileWaves;
+}
+
+void launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
+{
+	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has
+	// none).  The main grid covers min(estimate, largest possible frame); the overflow launch covers whatever lies beyond it.
+	const uint64_t maxTiles = (uint64_t)st.maxTiles + st.maxScreenTiles;
+	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
+	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
+	blocks = ((blocks + 7) / 8) * 8;
+	hipLaunchKernelGGL(marchTilesKernel<false>, dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+	if (blocks * kTileWaves < maxTiles)
+		hipLaunchKernelGGL(marchTilesKernel<true>, dim3(256), dim3(64 * kTileWaves), 0, s, st, (uint32_t)(blocks * kTileWaves));
+}
+} // namespace mv

@@ -264,3 +264,44 @@ def test_a_frame_without_light_march_keeps_the_light_maps(flags):
         from multivolumes_amd._lib import MVError
         with pytest.raises(MVError):
             c.rayMarchL()  # after the frame's view march: refused (the frame already reads the kept maps)
+
+
+@pytest.mark.parametrize("flags", [0, _lib.MV_FLAG_PIPELINE_FRAMES, _lib.MV_FLAG_RAY_QUEUE])
+def test_tile_count_jumps_between_frames(flags):
+    """The view-march grid is sized from the tile count of an EARLIER frame (the host never waits for the current cull): a
+    camera that jumps between far and near multiplies the tile count from one frame to the next, far beyond the margin, and
+    the overflow launch must march the rest.  Every frame is compared with a fresh context (no earlier report: upper-bound
+    grid) rendering the same camera."""
+    cfg = dict(scene.CONFIGS["T1"], W=320, H=240, N=64)
+    V = cfg["V"]
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+    eye0 = np.array(scene.camera(cfg)[0], np.float32)
+    eyes = [eye0 * s for s in (3.0, 0.45, 3.0, 0.5, 2.5, 0.45)]
+
+    def render(c, fr, e):
+        vp = rc.multiply(rc.look_at_lh(e, (0, 0, 0)), rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0))
+        c.UpdateFrame(vp, fr["shadowVP"], e)
+        c.Render(composite=True)
+        info = c.ReadBackVolumeInfo()
+        vis, cube = c.ReadBackVisibleLists()
+        return info, [c.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube], c.ReadBackComposite(), c.GetStats()["rays"]
+
+    with make_caster(cfg, 64, flags=flags) as c:
+        fr = scene.setup_raycaster(c, cfg, vols)
+        seq = []
+        for e in eyes:
+            c.ClearCubeMaps()
+            c.ResetStats()
+            c.m_frameIdx = 0
+            seq.append(render(c, fr, e))
+    rays = [s[3] for s in seq]
+    assert max(rays) > 2.5 * min(rays), f"the tile count must jump: {rays}"
+    for e, got in zip(eyes, seq):
+        with make_caster(cfg, 64) as ref:
+            fr = scene.setup_raycaster(ref, cfg, vols)
+            ref.m_frameIdx = 0
+            exp = render(ref, fr, e)
+        assert np.array_equal(exp[0], got[0]) and exp[3] == got[3]
+        for a, b in zip(exp[1], got[1]):
+            assert np.array_equal(a, b)
+        assert np.array_equal(exp[2], got[2])
