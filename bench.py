@@ -32,6 +32,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def march_source_hash():
+    """Hash of the sources that decide the view march's memory traffic: profiles/traffic.json carries the hash it was measured
+    at, and a stale measurement is not reported (scripts/make_profiles.sh regenerates it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mv_march_tiles.hip", "mv_march.hip", "mv_device.hpp", "mv_kernels.hpp", "mv_kernels.hip"):
+        with open(os.path.join(ROOT, "multivolumes_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
@@ -42,6 +53,10 @@ def parse():
     p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
     p.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of frame i+1's light march with frame i's view march")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--orbit", action="store_true", help="the camera moves every frame (an arc around the scene, there and back) instead of standing still: "
+                   "cull results, mips and the tile order's cost feedback (four frames old) then change from frame to frame")
+    p.add_argument("--mesh", action="store_true", help="depth / shadow maps rasterised on the GPU from the reference scenes' mesh (bunny.obj at 0 -9 0 x1.8, "
+                   "Bin/all16.bat:1) instead of the analytic sphere")
     p.add_argument("--ray-queue", action="store_true", help="MV_FLAG_RAY_QUEUE: the two-stage ray-queue march instead of one wavefront per tile")
     p.add_argument("--no-light", action="store_true", help="DIAGNOSTIC (not a valid bench line): leave the light march out of the timed frames, to price it")
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
@@ -108,6 +123,35 @@ def main():
         if rank == 0 and not args.no_cpu_baseline:
             vols_host[k] = v
     fr = scene.setup_raycaster(caster, cfg)
+    mesh = scene.load_bunny() if (args.mesh and cfg["mesh"]) else None
+    if mesh is not None:
+        scene.render_mesh_targets(caster, cfg, fr["viewProj"], mesh)  # replaces the analytic sphere's maps
+        fr["depth"] = caster.ReadBackDepthMap()
+    # --orbit: ORBIT_N camera positions 0.004 rad apart on an arc through the default eye point, visited there and back; the depth
+    # map of every position is made once, kept in HBM, and handed over per frame as a borrowed device pointer (as the reference
+    # hands over ObjectRenderer's depth buffer): no upload and no host wait inside the timed frames.
+    orbit = None
+    if args.orbit:
+        ORBIT_N = 128
+        e0 = np.asarray(fr["eye"], np.float64)
+        r, a0 = float(np.hypot(e0[0], e0[2])), float(np.arctan2(e0[0], -e0[2]))
+        proj = rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / float(cfg["H"]), scene.Z_NEAR, scene.Z_FAR)
+        orbit = []
+        for j in range(ORBIT_N):
+            a = a0 + 0.004 * j
+            e = np.array([r * np.sin(a), e0[1] * (1.0 + 0.25 * np.sin(3.0 * (a - a0))), -r * np.cos(a)], np.float32)
+            vp = rc.multiply(rc.look_at_lh(e, (0.0, 0.0, 0.0)), proj)
+            if mesh is not None:
+                scene.render_mesh_targets(caster, cfg, vp)
+                d = torch.from_numpy(caster.ReadBackDepthMap()).cuda()
+            elif cfg["mesh"]:
+                d = torch.from_numpy(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0.0, 0.0, 0.0), scene.SPHERE_RADIUS)).cuda()
+            else:
+                d = torch.ones((cfg["H"], cfg["W"]), dtype=torch.float32, device="cuda")
+            orbit.append((e, vp, d))
+        if mesh is not None:
+            scene.render_mesh_targets(caster, cfg, fr["viewProj"])  # (the shadow map does not depend on the camera)
+        torch.cuda.synchronize()
     t_setup = time.time() - t0
     do_composite = not args.no_composite
 
@@ -120,9 +164,20 @@ def main():
     xbytes = [0]
     skip_light = [False]
 
+    nframe = [0]
+    last_depth = [None]
+
     def frame(with_exchange=True):
         frame_idx = caster.m_frameIdx
-        caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        if orbit is None:
+            caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        else:
+            j = nframe[0] % (2 * len(orbit) - 2)
+            e, vp, d = orbit[j if j < len(orbit) else 2 * len(orbit) - 2 - j]
+            nframe[0] += 1
+            caster.SetRenderTargets(depthMapDevice=d.data_ptr())
+            caster.UpdateFrame(vp, fr["shadowVP"], e)
+            last_depth[0] = d
         if world == 1 and skip_light[0]:
             caster.cullVolumes()
             caster.rayMarchV()
@@ -214,13 +269,22 @@ def main():
         # rank-0 marchV launch: algorithmic bytes per launch (the counters cover every timed frame) / average launch duration
         # the view-march launch also marches the screen-space RayCast tiles (composite_samples) on single-GPU contexts
         fused = st["composite_samples"]  # the screen-space RayCast samples of this rank's rows, marched by the same launch
+        alg_a3 = (64 * st["view_samples"] + 32 * st["lit_samples"] + 16 * st["rays"]) / K  # SURVEY 8(d)'s unit: the a3 loop over cube-face texels
         alg_bytes = (64 * (st["view_samples"] + fused) + 32 * (st["lit_samples"] + st["fused_raycast_lit"]) + 16 * st["rays"]) / K
         achieved = alg_bytes / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0
-        traffic = None
+        # measured HBM traffic of the launch: PMC counters cannot be read from inside this process, so the figure comes from the
+        # rocprofv3 passes of scripts/make_profiles.sh -- and only if it was measured on the sources that are in the tree now
+        traffic, traffic_note = None, "no measurement under profiles/traffic.json"
         tf = os.path.join(ROOT, "profiles", "traffic.json")
+        key = f"{args.config}{'-stress' if args.stress else ''}" + ("-rayqueue" if args.ray_queue else "")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(f"{args.config}{'-stress' if args.stress else ''}", {}).get("marchViewKernel_hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                if tj.get("source_hash") != march_source_hash():
+                    traffic_note = "profiles/traffic.json was measured on other kernel sources: not reported (rerun scripts/make_profiles.sh)"
+                elif key in tj:
+                    traffic = tj[key].get("marchViewKernel_hbm_bytes_per_launch")
+                    traffic_note = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/make_profiles.sh on these sources (2 x FETCH_SIZE + WRITE_SIZE)"
             except Exception:
                 traffic = None
         # SURVEY 8(d) asks for two more reference points beside the spec peak: what a plain device copy reaches on this box, and the
@@ -249,7 +313,8 @@ def main():
             "config": {
                 "workload": f"{args.config}{'-stress' if args.stress else ''}: {V}x{N}^3 RGBA16F volumes, {cfg['W']}x{cfg['H']} viewport, "
                             f"{cfg['maxRay']} steps/ray, light grid {L}^3 x {cfg['maxLight']} light steps"
-                            + (", mesh depth occlusion (analytic sphere)" if cfg["mesh"] else ""),
+                            + ((", mesh depth occlusion (bunny mesh rasterised on the GPU)" if args.mesh else ", mesh depth occlusion (analytic sphere)") if cfg["mesh"] else "")
+                            + (", orbiting camera" if args.orbit else ""),
                 "visible_volumes": int(len(vis)), "cube_map_volumes": int(len(cube)),
                 "selected_mips": sorted(set(int(info[v, 0]) for v in vis)),
                 "samples_per_ray_cap": [int(info[v, 1]) for v in vis][:4],
@@ -265,9 +330,15 @@ def main():
             "kernel_ms": k_alone, "kernel_ms_in_flight": k_in_flight,
             "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,
             "light_msamples_per_s": tot_light / dt / 1e6,
-            "roofline": {"bound": "hbm", "kernel": "marchViewKernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": ms_v,
+            "roofline": {"bound": "hbm", "kernel": "marchViewKernel (mv_march.hip ray queue)" if args.ray_queue else "marchTilesKernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+                         # `achieved` / `frac` price ALGORITHMIC bytes (64 B per sample whether or not its texels were fetched or came from
+                         # cache): they can exceed what HBM delivers.  What HBM really moved per launch is `traffic`:
+                         "hbm_achieved": (traffic / (ms_v * 1e-3) / 1e9) if (traffic and ms_v > 0) else None,
+                         "hbm_frac": (traffic / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and ms_v > 0) else None,
+                         "frac_a3": (alg_a3 / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_v > 0 else None,
+                         "frac_a3_note": "cube-face samples only (the a3 loop); the launch also marches the fused screen-space RayCast tiles counted in `frac`",
+                         "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_a3_per_launch": alg_a3, "launch_ms": ms_v,
                          "requested_bytes_per_launch": alg_bytes - 64 * st.get("fetch_free_samples", 0) / K,
                          "compulsory_footprint_bytes": compulsory, "device_copy_measured": copy_gbs, "device_copy_unit": "GB/s (read + write)",
                          "launch_ms_in_flight": k_in_flight["march_view"],
@@ -278,6 +349,8 @@ def main():
         if args.no_light:
             out["INVALID"] = "--no-light: the light march was left out of the timed frames (diagnostic run)"
         if not args.no_cpu_baseline:
+            if last_depth[0] is not None:
+                fr["depth"] = last_depth[0].cpu().numpy()  # the depth map of the frame the buffers hold
             out["cpu_baseline"] = cpu_baseline(args, cfg, caster, fr, info, cube, vols_host)
         print(json.dumps(out))
     caster.close()
@@ -315,6 +388,7 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
         got = caster.ReadBackCubeMap(v, mip).view(np.float16).astype(np.float32)
         worst = max(worst, float(np.max(np.abs(exp - got))))
     return {"value": st["view_samples"] / dt / 1e6, "unit": "Msamples/s", "cores": o.load().mvo_num_threads(), "kind": "port",
+            "build": "oracle/mv_oracle.cpp, g++ -O3 -ffp-contract=off -fopenmp (the reference's HLSL path cannot run here)",
             "sample": f"marchV of {len(sel)} of the {len(cube)} cube-map volumes of the same frame ({st['view_samples']} samples, {dt:.2f} s)",
             "gpu_vs_oracle_max_abs_err": worst}
 

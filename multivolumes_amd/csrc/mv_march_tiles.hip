@@ -12,9 +12,8 @@ namespace mv
 #define MV_TILE_WAVES 2	// independent wavefronts per workgroup. Measured at C3: 1 -> 0.357 ms, 2 -> 0.352, 4 -> 0.364, 8 -> 0.416
 #endif
 constexpr uint32_t kTileWaves = MV_TILE_WAVES;
-#ifndef MV_ALPHA_FROM_TEXELS
-#define MV_ALPHA_FROM_TEXELS 1	// measured: 0.39 vs 0.44 ms at C3, 0.98 vs 0.99 ms at C3-stress (the alpha-cell form adds an HBM round trip to lit samples)
-#endif
+// (alpha comes from the eight RGBA texels themselves: testing a separate alpha structure first adds an HBM round trip to every lit
+// sample -- measured 0.44 vs 0.39 ms at C3)
 #ifndef MV_OCCUPANCY
 #define MV_OCCUPANCY 1	// skip the texel fetch of samples whose brick occupancy bit is clear (results unchanged by construction)
 #endif
@@ -191,7 +190,6 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 					}
 				}
 #endif
-#if MV_ALPHA_FROM_TEXELS
 				// latency-oriented form: the eight RGBA texels are fetched unconditionally and alpha comes from them
 				ColourFootprint cf = fetchColour(vol, fa);
 				LightFootprint lf;
@@ -205,34 +203,6 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 				if (lit)
 				{
 					if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
-#else
-				const AlphaFootprint ac = fetchAlphaCell(vol, fa);
-				// A ray's samples are a dependent chain, so its time is made of memory round trips.  Lit samples come in runs:
-				// when the previous sample was lit, the colour texels and the light quads are requested together with the alpha
-				// cell (one round trip for the whole sample); otherwise only the 16-byte cell is read and empty space costs one
-				// load per sample.  Prediction only changes which loads are issued, never the arithmetic.
-				LightFootprint lf;
-				ColourFootprint cf;
-				const bool early = MV_PREDICT_LIT && prevLit;
-				if (early)
-				{
-					if constexpr (X != 1) lf = fetchLightFootprint(lightQuads, st.L, uvw);
-					if constexpr (X != 2) cf = fetchColour(vol, fa);
-				}
-				const float alpha = resolveAlpha(ac);	// GetSample(...).w (RayMarch.hlsli:44-50)
-				++nSamples;
-				float newStep = stepScale;
-				const bool lit = alpha > kZeroThreshold;	// :128
-				prevLit = lit;
-
-				if (lit)
-				{
-					if (!early)
-					{
-						lf = fetchLightFootprint(lightQuads, st.L, uvw);	// GetLight (RayMarch.hlsli:235-240): same pos * 0.5 + 0.5
-						cf = fetchColour(vol, fa);
-					}
-#endif
 					const vec3 light = resolveLight(lf);
 					vec3 color = resolveRGB(cf);
 					++nLit;

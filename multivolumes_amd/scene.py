@@ -1,6 +1,7 @@
 """The benchmark / test scenes of BASELINE.json (C1..C5) built from the reference's own defaults
 (MultiVolumes.cpp:38-47, 264-279, 339-346; all{4,16,64}.bat) and the synthetic inputs of SURVEY.md 8(d)."""
 import math
+import os
 
 import numpy as np
 
@@ -52,6 +53,33 @@ def depth_and_shadow(cfg, view_proj, shadow_vp_t, M):
         depth = np.ones((H, W), np.float32)
         shadow = np.full((M, M), 65535, np.uint16)
     return depth, shadow
+
+
+MESH_POS, MESH_SCALE = (0.0, -9.0, 0.0), 1.8  # `-mesh Assets/bunny.obj 0.0 -9.0 0.0 1.8` (Bin/all16.bat:1, all64.bat:1)
+BUNNY_FIXTURE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "bunny_mesh.npz")
+
+
+def load_bunny():
+    """(positions[n, 3] f32, indices[m, 3] u32) of the reference scenes' mesh (fixture made by tests/golden/make_bunny_fixture.py)."""
+    d = np.load(BUNNY_FIXTURE)
+    return d["positions"], d["indices"]
+
+
+def mesh_matrices(cfg, view_proj, scale=MESH_SCALE, pos=MESH_POS):
+    """(world * viewProj, world * lightViewProj) of the mesh, row-major: what ObjectRenderer::UpdateFrame uploads
+    (ObjectRenderer.cpp:171-207, no TAA jitter)."""
+    world = rc.mesh_world(scale, pos)
+    svp_t = shadow_vp(dict(cfg, mesh=True))  # transposed light view-projection
+    return rc.multiply(world, view_proj), rc.multiply(world, svp_t.T.copy())
+
+
+def render_mesh_targets(caster, cfg, view_proj, mesh=None):
+    """Depth + shadow maps of the reference scenes' mesh, rasterised on the GPU by the context (mv_mesh_render_*)."""
+    if mesh is not None:
+        caster.SetMesh(*mesh)
+    wvp, swvp = mesh_matrices(cfg, view_proj)
+    caster.RenderMeshDepth(wvp)
+    caster.RenderMeshShadow(swvp)
 
 
 DEFAULT_SH = np.array([

@@ -305,3 +305,51 @@ def test_tile_count_jumps_between_frames(flags):
         for a, b in zip(exp[1], got[1]):
             assert np.array_equal(a, b)
         assert np.array_equal(exp[2], got[2])
+
+
+def test_c3_with_the_reference_scenes_mesh(oracle):
+    """BASELINE.json configs[2] with the mesh of the reference's own scene (`-mesh Assets/bunny.obj 0 -9 0 1.8`, Bin/all16.bat:1)
+    as the source of the depth and shadow maps: rasterised on the GPU (mv_mesh_render_*) bit for bit like the oracle rasteriser,
+    then the whole C3 frame -- cull, 16 light marches, view march -- against the oracle on those maps."""
+    from tests.helpers import default_descs, host_frame
+    cfg = scene.CONFIGS["C3"]
+    V, N, L, W, H = cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"]
+    M = 1024
+    pos, idx = scene.load_bunny()
+    assert len(idx) == 69666
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    with make_caster(cfg, M) as c:
+        fr = scene.setup_raycaster(c, cfg, vols)
+        scene.render_mesh_targets(c, cfg, fr["viewProj"], (pos, idx))
+        depth, shadow = c.ReadBackDepthMap(), c.ReadBackShadowMap()
+        wvp, swvp = scene.mesh_matrices(cfg, fr["viewProj"])
+        exp_d = oracle.raster_depth(pos, idx, rc.transpose_store(wvp), W, H)
+        exp_s = oracle.depth_to_d16(oracle.raster_depth(pos, idx, rc.transpose_store(swvp), M, M))
+        assert (exp_d < 1).sum() > 20000 and (exp_s < 65535).sum() > 20000, "the bunny covers a good part of both maps"
+        assert np.array_equal(depth, exp_d) and np.array_equal(shadow, exp_s)
+
+        relight_all(c, fr, V)
+        c.rayMarchV()
+        c.synchronize()
+        info = c.ReadBackVolumeInfo()
+        vis, cube = c.ReadBackVisibleLists()
+
+        # the oracle's frame on the rasterised maps
+        descs = default_descs(V, V, N)
+        _, _, _, cb, po = host_frame(cfg, 0)
+        oinfo, ovis, ocube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+        assert np.array_equal(info, oinfo) and np.array_equal(vis, ovis) and np.array_equal(cube, ocube)
+        lms = None
+        for f in range(V):
+            _, _, _, cbf, pof = host_frame(cfg, f)
+            _, lms, _ = oracle.march_light(V, N, L, M, vols, descs, pof, cbf, exp_s, None, ovis, cfg["maxLight"], lms)
+        for v in vis:
+            assert np.array_equal(c.ReadBackLightMap(int(v)), lms[v]), f"light map {v}"
+        _, _, _, cbl, pol = host_frame(cfg, V - 1)
+        cm, cd, st = oracle.march_view(V, N, L, W, H, vols, lms, exp_d, pol, cbl, oinfo, ocube)
+        for v in cube:
+            mip = int(info[v, 0])
+            assert np.array_equal(c.ReadBackCubeMap(int(v), mip), oracle.cube_face_view(cm[v], N, mip)), f"cube map {v}"
+            assert np.array_equal(c.ReadBackCubeDepth(int(v), mip), oracle.cube_face_view(cd[v], N, mip)), f"cube depth {v}"
+        g = c.GetStats()
+        assert g["view_samples"] == st["view_samples"] and g["lit_samples"] == st["lit_samples"] and g["rays"] == st["rays"]
