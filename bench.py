@@ -102,10 +102,12 @@ def main():
     pipelined = not args.no_pipeline
     if pipelined:
         flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
-        if world > 1:
-            # the RCCL collectives are ordered on the context's (= torch's current) stream between the view march and the composite:
-            # only upload, cull and light march run ahead
-            flags |= _lib.MV_FLAG_SINGLE_VIEW_STREAM
+    if world > 1:
+        # the in-library frame loop needs two output sets with every view march on the context's stream (mv_dist_frame)
+        if not pipelined and rank == 0:
+            print("warning: --no-pipeline is ignored with --gpus > 1", file=sys.stderr)
+        pipelined = True
+        flags |= _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
     # a real (non-blocking) torch stream, made current so that the RCCL collectives of the multi-GPU path are ordered on it too:
     # torch's default is the legacy null stream, whose implicit synchronisation rules cost the pipelined frame ~20 %
     if os.environ.get("MV_BENCH_NULL_STREAM", "0") != "1":
@@ -156,8 +158,8 @@ def main():
     do_composite = not args.no_composite
 
     from multivolumes_amd import distributed as D
-    cube_xchg = D.CubeFaceExchange(caster) if world > 1 else None
-    light_xchg = D.LightMapExchange(caster) if world > 1 else None
+    # N > 1: the per-frame protocol runs inside the library (mv_dist_frame); torch.distributed only distributes the RCCL ids
+    exchange = D.init_frame_loop(caster) if world > 1 else None
     H, W = cfg["H"], cfg["W"]
     band = D.row_range(H, rank, world)
     assert band == caster.ShardRows()
@@ -168,37 +170,27 @@ def main():
     last_depth = [None]
 
     def frame(with_exchange=True):
-        frame_idx = caster.m_frameIdx
-        if orbit is None:
-            caster.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
-        else:
+        e, vp = fr["eye"], fr["viewProj"]
+        if orbit is not None:
             j = nframe[0] % (2 * len(orbit) - 2)
             e, vp, d = orbit[j if j < len(orbit) else 2 * len(orbit) - 2 - j]
             nframe[0] += 1
             caster.SetRenderTargets(depthMapDevice=d.data_ptr())
-            caster.UpdateFrame(vp, fr["shadowVP"], e)
             last_depth[0] = d
+        if world > 1:
+            # begins this frame (upload, cull, light march + light-map exchange, view march) and finishes the previous one (cube-face
+            # all-gather, composite of this rank's rows, row-band all-gather): MultiRayCaster.cpp:355-385 across the ranks
+            caster.DistFrame(vp, fr["shadowVP"], e, composite=do_composite)
+            return
+        caster.UpdateFrame(vp, fr["shadowVP"], e)
         if world == 1 and skip_light[0]:
             caster.cullVolumes()
             caster.rayMarchV()
             caster.m_frameIdx += 1
         elif world == 1:
             caster.Render(composite=False)  # cull -> marchL -> marchV, stream ordered
-        else:
-            caster.cullVolumes()
-            info_h, vis_h, _, _ = caster.ReadBackCull()  # host sync on the cull alone: the exchange sizes depend on it
-            caster.rayMarchL()
-            # a light map relit this frame by another rank is needed here if its volume is on the screen-space scheme:
-            # every rank marches its own rows of every such volume inside the view march
-            xbytes[0] += light_xchg.run(info_h, vis_h, frame_idx)
-            caster.rayMarchV()
-            caster.m_frameIdx += 1  # what Render() does (MultiRayCaster.cpp:384)
-            if with_exchange:
-                xbytes[0] += cube_xchg.run(info_h, vis_h)  # pack -> RCCL all-gather -> unpack
         if do_composite:
             caster.composite(band[0], band[1])
-            if world > 1 and with_exchange:
-                xbytes[0] += D.gather_composite_rows(caster, H, W, rank, world)
 
     # Setup frames: relight every visible volume at least once so the light maps are real -- and get past the HIP runtime's
     # one-time 30-50 ms stall around the 140th frame of a process (see the module docstring) whatever --warmup the caller gives.
@@ -216,8 +208,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        caster.DistFlush()
+        caster.synchronize()
+        caster.DistExchangedBytes(reset=True)  # exchange bytes of the timed frames only
     barrier()
-    xbytes[0] = 0  # exchange bytes of the timed frames only
     t0 = time.perf_counter()
     trace = [] if os.environ.get("MV_BENCH_TRACE") else None
     for i in range(args.steps):
@@ -225,12 +220,14 @@ def main():
         frame()
         if trace is not None:
             trace.append(time.perf_counter())
+    if world > 1:
+        caster.DistFlush()  # the last frame's exchange + composite
     barrier()
     if trace:
         d = sorted(((b - a) * 1e3, i + 1) for i, (a, b) in enumerate(zip(trace, trace[1:])))
         print("host ms per frame: median %.3f, largest %s" % (d[len(d) // 2][0], [(round(x, 2), i) for x, i in d[-6:]]), file=sys.stderr)
     dt = time.perf_counter() - t0
-    xbytes_timed = xbytes[0]
+    xbytes_timed = caster.DistExchangedBytes() if world > 1 else 0
     caster.SetProfiling(False)
     st = caster.GetStats()
 
@@ -241,6 +238,8 @@ def main():
         caster.SetProfiling(True)
         for _ in range(args.roofline_frames):
             frame()
+            if world > 1:
+                caster.DistFlush()
             caster.synchronize()
         caster.SetProfiling(False)
         st_iso = caster.GetStats()
@@ -321,7 +320,7 @@ def main():
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
-                "parallelism": f"cube-map volumes sharded v%{world} + RCCL all-gather of cube faces, screen-space RayCast and composite sharded by rows" if world > 1 else "single GPU",
+                "parallelism": f"cube-map volumes sharded v%{world} + all-gather of the marched cube faces, screen-space RayCast and composite sharded by rows; frame loop inside the library (mv_dist_frame), transport: {exchange}" if world > 1 else "single GPU",
                 "frames_in_flight": ("up to 3 (constants / cull 4 slots, march outputs 2, light maps 3 buffers per volume)" if world == 1
                                      else "upload + cull + light march ahead of the view march / exchange / composite stream") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),

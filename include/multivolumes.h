@@ -227,6 +227,29 @@ int mv_exchange_pack(mv_ctx* ctx, void* d_dst, uint32_t slot_dim);
 /* Scatter an all-gathered buffer (shard_count x shard_bytes, rank-major) back into the cube maps / depths of every volume. */
 int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim);
 
+/* ---- multi-GPU frame loop inside the library: one process per GPU, context r of `shard_count` = rank r ----
+ * mv_dist_frame runs the whole per-frame protocol without Python and without a host wait on work of the current frame:
+ *   frame k:   constant upload, cull, light march (owner of the relit volume), light-map exchange (an all-reduce of that ONE map as
+ *              R11G11B10F words, 4 L^3 bytes: every rank keeps every light map current, because every rank marches its own screen
+ *              rows of every volume on the screen-space scheme), view march of the owned volumes;
+ *   frame k-1: (on a second stream, beside frame k's march) pack the marched faces of the owned cube-map volumes -> all-gather ->
+ *              unpack -> composite of this rank's rows -> all-gather of the row bands.
+ * The sizes of frame k-1's collectives come from its cull results, which reached the host a frame ago.  The composite of frame k is
+ * therefore complete after the NEXT mv_dist_frame (or mv_dist_flush).  Results equal the single-GPU frame bit for bit.
+ * Transport: RCCL (the library opens librccl.so itself; two communicators) or caller-supplied collectives (tests, other fabrics). */
+#define MV_DIST_ID_BYTES 256
+int mv_dist_unique_id(void* out /* MV_DIST_ID_BYTES; call on rank 0, hand the bytes to every rank */);
+int mv_dist_init_rccl(mv_ctx* ctx, const void* id /* MV_DIST_ID_BYTES, the same on every rank */);
+/* all-gather: every rank contributes `bytes` from `send`; `recv` receives shard_count x bytes in rank order.  all-reduce: in-place
+ * integer sum of `count` uint32.  `stream` is the hipStream_t the collective must be ordered on; which = 0 (cube faces / rows) or
+ * 1 (light maps): the two families run on different streams and need separate communicators.  Return 0 on success. */
+typedef int (*mv_dist_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* stream, int which);
+typedef int (*mv_dist_allreduce_u32_fn)(void* user, void* buf, size_t count, void* stream, int which);
+int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user);
+int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite);
+int mv_dist_flush(mv_ctx* ctx);	/* enqueue the exchange + composite of the last frame begun (then mv_synchronize / readbacks see it) */
+int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset);	/* bytes this rank received through the collectives */
+
 #ifdef __cplusplus
 }
 #endif

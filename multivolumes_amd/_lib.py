@@ -28,6 +28,10 @@ MV_FLAG_RAY_QUEUE = 16
 MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
 MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7
 
+MV_DIST_ID_BYTES = 256
+DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
+DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
+
 NUM_CUBE_MIP = 5
 PER_OBJECT_BYTES = 224
 CB_PER_FRAME_BYTES = 212
@@ -102,6 +106,12 @@ ABI = {
     "mv_exchange_pack": (C.c_int, [_P, _P, _U32]),
     "mv_exchange_unpack": (C.c_int, [_P, _P, _U32]),
     "mv_readback_cull": (C.c_int, [_P, _P, _P, C.POINTER(_U32), _P, C.POINTER(_U32), C.POINTER(_U32)]),
+    "mv_dist_unique_id": (C.c_int, [_P]),
+    "mv_dist_init_rccl": (C.c_int, [_P, _P]),
+    "mv_dist_init_callbacks": (C.c_int, [_P, _P, _P, _P]),
+    "mv_dist_frame": (C.c_int, [_P, _P, _P, C.c_int]),
+    "mv_dist_flush": (C.c_int, [_P]),
+    "mv_dist_exchanged_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "mv_mesh_upload": (C.c_int, [_P, _P, _U32, _P, _U32]),
     "mv_mesh_render_depth": (C.c_int, [_P, _P, _P]),
     "mv_mesh_render_shadow": (C.c_int, [_P, _P]),

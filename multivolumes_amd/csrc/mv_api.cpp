@@ -17,6 +17,8 @@
 #include <string>
 #include <vector>
 #include <new>
+#include <dlfcn.h>
+#include <rccl/rccl.h>	// types and prototypes only: the library is opened with dlopen when mv_dist_init_rccl is called
 
 using mv::DeviceState;
 
@@ -63,9 +65,38 @@ struct OutBufs
 	float* cubeDepths = nullptr;
 	uint2* composite = nullptr;
 	float4* screenLayers = nullptr;
+	uint32_t* faceStamps = nullptr;
 	uint64_t *waveStats = nullptr, *compositeStats = nullptr;
 	mv::RayRecord* rayRecords = nullptr;	// the view march's ray queue (mv_march.hip)
 	mv::TileInfo* tileInfo = nullptr;
+};
+
+// state of the in-library multi-GPU frame loop (mv_dist_*)
+struct DistState
+{
+	int transport = 0;				// 1 = RCCL, 2 = caller-supplied collectives
+	void* rcclLib = nullptr;
+	decltype(&ncclCommInitRank) commInitRank = nullptr;
+	decltype(&ncclAllGather) allGather = nullptr;
+	decltype(&ncclAllReduce) allReduce = nullptr;
+	decltype(&ncclCommDestroy) commDestroy = nullptr;
+	decltype(&ncclGetErrorString) errorString = nullptr;
+	ncclComm_t comm[2] = { nullptr, nullptr };	// [0] cube faces + row bands (stream X), [1] light maps (stream L)
+	mv_dist_allgather_fn cbAllGather = nullptr;
+	mv_dist_allreduce_u32_fn cbAllReduce = nullptr;
+	void* user = nullptr;
+	hipStream_t streamX = nullptr;	// exchange + composite of frame k - 1, beside frame k's view march
+	uint8_t *sendBuf = nullptr, *recvBuf = nullptr;	// one shard / shard_count shards of marched cube faces
+	size_t sendCap = 0;
+	uint32_t* lightWords = nullptr;	// L^3 R11G11B10F words of the relit light map
+	uint8_t *rowSend = nullptr, *rowRecv = nullptr;	// staged row-band gather (unequal bands, or a transport without in-place all-gather)
+	size_t maxBandBytes = 0;
+	uint8_t* pinnedCull[4] = {};	// per frame slot: counters + VolumeInfo + lists, copied behind the cull
+	hipEvent_t evCullCopied[4] = {};
+	bool pending = false, pendingComposite = false;
+	DeviceState stPending;			// the device state of the frame whose exchange + composite are still to be enqueued
+	uint32_t slotPending = 0;
+	uint64_t bytes = 0;
 };
 
 struct mv_ctx
@@ -83,6 +114,8 @@ struct mv_ctx
 	FrameBufs fb[kFrameSlots];			// constants + cull outputs per slot; march / composite outputs per PARITY (slot & 1), aliased
 	uint32_t slot = 0;					// frame counter mod kFrameSlots
 	hipEvent_t evStageA[kFrameSlots] = {}, evLight[kFrameSlots] = {}, evMainDone[kFrameSlots] = {}, evProducers = nullptr;
+	hipEvent_t evCopy[kFrameSlots] = {};	// a frame's unmarched cube faces are up to date (copyForward)
+	bool copiedForward = false;			// this frame's copy-forward has been enqueued
 	bool producersDirty = false;
 
 	// owned device allocations
@@ -131,6 +164,7 @@ struct mv_ctx
 	double msStage[4] = { 0, 0, 0, 0 };
 	uint64_t nStage[4] = { 0, 0, 0, 0 };
 	std::string lastError;
+	DistState* dist = nullptr;
 };
 
 namespace
@@ -172,7 +206,7 @@ void applyParity(mv_ctx* ctx)
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.lightDirs = f.lightDirs;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
 	const OutBufs& o = ctx->ob[ctx->set];
-	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers;
+	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers; st.faceStamps = o.faceStamps;
 	st.waveStats = o.waveStats; st.compositeStats = o.compositeStats; st.tileCost = f.tileCost;
 	st.rayRecords = o.rayRecords; st.tileInfo = o.tileInfo;
 	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
@@ -196,6 +230,11 @@ int syncAll(mv_ctx* ctx)
 			const hipError_t e = hipStreamSynchronize(ctx->streamB[i]);
 			if (e != hipSuccess) return (int)e;
 		}
+	if (ctx->dist && ctx->dist->streamX)
+	{
+		const hipError_t e = hipStreamSynchronize(ctx->dist->streamX);
+		if (e != hipSuccess) return (int)e;
+	}
 	return (int)hipStreamSynchronize(ctx->stream);
 }
 
@@ -329,6 +368,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->evLight[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->evProducers, hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
+	for (uint32_t i = 0; i < kFrameSlots; ++i)
+		if (hipEventCreateWithFlags(&ctx->evCopy[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 
 	DeviceState& st = ctx->st;
 	st.N = cfg->grid_size; st.bricks = (cfg->grid_size + 3u) >> 2; st.L = cfg->light_grid_size;
@@ -477,6 +518,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.faceStamps, (size_t)st.V * MV_NUM_CUBE_MIP * 6 * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.waveStats, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if (p == 0 && (rc = devAlloc(ctx, &st.timeline, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		// the ray queue: 64 records per tile of the largest frame (every owned volume at mip 0 with 6 faces + every screen tile); never cleared
@@ -519,6 +561,16 @@ void mv_destroy(mv_ctx* ctx)
 	if (!ctx) return;
 	if (ctx->stream) (void)syncAll(ctx);
 	foldEvents(ctx);
+	if (DistState* d = ctx->dist)
+	{
+		for (int i = 0; i < 2; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
+		if (d->streamX) (void)hipStreamDestroy(d->streamX);
+		for (uint32_t i = 0; i < kFrameSlots; ++i) { if (d->pinnedCull[i]) (void)hipHostFree(d->pinnedCull[i]); if (d->evCullCopied[i]) (void)hipEventDestroy(d->evCullCopied[i]); }
+		// (device buffers are in ctx->allocs; the RCCL library stays loaded)
+		delete d;
+		ctx->dist = nullptr;
+	}
+	for (uint32_t i = 0; i < kFrameSlots; ++i) if (ctx->evCopy[i]) (void)hipEventDestroy(ctx->evCopy[i]);
 	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); if (ctx->evLight[i]) (void)hipEventDestroy(ctx->evLight[i]); }
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
 	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
@@ -722,7 +774,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	MV_HIP(ctx, stageADone(ctx));
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
-	ctx->lightMarched = false; ctx->lightTableKept = false;
+	ctx->lightMarched = false; ctx->lightTableKept = false; ctx->copiedForward = false;
 	return MV_OK;
 }
 
@@ -769,13 +821,44 @@ int mv_march_light(mv_ctx* ctx)
 	return MV_OK;
 }
 
+// Bring the cube faces this frame does NOT march up to date from the other output set (mv_composite.hip copyForwardKernel).
+// It reads the other set -- complete once the previous frame's view march (and, on a multi-GPU rank, its unpack) has finished --
+// and writes faces nobody else writes this frame, so it can run beside this frame's view march; the composite of this frame and
+// the view march of the NEXT frame (which writes the other set again) wait for it.
+static int copyForward(mv_ctx* ctx, hipStream_t s)
+{
+	const OutBufs& other = ctx->ob[(ctx->set + ctx->numOutSets - 1u) % ctx->numOutSets];
+	mv::launchCopyForward(s, ctx->st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)ctx->frame);
+	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, hipEventRecord(ctx->evCopy[ctx->slot], s));
+	ctx->copiedForward = true;
+	return MV_OK;
+}
+
 int mv_march_view(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
 	{ const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
+	const uint32_t prevSlot = (ctx->slot + kFrameSlots - 1u) % kFrameSlots;
+#ifndef MV_COPY_FORWARD
+#define MV_COPY_FORWARD 1	// (0: A/B timing only -- the two output sets then drift apart in the faces a frame does not march)
+#endif
+	if (MV_COPY_FORWARD && ctx->numOutSets == 2u && !ctx->dist && !ctx->copiedForward)
+	{
+		// On the stream of the PREVIOUS frame's view march and composite -- which is also the stream of the next frame's: stream order
+		// alone then puts the copy behind the march that completed the other set and in front of the march that overwrites it again,
+		// and it runs beside this frame's march (a stream of its own would do, but HIP streams beyond four share hardware queues and
+		// false dependencies between the two view-march streams cost 0.1 ms per frame: measured).
+		hipStream_t s = ctx->streamB[(ctx->frame + ctx->numViewStreams - 1u) % ctx->numViewStreams];
+		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evMainDone[(ctx->slot + kFrameSlots - 2u) % kFrameSlots], 0));	// this set's last reader (composite of frame k - 2)
+		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evStageA[ctx->slot], 0));	// this frame's cull
+		const int rc = copyForward(ctx, s);
+		if (rc != MV_OK) return rc;
+	}
 	MV_HIP(ctx, stageBBegin(ctx));
+	if (ctx->numOutSets == 2u) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[prevSlot], 0));	// the previous frame's copy-forward read the set this march writes
 	// the previous user of this output set is frame i - numOutSets; with SINGLE_VIEW_STREAM / one stream it is on this stream anyway
 	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (ctx->numOutSets % kFrameSlots)) % kFrameSlots], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
@@ -820,6 +903,7 @@ int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
 	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
 	{ const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, stageBBegin(ctx));
+	if (ctx->numOutSets == 2u && ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[ctx->slot], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 3, ev, streamB(ctx));
 	mv::launchComposite(streamB(ctx), ctx->st, row0, row1);
@@ -963,6 +1047,7 @@ int mv_clear_cube_maps(mv_ctx* ctx)
 	{
 		MV_HIP(ctx, hipMemsetAsync(ctx->ob[p].cubeMaps, 0, (size_t)ctx->st.V * chain * sizeof(uint2), ctx->stream));
 		MV_HIP(ctx, hipMemsetAsync(ctx->ob[p].cubeDepths, 0, (size_t)ctx->st.V * chain * sizeof(float), ctx->stream));
+		MV_HIP(ctx, hipMemsetAsync(ctx->ob[p].faceStamps, 0, (size_t)ctx->st.V * MV_NUM_CUBE_MIP * 6 * sizeof(uint32_t), ctx->stream));
 	}
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
@@ -1204,6 +1289,253 @@ int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info, uint32_t* visible, uint
 	memcpy(volume_info, p + 64, V * 8);
 	memcpy(visible, p + 64 + V * 8, V * 4);
 	memcpy(cubeMapVolumes, p + 64 + V * 12, V * 4);
+	return MV_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU frame loop inside the library (include/multivolumes.h "mv_dist_*")
+// ---------------------------------------------------------------------------------------------
+static int distAllGather(mv_ctx* ctx, const void* send, void* recv, size_t bytes, hipStream_t stream, int which)
+{
+	DistState* d = ctx->dist;
+	if (d->transport == 1)
+	{
+		const ncclResult_t r = d->allGather(send, recv, bytes, ncclUint8, d->comm[which], stream);
+		if (r != ncclSuccess) return fail(ctx, MV_ERR_HIP, d->errorString ? d->errorString(r) : "ncclAllGather failed");
+		return MV_OK;
+	}
+	if (d->cbAllGather(d->user, send, recv, bytes, reinterpret_cast<void*>(stream), which) != 0) return fail(ctx, MV_ERR_HIP, "the caller's all-gather failed");
+	return MV_OK;
+}
+
+static int distAllReduceU32(mv_ctx* ctx, uint32_t* buf, size_t count, hipStream_t stream, int which)
+{
+	DistState* d = ctx->dist;
+	if (d->transport == 1)
+	{
+		const ncclResult_t r = d->allReduce(buf, buf, count, ncclUint32, ncclSum, d->comm[which], stream);
+		if (r != ncclSuccess) return fail(ctx, MV_ERR_HIP, d->errorString ? d->errorString(r) : "ncclAllReduce failed");
+		return MV_OK;
+	}
+	if (d->cbAllReduce(d->user, buf, count, reinterpret_cast<void*>(stream), which) != 0) return fail(ctx, MV_ERR_HIP, "the caller's all-reduce failed");
+	return MV_OK;
+}
+
+// buffers, streams and events shared by both transports
+static int distCommonInit(mv_ctx* ctx)
+{
+	DistState* d = ctx->dist;
+	const DeviceState& st = ctx->st;
+	MV_REQUIRE(ctx, (ctx->cfg.flags & MV_FLAG_PIPELINE_FRAMES) && (ctx->cfg.flags & MV_FLAG_SINGLE_VIEW_STREAM), MV_ERR_INVALID_ARG,
+		"mv_dist_* needs a context created with MV_FLAG_PIPELINE_FRAMES | MV_FLAG_SINGLE_VIEW_STREAM (two output sets, cull and light march ahead)");
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	MV_HIP(ctx, hipStreamCreateWithFlags(&d->streamX, hipStreamNonBlocking));
+	const uint32_t world = st.shardCount, perShard = (st.V + world - 1u) / world;
+	d->sendCap = (size_t)perShard * 6u * st.N * st.N * 12u;	// every owned volume at mip 0 with six faces
+	int rc;
+	if ((rc = devAlloc(ctx, &d->sendBuf, d->sendCap, false)) != MV_OK) return rc;
+	if ((rc = devAlloc(ctx, &d->recvBuf, d->sendCap * world, false)) != MV_OK) return rc;
+	if ((rc = devAlloc(ctx, &d->lightWords, (size_t)st.L * st.L * st.L * sizeof(uint32_t), false)) != MV_OK) return rc;
+	const uint32_t tiles = (st.H + 7u) >> 3;
+	d->maxBandBytes = (size_t)(((tiles + world - 1u) / world) * 8u) * st.W * sizeof(uint2);
+	if ((rc = devAlloc(ctx, &d->rowSend, d->maxBandBytes, true)) != MV_OK) return rc;
+	if ((rc = devAlloc(ctx, &d->rowRecv, d->maxBandBytes * world, false)) != MV_OK) return rc;
+	for (uint32_t i = 0; i < kFrameSlots; ++i)
+	{
+		if (hipHostMalloc(reinterpret_cast<void**>(&d->pinnedCull[i]), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned cull copy");
+		MV_HIP(ctx, hipEventCreateWithFlags(&d->evCullCopied[i], hipEventDisableTiming));
+	}
+	ctx->st.flags |= mv::kFlagRotateAllLightMaps;	// every rank rotates the relit volume's light buffer: the exchange fills it on the non-owners
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	return MV_OK;
+}
+
+int mv_dist_unique_id(void* out)
+{
+	if (!out) return MV_ERR_INVALID_ARG;
+	void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+	if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	if (!lib) return MV_ERR_NOT_READY;
+	auto getId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
+	if (!getId) return MV_ERR_NOT_READY;
+	static_assert(2 * sizeof(ncclUniqueId) == MV_DIST_ID_BYTES, "two RCCL unique ids");
+	ncclUniqueId* ids = reinterpret_cast<ncclUniqueId*>(out);
+	for (int i = 0; i < 2; ++i) if (getId(&ids[i]) != ncclSuccess) return MV_ERR_HIP;
+	return MV_OK;
+}
+
+int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
+{
+	if (!ctx || !id) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, !ctx->dist, MV_ERR_INVALID_ARG, "mv_dist_init_* was already called on this context");
+	MV_REQUIRE(ctx, ctx->st.shardCount >= 1, MV_ERR_INVALID_ARG, "shard_count");
+	DistState* d = new (std::nothrow) DistState();
+	if (!d) return MV_ERR_OUT_OF_MEMORY;
+	d->transport = 1;
+	d->rcclLib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+	if (!d->rcclLib) d->rcclLib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	if (d->rcclLib)
+	{
+		d->commInitRank = reinterpret_cast<decltype(d->commInitRank)>(dlsym(d->rcclLib, "ncclCommInitRank"));
+		d->allGather = reinterpret_cast<decltype(d->allGather)>(dlsym(d->rcclLib, "ncclAllGather"));
+		d->allReduce = reinterpret_cast<decltype(d->allReduce)>(dlsym(d->rcclLib, "ncclAllReduce"));
+		d->commDestroy = reinterpret_cast<decltype(d->commDestroy)>(dlsym(d->rcclLib, "ncclCommDestroy"));
+		d->errorString = reinterpret_cast<decltype(d->errorString)>(dlsym(d->rcclLib, "ncclGetErrorString"));
+	}
+	if (!d->rcclLib || !d->commInitRank || !d->allGather || !d->allReduce || !d->commDestroy) { delete d; return fail(ctx, MV_ERR_NOT_READY, "librccl.so could not be opened"); }
+	MV_HIP(ctx, hipSetDevice(ctx->cfg.device));
+	const ncclUniqueId* ids = reinterpret_cast<const ncclUniqueId*>(id);
+	for (int i = 0; i < 2; ++i)
+	{
+		const ncclResult_t r = d->commInitRank(&d->comm[i], (int)ctx->st.shardCount, ids[i], (int)ctx->st.shardIndex);
+		if (r != ncclSuccess)
+		{
+			const int rc = fail(ctx, MV_ERR_HIP, d->errorString ? d->errorString(r) : "ncclCommInitRank failed");
+			if (i == 1 && d->comm[0]) (void)d->commDestroy(d->comm[0]);
+			delete d;
+			return rc;
+		}
+	}
+	ctx->dist = d;
+	return distCommonInit(ctx);
+}
+
+int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user)
+{
+	if (!ctx || !allgather || !allreduce) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, !ctx->dist, MV_ERR_INVALID_ARG, "mv_dist_init_* was already called on this context");
+	DistState* d = new (std::nothrow) DistState();
+	if (!d) return MV_ERR_OUT_OF_MEMORY;
+	d->transport = 2; d->cbAllGather = allgather; d->cbAllReduce = allreduce; d->user = user;
+	ctx->dist = d;
+	return distCommonInit(ctx);
+}
+
+// exchange + composite of the pending frame, on stream X (beside the view march of the frame begun after it)
+static int distTail(mv_ctx* ctx)
+{
+	DistState* d = ctx->dist;
+	if (!d->pending) return MV_OK;
+	const DeviceState& st = d->stPending;
+	const uint32_t slot = d->slotPending, world = st.shardCount, rank = st.shardIndex;
+
+	// This frame's cull results were copied to pinned memory behind its cull, at least one mv_dist_frame ago: the wait returns at once
+	// in steady state.  They give the size of the frame's all-gather (the same on every rank: the cull is replicated).
+	MV_HIP(ctx, hipEventSynchronize(d->evCullCopied[slot]));
+	const uint8_t* p = d->pinnedCull[slot];
+	const uint32_t* counters = reinterpret_cast<const uint32_t*>(p);
+	const uint16_t* info = reinterpret_cast<const uint16_t*>(p + 64);
+	const uint32_t* visible = reinterpret_cast<const uint32_t*>(p + 64 + (size_t)st.V * 8);
+	std::vector<size_t> perRank(world, 0);
+	for (uint32_t k = 0; k < counters[0] && k < st.V; ++k)
+	{
+		const uint32_t v = visible[k];
+		if (v >= st.V || !(info[4 * v + 2] & MV_CUBEMAP_RAYMARCH_BIT)) continue;
+		const size_t dim = st.N >> info[4 * v + 0];
+		perRank[v % world] += (size_t)__builtin_popcount(info[4 * v + 2] & 0x3fu) * dim * dim * 12u;
+	}
+	size_t shardBytes = 16;
+	for (size_t b : perRank) shardBytes = std::max(shardBytes, (b + 15u) & ~(size_t)15u);
+	MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
+
+	hipStream_t X = d->streamX;
+	MV_HIP(ctx, hipStreamWaitEvent(X, ctx->evMainDone[slot], 0));	// the frame's view march
+	if (world > 1)
+	{
+		mv::launchExchangeCompact(X, st, true, d->sendBuf, shardBytes);
+		MV_HIP(ctx, hipGetLastError());
+		int rc = distAllGather(ctx, d->sendBuf, d->recvBuf, shardBytes, X, 0);
+		if (rc != MV_OK) return rc;
+		mv::launchExchangeCompact(X, st, false, d->recvBuf, shardBytes);
+		MV_HIP(ctx, hipGetLastError());
+		d->bytes += shardBytes * world;
+	}
+	if (d->pendingComposite)
+	{
+		mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
+		MV_HIP(ctx, hipGetLastError());
+		if (world > 1)
+		{
+			const size_t rowBytes = (size_t)st.W * sizeof(uint2);
+			const uint32_t tiles = (st.H + 7u) >> 3;
+			uint8_t* frame = reinterpret_cast<uint8_t*>(st.composite);
+			const bool equalBands = tiles % world == 0u && (tiles / world) * 8u * world == st.H;
+			if (equalBands && d->transport == 1)
+			{
+				// the frame buffer is the all-gather's output and this rank's band its input, in place (sendbuff == recvbuff + rank * count)
+				const size_t band = (size_t)(st.bandRow1 - st.bandRow0) * rowBytes;
+				const int rc = distAllGather(ctx, frame + (size_t)st.bandRow0 * rowBytes, frame, band, X, 0);
+				if (rc != MV_OK) return rc;
+			}
+			else
+			{
+				MV_HIP(ctx, hipMemcpyAsync(d->rowSend, frame + (size_t)st.bandRow0 * rowBytes, (size_t)(st.bandRow1 - st.bandRow0) * rowBytes, hipMemcpyDeviceToDevice, X));
+				const int rc = distAllGather(ctx, d->rowSend, d->rowRecv, d->maxBandBytes, X, 0);
+				if (rc != MV_OK) return rc;
+				for (uint32_t r = 0; r < world; ++r)
+				{
+					if (r == rank) continue;
+					const uint32_t t0 = (uint32_t)(((uint64_t)tiles * r) / world), t1 = (uint32_t)(((uint64_t)tiles * (r + 1u)) / world);
+					const uint32_t r0 = std::min(t0 * 8u, st.H), r1 = std::min(t1 * 8u, st.H);
+					if (r1 > r0) MV_HIP(ctx, hipMemcpyAsync(frame + (size_t)r0 * rowBytes, d->rowRecv + (size_t)r * d->maxBandBytes, (size_t)(r1 - r0) * rowBytes, hipMemcpyDeviceToDevice, X));
+				}
+			}
+			d->bytes += (size_t)st.H * rowBytes;
+		}
+	}
+	// everything that reads this frame's buffers has been enqueued: the next users of its slot / output set / light buffers wait for this
+	MV_HIP(ctx, hipEventRecord(ctx->evMainDone[slot], X));
+	d->pending = false;
+	return MV_OK;
+}
+
+int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite)
+{
+	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
+	DistState* d = ctx->dist;
+	int rc;
+	// ---- frame k: upload, cull, light march + light-map exchange (all ahead, on streams A and L), view march ----
+	if ((rc = mv_update_frame(ctx, cbPerFrame, perObject)) != MV_OK) return rc;
+	if ((rc = mv_cull(ctx)) != MV_OK) return rc;
+	MV_HIP(ctx, hipMemcpyAsync(d->pinnedCull[ctx->slot], ctx->fb[ctx->slot].cullBlock, 64 + (size_t)ctx->st.V * 24, hipMemcpyDeviceToHost, ctx->streamA));
+	MV_HIP(ctx, hipEventRecord(d->evCullCopied[ctx->slot], ctx->streamA));
+	if ((rc = mv_march_light(ctx)) != MV_OK) return rc;
+	if (ctx->st.shardCount > 1)
+	{
+		const size_t words = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
+		mv::launchLightExchange(ctx->streamL, ctx->st, d->lightWords, false);
+		MV_HIP(ctx, hipGetLastError());
+		if ((rc = distAllReduceU32(ctx, d->lightWords, words, ctx->streamL, 1)) != MV_OK) return rc;
+		mv::launchLightExchange(ctx->streamL, ctx->st, d->lightWords, true);
+		MV_HIP(ctx, hipGetLastError());
+		MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], ctx->streamL));	// the view march waits for the exchanged map, not only for the light march
+		d->bytes += words * sizeof(uint32_t);
+	}
+	if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
+	// ---- frame k - 1: exchange + composite, on stream X beside this frame's march ----
+	if ((rc = distTail(ctx)) != MV_OK) return rc;
+	// ---- frame k's unmarched cube faces <- frame k - 1's set, now complete on this rank (stream X is in order); frame k + 1's march waits for it ----
+	MV_HIP(ctx, hipStreamWaitEvent(d->streamX, ctx->evStageA[ctx->slot], 0));
+	if ((rc = copyForward(ctx, d->streamX)) != MV_OK) return rc;
+	d->stPending = ctx->st; d->slotPending = ctx->slot; d->pendingComposite = with_composite != 0; d->pending = true;
+	return MV_OK;
+}
+
+int mv_dist_flush(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
+	return distTail(ctx);
+}
+
+int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset)
+{
+	if (!ctx || !bytes) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
+	*bytes = ctx->dist->bytes;
+	if (reset) ctx->dist->bytes = 0;
 	return MV_OK;
 }
 

@@ -68,6 +68,137 @@ void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exchange, compact form (mv_dist_frame): a shard's buffer holds ONLY what the other ranks' composites can read -- the marched
+// faces (MaskBits) of its visible volumes on the cube-map scheme, at the selected mip -- back to back in ascending volume order:
+// per volume [k faces x d^2 RGBA16F texels][k faces x d^2 R32F depths], faces in mask order.  Every rank derives the same offsets
+// from the replicated cull (volumeFlags); the host only needs the padded shard size (mv_api.cpp distShardBytes).
+// C4 at the default camera: 10 cube-map volumes x 3 faces x 128^2 x 12 B = 5.9 MB per frame instead of 18.9 MB for whole cubes.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t exchangeFaceTexels(uint32_t info, uint32_t N)
+{
+	if ((info & 3u) != 3u) return 0u;	// visible and on the cube-map scheme
+	const uint32_t d = N >> ((info >> 2) & 7u);
+	return (uint32_t)__popc((info >> 5) & 0x3fu) * d * d;
+}
+
+// texel offset of volume v inside the shard of rank `r` (volumes u < v with u % shardCount == r)
+__device__ __forceinline__ uint32_t exchangeOffsetTexels(const DeviceState& st, uint32_t r, uint32_t v)
+{
+	uint32_t off = 0;
+	for (uint32_t u = r; u < v; u += st.shardCount) off += exchangeFaceTexels(st.volumeFlags[u], st.N);
+	return off;
+}
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void exchangeCompactKernel(DeviceState st, uint8_t* __restrict__ buf, size_t shardBytes)
+{
+	const uint32_t perShard = (st.V + st.shardCount - 1u) / st.shardCount;
+	const uint32_t r = PACK ? st.shardIndex : blockIdx.y / perShard, j = PACK ? blockIdx.y : blockIdx.y % perShard;
+	if (!PACK && r == st.shardIndex) return;	// own volumes are already in place
+	const uint32_t v = j * st.shardCount + r;
+	if (v >= st.V) return;
+	const uint32_t info = st.volumeFlags[v];
+	const uint32_t n = exchangeFaceTexels(info, st.N);
+	if (!n) return;
+	const uint32_t d = st.N >> ((info >> 2) & 7u), mask = (info >> 5) & 0x3fu, face2 = d * d;
+	uint8_t* shard = buf + (PACK ? 0 : (size_t)r * shardBytes) + (size_t)exchangeOffsetTexels(st, r, v) * 12u;
+	uint2* colour = reinterpret_cast<uint2*>(shard);
+	float* depth = reinterpret_cast<float*>(shard + (size_t)n * 8u);
+	const size_t cube = (size_t)st.cubeOffset[v];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+	{
+		// the k-th marched face
+		uint32_t k = i / face2, m = mask, f = 0;
+		for (;;) { f = (uint32_t)__ffs((int)m) - 1u; if (!k) break; m &= m - 1u; --k; }
+		const size_t texel = cube + (size_t)f * face2 + (i % face2);
+		if (PACK) { colour[i] = st.cubeMaps[texel]; depth[i] = st.cubeDepths[texel]; }
+		else { st.cubeMaps[texel] = colour[i]; st.cubeDepths[texel] = depth[i]; }
+	}
+}
+
+void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes)
+{
+	const uint32_t perShard = (st.V + st.shardCount - 1u) / st.shardCount;
+	const size_t n = (size_t)6 * st.N * st.N;
+	const uint32_t gx = (uint32_t)((n + 2047) / 2048);
+	if (pack) hipLaunchKernelGGL(exchangeCompactKernel<true>, dim3(gx ? gx : 1, perShard), dim3(256), 0, s, st, reinterpret_cast<uint8_t*>(buf), shardBytes);
+	else hipLaunchKernelGGL(exchangeCompactKernel<false>, dim3(gx ? gx : 1, perShard * st.shardCount), dim3(256), 0, s, st, reinterpret_cast<uint8_t*>(buf), shardBytes);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Two output sets, one history.  The reference never clears its cube maps: a face that a frame does not march (face bit clear,
+// CSRayMarch.hlsl:84-85) keeps what the last frame that marched it left there, and a CubeCast gather across a cube edge can read it.
+// With frames in flight (and on every rank of the multi-GPU loop) consecutive frames write alternating output sets, so the newest
+// data of such a face may sit in the OTHER set.  Every (volume, mip, face) carries a stamp per set -- the frame that last wrote it
+// there -- and before a frame composites, the faces it does not march are brought up to date from the other set where that one is
+// newer.  In steady state nothing is copied; a face is copied once when it stops being marched.  Both sets then read exactly like
+// the reference's single set.  (Texels of a MARCHED face whose ray misses the box by an ulp are not tracked.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copyForwardKernel(DeviceState st, const uint2* __restrict__ otherMaps, const float* __restrict__ otherDepths,
+	const uint32_t* __restrict__ otherStamps, uint32_t tag)
+{
+	const uint32_t v = blockIdx.x / 6u, f = blockIdx.x % 6u;
+	const uint32_t info = st.volumeFlags[v];
+	if ((info & 3u) != 3u) return;	// not visible, or on the screen-space scheme: this frame's composite does not read its cube map
+	const uint32_t mip = (info >> 2) & 7u, mask = (info >> 5) & 0x3fu;
+	const uint32_t idx = (v * kNumCubeMip + mip) * 6u + f;
+	if (mask & (1u << f))
+	{
+		if (threadIdx.x == 0) st.faceStamps[idx] = tag;	// marched this frame (here, or by its owner and unpacked here)
+		return;
+	}
+	const uint32_t mine = st.faceStamps[idx], theirs = otherStamps[idx];
+	if ((int32_t)(theirs - mine) <= 0) return;
+	const uint32_t d = st.N >> mip;
+	const size_t base = (size_t)st.cubeOffset[v] + (size_t)f * d * d;
+	for (uint32_t i = threadIdx.x; i < d * d; i += blockDim.x)
+	{
+		st.cubeMaps[base + i] = otherMaps[base + i];
+		st.cubeDepths[base + i] = otherDepths[base + i];
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) st.faceStamps[idx] = theirs;
+}
+
+void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag)
+{
+	hipLaunchKernelGGL(copyForwardKernel, dim3(st.V * 6u), dim3(256), 0, s, st, otherMaps, otherDepths, otherStamps, tag);
+}
+
+// Light map of the volume relit this frame (CSRayMarchL.hlsl:29-33: ONE volume per frame, marched by its owner), for the ranks that
+// do not own it: every rank marches its own screen rows of every volume on the screen-space scheme (RayCast.hlsli:76 reads GetLight),
+// and which volumes are on that scheme changes with the camera, so every rank keeps every light map current.  The map travels as
+// plain R11G11B10F words (4 B per texel) through an all-reduce (integer sum) in which only the owner contributes non-zero words:
+// no rank needs to know the root on the host.
+__global__ __launch_bounds__(256) void lightExchangeKernel(DeviceState st, uint32_t* __restrict__ words, int unpack)
+{
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	const uint32_t visibleCount = st.counters[0];
+	const uint32_t relit = visibleCount ? st.visibleVolumes[cb->frameIdx % visibleCount] : cb->frameIdx % st.V;
+	const bool owner = relit % st.shardCount == st.shardIndex;
+	const uint32_t L = st.L, total = L * L * L;
+	uint4* quads = st.lightTable[relit];
+	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+	{
+		if (!unpack) words[i] = owner ? quads[i].x : 0u;
+		else if (!owner)
+		{
+			const uint32_t x = i % L, y = (i / L) % L;
+			const uint32_t x1 = x + 1 < L ? x + 1 : L - 1, y1 = y + 1 < L ? y + 1 : L - 1;
+			const uint32_t* sl = words + (size_t)(i / (L * L)) * L * L;
+			quads[i] = make_uint4(sl[y * L + x], sl[y * L + x1], sl[y1 * L + x], sl[y1 * L + x1]);
+		}
+	}
+}
+
+void launchLightExchange(hipStream_t s, const DeviceState& st, uint32_t* words, bool unpack)
+{
+	const size_t total = (size_t)st.L * st.L * st.L;
+	const size_t g = (total + 255) / 256;
+	hipLaunchKernelGGL(lightExchangeKernel, dim3((uint32_t)(g < 4096 ? g : 4096)), dim3(256), 0, s, st, words, unpack ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------
 // a7: K-buffer OIT composite = VSCube.hlsl:51-76 + PSDepthPeel.hlsl:12-24 + PSCube.hlsl:30-60 (CubeCast, PSCube.hlsli:51-108,
 // or the screen-space RayCast, RayCast.hlsli:43-108) + PSResolveOIT.hlsl:12-26.
 // The reference rasterises every visible cube with front-face culling and no depth test (MultiRayCaster.cpp:868-869,

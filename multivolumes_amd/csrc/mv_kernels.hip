@@ -457,7 +457,9 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			}
 		}
 		else relit = relitVolume(st, cb->frameIdx, 0u, nullptr);
-		if (!ownsVolume(st, relit)) relit = 0xffffffffu;	// another shard's: nothing rotates here (its map, if needed, arrives by exchange)
+		// another shard's: nothing rotates here -- unless the context keeps every light map current through mv_dist_frame's exchange,
+		// which fills the fresh buffer on the ranks that do not own the volume
+		if (!ownsVolume(st, relit) && !(st.flags & kFlagRotateAllLightMaps)) relit = 0xffffffffu;
 		const size_t L3 = (size_t)st.L * st.L * st.L;
 		for (uint32_t v = lane; v < st.V; v += 64)
 		{

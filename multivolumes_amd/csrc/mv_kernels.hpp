@@ -96,6 +96,7 @@ struct DeviceState
 	const uint16_t* shadowMap;		// M x M D16
 	uint2* cubeMaps;				// V x chain RGBA16F texels
 	float* cubeDepths;				// V x chain
+	uint32_t* faceStamps;			// V x 5 x 6: frame that last wrote (volume, mip, face) into THIS output set (mv_composite.hip copyForwardKernel)
 	uint2* composite;				// W x H RGBA16F
 	float4* screenLayers;			// screenSlots x W x H fp32 RGBA: RayCast results of screen-space-scheme volumes (marched inside marchViewKernel)
 	uint32_t* screenSlot;			// V: slot of volume v in screenLayers, or 0xffffffff (composite then marches it inline)
@@ -190,4 +191,8 @@ uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
 void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1);
 void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, void* dst);
 void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim, const void* src);
+void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes);	// marched faces only (mv_dist_frame)
+void launchLightExchange(hipStream_t s, const DeviceState& st, uint32_t* words, bool unpack);
+void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag);
+constexpr uint32_t kFlagRotateAllLightMaps = 0x80000000u;	// DeviceState.flags (internal): every rank rotates the relit volume's light buffer, not only its owner
 } // namespace mv

@@ -1,10 +1,11 @@
 """Multi-GPU plumbing for the path: one process per GPU, volumes sharded v % world, every rank holds
 every volume texture (marchL couples all volumes), cull replicated, marchL / marchV on owned volumes only, one RCCL
-all-gather per frame of the selected-mip cube faces (colour + depth), then each rank composites its band of screen rows.
+all-gather per frame of the marched cube faces (colour + depth), then each rank composites its band of screen rows.
 
-torch.distributed is plumbing here: it moves the bytes the C ABI packs (mv_exchange_pack / mv_exchange_unpack).
-The pure functions (owned_volumes, exchange_layout, row_range) mirror the device-side layout so that CPU tests can
-check the protocol over gloo without a GPU.
+The frame loop itself lives in the library (mv_dist_frame, include/multivolumes.h); init_frame_loop() below attaches it, with
+RCCL opened by the library or -- for gloo tests -- torch.distributed collectives handed over as callbacks.
+The pure functions (owned_volumes, exchange_layout, row_range, pack / unpack mirrors) state the slot-based layout of
+mv_exchange_pack / mv_exchange_unpack so that CPU tests can check that protocol over gloo without a GPU.
 """
 import os
 
@@ -79,105 +80,54 @@ def unpack_gathered_numpy(N, V, rank, world, volume_info, visible, gathered, cub
             cube_depths[v][off:off + n] = gathered[base + n_slot * 8:base + n_slot * 8 + n * 4].view(np.float32)
 
 
-class CubeFaceExchange:
-    """Per-rank driver of the per-frame exchange on the GPU: pack -> all_gather_into_tensor (RCCL) -> unpack.
-    Buffers are allocated once per layout and live in HBM; nothing crosses the host."""
+def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True):
+    """Attach the in-library multi-GPU frame loop (mv_dist_frame) to a sharded caster.
 
-    def __init__(self, caster, group=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.caster, self.group = caster, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._bytes = None
-        self.send = self.recv = None
-
-    def run(self, volume_info, visible):
-        """volume_info / visible: this frame's (replicated) cull results, e.g. from caster.ReadBackCull()."""
-        if self.world == 1:
-            return 0
-        c = self.caster
-        d, slot_bytes, shard_bytes = exchange_layout(c.gridSize, volume_info, visible, c.numVolumes, self.world)
-        if shard_bytes != self._bytes:
-            self.send = self.torch.empty(shard_bytes, dtype=self.torch.uint8, device="cuda")
-            self.recv = self.torch.empty(shard_bytes * self.world, dtype=self.torch.uint8, device="cuda")
-            self._bytes = shard_bytes
-        c.ExchangePack(self.send.data_ptr(), d)
-        self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
-        c.ExchangeUnpack(self.recv.data_ptr(), d)
-        return shard_bytes * self.world
-
-
-class LightMapExchange:
-    """Screen-space (RayCast) layers read the light map of their volume (RayCast.hlsli:76), and every rank marches its own rows
-    of every such volume inside the view march.  ONE volume is relit per frame -- visible[frameIdx % count], by the rank that
-    owns it (CSRayMarchL.hlsl:29-33; the cull is replicated, so every rank knows which) -- so per frame at most that one light
-    map has to travel, and only if its volume is on the screen-space scheme: a broadcast from its owner before the view march.
-    Frames whose relit volume is on the cube-map scheme move nothing."""
-
-    def __init__(self, caster, group=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.caster, self.group = caster, group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.stage = None
-
-    @staticmethod
-    def relit_volume(visible, frame_idx, V):
-        """The volume this frame relights (the same on every rank)."""
-        return int(visible[frame_idx % len(visible)]) if len(visible) else frame_idx % V
-
-    def run(self, volume_info, visible, frame_idx):
-        if self.world == 1:
-            return 0
-        v = self.relit_volume(visible, frame_idx, self.caster.numVolumes)
-        if not len(visible) or (int(volume_info[v][2]) & 0x8000):
-            return 0  # on the cube-map scheme (or nothing visible): only its owner's view march reads that light map
-        ptr, n = self.caster.GetBuffer(1, v)  # MV_BUF_LIGHT_MAP (device layout); the context's stream waits for the light march
-        view = _device_view(ptr, n)
-        # the collective runs on a torch-owned staging tensor (context buffers are only copied from / to)
-        if self.stage is None or self.stage.numel() != n:
-            self.stage = self.torch.empty(n, dtype=self.torch.uint8, device="cuda")
-        owner = v % self.world
-        if self.rank == owner:
-            self.stage.copy_(view)
-        self.dist.broadcast(self.stage, src=owner, group=self.group)
-        if self.rank != owner:
-            view.copy_(self.stage)
-        return n
-
-
-_IN_PLACE_REFUSED = []  # set once if torch rejects the in-place all-gather (argument checks raise before anything is enqueued)
-
-
-def gather_composite_rows(caster, H, W, rank, world, group=None):
-    """After every rank composited its row band: all-gather the bands so every rank's composite buffer holds the frame."""
+    With the NCCL (= RCCL) backend the library opens RCCL itself and creates its own two communicators from ids that rank 0 makes and
+    torch.distributed only broadcasts: no Python and no torch call inside the frame loop.  Otherwise (gloo: CPU-side tests, or RCCL
+    could not be initialised) the collectives are torch.distributed calls on tensors that alias the library's buffers, handed to the
+    library as callbacks.  Returns "rccl" or "torch-callbacks"."""
     import torch
     import torch.distributed as dist
-    ptr, nbytes = caster.GetBuffer(5)  # MV_BUF_COMPOSITE: W x H RGBA16F
-    bands = [row_range(H, r, world) for r in range(world)]
-    max_rows = max(b[1] - b[0] for b in bands)
-    row_bytes = W * 8
-    r0, r1 = bands[rank]
-    frame = _device_view(ptr, nbytes)  # aliases the context's buffer, no copy
-    if os.environ.get("MV_INPLACE_GATHER") == "1" and all(b[1] - b[0] == max_rows for b in bands) and dist.get_backend(group) == "nccl" and not _IN_PLACE_REFUSED:
-        # equal bands: the frame buffer IS the all-gather output and this rank's band its input, in place (no staging copies);
-        # NCCL / RCCL define that (sendbuff == recvbuff + rank * count) -- if this torch build objects to the overlap, stage instead
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = dist.get_backend()
+    if prefer_rccl and backend == "nccl":
         try:
-            dist.all_gather_into_tensor(frame[:world * max_rows * row_bytes], frame[r0 * row_bytes:r1 * row_bytes], group=group)
-            return world * max_rows * row_bytes
-        except (RuntimeError, ValueError):
-            _IN_PLACE_REFUSED.append(True)
-    send = torch.zeros(max_rows * row_bytes, dtype=torch.uint8, device="cuda")
-    send[:(r1 - r0) * row_bytes].copy_(frame[r0 * row_bytes:r1 * row_bytes])
-    recv = torch.empty(world * max_rows * row_bytes, dtype=torch.uint8, device="cuda")
-    dist.all_gather_into_tensor(recv, send, group=group)
-    for r, (a, b) in enumerate(bands):
-        if r != rank and b > a:
-            frame[a * row_bytes:b * row_bytes].copy_(recv[r * max_rows * row_bytes:r * max_rows * row_bytes + (b - a) * row_bytes])
-    return world * max_rows * row_bytes
+            ids = torch.zeros(256, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                ids.copy_(torch.frombuffer(bytearray(caster.DistUniqueId()), dtype=torch.uint8))
+            dist.broadcast(ids, src=0)
+            caster.DistInitRccl(bytes(ids.cpu().numpy().tobytes()))
+            return "rccl"
+        except Exception as e:  # loud, and visible in the bench line ("exchange": "torch-callbacks")
+            import sys
+            print(f"[rank {rank}] in-library RCCL transport unavailable ({e}); using torch.distributed callbacks", file=sys.stderr)
+    groups = [group_main if group_main is not None else dist.new_group(list(range(world))),
+              group_light if group_light is not None else dist.new_group(list(range(world)))]
+
+    def allgather(send, recv, nbytes, stream, which):
+        try:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                dist.all_gather_into_tensor(_device_view(recv, nbytes * world), _device_view(send, nbytes), group=groups[which])
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def allreduce(buf, count, stream, which):
+        try:
+            with torch.cuda.stream(torch.cuda.ExternalStream(stream)):
+                t = _device_view(buf, count * 4).view(torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=groups[which])
+            return 0
+        except Exception:
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    caster.DistInitCallbacks(allgather, allreduce)
+    return "torch-callbacks"
 
 
 def _device_view(ptr, nbytes):

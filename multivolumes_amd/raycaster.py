@@ -411,6 +411,43 @@ class MultiRayCaster:
     def ExchangeUnpack(self, device_ptr, slot_dim):
         self._check(self._lib.mv_exchange_unpack(self._ctx, C.c_void_p(device_ptr), slot_dim), "mv_exchange_unpack")
 
+    # ---- the multi-GPU frame loop inside the library (mv_dist_*) ----
+    @staticmethod
+    def DistUniqueId():
+        """Two RCCL unique ids (rank 0 calls this and hands the bytes to every rank)."""
+        buf = (C.c_uint8 * _lib.MV_DIST_ID_BYTES)()
+        rc_ = _lib.load().mv_dist_unique_id(buf)
+        if rc_ != 0:
+            raise _lib.MVError(rc_, "mv_dist_unique_id")
+        return bytes(buf)
+
+    def DistInitRccl(self, id_bytes):
+        buf = (C.c_uint8 * _lib.MV_DIST_ID_BYTES).from_buffer_copy(id_bytes)
+        self._check(self._lib.mv_dist_init_rccl(self._ctx, buf), "mv_dist_init_rccl")
+
+    def DistInitCallbacks(self, allgather, allreduce):
+        """allgather(send_ptr, recv_ptr, nbytes, stream, which) / allreduce(ptr, count_u32, stream, which) -> 0 on success."""
+        self._dist_cbs = (_lib.DIST_ALLGATHER_FN(lambda u, s_, r_, n, st, w: allgather(s_, r_, n, st, w)),
+                          _lib.DIST_ALLREDUCE_FN(lambda u, b, n, st, w: allreduce(b, n, st, w)))  # kept alive with the context
+        self._check(self._lib.mv_dist_init_callbacks(self._ctx, self._dist_cbs[0], self._dist_cbs[1], None), "mv_dist_init_callbacks")
+
+    def DistFrame(self, viewProj, shadowVP, eyePt, composite=True):
+        """One frame of the multi-GPU loop: begins this frame (upload .. view march) and finishes the previous one (exchange, composite)."""
+        W, H = self.viewport
+        self._lib.mvh_update_frame(self.numVolumes, _ptr(self.m_volumeWorlds), _ptr(_f32(viewProj, 16)), _ptr(_f32(shadowVP, 16)),
+                                   _ptr(_f32(eyePt, 3)), float(W), float(H), _ptr(self.m_lightPt), _ptr(self.m_lightColor),
+                                   _ptr(self.m_ambient), self.m_frameIdx, _ptr(self.cbPerFrame), _ptr(self.perObject))
+        self._check(self._lib.mv_dist_frame(self._ctx, _ptr(self.cbPerFrame), _ptr(self.perObject), 1 if composite else 0), "mv_dist_frame")
+        self.m_frameIdx += 1
+
+    def DistFlush(self):
+        self._check(self._lib.mv_dist_flush(self._ctx), "mv_dist_flush")
+
+    def DistExchangedBytes(self, reset=False):
+        n = C.c_uint64()
+        self._check(self._lib.mv_dist_exchanged_bytes(self._ctx, C.byref(n), 1 if reset else 0), "mv_dist_exchanged_bytes")
+        return n.value
+
     def ReadBackCull(self):
         """(VolumeInfo[V,4], visible list, cube-map list, min selected mip) with a single stream synchronisation."""
         info = np.zeros((self.numVolumes, 4), np.uint16)

@@ -2,11 +2,10 @@
 context; the composites and the counters must agree bit for bit at every checkpoint (event / slot / buffer rotation, counter
 width, nothing drifts).
 
-Run with MV_FORCE_TWO_SETS=1: the one-stream context then alternates its two output sets exactly like the pipelined one.
-Without it the two differ, very rarely, in single halfs of the composite: the reference never clears its cube maps, so a
-texel a frame does not write keeps old data (CSRayMarch.hlsl:84-85 returns early for faces that are not visible), a 4-tap
-CubeCast gather across a cube edge can read such a texel, and with two output sets "old" means two frames back instead of one
-(measured: 1 half of 256 k at 1 of 17 checkpoints of this orbit).  With MV_FORCE_TWO_SETS=1 every checkpoint is identical."""
+The reference never clears its cube maps, so a texel a frame does not write keeps old data (CSRayMarch.hlsl:84-85 returns early
+for faces that are not visible) and a 4-tap CubeCast gather across a cube edge can read it; with frames in flight the two output
+sets are kept reading like one by the copy-forward of unmarched faces (mv_composite.hip copyForwardKernel), which this run checks
+over tens of thousands of frames.  tests/test_gpu_configs.py holds a 600-frame version."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

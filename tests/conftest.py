@@ -4,6 +4,14 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # Load order matters in a process that uses both PyTorch-ROCm and the product library: torch bundles its own HIP runtime, and if
+    # libmultivolumes_amd.so (linked against /opt/rocm) comes first, torch's later CUDA initialisation finds "No HIP GPUs".  With torch
+    # first, the product library binds to the runtime that is already loaded.
+    import torch  # noqa: F401
+except Exception:  # CPU-only tests do not need it
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,65 @@
+"""Worker of tests/test_dist_frame_loop.py: one rank of a moving-camera sequence through the in-library multi-GPU frame loop
+(mv_dist_frame) with gloo collectives (ranks share cuda:0; RCCL refuses two ranks on one device).  Rank 0 saves the composites."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def camera_sequence(cfg, frames):
+    from multivolumes_amd import raycaster as rc, scene
+    eye0 = np.array(scene.camera(cfg)[0], np.float32)
+    proj = rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0)
+    out = []
+    for f in range(frames):
+        # orbit + dolly: volumes change scheme (cube map <-> screen-space RayCast), mip and visibility along the way
+        a = 0.11 * f
+        s = 1.0 - 0.55 * np.sin(0.35 * f) ** 2
+        e = np.array([eye0[0] * s + 30.0 * np.sin(a), eye0[1] * s, eye0[2] * s * np.cos(0.5 * a)], np.float32)
+        vp = rc.multiply(rc.look_at_lh(e, (0, 0, 0)), proj)
+        out.append((e, vp))
+    return out
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from multivolumes_amd import MultiRayCaster, _lib, scene
+    from multivolumes_amd import raycaster as rc
+    from multivolumes_amd import distributed as D
+    out_path, frames, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    cfg = dict(scene.CONFIGS["T2"], W=256, H=168 if world != 3 else 200)
+    V = cfg["V"]
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+    flags = _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
+    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world)) as c:
+        fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
+        kind = D.init_frame_loop(c)
+        assert kind == "torch-callbacks"
+        imgs, infos = [], []
+        for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
+            c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+            c.DistFrame(vp, fr["shadowVP"], e)
+            if f % every == every - 1 or f == frames - 1:
+                c.DistFlush()
+                imgs.append(c.ReadBackComposite())
+                infos.append(c.ReadBackVolumeInfo())
+        st = c.GetStats()
+        lms = np.stack([c.ReadBackLightMap(v) for v in range(V)])
+        nbytes = c.DistExchangedBytes()
+    cnt = torch.tensor([st[k] for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples")], dtype=torch.int64)
+    dist.all_reduce(cnt)
+    if rank == 0:
+        np.savez(out_path, imgs=np.stack(imgs), infos=np.stack(infos), counts=cnt.numpy(), lms=lms, nbytes=nbytes)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 """bench.py's multi-rank path on ONE GPU: two ranks share cuda:0 and the collectives go through gloo (MV_BENCH_SHARE_GPU=1, a
-functional mode -- RCCL refuses two ranks on one device).  Exercises the sharded contexts with frames in flight, the cull
-readback, the light-map broadcast, the cube-face all-gather, the row-band composite and its gather, end to end; rank 0's
-cpu_baseline leg checks its own cube maps against the oracle."""
+functional mode -- RCCL refuses two ranks on one device).  Exercises the in-library frame loop (mv_dist_frame: light-map all-reduce,
+cube-face all-gather, row-band composite and its gather, frame k - 1's exchange beside frame k's march) end to end through bench.py;
+rank 0's cpu_baseline leg checks its own cube maps against the oracle.  tests/test_dist_frame_loop.py compares pixels."""
 import json
 import os
 import socket
@@ -22,7 +22,7 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--no-pipeline"]])
+@pytest.mark.parametrize("extra", [[], ["--orbit"]])
 def test_two_ranks_on_one_gpu(extra):
     env = dict(os.environ, MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

@@ -1,0 +1,65 @@
+"""The multi-GPU frame loop inside the library (mv_dist_frame): a moving-camera sequence on 2 and 3 ranks (sharing cuda:0, gloo
+collectives handed to the library as callbacks) must reproduce the single-GPU composites, light maps and counters bit for bit --
+including the frames in which a volume changes between the cube-map and the screen-space scheme (every rank marches its own rows of
+such a volume and needs its light map whoever relit it)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def single_gpu(world, frames, every):
+    from multivolumes_amd import MultiRayCaster, _lib, scene
+    from multivolumes_amd import raycaster as rc
+    from tests.dist_worker import camera_sequence
+    cfg = dict(scene.CONFIGS["T2"], W=256, H=168 if world != 3 else 200)
+    V = cfg["V"]
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64) as c:
+        fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
+        imgs, infos = [], []
+        for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
+            c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+            c.UpdateFrame(vp, fr["shadowVP"], e)
+            c.Render(composite=True)
+            if f % every == every - 1 or f == frames - 1:
+                imgs.append(c.ReadBackComposite())
+                infos.append(c.ReadBackVolumeInfo())
+        st = c.GetStats()
+        lms = np.stack([c.ReadBackLightMap(v) for v in range(V)])
+    return np.stack(imgs), np.stack(infos), np.array([st[k] for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples")]), lms
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_dist_frame_loop_matches_single_gpu(tmp_path, world):
+    frames, every = 26, 3
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    imgs, infos, counts, lms = single_gpu(world, frames, every)
+    assert np.array_equal(d["infos"], infos), "the cull is replicated"
+    schemes = {tuple((infos[i][:, 2] & 0x8000).tolist()) for i in range(len(infos))}
+    assert len(schemes) > 1, "the sequence must move volumes between the cube-map and the screen-space scheme"
+    for i in range(len(imgs)):
+        assert np.array_equal(d["imgs"][i], imgs[i]), f"composite of checkpoint {i} differs ({(d['imgs'][i] != imgs[i]).sum()} halfs)"
+    assert np.array_equal(d["lms"], lms), "every rank holds every light map, current"
+    assert np.array_equal(d["counts"], counts), "the ranks together march exactly the single-GPU samples"
+    assert int(d["nbytes"]) > 0

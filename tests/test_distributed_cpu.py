@@ -65,7 +65,7 @@ def _worker(rank, world, port, out_path):
         # frame f relights visible[f % count] (CSRayMarchL.hlsl:29-33) on the rank that owns that volume; the others skip the light march
         lms = None
         for f in range(len(vis)):
-            if D.LightMapExchange.relit_volume(vis, f, V) not in mine:
+            if (int(vis[f % len(vis)]) if len(vis) else f % V) not in mine:
                 continue
             _, _, _, cbf, _ = host_frame(cfg, f)
             _, lms, _ = o.march_light(V, N, L, M, vols, descs, po, cbf, shadow, None, vis, cfg["maxLight"], lms)

@@ -353,3 +353,35 @@ def test_c3_with_the_reference_scenes_mesh(oracle):
             assert np.array_equal(c.ReadBackCubeDepth(int(v), mip), oracle.cube_face_view(cd[v], N, mip)), f"cube depth {v}"
         g = c.GetStats()
         assert g["view_samples"] == st["view_samples"] and g["lit_samples"] == st["lit_samples"] and g["rays"] == st["rays"]
+
+
+def test_orbit_with_frames_in_flight_reads_like_one_output_set():
+    """The reference never clears its cube maps: a face a frame does not march keeps older data, and a CubeCast gather across a cube
+    edge can read it.  With frames in flight two output sets alternate; the copy-forward of unmarched faces must make them read
+    exactly like the single set of a one-stream context.  An orbit that keeps changing face masks, mips and schemes, composites
+    compared every few frames (scripts/soak.py runs the same for 40 000 frames)."""
+    cfg = dict(scene.CONFIGS["T2"], W=320, H=200)
+    V, N = cfg["V"], cfg["N"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    proj = rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0)
+    cs = [make_caster(cfg, 64, flags=f) for f in (0, _lib.MV_FLAG_PIPELINE_FRAMES)]
+    try:
+        frs = [scene.setup_raycaster(c, cfg, vols, use_sh=True) for c in cs]
+        differing = 0
+        for f in range(1, 601):
+            a = 0.02 * f  # ten times the soak's angular speed: about two turns
+            e = np.array([90.0 * np.sin(a), 20.0 + 15.0 * np.sin(0.37 * a), -90.0 * np.cos(a)], np.float32)
+            vp = rc.multiply(rc.look_at_lh(e, (0, 0, 0)), proj)
+            for c, fr in zip(cs, frs):
+                c.UpdateFrame(vp, fr["shadowVP"], e)
+                c.Render(composite=True)
+            if f % 7 == 0:
+                a_img, b_img = cs[0].ReadBackComposite(), cs[1].ReadBackComposite()
+                differing += int((a_img != b_img).sum())
+        assert differing == 0, f"{differing} composite halfs differ between one stream and frames in flight"
+        sa, sb = cs[0].GetStats(), cs[1].GetStats()
+        for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples"):
+            assert sa[k] == sb[k], k
+    finally:
+        for c in cs:
+            c.close()
