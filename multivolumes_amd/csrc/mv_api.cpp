@@ -1530,6 +1530,57 @@ int mv_dist_flush(mv_ctx* ctx)
 	return distTail(ctx);
 }
 
+// One all-gather (separate buffers), one in-place all-gather and one all-reduce on each communicator, checked on the host: run once
+// after mv_dist_init_* so that a broken transport fails before any frame does.
+int mv_dist_selftest(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
+	DistState* d = ctx->dist;
+	const uint32_t world = ctx->st.shardCount, rank = ctx->st.shardIndex;
+	const size_t n = 4096;	// bytes per rank
+	MV_REQUIRE(ctx, d->sendCap >= n && d->maxBandBytes >= n, MV_ERR_RANGE, "self-test buffers");
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	std::vector<uint8_t> h(n * world), g(n * world);
+	for (int which = 0; which < 2; ++which)
+	{
+		hipStream_t s = which == 0 ? d->streamX : ctx->streamL;
+		// all-gather, separate buffers
+		for (size_t i = 0; i < n; ++i) h[i] = (uint8_t)(rank * 31u + i * 7u + which);
+		MV_HIP(ctx, hipMemcpyAsync(d->sendBuf, h.data(), n, hipMemcpyHostToDevice, s));
+		int rc = distAllGather(ctx, d->sendBuf, d->recvBuf, n, s, which);
+		if (rc != MV_OK) return rc;
+		MV_HIP(ctx, hipMemcpyAsync(g.data(), d->recvBuf, n * world, hipMemcpyDeviceToHost, s));
+		MV_HIP(ctx, hipStreamSynchronize(s));
+		for (uint32_t r = 0; r < world; ++r)
+			for (size_t i = 0; i < n; ++i)
+				MV_REQUIRE(ctx, g[r * n + i] == (uint8_t)(r * 31u + i * 7u + which), MV_ERR_HIP, "all-gather self-test: wrong bytes");
+		// in place (the row-band gather of equal bands): sendbuff == recvbuff + rank * count
+		if (d->transport == 1)
+		{
+			MV_HIP(ctx, hipMemsetAsync(d->rowRecv, 0, n * world, s));
+			MV_HIP(ctx, hipMemcpyAsync(d->rowRecv + (size_t)rank * n, h.data(), n, hipMemcpyHostToDevice, s));
+			rc = distAllGather(ctx, d->rowRecv + (size_t)rank * n, d->rowRecv, n, s, which);
+			if (rc != MV_OK) return rc;
+			MV_HIP(ctx, hipMemcpyAsync(g.data(), d->rowRecv, n * world, hipMemcpyDeviceToHost, s));
+			MV_HIP(ctx, hipStreamSynchronize(s));
+			for (uint32_t r = 0; r < world; ++r)
+				for (size_t i = 0; i < n; ++i)
+					MV_REQUIRE(ctx, g[r * n + i] == (uint8_t)(r * 31u + i * 7u + which), MV_ERR_HIP, "in-place all-gather self-test: wrong bytes");
+		}
+		// all-reduce (integer sum; only one rank contributes non-zero words, like the light-map exchange)
+		std::vector<uint32_t> w(256, 0u);
+		if (rank == world - 1u) for (uint32_t i = 0; i < 256; ++i) w[i] = 0x9e3779b9u * (i + 1u) + which;
+		MV_HIP(ctx, hipMemcpyAsync(d->lightWords, w.data(), 1024, hipMemcpyHostToDevice, s));
+		rc = distAllReduceU32(ctx, d->lightWords, 256, s, which);
+		if (rc != MV_OK) return rc;
+		MV_HIP(ctx, hipMemcpyAsync(w.data(), d->lightWords, 1024, hipMemcpyDeviceToHost, s));
+		MV_HIP(ctx, hipStreamSynchronize(s));
+		for (uint32_t i = 0; i < 256; ++i) MV_REQUIRE(ctx, w[i] == 0x9e3779b9u * (i + 1u) + which, MV_ERR_HIP, "all-reduce self-test: wrong words");
+	}
+	return MV_OK;
+}
+
 int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset)
 {
 	if (!ctx || !bytes) return MV_ERR_INVALID_ARG;

@@ -98,6 +98,7 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
                 ids.copy_(torch.frombuffer(bytearray(caster.DistUniqueId()), dtype=torch.uint8))
             dist.broadcast(ids, src=0)
             caster.DistInitRccl(bytes(ids.cpu().numpy().tobytes()))
+            caster.DistSelfTest()  # every collective the frame loop uses, verified once, before any frame
             return "rccl"
         except Exception as e:  # loud, and visible in the bench line ("exchange": "torch-callbacks")
             import sys
@@ -127,6 +128,7 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
             return 1
 
     caster.DistInitCallbacks(allgather, allreduce)
+    caster.DistSelfTest()
     return "torch-callbacks"
 
 

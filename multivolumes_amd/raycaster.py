@@ -431,6 +431,9 @@ class MultiRayCaster:
                           _lib.DIST_ALLREDUCE_FN(lambda u, b, n, st, w: allreduce(b, n, st, w)))  # kept alive with the context
         self._check(self._lib.mv_dist_init_callbacks(self._ctx, self._dist_cbs[0], self._dist_cbs[1], None), "mv_dist_init_callbacks")
 
+    def DistSelfTest(self):
+        self._check(self._lib.mv_dist_selftest(self._ctx), "mv_dist_selftest")
+
     def DistFrame(self, viewProj, shadowVP, eyePt, composite=True):
         """One frame of the multi-GPU loop: begins this frame (upload .. view march) and finishes the previous one (exchange, composite)."""
         W, H = self.viewport

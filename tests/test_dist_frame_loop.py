@@ -63,3 +63,36 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world):
     assert np.array_equal(d["lms"], lms), "every rank holds every light map, current"
     assert np.array_equal(d["counts"], counts), "the ranks together march exactly the single-GPU samples"
     assert int(d["nbytes"]) > 0
+
+
+def test_rccl_transport_on_one_rank():
+    """What can be checked of the RCCL transport on a one-GPU box: the library opens librccl itself, creates its two communicators
+    from the ids (world size 1), and every collective the frame loop uses passes the verified self-test; a short mv_dist_frame
+    sequence then equals the plain single-GPU frames.  (More than one rank per GPU is refused by RCCL: the protocol itself is
+    tested over gloo above; 8 physical GPUs are the driver's to launch.)"""
+    import torch.distributed as dist
+    from multivolumes_amd import MultiRayCaster, _lib, scene
+    from multivolumes_amd import raycaster as rc
+    from multivolumes_amd import distributed as D
+    from tests.dist_worker import camera_sequence
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cfg = dict(scene.CONFIGS["T2"], W=256, H=168)
+        V = cfg["V"]
+        vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+        frames = 9
+        flags = _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
+        with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(0, 1)) as c:
+            fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
+            assert D.init_frame_loop(c) == "rccl"
+            for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
+                c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+                c.DistFrame(vp, fr["shadowVP"], e)
+            c.DistFlush()
+            got = c.ReadBackComposite()
+        imgs, _, _, _ = single_gpu(2, frames, frames)
+        assert np.array_equal(got, imgs[-1])
+    finally:
+        dist.destroy_process_group()
