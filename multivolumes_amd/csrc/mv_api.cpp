@@ -877,16 +877,18 @@ int mv_march_view(mv_ctx* ctx)
 		// with one plain read and no wait.  Tile counts move slowly from frame to frame; when one jumps past the margin (a volume
 		// changing scheme) the overflow launch inside launchMarchTiles marches the rest, so the estimate only affects speed.
 		uint32_t tiles = 0xffffffffu;
+		bool exact = false;
 		if (ctx->pinnedTiles)
 		{
 			const unsigned long long v = *reinterpret_cast<const volatile unsigned long long*>(ctx->pinnedTiles);
 			if (v != ~0ull)
 			{
 				const uint32_t count = (uint32_t)v;
-				tiles = (uint32_t)(v >> 32) == (uint32_t)ctx->frame ? count : count + count / 4u + 256u;
+				exact = (uint32_t)(v >> 32) == (uint32_t)ctx->frame;	// this frame's cull has already run (it runs ahead on stream A)
+				tiles = exact ? count : count + count / 4u + 256u;
 			}
 		}
-		mv::launchMarchTiles(streamB(ctx), ctx->st, tiles);
+		mv::launchMarchTiles(streamB(ctx), ctx->st, tiles, exact);
 	}
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());

@@ -287,6 +287,37 @@ __device__ __forceinline__ FootprintAddr footprintAddr(const VolumeView& v, vec3
 	return footprintAddr(v.N, v.strideY, v.strideZ, uvw, ox, oy, oz);
 }
 
+// ---- address tables in LDS ----------------------------------------------------------------------
+// What a texture unit's address path does per tap -- clamp, split into brick and in-brick index, multiply by the pitches -- depends
+// only on ONE integer per axis, so a kernel can tabulate it: entry j of an axis holds, for the first tap i0 = max(j - 1, 0) and the
+// second tap i1 = min(j, N - 1) (j = floor(coordinate) + 1 clamped to [0, N]: clamp addressing is in the table),
+//   .x / .y = the byte offsets the two taps contribute to a texel address,
+//   .z      = what i0 contributes to the brick-occupancy lookup: word index in bits 0-23, bit index in bits 24-29 (the three axes'
+//             contributions simply add up: their fields cannot carry into each other),
+//   .w      = 0 where both taps are the same texel, all ones otherwise (the mask of the weight for cell fetches).
+// 3 (N + 1) entries of 16 bytes per workgroup: 12 KiB at N = 256.  One ds_read_b128 per axis replaces about twenty VALU
+// instructions of clamping, shifting and multiplying, in a kernel that issues about 230 VALU instructions per wave-sample.
+__device__ __forceinline__ u32x4 axisTableEntry(uint32_t axis, uint32_t j, uint32_t N, uint32_t strideY, uint32_t strideZ, uint32_t regions)
+{
+	const uint32_t i0 = j ? j - 1u : 0u, i1 = j < N - 1u ? j : N - 1u;
+	u32x4 e;
+	if (axis == 0u) { e.x = offX((int)i0); e.y = offX((int)i1); e.z = (i0 >> 4) | (((i0 >> 2) & 3u) << 24); }
+	else if (axis == 1u) { e.x = offY((int)i0, strideY); e.y = offY((int)i1, strideY); e.z = ((i0 >> 4) * regions) | (((i0 >> 2) & 3u) << 26); }
+	else { e.x = offZ((int)i0, strideZ); e.y = offZ((int)i1, strideZ); e.z = ((i0 >> 4) * regions * regions) | (((i0 >> 2) & 3u) << 28); }
+	e.w = i1 == i0 ? 0u : 0xffffffffu;
+	return e;
+}
+
+// index of a coordinate's table entry and its filter weight (LINEAR sampler: c = u * size - 0.5)
+__device__ __forceinline__ uint32_t axisTableIndex(float coord01, uint32_t size, float& frac)
+{
+	const float c = coord01 * (float)size - 0.5f;
+	const float fl = __builtin_floorf(c);
+	frac = c - fl;
+	// float clamp first (NaN -> -1), so that the conversion is in range: floor + 1 in [0, size]
+	return (uint32_t)((int)__builtin_fminf(__builtin_fmaxf(fl, -1.0f), (float)size - 1.0f) + 1);
+}
+
 // ---- brick occupancy ---------------------------------------------------------------------------
 // One bit per 4x4x4 brick: set when ANY texel of the brick or of its +1 halo (the texels a trilinear footprint whose first
 // taps lie in the brick can read) has alpha above kOccupancyLimit.  A clear bit proves that the interpolated alpha of such a

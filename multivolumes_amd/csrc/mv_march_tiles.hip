@@ -20,6 +20,9 @@ constexpr uint32_t kTileWaves = MV_TILE_WAVES;
 #ifndef MV_PREDICT_LIT
 #define MV_PREDICT_LIT 1
 #endif
+#ifndef MV_TILE_LUT
+#define MV_TILE_LUT 1	// per-axis address tables in LDS (N <= 256); 0 = compute every tap's offsets (A/B timing)
+#endif
 #ifndef MV_TILE_MIN_WAVES
 #define MV_TILE_MIN_WAVES 3	// occupancy bound given to the register allocator / scheduler. Measured at C3: 3 -> 0.360 ms, 5 -> 0.395, 6 -> 0.414,
 							// 7 -> 0.46, 8 -> 0.60 (spills); all of 1..5 allocate about 90 VGPRs, the looser bound schedules loads earlier
@@ -34,12 +37,25 @@ static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 
 // OVERFLOW = false: the main launch, wavefront w marches dispatch slot w.  OVERFLOW = true: a small second launch that marches every
 // slot from `firstSlot` on, a grid apart (the loop costs 20 VGPRs, i.e. one wavefront per SIMD, which is why the main launch has none).
-template <bool OVERFLOW>
+// LUT = the volume's per-axis address tables live in LDS (mv_device.hpp "address tables"): used while they leave room for five
+// wavefronts per SIMD (N <= kLutMaxN).
+constexpr uint32_t kLutMaxN = 256;
+template <bool OVERFLOW, bool LUT>
 __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesKernel(DeviceState st, uint32_t firstSlot)
 {
+	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
+	if (LUT)
+	{
+		if (!OVERFLOW && blockIdx.x * kTileWaves >= nTiles) return;	// a surplus workgroup: nothing to march, no table to build
+		const uint32_t P = st.N + 1u, regions = occupancyRegions(st.bricks);
+		const uint32_t strideY = brickPitchY(st.bricks) * 512u, strideZ = brickPitchZ(st.bricks) * 512u;
+		for (uint32_t k = threadIdx.x; k < 3u * P; k += 64u * kTileWaves)
+			sAxis[(k / P) * (kLutMaxN + 1u) + k % P] = axisTableEntry(k / P, k % P, st.N, strideY, strideZ, regions);
+		__syncthreads();
+	}
 
 	// Dispatch slot -> tile: list order or the cost-binned order (tileOrderKernel).  Workgroups are dealt round-robin over the 8
 	// XCDs, so every XCD sees an even mix of volumes and of cube / screen tiles; placement only affects speed.
@@ -170,16 +186,27 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 				if (outsideBox(pos)) break;	// :120
 				const vec3 uvw = LocalToTex3DSpace(pos);
 
-				const FootprintAddr fa = footprintAddr(vol, uvw);
+				FootprintAddr fa;
+				uint32_t occSum = 0u;
+				if (LUT)
+				{
+					const u32x4 ex = sAxis[axisTableIndex(uvw.x, vol.N, fa.fx)];
+					const u32x4 ey = sAxis[(kLutMaxN + 1u) + axisTableIndex(uvw.y, vol.N, fa.fy)];
+					const u32x4 ez = sAxis[2u * (kLutMaxN + 1u) + axisTableIndex(uvw.z, vol.N, fa.fz)];
+					fa.x0 = ex.x; fa.x1 = ex.y;
+					fa.r00 = ey.x + ez.x; fa.r10 = ey.y + ez.x; fa.r01 = ey.x + ez.y; fa.r11 = ey.y + ez.y;
+					occSum = ex.z + ey.z + ez.z;
+				}
+				else fa = footprintAddr(vol, uvw);
 #if MV_OCCUPANCY
 				// Empty space: a clear occupancy bit proves alpha <= ZERO_THRESHOLD, for which the loop below only advances t.
 				// At C3 this skips the fetch of 44 % of the samples (87 % of the unlit ones): 0.325 -> 0.258 ms, HBM traffic
 				// 1.66 -> 1.24 GB per launch.  One 64-bit word covers a 16^3-texel region and is reloaded (an L2 hit) when the
 				// ray enters another one; requesting the next region's word ahead of time was measured slower (0.289 ms).
 				{
-					const uint32_t w = occupancyWord(fa.ix, fa.iy, fa.iz, regions);
+					const uint32_t w = LUT ? occSum & 0xffffffu : occupancyWord(fa.ix, fa.iy, fa.iz, regions);
 					if (w != occIndex) { occWord = occupancy[w]; occIndex = w; }
-					if (!((occWord >> occupancyBit(fa.ix, fa.iy, fa.iz)) & 1ull))
+					if (!((occWord >> (LUT ? occSum >> 24 : occupancyBit(fa.ix, fa.iy, fa.iz))) & 1ull))
 					{
 						++nSamples;
 						++nSkipped;
@@ -269,12 +296,12 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 uint32_t marchTilesResidentWaves(int device)
 {
 	int perCu = 0, cus = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, marchTilesKernel<false>, 64 * kTileWaves, 0) != hipSuccess || perCu <= 0) perCu = 8;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, marchTilesKernel<false, true>, 64 * kTileWaves, 0) != hipSuccess || perCu <= 0) perCu = 8;
 	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
 	return (uint32_t)perCu * (uint32_t)cus * kTileWaves;
 }
 
-void launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
+void launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles, bool exact)
 {
 	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has
 	// none).  The main grid covers min(estimate, largest possible frame); the overflow launch covers whatever lies beyond it.
@@ -282,8 +309,9 @@ void launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
 	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
 	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
 	blocks = ((blocks + 7) / 8) * 8;
-	hipLaunchKernelGGL(marchTilesKernel<false>, dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
-	if (blocks * kTileWaves < maxTiles)
-		hipLaunchKernelGGL(marchTilesKernel<true>, dim3(256), dim3(64 * kTileWaves), 0, s, st, (uint32_t)(blocks * kTileWaves));
+	if (st.N <= kLutMaxN) hipLaunchKernelGGL((marchTilesKernel<false, MV_TILE_LUT != 0>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+	else hipLaunchKernelGGL((marchTilesKernel<false, false>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+	if (!exact && blocks * kTileWaves < maxTiles)	// (an exact count is this frame's own: nothing can lie beyond the grid)
+		hipLaunchKernelGGL((marchTilesKernel<true, false>), dim3(256), dim3(64 * kTileWaves), 0, s, st, (uint32_t)(blocks * kTileWaves));
 }
 } // namespace mv

@@ -6,12 +6,12 @@ f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].replace("mv::", ""), r.get("Queue_Id", "?")) for r in rows)
 # keep the steady state: from the (skip)th marchViewKernel on
-mv = [i for i, e in enumerate(ev) if e[2].startswith("marchViewKernel")]
+mv = [i for i, e in enumerate(ev) if e[2].startswith("marchTilesKernel")]
 lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.34
 hi = float(sys.argv[3]) if len(sys.argv) > 3 else 0.99
 ev = ev[mv[int(lo * len(mv))]:mv[min(len(mv) - 2, int(hi * len(mv)))]]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
-n = sum(1 for e in ev if e[2].startswith("marchViewKernel"))
+n = sum(1 for e in ev if e[2].startswith("marchTilesKernel"))
 print("frames %d  span %.3f ms  -> %.4f ms/frame" % (n, (t1 - t0) / 1e6, (t1 - t0) / 1e6 / n))
 dur = collections.defaultdict(list)
 for s, e, k, q in ev: dur[(k, q)].append(e - s)

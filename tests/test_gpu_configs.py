@@ -141,6 +141,7 @@ def check_sharded(cfg, M, world):
             d, slot_bytes, shard_bytes = c.ExchangeLayout()
             assert (d, slot_bytes, shard_bytes) == D.exchange_layout(N, info, vis, V, world)
             buf = torch.zeros(shard_bytes, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # torch fills on ITS stream; the pack below runs on the context's
             c.ExchangePack(buf.data_ptr(), d)
             c.synchronize()
             packed.append(buf)
@@ -157,6 +158,7 @@ def check_sharded(cfg, M, world):
         assert tot["composite_samples"] == ref_stats["composite_samples"], "RayCast pixels are split by rows, none marched twice"
         assert tot["light_samples"] == ref_stats["light_samples"], "every light march ran on exactly one shard"
         gathered = torch.cat(packed)
+        torch.cuda.synchronize()  # torch.cat ran on torch's stream; the unpack below runs on the context's
         for r, c in enumerate(shards):
             c.ExchangeUnpack(gathered.data_ptr(), d)
             for v in cube:

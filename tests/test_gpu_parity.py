@@ -397,6 +397,7 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
             d, slot_bytes, shard_bytes = c.ExchangeLayout()
             assert (d, slot_bytes, shard_bytes) == D.exchange_layout(N, info, vis, V, world)
             buf = torch.zeros(shard_bytes, dtype=torch.uint8, device="cuda")
+            torch.cuda.synchronize()  # torch fills on ITS stream; the pack below runs on the context's
             c.ExchangePack(buf.data_ptr(), d)
             info2, vis2, cube2, min_mip = c.ReadBackCull()
             assert np.array_equal(info2, info) and np.array_equal(vis2, vis) and np.array_equal(cube2, cube) and (N >> min_mip) == d
@@ -416,6 +417,7 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
         assert tot_samples == ref_stats["view_samples"] and tot_rays == ref_stats["rays"]
         assert tot_raycast == ref_stats["composite_samples"] > 0, "the RayCast pixels are split by rows, none marched twice"
         gathered = torch.cat(packed)
+        torch.cuda.synchronize()  # torch.cat ran on torch's stream; the unpack below runs on the context's
         for r, c in enumerate(shards):
             c.ExchangeUnpack(gathered.data_ptr(), d)
             for v in cube:

@@ -288,3 +288,45 @@ def test_eight_bit_filter_weights_bound(oracle):
     # a ray whose alpha crosses ZERO_THRESHOLD or whose step changes under the snapped weights takes other samples: single texels
     # move by far more than the filter error; the bulk does not
     assert d.mean() < 2e-3 and frac < 0.25
+
+
+def test_kat_a7_screen_space_raycast_layer(oracle):
+    """A volume on the screen-space scheme (MaskBits without CUBEMAP_RAYMARCH_BIT, VSCube.hlsl:73 -> SmpCnt > 0) is marched per pixel by
+    RayCast (RayCast.hlsli:43-108): the same loop as the view march, from the box entry along normalize(LPt - eye), no target clamp,
+    tMax from the pixel's own depth.  Homogeneous volume + constant light: the centre pixel equals the closed-form recurrence of KAT 1,
+    and a mesh plane in front of the far face cuts the march (GetTMax, RayMarch.hlsli:82-97)."""
+    from tests.test_oracle_kat import emulate_march, homogeneous_volume, MAX_DIST
+    lib = oracle.load()
+    N, L, smp, W, H = 8, 4, 16, 64, 64
+    alpha, c = F(np.float16(0.3)), F(np.float16(0.5))
+    vol = homogeneous_volume(N, c, alpha)
+    cb, po = scene([(0, 0, 0)], W=W, H=H)
+    info = np.array([[0, smp, 0x3F, 0]], np.uint16)  # all faces, screen-space scheme
+    lm = np.full((1, L, L, L), lib.mvo_pack_r11g11b10f(1.0, 1.0, 1.0), np.uint32)
+    chain = oracle.cube_chain_texels(N)
+    cm, cd = np.zeros((1, chain, 4), np.uint16), np.ones((1, chain), np.float32)
+    vis = np.array([0], np.uint32)
+
+    def centre(depth_map):
+        img, n = oracle.composite(1, N, L, W, H, [vol], lm, depth_map, po, cb, info, vis, cm, cd)
+        return half_to_float(img)[32, 32], n
+
+    # the pixel's ray: eye (0, 0, -5), through ndc (1/64, -1/64) -> enters at z = -1
+    t = math.tan(math.pi / 8)
+    d = np.array([(32.5 / 32 - 1) * t, -(32.5 / 32 - 1) * t, 1.0], np.float64)
+    d /= np.linalg.norm(d)
+    o = np.array([0, 0, -5], np.float64) + d * (4.0 / d[2])
+    rgb, A, it = emulate_march(alpha, c, 1.0, smp, F(3.0e38), o.astype(F), d.astype(F))
+    px, n = centre(np.ones((H, W), np.float32))
+    assert n > 0
+    assert px[3] == pytest.approx(float(A), abs=1e-3) and px[0] == pytest.approx(float(rgb), abs=1e-3) and px[0] == px[1] == px[2]
+    # closed form: A_n = 1 - (1 - 0.8 a)^n with n = iterations of the recurrence
+    assert float(A) == pytest.approx(1 - (1 - 0.8 * float(alpha)) ** it, abs=2e-3)
+
+    # a mesh plane at view z = 5.0 (local z = 0: half way through the cube) stops the ray there
+    zv = 5.0
+    plane = np.full((H, W), (1000.0 / 999.0) * (1.0 - 1.0 / zv), np.float32)
+    t_max = (0.0 - o[2]) / d[2]
+    rgb2, A2, it2 = emulate_march(alpha, c, 1.0, smp, F(t_max), o.astype(F), d.astype(F))
+    px2, _ = centre(plane)
+    assert it2 < it and px2[3] == pytest.approx(float(A2), abs=1e-3) and px2[0] == pytest.approx(float(rgb2), abs=1e-3)
