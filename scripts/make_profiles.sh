@@ -18,11 +18,11 @@ traffic = {"source_hash": H}
 for tag, name in (("c3", "C3"), ("c3_stress", "C3-stress")):
     k = {}
     for line in open(f"{out}/pmc_{tag}.txt"):
-        m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+(\S+)\s+n\s+\d+\s+mean\(last 8\)\s+(\S+)", line)
+        m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+(.+?)\s+n\s+\d+\s+mean\(last 8\)\s+(\S+)", line)
         if m: k.setdefault(m.group(2), {})[m.group(1) + "_KB_per_launch"] = float(m.group(3))
     for v in k.values(): v["hbm_bytes_per_launch"] = (2 * v.get("FETCH_SIZE_KB_per_launch", 0) + v.get("WRITE_SIZE_KB_per_launch", 0)) * 1024
     res["configs"][name] = k
-    mv = [v for n, v in k.items() if "marchTilesKernel<false>" in n or "marchTilesKernel<(bool)0>" in n]
+    mv = [v for n, v in k.items() if "marchTilesKernel<false" in n]
     if mv: traffic[name] = {"marchViewKernel_hbm_bytes_per_launch": mv[0]["hbm_bytes_per_launch"]}
 json.dump(res, open(f"{out}/{R}_pmc_hbm_traffic.json", "w"), indent=1)
 json.dump(traffic, open("/root/repo/profiles/traffic.json", "w"), indent=1)   # bench.py reads it for roofline.traffic (only while source_hash matches)
