@@ -166,8 +166,12 @@ int mv_march_light(mv_ctx* ctx);
 /* rayMarchV (MultiRayCaster.cpp:1329-1368) = CSRayMarch.hlsl:77-158 with _LIGHT_PASS_ (CSRayMarchV.hlsl). */
 int mv_march_view(mv_ctx* ctx);
 /* cubeDepthPeel + renderCube + resolveOIT (MultiRayCaster.cpp:1440-1492, 1544-1580, 1615-1633) over screen rows
- * [row0, row1) of the W x H RGBA16F output (row1 = 0 -> H). Background = transparent black. */
+ * [row0, row1) of the W x H RGBA16F output (row1 = 0 -> H). Background = transparent black (see mv_composite_over). */
 int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1);
+/* The same drawn OVER an existing colour target, as the reference's resolve pass is (PREMULTIPLITED blend preset, MultiRayCaster.cpp:931,
+ * 1615-1633): out = src + dst * (1 - src.a) on all four channels.  d_background: W x H RGBA16F texels on the device (borrowed, only read),
+ * e.g. the scene the mesh renderer produced; NULL = transparent black = mv_composite. */
+int mv_composite_over(mv_ctx* ctx, uint32_t row0, uint32_t row1, const void* d_background);
 /* Render (MultiRayCaster.cpp:355-385), non-work-graph branch: cull -> marchL -> marchV [-> composite]; FrameIdx += 1 is the caller's job. */
 int mv_render(mv_ctx* ctx, int with_composite);
 

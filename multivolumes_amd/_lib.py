@@ -83,6 +83,7 @@ ABI = {
     "mv_march_light": (C.c_int, [_P]),
     "mv_march_view": (C.c_int, [_P]),
     "mv_composite": (C.c_int, [_P, _U32, _U32]),
+    "mv_composite_over": (C.c_int, [_P, _U32, _U32, _P]),
     "mv_render": (C.c_int, [_P, C.c_int]),
     "mv_readback_volume_info": (C.c_int, [_P, _P]),
     "mv_readback_visible_lists": (C.c_int, [_P, _P, C.POINTER(_U32), _P, C.POINTER(_U32)]),

@@ -896,7 +896,9 @@ int mv_march_view(mv_ctx* ctx)
 	return MV_OK;
 }
 
-int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
+int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1) { return mv_composite_over(ctx, row0, row1, nullptr); }
+
+int mv_composite_over(mv_ctx* ctx, uint32_t row0, uint32_t row1, const void* d_background)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
@@ -908,7 +910,7 @@ int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1)
 	if (ctx->numOutSets == 2u && ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[ctx->slot], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 3, ev, streamB(ctx));
-	mv::launchComposite(streamB(ctx), ctx->st, row0, row1);
+	mv::launchComposite(streamB(ctx), ctx->st, row0, row1, d_background);
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, stageBDone(ctx));

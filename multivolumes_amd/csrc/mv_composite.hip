@@ -314,7 +314,7 @@ __device__ __forceinline__ vec4 CubeCast(const uint2* cubeMap, const float* cube
 #ifndef MV_COMPOSITE_MIN_WAVES
 #define MV_COMPOSITE_MIN_WAVES 4
 #endif
-__global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1)
+__global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t tilesX = (st.W + 7u) >> 3;
@@ -420,6 +420,14 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 			}
 		}
 		result.w = __builtin_fminf(result.w, 0.9997f);	// PSResolveOIT.hlsl:23
+		if (background)
+		{
+			// the resolve is drawn over the scene's colour target with the PREMULTIPLITED blend preset (MultiRayCaster.cpp:931):
+			// dst = src + dst * (1 - src.a), colour and alpha alike, blended in fp32 and rounded to the target's format once
+			const vec4 dst = decodeTexel(background[(size_t)py * st.W + px]);
+			const float inv = 1.0f - result.w;
+			result.x = result.x + dst.x * inv; result.y = result.y + dst.y * inv; result.z = result.z + dst.z * inv; result.w = result.w + dst.w * inv;
+		}
 		uint2 o;
 		o.x = (uint32_t)float_to_half_bits(result.x) | ((uint32_t)float_to_half_bits(result.y) << 16);
 		o.y = (uint32_t)float_to_half_bits(result.z) | ((uint32_t)float_to_half_bits(result.w) << 16);
@@ -433,9 +441,9 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 	if (lane == 0 && tot && slot < st.compositeSlots) st.compositeStats[slot] += tot;
 }
 
-void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1)
+void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background)
 {
 	const uint32_t tilesX = (st.W + 7u) >> 3, tilesY = (row1 - row0 + 7u) >> 3;
-	hipLaunchKernelGGL(compositeKernel, dim3(tilesX * tilesY), dim3(64), 0, s, st, row0, row1);
+	hipLaunchKernelGGL(compositeKernel, dim3(tilesX * tilesY), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background));
 }
 } // namespace mv

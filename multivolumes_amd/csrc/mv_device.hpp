@@ -340,7 +340,37 @@ __device__ __forceinline__ uint32_t occupancyBit(uint32_t ix, uint32_t iy, uint3
 #ifndef MV_ALPHA_QUADS
 #define MV_ALPHA_QUADS 1
 #endif
-#if MV_ALPHA_QUADS
+#if MV_ALPHA_QUADS == 2
+// Pair form: the companion holds 4 bytes per texel -- {a(x,y,z), a(x+1,y,z)}, +1 clamped -- in the texels' own brick layout
+// (256 bytes per brick), and a footprint is the pairs of its four (y, z) rows: four aligned 4-byte loads, half the bytes of the quads.
+struct AlphaFootprint { uint32_t p00, p10, p01, p11; float cx, cy, cz; };
+
+__device__ __forceinline__ AlphaFootprint fetchAlphaCell(const VolumeView& v, const FootprintAddr& a)
+{
+	AlphaFootprint f;
+	f.p00 = *(GlobalUint)(v.cells + ((a.r00 + a.x0) >> 1));
+	f.p10 = *(GlobalUint)(v.cells + ((a.r10 + a.x0) >> 1));
+	f.p01 = *(GlobalUint)(v.cells + ((a.r01 + a.x0) >> 1));
+	f.p11 = *(GlobalUint)(v.cells + ((a.r11 + a.x0) >> 1));
+	f.cx = a.cx; f.cy = a.fy; f.cz = a.fz;	// the y and z taps are the sampler's own: their own weights
+	return f;
+}
+
+__device__ __forceinline__ float lerpRegisterHalves(uint32_t reg, float w)
+{
+	float d, r;
+	asm("v_fma_mix_f32 %0, %1, 1.0, -%1 op_sel:[1,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(reg));
+	asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(w), "v"(d), "v"(reg));
+	return r;
+}
+
+__device__ __forceinline__ float resolveAlpha(const AlphaFootprint& f)
+{
+	const float x00 = lerpRegisterHalves(f.p00, f.cx), x10 = lerpRegisterHalves(f.p10, f.cx);
+	const float x01 = lerpRegisterHalves(f.p01, f.cx), x11 = lerpRegisterHalves(f.p11, f.cx);
+	return lerpf(lerpf(x00, x10, f.cy), lerpf(x01, x11, f.cy), f.cz);
+}
+#elif MV_ALPHA_QUADS
 // Quad form (default): the companion holds 8 bytes per texel -- {a(x,y,z), a(x+1,y,z), a(x,y,z+1), a(x+1,y,z+1)}, +1 neighbours
 // clamped -- in the texels' own brick layout, and a footprint is the quads of its two y rows (32 bytes apart inside one
 // 128-byte line three times out of four).  Half the bytes of the 16-byte cell form behind every sample: the light march

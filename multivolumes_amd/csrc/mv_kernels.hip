@@ -150,7 +150,9 @@ __global__ __launch_bounds__(256) void buildAlphaCellsKernel(const uint2* __rest
 			c.w = MV_A(x, y1, z1) | (MV_A(x1, y1, z1) << 16);
 #undef MV_A
 		}
-#if MV_ALPHA_QUADS
+#if MV_ALPHA_QUADS == 2
+		reinterpret_cast<uint32_t*>(cells)[volBrickIndex(bx, by, bz, bricks) * 64 + in] = c.x;	// {a000, a100}
+#elif MV_ALPHA_QUADS
 		reinterpret_cast<uint2*>(cells)[volBrickIndex(bx, by, bz, bricks) * 64 + in] = make_uint2(c.x, c.z);	// {a000,a100 | a001,a101}: the y+1 pair is the next row's quad
 #else
 		cells[volBrickIndex(bx, by, bz, bricks) * 64 + in] = c;

@@ -188,7 +188,7 @@ uint32_t marchViewResidentWaves(int device, bool wideAddressing);	// wavefronts 
 void launchTileOrder(hipStream_t s, const DeviceState& st, uint32_t* binCounts, uint32_t* order);	// binCounts: 256 x 8 scratch; order: maxTiles + maxScreenTiles
 void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight);
 uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
-void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1);
+void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background = nullptr);	// background: W x H RGBA16F (device) or NULL
 void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, void* dst);
 void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim, const void* src);
 void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes);	// marched faces only (mv_dist_frame)

@@ -307,8 +307,12 @@ class MultiRayCaster:
     def rayMarchV(self):
         self._check(self._lib.mv_march_view(self._ctx), "mv_march_view")
 
-    def composite(self, row0=0, row1=0):
-        self._check(self._lib.mv_composite(self._ctx, row0, row1), "mv_composite")
+    def composite(self, row0=0, row1=0, backgroundDevice=None):
+        """cubeDepthPeel + renderCube + resolveOIT; backgroundDevice: device pointer of a W x H RGBA16F colour target to draw over."""
+        if backgroundDevice is None:
+            self._check(self._lib.mv_composite(self._ctx, row0, row1), "mv_composite")
+        else:
+            self._check(self._lib.mv_composite_over(self._ctx, row0, row1, C.c_void_p(backgroundDevice)), "mv_composite_over")
 
     def Render(self, composite=False):
         """Render (MultiRayCaster.cpp:355-385), non-work-graph branch; increments m_frameIdx like :384."""

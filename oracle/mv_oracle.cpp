@@ -1133,10 +1133,25 @@ void mvo_set_options(int weightBits, int libRayMarch)
 }
 }
 
+extern "C" void mvo_composite_over(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+	const uint16_t* const* volumes, const uint32_t* lightMaps, const float* depthMap, const void* perObjectBytes, const void* cbBytes,
+	const uint16_t* volumeInfo, const uint32_t* visibleVolumes, uint32_t visibleCount,
+	const uint16_t* cubeMaps, const float* cubeDepths, const uint16_t* background, uint16_t* outRGBA, mvo_stats* stats);
+
 extern "C" void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
 	const uint16_t* const* volumes, const uint32_t* lightMaps, const float* depthMap, const void* perObjectBytes, const void* cbBytes,
 	const uint16_t* volumeInfo, const uint32_t* visibleVolumes, uint32_t visibleCount,
 	const uint16_t* cubeMaps, const float* cubeDepths, uint16_t* outRGBA, mvo_stats* stats)
+{
+	mvo_composite_over(V, N, L, W, H, y0, y1, volumes, lightMaps, depthMap, perObjectBytes, cbBytes, volumeInfo, visibleVolumes, visibleCount,
+		cubeMaps, cubeDepths, nullptr, outRGBA, stats);
+}
+
+// background: W x H RGBA16F the resolve is drawn over (PREMULTIPLITED blend preset, MultiRayCaster.cpp:931), or NULL
+extern "C" void mvo_composite_over(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1,
+	const uint16_t* const* volumes, const uint32_t* lightMaps, const float* depthMap, const void* perObjectBytes, const void* cbBytes,
+	const uint16_t* volumeInfo, const uint32_t* visibleVolumes, uint32_t visibleCount,
+	const uint16_t* cubeMaps, const float* cubeDepths, const uint16_t* background, uint16_t* outRGBA, mvo_stats* stats)
 {
 	(void)V;
 	const PerObject* perObjects = (const PerObject*)perObjectBytes;
@@ -1249,6 +1264,13 @@ extern "C" void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, ui
 				}
 			}
 			result.w = fminf(result.w, 0.9997f);
+			if (background)
+			{
+				// dst = src + dst * (1 - src.a) on all four channels (premultiplied alpha), fp32, one rounding at the store
+				const uint16_t* b = background + 4 * ((size_t)py * W + px);
+				const float inv = 1.0f - result.w;
+				result.x = result.x + h2f(b[0]) * inv; result.y = result.y + h2f(b[1]) * inv; result.z = result.z + h2f(b[2]) * inv; result.w = result.w + h2f(b[3]) * inv;
+			}
 			uint16_t* o = outRGBA + 4 * ((size_t)py * W + px);
 			o[0] = f2h(result.x); o[1] = f2h(result.y); o[2] = f2h(result.z); o[3] = f2h(result.w);
 		}

@@ -104,6 +104,14 @@ void mvo_composite(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
 	const uint16_t* volumeInfo, const uint32_t* visibleVolumes, uint32_t visibleCount,
 	const uint16_t* cubeMaps, const float* cubeDepths,
 	uint16_t* outRGBA /* W x H x 4 halfs, rows outside [y0,y1) untouched */, mvo_stats* stats);
+/* the same drawn over a W x H RGBA16F colour target (PREMULTIPLITED blend, MultiRayCaster.cpp:931): out = src + dst (1 - src.a); background may be NULL */
+void mvo_composite_over(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
+	uint32_t y0, uint32_t y1 /* rows [y0,y1) */,
+	const uint16_t* const* volumes, const uint32_t* lightMaps,
+	const float* depthMap, const void* perObject, const void* cbPerFrame,
+	const uint16_t* volumeInfo, const uint32_t* visibleVolumes, uint32_t visibleCount,
+	const uint16_t* cubeMaps, const float* cubeDepths,
+	const uint16_t* background, uint16_t* outRGBA /* W x H x 4 halfs, rows outside [y0,y1) untouched */, mvo_stats* stats);
 
 /* number of OpenMP threads the march functions will use (1 if built without OpenMP) */
 /* composite building blocks, exported for the known-answer tests */

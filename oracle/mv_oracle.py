@@ -60,6 +60,8 @@ def load():
     if hasattr(lib, "mvo_composite"):
         lib.mvo_composite.restype = None
         lib.mvo_composite.argtypes = [_U32, _U32, _U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P]
+        lib.mvo_composite_over.restype = None
+        lib.mvo_composite_over.argtypes = [_U32, _U32, _U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P]
     _lib = lib
     return lib
 
@@ -164,7 +166,7 @@ def cube_face_view(chain_array, N, mip):
 
 
 def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame, volumeInfo, visible, cubeMaps, cubeDepths,
-              y0=0, y1=None, out=None):
+              y0=0, y1=None, out=None, background=None):
     """K-buffer OIT composite over rows [y0, y1). Returns (out[H, W, 4] u16, RayCast sample count)."""
     vols, arr = _vol_ptrs(volumes)
     y1 = H if y1 is None else y1
@@ -178,8 +180,9 @@ def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame
     cm = np.ascontiguousarray(cubeMaps, np.uint16)
     cd = np.ascontiguousarray(cubeDepths, np.float32)
     st = mvo_stats()
-    load().mvo_composite(V, N, L, W, H, y0, y1, arr, _ptr(lm), _ptr(dm), _ptr(po), _ptr(cb), _ptr(vi), _ptr(vl), len(vl),
-                         _ptr(cm), _ptr(cd), _ptr(o), C.byref(st))
+    bg = None if background is None else np.ascontiguousarray(background, np.uint16)
+    load().mvo_composite_over(V, N, L, W, H, y0, y1, arr, _ptr(lm), _ptr(dm), _ptr(po), _ptr(cb), _ptr(vi), _ptr(vl), len(vl),
+                              _ptr(cm), _ptr(cd), _ptr(bg), _ptr(o), C.byref(st))
     return o, int(st.view_samples)
 
 

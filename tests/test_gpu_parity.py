@@ -321,6 +321,11 @@ def oracle_composite(o, cfg, vols, ref, lightMaps=None, cubeMaps=None, cubeDepth
                        ref["cubeMaps"] if cubeMaps is None else cubeMaps, ref["cubeDepths"] if cubeDepths is None else cubeDepths, y0, y1)
 
 
+def oracle_composite_over(o, cfg, vols, ref, background):
+    return o.composite(cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], ref["info"], ref["vis"],
+                       ref["cubeMaps"], ref["cubeDepths"], background=background)
+
+
 @pytest.mark.parametrize("name,W,H", [("T1", 256, 256), ("T2", 320, 200), ("T1", 48, 48)])
 def test_composite_parity(oracle, name, W, H):
     """K-buffer OIT composite (a7): CubeCast layers for cube-map volumes, screen-space RayCast for the others
@@ -342,6 +347,18 @@ def test_composite_parity(oracle, name, W, H):
         assert (e[..., 3] > 0).sum() > 0.1 * W * H, "scene should cover a good part of the screen"
         assert diff.max() <= TOL, f"max |gpu - oracle| = {diff.max()} at {np.unravel_index(diff.argmax(), diff.shape)}"
         assert c.GetStats()["composite_samples"] == exp_samples
+        # drawn over a colour target (the reference's resolve blends over the scene, MultiRayCaster.cpp:931)
+        import torch
+        rng = np.random.default_rng(7)
+        bg = rng.random((H, W, 4), np.float32).astype(np.float16)
+        d_bg = torch.from_numpy(bg.view(np.uint16).astype(np.int16)).cuda()
+        torch.cuda.synchronize()
+        c.composite(backgroundDevice=d_bg.data_ptr())
+        over = c.ReadBackComposite()
+        exp_over, _ = oracle_composite_over(oracle, cfg, vols, ref, bg.view(np.uint16))
+        assert np.array_equal(over, exp_over), f"{(over != exp_over).sum()} halfs differ when drawn over a background"
+        assert (half_to_float(over)[..., 3] >= half_to_float(got)[..., 3]).all()
+        c.composite()
         # row-range form (what a rank composites of its screen tile): only rows [r0, r1) are written
         c2 = c.ReadBackComposite()
         r0, r1 = H // 3, (2 * H) // 3 + 1

@@ -330,3 +330,20 @@ def test_kat_a7_screen_space_raycast_layer(oracle):
     rgb2, A2, it2 = emulate_march(alpha, c, 1.0, smp, F(t_max), o.astype(F), d.astype(F))
     px2, _ = centre(plane)
     assert it2 < it and px2[3] == pytest.approx(float(A2), abs=1e-3) and px2[0] == pytest.approx(float(rgb2), abs=1e-3)
+
+
+def test_kat_a7_resolve_over_a_background(oracle):
+    """The resolve pass is drawn over the scene's colour target with premultiplied-alpha blending (MultiRayCaster.cpp:931, 1615-1633):
+    out = src + dst (1 - src.a) on all four channels; pixels the volumes do not cover keep the background."""
+    V, N, W, H = 1, 8, 64, 64
+    c = (0.25, 0.5, 0.75, 0.5)
+    cb, po = scene([(0, 0, 0)], W=W, H=H)
+    cm, cd = constant_cube_maps(oracle, V, N, [c])
+    info = np.array([[0, 16, CUBE_BIT | 0x3F, 0]], np.uint16)
+    bg = np.zeros((H, W, 4), np.float16)
+    bg[...] = (0.5, 0.25, 1.0, 1.0)
+    img, _ = oracle.composite(V, N, 4, W, H, [np.zeros((N, N, N, 4), np.uint16)], np.zeros((V, 4, 4, 4), np.uint32), np.ones((H, W), np.float32),
+                              po, cb, info, np.array([0], np.uint32), cm, cd, background=bg.view(np.uint16))
+    img = half_to_float(img)
+    assert np.array_equal(img[32, 32], np.array([0.25 + 0.5 * 0.5, 0.5 + 0.25 * 0.5, 0.75 + 1.0 * 0.5, 0.5 + 1.0 * 0.5], np.float32))
+    assert np.array_equal(img[0, 0], np.array([0.5, 0.25, 1.0, 1.0], np.float32)), "uncovered pixel: the background, untouched"
