@@ -888,7 +888,11 @@ int mv_march_view(mv_ctx* ctx)
 				tiles = exact ? count : count + count / 4u + 256u;
 			}
 		}
-		mv::launchMarchTiles(streamB(ctx), ctx->st, tiles, exact);
+		const uint32_t beyond = mv::launchMarchTiles(streamB(ctx), ctx->st, tiles);
+		// (an exact count is this frame's own: nothing can lie beyond the grid.  Otherwise the overflow launch follows on the same
+		// stream: on the high-priority stream A it would have to wait for this frame's light march and held up the next frame's cull --
+		// measured slower.  It is kept small, 64 workgroups, because its wavefronts must find slots on a GPU the other frame's march fills.)
+		if (!exact && beyond != 0xffffffffu) mv::launchMarchTilesOverflow(streamB(ctx), ctx->st, beyond);
 	}
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());

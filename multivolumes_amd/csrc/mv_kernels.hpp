@@ -180,7 +180,8 @@ void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uin
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchMarchLight(hipStream_t s, const DeviceState& st);
-void launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles, bool exact);	// one wavefront per tile (mv_march_tiles.hip)
+uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// returns the first slot its grid does not cover (0xffffffff: none)
+void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
 uint32_t marchTilesResidentWaves(int device);
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)

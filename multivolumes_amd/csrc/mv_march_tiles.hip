@@ -301,17 +301,22 @@ uint32_t marchTilesResidentWaves(int device)
 	return (uint32_t)perCu * (uint32_t)cus * kTileWaves;
 }
 
-void launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles, bool exact)
+uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
 {
 	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has
-	// none).  The main grid covers min(estimate, largest possible frame); the overflow launch covers whatever lies beyond it.
+	// none).  The grid covers min(estimate, largest possible frame); returns the first dispatch slot beyond it (what the overflow
+	// launch has to cover), or 0xffffffff if the grid covers every frame there can be.
 	const uint64_t maxTiles = (uint64_t)st.maxTiles + st.maxScreenTiles;
 	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
 	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
 	blocks = ((blocks + 7) / 8) * 8;
 	if (st.N <= kLutMaxN) hipLaunchKernelGGL((marchTilesKernel<false, MV_TILE_LUT != 0>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
 	else hipLaunchKernelGGL((marchTilesKernel<false, false>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
-	if (!exact && blocks * kTileWaves < maxTiles)	// (an exact count is this frame's own: nothing can lie beyond the grid)
-		hipLaunchKernelGGL((marchTilesKernel<true, false>), dim3(256), dim3(64 * kTileWaves), 0, s, st, (uint32_t)(blocks * kTileWaves));
+	return blocks * kTileWaves < maxTiles ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
+}
+
+void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot)
+{
+	hipLaunchKernelGGL((marchTilesKernel<true, false>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
 }
 } // namespace mv
