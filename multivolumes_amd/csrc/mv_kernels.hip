@@ -552,8 +552,28 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 #ifndef MV_LIGHT_SPECULATE
 #define MV_LIGHT_SPECULATE 1	// alpha footprints in flight per light ray (0 = the plain loop)
 #endif
+// the footprint of a density sample: through the per-axis address tables in LDS when the kernel has them (mv_device.hpp)
+template <uint32_t TABLE_PITCH>
+__device__ __forceinline__ FootprintAddr densityFootprint(const VolumeView& vol, const u32x4* axisTables, vec3 uvw)
+{
+	if (!axisTables) return footprintAddr(vol, uvw);
+	FootprintAddr a;
+	const u32x4 ex = axisTables[axisTableIndex(uvw.x, vol.N, a.fx)];
+	const u32x4 ey = axisTables[TABLE_PITCH + axisTableIndex(uvw.y, vol.N, a.fy)];
+	const u32x4 ez = axisTables[2u * TABLE_PITCH + axisTableIndex(uvw.z, vol.N, a.fz)];
+	a.x0 = ex.x; a.x1 = ex.y;
+	a.r00 = ey.x + ez.x; a.r10 = ey.y + ez.x; a.r01 = ey.x + ez.y; a.r11 = ey.y + ez.y;
+	a.cx = __uint_as_float(__float_as_uint(a.fx) & ex.w);	// weight 0 where both taps are the same texel
+	a.cy = __uint_as_float(__float_as_uint(a.fy) & ey.w);
+	a.cz = __uint_as_float(__float_as_uint(a.fz) & ez.w);
+	a.ix = a.iy = a.iz = 0u;	// (not needed by a cell fetch)
+	return a;
+}
+
+constexpr uint32_t kLightLutMaxN = 256, kLightWaves = 4;
+
 __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vol, vec3 rayOrigin, vec3 rayDir,
-	float stepScale, uint32_t numSamples, uint32_t& samples)
+	float stepScale, uint32_t numSamples, uint32_t& samples, const u32x4* axisTables = nullptr)
 {
 	float t = stepScale;
 	float step = stepScale;
@@ -577,7 +597,7 @@ __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vo
 #pragma unroll
 			for (int j = 0; j < K; ++j)
 			{
-				batch[j] = fetchAlphaCell(vol, footprintAddr(vol, LocalToTex3DSpace(rayAt(rayOrigin, rayDir, tj))));
+				batch[j] = fetchAlphaCell(vol, densityFootprint<kLightLutMaxN + 1u>(vol, axisTables, LocalToTex3DSpace(rayAt(rayOrigin, rayDir, tj))));
 				tj += stepScale;
 			}
 		}
@@ -658,8 +678,12 @@ __device__ __forceinline__ vec3 EvaluateSHIrradiance(const float* sh, vec3 norm)
 #ifndef MV_LIGHT_MIN_WAVES
 #define MV_LIGHT_MIN_WAVES 4	// measured: 8 -> 0.150 ms, 6/4 -> 0.144 ms
 #endif
-__global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st)
+// kLightWaves voxel blocks per workgroup: they share the per-axis address tables of the volumes in LDS (LUT, N <= 256; every
+// volume source has the same N and pitches).
+template <bool LUT>
+__global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st)
 {
+	__shared__ u32x4 sAxis[LUT ? 3 * (kLightLutMaxN + 1) : 1];
 	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 
@@ -668,11 +692,23 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 	volumeId = __builtin_amdgcn_readfirstlane(volumeId);
 	if (!ownsVolume(st, volumeId)) return;
 
+	const u32x4* axisTables = nullptr;
+	if (LUT)
+	{
+		const uint32_t P = st.N + 1u, regions = occupancyRegions(st.bricks);
+		const uint32_t strideY = brickPitchY(st.bricks) * 512u, strideZ = brickPitchZ(st.bricks) * 512u;
+		for (uint32_t k = threadIdx.x; k < 3u * P; k += 64u * kLightWaves)
+			sAxis[(k / P) * (kLightLutMaxN + 1u) + k % P] = axisTableEntry(k / P, k % P, st.N, strideY, strideZ, regions);
+		__syncthreads();
+		axisTables = sAxis;
+	}
+
 	const uint32_t L = st.L;
 	const uint32_t blocksPerAxis = (L + 3u) >> 2;
-	const uint32_t b = blockIdx.x;
+	const uint32_t b = blockIdx.x * kLightWaves + (threadIdx.x >> 6);
+	if (b >= blocksPerAxis * blocksPerAxis * blocksPerAxis) return;
 	const uint32_t bx = b % blocksPerAxis, by = (b / blocksPerAxis) % blocksPerAxis, bz = b / (blocksPerAxis * blocksPerAxis);
-	const uint32_t lane = threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t xx = bx * 4 + (lane & 3u), yy = by * 4 + ((lane >> 2) & 3u), zz = bz * 4 + (lane >> 4);
 	const bool inRange = xx < L && yy < L && zz < L;
 
@@ -736,7 +772,7 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 					const vec3 rayDir = v3(ld.x, ld.y, ld.z);
 					if (missesUnitBox(localRayOrigin, rayDir)) continue;	// what ComputeRayOrigin would conclude, at a fifth of the cost
 					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
-					CastLightRay(shadow, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS);
+					CastLightRay(shadow, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS, axisTables);
 				}
 
 				if (st.hasLightProbe)
@@ -745,7 +781,7 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 					if (missesUnitBox(localRayOrigin, rayDir)) continue;
 					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
 					float transm = 1.0f;
-					CastLightRay(transm, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS);
+					CastLightRay(transm, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS, axisTables);
 					ao *= n == volumeId ? transm : __builtin_sqrtf(__builtin_sqrtf(saturatef(transm + 0.5f)));	// pow(x, 0.25)
 				}
 			}
@@ -773,7 +809,7 @@ __global__ __launch_bounds__(64, MV_LIGHT_MIN_WAVES) void marchLightKernel(Devic
 	}
 
 	const uint32_t tot = waveSumU32(nS);
-	if (lane == 0 && tot) st.lightStats[blockIdx.x] += tot;	// this block's own slot: no atomics
+	if (lane == 0 && tot) st.lightStats[b] += tot;	// this voxel block's own slot: no atomics
 }
 
 constexpr uint32_t kOrderBins = 8, kOrderWaves = 256;
@@ -972,10 +1008,15 @@ void launchCull(hipStream_t s, const DeviceState& st)
 	hipLaunchKernelGGL(cullKernel, dim3((st.V + 7u) / 8u), dim3(kCullThreads), st.V * 3 * sizeof(uint32_t), s, st);
 }
 
+#ifndef MV_LIGHT_LUT
+#define MV_LIGHT_LUT 1	// per-axis address tables in LDS for the light march (N <= 256); 0 = compute every tap's offsets (A/B timing)
+#endif
 void launchMarchLight(hipStream_t s, const DeviceState& st)
 {
 	const uint32_t b = (st.L + 3u) >> 2;
-	hipLaunchKernelGGL(marchLightKernel, dim3(b * b * b), dim3(64), 0, s, st);
+	const uint32_t groups = (b * b * b + kLightWaves - 1u) / kLightWaves;
+	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL(marchLightKernel<true>, dim3(groups), dim3(64 * kLightWaves), 0, s, st);
+	else hipLaunchKernelGGL(marchLightKernel<false>, dim3(groups), dim3(64 * kLightWaves), 0, s, st);
 }
 
 } // namespace mv
