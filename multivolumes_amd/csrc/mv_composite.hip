@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 #pragma unroll
 		for (uint32_t m = 0; m < kNumOitLayers; ++m) keys[m] = ~0ull;
 
+		vec3 lpt0 = v3(0.0f, 0.0f, 0.0f), lpt1 = v3(0.0f, 0.0f, 0.0f);
 		for (uint32_t k = 0; k < visibleCount; ++k)
 		{
 			const uint32_t v = st.visibleVolumes[k];
@@ -353,6 +354,10 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 
 			// sorted insert (stable for equal depths: the list index k is the low word)
 			unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | k;
+			// the exit points of the two nearest fragments stay in registers (most pixels have one or two layers); deeper layers
+			// recompute theirs in the shading loop below
+			if (key < keys[0]) { lpt1 = lpt0; lpt0 = lpt; }
+			else if (key < keys[1]) lpt1 = lpt;
 #pragma unroll
 			for (uint32_t m = 0; m < kNumOitLayers; ++m)
 			{
@@ -385,10 +390,14 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 			}
 			else
 			{
-				// recompute the exit point exactly as in the peel loop (cheaper than keeping 8 float3 in registers)
-				vec3 lpt;
-				float z;
-				findExitFragment(po, localSpaceEyePt, dirW, lpt, z);
+				// the exit point: kept from the peel loop for the two nearest layers, recomputed exactly as there for deeper ones
+				// (cheaper than keeping 8 float3 in registers)
+				vec3 lpt = m == 0u ? lpt0 : lpt1;
+				if (m >= 2u)
+				{
+					float z;
+					findExitFragment(po, localSpaceEyePt, dirW, lpt, z);
+				}
 				const vec3 rayDir = lpt - localSpaceEyePt;
 				if (!(vi.z & kCubeMapRayMarchBit))
 				{
