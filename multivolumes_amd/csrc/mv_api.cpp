@@ -67,6 +67,7 @@ struct OutBufs
 	float4* screenLayers = nullptr;
 	uint32_t* faceStamps = nullptr;
 	uint64_t *waveStats = nullptr, *compositeStats = nullptr;
+	uint32_t* compositeRetry = nullptr;
 	mv::RayRecord* rayRecords = nullptr;	// the view march's ray queue (mv_march.hip)
 	mv::TileInfo* tileInfo = nullptr;
 };
@@ -109,7 +110,8 @@ struct mv_ctx
 	OutBufs ob[kMaxOutSets];
 	uint32_t numOutSets = 1, numViewStreams = 1;
 	uint32_t set = 0;
-	bool ownStream = false, ownStreamA = false, ownStreamB1 = false;
+	bool ownStream = false, ownStreamA = false, ownStreamL = false, ownStreamB1 = false;
+	bool lightOnViewStream = false;		// pipelined with several view streams: a frame's light march runs on that frame's view stream
 	DeviceState st;						// always holds the CURRENT frame slot's pointers (applyParity)
 	FrameBufs fb[kFrameSlots];			// constants + cull outputs per slot; march / composite outputs per PARITY (slot & 1), aliased
 	uint32_t slot = 0;					// frame counter mod kFrameSlots
@@ -207,7 +209,7 @@ void applyParity(mv_ctx* ctx)
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
 	const OutBufs& o = ctx->ob[ctx->set];
 	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers; st.faceStamps = o.faceStamps;
-	st.waveStats = o.waveStats; st.compositeStats = o.compositeStats; st.tileCost = f.tileCost;
+	st.waveStats = o.waveStats; st.compositeStats = o.compositeStats; st.compositeRetry = o.compositeRetry; st.tileCost = f.tileCost;
 	st.rayRecords = o.rayRecords; st.tileInfo = o.tileInfo;
 	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
 }
@@ -246,7 +248,15 @@ hipError_t stageBBegin(mv_ctx* ctx)
 {
 	const hipError_t e = hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->slot], 0);
 	if (e != hipSuccess) return e;
-	return hipStreamWaitEvent(streamB(ctx), ctx->evLight[ctx->slot], 0);	// this frame's light march, if one has been enqueued
+	// this frame's light march, if one has been enqueued (and, when light marches run on their frames' view streams, those of the
+	// frames before it on the OTHER view streams: a view march reads every visible volume's light map)
+	const uint32_t others = ctx->lightOnViewStream ? ctx->numViewStreams - 1u : 0u;
+	for (uint32_t j = 0; j <= others; ++j)
+	{
+		const hipError_t e2 = hipStreamWaitEvent(streamB(ctx), ctx->evLight[(ctx->slot + kFrameSlots - j) % kFrameSlots], 0);
+		if (e2 != hipSuccess) return e2;
+	}
+	return hipSuccess;
 }
 // stage of stream B finished being enqueued: the next user of this slot's buffers (kFrameSlots frames on) and the light march two frames on wait for it
 hipError_t stageBDone(mv_ctx* ctx) { return hipEventRecord(ctx->evMainDone[ctx->slot], streamB(ctx)); }
@@ -350,9 +360,21 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		int prLow = 0, prHigh = 0;
 		(void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
 		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
-		if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamA = true;
-		ctx->numOutSets = 2u;
+		// One view stream (MV_FLAG_SINGLE_VIEW_STREAM, the multi-GPU loop): the light marches get a stream of their own and two
+		// output sets rotate.  Otherwise three output sets on three view streams, each frame's light march on its view stream:
+		// four streams in all either way -- a HIP process has four hardware queues, and streams that share one wait for each other.
+		if (cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM)
+		{
+			if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
+			ctx->ownStreamL = true;
+			ctx->numOutSets = 2u;
+		}
+		else
+		{
+			ctx->lightOnViewStream = true;
+			ctx->numOutSets = 3u;
+		}
 #ifdef MV_DIAGNOSTICS	// A/B measurements only (csrc/build.sh -DMV_DIAGNOSTICS); the shipped library reads no environment variable
 		{ const char* e = getenv("MV_OUT_SETS"); if (e) ctx->numOutSets = (uint32_t)atoi(e); if (ctx->numOutSets < 2u || ctx->numOutSets > kMaxOutSets) ctx->numOutSets = 2u; }
 #endif
@@ -522,9 +544,13 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if ((rc = devAlloc(ctx, &f.waveStats, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		if (p == 0 && (rc = devAlloc(ctx, &st.timeline, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
 		// the ray queue: 64 records per tile of the largest frame (every owned volume at mip 0 with 6 faces + every screen tile); never cleared
-		if ((rc = devAlloc(ctx, &f.rayRecords, ((size_t)st.maxTiles + st.maxScreenTiles) * 64 * sizeof(mv::RayRecord), false)) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.tileInfo, ((size_t)st.maxTiles + st.maxScreenTiles) * sizeof(mv::TileInfo), false)) != MV_OK) return bail(rc);
+		if (cfg->flags & MV_FLAG_RAY_QUEUE)
+		{
+			if ((rc = devAlloc(ctx, &f.rayRecords, ((size_t)st.maxTiles + st.maxScreenTiles) * 64 * sizeof(mv::RayRecord), false)) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.tileInfo, ((size_t)st.maxTiles + st.maxScreenTiles) * sizeof(mv::TileInfo), false)) != MV_OK) return bail(rc);
+		}
 		if ((rc = devAlloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &f.compositeRetry, ((size_t)st.compositeSlots + 2u) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	}
 	st.volumeDescs = ctx->dDescs; st.sh = ctx->dSh;
 	ctx->slot = 0; ctx->set = 0;
@@ -574,7 +600,7 @@ void mv_destroy(mv_ctx* ctx)
 	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); if (ctx->evLight[i]) (void)hipEventDestroy(ctx->evLight[i]); }
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
 	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
-	if (ctx->ownStreamA && ctx->streamL && ctx->streamL != ctx->stream) (void)hipStreamDestroy(ctx->streamL);
+	if (ctx->ownStreamL && ctx->streamL) (void)hipStreamDestroy(ctx->streamL);
 	for (uint32_t i = 1; i < kMaxOutSets; ++i) if (ctx->ownStreamB1 && ctx->streamB[i] && ctx->streamB[i] != ctx->stream) (void)hipStreamDestroy(ctx->streamB[i]);
 	for (EventPair& ev : ctx->freeEvents) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
 	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
@@ -808,15 +834,20 @@ int mv_march_light(mv_ctx* ctx)
 	MV_REQUIRE(ctx, !ctx->lightTableKept, MV_ERR_NOT_READY, "mv_march_light must come before the frame's mv_march_view / mv_composite");
 	// The light buffer this launch writes was last read by a frame at least kLightBuffers (3) frames back (the relit volume's
 	// table entry has rotated since): that frame's view march / composite must be over.  Older ones are, by stream order.
-	static_assert(mv::kLightBuffers == 3 && kFrameSlots == 4, "the wait below names frame i - 3");
-	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamL, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));
-	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamL, ctx->evStageA[ctx->slot], 0));	// this frame's upload + cull
+	static_assert(mv::kLightBuffers == 3 && kFrameSlots == 4 && kMaxOutSets < kFrameSlots, "the wait below names frame i - 3");
+	// With several view streams the light march goes in front of its frame's view march on that frame's stream: every stream then
+	// carries a whole frame (light march, view march, composite) and the frames overlap as wholes.  (A stream of its own for the
+	// light marches serialises them at the share of the GPU one kernel gets beside two view marches, which made them the chain
+	// every frame waited for: 0.349 -> 0.331 ms per frame at C3 with two output sets, 0.311 ms with three.)
+	hipStream_t L = ctx->lightOnViewStream ? streamB(ctx) : ctx->streamL;
+	MV_HIP(ctx, hipStreamWaitEvent(L, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));
+	MV_HIP(ctx, hipStreamWaitEvent(L, ctx->evStageA[ctx->slot], 0));	// this frame's upload + cull
 	EventPair ev = { nullptr, nullptr, 0 };
-	beginStage(ctx, 1, ev, ctx->streamL);
-	mv::launchMarchLight(ctx->streamL, ctx->st);
-	endStage(ctx, ev, ctx->streamL);
+	beginStage(ctx, 1, ev, L);
+	mv::launchMarchLight(L, ctx->st);
+	endStage(ctx, ev, L);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], ctx->streamL));
+	MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], L));
 	ctx->lightMarched = true;
 	return MV_OK;
 }
@@ -845,22 +876,25 @@ int mv_march_view(mv_ctx* ctx)
 #ifndef MV_COPY_FORWARD
 #define MV_COPY_FORWARD 1	// (0: A/B timing only -- the two output sets then drift apart in the faces a frame does not march)
 #endif
-	if (MV_COPY_FORWARD && ctx->numOutSets == 2u && !ctx->dist && !ctx->copiedForward)
+	const uint32_t n = ctx->numOutSets;
+	if (MV_COPY_FORWARD && n >= 2u && !ctx->dist && !ctx->copiedForward)
 	{
-		// On the stream of the PREVIOUS frame's view march and composite -- which is also the stream of the next frame's: stream order
-		// alone then puts the copy behind the march that completed the other set and in front of the march that overwrites it again,
-		// and it runs beside this frame's march (a stream of its own would do, but HIP streams beyond four share hardware queues and
-		// false dependencies between the two view-march streams cost 0.1 ms per frame: measured).
+		// On the stream of the PREVIOUS frame's view march (and composite): stream order alone puts the copy behind the march that
+		// completed the set it reads (a stream of its own would do, but HIP streams beyond four share hardware queues and wait for
+		// each other: measured).  It writes this frame's set, so the set's last reader (the composite of frame k - n) must be
+		// over, and it reads what the previous frame's copy wrote (a face nobody has marched for two frames travels set to set).
 		hipStream_t s = ctx->streamB[(ctx->frame + ctx->numViewStreams - 1u) % ctx->numViewStreams];
-		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evMainDone[(ctx->slot + kFrameSlots - 2u) % kFrameSlots], 0));	// this set's last reader (composite of frame k - 2)
+		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evMainDone[(ctx->slot + kFrameSlots - n) % kFrameSlots], 0));
+		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evCopy[prevSlot], 0));
 		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evStageA[ctx->slot], 0));	// this frame's cull
 		const int rc = copyForward(ctx, s);
 		if (rc != MV_OK) return rc;
 	}
 	MV_HIP(ctx, stageBBegin(ctx));
-	if (ctx->numOutSets == 2u) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[prevSlot], 0));	// the previous frame's copy-forward read the set this march writes
-	// the previous user of this output set is frame i - numOutSets; with SINGLE_VIEW_STREAM / one stream it is on this stream anyway
-	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (ctx->numOutSets % kFrameSlots)) % kFrameSlots], 0));
+	// the set this march writes was read by the copy-forward of frame k - n + 1 (as the set before its own) ...
+	if (n >= 2u) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[(ctx->slot + kFrameSlots - (n - 1u)) % kFrameSlots], 0));
+	// ... and by the composite of frame k - n, its previous user (with SINGLE_VIEW_STREAM / one stream that is on this stream anyway)
+	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (n % kFrameSlots)) % kFrameSlots], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 2, ev, streamB(ctx));
 	// Nothing between the cull and the march waits for the host (the shape of the work-graph variant, Sh/LibRayMarch.hlsl:39-134).
@@ -911,7 +945,7 @@ int mv_composite_over(mv_ctx* ctx, uint32_t row0, uint32_t row1, const void* d_b
 	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
 	{ const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, stageBBegin(ctx));
-	if (ctx->numOutSets == 2u && ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[ctx->slot], 0));
+	if (ctx->numOutSets >= 2u && ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[ctx->slot], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 3, ev, streamB(ctx));
 	mv::launchComposite(streamB(ctx), ctx->st, row0, row1, d_background);

@@ -126,31 +126,32 @@ void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void
 }
 
 // ---------------------------------------------------------------------------------------------
-// Two output sets, one history.  The reference never clears its cube maps: a face that a frame does not march (face bit clear,
-// CSRayMarch.hlsl:84-85) keeps what the last frame that marched it left there, and a CubeCast gather across a cube edge can read it.
-// With frames in flight (and on every rank of the multi-GPU loop) consecutive frames write alternating output sets, so the newest
-// data of such a face may sit in the OTHER set.  Every (volume, mip, face) carries a stamp per set -- the frame that last wrote it
-// there -- and before a frame composites, the faces it does not march are brought up to date from the other set where that one is
-// newer.  In steady state nothing is copied; a face is copied once when it stops being marched.  Both sets then read exactly like
-// the reference's single set.  (Texels of a MARCHED face whose ray misses the box by an ulp are not tracked.)
+// Rotating output sets, one history.  The reference never clears its cube maps: a face that a frame does not march (face bit clear,
+// CSRayMarch.hlsl:84-85, a volume that is culled or on the screen-space scheme, another mip) keeps what the last frame that
+// marched it left there, and a CubeCast gather across a cube edge can read it.  With frames in flight (and on every rank of the
+// multi-GPU loop) consecutive frames write different output sets, so the newest data of such a face sits in the set of an earlier
+// frame.  Every (volume, mip, face) carries a stamp per set -- the frame that last marched what the set holds -- and every frame
+// first brings EVERY face it does not march up to date from the previous frame's set where that one is newer.  By induction the
+// previous frame's set is complete, so one source set is enough however many sets rotate, and every set reads exactly like the
+// reference's single one once its frame has marched.  In steady state nothing is copied: a face is copied once per set when it stops
+// being marched.  (Texels of a MARCHED face whose ray misses the box by an ulp are not tracked.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void copyForwardKernel(DeviceState st, const uint2* __restrict__ otherMaps, const float* __restrict__ otherDepths,
 	const uint32_t* __restrict__ otherStamps, uint32_t tag)
 {
-	const uint32_t v = blockIdx.x / 6u, f = blockIdx.x % 6u;
+	const uint32_t f = blockIdx.x % 6u, mip = (blockIdx.x / 6u) % kNumCubeMip, v = blockIdx.x / (6u * kNumCubeMip);
 	const uint32_t info = st.volumeFlags[v];
-	if ((info & 3u) != 3u) return;	// not visible, or on the screen-space scheme: this frame's composite does not read its cube map
-	const uint32_t mip = (info >> 2) & 7u, mask = (info >> 5) & 0x3fu;
 	const uint32_t idx = (v * kNumCubeMip + mip) * 6u + f;
-	if (mask & (1u << f))
+	// visible, on the cube-map scheme, at this mip, face bit set: marched this frame (here, or by its owner and unpacked here)
+	if ((info & 3u) == 3u && ((info >> 2) & 7u) == mip && (((info >> 5) & 0x3fu) & (1u << f)))
 	{
-		if (threadIdx.x == 0) st.faceStamps[idx] = tag;	// marched this frame (here, or by its owner and unpacked here)
+		if (threadIdx.x == 0) st.faceStamps[idx] = tag;
 		return;
 	}
 	const uint32_t mine = st.faceStamps[idx], theirs = otherStamps[idx];
 	if ((int32_t)(theirs - mine) <= 0) return;
 	const uint32_t d = st.N >> mip;
-	const size_t base = (size_t)st.cubeOffset[v] + (size_t)f * d * d;
+	const size_t base = (size_t)v * cubeChainTexels(st.N) + cubeMipOffset(st.N, mip) + (size_t)f * d * d;
 	for (uint32_t i = threadIdx.x; i < d * d; i += blockDim.x)
 	{
 		st.cubeMaps[base + i] = otherMaps[base + i];
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void copyForwardKernel(DeviceState st, const u
 
 void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag)
 {
-	hipLaunchKernelGGL(copyForwardKernel, dim3(st.V * 6u), dim3(256), 0, s, st, otherMaps, otherDepths, otherStamps, tag);
+	hipLaunchKernelGGL(copyForwardKernel, dim3(st.V * kNumCubeMip * 6u), dim3(256), 0, s, st, otherMaps, otherDepths, otherStamps, tag);
 }
 
 // Light map of the volume relit this frame (CSRayMarchL.hlsl:29-33: ONE volume per frame, marched by its owner), for the ranks that
@@ -311,16 +312,43 @@ __device__ __forceinline__ vec4 CubeCast(const uint2* cubeMap, const float* cube
 	return color;
 }
 
+#ifndef MV_COMPOSITE_LDS
+#define MV_COMPOSITE_LDS 0
+#endif
 #ifndef MV_COMPOSITE_MIN_WAVES
 #define MV_COMPOSITE_MIN_WAVES 4
 #endif
-__global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background)
+// a layer's colour as the K-buffer holds it: kColors is RGBA16F (MultiRayCaster.cpp:236), so every layer is rounded to fp16 before
+// the resolve; a colour that fails PSResolveOIT's test (alpha outside (0, 1]) is stored as zeros, which the resolve adds as nothing
+__device__ __forceinline__ uint2 packLayer(vec4 color)
+{
+	uint2 o; o.x = 0u; o.y = 0u;
+	if (color.w > 0.0f && color.w <= 1.0f)
+	{
+		o.x = (uint32_t)float_to_half_bits(color.x) | ((uint32_t)float_to_half_bits(color.y) << 16);
+		o.y = (uint32_t)float_to_half_bits(color.z) | ((uint32_t)float_to_half_bits(color.w) << 16);
+	}
+	return o;
+}
+constexpr uint32_t kLayerNeedsMarch = 0xffff0000u;	// in .y: alpha = an fp16 NaN, which packLayer never produces
+
+// MARCH = false: the launch over every 8x8 tile of the row range.  It leaves out the inline RayCast march (which alone costs the
+// kernel half of its wavefronts per SIMD): a tile in which some surviving layer needs that march is appended to `retry`
+// ({count, finished workgroups, tile ...}) and written by the MARCH = true launch behind it, which walks that list.
+template <bool MARCH>
+__global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background,
+	uint32_t* __restrict__ retry)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t tilesX = (st.W + 7u) >> 3;
-	const uint32_t tileX0 = (blockIdx.x % tilesX) * 8u, tileY0 = row0 + (blockIdx.x / tilesX) * 8u;
+	const uint32_t nRetry = MARCH ? retry[0] : 0u;
+	for (uint32_t item = blockIdx.x; !MARCH || item < nRetry; item += gridDim.x)
+	{
+	const uint32_t tileIndex = MARCH ? retry[2u + item] : blockIdx.x;
+	const uint32_t tileX0 = (tileIndex % tilesX) * 8u, tileY0 = row0 + (tileIndex / tilesX) * 8u;
 	const uint32_t px = tileX0 + (lane & 7u), py = tileY0 + (lane >> 3);
 	uint32_t nSamples = 0, nLit = 0;
+	bool deferred = false;
 
 	if (px < st.W && py < row1)
 	{
@@ -328,19 +356,26 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 		const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 		const vec3 eyePt = v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]);
 		const uint32_t visibleCount = st.counters[0];
+		const uint64_t chain = cubeChainTexels(st.N);
 
 		// PSCube.hlsl:37-39
 		float nx = ((float)px + 0.5f) / (float)st.W, ny = ((float)py + 0.5f) / (float)st.H;
 		nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
 		const float depthPix = st.depthMap[(size_t)py * st.W + px];
 		const vec3 dirW = pixelRayWorld(cb, nx, ny);
+		const bool inBand = py >= st.bandRow0 && py < st.bandRow1;
 
-		// PSDepthPeel.hlsl:12-24: the NUM_OIT_LAYERS nearest fragments, ascending depth; key = depth bits : list index
+		// PSDepthPeel.hlsl:12-24: the NUM_OIT_LAYERS nearest fragments, ascending depth; key = depth bits : list index.
+		// A fragment's colour (PSCube.hlsl:30-60) does not depend on the other fragments, so it is shaded here, where the volume
+		// is wave-uniform (its constants come through scalar loads and the cube-map gathers of successive volumes do not wait
+		// for one another), and travels through the sorted insert with its key; only the resolve below is ordered.  The one
+		// expensive kind -- a screen-space volume without a marched layer -- is left to the layers that survive the peel.
 		unsigned long long keys[kNumOitLayers];
+		uint2 layers[kNumOitLayers];
 #pragma unroll
-		for (uint32_t m = 0; m < kNumOitLayers; ++m) keys[m] = ~0ull;
+		for (uint32_t m = 0; m < kNumOitLayers; ++m) { keys[m] = ~0ull; layers[m].x = layers[m].y = 0u; }
+		bool needMarch = false;
 
-		vec3 lpt0 = v3(0.0f, 0.0f, 0.0f), lpt1 = v3(0.0f, 0.0f, 0.0f);
 		for (uint32_t k = 0; k < visibleCount; ++k)
 		{
 			const uint32_t v = st.visibleVolumes[k];
@@ -348,111 +383,137 @@ __global__ __launch_bounds__(64, MV_COMPOSITE_MIN_WAVES) void compositeKernel(De
 			const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[v];
 			if (tileX0 + 7u < rect.x || tileX0 > rect.z || tileY0 + 7u < rect.y || tileY0 > rect.w) continue;
 			const PerObject& po = perObjects[v];
+			const vec3 localSpaceEyePt = mul43(eyePt, po.worldI);
 			vec3 lpt;
 			float z;
-			if (!findExitFragment(po, mul43(eyePt, po.worldI), dirW, lpt, z)) continue;
+			if (!findExitFragment(po, localSpaceEyePt, dirW, lpt, z)) continue;
+
+			const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[v];
+			uint2 layer;
+			if (vi.z & kCubeMapRayMarchBit)
+			{
+				const int dims = (int)(st.N >> vi.x);
+				const size_t off = (size_t)v * chain + cubeMipOffset(st.N, vi.x);
+				layer = packLayer(CubeCast(st.cubeMaps + off, st.cubeDepths + off, dims, depthPix, lpt, lpt - localSpaceEyePt));
+			}
+			else
+			{
+				const uint32_t slot = st.screenSlot[v];
+				if (slot != 0xffffffffu && inBand)
+				{
+					// RayCast (RayCast.hlsli:43-108) already marched for this pixel by the view march's screen tiles
+					const float4 c = st.screenLayers[((size_t)slot * st.H + py) * st.W + px];
+					vec4 color; color.x = c.x; color.y = c.y; color.z = c.z; color.w = c.w;
+					layer = packLayer(color);
+				}
+				else { layer.x = 0u; layer.y = kLayerNeedsMarch; needMarch = true; }
+			}
 
 			// sorted insert (stable for equal depths: the list index k is the low word)
 			unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | k;
-			// the exit points of the two nearest fragments stay in registers (most pixels have one or two layers); deeper layers
-			// recompute theirs in the shading loop below
-			if (key < keys[0]) { lpt1 = lpt0; lpt0 = lpt; }
-			else if (key < keys[1]) lpt1 = lpt;
 #pragma unroll
 			for (uint32_t m = 0; m < kNumOitLayers; ++m)
 			{
 				const unsigned long long cur = keys[m];
+				const uint2 curLayer = layers[m];
 				const bool smaller = key < cur;
 				keys[m] = smaller ? key : cur;
+				layers[m].x = smaller ? layer.x : curLayer.x; layers[m].y = smaller ? layer.y : curLayer.y;
 				key = smaller ? cur : key;
+				layer.x = smaller ? curLayer.x : layer.x; layer.y = smaller ? curLayer.y : layer.y;
 			}
 		}
 
-		// PSCube.hlsl:30-60 per layer, PSResolveOIT.hlsl:12-26
-		vec4 result; result.x = result.y = result.z = result.w = 0.0f;
-		const uint64_t chain = cubeChainTexels(st.N);
-#pragma unroll 1
-		for (uint32_t m = 0; m < kNumOitLayers; ++m)
+		// RayCast (RayCast.hlsli:43-108) inline for the surviving layers of screen-space volumes that the view march did not march
+		// for this pixel (sharded contexts outside their row band, or more screen-space volumes than slots): rare, per-lane volumes
+		if (!MARCH) deferred = __any(needMarch);
+		else if (__any(needMarch))
 		{
-			if (keys[m] == ~0ull) break;
-			const uint32_t v = st.visibleVolumes[(uint32_t)(keys[m] & 0xffffffffull)];
-			const PerObject& po = perObjects[v];
-			const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[v];
-			const vec3 localSpaceEyePt = mul43(eyePt, po.worldI);
+#pragma unroll 1
+			for (uint32_t m = 0; m < kNumOitLayers; ++m)
+			{
+				unsigned long long key = keys[0];
+				uint32_t tag = layers[0].y;
+#pragma unroll
+				for (uint32_t j = 1; j < kNumOitLayers; ++j) if (m == j) { key = keys[j]; tag = layers[j].y; }
+				if (key == ~0ull || tag != kLayerNeedsMarch) continue;
+				const uint32_t v = st.visibleVolumes[(uint32_t)(key & 0xffffffffull)];
+				const PerObject& po = perObjects[v];
+				const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[v];
+				const vec3 localSpaceEyePt = mul43(eyePt, po.worldI);
+				vec3 lpt;
+				float z;
+				findExitFragment(po, localSpaceEyePt, dirW, lpt, z);	// the exit point exactly as in the peel loop
+				vec3 ro = localSpaceEyePt;
+				const vec3 rd = normalize3(lpt - localSpaceEyePt);
+				vec4 color; color.x = color.y = color.z = color.w = 0.0f;
+				if (ComputeRayOrigin(ro, rd))
+				{
+					const float tMax = GetTMax(v3(nx, ny, depthPix), ro, rd, po.wvpI);
+					const VolumeView vol = makeVolumeView(st.volumes[vi.w], st.alphaCells[vi.w], st.N, st.bricks);
+					color = marchRay(vol, st.lightTable[v], st.L, ro, rd, tMax, vi.y, nSamples, nLit);
+				}
+				const uint2 layer = packLayer(color);
+#pragma unroll
+				for (uint32_t j = 0; j < kNumOitLayers; ++j) if (m == j) layers[j] = layer;
+			}
+		}
 
-			vec4 color;
-			const uint32_t slot = (vi.z & kCubeMapRayMarchBit) ? 0xffffffffu : st.screenSlot[v];
-			if (!(vi.z & kCubeMapRayMarchBit) && slot != 0xffffffffu && py >= st.bandRow0 && py < st.bandRow1)
+		if (!deferred)
+		{
+			// PSResolveOIT.hlsl:12-26: front to back over the layers
+			vec4 result; result.x = result.y = result.z = result.w = 0.0f;
+	#pragma unroll
+			for (uint32_t m = 0; m < kNumOitLayers; ++m)
 			{
-				// RayCast (RayCast.hlsli:43-108) already marched for this pixel by marchViewKernel's screen tiles
-				const float4 c = st.screenLayers[((size_t)slot * st.H + py) * st.W + px];
-				color.x = c.x; color.y = c.y; color.z = c.z; color.w = c.w;
-			}
-			else
-			{
-				// the exit point: kept from the peel loop for the two nearest layers, recomputed exactly as there for deeper ones
-				// (cheaper than keeping 8 float3 in registers)
-				vec3 lpt = m == 0u ? lpt0 : lpt1;
-				if (m >= 2u)
-				{
-					float z;
-					findExitFragment(po, localSpaceEyePt, dirW, lpt, z);
-				}
-				const vec3 rayDir = lpt - localSpaceEyePt;
-				if (!(vi.z & kCubeMapRayMarchBit))
-				{
-					// RayCast (RayCast.hlsli:43-108), inline fallback (sharded contexts, or more screen-space volumes than slots)
-					vec3 ro = localSpaceEyePt;
-					const vec3 rd = normalize3(rayDir);
-					color.x = color.y = color.z = color.w = 0.0f;
-					if (ComputeRayOrigin(ro, rd))
-					{
-						const float tMax = GetTMax(v3(nx, ny, depthPix), ro, rd, po.wvpI);
-						const VolumeView vol = makeVolumeView(st.volumes[vi.w], st.alphaCells[vi.w], st.N, st.bricks);
-						color = marchRay(vol, st.lightTable[v], st.L, ro, rd, tMax, vi.y, nSamples, nLit);
-					}
-				}
-				else
-				{
-					const int dims = (int)(st.N >> vi.x);
-					const size_t off = (size_t)v * chain + cubeMipOffset(st.N, vi.x);
-					color = CubeCast(st.cubeMaps + off, st.cubeDepths + off, dims, depthPix, lpt, rayDir);
-				}
-			}
-			if (color.w > 0.0f && color.w <= 1.0f)
-			{
-				// kColors is RGBA16F (MultiRayCaster.cpp:236): each layer is rounded to fp16 before the resolve
-				const float cr = half_bits_to_float(float_to_half_bits(color.x)), cg = half_bits_to_float(float_to_half_bits(color.y));
-				const float cbl = half_bits_to_float(float_to_half_bits(color.z)), ca = half_bits_to_float(float_to_half_bits(color.w));
+				const uint2 c = layers[m];	// zeros where there is no layer
+				const float cr = half_bits_to_float((uint16_t)(c.x & 0xffffu)), cg = half_bits_to_float((uint16_t)(c.x >> 16));
+				const float cbl = half_bits_to_float((uint16_t)(c.y & 0xffffu)), ca = half_bits_to_float((uint16_t)(c.y >> 16));
 				const float it = 1.0f - result.w;
 				result.x += cr * it; result.y += cg * it; result.z += cbl * it; result.w += ca * it;
 			}
+			result.w = __builtin_fminf(result.w, 0.9997f);	// PSResolveOIT.hlsl:23
+			if (background)
+			{
+				// the resolve is drawn over the scene's colour target with the PREMULTIPLITED blend preset (MultiRayCaster.cpp:931):
+				// dst = src + dst * (1 - src.a), colour and alpha alike, blended in fp32 and rounded to the target's format once
+				const vec4 dst = decodeTexel(background[(size_t)py * st.W + px]);
+				const float inv = 1.0f - result.w;
+				result.x = result.x + dst.x * inv; result.y = result.y + dst.y * inv; result.z = result.z + dst.z * inv; result.w = result.w + dst.w * inv;
+			}
+			uint2 o;
+			o.x = (uint32_t)float_to_half_bits(result.x) | ((uint32_t)float_to_half_bits(result.y) << 16);
+			o.y = (uint32_t)float_to_half_bits(result.z) | ((uint32_t)float_to_half_bits(result.w) << 16);
+			st.composite[(size_t)py * st.W + px] = o;
 		}
-		result.w = __builtin_fminf(result.w, 0.9997f);	// PSResolveOIT.hlsl:23
-		if (background)
-		{
-			// the resolve is drawn over the scene's colour target with the PREMULTIPLITED blend preset (MultiRayCaster.cpp:931):
-			// dst = src + dst * (1 - src.a), colour and alpha alike, blended in fp32 and rounded to the target's format once
-			const vec4 dst = decodeTexel(background[(size_t)py * st.W + px]);
-			const float inv = 1.0f - result.w;
-			result.x = result.x + dst.x * inv; result.y = result.y + dst.y * inv; result.z = result.z + dst.z * inv; result.w = result.w + dst.w * inv;
-		}
-		uint2 o;
-		o.x = (uint32_t)float_to_half_bits(result.x) | ((uint32_t)float_to_half_bits(result.y) << 16);
-		o.y = (uint32_t)float_to_half_bits(result.z) | ((uint32_t)float_to_half_bits(result.w) << 16);
-		st.composite[(size_t)py * st.W + px] = o;
 	}
 
+	if (!MARCH)
+	{
+		if (__any(deferred) && lane == 0) retry[2u + atomicAdd(retry, 1u)] = tileIndex;
+		break;
+	}
 	uint32_t tot = nSamples;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o);
-	const uint32_t slot = ((row0 >> 3) * tilesX + blockIdx.x);
+	const uint32_t slot = ((row0 >> 3) * tilesX + tileIndex);
 	if (lane == 0 && tot && slot < st.compositeSlots) st.compositeStats[slot] += tot;
+	}
+	if (MARCH && lane == 0)
+	{
+		// the last workgroup to finish empties the list for the next composite into this output set
+		__threadfence();
+		if (atomicAdd(retry + 1, 1u) == gridDim.x - 1u) { retry[0] = 0u; retry[1] = 0u; }
+	}
 }
 
 void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background)
 {
 	const uint32_t tilesX = (st.W + 7u) >> 3, tilesY = (row1 - row0 + 7u) >> 3;
-	hipLaunchKernelGGL(compositeKernel, dim3(tilesX * tilesY), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background));
+	hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	// The inline march can only be asked for by a screen-space volume without a slot or by rows outside this context's band
+	// (what the view march's screen tiles cover): when neither can happen the second launch is left out.
+	if (st.screenSlots < st.V || row0 < st.bandRow0 || row1 > st.bandRow1)
+		hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 }
 } // namespace mv

@@ -809,7 +809,8 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 	}
 
 	const uint32_t tot = waveSumU32(nS);
-	if (lane == 0 && tot) st.lightStats[b] += tot;	// this voxel block's own slot: no atomics
+	// this voxel block's own slot; an atomic because light marches of consecutive frames may run side by side
+	if (lane == 0 && tot) atomicAdd(reinterpret_cast<unsigned long long*>(st.lightStats) + b, (unsigned long long)tot);
 }
 
 constexpr uint32_t kOrderBins = 8, kOrderWaves = 256;

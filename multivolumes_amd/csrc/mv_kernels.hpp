@@ -130,6 +130,7 @@ struct DeviceState
 	uint64_t* waveStats;			// marchWaves x 8: {view samples, lit, rays, lane slots, RayCast samples, RayCast lit, fetch-free samples, -} per march wavefront
 	uint64_t* lightStats;			// ceil(L/4)^3: light samples per marchL block
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
+	uint32_t* compositeRetry;		// 2 + compositeSlots: {count, finished workgroups, tiles the composite's second launch has to march inline}
 	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles, marchWaves;
 	const uint32_t* tileOrder;		// permutation of the tile list (dispatch slot -> tile), longest bins first (launchTileOrder); NULL = list order
 	uint32_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch, by stable tile key

@@ -28,7 +28,7 @@ tot = sum(cov.values())
 print("  concurrency: " + "  ".join("%d kernels: %.1f%% (%.1f us/frame)" % (k, 100.0 * v / tot, v / n / 1e3) for k, v in sorted(cov.items())))
 # a sample of the steady-state schedule
 base = ev[len(ev) // 2][0]
-for s, e, k, q in ev[len(ev) // 2: len(ev) // 2 + 24]:
+for s, e, k, q in ev[len(ev) // 2: len(ev) // 2 + 40]:
     print("   %9.1f .. %9.1f us  q%-3s %s" % ((s - base) / 1e3, (e - base) / 1e3, q, k))
 # the largest idle gaps (no kernel running) of the window
 gaps = []; cur = 0; last = None
