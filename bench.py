@@ -321,7 +321,7 @@ def main():
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
                 "parallelism": f"cube-map volumes sharded v%{world} + all-gather of the marched cube faces, screen-space RayCast and composite sharded by rows; frame loop inside the library (mv_dist_frame), transport: {exchange}" if world > 1 else "single GPU",
-                "frames_in_flight": ("up to 3 (constants / cull 4 slots, march outputs 2, light maps 3 buffers per volume)" if world == 1
+                "frames_in_flight": ("up to 3 whole frames (light march, view march, composite) on 3 view streams; constants / cull 4 slots, march outputs 3 sets, light maps 3 buffers per volume" if world == 1
                                      else "upload + cull + light march ahead of the view march / exchange / composite stream") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes_timed // max(1, K),

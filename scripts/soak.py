@@ -3,8 +3,8 @@ context; the composites and the counters must agree bit for bit at every checkpo
 width, nothing drifts).
 
 The reference never clears its cube maps, so a texel a frame does not write keeps old data (CSRayMarch.hlsl:84-85 returns early
-for faces that are not visible) and a 4-tap CubeCast gather across a cube edge can read it; with frames in flight the two output
-sets are kept reading like one by the copy-forward of unmarched faces (mv_composite.hip copyForwardKernel), which this run checks
+for faces that are not visible) and a 4-tap CubeCast gather across a cube edge can read it; with frames in flight the rotating
+output sets are kept reading like one by the copy-forward of unmarched faces (mv_composite.hip copyForwardKernel), which this run checks
 over tens of thousands of frames.  tests/test_gpu_configs.py holds a 600-frame version."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -359,8 +359,8 @@ def test_c3_with_the_reference_scenes_mesh(oracle):
 
 def test_orbit_with_frames_in_flight_reads_like_one_output_set():
     """The reference never clears its cube maps: a face a frame does not march keeps older data, and a CubeCast gather across a cube
-    edge can read it.  With frames in flight two output sets alternate; the copy-forward of unmarched faces must make them read
-    exactly like the single set of a one-stream context.  An orbit that keeps changing face masks, mips and schemes, composites
+    edge can read it.  With frames in flight three output sets rotate; the copy-forward of unmarched faces must make every one
+    of them read exactly like the single set of a one-stream context.  An orbit that keeps changing face masks, mips and schemes, composites
     compared every few frames (scripts/soak.py runs the same for 40 000 frames)."""
     cfg = dict(scene.CONFIGS["T2"], W=320, H=200)
     V, N = cfg["V"], cfg["N"]
