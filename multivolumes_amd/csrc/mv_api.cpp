@@ -50,6 +50,7 @@ struct FrameBufs
 	uint32_t* screenSlot = nullptr;
 	uint4** lightTable = nullptr;
 	uint32_t* tileCost = nullptr;
+	uint32_t* lightOrder = nullptr;	// dispatch order of the light march's voxel blocks (launchLightOrder), per slot
 	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per slot
 	mv::VolumeConsts* volConsts = nullptr;
 	uint32_t* queueHeads = nullptr;
@@ -205,7 +206,7 @@ void applyParity(mv_ctx* ctx)
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
-	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.lightDirs = f.lightDirs;
+	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
 	const OutBufs& o = ctx->ob[ctx->set];
 	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers; st.faceStamps = o.faceStamps;
@@ -495,6 +496,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			if ((rc = devAlloc(ctx, &f.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.lightDirs, (size_t)st.V * sizeof(float4))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.lightOrder, (size_t)((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.volConsts, (size_t)st.V * sizeof(mv::VolumeConsts))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.queueHeads, (size_t)mv::kRayQueues * mv::kRayQueueStride * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if (hipMemcpyAsync(f.lightTable, table.data(), (size_t)st.V * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
@@ -812,6 +814,7 @@ int mv_cull(mv_ctx* ctx)
 	beginStage(ctx, 0, ev, ctx->streamA);
 	mv::launchCull(ctx->streamA, ctx->st);
 	endStage(ctx, ev, ctx->streamA);
+	mv::launchLightOrder(ctx->streamA, ctx->st);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, stageADone(ctx));
 	if (ctx->orderTiles)

@@ -680,7 +680,7 @@ __device__ __forceinline__ vec3 EvaluateSHIrradiance(const float* sh, vec3 norm)
 #endif
 // kLightWaves voxel blocks per workgroup: they share the per-axis address tables of the volumes in LDS (LUT, N <= 256; every
 // volume source has the same N and pitches).
-template <bool LUT>
+template <bool LUT, bool ORDERED>
 __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLightLutMaxN + 1) : 1];
@@ -705,8 +705,17 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 
 	const uint32_t L = st.L;
 	const uint32_t blocksPerAxis = (L + 3u) >> 2;
-	const uint32_t b = blockIdx.x * kLightWaves + (threadIdx.x >> 6);
-	if (b >= blocksPerAxis * blocksPerAxis * blocksPerAxis) return;
+	const uint32_t totalBlocks = blocksPerAxis * blocksPerAxis * blocksPerAxis;
+	uint32_t b = blockIdx.x * kLightWaves + (threadIdx.x >> 6);
+	if (ORDERED)
+	{
+		// workgroup i runs on XCD i % 8: it takes the next kLightWaves blocks of that XCD's eighth of the tube order (lightOrderKernel)
+		const uint32_t perXcd = (totalBlocks + 7u) >> 3, xcd = blockIdx.x & 7u;
+		const uint32_t e = xcd * perXcd + (blockIdx.x >> 3) * kLightWaves + (threadIdx.x >> 6);
+		if (e >= (xcd + 1u) * perXcd || e >= totalBlocks) return;
+		b = st.lightOrder[e];
+	}
+	if (b >= totalBlocks) return;
 	const uint32_t bx = b % blocksPerAxis, by = (b / blocksPerAxis) % blocksPerAxis, bz = b / (blocksPerAxis * blocksPerAxis);
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t xx = bx * 4 + (lane & 3u), yy = by * 4 + ((lane >> 2) & 3u), zz = bz * 4 + (lane >> 4);
@@ -1009,15 +1018,92 @@ void launchCull(hipStream_t s, const DeviceState& st)
 	hipLaunchKernelGGL(cullKernel, dim3((st.V + 7u) / 8u), dim3(kCullThreads), st.V * 3 * sizeof(uint32_t), s, st);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Dispatch order of the light march, XCD-aware.  Every voxel of the relit volume casts a ray towards the light through its own
+// volume, and the light is directional: the rays are parallel, so the 4x4x4 voxel blocks along the light direction walk through the
+// same texels one after the other.  Workgroups are dealt round-robin over the 8 XCDs, each with its own L2; in plain x-y-z order every
+// XCD touches the whole volume and every line is fetched by several L2s (3.2 L2 misses per line of the alpha structure at C3).
+// This kernel sorts the blocks by the "tube" they belong to -- block coordinates sheared along the dominant axis of the light
+// direction, so that the blocks of one tube follow the light -- and the march gives XCD x the x-th eighth of that order, one
+// contiguous bundle of tubes, walked tube by tube.  The order only decides which wavefront marches which block.
+// One workgroup, a counting sort over at most (2 B)^2 tubes in LDS (B = blocks per axis <= kLightOrderMaxB), behind the cull.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kLightOrderMaxB = 32, kLightOrderThreads = 1024;
+__global__ __launch_bounds__(kLightOrderThreads) void lightOrderKernel(DeviceState st)
+{
+	__shared__ uint32_t sCursor[4u * kLightOrderMaxB * kLightOrderMaxB];
+	__shared__ uint32_t sWave[kLightOrderThreads / 64u];
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	const uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
+	const uint32_t B = (st.L + 3u) >> 2, T = 2u * B, total = B * B * B, tubes = T * T;
+	const float4 ld = st.lightDirs[volumeId];
+	float d[3] = { ld.x, ld.y, ld.z };
+	// dominant axis a; p, q the other two; slopes of the shear (0 for a direction that is not a finite, non-zero vector)
+	uint32_t a = 0;
+	if (__builtin_fabsf(d[1]) > __builtin_fabsf(d[a])) a = 1;
+	if (__builtin_fabsf(d[2]) > __builtin_fabsf(d[a])) a = 2;
+	const uint32_t p = (a + 1u) % 3u, q = (a + 2u) % 3u;
+	const bool usable = __builtin_fabsf(d[a]) > 0.0f && __builtin_fabsf(d[a]) < 3.0e38f;
+	const float sp = usable ? d[p] / d[a] : 0.0f, sq = usable ? d[q] / d[a] : 0.0f;
+	auto tubeOf = [&](uint32_t b) -> uint32_t
+	{
+		uint32_t c[3] = { b % B, (b / B) % B, b / (B * B) };
+		const float ka = (float)c[a];
+		// |slope| <= 1, so the sheared coordinate spans 2 B - 1 values: [-(B - 1), B - 1] for a positive slope, [0, 2 B - 2] for a negative one
+		const int tp = (int)c[p] - (int)__builtin_rintf(sp * ka) + (sp >= 0.0f ? (int)B - 1 : 0), tq = (int)c[q] - (int)__builtin_rintf(sq * ka) + (sq >= 0.0f ? (int)B - 1 : 0);
+		// (the clamp keeps any rounding surprise a valid, if poorer, bucket)
+		const uint32_t up = (uint32_t)(tp < 0 ? 0 : tp) % T, uq = (uint32_t)(tq < 0 ? 0 : tq) % T;
+		return up * T + uq;
+	};
+	for (uint32_t i = threadIdx.x; i < tubes; i += kLightOrderThreads) sCursor[i] = 0u;
+	__syncthreads();
+	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) atomicAdd(&sCursor[tubeOf(b)], 1u);
+	__syncthreads();
+	// exclusive prefix over the tubes: every thread owns tubes / 1024 (<= 4) consecutive counts
+	const uint32_t per = (tubes + kLightOrderThreads - 1u) / kLightOrderThreads;
+	uint32_t mine[4] = { 0u, 0u, 0u, 0u }, sum = 0u;
+	for (uint32_t k = 0; k < per; ++k) { const uint32_t i = threadIdx.x * per + k; mine[k] = i < tubes ? sCursor[i] : 0u; sum += mine[k]; }
+	uint32_t incl = sum;
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o); if ((int)lane >= o) incl += v; }
+	if (lane == 63u) sWave[wave] = incl;
+	__syncthreads();
+	uint32_t base = incl - sum;
+	for (uint32_t w = 0; w < wave; ++w) base += sWave[w];
+	__syncthreads();
+	for (uint32_t k = 0; k < per; ++k) { const uint32_t i = threadIdx.x * per + k; if (i < tubes) sCursor[i] = base; base += mine[k]; }
+	__syncthreads();
+	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) st.lightOrder[atomicAdd(&sCursor[tubeOf(b)], 1u)] = b;
+}
+
+void launchLightOrder(hipStream_t s, const DeviceState& st)
+{
+	if (!st.lightOrder || ((st.L + 3u) >> 2) > kLightOrderMaxB) return;
+	hipLaunchKernelGGL(lightOrderKernel, dim3(1), dim3(kLightOrderThreads), 0, s, st);
+}
+
+#ifndef MV_LIGHT_ORDER
+#define MV_LIGHT_ORDER 1	// XCD-aware tube order of the light march's voxel blocks (lightOrderKernel); 0 = x-y-z order (A/B timing)
+#endif
 #ifndef MV_LIGHT_LUT
 #define MV_LIGHT_LUT 1	// per-axis address tables in LDS for the light march (N <= 256); 0 = compute every tap's offsets (A/B timing)
 #endif
 void launchMarchLight(hipStream_t s, const DeviceState& st)
 {
-	const uint32_t b = (st.L + 3u) >> 2;
-	const uint32_t groups = (b * b * b + kLightWaves - 1u) / kLightWaves;
-	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL(marchLightKernel<true>, dim3(groups), dim3(64 * kLightWaves), 0, s, st);
-	else hipLaunchKernelGGL(marchLightKernel<false>, dim3(groups), dim3(64 * kLightWaves), 0, s, st);
+	const uint32_t b = (st.L + 3u) >> 2, total = b * b * b;
+	if (MV_LIGHT_ORDER && st.lightOrder && b <= kLightOrderMaxB)
+	{
+		const uint32_t perXcd = (total + 7u) >> 3;
+		const uint32_t groups = 8u * ((perXcd + kLightWaves - 1u) / kLightWaves);
+		if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
+		else hipLaunchKernelGGL((marchLightKernel<false, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
+		return;
+	}
+	const uint32_t groups = (total + kLightWaves - 1u) / kLightWaves;
+	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
+	else hipLaunchKernelGGL((marchLightKernel<false, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
 }
 
 } // namespace mv

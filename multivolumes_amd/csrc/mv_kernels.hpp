@@ -129,6 +129,7 @@ struct DeviceState
 	uint64_t* timeline;				// marchWaves x 8 (filled by -DMV_TIMELINE builds only): per-wavefront stamps of the last march
 	uint64_t* waveStats;			// marchWaves x 8: {view samples, lit, rays, lane slots, RayCast samples, RayCast lit, fetch-free samples, -} per march wavefront
 	uint64_t* lightStats;			// ceil(L/4)^3: light samples per marchL block
+	uint32_t* lightOrder;			// ceil(L/4)^3: dispatch order of the light march's voxel blocks (lightOrderKernel), per frame slot
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
 	uint32_t* compositeRetry;		// 2 + compositeSlots: {count, finished workgroups, tiles the composite's second launch has to march inline}
 	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles, marchWaves;
@@ -180,6 +181,7 @@ void launchBuildOccupancy(hipStream_t s, const uint2* bricked, uint64_t* words, 
 void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uint32_t L);
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
+void launchLightOrder(hipStream_t s, const DeviceState& st);	// behind the cull: XCD-aware order of the light march's voxel blocks
 void launchMarchLight(hipStream_t s, const DeviceState& st);
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// returns the first slot its grid does not cover (0xffffffff: none)
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
