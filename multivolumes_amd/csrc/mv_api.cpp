@@ -1549,13 +1549,20 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 	if ((rc = mv_march_light(ctx)) != MV_OK) return rc;
 	if (ctx->st.shardCount > 1)
 	{
+		// The light-map exchange goes in front of the view march that needs it, on that march's stream -- not behind the light march on
+		// stream L: there it would hold up the NEXT frame's light march (owned by another rank, ready to run beside this one) until this
+		// frame's owner has finished.  Stream L of a rank then only ever carries its own light marches.
+		hipStream_t E = ctx->stream;
 		const size_t words = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
-		mv::launchLightExchange(ctx->streamL, ctx->st, d->lightWords, false);
+		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evLight[ctx->slot], 0));	// the owner's light march (nothing on the other ranks)
+		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evStageA[ctx->slot], 0));	// this frame's cull: the relit volume, its rotated buffer
+		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));	// frame k - 3, the last reader of the buffer the unpack overwrites
+		mv::launchLightExchange(E, ctx->st, d->lightWords, false);
 		MV_HIP(ctx, hipGetLastError());
-		if ((rc = distAllReduceU32(ctx, d->lightWords, words, ctx->streamL, 1)) != MV_OK) return rc;
-		mv::launchLightExchange(ctx->streamL, ctx->st, d->lightWords, true);
+		if ((rc = distAllReduceU32(ctx, d->lightWords, words, E, 1)) != MV_OK) return rc;
+		mv::launchLightExchange(E, ctx->st, d->lightWords, true);
 		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], ctx->streamL));	// the view march waits for the exchanged map, not only for the light march
+		MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], E));	// "this frame's light map is current on this rank": the next user of the slot waits for it
 		d->bytes += words * sizeof(uint32_t);
 	}
 	if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
@@ -1589,7 +1596,7 @@ int mv_dist_selftest(mv_ctx* ctx)
 	std::vector<uint8_t> h(n * world), g(n * world);
 	for (int which = 0; which < 2; ++which)
 	{
-		hipStream_t s = which == 0 ? d->streamX : ctx->streamL;
+		hipStream_t s = which == 0 ? d->streamX : ctx->stream;	// the streams the frame loop uses the two communicators on
 		// all-gather, separate buffers
 		for (size_t i = 0; i < n; ++i) h[i] = (uint8_t)(rank * 31u + i * 7u + which);
 		MV_HIP(ctx, hipMemcpyAsync(d->sendBuf, h.data(), n, hipMemcpyHostToDevice, s));
