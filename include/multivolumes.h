@@ -59,14 +59,15 @@ extern "C" {
 /* mv_config.flags */
 #define MV_FLAG_NONE 0u
 #define MV_FLAG_FORCE_MIP0_ALL_FACES 1u	/* stress variant of SURVEY 8(d): cull forces mip 0, all 6 faces, cube-map scheme */
-#define MV_FLAG_PIPELINE_FRAMES 2u			/* frames in flight (the reference keeps FrameCount = 3, MultiRayCaster.h:52): constant upload + cull, the light march,
-										   and the view march + composite of even / odd frames run on internal streams with 4 slots of cull outputs,
-										   3 light buffers per volume and 2 output sets.  Everything a frame WRITES is identical; cube-map texels a frame
-										   does not write (faces not marched that frame) hold what frame i - 2 left there instead of frame i - 1, which a
-										   CubeCast gather across a cube edge can touch.  Calls stay asynchronous; every readback / mv_get_stats /
-										   producer synchronises first. */
+#define MV_FLAG_PIPELINE_FRAMES 2u			/* frames in flight (the reference keeps FrameCount = 3, MultiRayCaster.h:52): constant upload + cull run ahead on
+										   an internal stream, and frame i's light march, view march and composite run on internal view stream i mod 3
+										   and write output set i mod 3 (4 slots of cull outputs, 3 light buffers per volume).  Everything a frame writes
+										   AND everything it leaves alone is identical to the one-stream schedule: cube faces a frame does not march are
+										   first brought up to date from the previous frame's set, so every set reads like the reference's single,
+										   never-cleared one.  Calls stay asynchronous; every readback / mv_get_stats / input setter / producer
+										   synchronises first. */
 #define MV_FLAG_SINGLE_VIEW_STREAM 4u		/* with MV_FLAG_PIPELINE_FRAMES: keep the view march, exchange and composite of EVERY frame on the context's
-										   stream (only upload, cull and light march run ahead on internal streams) -- for callers that order their own
+										   stream, with two output sets (only upload, cull and light march run ahead on internal streams) -- for callers that order their own
 										   work, e.g. RCCL collectives, on that stream between mv_march_view and mv_composite */
 
 #define MV_FLAG_LIST_ORDER 8u				/* march the tiles in list order instead of the cost-binned order (longest rays first).  The order only
