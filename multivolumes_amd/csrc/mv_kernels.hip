@@ -847,7 +847,9 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 	const uint32_t we = sEntry[lo];
 	const uint32_t key = tileCostKey(st, we & 0xffffu, we >> 16, tile - sStart[lo], tile, nCubeTiles);
 	const uint32_t width = st.maxRaySamples >= kOrderBins ? st.maxRaySamples / kOrderBins : 1u;
-	const uint32_t b = st.tileCost[key] / width;
+	const uint32_t cost = st.tileCost[key];
+	if (cost == 0u) return 0u;	// never marched (a face or a screen tile that has just come into view): with the longest, where a wrong guess costs nothing
+	const uint32_t b = (cost - 1u) / width;
 	return kOrderBins - 1u - (b < kOrderBins - 1u ? b : kOrderBins - 1u);
 }
 

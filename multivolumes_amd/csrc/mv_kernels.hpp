@@ -148,13 +148,22 @@ __host__ __device__ inline uint32_t tileCostKeyCount(uint32_t V, uint32_t N, uin
 	const uint32_t t = (N + 7u) >> 3;
 	return V * 6u * t * t + maxScreenTiles + 1u;
 }
-__host__ __device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
+// Key of a tile in the cost table (the sample count of its longest ray + 1 the last time it was marched; 0 = never): a cube tile by
+// (volume, face, tile of the face), a screen tile by (screen slot, ABSOLUTE 8x8 pixel tile of this context's row band) -- not by its
+// index in the volume's rectangle, which changes whenever the rectangle does (a moving camera).
+__device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
 {
 	const uint32_t t = (st.N + 7u) >> 3;
 	if (faceId == 7u)
 	{
-		const uint32_t sIdx = tile - nCubeTiles;
-		return st.V * 6u * t * t + (sIdx < st.maxScreenTiles ? sIdx : st.maxScreenTiles);
+		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
+		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
+		const uint32_t tx0 = rect.x >> 3, ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3, tw = (x1 >> 3) - tx0 + 1u;
+		const uint32_t tilesX = (st.W + 7u) >> 3, bandTilesY = (st.bandRow1 - st.bandRow0 + 7u) >> 3;
+		const uint32_t tx = tx0 + localTile % tw, ty = ty0 + localTile / tw - (st.bandRow0 >> 3);
+		const uint32_t slot = st.screenSlot[volumeId];
+		const uint32_t idx = ((slot < st.screenSlots ? slot : 0u) * bandTilesY + (ty < bandTilesY ? ty : bandTilesY - 1u)) * tilesX + (tx < tilesX ? tx : tilesX - 1u);
+		return st.V * 6u * t * t + (idx < st.maxScreenTiles ? idx : st.maxScreenTiles);
 	}
 	return (volumeId * 6u + faceId) * t * t + localTile;
 }

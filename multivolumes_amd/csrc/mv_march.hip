@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64 * kMarchWaves, MV_MARCH_MIN_WAVES) void marchVie
 				// longest ray of the tile so far (tileOrderKernel bins the tile by it four frames on): only a new maximum is stored.
 				// (A ray that outlives kCostRing chunks of its wavefront compares against another tile's maximum: that can only misorder
 				// a later dispatch.)
-				if (nS > atomicMax(&sCost[wave][key >> 27], nS)) st.tileCost[key & 0x7ffffffu] = nS;
+				if (nS > atomicMax(&sCost[wave][key >> 27], nS)) st.tileCost[key & 0x7ffffffu] = nS + 1u;	// (0 = never marched)
 				atomicAdd(&sStats[wave][screen ? 4 : 0], nS);
 				atomicAdd(&sStats[wave][screen ? 5 : 1], nL);
 				active = false;

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 	const uint32_t nCubeTiles = st.counters[6];
 	if (lane == 0)
 	{
-		st.tileCost[tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles)] = maxS;
+		st.tileCost[tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles)] = maxS + 1u;	// (0 = never marched)
 		// counters: a slot of the wave-stats table shared by the tiles that map to it (no-return atomics, once per tile)
 		unsigned long long* s = reinterpret_cast<unsigned long long*>(st.waveStats) + (size_t)(slot % st.marchWaves) * 8u;
 		if (!screenTile)
