@@ -210,6 +210,7 @@ void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */
 #define MV_BUF_COMPOSITE 5
 #define MV_BUF_DEPTH_MAP 6
 #define MV_BUF_SHADOW_MAP 7
+#define MV_BUF_TILE_COST 9		/* index = frame slot (0..3): the view march's tile cost table, uint32 per key: longest ray's samples + 1, 0 = never marched (diagnostics) */
 #define MV_BUF_MARCH_TIMELINE 8	/* 8 x uint64 per march wavefront; only diagnostic builds (-DMV_TIMELINE) fill it (scripts/march_timeline.py) */
 int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, size_t* bytes);
 

@@ -1194,6 +1194,9 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 	case MV_BUF_COMPOSITE: *d_ptr = st.composite; *bytes = (size_t)st.W * st.H * sizeof(uint2); return MV_OK;
 	case MV_BUF_DEPTH_MAP: *d_ptr = ctx->ownDepth; *bytes = (size_t)st.W * st.H * sizeof(float); return MV_OK;
 	case MV_BUF_SHADOW_MAP: *d_ptr = ctx->ownShadow; *bytes = (size_t)st.M * st.M * sizeof(uint16_t); return MV_OK;
+	case MV_BUF_TILE_COST:
+		MV_REQUIRE(ctx, index < kFrameSlots, MV_ERR_RANGE, "frame slot out of range");
+		*d_ptr = ctx->fb[index].tileCost; *bytes = (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t); return MV_OK;
 	case MV_BUF_MARCH_TIMELINE: *d_ptr = st.timeline; *bytes = (size_t)st.marchWaves * 8 * sizeof(uint64_t); return MV_OK;
 	default: return fail(ctx, MV_ERR_INVALID_ARG, "unknown buffer id");
 	}

@@ -525,6 +525,18 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		}
 		nEntries += totE; nTiles += totT; nScreen += (uint32_t)__popcll(bScr);
 	}
+	// what the tile costs of a frame depend on besides the volumes' contents: CBPerFrame's eye / viewport / screenToWorld and every PerObject
+	uint32_t viewHash = 0u;
+	{
+		const uint32_t* cbWords = reinterpret_cast<const uint32_t*>(st.cbPerFrame);
+		const uint32_t* poWords = reinterpret_cast<const uint32_t*>(st.perObject);
+		const uint32_t nCb = 24u, nPo = st.V * (uint32_t)(sizeof(PerObject) / 4u);
+		for (uint32_t i = lane; i < nCb + nPo; i += 64u)
+			viewHash ^= ((i < nCb ? cbWords[i] : poWords[i - nCb]) + 0x9e3779b9u * (i + 1u)) * 0x85ebca6bu;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) viewHash ^= __shfl_xor(viewHash, o);
+		viewHash |= 1u;	// never 0, the value of a slot no frame has used yet
+	}
 	if (lane == 0)
 	{
 		st.workTileStart[nEntries] = nTiles;
@@ -541,6 +553,10 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		}
 		st.counters[7] = nTiles < 2u ? 1u : stride;
 		st.counters[8] = 0u;	// the ticket, for the next cull that uses this slot
+		// [10] a hash of this frame's camera and volume transforms, [11] "it differs from the hash of this slot's previous frame",
+		// i.e. of the frame whose view march wrote the tile cost table this frame's tile order reads (tileBinOf)
+		st.counters[11] = st.counters[10] != viewHash ? 1u : 0u;
+		st.counters[10] = viewHash;
 		// host-visible {frame tag : tile count}: a hint for the grid sizes of later launches; the host never waits for it (mv_api.cpp)
 		if (st.tilesReport) *st.tilesReport = ((unsigned long long)st.frameTag << 32) | nTiles;
 	}
@@ -822,6 +838,9 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 	if (lane == 0 && tot) atomicAdd(reinterpret_cast<unsigned long long*>(st.lightStats) + b, (unsigned long long)tot);
 }
 
+#ifndef MV_ORDER_DILATE
+#define MV_ORDER_DILATE 1	// bin a tile by the largest cost in its 3x3 neighbourhood when the camera or a volume has moved since the costs were taken (0: never, 2: always; A/B timing)
+#endif
 constexpr uint32_t kOrderBins = 8, kOrderWaves = 256;
 
 // ---------------------------------------------------------------------------------------------
@@ -845,9 +864,43 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 		if (sStart[mid] <= tile) lo = mid; else hi = mid;
 	}
 	const uint32_t we = sEntry[lo];
-	const uint32_t key = tileCostKey(st, we & 0xffffu, we >> 16, tile - sStart[lo], tile, nCubeTiles);
+	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16, localTile = tile - sStart[lo];
+	const uint32_t key = tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles);
 	const uint32_t width = st.maxRaySamples >= kOrderBins ? st.maxRaySamples / kOrderBins : 1u;
-	const uint32_t cost = st.tileCost[key];
+	uint32_t cost = st.tileCost[key];
+#if MV_ORDER_DILATE
+	if (MV_ORDER_DILATE == 2 || st.counters[11])
+	// The table is four frames old.  With a moving camera (or moving volumes: the cull compares a hash of both with the one of the
+	// frame that wrote the table) nearly every tile still costs what it did (5 % change bin, 1.2 samples of
+	// mean drift at 0.004 rad per frame) -- but the few tiles a silhouette has moved INTO start late and run long, and the launch ends
+	// with them (+10 %: scripts/exp_orbit_positions.py).  A tile is therefore binned by the largest cost among itself and its
+	// neighbours in the face (or on the screen): a silhouette moves less than a tile in four frames.
+	{
+		uint32_t tilesX, tilesY, stride = 1u;
+		if (faceId == 7u)
+		{
+			const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
+			const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u, y1 = rect.w < st.bandRow1 - 1u ? rect.w : st.bandRow1 - 1u;
+			const uint32_t ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3;
+			tilesX = (x1 >> 3) - (rect.x >> 3) + 1u; tilesY = (y1 >> 3) >= ty0 ? (y1 >> 3) - ty0 + 1u : 1u;
+			stride = (st.W + 7u) >> 3;	// screen keys are absolute: one row of tiles down = one row of the viewport
+		}
+		else
+		{
+			const uint32_t dims = st.N >> reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId].x;
+			tilesX = tilesY = (dims + 7u) >> 3;
+			stride = tilesX;
+		}
+		const uint32_t lx = localTile % tilesX, ly = localTile / tilesX;
+		for (int dy = -1; dy <= 1; ++dy)
+			for (int dx = -1; dx <= 1; ++dx)
+			{
+				if ((dx | dy) == 0 || (int)lx + dx < 0 || (int)lx + dx >= (int)tilesX || (int)ly + dy < 0 || (int)ly + dy >= (int)tilesY) continue;
+				const uint32_t c = st.tileCost[(uint32_t)((int)key + dy * (int)stride + dx)];
+				cost = c > cost ? c : cost;
+			}
+	}
+#endif
 	if (cost == 0u) return 0u;	// never marched (a face or a screen tile that has just come into view): with the longest, where a wrong guess costs nothing
 	const uint32_t b = (cost - 1u) / width;
 	return kOrderBins - 1u - (b < kOrderBins - 1u ? b : kOrderBins - 1u);

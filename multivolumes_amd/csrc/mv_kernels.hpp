@@ -111,7 +111,8 @@ struct DeviceState
 	uint32_t frameTag;				// low 32 bits of the context's frame counter
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
 									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow),
-									// [8] the cull's ticket, [9] head of the march's ray queue (device-only)
+									// [8] the cull's ticket, [9] head of the march's ray queue (device-only), [10] hash of the frame's camera and volume
+									// transforms, [11] that hash differs from the one of the slot's previous frame (whose march wrote the tile costs)
 	VolumeConsts* volConsts;		// V (written by the cull)
 	uint32_t* queueHeads;			// kRayQueues heads of the march's ray queue, one per 128-byte line (zeroed by the ray setup)
 	uint32_t* ownedVisible;			// V: visible volumes of this shard, ascending

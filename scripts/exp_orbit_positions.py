@@ -9,7 +9,7 @@ from multivolumes_amd import MultiRayCaster, scene, _lib
 from multivolumes_amd import raycaster as rc
 cfg = dict(scene.CONFIGS["C3"]); V, N, L = cfg["V"], cfg["N"], cfg["L"]
 vols = [rc.synth_volume(N, k) for k in range(V)]
-c = MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=1024, flags=0)
+c = MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=1024, flags=int(os.environ.get("MV_EXP_FLAGS", "0")))
 fr = scene.setup_raycaster(c, cfg, vols)
 e0 = np.asarray(fr["eye"], np.float64)
 r, a0 = float(np.hypot(e0[0], e0[2])), float(np.arctan2(e0[0], -e0[2]))
@@ -41,3 +41,24 @@ def moving(i):
 run(moving, 254)
 ms, smp, rays = run(moving, 508)
 print("moving over the arc: march %.4f ms  %.2f M samples  %.0f rays   (mean of the standing positions %.4f ms)" % (ms, smp / 1e6, rays, sum(standing) / len(standing)))
+if os.environ.get("MV_EXP_PER_FRAME"):
+    # per-frame march time while moving, beside the standing time at the same position
+    seq = []
+    run(moving, 254)
+    for i in range(0, 128, 4):
+        pass
+    c.synchronize(); c.ResetStats(); c.SetProfiling(True)
+    last = 0.0
+    for i in range(254):
+        e, vp, d = moving(i)
+        c.SetRenderTargets(depthMapDevice=d.data_ptr()); c.UpdateFrame(vp, fr["shadowVP"], e); c.Render(composite=True); c.synchronize()
+        st = c.GetStats()
+        seq.append(st["ms_march_view"] - last); last = st["ms_march_view"]
+    print("moving, per frame (position: ms):", " ".join("%d:%.3f" % (i if i < 128 else 254 - i, seq[i]) for i in range(0, 254, 3)))
+if os.environ.get("MV_EXP_OSC"):
+    for j in (0, 48, 96):
+        for _ in range(8): run(lambda i: pos[j], 1)
+        a = run(lambda i: pos[j], 48)[0]
+        b = run(lambda i: pos[j + (i & 1)], 48)[0]           # two positions one step apart, alternating
+        d = run(lambda i: pos[j + (i % 8)], 48)[0]           # eight positions, round and round (every slot's table sees a 4-step-old one)
+        print("position %3d: standing %.4f  alternating j / j+1 %.4f  cycling j..j+7 %.4f" % (j, a, b, d))
