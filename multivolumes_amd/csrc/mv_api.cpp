@@ -496,7 +496,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			if ((rc = devAlloc(ctx, &f.volumeFlags, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.volumeRects, (size_t)st.V * 4 * sizeof(uint16_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.lightDirs, (size_t)st.V * sizeof(float4))) != MV_OK) return bail(rc);
-			if ((rc = devAlloc(ctx, &f.lightOrder, (size_t)((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.lightOrder, ((size_t)((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) + 4u) * sizeof(uint32_t))) != MV_OK) return bail(rc);	// + the direction the order was made for
 			if ((rc = devAlloc(ctx, &f.volConsts, (size_t)st.V * sizeof(mv::VolumeConsts))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.queueHeads, (size_t)mv::kRayQueues * mv::kRayQueueStride * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if (hipMemcpyAsync(f.lightTable, table.data(), (size_t)st.V * sizeof(uint4*), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);

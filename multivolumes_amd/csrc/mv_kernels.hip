@@ -531,8 +531,9 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		const uint32_t* cbWords = reinterpret_cast<const uint32_t*>(st.cbPerFrame);
 		const uint32_t* poWords = reinterpret_cast<const uint32_t*>(st.perObject);
 		const uint32_t nCb = 24u, nPo = st.V * (uint32_t)(sizeof(PerObject) / 4u);
-		for (uint32_t i = lane; i < nCb + nPo; i += 64u)
-			viewHash ^= ((i < nCb ? cbWords[i] : poWords[i - nCb]) + 0x9e3779b9u * (i + 1u)) * 0x85ebca6bu;
+		if (lane < nCb) viewHash = (cbWords[lane] + 0x9e3779b9u * (lane + 1u)) * 0x85ebca6bu;
+#pragma unroll 4
+		for (uint32_t i = lane; i < nPo; i += 64u) viewHash ^= (poWords[i] + 0x9e3779b9u * (i + 25u)) * 0x85ebca6bu;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) viewHash ^= __shfl_xor(viewHash, o);
 		viewHash |= 1u;	// never 0, the value of a slot no frame has used yet
@@ -1094,6 +1095,15 @@ __global__ __launch_bounds__(kLightOrderThreads) void lightOrderKernel(DeviceSta
 	const uint32_t B = (st.L + 3u) >> 2, T = 2u * B, total = B * B * B, tubes = T * T;
 	const float4 ld = st.lightDirs[volumeId];
 	float d[3] = { ld.x, ld.y, ld.z };
+	// The order depends on the direction only, and the slot's table still holds the order for the direction of four frames ago (kept
+	// behind the table): with volumes that share an orientation and a light that stands still it is the same one, frame after frame.
+	{
+		uint32_t* tag = st.lightOrder + total;
+		const bool same = tag[0] == __float_as_uint(d[0]) && tag[1] == __float_as_uint(d[1]) && tag[2] == __float_as_uint(d[2]) && tag[3] == total;
+		__syncthreads();	// everybody has read the tag
+		if (same) return;
+		if (threadIdx.x == 0) { tag[0] = __float_as_uint(d[0]); tag[1] = __float_as_uint(d[1]); tag[2] = __float_as_uint(d[2]); tag[3] = total; }
+	}
 	// dominant axis a; p, q the other two; slopes of the shear (0 for a direction that is not a finite, non-zero vector)
 	uint32_t a = 0;
 	if (__builtin_fabsf(d[1]) > __builtin_fabsf(d[a])) a = 1;

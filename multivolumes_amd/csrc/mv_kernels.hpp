@@ -130,7 +130,7 @@ struct DeviceState
 	uint64_t* timeline;				// marchWaves x 8 (filled by -DMV_TIMELINE builds only): per-wavefront stamps of the last march
 	uint64_t* waveStats;			// marchWaves x 8: {view samples, lit, rays, lane slots, RayCast samples, RayCast lit, fetch-free samples, -} per march wavefront
 	uint64_t* lightStats;			// ceil(L/4)^3: light samples per marchL block
-	uint32_t* lightOrder;			// ceil(L/4)^3: dispatch order of the light march's voxel blocks (lightOrderKernel), per frame slot
+	uint32_t* lightOrder;			// ceil(L/4)^3 (+ 4: the light direction it was made for): dispatch order of the light march's voxel blocks (lightOrderKernel), per frame slot
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
 	uint32_t* compositeRetry;		// 2 + compositeSlots: {count, finished workgroups, tiles the composite's second launch has to march inline}
 	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles, marchWaves;
