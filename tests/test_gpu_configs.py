@@ -387,3 +387,38 @@ def test_orbit_with_frames_in_flight_reads_like_one_output_set():
     finally:
         for c in cs:
             c.close()
+
+
+@pytest.mark.parametrize("L", [10, 24])
+def test_light_march_block_order_for_any_light_direction(oracle, L):
+    """The light march's voxel blocks are dealt to the XCDs in an order built from the light direction (lightOrderKernel: blocks
+    sheared along the dominant axis into tubes, counting sort, one eighth of the order per XCD).  Whatever the direction -- every
+    dominant axis, both signs of every slope, axis-aligned, ragged L -- the order must be a permutation of the blocks: the light map
+    and the sample count equal the oracle's.  Every light stays for five frames, so that the fifth one finds the order of the first
+    still valid in its frame slot (the kernel's early exit)."""
+    from tests.helpers import default_descs
+    cfg = dict(scene.CONFIGS["C1"], N=24, L=L, V=2, maxRay=16, maxLight=24, W=64, H=64)
+    N, M, V = cfg["N"], 32, cfg["V"]
+    vols = [rc.synth_volume(N, 3), rc.synth_volume(N, 5)]
+    lights = [(75, 75, -75), (0, 100, 0), (100, 0, 0), (0, 0, -100), (-60, 20, 5), (10, -80, 30), (-5, -7, 90), (33, -33, 33), (1, 100, -2), (-90, -89, 88)]
+    shadow = np.full((M, M), 0xffff, np.uint16)
+    with make_caster(cfg, M) as c:
+        fr = scene.setup_raycaster(c, cfg, vols)
+        c.SetRenderTargets(np.ones((cfg["H"], cfg["W"]), np.float32), shadow)
+        descs = default_descs(V, V, N)
+        expected = 0
+        c.ResetStats()
+        lm = np.zeros((V, L, L, L), np.uint32)
+        for i, lp in enumerate(lights):
+            c.SetLight(lp, scene.LIGHT_COLOR, scene.LIGHT_INTENSITY)
+            for rep in range(5):
+                c.m_frameIdx = i * 5 + rep
+                c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+                c.cullVolumes()
+                c.rayMarchL()
+                c.synchronize()
+                vis, _ = c.ReadBackVisibleLists()
+                vid, lm, n = oracle.march_light(V, N, L, M, vols, descs, c.perObject, c.cbPerFrame, shadow, None, vis, cfg["maxLight"], lightMaps=lm)
+                expected += n
+                assert np.array_equal(c.ReadBackLightMap(vid), lm[vid]), f"light {lp}, frame {rep}: light map of volume {vid} differs"
+        assert c.GetStats()["light_samples"] == expected
