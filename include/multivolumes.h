@@ -167,7 +167,10 @@ int mv_march_light(mv_ctx* ctx);
 /* rayMarchV (MultiRayCaster.cpp:1329-1368) = CSRayMarch.hlsl:77-158 with _LIGHT_PASS_ (CSRayMarchV.hlsl). */
 int mv_march_view(mv_ctx* ctx);
 /* cubeDepthPeel + renderCube + resolveOIT (MultiRayCaster.cpp:1440-1492, 1544-1580, 1615-1633) over screen rows
- * [row0, row1) of the W x H RGBA16F output (row1 = 0 -> H). Background = transparent black (see mv_composite_over). */
+ * [row0, row1) of the W x H RGBA16F output (row1 = 0 -> H). Background = transparent black (see mv_composite_over).
+ * A frame may composite without mv_march_view (or march without compositing, or do neither): the composite then shows the cube maps
+ * as the last marches left them and ray-casts screen-space-scheme volumes itself, as the reference's passes would; with
+ * MV_FLAG_PIPELINE_FRAMES such a frame first drains the frames in flight. */
 int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1);
 /* The same drawn OVER an existing colour target, as the reference's resolve pass is (PREMULTIPLITED blend preset, MultiRayCaster.cpp:931,
  * 1615-1633): out = src + dst * (1 - src.a) on all four channels.  d_background: W x H RGBA16F texels on the device (borrowed, only read),

@@ -119,6 +119,8 @@ struct mv_ctx
 	hipEvent_t evStageA[kFrameSlots] = {}, evLight[kFrameSlots] = {}, evMainDone[kFrameSlots] = {}, evProducers = nullptr;
 	hipEvent_t evCopy[kFrameSlots] = {};	// a frame's unmarched cube faces are up to date (copyForward)
 	bool copiedForward = false;			// this frame's copy-forward has been enqueued
+	bool marchedThisFrame = false;		// mv_march_view has run for the current frame (its RayCast layers are this frame's)
+	uint64_t lastCompleteFrame = 0;		// the last frame whose output set was completed (view march, or a composite-only frame's copy from every set)
 	bool producersDirty = false;
 
 	// owned device allocations
@@ -802,7 +804,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	MV_HIP(ctx, stageADone(ctx));
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
-	ctx->lightMarched = false; ctx->lightTableKept = false; ctx->copiedForward = false;
+	ctx->lightMarched = false; ctx->lightTableKept = false; ctx->copiedForward = false; ctx->marchedThisFrame = false;
 	return MV_OK;
 }
 
@@ -862,8 +864,28 @@ int mv_march_light(mv_ctx* ctx)
 static int copyForward(mv_ctx* ctx, hipStream_t s)
 {
 	const OutBufs& other = ctx->ob[(ctx->set + ctx->numOutSets - 1u) % ctx->numOutSets];
-	mv::launchCopyForward(s, ctx->st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)ctx->frame);
+	mv::launchCopyForward(s, ctx->st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)ctx->frame, true);
 	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, hipEventRecord(ctx->evCopy[ctx->slot], s));
+	ctx->copiedForward = true;
+	return MV_OK;
+}
+
+// The same for a frame that cannot rely on "the previous frame's set is complete": the previous frame neither marched nor composited
+// (its set was never brought up to date), or this frame has no view march at all (mv_composite without mv_march_view: the reference
+// would show the cube maps as the last march left them).  Rare call patterns: the frames in flight are drained, then every other
+// set is a source -- the stamps pick the newest data of every face whatever the order.
+static int copyForwardFromAllSets(mv_ctx* ctx, bool marchFollows)
+{
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	hipStream_t s = streamB(ctx);
+	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
+	{
+		if (p == ctx->set) continue;
+		const OutBufs& other = ctx->ob[p];
+		mv::launchCopyForward(s, ctx->st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)ctx->frame, marchFollows);
+		MV_HIP(ctx, hipGetLastError());
+	}
 	MV_HIP(ctx, hipEventRecord(ctx->evCopy[ctx->slot], s));
 	ctx->copiedForward = true;
 	return MV_OK;
@@ -880,8 +902,15 @@ int mv_march_view(mv_ctx* ctx)
 #define MV_COPY_FORWARD 1	// (0: A/B timing only -- the two output sets then drift apart in the faces a frame does not march)
 #endif
 	const uint32_t n = ctx->numOutSets;
-	if (MV_COPY_FORWARD && n >= 2u && !ctx->dist && !ctx->copiedForward)
+	if (MV_COPY_FORWARD && n >= 2u && !ctx->dist && ctx->lastCompleteFrame != 0u && ctx->lastCompleteFrame + 1u != ctx->frame && !ctx->copiedForward)
 	{
+		// the previous frame left its set untouched (no view march, no composite): it is not the complete history the fast path reads
+		const int rc = copyForwardFromAllSets(ctx, true);
+		if (rc != MV_OK) return rc;
+	}
+	else if (MV_COPY_FORWARD && n >= 2u && !ctx->dist)
+	{
+		// (also when a composite of this frame has already copied, without marking the faces this march is about to write)
 		// On the stream of the PREVIOUS frame's view march (and composite): stream order alone puts the copy behind the march that
 		// completed the set it reads (a stream of its own would do, but HIP streams beyond four share hardware queues and wait for
 		// each other: measured).  It writes this frame's set, so the set's last reader (the composite of frame k - n) must be
@@ -889,10 +918,13 @@ int mv_march_view(mv_ctx* ctx)
 		hipStream_t s = ctx->streamB[(ctx->frame + ctx->numViewStreams - 1u) % ctx->numViewStreams];
 		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evMainDone[(ctx->slot + kFrameSlots - n) % kFrameSlots], 0));
 		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evCopy[prevSlot], 0));
+		if (ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evCopy[ctx->slot], 0));
 		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evStageA[ctx->slot], 0));	// this frame's cull
 		const int rc = copyForward(ctx, s);
 		if (rc != MV_OK) return rc;
 	}
+	ctx->lastCompleteFrame = ctx->frame;
+	ctx->marchedThisFrame = true;
 	MV_HIP(ctx, stageBBegin(ctx));
 	// the set this march writes was read by the copy-forward of frame k - n + 1 (as the set before its own) ...
 	if (n >= 2u) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[(ctx->slot + kFrameSlots - (n - 1u)) % kFrameSlots], 0));
@@ -948,10 +980,24 @@ int mv_composite_over(mv_ctx* ctx, uint32_t row0, uint32_t row1, const void* d_b
 	MV_REQUIRE(ctx, row0 < row1, MV_ERR_RANGE, "empty row range");
 	{ const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, stageBBegin(ctx));
+	if (MV_COPY_FORWARD && ctx->numOutSets >= 2u && !ctx->dist && !ctx->copiedForward)
+	{
+		// a composite without a view march this frame: it shows the cube maps as the last marches left them, wherever they are
+		const int rc = copyForwardFromAllSets(ctx, false);
+		if (rc != MV_OK) return rc;
+		ctx->lastCompleteFrame = ctx->frame;
+	}
 	if (ctx->numOutSets >= 2u && ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[ctx->slot], 0));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 3, ev, streamB(ctx));
-	mv::launchComposite(streamB(ctx), ctx->st, row0, row1, d_background);
+	if (ctx->marchedThisFrame) mv::launchComposite(streamB(ctx), ctx->st, row0, row1, d_background);
+	else
+	{
+		// no view march this frame: the RayCast layers of the output set belong to an older frame's camera
+		DeviceState st = ctx->st;
+		st.flags |= mv::kFlagNoScreenLayers;
+		mv::launchComposite(streamB(ctx), st, row0, row1, d_background);
+	}
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, stageBDone(ctx));

@@ -137,13 +137,14 @@ void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void
 // being marched.  (Texels of a MARCHED face whose ray misses the box by an ulp are not tracked.)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void copyForwardKernel(DeviceState st, const uint2* __restrict__ otherMaps, const float* __restrict__ otherDepths,
-	const uint32_t* __restrict__ otherStamps, uint32_t tag)
+	const uint32_t* __restrict__ otherStamps, uint32_t tag, int marchFollows)
 {
 	const uint32_t f = blockIdx.x % 6u, mip = (blockIdx.x / 6u) % kNumCubeMip, v = blockIdx.x / (6u * kNumCubeMip);
 	const uint32_t info = st.volumeFlags[v];
 	const uint32_t idx = (v * kNumCubeMip + mip) * 6u + f;
-	// visible, on the cube-map scheme, at this mip, face bit set: marched this frame (here, or by its owner and unpacked here)
-	if ((info & 3u) == 3u && ((info >> 2) & 7u) == mip && (((info >> 5) & 0x3fu) & (1u << f)))
+	// visible, on the cube-map scheme, at this mip, face bit set: marched this frame (here, or by its owner and unpacked here) --
+	// unless this frame has no view march at all (a composite-only frame: marchFollows == 0), which leaves every face to the copy
+	if (marchFollows && (info & 3u) == 3u && ((info >> 2) & 7u) == mip && (((info >> 5) & 0x3fu) & (1u << f)))
 	{
 		if (threadIdx.x == 0) st.faceStamps[idx] = tag;
 		return;
@@ -161,9 +162,9 @@ __global__ __launch_bounds__(256) void copyForwardKernel(DeviceState st, const u
 	if (threadIdx.x == 0) st.faceStamps[idx] = theirs;
 }
 
-void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag)
+void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag, bool marchFollows)
 {
-	hipLaunchKernelGGL(copyForwardKernel, dim3(st.V * kNumCubeMip * 6u), dim3(256), 0, s, st, otherMaps, otherDepths, otherStamps, tag);
+	hipLaunchKernelGGL(copyForwardKernel, dim3(st.V * kNumCubeMip * 6u), dim3(256), 0, s, st, otherMaps, otherDepths, otherStamps, tag, marchFollows ? 1 : 0);
 }
 
 // Light map of the volume relit this frame (CSRayMarchL.hlsl:29-33: ONE volume per frame, marched by its owner), for the ranks that
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 			else
 			{
 				const uint32_t slot = st.screenSlot[v];
-				if (slot != 0xffffffffu && inBand)
+				if (slot != 0xffffffffu && inBand && !(st.flags & kFlagNoScreenLayers))
 				{
 					// RayCast (RayCast.hlsli:43-108) already marched for this pixel by the view march's screen tiles
 					const float4 c = st.screenLayers[((size_t)slot * st.H + py) * st.W + px];
@@ -511,9 +512,9 @@ void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32
 {
 	const uint32_t tilesX = (st.W + 7u) >> 3, tilesY = (row1 - row0 + 7u) >> 3;
 	hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
-	// The inline march can only be asked for by a screen-space volume without a slot or by rows outside this context's band
-	// (what the view march's screen tiles cover): when neither can happen the second launch is left out.
-	if (st.screenSlots < st.V || row0 < st.bandRow0 || row1 > st.bandRow1)
+	// The inline march can only be asked for by a screen-space volume without a slot, by rows outside this context's band (what the
+	// view march's screen tiles cover) or by a frame without a view march: when none of them can happen the second launch is left out.
+	if (st.screenSlots < st.V || row0 < st.bandRow0 || row1 > st.bandRow1 || (st.flags & kFlagNoScreenLayers))
 		hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 }
 } // namespace mv

@@ -207,6 +207,7 @@ void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, 
 void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim, const void* src);
 void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes);	// marched faces only (mv_dist_frame)
 void launchLightExchange(hipStream_t s, const DeviceState& st, uint32_t* words, bool unpack);
-void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag);
+void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag, bool marchFollows = true);
+constexpr uint32_t kFlagNoScreenLayers = 0x40000000u;	// DeviceState.flags (internal, per composite launch): this frame has had no view march, so the RayCast layers are not this frame's: the composite marches screen-space volumes itself
 constexpr uint32_t kFlagRotateAllLightMaps = 0x80000000u;	// DeviceState.flags (internal): every rank rotates the relit volume's light buffer, not only its owner
 } // namespace mv

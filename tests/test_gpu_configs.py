@@ -422,3 +422,61 @@ def test_light_march_block_order_for_any_light_direction(oracle, L):
                 expected += n
                 assert np.array_equal(c.ReadBackLightMap(vid), lm[vid]), f"light {lp}, frame {rep}: light map of volume {vid} differs"
         assert c.GetStats()["light_samples"] == expected
+
+
+def test_frames_that_skip_the_view_march_or_only_composite():
+    """Call patterns other than mv_render's: frames without a view march (their output set stays behind), frames that only composite
+    (the reference would show the cube maps as the last marches left them), frames with neither.  With frames in flight the rotating
+    output sets must still read like the one set of a one-stream context: same composites, same cube maps at the end."""
+    cfg = dict(scene.CONFIGS["T2"], W=320, H=200)
+    V, N = cfg["V"], cfg["N"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    proj = rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0)
+    #            cull  light march composite
+    kinds = {"full": (1, 1, 1, 1), "no_march": (1, 1, 0, 0), "composite_only": (1, 0, 0, 1), "idle": (1, 0, 0, 0), "march_no_composite": (1, 1, 1, 0),
+             "composite_then_march": (1, 1, 2, 1)}
+    pattern = ["full", "full", "full", "composite_only", "full", "no_march", "full", "idle", "idle", "full", "march_no_composite", "composite_only",
+               "composite_only", "full", "no_march", "no_march", "composite_only", "full", "composite_then_march", "full", "idle", "composite_only", "full"]
+    cs = [make_caster(cfg, 64, flags=f) for f in (0, _lib.MV_FLAG_PIPELINE_FRAMES)]
+    try:
+        frs = [scene.setup_raycaster(c, cfg, vols, use_sh=True) for c in cs]
+        checked = 0
+        for f in range(1, 8 * len(pattern) + 1):
+            kind = pattern[f % len(pattern)]
+            cull, light, march, comp = kinds[kind]
+            a = 0.03 * f
+            e = np.array([90.0 * np.sin(a), 20.0 + 15.0 * np.sin(0.37 * a), -90.0 * np.cos(a)], np.float32)
+            vp = rc.multiply(rc.look_at_lh(e, (0, 0, 0)), proj)
+            imgs = []
+            for c, fr in zip(cs, frs):
+                c.UpdateFrame(vp, fr["shadowVP"], e)
+                c.cullVolumes()
+                if light:
+                    c.rayMarchL()
+                if march == 2:  # composite first, view march afterwards (the composite shows the previous marches; the march then writes this frame's faces)
+                    c.composite()
+                    c.rayMarchV()
+                else:
+                    if march:
+                        c.rayMarchV()
+                    if comp:
+                        c.composite()
+                if comp and f % 3 == 0:
+                    imgs.append(c.ReadBackComposite())
+            if len(imgs) == 2:
+                checked += 1
+                assert np.array_equal(imgs[0], imgs[1]), f"frame {f} ({kind}): {int((imgs[0] != imgs[1]).sum())} composite halfs differ"
+        assert checked > 20
+        # a final full frame, then every cube map of the visible cube-map volumes
+        for c, fr in zip(cs, frs):
+            c.UpdateFrame(vp, fr["shadowVP"], e)
+            c.Render(composite=True)
+        info = [c.ReadBackVolumeInfo() for c in cs]
+        assert np.array_equal(info[0], info[1])
+        vis, cube = cs[0].ReadBackVisibleLists()
+        for v in cube:
+            for mip in range(5):
+                assert np.array_equal(cs[0].ReadBackCubeMap(int(v), mip), cs[1].ReadBackCubeMap(int(v), mip)), f"cube map of volume {v}, mip {mip}"
+    finally:
+        for c in cs:
+            c.close()
