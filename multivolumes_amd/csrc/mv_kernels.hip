@@ -587,7 +587,10 @@ __device__ __forceinline__ FootprintAddr densityFootprint(const VolumeView& vol,
 	return a;
 }
 
-constexpr uint32_t kLightLutMaxN = 256, kLightWaves = 4;
+#ifndef MV_LIGHT_WAVES
+#define MV_LIGHT_WAVES 4	// voxel blocks (wavefronts) per light-march workgroup: they share the per-axis address tables in LDS
+#endif
+constexpr uint32_t kLightLutMaxN = 256, kLightWaves = MV_LIGHT_WAVES;
 
 __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vol, vec3 rayOrigin, vec3 rayDir,
 	float stepScale, uint32_t numSamples, uint32_t& samples, const u32x4* axisTables = nullptr)
