@@ -1086,9 +1086,9 @@ void launchCull(hipStream_t s, const DeviceState& st)
 // This kernel sorts the blocks by the "tube" they belong to -- block coordinates sheared along the dominant axis of the light
 // direction, so that the blocks of one tube follow the light -- and the march gives XCD x the x-th eighth of that order, one
 // contiguous bundle of tubes, walked tube by tube.  The order only decides which wavefront marches which block.
-// One workgroup, a counting sort over at most (2 B)^2 tubes in LDS (B = blocks per axis <= kLightOrderMaxB), behind the cull.
+// One small workgroup, a counting sort over at most (2 B)^2 tubes in LDS (B = blocks per axis <= kLightOrderMaxB), behind the cull.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kLightOrderMaxB = 32, kLightOrderThreads = 1024;
+constexpr uint32_t kLightOrderMaxB = 32, kLightOrderThreads = 256;	// (four wavefronts: a 1024-thread workgroup waited 80-160 us for sixteen free wave slots on one CU of a GPU the view marches fill)
 __global__ __launch_bounds__(kLightOrderThreads) void lightOrderKernel(DeviceState st)
 {
 	__shared__ uint32_t sCursor[4u * kLightOrderMaxB * kLightOrderMaxB];
@@ -1128,10 +1128,10 @@ __global__ __launch_bounds__(kLightOrderThreads) void lightOrderKernel(DeviceSta
 	__syncthreads();
 	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) atomicAdd(&sCursor[tubeOf(b)], 1u);
 	__syncthreads();
-	// exclusive prefix over the tubes: every thread owns tubes / 1024 (<= 4) consecutive counts
+	// exclusive prefix over the tubes: every thread owns a run of consecutive counts
 	const uint32_t per = (tubes + kLightOrderThreads - 1u) / kLightOrderThreads;
-	uint32_t mine[4] = { 0u, 0u, 0u, 0u }, sum = 0u;
-	for (uint32_t k = 0; k < per; ++k) { const uint32_t i = threadIdx.x * per + k; mine[k] = i < tubes ? sCursor[i] : 0u; sum += mine[k]; }
+	uint32_t sum = 0u;
+	for (uint32_t k = 0; k < per; ++k) { const uint32_t i = threadIdx.x * per + k; sum += i < tubes ? sCursor[i] : 0u; }
 	uint32_t incl = sum;
 	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -1140,8 +1140,11 @@ __global__ __launch_bounds__(kLightOrderThreads) void lightOrderKernel(DeviceSta
 	__syncthreads();
 	uint32_t base = incl - sum;
 	for (uint32_t w = 0; w < wave; ++w) base += sWave[w];
-	__syncthreads();
-	for (uint32_t k = 0; k < per; ++k) { const uint32_t i = threadIdx.x * per + k; if (i < tubes) sCursor[i] = base; base += mine[k]; }
+	for (uint32_t k = 0; k < per; ++k)
+	{
+		const uint32_t i = threadIdx.x * per + k;
+		if (i < tubes) { const uint32_t c = sCursor[i]; sCursor[i] = base; base += c; }	// (a thread's own run: nobody else reads or writes it)
+	}
 	__syncthreads();
 	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) st.lightOrder[atomicAdd(&sCursor[tubeOf(b)], 1u)] = b;
 }
