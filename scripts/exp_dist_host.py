@@ -1,6 +1,6 @@
 import sys, os, time
 import torch; torch.cuda.init()
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from multivolumes_amd import MultiRayCaster, scene, _lib
 from multivolumes_amd import raycaster as rc
 cfg = dict(scene.CONFIGS["C3"]); V, N, L = cfg["V"], cfg["N"], cfg["L"]
