@@ -6,7 +6,8 @@
 //
 // Numeric contract (DESIGN.md "Numerics"): fp32 arithmetic, fp16/packed formats only in storage;
 // compiled with -ffp-contract=off, a multiply-add is fused only where __builtin_fmaf is written
-// (lerp, ray-point evaluation); HLSL min/max = fminf/fmaxf (NaN-ignoring); normalize = v / sqrt(dot).
+// (the sampler's lerps); HLSL min/max = fminf/fmaxf (NaN-ignoring); normalize = v * (1 / sqrt(dot)); the order of operations and the
+// half-folded constants follow the reference's compiled shaders.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -14,9 +15,12 @@
 
 namespace mv
 {
-constexpr float kMaxDist = 3.4641016151377544f;	// Sh/RayMarch.hlsli:17  2.0 * sqrt(3.0)
-constexpr float kAbsorption = 0.8f;				// Sh/RayMarch.hlsli:11
-constexpr float kZeroThreshold = 0.01f;			// Sh/RayMarch.hlsli:12
+// min16float constants: the reference's compiler folds them to half precision (its shipped Bin/*.cso read through oracle/dxil), so
+// every implementation starts from the half values whatever precision it then computes in
+constexpr float kMaxDist = 3.46484375f;			// Sh/RayMarch.hlsli:17  half(2.0 * sqrt(3.0)) = 0x42EE
+constexpr float kAbsorption = 0.7998046875f;		// Sh/RayMarch.hlsli:11  half(0.8) = 0x3A66
+constexpr float kZeroThreshold = 0.010002136230468750f;	// Sh/RayMarch.hlsli:12  half(0.01) = 0x211F
+constexpr float kInvTwoPi = 0.1591796875f;			// Sh/CSRayMarch.hlsl:155  half(1 / (2 PI)) = 0x3118: `/ (2 PI)` is compiled as a multiplication
 constexpr float kPI = 3.1415926535897f;			// XUSG/Shaders/SHIrradiance.hlsli:5-7
 constexpr float kFltMax = 3.402823466e+38f;		// Sh/Common.hlsli:9
 constexpr float kSqrt3 = 1.7320508075688772f;
@@ -34,12 +38,12 @@ __device__ __forceinline__ vec3 operator-(vec3 a, vec3 b) { return v3(a.x - b.x,
 __device__ __forceinline__ vec3 operator/(vec3 a, vec3 b) { return v3(a.x / b.x, a.y / b.y, a.z / b.z); }
 __device__ __forceinline__ float comp(const vec3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 __device__ __forceinline__ float dot3(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ vec3 normalize3(vec3 v) { const float l = __builtin_sqrtf(dot3(v, v)); return v3(v.x / l, v.y / l, v.z / l); }
+__device__ __forceinline__ vec3 normalize3(vec3 v) { const float r = 1.0f / __builtin_sqrtf(dot3(v, v)); return v3(v.x * r, v.y * r, v.z * r); }	// compiled as v * rsqrt(dot(v, v))
 __device__ __forceinline__ float saturatef(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
 __device__ __forceinline__ float lerpf(float a, float b, float w) { return __builtin_fmaf(w, b - a, a); }
 __device__ __forceinline__ float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-__device__ __forceinline__ vec3 rayAt(vec3 o, vec3 d, float t) { return v3(__builtin_fmaf(d.x, t, o.x), __builtin_fmaf(d.y, t, o.y), __builtin_fmaf(d.z, t, o.z)); }
+__device__ __forceinline__ vec3 rayAt(vec3 o, vec3 d, float t) { return v3(t * d.x + o.x, t * d.y + o.y, t * d.z + o.z); }	// compiled as a multiplication and an addition (the build has -ffp-contract=off)
 __device__ __forceinline__ bool outsideBox(vec3 p) { return __builtin_fabsf(p.x) > 1.0f || __builtin_fabsf(p.y) > 1.0f || __builtin_fabsf(p.z) > 1.0f; }
 
 __device__ __forceinline__ uint32_t f2u_sat(float x)	// D3D ftou
@@ -667,6 +671,15 @@ __device__ __forceinline__ float GetStep(float dDensity, float transm, float den
 	return step;
 }
 
+// The same inside the view march / RayCast loop, as the reference's compiler emitted it: factorTh = 1 - transm = 1 - (1 - scatter.w)
+// was simplified to scatter.w (fast math), and the product is taken in the order ((scatter.w * 1.5) * factorEv) * factorUi.
+__device__ __forceinline__ float GetViewStep(float dDensity, float scatterW, float density, float step)
+{
+	const float factorEv = __builtin_fminf(1.0f / 256.0f / __builtin_fabsf(dDensity), 2.0f);
+	const float factorUi = __builtin_fminf(1.0f - density, 1.0f);
+	return __builtin_fmaxf(scatterW * 1.5f * factorEv * factorUi, 1.0f) * step;
+}
+
 // Sh/CSRayMarch.hlsl:28-53
 __device__ __forceinline__ vec3 GetLocalPos(float px, float py, uint32_t slice, float dims)
 {
@@ -708,7 +721,8 @@ __device__ __forceinline__ bool findExitFragment(const PerObject& po, vec3 eyeLo
 	}
 	if (miss || farAxis < 0 || !(tFar > 0.0f) || !(tNear <= tFar)) return false;
 
-	lpt = rayAt(eyeLocal, d, tFar);
+	// (the rasteriser's interpolated LPt in the reference: this stand-in keeps its fused form, like the oracle's)
+	lpt = v3(__builtin_fmaf(d.x, tFar, eyeLocal.x), __builtin_fmaf(d.y, tFar, eyeLocal.y), __builtin_fmaf(d.z, tFar, eyeLocal.z));
 	lpt = v3(clampf(lpt.x, -1.0f, 1.0f), clampf(lpt.y, -1.0f, 1.0f), clampf(lpt.z, -1.0f, 1.0f));
 	const float snap = comp(d, farAxis) > 0.0f ? 1.0f : -1.0f;
 	if (farAxis == 0) lpt.x = snap; else if (farAxis == 1) lpt.y = snap; else lpt.z = snap;
@@ -760,15 +774,15 @@ __device__ __forceinline__ vec4 marchRay(const VolumeView& vol, const uint4* lig
 
 			const float transm = 1.0f - scatter.w;
 			const float dDensity = alpha - prevDensity;
-			newStep = GetStep(dDensity, transm, alpha, stepScale);
+			newStep = GetViewStep(dDensity, scatter.w, alpha, stepScale);
 			prevDensity = alpha;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
 
-			color.x *= alpha; color.y *= alpha; color.z *= alpha;	// :140-142 not pre-multiplied
-			color.x *= light.x; color.y *= light.y; color.z *= light.z;
-			scatter.x += color.x * kAbsorption * transm;
-			scatter.y += color.y * kAbsorption * transm;
-			scatter.z += color.z * kAbsorption * transm;
-			scatter.w += alpha * kAbsorption * transm;
+			// :140-146 as compiled: a = (transm * ABSORPTION) * alpha, scatter.rgb += (a * color) * light, scatter.a += a
+			const float a = transm * kAbsorption * alpha;
+			scatter.x += a * color.x * light.x;
+			scatter.y += a * color.y * light.y;
+			scatter.z += a * color.z * light.z;
+			scatter.w += a;
 
 			if (transm < kZeroThreshold) break;
 		}
@@ -776,8 +790,7 @@ __device__ __forceinline__ vec4 marchRay(const VolumeView& vol, const uint4* lig
 		t += newStep;
 		if (t > tMax) break;
 	}
-	const float twoPi = 2.0f * kPI;
-	scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;
+	scatter.x *= kInvTwoPi; scatter.y *= kInvTwoPi; scatter.z *= kInvTwoPi;
 	return scatter;
 }
 } // namespace mv

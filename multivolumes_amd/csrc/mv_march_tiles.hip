@@ -113,15 +113,14 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 				vec3 clip;
 				{
 					vec4 hPos;
-					hPos.x = __builtin_fmaf(0.01f, rayDir.x, rayOrigin.x);
-					hPos.y = __builtin_fmaf(0.01f, rayDir.y, rayOrigin.y);
-					hPos.z = __builtin_fmaf(0.01f, rayDir.z, rayOrigin.z);
+					hPos.x = rayOrigin.x + rayDir.x * 0.01f;
+					hPos.y = rayOrigin.y + rayDir.y * 0.01f;
+					hPos.z = rayOrigin.z + rayDir.z * 0.01f;
 					hPos.w = 1.0f;
 					hPos = mul44(hPos, po.wvp);
 					const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
 					const float u = cx * 0.5f + 0.5f;
-					float v = cy * 0.5f + 0.5f;
-					v = 1.0f - v;
+					const float v = 0.5f - cy * 0.5f;	// `1 - (y * 0.5 + 0.5)`, compiled (fast math) as 0.5 - y * 0.5
 					clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
 				}
 				st.cubeDepths[outIndex] = clip.z;	// :105
@@ -236,15 +235,15 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 
 					const float transm = 1.0f - scatter.w;
 					const float dDensity = alpha - prevDensity;
-					newStep = GetStep(dDensity, transm, alpha, stepScale);
+					newStep = GetViewStep(dDensity, scatter.w, alpha, stepScale);
 					prevDensity = alpha;	// (:136 `step = (step + newStep) * 0.5` is dead: overwritten at :150)
 
-					color.x *= alpha; color.y *= alpha; color.z *= alpha;	// :140-142 not pre-multiplied
-					color.x *= light.x; color.y *= light.y; color.z *= light.z;
-					scatter.x += color.x * kAbsorption * transm;
-					scatter.y += color.y * kAbsorption * transm;
-					scatter.z += color.z * kAbsorption * transm;
-					scatter.w += alpha * kAbsorption * transm;
+					// :140-146 as compiled: a = (transm * ABSORPTION) * alpha, scatter.rgb += (a * color) * light, scatter.a += a
+					const float a = transm * kAbsorption * alpha;
+					scatter.x += a * color.x * light.x;
+					scatter.y += a * color.y * light.y;
+					scatter.z += a * color.z * light.z;
+					scatter.w += a;
 
 					if (transm < kZeroThreshold) break;	// :146
 				}
@@ -253,8 +252,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 				if (t > tMax) break;	// :152
 			}
 
-			const float twoPi = 2.0f * kPI;
-			scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;	// :155
+			scatter.x *= kInvTwoPi; scatter.y *= kInvTwoPi; scatter.z *= kInvTwoPi;	// :155
 
 			if (!screenTile)
 			{

@@ -1,0 +1,480 @@
+/* TEST INFRASTRUCTURE: the "device" under the reference's compiled shaders when they run on the CPU (oracle/_ref/libmv_dxref.so, see
+ * cso2ll.py).  The translated DXIL calls rt_* for every dx.op intrinsic; this file answers them:
+ *   - thread / group ids, resource handles, raw / structured / typed / constant buffer loads and stores: plain memory semantics;
+ *   - dx.op.unary / binary / tertiary / dot: IEEE fp32, one operation = one rounding (FMad: see dxref_set_fused_mad);
+ *   - wave intrinsics: the lanes of a wavefront run as threads that meet at every wave operation (dxref_dispatch);
+ *   - texture sampling, typed texture loads / stores and their format conversion: THE ORACLE'S sampler / format contract
+ *     (mvo_sample_*, mvo_f32_to_f16, mvo_pack_r11g11b10f from oracle/mv_oracle.cpp).  This is hardware behaviour that the bytecode
+ *     does not contain; comparing the oracle with this library therefore pins the oracle's SHADER LOGIC to the reference's compiled
+ *     code, not its sampler model.
+ * Only tests/ (and scripts that make fixtures) may use this library. */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../mv_oracle.h"
+
+enum { DXR_RAW = 1, DXR_TYPED_BUF = 2, DXR_CBUF = 3, DXR_TEX2D = 4, DXR_TEX3D = 5, DXR_TEX2DARRAY = 6, DXR_SAMPLER = 7 };
+enum { DXF_NONE = 0, DXF_RGBA16F = 1, DXF_R11G11B10F = 2, DXF_R32F = 3, DXF_D16 = 4, DXF_RGBA16U = 5, DXF_R32U = 6, DXF_RGBA32F = 7 };
+
+typedef struct dxr_res
+{
+	int kind, fmt;
+	void* data;
+	uint32_t w, h, d, stride;	/* stride: bytes per element of a structured buffer */
+	uint32_t counter;			/* UAV counter (IncrementCounter) */
+	int cmp_sampler;
+} dxr_res;
+
+#define DXR_MAX_BINDINGS 4096
+typedef struct { uint32_t cls, range, index; dxr_res res; } dxr_binding;
+static dxr_binding g_bind[DXR_MAX_BINDINGS];
+static uint32_t g_nbind;
+static int g_fused_mad = 0;
+static dxr_res g_null_res;
+
+/* per-lane context */
+typedef struct
+{
+	uint32_t tid[3], gid[3], tig[3], flat, lane;
+	struct dxr_wave* wave;
+} dxr_ctx;
+static __thread dxr_ctx* t_ctx;
+
+/* ---------------- wavefront rendezvous ---------------- */
+typedef struct dxr_wave
+{
+	pthread_mutex_t mu;
+	pthread_cond_t cv;
+	uint32_t size, running, arrived, generation;
+	uint32_t val_u[64];
+	float val_f[64];
+	uint8_t present[64];
+	uint32_t out_u[64];
+	float out_f[64];
+	uint32_t ballot[4];
+	void (*fn)(struct dxr_wave*, void*);
+	uint8_t arg[16];
+} dxr_wave;
+
+typedef void (*wave_fn)(dxr_wave* w, void* arg);
+/* every running lane of the wave calls this with its value; when the last running lane has arrived `fn` runs over the gathered values */
+static void wave_complete(dxr_wave* w)
+{
+	w->fn(w, w->arg);
+	memset(w->present, 0, sizeof(w->present));
+	w->arrived = 0;
+	++w->generation;
+	pthread_cond_broadcast(&w->cv);
+}
+static void wave_meet(uint32_t vu, float vf, wave_fn fn, const void* arg, size_t arg_size)
+{
+	dxr_wave* w = t_ctx->wave;
+	const uint32_t lane = t_ctx->lane;
+	pthread_mutex_lock(&w->mu);
+	w->val_u[lane] = vu; w->val_f[lane] = vf; w->present[lane] = 1;
+	w->fn = fn;
+	if (arg_size) memcpy(w->arg, arg, arg_size);
+	const uint32_t gen = w->generation;
+	if (++w->arrived == w->running) wave_complete(w);
+	else while (w->generation == gen) pthread_cond_wait(&w->cv, &w->mu);
+	pthread_mutex_unlock(&w->mu);
+}
+static void wave_lane_exit(dxr_wave* w)
+{
+	/* a lane that returns from the shader no longer takes part: lanes waiting at a wave operation only wait for the running ones */
+	pthread_mutex_lock(&w->mu);
+	--w->running;
+	if (w->running && w->arrived == w->running) wave_complete(w);
+	pthread_mutex_unlock(&w->mu);
+}
+
+/* ---------------- binding ---------------- */
+void dxref_reset(void) { g_nbind = 0; }
+void dxref_set_fused_mad(int on) { g_fused_mad = on; }
+int dxref_bind(uint32_t cls, uint32_t range, uint32_t index, int kind, int fmt, void* data, uint32_t w, uint32_t h, uint32_t d, uint32_t stride)
+{
+	if (g_nbind == DXR_MAX_BINDINGS) return -1;
+	dxr_binding* b = &g_bind[g_nbind++];
+	b->cls = cls; b->range = range; b->index = index;
+	memset(&b->res, 0, sizeof(b->res));
+	b->res.kind = kind; b->res.fmt = fmt; b->res.data = data; b->res.w = w; b->res.h = h; b->res.d = d; b->res.stride = stride;
+	return 0;
+}
+uint32_t dxref_counter(uint32_t cls, uint32_t range, uint32_t index)
+{
+	for (uint32_t i = 0; i < g_nbind; ++i) if (g_bind[i].cls == cls && g_bind[i].range == range && g_bind[i].index == index) return g_bind[i].res.counter;
+	return 0;
+}
+
+void* rt_createHandle(int32_t op, int32_t cls, int32_t range, int32_t index, int32_t nonuniform)
+{
+	(void)op; (void)nonuniform;
+	for (uint32_t i = 0; i < g_nbind; ++i)
+		if (g_bind[i].cls == (uint32_t)cls && g_bind[i].range == (uint32_t)range && g_bind[i].index == (uint32_t)index) return &g_bind[i].res;
+	return &g_null_res;	/* an unbound descriptor: loads give 0, stores are dropped (D3D's null descriptor) */
+}
+
+/* ---------------- ids ---------------- */
+int32_t rt_threadId_i32(int32_t op, int32_t c) { (void)op; return (int32_t)t_ctx->tid[c]; }
+int32_t rt_groupId_i32(int32_t op, int32_t c) { (void)op; return (int32_t)t_ctx->gid[c]; }
+int32_t rt_threadIdInGroup_i32(int32_t op, int32_t c) { (void)op; return (int32_t)t_ctx->tig[c]; }
+int32_t rt_flattenedThreadIdInGroup_i32(int32_t op) { (void)op; return (int32_t)t_ctx->flat; }
+
+/* ---------------- buffers ---------------- */
+typedef struct { int32_t v[4]; int32_t status; } ret_i32;
+typedef struct { float v[4]; int32_t status; } ret_f32;
+typedef struct { float v[4]; } cbuf_f32;
+typedef struct { int32_t v[4]; } cbuf_i32;
+typedef struct { int32_t v[4]; } dims_t;
+
+static const uint8_t* elem_ptr(const dxr_res* r, int32_t index, int32_t offset)
+{
+	if (!r->data) return NULL;
+	if (!r->stride) return (const uint8_t*)r->data + (size_t)(uint32_t)index;	/* ByteAddressBuffer: the index is the byte address */
+	return (const uint8_t*)r->data + (size_t)(uint32_t)index * r->stride + (size_t)(uint32_t)offset;
+}
+void rt_rawBufferLoad_i32(ret_i32* out, int32_t op, dxr_res* r, int32_t index, int32_t offset, int32_t mask, int32_t align)
+{
+	(void)op; (void)align;
+	memset(out, 0, sizeof(*out));
+	const uint8_t* p = elem_ptr(r, index, offset);
+	if (!p) return;
+	for (int c = 0, k = 0; c < 4; ++c) if (mask & (1 << c)) { memcpy(&out->v[c], p + 4 * k, 4); ++k; }
+}
+void rt_rawBufferLoad_f32(ret_f32* out, int32_t op, dxr_res* r, int32_t index, int32_t offset, int32_t mask, int32_t align)
+{
+	rt_rawBufferLoad_i32((ret_i32*)out, op, r, index, offset, mask, align);
+}
+void rt_rawBufferStore_i32(int32_t op, dxr_res* r, int32_t index, int32_t offset, int32_t v0, int32_t v1, int32_t v2, int32_t v3, int32_t mask, int32_t align)
+{
+	(void)op; (void)align;
+	uint8_t* p = (uint8_t*)elem_ptr(r, index, offset);
+	if (!p) return;
+	const int32_t v[4] = { v0, v1, v2, v3 };
+	for (int c = 0, k = 0; c < 4; ++c) if (mask & (1 << c)) { memcpy(p + 4 * k, &v[c], 4); ++k; }
+}
+void rt_bufferLoad_i32(ret_i32* out, int32_t op, dxr_res* r, int32_t index, int32_t woffset)
+{
+	(void)op; (void)woffset;
+	memset(out, 0, sizeof(*out));
+	if (!r->data) return;
+	if (r->fmt == DXF_RGBA16U) { const uint16_t* p = (const uint16_t*)r->data + 4 * (size_t)(uint32_t)index; for (int c = 0; c < 4; ++c) out->v[c] = p[c]; }
+	else if (r->fmt == DXF_R32U) out->v[0] = (int32_t)((const uint32_t*)r->data)[(uint32_t)index];
+	else { fprintf(stderr, "dxil_rt: bufferLoad on format %d\n", r->fmt); abort(); }
+}
+void rt_bufferStore_i32(int32_t op, dxr_res* r, int32_t index, int32_t woffset, int32_t v0, int32_t v1, int32_t v2, int32_t v3, int32_t mask)
+{
+	(void)op; (void)woffset; (void)mask;
+	if (!r->data) return;
+	if (r->fmt == DXF_RGBA16U) { uint16_t* p = (uint16_t*)r->data + 4 * (size_t)(uint32_t)index; p[0] = (uint16_t)v0; p[1] = (uint16_t)v1; p[2] = (uint16_t)v2; p[3] = (uint16_t)v3; }
+	else if (r->fmt == DXF_R32U) ((uint32_t*)r->data)[(uint32_t)index] = (uint32_t)v0;
+	else { fprintf(stderr, "dxil_rt: bufferStore on format %d\n", r->fmt); abort(); }
+}
+int32_t rt_bufferUpdateCounter(int32_t op, dxr_res* r, int32_t inc)
+{
+	(void)op;
+	/* IncrementCounter returns the value before, DecrementCounter the value after */
+	if ((int8_t)inc > 0) return (int32_t)__atomic_fetch_add(&r->counter, 1u, __ATOMIC_RELAXED);
+	return (int32_t)__atomic_sub_fetch(&r->counter, 1u, __ATOMIC_RELAXED);
+}
+void rt_cbufferLoadLegacy_f32(cbuf_f32* out, int32_t op, dxr_res* r, int32_t reg)
+{
+	(void)op;
+	memset(out, 0, sizeof(*out));
+	if (!r->data) return;
+	const size_t off = (size_t)(uint32_t)reg * 16u, size = r->w;
+	for (int c = 0; c < 4; ++c) if (off + 4u * c + 4u <= size) memcpy(&out->v[c], (const uint8_t*)r->data + off + 4u * c, 4);
+}
+void rt_cbufferLoadLegacy_i32(cbuf_i32* out, int32_t op, dxr_res* r, int32_t reg) { rt_cbufferLoadLegacy_f32((cbuf_f32*)out, op, r, reg); }
+void rt_getDimensions(dims_t* out, int32_t op, dxr_res* r, int32_t mip)
+{
+	(void)op; (void)mip;
+	out->v[0] = (int32_t)r->w; out->v[1] = (int32_t)r->h; out->v[2] = (int32_t)r->d; out->v[3] = 1;
+	if (r->kind == DXR_RAW) { out->v[0] = (int32_t)r->w; out->v[1] = (int32_t)r->stride; }	/* element count, stride */
+}
+
+/* ---------------- textures: the oracle's sampler / format contract ---------------- */
+void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, float c0, float c1, float c2, float c3, int32_t o0, int32_t o1, int32_t o2, float lod)
+{
+	(void)op; (void)smp; (void)c3; (void)lod;
+	memset(out, 0, sizeof(*out));
+	if (!t->data) return;
+	if (t->kind == DXR_TEX3D && t->fmt == DXF_RGBA16F)
+	{
+		const float uvw[3] = { c0, c1, c2 };
+		const int32_t off[3] = { o0, o1, o2 };
+		mvo_sample_rgba16f((const uint16_t*)t->data, t->w, uvw, off, out->v);
+	}
+	else if (t->kind == DXR_TEX3D && t->fmt == DXF_R11G11B10F)
+	{
+		const float uvw[3] = { c0, c1, c2 };
+		mvo_sample_r11g11b10f((const uint32_t*)t->data, t->w, uvw, out->v);
+		out->v[3] = 1.0f;
+	}
+	else if (t->kind == DXR_TEX3D && t->fmt == DXF_R32F)
+	{
+		/* CSR32FToRGBA16F's source: a linear sampler on an R32F volume -- the oracle's converter exposes the whole pass only */
+		fprintf(stderr, "dxil_rt: sampleLevel on an R32F volume is not wired (use mvo_r32f_to_rgba16f's KAT instead)\n"); abort();
+	}
+	else if (t->kind == DXR_TEX2D && t->fmt == DXF_R32F)
+	{
+		const float v = mvo_sample_point_r32f((const float*)t->data, t->w, t->h, c0, c1);
+		out->v[0] = out->v[1] = out->v[2] = out->v[3] = v;	/* R32F: (r, 0, 0, 1); the shaders read .x only */
+		out->v[1] = out->v[2] = 0.0f; out->v[3] = 1.0f;
+	}
+	else { fprintf(stderr, "dxil_rt: sampleLevel on kind %d format %d\n", t->kind, t->fmt); abort(); }
+}
+float rt_sampleCmpLevelZero_f32_scalar(dxr_res* t, float u, float v, float ref)
+{
+	if (!t->data) return 0.0f;
+	if (t->kind == DXR_TEX2D && t->fmt == DXF_D16) return mvo_sample_cmp_d16((const uint16_t*)t->data, t->w, u, v, ref);
+	fprintf(stderr, "dxil_rt: sampleCmpLevelZero on kind %d format %d\n", t->kind, t->fmt); abort();
+}
+void rt_sampleCmpLevelZero_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, float c0, float c1, float c2, float c3, int32_t o0, int32_t o1, int32_t o2, float ref)
+{
+	(void)op; (void)smp; (void)c2; (void)c3; (void)o0; (void)o1; (void)o2;
+	memset(out, 0, sizeof(*out));
+	out->v[0] = out->v[1] = out->v[2] = out->v[3] = rt_sampleCmpLevelZero_f32_scalar(t, c0, c1, ref);
+}
+void rt_textureStore_f32(int32_t op, dxr_res* t, int32_t x, int32_t y, int32_t z, float v0, float v1, float v2, float v3, int32_t mask)
+{
+	(void)op; (void)mask;
+	if (!t->data) return;
+	const uint32_t ux = (uint32_t)x, uy = (uint32_t)y, uz = (uint32_t)z;
+	const uint32_t depth = t->kind == DXR_TEX2D ? 1u : t->d;
+	if (ux >= t->w || uy >= t->h || (t->kind != DXR_TEX2D && uz >= depth)) return;	/* out-of-bounds UAV writes are dropped */
+	const size_t i = ((size_t)(t->kind == DXR_TEX2D ? 0u : uz) * t->h + uy) * t->w + ux;
+	switch (t->fmt)
+	{
+	case DXF_RGBA16F: { uint16_t* p = (uint16_t*)t->data + 4 * i; p[0] = mvo_f32_to_f16(v0); p[1] = mvo_f32_to_f16(v1); p[2] = mvo_f32_to_f16(v2); p[3] = mvo_f32_to_f16(v3); break; }
+	case DXF_R11G11B10F: ((uint32_t*)t->data)[i] = mvo_pack_r11g11b10f(v0, v1, v2); break;
+	case DXF_R32F: ((float*)t->data)[i] = v0; break;
+	default: fprintf(stderr, "dxil_rt: textureStore on format %d\n", t->fmt); abort();
+	}
+}
+
+/* ---------------- arithmetic ---------------- */
+float rt_unary_f32(int32_t op, float x)
+{
+	switch (op)
+	{
+	case 6: return fabsf(x);
+	case 7: return x != x ? 0.0f : (x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x));	/* Saturate */
+	case 12: return cosf(x);
+	case 13: return sinf(x);
+	case 21: return exp2f(x);
+	case 22: return x - floorf(x);	/* Frc */
+	case 23: return log2f(x);
+	case 24: return sqrtf(x);
+	case 25: return 1.0f / sqrtf(x);	/* Rsqrt: two correctly rounded operations */
+	case 26: return nearbyintf(x);
+	case 27: return floorf(x);
+	case 28: return ceilf(x);
+	case 29: return truncf(x);
+	default: fprintf(stderr, "dxil_rt: unary.f32 opcode %d\n", op); abort();
+	}
+}
+float rt_binary_f32(int32_t op, float a, float b)
+{
+	switch (op)
+	{
+	case 35: return fmaxf(a, b);	/* FMax: the operand that is not a NaN */
+	case 36: return fminf(a, b);
+	default: fprintf(stderr, "dxil_rt: binary.f32 opcode %d\n", op); abort();
+	}
+}
+int32_t rt_binary_i32(int32_t op, int32_t a, int32_t b)
+{
+	switch (op)
+	{
+	case 37: return a > b ? a : b;
+	case 38: return a < b ? a : b;
+	case 39: return (uint32_t)a > (uint32_t)b ? a : b;
+	case 40: return (uint32_t)a < (uint32_t)b ? a : b;
+	default: fprintf(stderr, "dxil_rt: binary.i32 opcode %d\n", op); abort();
+	}
+}
+int32_t rt_unaryBits_i32(int32_t op, int32_t a)
+{
+	switch (op)
+	{
+	case 30: { uint32_t v = (uint32_t)a, r = 0; for (int i = 0; i < 32; ++i) { r = (r << 1) | (v & 1u); v >>= 1; } return (int32_t)r; }	/* Bfrev */
+	case 31: return __builtin_popcount((uint32_t)a);	/* Countbits */
+	case 32: return a ? __builtin_ctz((uint32_t)a) : -1;	/* FirstbitLo */
+	case 33: return a ? 31 - __builtin_clz((uint32_t)a) : -1;	/* FirstbitHi (position from the LSB, as HLSL's firstbithigh returns) */
+	default: fprintf(stderr, "dxil_rt: unaryBits.i32 opcode %d\n", op); abort();
+	}
+}
+float rt_tertiary_f32(int32_t op, float a, float b, float c)
+{
+	switch (op)
+	{
+	case 46: return g_fused_mad ? fmaf(a, b, c) : a * b + c;	/* FMad: fused or not is the implementation's choice in D3D */
+	case 47: return fmaf(a, b, c);
+	default: fprintf(stderr, "dxil_rt: tertiary.f32 opcode %d\n", op); abort();
+	}
+}
+int32_t rt_tertiary_i32(int32_t op, int32_t a, int32_t b, int32_t c)
+{
+	switch (op)
+	{
+	case 48: case 49: return (int32_t)((uint32_t)a * (uint32_t)b + (uint32_t)c);
+	default: fprintf(stderr, "dxil_rt: tertiary.i32 opcode %d\n", op); abort();
+	}
+}
+float rt_dot2_f32(int32_t op, float ax, float ay, float bx, float by) { (void)op; return rt_tertiary_f32(46, ay, by, ax * bx); }
+float rt_dot3_f32(int32_t op, float ax, float ay, float az, float bx, float by, float bz) { (void)op; return rt_tertiary_f32(46, az, bz, rt_tertiary_f32(46, ay, by, ax * bx)); }
+float rt_dot4_f32(int32_t op, float ax, float ay, float az, float aw, float bx, float by, float bz, float bw)
+{
+	(void)op;
+	return rt_tertiary_f32(46, aw, bw, rt_tertiary_f32(46, az, bz, rt_tertiary_f32(46, ay, by, ax * bx)));
+}
+
+/* mode "fp16": the same operations on IEEE half operands (computed in fp32 and rounded once: exact for min / max / abs / saturate) */
+_Float16 rt_unary_f16(int32_t op, _Float16 x) { return (_Float16)rt_unary_f32(op, (float)x); }
+_Float16 rt_binary_f16(int32_t op, _Float16 a, _Float16 b) { return (_Float16)rt_binary_f32(op, (float)a, (float)b); }
+_Float16 rt_tertiary_f16(int32_t op, _Float16 a, _Float16 b, _Float16 c) { return (_Float16)rt_tertiary_f32(op, (float)a, (float)b, (float)c); }
+
+/* ---------------- wave intrinsics ---------------- */
+int32_t rt_waveGetLaneIndex(int32_t op) { (void)op; return (int32_t)t_ctx->lane; }
+int32_t rt_waveGetLaneCount(int32_t op) { (void)op; return t_ctx->wave ? (int32_t)t_ctx->wave->size : 1; }
+
+/* ReadLaneAt: every lane publishes (value, wanted lane); after the meeting it picks the wanted lane's value */
+static void fn_noop(dxr_wave* w, void* arg) { (void)arg; memcpy(w->out_u, w->val_u, sizeof(w->out_u)); memcpy(w->out_f, w->val_f, sizeof(w->out_f)); }
+int32_t rt_waveReadLaneAt_i32(int32_t op, int32_t v, int32_t lane)
+{
+	(void)op;
+	if (!t_ctx->wave) return v;
+	wave_meet((uint32_t)v, 0.0f, fn_noop, NULL, 0);
+	/* out_u is stable until the next meeting completes, which needs this lane */
+	return (uint32_t)lane < t_ctx->wave->size ? (int32_t)t_ctx->wave->out_u[(uint32_t)lane] : 0;
+}
+float rt_waveReadLaneAt_f32(int32_t op, float v, int32_t lane)
+{
+	(void)op;
+	if (!t_ctx->wave) return v;
+	wave_meet(0u, v, fn_noop, NULL, 0);
+	return (uint32_t)lane < t_ctx->wave->size ? t_ctx->wave->out_f[(uint32_t)lane] : 0.0f;
+}
+static void fn_first(dxr_wave* w, void* arg)
+{
+	(void)arg;
+	uint32_t first = 0;
+	while (first < w->size && !w->present[first]) ++first;
+	for (uint32_t l = 0; l < w->size; ++l) { w->out_u[l] = w->val_u[first < w->size ? first : 0]; w->out_f[l] = w->val_f[first < w->size ? first : 0]; }
+}
+int32_t rt_waveReadLaneFirst_i32(int32_t op, int32_t v)
+{
+	(void)op;
+	if (!t_ctx->wave) return v;
+	wave_meet((uint32_t)v, 0.0f, fn_first, NULL, 0);
+	return (int32_t)t_ctx->wave->out_u[t_ctx->lane];
+}
+typedef struct { int32_t v[4]; } ballot_t;
+static void fn_ballot(dxr_wave* w, void* arg)
+{
+	(void)arg;
+	memset(w->ballot, 0, sizeof(w->ballot));
+	for (uint32_t l = 0; l < w->size; ++l) if (w->present[l] && w->val_u[l]) w->ballot[l >> 5] |= 1u << (l & 31);
+}
+void rt_waveActiveBallot(ballot_t* out, int32_t op, int32_t cond)
+{
+	(void)op;
+	memset(out, 0, sizeof(*out));
+	if (!t_ctx->wave) { out->v[0] = cond ? 1 : 0; return; }
+	wave_meet(cond ? 1u : 0u, 0.0f, fn_ballot, NULL, 0);
+	for (int i = 0; i < 4; ++i) out->v[i] = (int32_t)t_ctx->wave->ballot[i];
+}
+typedef struct { int op, sign; } active_op;
+static void fn_active_f(dxr_wave* w, void* arg)
+{
+	const active_op* a = (const active_op*)arg;
+	float acc = 0.0f;
+	int have = 0;
+	for (uint32_t l = 0; l < w->size; ++l)
+	{
+		if (!w->present[l]) continue;
+		const float v = w->val_f[l];
+		if (!have) { acc = v; have = 1; continue; }
+		switch (a->op) { case 0: acc += v; break; case 1: acc *= v; break; case 2: acc = fminf(acc, v); break; case 3: acc = fmaxf(acc, v); break; default: abort(); }
+	}
+	for (uint32_t l = 0; l < w->size; ++l) w->out_f[l] = acc;
+}
+float rt_waveActiveOp_f32(int32_t opc, float v, int32_t op, int32_t sign)
+{
+	(void)opc;
+	if (!t_ctx->wave) return v;
+	active_op a = { op, sign };
+	wave_meet(0u, v, fn_active_f, &a, sizeof(a));
+	return t_ctx->wave->out_f[t_ctx->lane];
+}
+
+/* ---------------- dispatch ---------------- */
+typedef void (*shader_fn)(void);
+typedef struct { shader_fn fn; dxr_ctx ctx; } lane_arg;
+static void* lane_main(void* p)
+{
+	lane_arg* a = (lane_arg*)p;
+	t_ctx = &a->ctx;
+	a->fn();
+	if (a->ctx.wave) wave_lane_exit(a->ctx.wave);
+	return NULL;
+}
+
+/* Runs fn for every thread of a gx x gy x gz dispatch of (tx, ty, tz)-thread groups.  wave_size = 0: lanes one after the other on
+ * the calling thread (shaders whose wave intrinsics only broadcast group-uniform values: ReadLaneAt / ReadLaneFirst return the
+ * caller's value).  wave_size > 0: the group is cut into waves of that many lanes, each lane a thread, meeting at wave intrinsics. */
+int dxref_dispatch(shader_fn fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tx, uint32_t ty, uint32_t tz, uint32_t wave_size)
+{
+	const uint32_t per_group = tx * ty * tz;
+	if (wave_size > 64) return -1;
+	for (uint32_t z = 0; z < gz; ++z)
+		for (uint32_t y = 0; y < gy; ++y)
+			for (uint32_t x = 0; x < gx; ++x)
+			{
+				if (!wave_size)
+				{
+					dxr_ctx c;
+					memset(&c, 0, sizeof(c));
+					t_ctx = &c;
+					for (uint32_t f = 0; f < per_group; ++f)
+					{
+						c.flat = f; c.lane = 0; c.wave = NULL;
+						c.tig[0] = f % tx; c.tig[1] = (f / tx) % ty; c.tig[2] = f / (tx * ty);
+						c.gid[0] = x; c.gid[1] = y; c.gid[2] = z;
+						c.tid[0] = x * tx + c.tig[0]; c.tid[1] = y * ty + c.tig[1]; c.tid[2] = z * tz + c.tig[2];
+						fn();
+					}
+					continue;
+				}
+				for (uint32_t base = 0; base < per_group; base += wave_size)
+				{
+					const uint32_t n = per_group - base < wave_size ? per_group - base : wave_size;
+					dxr_wave w;
+					memset(&w, 0, sizeof(w));
+					pthread_mutex_init(&w.mu, NULL); pthread_cond_init(&w.cv, NULL);
+					w.size = wave_size; w.running = n;
+					lane_arg args[64];
+					pthread_t th[64];
+					for (uint32_t l = 0; l < n; ++l)
+					{
+						const uint32_t f = base + l;
+						memset(&args[l], 0, sizeof(args[l]));
+						args[l].fn = fn;
+						dxr_ctx* c = &args[l].ctx;
+						c->flat = f; c->lane = l; c->wave = &w;
+						c->tig[0] = f % tx; c->tig[1] = (f / tx) % ty; c->tig[2] = f / (tx * ty);
+						c->gid[0] = x; c->gid[1] = y; c->gid[2] = z;
+						c->tid[0] = x * tx + c->tig[0]; c->tid[1] = y * ty + c->tig[1]; c->tid[2] = z * tz + c->tig[2];
+						if (pthread_create(&th[l], NULL, lane_main, &args[l]) != 0) return -2;
+					}
+					for (uint32_t l = 0; l < n; ++l) pthread_join(th[l], NULL);
+					pthread_mutex_destroy(&w.mu); pthread_cond_destroy(&w.cv);
+				}
+			}
+	return 0;
+}

@@ -1,0 +1,171 @@
+"""TEST INFRASTRUCTURE: runs the reference's SHIPPED compiled shaders (DXIL from /root/reference/Bin/*.cso, translated to x86-64 by
+oracle/dxil/cso2ll.py into oracle/_ref/libmv_dxref.so) on the same inputs as the oracle's functions, with the same signatures, so
+that tests can compare the oracle's restatement with the reference's own compiled code.
+
+What is the reference's: control flow, arithmetic, constants, order of operations, early-outs of every shader.
+What is NOT (oracle/dxil/dxil_rt.c): the sampler and the format conversion of typed loads / stores -- the oracle's contract, shared.
+Register ranges below are the shaders' own (dx.resources metadata of each .cso, printed by `python oracle/dxil/cso2ll.py`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import mv_oracle as O
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_DIR, "_ref", "libmv_dxref.so")
+_lib = None
+
+SRV, UAV, CBV, SAMPLER = 0, 1, 2, 3
+RAW, TYPED_BUF, CBUF, TEX2D, TEX3D, TEX2DARRAY, SAMPLER_KIND = 1, 2, 3, 4, 5, 6, 7
+F_NONE, F_RGBA16F, F_R11G11B10F, F_R32F, F_D16, F_RGBA16U, F_R32U = 0, 1, 2, 3, 4, 5, 6
+
+
+def available():
+    return os.path.exists(_PATH)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        O.load()  # libmv_oracle.so first (the runtime links against it)
+        lib = C.CDLL(_PATH, mode=C.RTLD_GLOBAL)
+        lib.dxref_bind.restype = C.c_int
+        lib.dxref_bind.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        lib.dxref_dispatch.restype = C.c_int
+        lib.dxref_dispatch.argtypes = [C.c_void_p] + [C.c_uint32] * 7
+        lib.dxref_counter.restype = C.c_uint32
+        lib.dxref_counter.argtypes = [C.c_uint32] * 3
+        _lib = lib
+    return _lib
+
+
+def _bind(cls, rng, index, kind, fmt, arr, w=0, h=0, d=0, stride=0):
+    ptr = arr.ctypes.data if arr is not None else None
+    assert load().dxref_bind(cls, rng, index, kind, fmt, ptr, w, h, d, stride) == 0
+
+
+def _entry(shader, mode):
+    return C.cast(getattr(load(), f"dxil_{shader}_{mode}"), C.c_void_p)
+
+
+def _dispatch(shader, mode, groups, threads, wave=0):
+    rc = load().dxref_dispatch(_entry(shader, mode), groups[0], groups[1], groups[2], threads[0], threads[1], threads[2], wave)
+    assert rc == 0, rc
+
+
+def _bind_cube_targets(N, V, cm, cd):
+    """RWTexture2DArray g_rwCubeMaps[] / g_rwCubeDepths[] (u0.., space 0 / 1): descriptor 5 v + mip, six slices of (N >> mip)^2."""
+    for v in range(V):
+        for mip in range(O.MVO_NUM_CUBE_MIP if hasattr(O, "MVO_NUM_CUBE_MIP") else 5):
+            dim = N >> mip
+            if dim == 0:
+                continue
+            off = O.cube_mip_offset(N, mip)
+            _bind(UAV, 0, 5 * v + mip, TEX2DARRAY, F_RGBA16F, cm[v][off:], dim, dim, 6)
+            _bind(UAV, 1, 5 * v + mip, TEX2DARRAY, F_R32F, cd[v][off:], dim, dim, 6)
+
+
+def march_view(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame, volumeInfo, cubeMapVolumes,
+               cubeMaps=None, cubeDepths=None, mode="fp32", fused_mad=False):
+    """CSRayMarchV.cso over the cube-map volume list: same arguments and outputs as mv_oracle.march_view (no counters).
+    Dispatch = (N / 8, N / 8, number of cube-map volumes) groups of 8 x 8 x 6 threads (MultiRayCaster.cpp:1329-1368)."""
+    lib = load()
+    lib.dxref_reset()
+    lib.dxref_set_fused_mad(1 if fused_mad else 0)
+    chain = O.cube_chain_texels(N)
+    vols = [np.ascontiguousarray(v).view(np.uint16) for v in volumes]
+    cm = np.zeros((V, chain, 4), np.uint16) if cubeMaps is None else np.ascontiguousarray(cubeMaps, np.uint16).copy()
+    cd = np.zeros((V, chain), np.float32) if cubeDepths is None else np.ascontiguousarray(cubeDepths, np.float32).copy()
+    lm = np.ascontiguousarray(lightMaps, np.uint32)
+    dm = np.ascontiguousarray(depthMap, np.float32)
+    po = np.ascontiguousarray(perObject).view(np.uint8).copy()
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8).copy()
+    vi = np.ascontiguousarray(volumeInfo, np.uint16)
+    cl = np.ascontiguousarray(cubeMapVolumes, np.uint32)
+    # SRVs (CSRayMarchV.cso dx.resources): range 0 = Texture3D light maps t3.. space0 (index 3 + volume), range 1 = Texture3D grids
+    # space1 (index = VolTexId), range 2 = depth Texture2D, range 3 = PerObject structured (224 B), range 4 = volume list (uint),
+    # range 5 = VolumeInfo typed buffer (R16G16B16A16_UINT)
+    for v in range(V):
+        _bind(SRV, 0, 3 + v, TEX3D, F_R11G11B10F, lm[v], L, L, L)
+    for i, g in enumerate(vols):
+        _bind(SRV, 1, i, TEX3D, F_RGBA16F, g, N, N, N)
+    _bind(SRV, 2, 0, TEX2D, F_R32F, dm, W, H, 1)
+    _bind(SRV, 3, 0, RAW, F_NONE, po, V, 0, 0, 224)
+    _bind(SRV, 4, 1, RAW, F_NONE, cl, len(cl), 0, 0, 4)
+    _bind(SRV, 5, 2, TYPED_BUF, F_RGBA16U, vi, V)
+    _bind_cube_targets(N, V, cm, cd)
+    _bind(CBV, 0, 0, CBUF, F_NONE, cb, len(cb))
+    _bind(SAMPLER, 0, 0, SAMPLER_KIND, F_NONE, None)
+    _bind(SAMPLER, 1, 1, SAMPLER_KIND, F_NONE, None)
+    g = (N + 7) // 8
+    if len(cl):
+        _dispatch("CSRayMarchV", mode, (g, g, len(cl)), (8, 8, 6))
+    return cm, cd
+
+
+def march_light(V, N, L, M, volumes, descs, perObject, cbPerFrame, shadowMap, sh27, visible, maxLightSamples, lightMaps=None,
+                mode="fp32", fused_mad=False):
+    """CSRayMarchL.cso (the shipped one has _HAS_SHADOW_MAP_ and _HAS_LIGHT_PROBE_ compiled in; the probe is switched by
+    cbSampleRes.g_hasLightProbe): same arguments as mv_oracle.march_light; returns the light maps [V, L, L, L] u32."""
+    lib = load()
+    lib.dxref_reset()
+    lib.dxref_set_fused_mad(1 if fused_mad else 0)
+    vols = [np.ascontiguousarray(v).view(np.uint16) for v in volumes]
+    lm = np.zeros((V, L, L, L), np.uint32) if lightMaps is None else np.ascontiguousarray(lightMaps, np.uint32).copy()
+    po = np.ascontiguousarray(perObject).view(np.uint8).copy()
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8).copy()
+    d = np.ascontiguousarray(descs, np.uint32)
+    sm = np.ascontiguousarray(shadowMap, np.uint16)
+    vis = np.ascontiguousarray(visible, np.uint32)
+    cnt = np.array([len(vis)], np.uint32)
+    if len(vis) == 0:
+        vis = np.zeros(1, np.uint32)
+    sh = np.zeros((9, 3), np.float32) if sh27 is None else np.ascontiguousarray(sh27, np.float32).reshape(9, 3).copy()
+    cb1 = np.array([maxLightSamples, 0 if sh27 is None else 1, 0, 0], np.uint32)
+    # SRVs (CSRayMarchL.cso dx.resources): range 0 = grids (space1), 1 = shadow map (space2 t0), 2 = SH coefficients (space2 t1),
+    # 3 = PerObject, 4 = VolumeDesc, 5 = visible volumes, 6 = visible volume count; UAV range 0 = light maps; CBV 0 / 1
+    for i, g in enumerate(vols):
+        _bind(SRV, 0, i, TEX3D, F_RGBA16F, g, N, N, N)
+    _bind(SRV, 1, 0, TEX2D, F_D16, sm, M, M, 1)
+    _bind(SRV, 2, 1, RAW, F_NONE, sh, 9, 0, 0, 12)
+    _bind(SRV, 3, 0, RAW, F_NONE, po, V, 0, 0, 224)
+    _bind(SRV, 4, 1, RAW, F_NONE, d, V, 0, 0, 4)
+    _bind(SRV, 5, 2, RAW, F_NONE, vis, len(vis), 0, 0, 4)
+    _bind(SRV, 6, 3, RAW, F_NONE, cnt, 1, 0, 0, 4)
+    for v in range(V):
+        _bind(UAV, 0, v, TEX3D, F_R11G11B10F, lm[v], L, L, L)
+    _bind(CBV, 0, 0, CBUF, F_NONE, cb, len(cb))
+    _bind(CBV, 1, 1, CBUF, F_NONE, cb1, 8)
+    _bind(SAMPLER, 0, 0, SAMPLER_KIND, F_NONE, None)
+    _bind(SAMPLER, 1, 1, SAMPLER_KIND, F_NONE, None)
+    g = (L + 3) // 4
+    _dispatch("CSRayMarchL", mode, (g, g, g), (4, 4, 4))
+    return lm
+
+
+def cull(V, perObject, descs, cbPerFrame, maxRaySamples, volumeInfo=None, mode="fp32", fused_mad=False):
+    """CSVolumeCull.cso: groups of 8 x 4 threads = four volumes x eight cube vertices in one 32-lane wave (the shader's wave intrinsics
+    need the lanes to run side by side: dxref_dispatch's wave mode).  Same arguments and results as mv_oracle.cull; the two append
+    buffers come back sorted (on a GPU their order is whatever the atomics' order was)."""
+    lib = load()
+    lib.dxref_reset()
+    lib.dxref_set_fused_mad(1 if fused_mad else 0)
+    info = np.zeros((V, 4), np.uint16) if volumeInfo is None else np.ascontiguousarray(volumeInfo, np.uint16).copy()
+    vis = np.zeros(max(V, 1), np.uint32)
+    cube = np.zeros(max(V, 1), np.uint32)
+    po = np.ascontiguousarray(perObject).view(np.uint8).copy()
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8).copy()
+    d = np.ascontiguousarray(descs, np.uint32)
+    cb1 = np.array([maxRaySamples, 0, 0, 0], np.uint32)
+    _bind(SRV, 0, 0, RAW, F_NONE, po, V, 0, 0, 224)
+    _bind(SRV, 1, 1, RAW, F_NONE, d, V, 0, 0, 4)
+    _bind(UAV, 0, 0, RAW, F_NONE, vis, V, 0, 0, 4)
+    _bind(UAV, 1, 1, TYPED_BUF, F_RGBA16U, info, V)
+    _bind(UAV, 2, 2, RAW, F_NONE, cube, V, 0, 0, 4)
+    _bind(CBV, 0, 0, CBUF, F_NONE, cb, len(cb))
+    _bind(CBV, 1, 1, CBUF, F_NONE, cb1, 8)
+    _dispatch("CSVolumeCull", mode, ((V + 3) // 4, 1, 1), (8, 4, 1), wave=32)
+    nv, nc = int(lib.dxref_counter(UAV, 0, 0)), int(lib.dxref_counter(UAV, 2, 2))
+    return info, np.sort(vis[:nv]), np.sort(cube[:nc])

@@ -35,9 +35,12 @@
 
 namespace
 {
-const float kMaxDist = 3.4641016151377544f;	// RayMarch.hlsli:17   2.0 * sqrt(3.0)
-const float kAbsorption = 0.8f;				// RayMarch.hlsli:11
-const float kZeroThreshold = 0.01f;			// RayMarch.hlsli:12
+// The shaders declare these as min16float: the reference's compiler (the shipped Bin/*.cso, read through oracle/dxil) has folded them
+// to half precision, and every implementation -- whether it then computes at 16 or 32 bits -- starts from the half values.
+const float kMaxDist = 3.46484375f;			// RayMarch.hlsli:17   half(2.0 * sqrt(3.0)) = 0x42EE
+const float kAbsorption = 0.7998046875f;		// RayMarch.hlsli:11   half(0.8) = 0x3A66
+const float kZeroThreshold = 0.010002136230468750f;	// RayMarch.hlsli:12   half(0.01) = 0x211F
+const float kInvTwoPi = 0.1591796875f;			// CSRayMarch.hlsl:155  half(1 / (2 PI)) = 0x3118: the division compiled into a multiplication
 const float kPI = 3.1415926535897f;			// XUSG/Shaders/SHIrradiance.hlsli:5-7
 const float kFltMax = 3.402823466e+38f;		// Common.hlsli:9
 const float kSqrt3 = 1.7320508075688772f;
@@ -54,12 +57,12 @@ inline float3 operator*(float3 a, float s) { return f3(a.x * s, a.y * s, a.z * s
 inline float3 operator/(float3 a, float3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
 inline float idx(const float3& v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 inline float dot3(float3 a, float3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-inline float3 normalize3(float3 v) { const float l = sqrtf(dot3(v, v)); return f3(v.x / l, v.y / l, v.z / l); }
+inline float3 normalize3(float3 v) { const float r = 1.0f / sqrtf(dot3(v, v)); return f3(v.x * r, v.y * r, v.z * r); }	// compiled as v * rsqrt(dot(v, v))
 inline float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }	// NaN -> 0
 inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 inline float lerpf(float a, float b, float w) { return fmaf(w, b - a, a); }
 inline float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
-inline float3 rayAt(float3 o, float3 d, float t) { return f3(fmaf(d.x, t, o.x), fmaf(d.y, t, o.y), fmaf(d.z, t, o.z)); }
+inline float3 rayAt(float3 o, float3 d, float t) { return f3(t * d.x + o.x, t * d.y + o.y, t * d.z + o.z); }	// compiled as a multiplication and an addition
 
 inline uint32_t f2u(float x)	// D3D ftou: NaN/negative -> 0, saturating
 {
@@ -522,16 +525,22 @@ float4 marchLoop(const uint16_t* vol, uint32_t N, const uint32_t* lightMap, uint
 
 			const float transm = 1.0f - scatter.w;
 			const float dDensity = color.w - prevDensity;
-			newStep = GetStep(dDensity, transm, color.w, stepScale);
+			// GetStep (RayMarch.hlsli:182-192) as compiled: factorTh = 1 - transm = 1 - (1 - scatter.w) was simplified to scatter.w
+			// (fast math), and the product is taken in the order ((scatter.w * 1.5) * factorEv) * factorUi
+			{
+				const float factorEv = fminf(1.0f / 256.0f / fabsf(dDensity), 2.0f);
+				const float factorUi = fminf(1.0f - color.w, 1.0f);
+				newStep = fmaxf(scatter.w * 1.5f * factorEv * factorUi, 1.0f) * stepScale;
+			}
 			// step = (step + newStep) * 0.5;	-- CSRayMarch.hlsl:136, dead: overwritten at :150
 			prevDensity = color.w;
 
-			color.x *= color.w; color.y *= color.w; color.z *= color.w;	// not pre-multiplied (:140-142)
-			color.x *= light.x; color.y *= light.y; color.z *= light.z;
-			scatter.x += color.x * kAbsorption * transm;
-			scatter.y += color.y * kAbsorption * transm;
-			scatter.z += color.z * kAbsorption * transm;
-			scatter.w += color.w * kAbsorption * transm;
+			// :140-146 as compiled: a = (transm * ABSORPTION) * alpha, scatter.rgb += (a * color) * light, scatter.a += a
+			const float a = transm * kAbsorption * color.w;
+			scatter.x += a * color.x * light.x;
+			scatter.y += a * color.y * light.y;
+			scatter.z += a * color.z * light.z;
+			scatter.w += a;
 
 			if (transm < kZeroThreshold) break;
 		}
@@ -542,8 +551,7 @@ float4 marchLoop(const uint16_t* vol, uint32_t N, const uint32_t* lightMap, uint
 	}
 	(void)step;
 
-	const float twoPi = 2.0f * kPI;
-	scatter.x /= twoPi; scatter.y /= twoPi; scatter.z /= twoPi;
+	scatter.x *= kInvTwoPi; scatter.y *= kInvTwoPi; scatter.z *= kInvTwoPi;	// :155 `/ (2 PI)` compiled as a multiplication by half(1 / (2 PI))
 	return scatter;
 }
 } // namespace
@@ -962,12 +970,11 @@ void mvo_march_view(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
 					// GetClipPos (:59-71)
 					float3 clip;
 					{
-						float4 hPos = { fmaf(0.01f, rayDir.x, rayOrigin.x), fmaf(0.01f, rayDir.y, rayOrigin.y), fmaf(0.01f, rayDir.z, rayOrigin.z), 1.0f };
+						float4 hPos = { rayOrigin.x + rayDir.x * 0.01f, rayOrigin.y + rayDir.y * 0.01f, rayOrigin.z + rayDir.z * 0.01f, 1.0f };
 						hPos = mul44(hPos, po.wvp);
 						const float cx = hPos.x / hPos.w, cy = hPos.y / hPos.w;
-						float u = cx * 0.5f + 0.5f;
-						float v = cy * 0.5f + 0.5f;
-						v = 1.0f - v;
+						const float u = cx * 0.5f + 0.5f;
+						const float v = 0.5f - cy * 0.5f;	// `1 - (y * 0.5 + 0.5)` compiled (fast math) as 0.5 - y * 0.5
 						const float z = samplePointR32F(depthMap, W, H, u, v);
 						clip = f3(cx, cy, z);
 					}

@@ -37,14 +37,17 @@ def check(oracle, cfg, vols, M=64):
     return st
 
 
-BELOW = float(np.float16(0.01))            # 0.010002: the fp16 nearest 0.01 is ABOVE the fp32 threshold 0.01f
+# ZERO_THRESHOLD is a min16float constant: the reference's compiler folded it to half(0.01) = 0x211F = 0.010002136 (oracle/dxil), and
+# the test is a strict `>`: a texel AT the threshold is not lit
+AT = float(np.float16(0.01))               # 0.010002 = the threshold itself
+ABOVE = float(np.nextafter(np.float16(0.01), np.float16(1)))       # 0.010010, the smallest fp16 above it
 JUST_BELOW = float(np.nextafter(np.float16(0.01), np.float16(0)))  # 0.0099945, the largest fp16 below it
 
 
 def test_uniform_alpha_around_the_threshold(oracle):
     cfg = dict(scene.CONFIGS["C1"], N=24, L=12, maxRay=24, maxLight=12)
-    assert BELOW > 0.01 > JUST_BELOW > 0.00999
-    for alpha, lit, skipped in ((0.0, False, True), (0.005, False, True), (JUST_BELOW, False, False), (BELOW, True, False), (0.02, True, False)):
+    assert ABOVE > AT > 0.01 > JUST_BELOW > 0.00999
+    for alpha, lit, skipped in ((0.0, False, True), (0.005, False, True), (JUST_BELOW, False, False), (AT, False, False), (ABOVE, True, False), (0.02, True, False)):
         st = check(oracle, cfg, [uniform(cfg["N"], alpha)])
         assert (st["lit_samples"] > 0) == lit, alpha
         if skipped:
