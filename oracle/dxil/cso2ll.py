@@ -95,7 +95,7 @@ def _stub(ret, name, args):
             call_args.append(f"i32 %z{i}")
         else:
             call_args.append(f"{a} {v}")
-    body = [f"define internal {ret} @{name}({', '.join(params)}) {{"] + pre
+    body = [f"define internal {ret} @{name}({', '.join(params)}) alwaysinline {{"] + pre
     decl_args = ", ".join(x.split(" ")[0] for x in call_args)
     if ret == "void":
         body += [f"  call void @{cname}({', '.join(call_args)})", "  ret void"]
@@ -136,6 +136,38 @@ def translate(ll, entry, mode="fp32"):
         s = re.sub(r"@dx\.op\.(\w+)\.f16\b", r"@dx.op.\1.f32", s)
     elif mode != "fp16":
         raise ValueError(mode)
+    # WaveReadLaneAt reads a REGISTER of another lane -- also of a lane that is inactive at the reading site (CSVolumeCull reads the
+    # vertices of lanes 6 and 7 inside `if (wTid.x < 6)`; on hardware an inactive lane's register still holds the value).  The lanes
+    # run as threads here, so every value that some ReadLaneAt passes is published by each lane where it is DEFINED, and the read
+    # fetches the wanted lane's published value (waiting for it if that lane is behind).
+    pub, lines = {}, s.splitlines()
+    rd = re.compile(r"^(\s*)(%\S+) = call (float|i32) @dx\.op\.waveReadLaneAt\.(f32|i32)\(i32 117, (float|i32) (%[\w.]+), i32 ([^)]+)\)\s*$")
+    for i, line in enumerate(lines):
+        m = rd.match(line)
+        if not m:
+            continue
+        ind, res, ty, suf, _, val, lane = m.groups()
+        if val not in pub:
+            pub[val] = (len(pub), ty, suf)
+        lines[i] = f"{ind}{res} = call {ty} @rt_readlane_{suf}(i32 {pub[val][0]}, {ty} {val}, i32 {lane})"
+    if pub:
+        out2, pending = [], []
+        for i, line in enumerate(lines):
+            out2.append(line)
+            m = re.match(r"^\s*(%[\w.]+) = (\w+)", line)
+            if m and m.group(1) in pub:
+                pending.append(m.group(1))
+            # publish right behind the definition; behind the block's last phi when the definition is a phi
+            nxt = lines[i + 1] if i + 1 < len(lines) else ""
+            if pending and not re.match(r"^\s*%[\w.]+ = phi ", nxt):
+                for v in pending:
+                    k, ty, suf = pub[v]
+                    out2.append(f"  call void @rt_publish_{suf}(i32 {k}, {ty} {v})")
+                pending = []
+        lines = out2
+        lines += ["", "declare void @rt_publish_f32(i32, float)", "declare void @rt_publish_i32(i32, i32)",
+                  "declare float @rt_readlane_f32(i32, float, i32)", "declare i32 @rt_readlane_i32(i32, i32, i32)"]
+    s = "\n".join(lines)
     # dx.op declarations -> stubs
     decls, seen, body_lines = [], set(), []
     for line in s.splitlines():

@@ -44,51 +44,104 @@ typedef struct
 } dxr_ctx;
 static __thread dxr_ctx* t_ctx;
 
-/* ---------------- wavefront rendezvous ---------------- */
+/* ---------------- wavefront rendezvous ----------------
+ * The lanes of a wave run as threads.  A wave intrinsic blocks its lane; when EVERY lane that is still running is blocked, the
+ * blocked lanes at the earliest call site (lowest code address: the shaders' wave intrinsics sit in forward control flow) form the
+ * set of lanes that a SIMT machine would have active there -- lanes that skipped the enclosing branch are waiting further down, lanes
+ * that left the shader no longer count -- and the operation completes for them.  `cluster` (dxref_dispatch) > 0 additionally splits
+ * WaveActive* reductions by lane / cluster: CSVolumeCull runs them inside `for (i ...) if (i == wTid.y) return WaveActiveMax(x)`,
+ * i.e. once per 8-lane volume cluster with only that cluster active. */
 typedef struct dxr_wave
 {
 	pthread_mutex_t mu;
 	pthread_cond_t cv;
-	uint32_t size, running, arrived, generation;
+	uint32_t size, running, blocked, cluster;
+	void* site[64];			/* call site a lane is blocked at (NULL: running) */
 	uint32_t val_u[64];
 	float val_f[64];
-	uint8_t present[64];
 	uint32_t out_u[64];
 	float out_f[64];
-	uint32_t ballot[4];
-	void (*fn)(struct dxr_wave*, void*);
-	uint8_t arg[16];
+	uint32_t ballot[64][4];
+	uint8_t present[64];	/* lanes of the group being completed */
+	int kind[64], op[64];
+	uint32_t want[64];		/* ReadLaneAt: the lane whose value this lane asked for */
+	/* registers published for ReadLaneAt (cso2ll.py): value and "has been written" per (id, lane) */
+	uint32_t pub_u[256][64];
+	uint8_t pub_set[256][64];
+	uint8_t exited[64];
 } dxr_wave;
 
-typedef void (*wave_fn)(dxr_wave* w, void* arg);
-/* every running lane of the wave calls this with its value; when the last running lane has arrived `fn` runs over the gathered values */
-static void wave_complete(dxr_wave* w)
+enum { WK_READ = 1, WK_FIRST = 2, WK_BALLOT = 3, WK_ACTIVE = 4 };
+
+static void wave_try_complete(dxr_wave* w)
 {
-	w->fn(w, w->arg);
-	memset(w->present, 0, sizeof(w->present));
-	w->arrived = 0;
-	++w->generation;
-	pthread_cond_broadcast(&w->cv);
+	while (w->running && w->blocked == w->running)
+	{
+		void* s = NULL;
+		for (uint32_t l = 0; l < w->size; ++l) if (w->site[l] && (!s || (uintptr_t)w->site[l] < (uintptr_t)s)) s = w->site[l];
+		if (!s) return;
+		int kind = 0, op = 0;
+		memset(w->present, 0, sizeof(w->present));
+		for (uint32_t l = 0; l < w->size; ++l) if (w->site[l] == s) { w->present[l] = 1; kind = w->kind[l]; op = w->op[l]; }
+		if (kind == WK_READ)
+		{
+			/* every result goes to the asking lane's own slot: another group may complete before this one has read its results */
+			for (uint32_t l = 0; l < w->size; ++l)
+				if (w->present[l]) { const uint32_t q = w->want[l] < w->size ? w->want[l] : l; w->out_u[l] = w->val_u[q]; w->out_f[l] = w->val_f[q]; }
+		}
+		else if (kind == WK_FIRST)
+		{
+			uint32_t first = 0;
+			while (first < w->size && !w->present[first]) ++first;
+			for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) { w->out_u[l] = w->val_u[first]; w->out_f[l] = w->val_f[first]; }
+		}
+		else if (kind == WK_BALLOT)
+		{
+			uint32_t b[4] = { 0, 0, 0, 0 };
+			for (uint32_t l = 0; l < w->size; ++l) if (w->present[l] && w->val_u[l]) b[l >> 5] |= 1u << (l & 31);
+			for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) memcpy(w->ballot[l], b, sizeof(b));
+		}
+		else if (kind == WK_ACTIVE)
+		{
+			const uint32_t cl = w->cluster ? w->cluster : w->size;
+			for (uint32_t base = 0; base < w->size; base += cl)
+			{
+				float acc = 0.0f;
+				int have = 0;
+				for (uint32_t l = base; l < base + cl && l < w->size; ++l)
+				{
+					if (!w->present[l]) continue;
+					const float v = w->val_f[l];
+					if (!have) { acc = v; have = 1; continue; }
+					switch (op) { case 0: acc += v; break; case 1: acc *= v; break; case 2: acc = fminf(acc, v); break; case 3: acc = fmaxf(acc, v); break; default: abort(); }
+				}
+				for (uint32_t l = base; l < base + cl && l < w->size; ++l) if (w->present[l]) w->out_f[l] = acc;
+			}
+		}
+		if (getenv("DXREF_TRACE")) { fprintf(stderr, "wave op kind %d op %d site %p lanes:", kind, op, s); for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) fprintf(stderr, " %u(v=%g,u=%u,want=%u->%g)", l, w->val_f[l], w->val_u[l], w->want[l], w->out_f[l]); fprintf(stderr, "\n"); }
+		for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) { w->site[l] = NULL; --w->blocked; }
+		pthread_cond_broadcast(&w->cv);
+	}
 }
-static void wave_meet(uint32_t vu, float vf, wave_fn fn, const void* arg, size_t arg_size)
+static void wave_meet(void* site, int kind, int op, uint32_t vu, float vf, uint32_t want)
 {
 	dxr_wave* w = t_ctx->wave;
 	const uint32_t lane = t_ctx->lane;
 	pthread_mutex_lock(&w->mu);
-	w->val_u[lane] = vu; w->val_f[lane] = vf; w->present[lane] = 1;
-	w->fn = fn;
-	if (arg_size) memcpy(w->arg, arg, arg_size);
-	const uint32_t gen = w->generation;
-	if (++w->arrived == w->running) wave_complete(w);
-	else while (w->generation == gen) pthread_cond_wait(&w->cv, &w->mu);
+	w->val_u[lane] = vu; w->val_f[lane] = vf; w->kind[lane] = kind; w->op[lane] = op; w->want[lane] = want;
+	w->site[lane] = site;
+	++w->blocked;
+	wave_try_complete(w);
+	while (w->site[lane]) pthread_cond_wait(&w->cv, &w->mu);
 	pthread_mutex_unlock(&w->mu);
 }
 static void wave_lane_exit(dxr_wave* w)
 {
-	/* a lane that returns from the shader no longer takes part: lanes waiting at a wave operation only wait for the running ones */
 	pthread_mutex_lock(&w->mu);
 	--w->running;
-	if (w->running && w->arrived == w->running) wave_complete(w);
+	w->exited[t_ctx->lane] = 1;
+	pthread_cond_broadcast(&w->cv);	/* lanes waiting for a register of this one */
+	wave_try_complete(w);
 	pthread_mutex_unlock(&w->mu);
 }
 
@@ -342,74 +395,74 @@ _Float16 rt_tertiary_f16(int32_t op, _Float16 a, _Float16 b, _Float16 c) { retur
 /* ---------------- wave intrinsics ---------------- */
 int32_t rt_waveGetLaneIndex(int32_t op) { (void)op; return (int32_t)t_ctx->lane; }
 int32_t rt_waveGetLaneCount(int32_t op) { (void)op; return t_ctx->wave ? (int32_t)t_ctx->wave->size : 1; }
-
-/* ReadLaneAt: every lane publishes (value, wanted lane); after the meeting it picks the wanted lane's value */
-static void fn_noop(dxr_wave* w, void* arg) { (void)arg; memcpy(w->out_u, w->val_u, sizeof(w->out_u)); memcpy(w->out_f, w->val_f, sizeof(w->out_f)); }
+/* ReadLaneAt through published registers (see cso2ll.py) */
+void rt_publish_i32(int32_t id, int32_t v)
+{
+	dxr_wave* w = t_ctx->wave;
+	if (!w || (uint32_t)id >= 256u) return;
+	pthread_mutex_lock(&w->mu);
+	w->pub_u[id][t_ctx->lane] = (uint32_t)v; w->pub_set[id][t_ctx->lane] = 1;
+	pthread_cond_broadcast(&w->cv);
+	pthread_mutex_unlock(&w->mu);
+}
+void rt_publish_f32(int32_t id, float v) { int32_t u; memcpy(&u, &v, 4); rt_publish_i32(id, u); }
+int32_t rt_readlane_i32(int32_t id, int32_t own, int32_t lane)
+{
+	dxr_wave* w = t_ctx->wave;
+	if (!w) return own;
+	if ((uint32_t)lane >= w->size || (uint32_t)id >= 256u) return 0;
+	pthread_mutex_lock(&w->mu);
+	/* the wanted lane defines the value at the same place in the program: it has, or will, unless it has left the shader.
+	 * While waiting this lane counts as blocked for nobody: it waits for a lane that is RUNNING, not for a meeting. */
+	while (!w->pub_set[id][lane] && !w->exited[lane] && lane < (int32_t)w->size) pthread_cond_wait(&w->cv, &w->mu);
+	const int32_t r = w->pub_set[id][lane] ? (int32_t)w->pub_u[id][lane] : 0;
+	pthread_mutex_unlock(&w->mu);
+	return r;
+}
+float rt_readlane_f32(int32_t id, float own, int32_t lane)
+{
+	int32_t o, r; memcpy(&o, &own, 4);
+	r = rt_readlane_i32(id, o, lane);
+	float f; memcpy(&f, &r, 4);
+	return f;
+}
+/* (the stubs in the translated IR are always inlined: the return address identifies the shader's call site) */
+#define SITE() __builtin_extract_return_addr(__builtin_return_address(0))
 int32_t rt_waveReadLaneAt_i32(int32_t op, int32_t v, int32_t lane)
 {
 	(void)op;
 	if (!t_ctx->wave) return v;
-	wave_meet((uint32_t)v, 0.0f, fn_noop, NULL, 0);
-	/* out_u is stable until the next meeting completes, which needs this lane */
-	return (uint32_t)lane < t_ctx->wave->size ? (int32_t)t_ctx->wave->out_u[(uint32_t)lane] : 0;
+	wave_meet(SITE(), WK_READ, 0, (uint32_t)v, 0.0f, (uint32_t)lane);
+	return (int32_t)t_ctx->wave->out_u[t_ctx->lane];	/* this lane's own slot: stable until it blocks again */
 }
 float rt_waveReadLaneAt_f32(int32_t op, float v, int32_t lane)
 {
 	(void)op;
 	if (!t_ctx->wave) return v;
-	wave_meet(0u, v, fn_noop, NULL, 0);
-	return (uint32_t)lane < t_ctx->wave->size ? t_ctx->wave->out_f[(uint32_t)lane] : 0.0f;
-}
-static void fn_first(dxr_wave* w, void* arg)
-{
-	(void)arg;
-	uint32_t first = 0;
-	while (first < w->size && !w->present[first]) ++first;
-	for (uint32_t l = 0; l < w->size; ++l) { w->out_u[l] = w->val_u[first < w->size ? first : 0]; w->out_f[l] = w->val_f[first < w->size ? first : 0]; }
+	wave_meet(SITE(), WK_READ, 0, 0u, v, (uint32_t)lane);
+	return t_ctx->wave->out_f[t_ctx->lane];
 }
 int32_t rt_waveReadLaneFirst_i32(int32_t op, int32_t v)
 {
 	(void)op;
 	if (!t_ctx->wave) return v;
-	wave_meet((uint32_t)v, 0.0f, fn_first, NULL, 0);
+	wave_meet(SITE(), WK_FIRST, 0, (uint32_t)v, 0.0f, 0u);
 	return (int32_t)t_ctx->wave->out_u[t_ctx->lane];
 }
 typedef struct { int32_t v[4]; } ballot_t;
-static void fn_ballot(dxr_wave* w, void* arg)
-{
-	(void)arg;
-	memset(w->ballot, 0, sizeof(w->ballot));
-	for (uint32_t l = 0; l < w->size; ++l) if (w->present[l] && w->val_u[l]) w->ballot[l >> 5] |= 1u << (l & 31);
-}
 void rt_waveActiveBallot(ballot_t* out, int32_t op, int32_t cond)
 {
 	(void)op;
 	memset(out, 0, sizeof(*out));
 	if (!t_ctx->wave) { out->v[0] = cond ? 1 : 0; return; }
-	wave_meet(cond ? 1u : 0u, 0.0f, fn_ballot, NULL, 0);
-	for (int i = 0; i < 4; ++i) out->v[i] = (int32_t)t_ctx->wave->ballot[i];
-}
-typedef struct { int op, sign; } active_op;
-static void fn_active_f(dxr_wave* w, void* arg)
-{
-	const active_op* a = (const active_op*)arg;
-	float acc = 0.0f;
-	int have = 0;
-	for (uint32_t l = 0; l < w->size; ++l)
-	{
-		if (!w->present[l]) continue;
-		const float v = w->val_f[l];
-		if (!have) { acc = v; have = 1; continue; }
-		switch (a->op) { case 0: acc += v; break; case 1: acc *= v; break; case 2: acc = fminf(acc, v); break; case 3: acc = fmaxf(acc, v); break; default: abort(); }
-	}
-	for (uint32_t l = 0; l < w->size; ++l) w->out_f[l] = acc;
+	wave_meet(SITE(), WK_BALLOT, 0, cond ? 1u : 0u, 0.0f, 0u);
+	for (int i = 0; i < 4; ++i) out->v[i] = (int32_t)t_ctx->wave->ballot[t_ctx->lane][i];
 }
 float rt_waveActiveOp_f32(int32_t opc, float v, int32_t op, int32_t sign)
 {
-	(void)opc;
+	(void)opc; (void)sign;
 	if (!t_ctx->wave) return v;
-	active_op a = { op, sign };
-	wave_meet(0u, v, fn_active_f, &a, sizeof(a));
+	wave_meet(SITE(), WK_ACTIVE, op, 0u, v, 0u);
 	return t_ctx->wave->out_f[t_ctx->lane];
 }
 
@@ -427,8 +480,9 @@ static void* lane_main(void* p)
 
 /* Runs fn for every thread of a gx x gy x gz dispatch of (tx, ty, tz)-thread groups.  wave_size = 0: lanes one after the other on
  * the calling thread (shaders whose wave intrinsics only broadcast group-uniform values: ReadLaneAt / ReadLaneFirst return the
- * caller's value).  wave_size > 0: the group is cut into waves of that many lanes, each lane a thread, meeting at wave intrinsics. */
-int dxref_dispatch(shader_fn fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tx, uint32_t ty, uint32_t tz, uint32_t wave_size)
+ * caller's value).  wave_size > 0: the group is cut into waves of that many lanes, each lane a thread, meeting at wave intrinsics
+ * (see "wavefront rendezvous"; `cluster`: lanes per WaveActive* reduction group, 0 = the whole wave). */
+int dxref_dispatch(shader_fn fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tx, uint32_t ty, uint32_t tz, uint32_t wave_size, uint32_t cluster)
 {
 	const uint32_t per_group = tx * ty * tz;
 	if (wave_size > 64) return -1;
@@ -457,7 +511,7 @@ int dxref_dispatch(shader_fn fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t
 					dxr_wave w;
 					memset(&w, 0, sizeof(w));
 					pthread_mutex_init(&w.mu, NULL); pthread_cond_init(&w.cv, NULL);
-					w.size = wave_size; w.running = n;
+					w.size = wave_size; w.running = n; w.cluster = cluster;
 					lane_arg args[64];
 					pthread_t th[64];
 					for (uint32_t l = 0; l < n; ++l)

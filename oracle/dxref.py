@@ -34,7 +34,7 @@ def load():
         lib.dxref_bind.restype = C.c_int
         lib.dxref_bind.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.dxref_dispatch.restype = C.c_int
-        lib.dxref_dispatch.argtypes = [C.c_void_p] + [C.c_uint32] * 7
+        lib.dxref_dispatch.argtypes = [C.c_void_p] + [C.c_uint32] * 8
         lib.dxref_counter.restype = C.c_uint32
         lib.dxref_counter.argtypes = [C.c_uint32] * 3
         _lib = lib
@@ -50,8 +50,8 @@ def _entry(shader, mode):
     return C.cast(getattr(load(), f"dxil_{shader}_{mode}"), C.c_void_p)
 
 
-def _dispatch(shader, mode, groups, threads, wave=0):
-    rc = load().dxref_dispatch(_entry(shader, mode), groups[0], groups[1], groups[2], threads[0], threads[1], threads[2], wave)
+def _dispatch(shader, mode, groups, threads, wave=0, cluster=0):
+    rc = load().dxref_dispatch(_entry(shader, mode), groups[0], groups[1], groups[2], threads[0], threads[1], threads[2], wave, cluster)
     assert rc == 0, rc
 
 
@@ -166,6 +166,6 @@ def cull(V, perObject, descs, cbPerFrame, maxRaySamples, volumeInfo=None, mode="
     _bind(UAV, 2, 2, RAW, F_NONE, cube, V, 0, 0, 4)
     _bind(CBV, 0, 0, CBUF, F_NONE, cb, len(cb))
     _bind(CBV, 1, 1, CBUF, F_NONE, cb1, 8)
-    _dispatch("CSVolumeCull", mode, ((V + 3) // 4, 1, 1), (8, 4, 1), wave=32)
+    _dispatch("CSVolumeCull", mode, ((V + 3) // 4, 1, 1), (8, 4, 1), wave=32, cluster=8)
     nv, nc = int(lib.dxref_counter(UAV, 0, 0)), int(lib.dxref_counter(UAV, 2, 2))
     return info, np.sort(vis[:nv]), np.sort(cube[:nc])

@@ -1,7 +1,11 @@
 /*
  * mv_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code; see mv_oracle.h).
  *
- * PARITY UNPINNED: no reference test, golden vector or runnable reference exists for this path.
+ * PARITY: the cull, the light march and the view march (a1, a2, a3) are PINNED to the reference's shipped compiled shaders
+ * (Bin/*.cso run on the CPU through oracle/dxil -> oracle/_ref/libmv_dxref.so; tests/test_oracle_vs_reference_dxil.py: cull identical
+ * in 400 / 400 cases, view march bit-identical, light maps bit-identical without the probe), with the fixed-function sampler and the
+ * format conversions as a stated contract the bytecode does not contain.  The composite (a7) is UNPINNED: no reference test, golden
+ * vector or runnable reference exists for it (its pixel shaders need a rasteriser's interpolated inputs).
  * Line-for-line scalar fp32 restatement of the reference HLSL:
  *   Sh/Common.hlsli, SharedConsts.h, Sh/RayMarch.hlsli, Sh/CSRayMarch.hlsl (+CSRayMarchV.hlsl),
  *   Sh/CSRayMarchL.hlsl, Sh/CSVolumeCull.hlsl, Sh/VolumeCull.hlsli,
@@ -10,10 +14,10 @@
  *
  * Numeric conventions (documented in DESIGN.md, mirrored by the HIP kernels):
  *   - `min16float` is a minimum-precision hint (SM6.3 without -enable-16bit-types): fp32 everywhere,
- *     fp16 / 11-11-10 only in storage.
+ *     fp16 / 11-11-10 only in storage; min16float CONSTANTS are the half values the reference's compiler folded them to.
  *   - build with -ffp-contract=off; a multiply-add is fused ONLY where fmaf() is written out
- *     (lerp and ray-point evaluation -- the places a shader compiler emits `mad`).
- *   - normalize(v) = v / sqrt(dot(v,v)); dot and mul() accumulate left to right.
+ *     (the sampler's lerps, the composite's analytic exit point); operation order follows the reference's bytecode.
+ *   - normalize(v) = v * (1 / sqrt(dot(v,v))); dot and mul() accumulate left to right.
  *   - HLSL min/max return the non-NaN operand (fminf/fmaxf); saturate(NaN) = 0.
  *   - float -> uint casts saturate (D3D ftou).
  *   - pow(x, 0.25) is evaluated as sqrt(sqrt(x)) (correctly rounded steps, identical on CPU and GPU).

@@ -4,10 +4,12 @@
  * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg may link or call it.  The product (multivolumes_amd/) never does.
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or runnable CPU path
- * (HLSL -> DXIL via a Windows-only dxc.exe, D3D12 + closed XUSG.dll).  This file is a
- * line-for-line scalar fp32 restatement of the HLSL, anchored by analytic known-answer
- * tests (tests/test_oracle_kat.py) derived from the shader math.
+ * PARITY: the reference ships no tests or golden vectors and its sources cannot be built here (HLSL -> DXIL via a
+ * Windows-only dxc.exe, D3D12 + closed XUSG.dll) -- but it ships its COMPILED shaders, and oracle/dxil runs those on the CPU
+ * (oracle/_ref/libmv_dxref.so).  Cull, light march and view march of this file are PINNED to them
+ * (tests/test_oracle_vs_reference_dxil.py; vectors in tests/golden/dxil_small.npz); the composite and the fixed-function sampler
+ * are UNPINNED (a stated contract).  This file is a line-for-line scalar fp32 restatement of the HLSL, also anchored by analytic
+ * known-answer tests (tests/test_oracle_kat*.py) derived from the shader math.
  *
  * Every function cites the reference file:line it follows (paths relative to
  * /root/reference/MultiVolumes/Content unless noted; Sh/ = Shaders/).

@@ -1,7 +1,8 @@
 """ctypes wrapper of the CPU oracle (oracle/libmv_oracle.so).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
-the product package.  PARITY UNPINNED: see oracle/mv_oracle.h.
+the product package.  Parity: a1 / a2 / a3 pinned to the reference's shipped compiled shaders (oracle/dxref.py), composite and
+sampler unpinned: see oracle/mv_oracle.h.
 """
 import ctypes as C
 import os

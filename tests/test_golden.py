@@ -75,3 +75,63 @@ def test_gpu_matches_golden():
         assert np.abs(half_to_float(mc.ReadBackComposite()) - half_to_float(g["composite"])).max() <= 1e-3
         st = mc.GetStats()
         assert [st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"], st["composite_samples"]] == [int(x) for x in g["stats"]]
+
+
+def test_oracle_reproduces_dxil_golden(oracle):
+    """tests/golden/dxil_small.npz holds what the REFERENCE'S SHIPPED COMPILED SHADERS (CSVolumeCull / CSRayMarchL / CSRayMarchV .cso, run
+    on the CPU through oracle/dxil, made by tests/golden/make_dxil_golden.py) produce for a small seeded frame: VolumeInfo and lists,
+    the light maps after four frames, every cube map and cube depth.  The oracle reproduces all of it bit for bit -- on any machine,
+    without the reference and without the translated library."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_dxil_golden.py")
+    spec = importlib.util.spec_from_file_location("make_dxil_golden", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(os.path.dirname(path), "dxil_small.npz"))
+    out = mod.oracle_run()
+    for k in ("info", "vis", "cube", "lightMaps", "cubeMaps", "cubeDepths"):
+        assert np.array_equal(out[k], g[k]), k
+    assert len(g["cube"]) > 0 and g["cubeMaps"].any() and g["lightMaps"].any()
+
+
+@pytest.mark.gpu
+def test_gpu_matches_dxil_golden():
+    """The HIP path against the outputs of the reference's shipped compiled shaders themselves (tests/golden/dxil_small.npz), without
+    the oracle in between: VolumeInfo and lists, light maps, cube maps and cube depths, bit for bit."""
+    import importlib.util
+    from multivolumes_amd import MultiRayCaster, scene
+    from multivolumes_amd import raycaster as rc
+    from multivolumes_amd.raycaster import cube_mip_offset
+    from tests.helpers import host_frame
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_dxil_golden.py")
+    spec = importlib.util.spec_from_file_location("make_dxil_golden", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(os.path.dirname(path), "dxil_small.npz"))
+    c = mod.CFG
+    V, N, L = c["V"], c["N"], c["L"]
+    _, vp, svp, cb, po = host_frame(c, 0, mod.EYE)
+    depth, shadow = scene.depth_and_shadow(c, vp, svp, mod.M)
+    with MultiRayCaster(N, L, V, V, (c["W"], c["H"]), shadowMapSize=mod.M) as mc:
+        for k in range(V):
+            mc.LoadVolumeData(k, rc.synth_volume(N, k + 1))
+        mc.SetRenderTargets(depth, shadow)
+        mc.SetSH(None)
+        mc.SetMaxSamples(c["maxRay"], c["maxLight"])
+        for f in range(V):
+            _, _, _, cb, po = host_frame(c, f, mod.EYE)
+            mc.UpdateFrameRaw(cb, po)
+            mc.cullVolumes()
+            mc.rayMarchL()
+        mc.rayMarchV()
+        assert np.array_equal(mc.ReadBackVolumeInfo(), g["info"])
+        vis, cube = mc.ReadBackVisibleLists()
+        assert np.array_equal(np.sort(vis), g["vis"]) and np.array_equal(np.sort(cube), g["cube"])
+        for v in vis:
+            assert np.array_equal(mc.ReadBackLightMap(int(v)), g["lightMaps"][v]), f"light map of volume {v}"
+        for v in cube:
+            mip = int(g["info"][v, 0])
+            d = N >> mip
+            off = cube_mip_offset(N, mip)
+            assert np.array_equal(mc.ReadBackCubeMap(int(v), mip), g["cubeMaps"][v][off:off + 6 * d * d].reshape(6, d, d, 4)), f"cube map of volume {v}"
+            assert np.array_equal(mc.ReadBackCubeDepth(int(v), mip), g["cubeDepths"][v][off:off + 6 * d * d].reshape(6, d, d))

@@ -1,0 +1,99 @@
+"""The oracle against the reference's SHIPPED compiled shaders (/root/reference/Bin/*.cso -- DXIL, translated to x86-64 through LLVM
+by oracle/dxil into oracle/_ref/libmv_dxref.so; `make -C oracle ref`, also run by __graft_entry__.build() where /root/reference exists).
+
+What this pins: the oracle's SHADER LOGIC -- control flow, arithmetic, constants (min16float constants as the compiler folded them),
+order of operations, early-outs -- to the reference's own compiled code for a1 (CSVolumeCull), a2 (CSRayMarchL) and a3 (CSRayMarchV).
+What it does not: the fixed-function sampler and the format conversion of typed loads / stores, which the bytecode does not contain and
+which oracle/dxil/dxil_rt.c answers with the oracle's own contract.  The translation runs the shaders in IEEE fp32 with min16float
+values carried at 32 bits (as WARP and most GPUs do), FMad with two roundings, no reassociation.
+
+Skipped when oracle/_ref is absent (it cannot be built without /root/reference); tests/test_golden.py::test_oracle_reproduces_dxil_golden
+checks vectors made by this library and needs no library.
+"""
+import numpy as np
+import pytest
+
+from multivolumes_amd import scene
+from multivolumes_amd import raycaster as rc
+from tests.conftest import half_to_float
+from tests.helpers import default_descs, host_frame, oracle_pipeline
+
+dxref = pytest.importorskip("oracle.dxref")
+pytestmark = pytest.mark.skipif(not dxref.available(), reason="oracle/_ref/libmv_dxref.so not built (needs /root/reference/Bin/*.cso: make -C oracle ref)")
+
+
+def cameras(n, seed):
+    rng = np.random.default_rng(seed)
+    out = [None]
+    for _ in range(n - 1):
+        a, r, h = rng.uniform(0, 6.28), rng.uniform(20, 400), rng.uniform(-60, 120)
+        out.append((r * np.sin(a), h, -r * np.cos(a)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["C1", "T1", "T2", "C3", "C5"])
+def test_cull_equals_the_compiled_cull(oracle, name):
+    """CSVolumeCull.cso: VolumeInfo (mip, sample count, face mask + scheme bit, texture id) and both lists, bit for bit, with the
+    configured sample cap and with the cap out of the way (65535: the LOD then comes from the projected edge length alone)."""
+    cfg = dict(scene.CONFIGS[name])
+    V, N = cfg["V"], cfg["N"]
+    descs = default_descs(V, V, N)
+    for eye in cameras(10, 11):
+        _, _, _, cb, po = host_frame(cfg, 0, eye)
+        for cap in (cfg["maxRay"], 65535):
+            i0, v0, c0 = oracle.cull(V, po, descs, cb, cap)
+            i1, v1, c1 = dxref.cull(V, po, descs, cb, cap)
+            assert np.array_equal(i0, i1), (eye, cap)
+            assert np.array_equal(np.sort(v0), v1) and np.array_equal(np.sort(c0), c1), (eye, cap)
+
+
+@pytest.mark.parametrize("name,eye", [("T1", None), ("C1", None), ("T1", (60.0, 35.0, -50.0))])
+def test_view_march_equals_the_compiled_view_march(oracle, name, eye):
+    """CSRayMarchV.cso over the whole frame: every half of every marched cube face and every cube depth, bit for bit."""
+    cfg = dict(scene.CONFIGS[name])
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    ref = oracle_pipeline(oracle, cfg, vols, 32, eye=eye)
+    assert len(ref["cube"]) > 0
+    cm, cd = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], ref["info"], ref["cube"])
+    assert np.array_equal(cm, ref["cubeMaps"])
+    assert np.array_equal(cd, ref["cubeDepths"])
+    # what the reference itself leaves open: a device that fuses FMad moves a handful of halves by one ulp; one that honours min16float
+    # at 16 bits moves a quarter of them, by up to 0.3 -- reported, not asserted
+    fused, _ = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], ref["info"], ref["cube"], fused_mad=True)
+    half, _ = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], ref["info"], ref["cube"], mode="fp16")
+    d_f = np.nanmax(np.abs(half_to_float(fused) - half_to_float(ref["cubeMaps"])))
+    d_h = np.nanmax(np.abs(half_to_float(half) - half_to_float(ref["cubeMaps"])))
+    print(f"{name}: fused FMad differs in {int((fused != ref['cubeMaps']).sum())} halves (max {d_f:.2e}); 16-bit min16float in {int((half != ref['cubeMaps']).sum())} (max {d_h:.2e})")
+    assert d_f <= 1e-3
+
+
+@pytest.mark.parametrize("use_sh", [False, True])
+def test_light_march_equals_the_compiled_light_march(oracle, use_sh):
+    """CSRayMarchL.cso (shadow map and light probe compiled in, the probe switched by cbSampleRes): the relit volume's light map,
+    four consecutive frames.  With the probe the compiled spherical-harmonics sum is in the compiler's (fast-math) order: a voxel may
+    land on the neighbouring 11-bit value."""
+    cfg = dict(scene.CONFIGS["T1"])
+    V, N, L, M = cfg["V"], cfg["N"], cfg["L"], 32
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    descs = default_descs(V, V, N)
+    _, vp, svp, cb, po = host_frame(cfg, 0)
+    _, shadow = scene.depth_and_shadow(cfg, vp, svp, M)
+    _, vis, _ = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+    sh = scene.DEFAULT_SH if use_sh else None
+    lib = oracle.load()
+    for f in range(4):
+        _, _, _, cb, po = host_frame(cfg, f)
+        vid, lms, _ = oracle.march_light(V, N, L, M, vols, descs, po, cb, shadow, sh, vis, cfg["maxLight"])
+        lm = dxref.march_light(V, N, L, M, vols, descs, po, cb, shadow, sh, vis, cfg["maxLight"])
+        a, b = lm[vid], lms[vid]
+        if not use_sh:
+            assert np.array_equal(a, b), f
+            continue
+        idx = np.nonzero(a != b)
+        assert len(idx[0]) <= 4, f
+        g, e = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        for x, y in zip(a[idx], b[idx]):
+            lib.mvo_unpack_r11g11b10f(int(x), rc._ptr(g))
+            lib.mvo_unpack_r11g11b10f(int(y), rc._ptr(e))
+            assert np.max(np.abs(g - e) / np.maximum(np.abs(e), 1e-6)) <= 1.0 / 32
