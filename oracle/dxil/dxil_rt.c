@@ -17,7 +17,7 @@
 
 #include "../mv_oracle.h"
 
-enum { DXR_RAW = 1, DXR_TYPED_BUF = 2, DXR_CBUF = 3, DXR_TEX2D = 4, DXR_TEX3D = 5, DXR_TEX2DARRAY = 6, DXR_SAMPLER = 7 };
+enum { DXR_RAW = 1, DXR_TYPED_BUF = 2, DXR_CBUF = 3, DXR_TEX2D = 4, DXR_TEX3D = 5, DXR_TEX2DARRAY = 6, DXR_SAMPLER = 7, DXR_TEXCUBE = 8 };
 enum { DXF_NONE = 0, DXF_RGBA16F = 1, DXF_R11G11B10F = 2, DXF_R32F = 3, DXF_D16 = 4, DXF_RGBA16U = 5, DXF_R32U = 6, DXF_RGBA32F = 7 };
 
 typedef struct dxr_res
@@ -41,6 +41,8 @@ typedef struct
 {
 	uint32_t tid[3], gid[3], tig[3], flat, lane;
 	struct dxr_wave* wave;
+	const uint32_t (*in)[4];	/* pixel / vertex shader inputs: [signature element][component], raw bits */
+	float out[8][4];			/* outputs: [signature element][component] */
 } dxr_ctx;
 static __thread dxr_ctx* t_ctx;
 
@@ -251,6 +253,8 @@ void rt_getDimensions(dims_t* out, int32_t op, dxr_res* r, int32_t mip)
 }
 
 /* ---------------- textures: the oracle's sampler / format contract ---------------- */
+static void cube_taps(const dxr_res* t, float x, float y, float z, uint64_t idx[4], float w[4]);
+static float cube_texel(const dxr_res* t, uint64_t i, int ch);
 void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, float c0, float c1, float c2, float c3, int32_t o0, int32_t o1, int32_t o2, float lod)
 {
 	(void)op; (void)smp; (void)c3; (void)lod;
@@ -272,6 +276,14 @@ void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, floa
 	{
 		/* CSR32FToRGBA16F's source: a linear sampler on an R32F volume -- the oracle's converter exposes the whole pass only */
 		fprintf(stderr, "dxil_rt: sampleLevel on an R32F volume is not wired (use mvo_r32f_to_rgba16f's KAT instead)\n"); abort();
+	}
+	else if (t->kind == DXR_TEXCUBE)
+	{
+		/* bilinear over the Gather footprint, summed tap 0..3 like the oracle's fallback colour (PSCube.hlsli:59) */
+		uint64_t idx[4]; float w[4];
+		cube_taps(t, c0, c1, c2, idx, w);
+		for (int ch = 0; ch < 4; ++ch)
+			out->v[ch] = cube_texel(t, idx[0], ch) * w[0] + cube_texel(t, idx[1], ch) * w[1] + cube_texel(t, idx[2], ch) * w[2] + cube_texel(t, idx[3], ch) * w[3];
 	}
 	else if (t->kind == DXR_TEX2D && t->fmt == DXF_R32F)
 	{
@@ -308,6 +320,89 @@ void rt_textureStore_f32(int32_t op, dxr_res* t, int32_t x, int32_t y, int32_t z
 	case DXF_R32F: ((float*)t->data)[i] = v0; break;
 	default: fprintf(stderr, "dxil_rt: textureStore on format %d\n", t->fmt); abort();
 	}
+}
+
+/* ---------------- graphics stages: inputs, outputs, typed loads, atomics, cube maps ---------------- */
+float rt_loadInput_f32(int32_t op, int32_t sig, int32_t row, int32_t col, int32_t vertex)
+{
+	(void)op; (void)row; (void)vertex;
+	float f; memcpy(&f, &t_ctx->in[sig][col & 3], 4); return f;
+}
+int32_t rt_loadInput_i32(int32_t op, int32_t sig, int32_t row, int32_t col, int32_t vertex)
+{
+	(void)op; (void)row; (void)vertex;
+	return (int32_t)t_ctx->in[sig][col & 3];
+}
+void rt_storeOutput_f32(int32_t op, int32_t sig, int32_t row, int32_t col, float v) { (void)op; (void)row; t_ctx->out[sig & 7][col & 3] = v; }
+void rt_storeOutput_i32(int32_t op, int32_t sig, int32_t row, int32_t col, int32_t v) { (void)op; (void)row; memcpy(&t_ctx->out[sig & 7][col & 3], &v, 4); }
+
+static int tex_index(const dxr_res* t, int32_t x, int32_t y, int32_t z, size_t* i)
+{
+	const uint32_t ux = (uint32_t)x, uy = (uint32_t)y, uz = t->kind == DXR_TEX2D ? 0u : (uint32_t)z;
+	const uint32_t depth = t->kind == DXR_TEX2D ? 1u : t->d;
+	if (!t->data || ux >= t->w || uy >= t->h || uz >= depth) return 0;
+	*i = ((size_t)uz * t->h + uy) * t->w + ux;
+	return 1;
+}
+void rt_textureLoad_f32(ret_f32* out, int32_t op, dxr_res* t, int32_t mip, int32_t c0, int32_t c1, int32_t c2, int32_t o0, int32_t o1, int32_t o2)
+{
+	(void)op; (void)mip; (void)o0; (void)o1; (void)o2;
+	memset(out, 0, sizeof(*out));
+	size_t i;
+	if (!tex_index(t, c0, c1, c2, &i)) return;	/* out of bounds: zeros */
+	switch (t->fmt)
+	{
+	case DXF_R32F: out->v[0] = ((const float*)t->data)[i]; out->v[3] = 1.0f; break;
+	case DXF_RGBA16F: { const uint16_t* p = (const uint16_t*)t->data + 4 * i; for (int c = 0; c < 4; ++c) out->v[c] = mvo_f16_to_f32(p[c]); break; }
+	default: fprintf(stderr, "dxil_rt: textureLoad.f32 on format %d\n", t->fmt); abort();
+	}
+}
+void rt_textureLoad_i32(ret_i32* out, int32_t op, dxr_res* t, int32_t mip, int32_t c0, int32_t c1, int32_t c2, int32_t o0, int32_t o1, int32_t o2)
+{
+	(void)op; (void)mip; (void)o0; (void)o1; (void)o2;
+	memset(out, 0, sizeof(*out));
+	size_t i;
+	if (!tex_index(t, c0, c1, c2, &i)) return;
+	if (t->fmt == DXF_R32U) out->v[0] = (int32_t)((const uint32_t*)t->data)[i];
+	else { fprintf(stderr, "dxil_rt: textureLoad.i32 on format %d\n", t->fmt); abort(); }
+}
+int32_t rt_atomicBinOp_i32(int32_t op, dxr_res* t, int32_t aop, int32_t c0, int32_t c1, int32_t c2, int32_t v)
+{
+	(void)op;
+	size_t i;
+	if (t->fmt != DXF_R32U || !tex_index(t, c0, c1, c2, &i)) return 0;
+	uint32_t* p = (uint32_t*)t->data + i;
+	const uint32_t old = *p, u = (uint32_t)v;
+	switch (aop)
+	{
+	case 0: *p = old + u; break; case 1: *p = old & u; break; case 2: *p = old | u; break; case 3: *p = old ^ u; break;
+	case 4: *p = (uint32_t)((int32_t)old < v ? (int32_t)old : v); break; case 5: *p = (uint32_t)((int32_t)old > v ? (int32_t)old : v); break;
+	case 6: *p = old < u ? old : u; break; case 7: *p = old > u ? old : u; break; case 8: *p = u; break;
+	default: fprintf(stderr, "dxil_rt: atomicBinOp %d\n", aop); abort();
+	}
+	return (int32_t)old;
+}
+/* TextureCube: the oracle's contract for the footprint (face selection, the texel a tap across a face edge resolves to, bilinear weights) */
+static void cube_taps(const dxr_res* t, float x, float y, float z, uint64_t idx[4], float w[4])
+{
+	const float dir[3] = { x, y, z };
+	mvo_cube_footprint(dir, t->w, idx, w);
+}
+static float cube_texel(const dxr_res* t, uint64_t i, int ch)
+{
+	if (t->fmt == DXF_RGBA16F) return mvo_f16_to_f32(((const uint16_t*)t->data)[4 * i + ch]);
+	if (t->fmt == DXF_R32F) return ch == 0 ? ((const float*)t->data)[i] : (ch == 3 ? 1.0f : 0.0f);
+	fprintf(stderr, "dxil_rt: cube map format %d\n", t->fmt); abort();
+}
+void rt_textureGather_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, float c0, float c1, float c2, float c3, int32_t o0, int32_t o1, int32_t channel)
+{
+	(void)op; (void)smp; (void)c3; (void)o0; (void)o1;
+	memset(out, 0, sizeof(*out));
+	if (!t->data) return;
+	if (t->kind != DXR_TEXCUBE) { fprintf(stderr, "dxil_rt: textureGather on kind %d\n", t->kind); abort(); }
+	uint64_t idx[4]; float w[4];
+	cube_taps(t, c0, c1, c2, idx, w);
+	for (int k = 0; k < 4; ++k) out->v[k] = cube_texel(t, idx[k], channel);
 }
 
 /* ---------------- arithmetic ---------------- */
@@ -467,6 +562,23 @@ float rt_waveActiveOp_f32(int32_t opc, float v, int32_t op, int32_t sign)
 }
 
 /* ---------------- dispatch ---------------- */
+/* n invocations of a pixel (or vertex) shader, one after the other: inputs[i] = 8 signature elements x 4 components (raw bits),
+ * outputs[i] = 4 floats of output element 0 (may be NULL) */
+int dxref_run_invocations(void (*fn)(void), uint32_t n, const uint32_t* inputs, float* outputs)
+{
+	dxr_ctx c;
+	memset(&c, 0, sizeof(c));
+	t_ctx = &c;
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		c.in = (const uint32_t (*)[4])(inputs + (size_t)i * 32u);
+		memset(c.out, 0, sizeof(c.out));
+		fn();
+		if (outputs) memcpy(outputs + (size_t)i * 4u, c.out[0], 16);
+	}
+	return 0;
+}
+
 typedef void (*shader_fn)(void);
 typedef struct { shader_fn fn; dxr_ctx ctx; } lane_arg;
 static void* lane_main(void* p)

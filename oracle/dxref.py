@@ -169,3 +169,102 @@ def cull(V, perObject, descs, cbPerFrame, maxRaySamples, volumeInfo=None, mode="
     _dispatch("CSVolumeCull", mode, ((V + 3) // 4, 1, 1), (8, 4, 1), wave=32, cluster=8)
     nv, nc = int(lib.dxref_counter(UAV, 0, 0)), int(lib.dxref_counter(UAV, 2, 2))
     return info, np.sort(vis[:nv]), np.sort(cube[:nc])
+
+
+TEXCUBE = 8
+
+
+def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame, volumeInfo, visible, cubeMaps, cubeDepths,
+              mode="fp32", fused_mad=False):
+    """The K-buffer OIT composite through the reference's three compiled pixel shaders: PSDepthPeel.cso (InterlockedMin peel into 8
+    depth layers), PSCube.cso (CubeCast or the screen-space RayCast per fragment, stored into the layer whose depth matches) and
+    PSResolveOIT.cso (front-to-back resolve), one invocation per fragment / pixel.  What the rasteriser would feed them -- one
+    fragment per visible cube where the pixel's view ray leaves it, with VSCube's interpolated outputs -- comes from the oracle's
+    analytic stand-in (mvo_pixel_fragments; UVW.xy = the exit point's cube-face (s, t) as VSCube.hlsl:69 defines it): that part,
+    the TextureCube footprint across face edges and the samplers are the oracle's contract, everything inside the shaders is the
+    reference's.  Returns the RGBA16F image [H, W, 4] u16 like mv_oracle.composite."""
+    lib = load()
+    olib = O.load()
+    lib.dxref_run_invocations.restype = C.c_int
+    lib.dxref_run_invocations.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    olib.mvo_pixel_fragments.restype = C.c_uint32
+    olib.mvo_pixel_fragments.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 3
+    olib.mvo_cube_face_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    chain = O.cube_chain_texels(N)
+    vols = [np.ascontiguousarray(v).view(np.uint16) for v in volumes]
+    lm = np.ascontiguousarray(lightMaps, np.uint32)
+    dm = np.ascontiguousarray(depthMap, np.float32)
+    po = np.ascontiguousarray(perObject).view(np.uint8).copy()
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8).copy()
+    vi = np.ascontiguousarray(volumeInfo, np.uint16)
+    vis = np.ascontiguousarray(visible, np.uint32)
+    cm = np.ascontiguousarray(cubeMaps, np.uint16)
+    cd = np.ascontiguousarray(cubeDepths, np.float32)
+
+    # fragments of every pixel (list order within a pixel)
+    vol_buf, lpt_buf, z_buf = np.zeros(max(V, 1), np.uint32), np.zeros((max(V, 1), 3), np.float32), np.zeros(max(V, 1), np.float32)
+    frags = []
+    face, st = C.c_uint32(), np.zeros(2, np.float32)
+    for py in range(H):
+        for px in range(W):
+            n = olib.mvo_pixel_fragments(W, H, px, py, po.ctypes.data, cb.ctypes.data, vis.ctypes.data, len(vis),
+                                         vol_buf.ctypes.data, lpt_buf.ctypes.data, z_buf.ctypes.data)
+            for k in range(n):
+                olib.mvo_cube_face_coords(lpt_buf[k].ctypes.data, C.byref(face), st.ctypes.data)
+                frags.append((px, py, int(vol_buf[k]), lpt_buf[k].copy(), float(z_buf[k]), float(st[0]), float(st[1]), int(face.value)))
+    nf = len(frags)
+    inputs = np.zeros((max(nf, 1), 8, 4), np.uint32)
+    fv = inputs.view(np.float32)
+    for i, (px, py, v, lpt, z, s, t, f) in enumerate(frags):
+        fv[i, 0] = (px + 0.5, py + 0.5, z, 1.0)                      # SV_Position
+        fv[i, 1, :3] = (s, t, float(f))                              # TEXCOORD = UVW
+        fv[i, 2, :3] = lpt                                           # POSLOCAL
+        inputs[i, 3, 0] = v                                          # VOLUMEID
+        inputs[i, 4, 0] = 5 * v + int(vi[v, 0])                      # SRVINDEX = NUM_CUBE_MIP * volume + mip (VSCube.hlsl:73)
+        inputs[i, 5, 0] = int(vi[v, 3])                              # VOLTEXID
+        inputs[i, 6, 0] = 0 if (int(vi[v, 2]) & 0x8000) else int(vi[v, 1])  # SAMPLECOUNT (0 = cube-map scheme)
+
+    k_depths = np.full((8, H, W), 0xffffffff, np.uint32)
+    k_colors = np.zeros((8, H, W, 4), np.uint16)
+    lib.dxref_set_fused_mad(1 if fused_mad else 0)
+
+    # pass 1: depth peel
+    lib.dxref_reset()
+    _bind(UAV, 0, 0, TEX2DARRAY, F_R32U, k_depths, W, H, 8)
+    if nf:
+        assert lib.dxref_run_invocations(_entry("PSDepthPeel", mode), nf, inputs.ctypes.data, None) == 0
+
+    # pass 2: colour of every fragment into its layer
+    lib.dxref_reset()
+    for v in range(V):
+        _bind(SRV, 0, 3 + v, TEX3D, F_R11G11B10F, lm[v], L, L, L)
+        for mip in range(5):
+            dim = N >> mip
+            if dim:
+                off = O.cube_mip_offset(N, mip)
+                _bind(SRV, 4, 5 * v + mip, TEXCUBE, F_RGBA16F, cm[v][off:], dim, dim, 6)
+                _bind(SRV, 5, 5 * v + mip, TEXCUBE, F_R32F, cd[v][off:], dim, dim, 6)
+    for i, g in enumerate(vols):
+        _bind(SRV, 1, i, TEX3D, F_RGBA16F, g, N, N, N)
+    _bind(SRV, 2, 0, TEX2D, F_R32F, dm, W, H, 1)
+    _bind(SRV, 3, 0, RAW, F_NONE, po, V, 0, 0, 224)
+    _bind(SRV, 6, 1, TEX2DARRAY, F_R32U, k_depths, W, H, 8)
+    _bind(UAV, 0, 0, TEX2DARRAY, F_RGBA16F, k_colors, W, H, 8)
+    _bind(CBV, 0, 0, CBUF, F_NONE, cb, len(cb))
+    _bind(SAMPLER, 0, 0, SAMPLER_KIND, F_NONE, None)
+    if nf:
+        assert lib.dxref_run_invocations(_entry("PSCube", mode), nf, inputs.ctypes.data, None) == 0
+
+    # pass 3: resolve, one invocation per pixel
+    lib.dxref_reset()
+    _bind(SRV, 0, 0, TEX2DARRAY, F_RGBA16F, k_colors, W, H, 8)
+    pin = np.zeros((W * H, 8, 4), np.uint32)
+    pf = pin.view(np.float32)
+    ys, xs = np.mgrid[0:H, 0:W]
+    pf[:, 0, 0] = xs.ravel() + 0.5
+    pf[:, 0, 1] = ys.ravel() + 0.5
+    pf[:, 0, 3] = 1.0
+    out = np.zeros((W * H, 4), np.float32)
+    assert lib.dxref_run_invocations(_entry("PSResolveOIT", mode), W * H, pin.ctypes.data, out.ctypes.data) == 0
+    img = np.array([olib.mvo_f32_to_f16(float(x)) for x in out.ravel()], np.uint16).reshape(H, W, 4)
+    return img

@@ -1,11 +1,11 @@
 /*
  * mv_oracle.cpp -- CPU ORACLE (test infrastructure, NOT product code; see mv_oracle.h).
  *
- * PARITY: the cull, the light march and the view march (a1, a2, a3) are PINNED to the reference's shipped compiled shaders
- * (Bin/*.cso run on the CPU through oracle/dxil -> oracle/_ref/libmv_dxref.so; tests/test_oracle_vs_reference_dxil.py: cull identical
+ * PARITY: the cull, the light march, the view march and the composite's shaders (a1, a2, a3, a7) are PINNED to the reference's shipped compiled shaders
+ * (the .cso files under Bin, run on the CPU through oracle/dxil -> oracle/_ref/libmv_dxref.so; tests/test_oracle_vs_reference_dxil.py: cull identical
  * in 400 / 400 cases, view march bit-identical, light maps bit-identical without the probe), with the fixed-function sampler and the
- * format conversions as a stated contract the bytecode does not contain.  The composite (a7) is UNPINNED: no reference test, golden
- * vector or runnable reference exists for it (its pixel shaders need a rasteriser's interpolated inputs).
+ * format conversions as a stated contract the bytecode does not contain.  For the composite the rasteriser is a contract too: the
+ * fragments its three pixel shaders run on come from this file's analytic stand-in (exitFragment), the shaders are the reference's.
  * Line-for-line scalar fp32 restatement of the reference HLSL:
  *   Sh/Common.hlsli, SharedConsts.h, Sh/RayMarch.hlsli, Sh/CSRayMarch.hlsl (+CSRayMarchV.hlsl),
  *   Sh/CSRayMarchL.hlsl, Sh/CSVolumeCull.hlsl, Sh/VolumeCull.hlsli,
@@ -1063,17 +1063,29 @@ inline float UnprojectZ(float depth)	// PSCube.hlsli:21-26
 }
 
 // CubeCast (PSCube.hlsli:51-108) + GetDomain (:31-46)
+// The four texels a TextureCube Gather / bilinear SampleLevel at direction `dir` touches on a d x d cube map, in Gather order
+// ((0,1), (1,1), (1,0), (0,0)), and the bilinear weights of the same footprint: the sampler contract shared with oracle/dxil.
+void cubeFootprint(float3 dir, int32_t d, size_t idx[4], float wl[4])
+{
+	const CubeCoord cc = cubeFaceCoords(dir);
+	const float gridSize = (float)d;
+	const float u = cc.s * gridSize - 0.5f, v = cc.t * gridSize - 0.5f;
+	const int32_t i0 = f2i_floor(u), j0 = f2i_floor(v);
+	const float fx = u - floorf(u), fy = v - floorf(v);
+	idx[0] = cubeTexelIndex(cc.face, i0, j0 + 1, d); idx[1] = cubeTexelIndex(cc.face, i0 + 1, j0 + 1, d);
+	idx[2] = cubeTexelIndex(cc.face, i0 + 1, j0, d); idx[3] = cubeTexelIndex(cc.face, i0, j0, d);
+	wl[0] = (1.0f - fx) * fy; wl[1] = fx * fy; wl[2] = fx * (1.0f - fy); wl[3] = (1.0f - fx) * (1.0f - fy);
+}
+
 float4 CubeCast(const uint16_t* cubeMap, const float* cubeDepth, int32_t d, float depthPix, float3 pos, float3 rayDir)
 {
 	const CubeCoord cc = cubeFaceCoords(pos);
 	const float gridSize = (float)d;
 
 	// gather footprint
-	const float u = cc.s * gridSize - 0.5f, v = cc.t * gridSize - 0.5f;
-	const int32_t i0 = f2i_floor(u), j0 = f2i_floor(v);
-	const float fx = u - floorf(u), fy = v - floorf(v);
-	const size_t idx[4] = { cubeTexelIndex(cc.face, i0, j0 + 1, d), cubeTexelIndex(cc.face, i0 + 1, j0 + 1, d),
-		cubeTexelIndex(cc.face, i0 + 1, j0, d), cubeTexelIndex(cc.face, i0, j0, d) };
+	size_t idx[4];
+	float wl[4];
+	cubeFootprint(pos, d, idx, wl);
 	float smp[4][4], z[4];
 	for (int k = 0; k < 4; ++k)
 	{
@@ -1082,7 +1094,6 @@ float4 CubeCast(const uint16_t* cubeMap, const float* cubeDepth, int32_t d, floa
 	}
 
 	// SampleLevel fallback colour: plain bilinear over the same footprint
-	const float wl[4] = { (1.0f - fx) * fy, fx * fy, fx * (1.0f - fy), (1.0f - fx) * (1.0f - fy) };
 	float color[4];
 	for (int ch = 0; ch < 4; ++ch) color[ch] = smp[0][ch] * wl[0] + smp[1][ch] * wl[1] + smp[2][ch] * wl[2] + smp[3][ch] * wl[3];
 
@@ -1116,11 +1127,84 @@ float4 CubeCast(const uint16_t* cubeMap, const float* cubeDepth, int32_t d, floa
 	return r;
 }
 
+// The fragment the reference's rasteriser produces for one visible cube at one pixel (VSCube.hlsl:51-76 + front-face culling, no depth
+// test: MultiRayCaster.cpp:868-869, 897-898): where the pixel's view ray leaves the cube.  Found analytically (slab test in volume
+// space) instead of by rasterisation.  Returns false when there is none; lpt = the exit point in volume space (VSCube's LPt,
+// interpolated), z = its depth (SV_Position.z).
+bool exitFragment(const PerObject& po, float3 eyePt, float3 dirW, float3& lpt, float& z)
+{
+	const float3 o = mul43(eyePt, po.worldI);
+	const float3 d = mul33(dirW, po.worldI);	// the pixel's world-space ray direction in volume space
+
+	// slab test from the eye along d
+	float tNear = -kFltMax, tFar = kFltMax;
+	int farAxis = -1;
+	bool miss = false;
+	for (int a = 0; a < 3; ++a)
+	{
+		const float da = idx(d, a), oa = idx(o, a);
+		if (da == 0.0f) { if (fabsf(oa) > 1.0f) miss = true; continue; }
+		const float sgn = da > 0.0f ? 1.0f : -1.0f;
+		const float tn = (-sgn - oa) / da, tf = (sgn - oa) / da;
+		if (tn > tNear) tNear = tn;
+		if (tf < tFar) { tFar = tf; farAxis = a; }
+	}
+	if (miss || farAxis < 0 || !(tFar > 0.0f) || !(tNear <= tFar)) return false;
+
+	lpt = f3(fmaf(d.x, tFar, o.x), fmaf(d.y, tFar, o.y), fmaf(d.z, tFar, o.z));
+	lpt = f3(clampf(lpt.x, -1.0f, 1.0f), clampf(lpt.y, -1.0f, 1.0f), clampf(lpt.z, -1.0f, 1.0f));
+	const float snap = idx(d, farAxis) > 0.0f ? 1.0f : -1.0f;
+	if (farAxis == 0) lpt.x = snap; else if (farAxis == 1) lpt.y = snap; else lpt.z = snap;
+
+	float4 lp = { lpt.x, lpt.y, lpt.z, 1.0f };
+	const float4 clip = mul44(lp, po.wvp);
+	if (!(clip.w > 0.0f)) return false;
+	z = clip.z / clip.w;
+	return z >= 0.0f && z < 1.0f;
+}
+
+// the pixel's view ray in world space: unproject its near and far points with g_screenToWorld (Common.hlsli:43)
+float3 pixelRayWorld(const CBPerFrame& cb, float nx, float ny)
+{
+	float4 c0 = { nx, ny, 0.0f, 1.0f }, c1 = { nx, ny, 1.0f, 1.0f };
+	const float4 h0 = mul44(c0, cb.screenToWorld), h1 = mul44(c1, cb.screenToWorld);
+	return f3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w) - f3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w);
+}
+
 struct Fragment { uint32_t zbits; uint32_t volume; float3 lpt; };
 } // namespace
 
 extern "C" {
 float mvo_unproject_z(float depth) { return UnprojectZ(depth); }
+
+void mvo_cube_footprint(const float dir[3], uint32_t d, uint64_t idx[4], float weights[4])
+{
+	size_t i[4];
+	cubeFootprint(f3(dir[0], dir[1], dir[2]), (int32_t)d, i, weights);
+	for (int k = 0; k < 4; ++k) idx[k] = i[k];
+}
+
+// every fragment of pixel (px, py): volume ids (in list order), exit points and depths; returns their number (<= visibleCount)
+uint32_t mvo_pixel_fragments(uint32_t W, uint32_t H, uint32_t px, uint32_t py, const void* perObjectBytes, const void* cbBytes,
+	const uint32_t* visibleVolumes, uint32_t visibleCount, uint32_t* volume, float* lpt3, float* z)
+{
+	const PerObject* perObjects = (const PerObject*)perObjectBytes;
+	CBPerFrame cb;
+	memcpy(&cb, cbBytes, sizeof(cb));
+	float nx = ((float)px + 0.5f) / (float)W, ny = ((float)py + 0.5f) / (float)H;
+	nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
+	const float3 dirW = pixelRayWorld(cb, nx, ny);
+	uint32_t n = 0;
+	for (uint32_t k = 0; k < visibleCount; ++k)
+	{
+		float3 l;
+		float zz;
+		if (!exitFragment(perObjects[visibleVolumes[k]], f3(cb.eyePos[0], cb.eyePos[1], cb.eyePos[2]), dirW, l, zz)) continue;
+		volume[n] = visibleVolumes[k]; lpt3[3 * n] = l.x; lpt3[3 * n + 1] = l.y; lpt3[3 * n + 2] = l.z; z[n] = zz;
+		++n;
+	}
+	return n;
+}
 
 // CubeCast on one cube map / cube depth of edge d (layout uint16[6][d][d][4] / float[6][d][d]) for the KATs
 void mvo_cube_cast(const uint16_t* cubeMap, const float* cubeDepth, uint32_t d, float depthPix, const float pos[3], const float rayDir[3], float out[4])
@@ -1181,13 +1265,7 @@ extern "C" void mvo_composite_over(uint32_t V, uint32_t N, uint32_t L, uint32_t 
 			float nx = ((float)px + 0.5f) / (float)W, ny = ((float)py + 0.5f) / (float)H;
 			nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
 			const float depthPix = depthMap[(size_t)py * W + px];
-			// the pixel's view ray in world space: unproject its near and far points with g_screenToWorld (Common.hlsli:43)
-			float3 dirW;
-			{
-				float4 c0 = { nx, ny, 0.0f, 1.0f }, c1 = { nx, ny, 1.0f, 1.0f };
-				const float4 h0 = mul44(c0, cb.screenToWorld), h1 = mul44(c1, cb.screenToWorld);
-				dirW = f3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w) - f3(h0.x / h0.w, h0.y / h0.w, h0.z / h0.w);
-			}
+			const float3 dirW = pixelRayWorld(cb, nx, ny);
 
 			Fragment frags[MVO_NUM_OIT_LAYERS];
 			uint32_t nFrags = 0;
@@ -1195,34 +1273,9 @@ extern "C" void mvo_composite_over(uint32_t V, uint32_t N, uint32_t L, uint32_t 
 			{
 				const uint32_t v = visibleVolumes[k];
 				const PerObject& po = perObjects[v];
-				const float3 o = mul43(eyePt, po.worldI);
-				const float3 d = mul33(dirW, po.worldI);	// the pixel's world-space ray direction in volume space
-
-				// slab test from the eye along d
-				float tNear = -kFltMax, tFar = kFltMax;
-				int farAxis = -1;
-				bool miss = false;
-				for (int a = 0; a < 3; ++a)
-				{
-					const float da = idx(d, a), oa = idx(o, a);
-					if (da == 0.0f) { if (fabsf(oa) > 1.0f) miss = true; continue; }
-					const float sgn = da > 0.0f ? 1.0f : -1.0f;
-					const float tn = (-sgn - oa) / da, tf = (sgn - oa) / da;
-					if (tn > tNear) tNear = tn;
-					if (tf < tFar) { tFar = tf; farAxis = a; }
-				}
-				if (miss || farAxis < 0 || !(tFar > 0.0f) || !(tNear <= tFar)) continue;
-
-				float3 lpt = f3(fmaf(d.x, tFar, o.x), fmaf(d.y, tFar, o.y), fmaf(d.z, tFar, o.z));
-				lpt = f3(clampf(lpt.x, -1.0f, 1.0f), clampf(lpt.y, -1.0f, 1.0f), clampf(lpt.z, -1.0f, 1.0f));
-				const float snap = idx(d, farAxis) > 0.0f ? 1.0f : -1.0f;
-				if (farAxis == 0) lpt.x = snap; else if (farAxis == 1) lpt.y = snap; else lpt.z = snap;
-
-				float4 lp = { lpt.x, lpt.y, lpt.z, 1.0f };
-				const float4 clip = mul44(lp, po.wvp);
-				if (!(clip.w > 0.0f)) continue;
-				const float z = clip.z / clip.w;
-				if (!(z >= 0.0f && z < 1.0f)) continue;
+				float3 lpt;
+				float z;
+				if (!exitFragment(po, eyePt, dirW, lpt, z)) continue;
 
 				// PSDepthPeel.hlsl:12-24: keep the NUM_OIT_LAYERS smallest depths, ascending
 				Fragment f; f.zbits = asuint(z); f.volume = v; f.lpt = lpt;

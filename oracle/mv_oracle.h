@@ -6,9 +6,9 @@
  *
  * PARITY: the reference ships no tests or golden vectors and its sources cannot be built here (HLSL -> DXIL via a
  * Windows-only dxc.exe, D3D12 + closed XUSG.dll) -- but it ships its COMPILED shaders, and oracle/dxil runs those on the CPU
- * (oracle/_ref/libmv_dxref.so).  Cull, light march and view march of this file are PINNED to them
- * (tests/test_oracle_vs_reference_dxil.py; vectors in tests/golden/dxil_small.npz); the composite and the fixed-function sampler
- * are UNPINNED (a stated contract).  This file is a line-for-line scalar fp32 restatement of the HLSL, also anchored by analytic
+ * (oracle/_ref/libmv_dxref.so).  Cull, light march, view march and the composite's pixel shaders of this file are PINNED to them
+ * (tests/test_oracle_vs_reference_dxil.py; vectors in tests/golden/dxil_small.npz); the fixed-function stages -- sampler, format
+ * conversion, rasteriser -- are a stated contract.  This file is a line-for-line scalar fp32 restatement of the HLSL, also anchored by analytic
  * known-answer tests (tests/test_oracle_kat*.py) derived from the shader math.
  *
  * Every function cites the reference file:line it follows (paths relative to
@@ -121,7 +121,11 @@ float mvo_unproject_z(float depth);                                             
 void  mvo_cube_cast(const uint16_t* cubeMap, const float* cubeDepth, uint32_t d, float depthPix,
 	const float pos[3], const float rayDir[3], float out[4]);                       /* Sh/PSCube.hlsli:31-108 */
 void  mvo_cube_face_coords(const float dir[3], uint32_t* face, float st[2]);       /* D3D TextureCube face selection */
-uint64_t mvo_cube_texel_index(uint32_t face, int32_t i, int32_t j, uint32_t d);    /* Gather tap -> texel, across face edges */
+uint64_t mvo_cube_texel_index(uint32_t face, int32_t i, int32_t j, uint32_t d);
+void  mvo_cube_footprint(const float dir[3], uint32_t d, uint64_t idx[4], float weights[4]); /* Gather order + bilinear weights */
+/* every fragment (one per visible cube the pixel's ray leaves) of pixel (px, py): the analytic stand-in for VSCube + rasteriser */
+uint32_t mvo_pixel_fragments(uint32_t W, uint32_t H, uint32_t px, uint32_t py, const void* perObject, const void* cbPerFrame,
+	const uint32_t* visibleVolumes, uint32_t visibleCount, uint32_t* volume, float* lpt3, float* z);    /* Gather tap -> texel, across face edges */
 /* optional modes, off by default: filter weights snapped to `weightBits` fractional bits (0 = exact fp32); the view march as
  * Sh/LibRayMarch.hlsl:205-287 states it (no ComputeTargetHit clamp) */
 void  mvo_set_options(int weightBits, int libRayMarch);

@@ -80,7 +80,8 @@ def test_gpu_matches_golden():
 def test_oracle_reproduces_dxil_golden(oracle):
     """tests/golden/dxil_small.npz holds what the REFERENCE'S SHIPPED COMPILED SHADERS (CSVolumeCull / CSRayMarchL / CSRayMarchV .cso, run
     on the CPU through oracle/dxil, made by tests/golden/make_dxil_golden.py) produce for a small seeded frame: VolumeInfo and lists,
-    the light maps after four frames, every cube map and cube depth.  The oracle reproduces all of it bit for bit -- on any machine,
+    the light maps after four frames, every cube map and cube depth, and the composite through PSDepthPeel / PSCube / PSResolveOIT .cso.
+    The oracle reproduces all of it bit for bit -- on any machine,
     without the reference and without the translated library."""
     import importlib.util
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_dxil_golden.py")
@@ -89,9 +90,9 @@ def test_oracle_reproduces_dxil_golden(oracle):
     spec.loader.exec_module(mod)
     g = np.load(os.path.join(os.path.dirname(path), "dxil_small.npz"))
     out = mod.oracle_run()
-    for k in ("info", "vis", "cube", "lightMaps", "cubeMaps", "cubeDepths"):
+    for k in ("info", "vis", "cube", "lightMaps", "cubeMaps", "cubeDepths", "composite"):
         assert np.array_equal(out[k], g[k]), k
-    assert len(g["cube"]) > 0 and g["cubeMaps"].any() and g["lightMaps"].any()
+    assert len(g["cube"]) > 0 and g["cubeMaps"].any() and g["lightMaps"].any() and (g["composite"][..., 3] != 0).sum() > 500
 
 
 @pytest.mark.gpu
@@ -135,3 +136,5 @@ def test_gpu_matches_dxil_golden():
             off = cube_mip_offset(N, mip)
             assert np.array_equal(mc.ReadBackCubeMap(int(v), mip), g["cubeMaps"][v][off:off + 6 * d * d].reshape(6, d, d, 4)), f"cube map of volume {v}"
             assert np.array_equal(mc.ReadBackCubeDepth(int(v), mip), g["cubeDepths"][v][off:off + 6 * d * d].reshape(6, d, d))
+        mc.composite()
+        assert np.array_equal(mc.ReadBackComposite(), g["composite"]), "composite"

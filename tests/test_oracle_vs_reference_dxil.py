@@ -97,3 +97,23 @@ def test_light_march_equals_the_compiled_light_march(oracle, use_sh):
             lib.mvo_unpack_r11g11b10f(int(x), rc._ptr(g))
             lib.mvo_unpack_r11g11b10f(int(y), rc._ptr(e))
             assert np.max(np.abs(g - e) / np.maximum(np.abs(e), 1e-6)) <= 1.0 / 32
+
+
+@pytest.mark.parametrize("name,W,H,eye", [("T1", 96, 64, None), ("T1", 96, 64, (18.0, 14.0, -38.0)), ("T2", 80, 56, None), ("T2", 80, 56, (30.0, 10.0, -45.0))])
+def test_composite_equals_the_compiled_pixel_shaders(oracle, name, W, H, eye):
+    """a7 through PSDepthPeel.cso + PSCube.cso (CubeCast and the screen-space RayCast) + PSResolveOIT.cso, one invocation per fragment /
+    pixel: the image equals the oracle's composite bit for bit.  The fragments (one per visible cube where the pixel's ray leaves it,
+    with VSCube's interpolated outputs), the TextureCube footprint across face edges and the samplers are the oracle's stand-ins
+    for rasteriser and texture unit -- what happens inside the three shaders (peel by InterlockedMin, layer matching, GetDomain, the
+    depth weights, the ws == 0 fallback, RayCast's march, the resolve and its 0.9997 clamp) is the reference's compiled code."""
+    cfg = dict(scene.CONFIGS[name], W=W, H=H)
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    ref = oracle_pipeline(oracle, cfg, vols, 32, eye=eye)
+    args = (V, N, L, W, H, vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], ref["info"], ref["vis"], ref["cubeMaps"], ref["cubeDepths"])
+    img, _ = oracle.composite(*args)
+    got = dxref.composite(*args)
+    assert (img[..., 3] != 0).sum() > 200
+    assert np.array_equal(got, img), f"{int((got != img).sum())} halves differ"
+    schemes = {bool(int(ref["info"][v, 2]) & 0x8000) for v in ref["vis"]}
+    print(f"{name} {W}x{H}: {int((img[..., 3] != 0).sum())} covered pixels, schemes present (cube map = True): {sorted(schemes)}")
