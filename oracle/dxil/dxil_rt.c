@@ -274,8 +274,9 @@ void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, floa
 	}
 	else if (t->kind == DXR_TEX3D && t->fmt == DXF_R32F)
 	{
-		/* CSR32FToRGBA16F's source: a linear sampler on an R32F volume -- the oracle's converter exposes the whole pass only */
-		fprintf(stderr, "dxil_rt: sampleLevel on an R32F volume is not wired (use mvo_r32f_to_rgba16f's KAT instead)\n"); abort();
+		const float uvw[3] = { c0, c1, c2 };
+		out->v[0] = mvo_sample_r32f_3d((const float*)t->data, t->w, t->h, t->d, uvw);
+		out->v[3] = 1.0f;
 	}
 	else if (t->kind == DXR_TEXCUBE)
 	{

@@ -268,3 +268,29 @@ def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame
     assert lib.dxref_run_invocations(_entry("PSResolveOIT", mode), W * H, pin.ctypes.data, out.ctypes.data) == 0
     img = np.array([olib.mvo_f32_to_f16(float(x)) for x in out.ravel()], np.uint16).reshape(H, W, 4)
     return img
+
+
+def init_grid_data(N, mode="fp32"):
+    """CSInitGridData.cso into an RGBA16F volume of edge N (groups of 4 x 4 x 4): same result as mv_oracle.init_grid_data."""
+    lib = load()
+    lib.dxref_reset()
+    out = np.zeros((N, N, N, 4), np.uint16)
+    _bind(UAV, 0, 0, TEX3D, F_RGBA16F, out, N, N, N)
+    g = (N + 3) // 4
+    _dispatch("CSInitGridData", mode, (g, g, g), (4, 4, 4))
+    return out
+
+
+def r32f_to_rgba16f(src, N, mode="fp32"):
+    """CSR32FToRGBA16F.cso: an R32F volume [d, h, w] resampled (linear sampler) into an RGBA16F volume of edge N."""
+    lib = load()
+    lib.dxref_reset()
+    src = np.ascontiguousarray(src, np.float32)
+    d, h, w = src.shape
+    out = np.zeros((N, N, N, 4), np.uint16)
+    _bind(SRV, 0, 0, TEX3D, F_R32F, src, w, h, d)
+    _bind(UAV, 0, 0, TEX3D, F_RGBA16F, out, N, N, N)
+    _bind(SAMPLER, 0, 0, SAMPLER_KIND, F_NONE, None)
+    g = (N + 3) // 4
+    _dispatch("CSR32FToRGBA16F", mode, (g, g, g), (4, 4, 4))
+    return out

@@ -671,6 +671,19 @@ void mvo_init_grid_data(uint32_t N, uint16_t* rgba)
 }
 
 // CSR32FToRGBA16F.hlsl:16-26 -- Texture3D<float>.SampleLevel(LINEAR_CLAMP) of a w x h x d R32F source
+// Texture3D<float>.SampleLevel(LINEAR_CLAMP, uvw, 0) on an R32F volume of w x h x d texels (the sampler contract, also used by oracle/dxil)
+float mvo_sample_r32f_3d(const float* src, uint32_t w, uint32_t h, uint32_t d, const float uvw[3])
+{
+	const Taps tx = linearTaps(uvw[0], w, 0), ty = linearTaps(uvw[1], h, 0), tz = linearTaps(uvw[2], d, 0);
+#define SRC(i, j, k) src[((size_t)(k) * h + (j)) * w + (i)]
+	const float c00 = lerpf(SRC(tx.i0, ty.i0, tz.i0), SRC(tx.i1, ty.i0, tz.i0), tx.f);
+	const float c10 = lerpf(SRC(tx.i0, ty.i1, tz.i0), SRC(tx.i1, ty.i1, tz.i0), tx.f);
+	const float c01 = lerpf(SRC(tx.i0, ty.i0, tz.i1), SRC(tx.i1, ty.i0, tz.i1), tx.f);
+	const float c11 = lerpf(SRC(tx.i0, ty.i1, tz.i1), SRC(tx.i1, ty.i1, tz.i1), tx.f);
+#undef SRC
+	return lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+}
+
 void mvo_r32f_to_rgba16f(const float* src, uint32_t w, uint32_t h, uint32_t d, uint32_t N, uint16_t* rgba)
 {
 	const float gridSize = (float)N;
@@ -680,15 +693,8 @@ void mvo_r32f_to_rgba16f(const float* src, uint32_t w, uint32_t h, uint32_t d, u
 		for (uint32_t y = 0; y < N; ++y)
 			for (uint32_t x = 0; x < N; ++x)
 			{
-				const float3 uvw = f3(((float)x + 0.5f) / gridSize, ((float)y + 0.5f) / gridSize, ((float)z + 0.5f) / gridSize);
-				const Taps tx = linearTaps(uvw.x, w, 0), ty = linearTaps(uvw.y, h, 0), tz = linearTaps(uvw.z, d, 0);
-#define SRC(i, j, k) src[((size_t)(k) * h + (j)) * w + (i)]
-				const float c00 = lerpf(SRC(tx.i0, ty.i0, tz.i0), SRC(tx.i1, ty.i0, tz.i0), tx.f);
-				const float c10 = lerpf(SRC(tx.i0, ty.i1, tz.i0), SRC(tx.i1, ty.i1, tz.i0), tx.f);
-				const float c01 = lerpf(SRC(tx.i0, ty.i0, tz.i1), SRC(tx.i1, ty.i0, tz.i1), tx.f);
-				const float c11 = lerpf(SRC(tx.i0, ty.i1, tz.i1), SRC(tx.i1, ty.i1, tz.i1), tx.f);
-#undef SRC
-				const float a = lerpf(lerpf(c00, c10, ty.f), lerpf(c01, c11, ty.f), tz.f);
+				const float uvw[3] = { ((float)x + 0.5f) / gridSize, ((float)y + 0.5f) / gridSize, ((float)z + 0.5f) / gridSize };
+				const float a = mvo_sample_r32f_3d(src, w, h, d, uvw);
 				uint16_t* o = rgba + 4 * (((size_t)z * N + y) * N + x);
 				o[0] = one; o[1] = one; o[2] = one; o[3] = f2h(a * 0.25f);
 			}

@@ -62,6 +62,7 @@ uint64_t mvo_cube_mip_offset(uint32_t N, uint32_t mip);
 void  mvo_sample_rgba16f(const uint16_t* tex, uint32_t N, const float uvw[3], const int32_t off[3], float out[4]);
 void  mvo_sample_r11g11b10f(const uint32_t* tex, uint32_t L, const float uvw[3], float out[3]);
 float mvo_sample_point_r32f(const float* tex, uint32_t W, uint32_t H, float u, float v);
+float mvo_sample_r32f_3d(const float* src, uint32_t w, uint32_t h, uint32_t d, const float uvw[3]); /* trilinear, clamp */
 float mvo_sample_cmp_d16(const uint16_t* tex, uint32_t M, float u, float v, float ref);
 
 /* ---- device functions of Sh/RayMarch.hlsli exposed for known-answer tests ---- */

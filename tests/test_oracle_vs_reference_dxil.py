@@ -117,3 +117,13 @@ def test_composite_equals_the_compiled_pixel_shaders(oracle, name, W, H, eye):
     assert np.array_equal(got, img), f"{int((got != img).sum())} halves differ"
     schemes = {bool(int(ref["info"][v, 2]) & 0x8000) for v in ref["vis"]}
     print(f"{name} {W}x{H}: {int((img[..., 3] != 0).sum())} covered pixels, schemes present (cube map = True): {sorted(schemes)}")
+
+
+def test_producers_equal_the_compiled_producers(oracle):
+    """a6: CSInitGridData.cso and CSR32FToRGBA16F.cso (its linear sampler on the R32F source = the oracle's, the contract)."""
+    for N in (16, 22, 40):
+        assert np.array_equal(dxref.init_grid_data(N), oracle.init_grid_data(N)), N
+    rng = np.random.default_rng(3)
+    for shape, N in (((12, 10, 14), 16), ((20, 20, 20), 20), ((7, 9, 5), 24)):
+        src = rng.random(shape, dtype=np.float32) * 3
+        assert np.array_equal(dxref.r32f_to_rgba16f(src, N), oracle.r32f_to_rgba16f(src, N)), (shape, N)
