@@ -450,20 +450,21 @@ float3 GetDensityGradient(const uint16_t* tex, uint32_t N, float3 uvw)
 // XUSG/Shaders/SHIrradianceTypeless.hlsli:15-36
 float3 EvaluateSHIrradiance(const float* sh /* 9 x float3 */, float3 norm)
 {
-	const float c1 = 0.42904276540489171563379376569857f;
-	const float c2 = 0.51166335397324424423977581244463f;
-	const float c3 = 0.24770795610037568833406429782001f;
-	const float c4 = 0.88622692545275801364908374167057f;
+	// XUSG/Shaders/SHIrradiance.hlsli as the reference's compiler emitted it inside CSRayMarchL.cso (oracle/dxil): the constants folded
+	// to fp32 (3 c3 and 2 c1, 2 c2 as single constants), the sum in this order
+	const float c1 = 0.4290427565574646f, c3x3 = 0.7431238889694214f, c3 = 0.24770796298980713f, c4 = 0.8862269520759583f;
+	const float c1x2 = 0.8580855131149292f, c2x2 = 1.0233267545700073f;
 	const float x = -norm.x, y = -norm.y, z = norm.z;
 	float r[3];
 	for (int ch = 0; ch < 3; ++ch)
 	{
 #define SHC(i) sh[3 * (i) + ch]
-		const float v = (c1 * (x * x - y * y)) * SHC(8)
-			+ (c3 * (3.0f * z * z - 1.0f)) * SHC(6)
-			+ c4 * SHC(0)
-			+ 2.0f * c1 * (SHC(4) * x * y + SHC(7) * x * z + SHC(5) * y * z)
-			+ 2.0f * c2 * (SHC(3) * x + SHC(1) * y + SHC(2) * z);
+		const float t8 = (norm.x * norm.x - norm.y * norm.y) * c1 * SHC(8);
+		const float t6 = (z * z * c3x3 + -c3) * SHC(6);
+		const float t0 = SHC(0) * c4;
+		const float q = ((z * SHC(5) + SHC(4) * x) * y + SHC(7) * x * z) * c1x2;
+		const float l = (SHC(3) * x + SHC(1) * y + z * SHC(2)) * c2x2;
+		const float v = t6 + t0 + t8 + l + q;
 #undef SHC
 		r[ch] = fmaxf(0.0f, v);
 	}
