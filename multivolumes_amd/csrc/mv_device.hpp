@@ -667,7 +667,7 @@ __device__ __forceinline__ float GetStep(float dDensity, float transm, float den
 	const float factorEv = __builtin_fminf(1.0f / 256.0f / __builtin_fabsf(dDensity), 2.0f);
 	const float factorUi = __builtin_fminf(1.0f - density, 1.0f);
 	const float factorTh = 1.0f - transm;
-	step *= __builtin_fmaxf(1.5f * factorEv * factorUi * factorTh, 1.0f);
+	step *= __builtin_fmaxf(factorTh * 1.5f * factorEv * factorUi, 1.0f);	// the compiled order: ((factorTh * 1.5) * factorEv) * factorUi
 	return step;
 }
 

@@ -752,7 +752,8 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 		const VolumeView vol0 = makeVolumeView(st.volumes[volTexId0], st.alphaCells[volTexId0], st.N, st.bricks);
 
 		vec3 rayOrigin = v3(((float)xx + 0.5f) / gridSize * 2.0f - 1.0f, ((float)yy + 0.5f) / gridSize * 2.0f - 1.0f, ((float)zz + 0.5f) / gridSize * 2.0f - 1.0f);
-		const vec3 uvw = LocalToTex3DSpace(rayOrigin);
+		// LocalToTex3DSpace(rayOrigin) = ((x + 0.5) / L * 2 - 1) * 0.5 + 0.5, compiled (fast math) as (x + 0.5) / L
+		const vec3 uvw = v3(((float)xx + 0.5f) / gridSize, ((float)yy + 0.5f) / gridSize, ((float)zz + 0.5f) / gridSize);
 		const float density = sampleAlpha16F(vol0, uvw);
 		const bool hasDensity = density >= kZeroThreshold;	// :46
 

@@ -400,7 +400,7 @@ inline float GetStep(float dDensity, float transm, float density, float step)
 	const float factorEv = fminf(1.0f / 256.0f / fabsf(dDensity), 2.0f);
 	const float factorUi = fminf(1.0f - density, 1.0f);
 	const float factorTh = 1.0f - transm;
-	step *= fmaxf(1.5f * factorEv * factorUi * factorTh, 1.0f);
+	step *= fmaxf(factorTh * 1.5f * factorEv * factorUi, 1.0f);	// the compiled order: ((factorTh * 1.5) * factorEv) * factorUi
 	return step;
 }
 
@@ -856,7 +856,8 @@ uint32_t mvo_march_light(uint32_t V, uint32_t N, uint32_t L, uint32_t M,
 					((float)yy + 0.5f) / gridSize * 2.0f - 1.0f,
 					((float)zz + 0.5f) / gridSize * 2.0f - 1.0f);
 
-				const float3 uvw = LocalToTex3DSpace(rayOrigin);
+				// LocalToTex3DSpace(rayOrigin) = ((x + 0.5) / L * 2 - 1) * 0.5 + 0.5, compiled (fast math) as (x + 0.5) / L
+				const float3 uvw = f3(((float)xx + 0.5f) / gridSize, ((float)yy + 0.5f) / gridSize, ((float)zz + 0.5f) / gridSize);
 				const float density = sampleAlpha16F(volumes[volTexId0], N, uvw);
 				const bool hasDensity = density >= kZeroThreshold;	// :46
 

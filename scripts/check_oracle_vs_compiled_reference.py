@@ -1,0 +1,43 @@
+"""The oracle against the reference's shipped compiled shaders (oracle/_ref, see oracle/dxil) at the BASELINE configs' full sizes, on the
+CPU: run where /root/reference exists (`make -C oracle ref` first).  tests/test_oracle_vs_reference_dxil.py holds the small cases."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import mv_oracle as o, dxref
+from multivolumes_amd import scene, raycaster as rc
+from tests.helpers import default_descs, host_frame, oracle_pipeline
+o.load()
+assert dxref.available()
+for name in sys.argv[1:] or ["C2", "C3"]:
+    cfg = dict(scene.CONFIGS[name]); V, N, L, M = cfg["V"], cfg["N"], cfg["L"], 256
+    t0 = time.time()
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    descs = default_descs(V, V, N)
+    _, vp, svp, cb, po = host_frame(cfg, 0)
+    depth, shadow = scene.depth_and_shadow(cfg, vp, svp, M)
+    i0, v0, c0 = o.cull(V, po, descs, cb, cfg["maxRay"])
+    i1, v1, c1 = dxref.cull(V, po, descs, cb, cfg["maxRay"])
+    print(f"{name}: cull identical: {np.array_equal(i0, i1) and np.array_equal(np.sort(v0), v1) and np.array_equal(np.sort(c0), c1)}  ({len(v0)} visible, {len(c0)} on the cube-map scheme)", flush=True)
+    lms = None
+    ref_lm = np.zeros((V, L, L, L), np.uint32)
+    nd = 0
+    for f in range(2):
+        _, _, _, cbf, pof = host_frame(cfg, f)
+        vid, lms, n = o.march_light(V, N, L, M, vols, descs, pof, cbf, shadow, None, v0, cfg["maxLight"], lms)
+        ref_lm = dxref.march_light(V, N, L, M, vols, descs, pof, cbf, shadow, None, v0, cfg["maxLight"], ref_lm)
+        nd += int((ref_lm[vid] != lms[vid]).sum())
+    print(f"{name}: light march, 2 frames x {L}^3 voxels: {nd} voxels differ  ({time.time() - t0:.0f} s)", flush=True)
+    cm, cd, st = o.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, i0, c0)
+    rm, rd = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, i0, c0)
+    print(f"{name}: view march, {st['view_samples']} samples, {st['rays']} rays: {int((rm != cm).sum())} of {int(sum(6 * (N >> int(i0[v, 0])) ** 2 * 4 for v in c0))} marched halves differ, "
+          f"{int((rd != cd).sum())} cube depths differ  ({time.time() - t0:.0f} s)", flush=True)
+    W2, H2 = 256, 256   # the composite runs one Python-driven invocation per fragment: a quarter-size viewport
+    cfg2 = dict(cfg, W=W2, H=H2)
+    _, vp2, svp2, cb2, po2 = host_frame(cfg2, 0)
+    depth2, _ = scene.depth_and_shadow(cfg2, vp2, svp2, M)
+    i2, v2, c2 = o.cull(V, po2, descs, cb2, cfg["maxRay"])
+    cm2, cd2, _ = o.march_view(V, N, L, W2, H2, vols, lms, depth2, po2, cb2, i2, c2)
+    args = (V, N, L, W2, H2, vols, lms, depth2, po2, cb2, i2, np.sort(v2), cm2, cd2)
+    img, _ = o.composite(*args)
+    got = dxref.composite(*args)
+    print(f"{name}: composite at {W2}x{H2}: {int((got != img).sum())} of {img.size} halves differ, {int((img[..., 3] != 0).sum())} covered pixels  ({time.time() - t0:.0f} s)", flush=True)

@@ -20,6 +20,20 @@ def _free_port():
     s.close()
     return p
 
+def run_group(cmd, timeout, env=None):
+    """subprocess.run in a process group of its own: on a timeout the whole group is killed (torchrun's workers would otherwise outlive
+    it and keep the GPU), and the failure carries what the ranks had printed."""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError(f"timed out after {timeout} s; stderr tail:\n{err[-3000:]}\nstdout tail:\n{out[-1000:]}")
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("extra", [[], ["--orbit"]])
@@ -27,15 +41,14 @@ def test_two_ranks_on_one_gpu(extra):
     env = dict(os.environ, MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    r = run_group(cmd, 240, env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange_bytes_per_frame"] > 0
     assert d["cpu_baseline"]["gpu_vs_oracle_max_abs_err"] == 0.0
     # the same frame on one rank: the sharded run marches the same samples
-    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + extra,
-                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    one = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + extra, 240)
     assert one.returncode == 0, one.stderr[-2000:]
     s = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     for k in ("view_samples_per_frame", "lit_samples_per_frame", "rays_per_frame", "light_samples_per_frame"):

@@ -21,6 +21,20 @@ def _free_port():
     s.close()
     return p
 
+def run_group(cmd, timeout, env=None):
+    """subprocess.run in a process group of its own: on a timeout the whole group is killed (torchrun's workers would otherwise outlive
+    it and keep the GPU), and the failure carries what the ranks had printed."""
+    import signal
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError(f"timed out after {timeout} s; stderr tail:\n{err[-3000:]}\nstdout tail:\n{out[-1000:]}")
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 
 def single_gpu(world, frames, every):
     from multivolumes_amd import MultiRayCaster, _lib, scene
@@ -51,7 +65,7 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every)]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    r = run_group(cmd, 300, env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = np.load(out)
     imgs, infos, counts, lms = single_gpu(world, frames, every)
