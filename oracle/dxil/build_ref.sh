@@ -10,7 +10,7 @@ CLANG=${CLANG:-/opt/rocm/lib/llvm/bin/clang}
 [ -f libmv_oracle.so ] || make libmv_oracle.so
 mkdir -p _ref
 objs=""
-for s in CSRayMarchV CSRayMarchL CSVolumeCull CSInitGridData CSR32FToRGBA16F PSDepthPeel PSCube PSResolveOIT; do
+for s in CSRayMarchV CSRayMarchL CSVolumeCull CSInitGridData CSR32FToRGBA16F VSCube PSDepthPeel PSCube PSResolveOIT; do
   for mode in fp32 fp16; do
     python3 dxil/cso2ll.py "$REF/Bin/$s.cso" "dxil_${s}_${mode}" $mode "_ref/${s}_${mode}.ll" "_ref/${s}.dxil.ll"
     "$CLANG" -O1 -fPIC -mf16c -c "_ref/${s}_${mode}.ll" -o "_ref/${s}_${mode}.o" -Wno-override-module

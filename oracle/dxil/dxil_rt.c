@@ -564,7 +564,7 @@ float rt_waveActiveOp_f32(int32_t opc, float v, int32_t op, int32_t sign)
 
 /* ---------------- dispatch ---------------- */
 /* n invocations of a pixel (or vertex) shader, one after the other: inputs[i] = 8 signature elements x 4 components (raw bits),
- * outputs[i] = 4 floats of output element 0 (may be NULL) */
+ * outputs[i] = 4 floats of output element 0 (may be NULL); dxref_run_invocations_full returns all 8 x 4 output components */
 int dxref_run_invocations(void (*fn)(void), uint32_t n, const uint32_t* inputs, float* outputs)
 {
 	dxr_ctx c;
@@ -576,6 +576,20 @@ int dxref_run_invocations(void (*fn)(void), uint32_t n, const uint32_t* inputs, 
 		memset(c.out, 0, sizeof(c.out));
 		fn();
 		if (outputs) memcpy(outputs + (size_t)i * 4u, c.out[0], 16);
+	}
+	return 0;
+}
+int dxref_run_invocations_full(void (*fn)(void), uint32_t n, const uint32_t* inputs, float* outputs)
+{
+	dxr_ctx c;
+	memset(&c, 0, sizeof(c));
+	t_ctx = &c;
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		c.in = (const uint32_t (*)[4])(inputs + (size_t)i * 32u);
+		memset(c.out, 0, sizeof(c.out));
+		fn();
+		memcpy(outputs + (size_t)i * 32u, c.out, sizeof(c.out));
 	}
 	return 0;
 }

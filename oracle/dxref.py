@@ -294,3 +294,27 @@ def r32f_to_rgba16f(src, N, mode="fp32"):
     g = (N + 3) // 4
     _dispatch("CSR32FToRGBA16F", mode, (g, g, g), (4, 4, 4))
     return out
+
+
+def vs_cube(V, perObject, volumeInfo, visible, mode="fp32"):
+    """VSCube.cso for the 24 vertices of every visible cube: returns [len(visible), 24, 8, 4] raw output components (uint32 view of
+    float / int): element 0 SV_Position, 1 UVW, 2 LPt, 3 VolId, 4 SrvId, 5 TexId, 6 SmpCnt (VSCube.hlsl:11-20)."""
+    lib = load()
+    lib.dxref_reset()
+    lib.dxref_run_invocations_full.restype = C.c_int
+    lib.dxref_run_invocations_full.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    po = np.ascontiguousarray(perObject).view(np.uint8).copy()
+    vi = np.ascontiguousarray(volumeInfo, np.uint16)
+    vis = np.ascontiguousarray(visible, np.uint32)
+    _bind(SRV, 0, 0, RAW, F_NONE, po, V, 0, 0, 224)
+    _bind(SRV, 1, 1, RAW, F_NONE, vis, len(vis), 0, 0, 4)
+    _bind(SRV, 2, 2, TYPED_BUF, F_RGBA16U, vi, V)
+    n = len(vis) * 24
+    inputs = np.zeros((n, 8, 4), np.uint32)
+    for i in range(len(vis)):
+        for vid in range(24):
+            inputs[i * 24 + vid, 0, 0] = vid  # SV_VertexID
+            inputs[i * 24 + vid, 1, 0] = i    # SV_InstanceID
+    out = np.zeros((n, 8, 4), np.float32)
+    assert lib.dxref_run_invocations_full(_entry("VSCube", mode), n, inputs.ctypes.data, out.ctypes.data) == 0
+    return out.view(np.uint32).reshape(len(vis), 24, 8, 4)

@@ -127,3 +127,35 @@ def test_producers_equal_the_compiled_producers(oracle):
     for shape, N in (((12, 10, 14), 16), ((20, 20, 20), 20), ((7, 9, 5), 24)):
         src = rng.random(shape, dtype=np.float32) * 3
         assert np.array_equal(dxref.r32f_to_rgba16f(src, N), oracle.r32f_to_rgba16f(src, N)), (shape, N)
+
+
+def test_fragment_inputs_match_the_compiled_vertex_shader(oracle):
+    """The composite test above feeds PSCube.cso with the oracle's stand-in for the rasteriser.  VSCube.cso (run here for the 24 vertices of
+    every visible cube) says what the rasteriser interpolates: LPt = the cube vertex, UVW.xy = the face-interior uv.  Interpolated to
+    points inside every face, UVW.xy must be the cube-face (s, t) the stand-in derives from LPt (mvo_cube_face_coords), and the flat
+    attributes the ones it passes (SrvId = 5 volume + mip, SmpCnt = 0 on the cube-map scheme)."""
+    import ctypes as C
+    cfg = dict(scene.CONFIGS["T2"], W=80, H=56)
+    V, N = cfg["V"], cfg["N"]
+    descs = default_descs(V, V, N)
+    _, _, _, cb, po = host_frame(cfg, 0, (30.0, 10.0, -45.0))
+    info, vis, _ = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+    assert {bool(int(info[v, 2]) & 0x8000) for v in vis} == {True, False}
+    out = dxref.vs_cube(V, po, info, vis)
+    f = out.view(np.float32)
+    lib = oracle.load()
+    lib.mvo_cube_face_coords.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for i, v in enumerate(vis):
+        assert int(out[i, 0, 3, 0]) == v and int(out[i, 0, 4, 0]) == 5 * v + int(info[v, 0]) and int(out[i, 0, 5, 0]) == int(info[v, 3])
+        assert int(out[i, 0, 6, 0]) == (0 if int(info[v, 2]) & 0x8000 else int(info[v, 1]))
+        for face in range(6):
+            q = f[i, 4 * face:4 * face + 4]
+            for tri in ((0, 1, 2), (2, 1, 3)):  # the strip's two triangles
+                for _ in range(4):
+                    w = rng.dirichlet((1.0, 1.0, 1.0)).astype(np.float32)
+                    uvw = sum(w[k] * q[tri[k], 1, :3] for k in range(3))
+                    lpt = np.ascontiguousarray(sum(w[k] * q[tri[k], 2, :3] for k in range(3)), np.float32)
+                    fid, st = C.c_uint32(), np.zeros(2, np.float32)
+                    lib.mvo_cube_face_coords(lpt.ctypes.data, C.byref(fid), st.ctypes.data)
+                    assert np.allclose(uvw[:2], st, atol=2e-6), (face, uvw, lpt, fid.value, st)
