@@ -12,7 +12,8 @@ SURVEY.md 8(d): 64 B/view sample + 32 B/lit sample + 16 B/ray, divided by its HI
 timed region keeps several frames in flight, so two view-march launches share the GPU and a launch's event-to-event time
 (`launch_ms_in_flight`) is not the kernel's own speed; `launch_ms` therefore comes from a second pass of the same frames
 run one at a time (synchronise after every frame), still HIP events inside this process.
-`cpu_baseline` is the CPU oracle (the reference has no Linux CPU path) timed on the same frame's marchV.
+`cpu_baseline` is the reference's own compiled view-march shader run on the host cores (oracle/_ref, kind "reference") when that
+library is there, with the CPU oracle's rate beside it ("port"); the oracle alone otherwise.  Both march the same frame's marchV.
 
 Defaults: 200 warm-up + 1000 timed frames (about 0.5 s of GPU time).  The HIP runtime stalls once for 30-50 ms around the
 140th frame of a process (its command / signal pools grow; measured, one-time): the setup phase below runs 176 frames for
@@ -386,10 +387,32 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
         exp = o.cube_face_view(cm[v], N, mip).view(np.float16).astype(np.float32)
         got = caster.ReadBackCubeMap(v, mip).view(np.float16).astype(np.float32)
         worst = max(worst, float(np.max(np.abs(exp - got))))
-    return {"value": st["view_samples"] / dt / 1e6, "unit": "Msamples/s", "cores": o.load().mvo_num_threads(), "kind": "port",
-            "build": "oracle/mv_oracle.cpp, g++ -O3 -ffp-contract=off -fopenmp (the reference's HLSL path cannot run here)",
+    port = {"value": st["view_samples"] / dt / 1e6, "unit": "Msamples/s", "cores": o.load().mvo_num_threads(), "kind": "port",
+            "build": "oracle/mv_oracle.cpp, g++ -O3 -ffp-contract=off -fopenmp",
             "sample": f"marchV of {len(sel)} of the {len(cube)} cube-map volumes of the same frame ({st['view_samples']} samples, {dt:.2f} s)",
             "gpu_vs_oracle_max_abs_err": worst}
+    # The reference's own code on the host cores, when oracle/_ref is there (built from the reference's shipped CSRayMarchV.cso through LLVM,
+    # oracle/dxil: its compiled DXIL on the CPU, the stand-in for the DX12 WARP path north_star asks for): the same volumes of the same
+    # frame, all cores.  Its cube maps must equal the oracle's bit for bit (they do: tests/test_oracle_vs_reference_dxil.py).
+    try:
+        from oracle import dxref
+        if dxref.available():
+            cores = os.cpu_count() or 1
+            dxref.load().dxref_set_threads(cores)
+            dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel[:1])  # warm
+            t0 = time.perf_counter()
+            rm, _ = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel)
+            dtr = time.perf_counter() - t0
+            same = all(np.array_equal(rm[v], cm[v]) for v in sel)
+            return {"value": st["view_samples"] / dtr / 1e6, "unit": "Msamples/s", "cores": min(cores, 256), "kind": "reference",
+                    "build": "oracle/_ref/libmv_dxref.so: the reference's shipped CSRayMarchV.cso (DXIL) translated to x86-64 by LLVM (clang -O1), "
+                             "resource intrinsics answered by oracle/dxil/dxil_rt.c, groups spread over the host threads",
+                    "sample": f"marchV of {len(sel)} of the {len(cube)} cube-map volumes of the same frame ({st['view_samples']} samples, {dtr:.2f} s)",
+                    "reference_equals_oracle": bool(same), "gpu_vs_oracle_max_abs_err": worst,
+                    "port": {k: port[k] for k in ("value", "cores", "build")}}
+    except Exception as e:  # the checker's checker must never take the bench line down
+        port["reference_error"] = str(e)[:200]
+    return port
 
 
 if __name__ == "__main__":

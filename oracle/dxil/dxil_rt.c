@@ -609,29 +609,66 @@ static void* lane_main(void* p)
  * the calling thread (shaders whose wave intrinsics only broadcast group-uniform values: ReadLaneAt / ReadLaneFirst return the
  * caller's value).  wave_size > 0: the group is cut into waves of that many lanes, each lane a thread, meeting at wave intrinsics
  * (see "wavefront rendezvous"; `cluster`: lanes per WaveActive* reduction group, 0 = the whole wave). */
+/* wave_size == 0: the groups are independent (no wave intrinsic that couples lanes, no group-shared memory in these shaders) and are
+ * spread over `dxref_set_threads` host threads */
+static int g_threads = 1;
+void dxref_set_threads(int n) { g_threads = n < 1 ? 1 : (n > 256 ? 256 : n); }
+typedef struct { shader_fn fn; uint32_t gx, gy, gz, tx, ty, tz; uint64_t first, last; uint64_t* next; } group_range;
+static void run_group_serial(shader_fn fn, uint32_t x, uint32_t y, uint32_t z, uint32_t tx, uint32_t ty, uint32_t tz)
+{
+	dxr_ctx c;
+	memset(&c, 0, sizeof(c));
+	t_ctx = &c;
+	const uint32_t per_group = tx * ty * tz;
+	for (uint32_t f = 0; f < per_group; ++f)
+	{
+		c.flat = f; c.lane = 0; c.wave = NULL;
+		c.tig[0] = f % tx; c.tig[1] = (f / tx) % ty; c.tig[2] = f / (tx * ty);
+		c.gid[0] = x; c.gid[1] = y; c.gid[2] = z;
+		c.tid[0] = x * tx + c.tig[0]; c.tid[1] = y * ty + c.tig[1]; c.tid[2] = z * tz + c.tig[2];
+		fn();
+	}
+}
+static void* group_worker(void* p)
+{
+	const group_range* r = (const group_range*)p;
+	for (;;)
+	{
+		/* chunks of 8 groups from a shared counter: the cost of a group varies with what its rays meet */
+		const uint64_t g0 = r->next ? __atomic_fetch_add(r->next, 8u, __ATOMIC_RELAXED) : r->first;
+		const uint64_t g1 = r->next ? (g0 + 8u < r->last ? g0 + 8u : r->last) : r->last;
+		for (uint64_t g = g0; g < g1; ++g)
+			run_group_serial(r->fn, (uint32_t)(g % r->gx), (uint32_t)((g / r->gx) % r->gy), (uint32_t)(g / ((uint64_t)r->gx * r->gy)), r->tx, r->ty, r->tz);
+		if (!r->next || g1 >= r->last) break;
+	}
+	return NULL;
+}
+
 int dxref_dispatch(shader_fn fn, uint32_t gx, uint32_t gy, uint32_t gz, uint32_t tx, uint32_t ty, uint32_t tz, uint32_t wave_size, uint32_t cluster)
 {
 	const uint32_t per_group = tx * ty * tz;
 	if (wave_size > 64) return -1;
+	if (!wave_size)
+	{
+		const uint64_t groups = (uint64_t)gx * gy * gz;
+		const int nt = (uint64_t)g_threads < groups ? g_threads : (int)groups;
+		if (nt <= 1) { group_range r = { fn, gx, gy, gz, tx, ty, tz, 0, groups, NULL }; group_worker(&r); return 0; }
+		static group_range ranges[256];
+		pthread_t th[256];
+		uint64_t next = 0;
+		for (int t = 0; t < nt; ++t)
+		{
+			const group_range r = { fn, gx, gy, gz, tx, ty, tz, 0, groups, &next };
+			ranges[t] = r;
+			if (pthread_create(&th[t], NULL, group_worker, &ranges[t]) != 0) return -2;
+		}
+		for (int t = 0; t < nt; ++t) pthread_join(th[t], NULL);
+		return 0;
+	}
 	for (uint32_t z = 0; z < gz; ++z)
 		for (uint32_t y = 0; y < gy; ++y)
 			for (uint32_t x = 0; x < gx; ++x)
 			{
-				if (!wave_size)
-				{
-					dxr_ctx c;
-					memset(&c, 0, sizeof(c));
-					t_ctx = &c;
-					for (uint32_t f = 0; f < per_group; ++f)
-					{
-						c.flat = f; c.lane = 0; c.wave = NULL;
-						c.tig[0] = f % tx; c.tig[1] = (f / tx) % ty; c.tig[2] = f / (tx * ty);
-						c.gid[0] = x; c.gid[1] = y; c.gid[2] = z;
-						c.tid[0] = x * tx + c.tig[0]; c.tid[1] = y * ty + c.tig[1]; c.tid[2] = z * tz + c.tig[2];
-						fn();
-					}
-					continue;
-				}
 				for (uint32_t base = 0; base < per_group; base += wave_size)
 				{
 					const uint32_t n = per_group - base < wave_size ? per_group - base : wave_size;
