@@ -75,9 +75,6 @@ def _half_const(m):
     return "0x%016X" % struct.unpack("<Q", struct.pack("<d", float(f)))[0]
 
 
-_SCALAR_C = {"float": "float", "i32": "i32", "half": "half", "i1": "i32", "i8": "i32", "double": "double", "i64": "i64", "i16": "i32"}
-
-
 def _stub(ret, name, args):
     """IR definition of one dx.op function: forwards to the C runtime function rt_<name with dots as underscores>.
     Aggregates come back through an out pointer; %dx.types.Handle travels as its pointer; i1 / i8 / i16 arguments as i32."""
