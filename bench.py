@@ -396,7 +396,7 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     # frame, all cores.  Its cube maps must equal the oracle's bit for bit (they do: tests/test_oracle_vs_reference_dxil.py).
     try:
         from oracle import dxref
-        if dxref.available():
+        if world == 1 and dxref.available():  # (N = 1 only: the multi-rank runs keep the oracle check of rank 0's cube maps and nothing else)
             cores = os.cpu_count() or 1
             dxref.load().dxref_set_threads(cores)
             dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel[:1])  # warm
