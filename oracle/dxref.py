@@ -175,14 +175,15 @@ TEXCUBE = 8
 
 
 def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame, volumeInfo, visible, cubeMaps, cubeDepths,
-              mode="fp32", fused_mad=False):
+              mode="fp32", fused_mad=False, fragments=None):
     """The K-buffer OIT composite through the reference's three compiled pixel shaders: PSDepthPeel.cso (InterlockedMin peel into 8
     depth layers), PSCube.cso (CubeCast or the screen-space RayCast per fragment, stored into the layer whose depth matches) and
     PSResolveOIT.cso (front-to-back resolve), one invocation per fragment / pixel.  What the rasteriser would feed them -- one
     fragment per visible cube where the pixel's view ray leaves it, with VSCube's interpolated outputs -- comes from the oracle's
     analytic stand-in (mvo_pixel_fragments; UVW.xy = the exit point's cube-face (s, t) as VSCube.hlsl:69 defines it): that part,
     the TextureCube footprint across face edges and the samplers are the oracle's contract, everything inside the shaders is the
-    reference's.  Returns the RGBA16F image [H, W, 4] u16 like mv_oracle.composite."""
+    reference's.  `fragments`: a list of (px, py, volume, lpt[3], z, u, v, face) to use instead (rasterised_fragments below).
+    Returns the RGBA16F image [H, W, 4] u16 like mv_oracle.composite."""
     lib = load()
     olib = O.load()
     lib.dxref_run_invocations.restype = C.c_int
@@ -202,16 +203,18 @@ def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame
     cd = np.ascontiguousarray(cubeDepths, np.float32)
 
     # fragments of every pixel (list order within a pixel)
-    vol_buf, lpt_buf, z_buf = np.zeros(max(V, 1), np.uint32), np.zeros((max(V, 1), 3), np.float32), np.zeros(max(V, 1), np.float32)
-    frags = []
-    face, st = C.c_uint32(), np.zeros(2, np.float32)
-    for py in range(H):
-        for px in range(W):
-            n = olib.mvo_pixel_fragments(W, H, px, py, po.ctypes.data, cb.ctypes.data, vis.ctypes.data, len(vis),
-                                         vol_buf.ctypes.data, lpt_buf.ctypes.data, z_buf.ctypes.data)
-            for k in range(n):
-                olib.mvo_cube_face_coords(lpt_buf[k].ctypes.data, C.byref(face), st.ctypes.data)
-                frags.append((px, py, int(vol_buf[k]), lpt_buf[k].copy(), float(z_buf[k]), float(st[0]), float(st[1]), int(face.value)))
+    frags = list(fragments) if fragments is not None else None
+    if frags is None:
+        vol_buf, lpt_buf, z_buf = np.zeros(max(V, 1), np.uint32), np.zeros((max(V, 1), 3), np.float32), np.zeros(max(V, 1), np.float32)
+        frags = []
+        face, st = C.c_uint32(), np.zeros(2, np.float32)
+        for py in range(H):
+            for px in range(W):
+                n = olib.mvo_pixel_fragments(W, H, px, py, po.ctypes.data, cb.ctypes.data, vis.ctypes.data, len(vis),
+                                             vol_buf.ctypes.data, lpt_buf.ctypes.data, z_buf.ctypes.data)
+                for k in range(n):
+                    olib.mvo_cube_face_coords(lpt_buf[k].ctypes.data, C.byref(face), st.ctypes.data)
+                    frags.append((px, py, int(vol_buf[k]), lpt_buf[k].copy(), float(z_buf[k]), float(st[0]), float(st[1]), int(face.value)))
     nf = len(frags)
     inputs = np.zeros((max(nf, 1), 8, 4), np.uint32)
     fv = inputs.view(np.float32)
@@ -318,3 +321,70 @@ def vs_cube(V, perObject, volumeInfo, visible, mode="fp32"):
     out = np.zeros((n, 8, 4), np.float32)
     assert lib.dxref_run_invocations_full(_entry("VSCube", mode), n, inputs.ctypes.data, out.ctypes.data) == 0
     return out.view(np.uint32).reshape(len(vis), 24, 8, 4)
+
+
+def rasterised_fragments(V, W, H, perObject, volumeInfo, visible, mode="fp32", subpixel_bits=8):
+    """What a D3D rasteriser produces from VSCube.cso's vertices: for every visible cube its 12 triangles (index list
+    MultiRayCaster.cpp:436-444), front faces culled (CULL_FRONT, clockwise = front), vertex positions snapped to 1/256 pixel (`subpixel_bits`), pixel
+    centres at +0.5, top-left rule, z interpolated linearly in screen space, UVW / LPt perspective-correct -- evaluated in float64 and
+    rounded to fp32 (an ideal interpolator; hardware's precision is its own).  Needs every vertex in front of the eye (w > 0: no
+    clipping here).  Returns the fragment list composite(fragments=...) takes."""
+    verts = vs_cube(V, perObject, volumeInfo, visible, mode).view(np.float32)
+    tris = [(0, 1, 2), (3, 2, 1)]
+    frags = []
+    for i, v in enumerate(np.asarray(visible)):
+        for face in range(6):
+            q = verts[i, 4 * face:4 * face + 4].astype(np.float64)
+            clip = q[:, 0, :4]
+            assert (clip[:, 3] > 0).all(), "a cube vertex behind the eye: this emulation does not clip"
+            ndc = clip[:, :3] / clip[:, 3:4]
+            one = 1 << subpixel_bits                                               # D3D: 8 (1/256 pixel); more = a finer snap
+            sx = np.rint((ndc[:, 0] * 0.5 + 0.5) * W * one).astype(np.int64)
+            sy = np.rint((-ndc[:, 1] * 0.5 + 0.5) * H * one).astype(np.int64)
+            for a, b, c in tris:
+                area = (sx[b] - sx[a]) * (sy[c] - sy[a]) - (sy[b] - sy[a]) * (sx[c] - sx[a])
+                if area >= 0:   # clockwise on a y-down screen = front face: culled (and degenerate)
+                    continue
+                x0, x1 = max(int(min(sx[a], sx[b], sx[c]) >> subpixel_bits), 0), min(int(max(sx[a], sx[b], sx[c]) >> subpixel_bits) + 1, W - 1)
+                y0, y1 = max(int(min(sy[a], sy[b], sy[c]) >> subpixel_bits), 0), min(int(max(sy[a], sy[b], sy[c]) >> subpixel_bits) + 1, H - 1)
+                if x0 > x1 or y0 > y1:
+                    continue
+                px = (np.arange(x0, x1 + 1, dtype=np.int64) * one + one // 2)[None, :]
+                py = (np.arange(y0, y1 + 1, dtype=np.int64) * one + one // 2)[:, None]
+                idx = (a, b, c)
+                inside = np.ones((y1 - y0 + 1, x1 - x0 + 1), bool)
+                lam = []
+                for k in range(3):
+                    p, r = idx[(k + 1) % 3], idx[(k + 2) % 3]      # edge opposite vertex k
+                    ex, ey = sx[r] - sx[p], sy[r] - sy[p]
+                    e = (px - sx[p]) * ey - (py - sy[p]) * ex      # same sign as `area` inside... with this orientation: e = -cross
+                    e = -e
+                    # counter-clockwise triangle (area < 0): inside where e <= 0; top-left rule decides e == 0
+                    top_left = (ey == 0 and ex < 0) or (ey < 0)     # for the flipped orientation
+                    inside &= (e < 0) | ((e == 0) & top_left)
+                    lam.append(e.astype(np.float64) / float(area))
+                ys, xs = np.nonzero(inside)
+                for yy, xx in zip(ys, xs):
+                    l = np.array([lam[0][yy, xx], lam[1][yy, xx], lam[2][yy, xx]])
+                    w = clip[list(idx), 3]
+                    z = float((l * ndc[list(idx), 2]).sum())
+                    if not (0.0 <= z <= 1.0):
+                        continue
+                    pw = l / w
+                    pw = pw / pw.sum()
+                    uvw = (pw[:, None] * q[list(idx), 1, :3]).sum(axis=0)
+                    lpt = (pw[:, None] * q[list(idx), 2, :3]).sum(axis=0).astype(np.float32)
+                    frags.append((int(x0 + xx), int(y0 + yy), int(v), lpt, float(np.float32(z)), float(np.float32(uvw[0])), float(np.float32(uvw[1])), int(round(uvw[2]))))
+    return frags
+
+
+def analytic_fragments(V, W, H, px, py, perObject, cbPerFrame, visible):
+    """The oracle's stand-in fragments of one pixel (mvo_pixel_fragments): [(volume, lpt[3], z)]."""
+    olib = O.load()
+    olib.mvo_pixel_fragments.restype = C.c_uint32
+    olib.mvo_pixel_fragments.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 3
+    po, cb = np.ascontiguousarray(perObject).view(np.uint8), np.ascontiguousarray(cbPerFrame).view(np.uint8)
+    vis = np.ascontiguousarray(visible, np.uint32)
+    vol, lpt, z = np.zeros(max(V, 1), np.uint32), np.zeros((max(V, 1), 3), np.float32), np.zeros(max(V, 1), np.float32)
+    n = olib.mvo_pixel_fragments(W, H, px, py, po.ctypes.data, cb.ctypes.data, vis.ctypes.data, len(vis), vol.ctypes.data, lpt.ctypes.data, z.ctypes.data)
+    return [(int(vol[k]), lpt[k].copy(), float(z[k])) for k in range(n)]

@@ -10,6 +10,8 @@ values carried at 32 bits (as WARP and most GPUs do), FMad with two roundings, n
 Skipped when oracle/_ref is absent (it cannot be built without /root/reference); tests/test_golden.py::test_oracle_reproduces_dxil_golden
 checks vectors made by this library and needs no library.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -159,3 +161,52 @@ def test_fragment_inputs_match_the_compiled_vertex_shader(oracle):
                     fid, st = C.c_uint32(), np.zeros(2, np.float32)
                     lib.mvo_cube_face_coords(lpt.ctypes.data, C.byref(fid), st.ctypes.data)
                     assert np.allclose(uvw[:2], st, atol=2e-6), (face, uvw, lpt, fid.value, st)
+
+
+def test_analytic_fragments_against_an_emulated_rasteriser(oracle):
+    """The composite's fragments are an analytic stand-in (the ray through the pixel centre against the cube's exit faces) for what the
+    rasteriser makes of VSCube.cso's triangles.  Emulating that rasteriser (dxref.rasterised_fragments: CULL_FRONT, 1/256-pixel vertex
+    snapping, top-left rule, perspective-correct interpolation) on the fixture frame: the SAME pixels get the SAME cubes' fragments,
+    their depth agrees to fp32 rounding and the interpolated local position to 1e-3 of the cube's half extent (1/256 snapping: 5e-4);
+    through the reference's pixel shaders the image then agrees to 1e-2 on all but the pixels where PSCube's in-shader adaptive
+    RayCast is itself discontinuous in the ray.  scripts/raster_vs_analytic_fragments.py prints the full report."""
+    import importlib.util
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_dxil_golden.py")
+    spec = importlib.util.spec_from_file_location("make_dxil_golden", path)
+    G = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(G)
+    o = oracle
+    c = G.CFG
+    V, N, L, W, H = c["V"], c["N"], c["L"], c["W"], c["H"]
+    vols = [rc.synth_volume(N, k + 1) for k in range(V)]
+    descs = default_descs(V, V, N)
+    _, vp, svp, cb, po = host_frame(c, 0, G.EYE)
+    depth, shadow = scene.depth_and_shadow(c, vp, svp, G.M)
+    info, vis, cube = o.cull(V, po, descs, cb, c["maxRay"])
+    vis = np.sort(vis)
+    frags = dxref.rasterised_fragments(V, W, H, po, info, vis)
+    by_pixel = {}
+    for f in frags:
+        by_pixel.setdefault((f[0], f[1]), []).append(f)
+    pixels, dz, dl = 0, 0.0, 0.0
+    for py in range(H):
+        for px in range(W):
+            a = dxref.analytic_fragments(V, W, H, px, py, po, cb, vis)
+            r = by_pixel.get((px, py), [])
+            assert sorted(f[0] for f in a) == sorted(f[2] for f in r), f"coverage differs at pixel ({px}, {py})"
+            pixels += len(a) > 0
+            for vol, lpt, z in a:
+                f = next(f for f in r if f[2] == vol)
+                dz = max(dz, abs(z - f[4]))
+                dl = max(dl, float(np.abs(lpt - f[3]).max()))
+    assert pixels > 4000 and len(frags) > pixels          # cubes overlap on screen
+    assert dz <= 2e-6 and dl <= 1e-3, (dz, dl)
+    lms = np.zeros((V, L, L, L), np.uint32)
+    for f in range(V):
+        _, _, _, cbf, pof = host_frame(c, f, G.EYE)
+        lms = o.march_light(V, N, L, G.M, vols, descs, pof, cbf, shadow, None, vis, c["maxLight"], lightMaps=lms)[1]
+    cm, cd = o.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)[:2]
+    analytic = half_to_float(dxref.composite(V, N, L, W, H, vols, lms, depth, po, cb, info, vis, cm, cd))
+    raster = half_to_float(dxref.composite(V, N, L, W, H, vols, lms, depth, po, cb, info, vis, cm, cd, fragments=frags))
+    d = np.abs(analytic - raster).max(axis=-1)
+    assert (d > 1e-2).sum() <= 4 and (d > 1e-3).sum() <= 0.02 * pixels, ((d > 1e-2).sum(), (d > 1e-3).sum())
