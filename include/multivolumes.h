@@ -255,6 +255,7 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id /* MV_DIST_ID_BYTES, the same 
 typedef int (*mv_dist_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* stream, int which);
 typedef int (*mv_dist_allreduce_u32_fn)(void* user, void* buf, size_t count, void* stream, int which);
 int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user);
+int mv_dist_shutdown(mv_ctx* ctx);	/* detach the frame loop (drains it first); mv_dist_init_* may then be called again, e.g. with the other transport. Collective in effect: every rank calls it */
 int mv_dist_selftest(mv_ctx* ctx);	/* one all-gather (plain and in place) and one all-reduce per communicator, verified: call once after init on every rank */
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite);
 int mv_dist_flush(mv_ctx* ctx);	/* enqueue the exchange + composite of the last frame begun (then mv_synchronize / readbacks see it) */

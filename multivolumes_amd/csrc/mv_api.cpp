@@ -586,20 +586,25 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	return MV_OK;
 }
 
+// Detach the multi-GPU frame loop: communicators, its stream, the pinned cull copies (device buffers stay in ctx->allocs until
+// mv_destroy; the RCCL library stays loaded).
+static void distRelease(mv_ctx* ctx)
+{
+	DistState* d = ctx->dist;
+	if (!d) return;
+	for (int i = 0; i < 2; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
+	if (d->streamX) (void)hipStreamDestroy(d->streamX);
+	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (d->pinnedCull[i]) (void)hipHostFree(d->pinnedCull[i]); if (d->evCullCopied[i]) (void)hipEventDestroy(d->evCullCopied[i]); }
+	delete d;
+	ctx->dist = nullptr;
+}
+
 void mv_destroy(mv_ctx* ctx)
 {
 	if (!ctx) return;
 	if (ctx->stream) (void)syncAll(ctx);
 	foldEvents(ctx);
-	if (DistState* d = ctx->dist)
-	{
-		for (int i = 0; i < 2; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
-		if (d->streamX) (void)hipStreamDestroy(d->streamX);
-		for (uint32_t i = 0; i < kFrameSlots; ++i) { if (d->pinnedCull[i]) (void)hipHostFree(d->pinnedCull[i]); if (d->evCullCopied[i]) (void)hipEventDestroy(d->evCullCopied[i]); }
-		// (device buffers are in ctx->allocs; the RCCL library stays loaded)
-		delete d;
-		ctx->dist = nullptr;
-	}
+	distRelease(ctx);
 	for (uint32_t i = 0; i < kFrameSlots; ++i) if (ctx->evCopy[i]) (void)hipEventDestroy(ctx->evCopy[i]);
 	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); if (ctx->evLight[i]) (void)hipEventDestroy(ctx->evLight[i]); }
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
@@ -1504,6 +1509,17 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
 	d->transport = 2; d->cbAllGather = allgather; d->cbAllReduce = allreduce; d->user = user;
 	ctx->dist = d;
 	return distCommonInit(ctx);
+}
+
+int mv_dist_shutdown(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	if (!ctx->dist) return MV_OK;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	if (ctx->dist->streamX) MV_HIP(ctx, hipStreamSynchronize(ctx->dist->streamX));
+	distRelease(ctx);
+	ctx->st.flags &= ~mv::kFlagRotateAllLightMaps;
+	return MV_OK;
 }
 
 // exchange + composite of the pending frame, on stream X (beside the view march of the frame begun after it)

@@ -92,6 +92,7 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()
     if prefer_rccl and backend == "nccl":
+        err = None
         try:
             ids = torch.zeros(256, dtype=torch.uint8, device="cuda")
             if rank == 0:
@@ -99,10 +100,17 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
             dist.broadcast(ids, src=0)
             caster.DistInitRccl(bytes(ids.cpu().numpy().tobytes()))
             caster.DistSelfTest()  # every collective the frame loop uses, verified once, before any frame
+        except Exception as e:
+            err = e
+        # every rank takes the same transport: one rank's failure moves them all to the callbacks
+        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
             return "rccl"
-        except Exception as e:  # loud, and visible in the bench line ("exchange": "torch-callbacks")
-            import sys
-            print(f"[rank {rank}] in-library RCCL transport unavailable ({e}); using torch.distributed callbacks", file=sys.stderr)
+        import sys  # loud, and visible in the bench line ("transport: torch-callbacks")
+        print(f"[rank {rank}] in-library RCCL transport unavailable ({err if err is not None else 'another rank failed'}); "
+              "using torch.distributed callbacks", file=sys.stderr)
+        caster.DistShutdown()
     groups = [group_main if group_main is not None else dist.new_group(list(range(world))),
               group_light if group_light is not None else dist.new_group(list(range(world)))]
 

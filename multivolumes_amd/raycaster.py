@@ -435,6 +435,10 @@ class MultiRayCaster:
                           _lib.DIST_ALLREDUCE_FN(lambda u, b, n, st, w: allreduce(b, n, st, w)))  # kept alive with the context
         self._check(self._lib.mv_dist_init_callbacks(self._ctx, self._dist_cbs[0], self._dist_cbs[1], None), "mv_dist_init_callbacks")
 
+    def DistShutdown(self):
+        self._check(self._lib.mv_dist_shutdown(self._ctx), "mv_dist_shutdown")
+        self._dist_cbs = None
+
     def DistSelfTest(self):
         self._check(self._lib.mv_dist_selftest(self._ctx), "mv_dist_selftest")
 

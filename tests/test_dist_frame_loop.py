@@ -108,5 +108,17 @@ def test_rccl_transport_on_one_rank():
             got = c.ReadBackComposite()
         imgs, _, _, _ = single_gpu(2, frames, frames)
         assert np.array_equal(got, imgs[-1])
+        # the fallback init_frame_loop takes when RCCL fails on any rank: detach (mv_dist_shutdown), attach the other transport
+        with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(0, 1)) as c:
+            fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
+            assert D.init_frame_loop(c) == "rccl"
+            c.DistShutdown()
+            c.DistShutdown()  # nothing attached: a no-op
+            assert D.init_frame_loop(c, prefer_rccl=False) == "torch-callbacks"
+            for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
+                c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+                c.DistFrame(vp, fr["shadowVP"], e)
+            c.DistFlush()
+            assert np.array_equal(c.ReadBackComposite(), imgs[-1])
     finally:
         dist.destroy_process_group()

@@ -210,3 +210,42 @@ def test_analytic_fragments_against_an_emulated_rasteriser(oracle):
     raster = half_to_float(dxref.composite(V, N, L, W, H, vols, lms, depth, po, cb, info, vis, cm, cd, fragments=frags))
     d = np.abs(analytic - raster).max(axis=-1)
     assert (d > 1e-2).sum() <= 4 and (d > 1e-3).sum() <= 0.02 * pixels, ((d > 1e-2).sum(), (d > 1e-3).sum())
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_close_cameras_against_the_compiled_shaders(oracle, seed):
+    """Cameras the fixed cases above do not reach: close to and inside the volumes (rays that start inside the box, faces that fill
+    the screen, volumes behind the eye, the screen-space RayCast scheme selected by the cull), random light-march frame index.
+    Cull, light map, cube maps / depths and the composite from the compiled shaders equal the oracle's, bit for bit."""
+    rng = np.random.default_rng(seed)
+    cfg = dict(scene.CONFIGS["T1"], W=96, H=64)
+    V, N, L, M = cfg["V"], cfg["N"], cfg["L"], 32
+    vols = [rc.synth_volume(N, k + seed) for k in range(V)]
+    descs = default_descs(V, V, N)
+    schemes, inside = set(), 0
+    for case in range(4):
+        r = rng.uniform(2.0, 45.0)
+        a, h = rng.uniform(0, 2 * np.pi), rng.uniform(-12.0, 25.0)
+        eye = (float(r * np.sin(a)), float(h), float(-r * np.cos(a)))
+        frame = int(rng.integers(0, 8))
+        _, vp, svp, cb, po = host_frame(cfg, frame, eye)
+        depth, shadow = scene.depth_and_shadow(cfg, vp, svp, M)
+        info, vis, cube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+        i1, v1, c1 = dxref.cull(V, po, descs, cb, cfg["maxRay"])
+        assert np.array_equal(info, i1) and np.array_equal(np.sort(vis), np.sort(v1)) and np.array_equal(np.sort(cube), np.sort(c1)), (seed, case, eye)
+        if len(vis) == 0:
+            continue
+        vid, lms, _ = oracle.march_light(V, N, L, M, vols, descs, po, cb, shadow, None, vis, cfg["maxLight"])
+        lm = dxref.march_light(V, N, L, M, vols, descs, po, cb, shadow, None, vis, cfg["maxLight"])
+        assert np.array_equal(lm[vid], lms[vid]), (seed, case, "light map")
+        cm, cd = oracle.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, info, cube)[:2]
+        if len(cube):
+            cm1, cd1 = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, info, cube)
+            assert np.array_equal(cm1, cm) and np.array_equal(cd1, cd), (seed, case, eye, int((cm1 != cm).sum()))
+        args = (V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, info, np.sort(vis), cm, cd)
+        img = oracle.composite(*args)[0]
+        got = dxref.composite(*args)
+        assert np.array_equal(got, img), (seed, case, eye, int((got != img).sum()))
+        schemes |= {bool(int(info[v, 2]) & 0x8000) for v in vis}
+        inside += r < 14.0
+    print(f"seed {seed}: schemes seen (cube map = True) {sorted(schemes)}, close-up cameras {inside}")
