@@ -1,8 +1,8 @@
 """ctypes wrapper of the CPU oracle (oracle/libmv_oracle.so).
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg -- never by
-the product package.  Parity: a1 / a2 / a3 pinned to the reference's shipped compiled shaders (oracle/dxref.py), composite and
-sampler unpinned: see oracle/mv_oracle.h.
+the product package.  Parity: a1 / a2 / a3 / a6 and the composite's shaders pinned to the reference's shipped compiled shaders
+(oracle/dxref.py); rasteriser and sampler are a stated contract: see oracle/mv_oracle.h.
 """
 import ctypes as C
 import os
@@ -34,8 +34,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    build()
-    lib = C.CDLL(LIB_PATH)
+    alt = os.environ.get("MV_ORACLE_LIB")  # scripts/sanitize_cpu.sh: the same sources built with ASan / UBSan
+    if alt:
+        lib = C.CDLL(alt)
+    else:
+        build()
+        lib = C.CDLL(LIB_PATH)
     sig = {
         "mvo_f32_to_f16": (C.c_uint16, [_F]), "mvo_f16_to_f32": (_F, [C.c_uint16]),
         "mvo_pack_r11g11b10f": (_U32, [_F, _F, _F]), "mvo_unpack_r11g11b10f": (None, [_U32, _P]),

@@ -1,0 +1,33 @@
+#!/bin/bash
+# CPU sanitizer pass (GPU AddressSanitizer is not available on this pool): the oracle and the host helpers of the product library
+# (mv_host.cpp: DDS / OBJ loaders, frame constants, camera math) built with AddressSanitizer + UndefinedBehaviorSanitizer by g++,
+# everything else of the library unchanged, and the CPU test suite run against them.
+# Output: gpurun_out-free; prints the pytest tail and any sanitizer report.  Usage: bash scripts/sanitize_cpu.sh [pytest args]
+set -euo pipefail
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+OUT="$ROOT/oracle/_san"
+mkdir -p "$OUT"
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
+# the oracle
+g++ -O1 -std=c++17 -fPIC -ffp-contract=off -mfma -fopenmp $SAN -shared -o "$OUT/libmv_oracle.so" "$ROOT/oracle/mv_oracle.cpp" "$ROOT/oracle/mv_oracle_mesh.cpp"
+# the product library: device objects by hipcc as always, host objects by g++ with the sanitizers
+cd "$ROOT/multivolumes_amd/csrc"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+pids=()
+for f in mv_kernels mv_march mv_march_tiles mv_composite mv_mesh; do
+	$HIPCC $FLAGS -c $f.hip -o "$OUT/$f.o" & pids+=($!)
+done
+$HIPCC $FLAGS -c mv_api.cpp -o "$OUT/mv_api.o" & pids+=($!)	# includes device headers: not a g++ translation unit (without a GPU it only ever rejects arguments)
+g++ -O1 -std=c++17 -fPIC -Wall $SAN -c mv_host.cpp -o "$OUT/mv_host.o" & pids+=($!)
+rc=0
+for p in "${pids[@]}"; do wait "$p" || rc=1; done
+[ $rc -eq 0 ] || { echo "sanitize_cpu.sh: a compile job failed" >&2; exit 1; }
+g++ -shared -fPIC $SAN -o "$OUT/libmultivolumes_amd.so" "$OUT"/mv_kernels.o "$OUT"/mv_march.o "$OUT"/mv_march_tiles.o "$OUT"/mv_composite.o "$OUT"/mv_mesh.o \
+	"$OUT/mv_api.o" "$OUT/mv_host.o" -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread -ldl
+cd "$ROOT"
+export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
+export ASAN_OPTIONS="detect_leaks=0:alloc_dealloc_mismatch=0:halt_on_error=1:abort_on_error=0"
+export UBSAN_OPTIONS="print_stacktrace=1"
+export MV_LIB_PATH="$OUT/libmultivolumes_amd.so" MV_ORACLE_LIB="$OUT/libmv_oracle.so"
+python -m pytest tests -q -m "not gpu" -p no:cacheprovider "$@"
