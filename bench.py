@@ -54,6 +54,7 @@ def parse():
     p.add_argument("--no-composite", action="store_true", help="leave the K-buffer OIT composite out of the step")
     p.add_argument("--no-pipeline", action="store_true", help="one stream, no overlap of frame i+1's light march with frame i's view march")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--dist-single-stream", action="store_true", help="--gpus > 1: the multi-GPU loop's single-view-stream schedule instead of whole frames on three view streams")
     p.add_argument("--orbit", action="store_true", help="the camera moves every frame (an arc around the scene, there and back) instead of standing still: "
                    "cull results, mips and the tile order's cost feedback (four frames old) then change from frame to frame")
     p.add_argument("--mesh", action="store_true", help="depth / shadow maps rasterised on the GPU from the reference scenes' mesh (bunny.obj at 0 -9 0 x1.8, "
@@ -104,11 +105,12 @@ def main():
     if pipelined:
         flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
     if world > 1:
-        # the in-library frame loop needs two output sets with every view march on the context's stream (mv_dist_frame)
+        # the in-library frame loop (mv_dist_frame): whole frames on three view streams, a communicator each; --dist-single-stream
+        # selects its other schedule (one view stream, the exchange beside it)
         if not pipelined and rank == 0:
             print("warning: --no-pipeline is ignored with --gpus > 1", file=sys.stderr)
         pipelined = True
-        flags |= _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
+        flags |= _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if args.dist_single_stream else 0)
     # a real (non-blocking) torch stream, made current so that the RCCL collectives of the multi-GPU path are ordered on it too:
     # torch's default is the legacy null stream, whose implicit synchronisation rules cost the pipelined frame ~20 %
     if os.environ.get("MV_BENCH_NULL_STREAM", "0") != "1":
@@ -323,7 +325,8 @@ def main():
                 "fetch_free_samples_per_frame": tot_free // K,
                 "parallelism": f"cube-map volumes sharded v%{world} + all-gather of the marched cube faces, screen-space RayCast and composite sharded by rows; frame loop inside the library (mv_dist_frame), transport: {exchange}" if world > 1 else "single GPU",
                 "frames_in_flight": ("up to 3 whole frames (light march, view march, composite) on 3 view streams; constants / cull 4 slots, march outputs 3 sets, light maps 3 buffers per volume" if world == 1
-                                     else "upload + cull + light march ahead of the view march / exchange / composite stream") if pipelined else 1,
+                                     else "upload + cull + light march ahead of the view march / exchange / composite stream" if args.dist_single_stream
+                                     else "up to 3 whole frames (light march + light-map all-reduce, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes_timed // max(1, K),
             },

@@ -241,20 +241,31 @@ int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim);
  *   frame k:   constant upload, cull, light march (owner of the relit volume), light-map exchange (an all-reduce of that ONE map as
  *              R11G11B10F words, 4 L^3 bytes: every rank keeps every light map current, because every rank marches its own screen
  *              rows of every volume on the screen-space scheme), view march of the owned volumes;
- *   frame k-1: (on a second stream, beside frame k's march) pack the marched faces of the owned cube-map volumes -> all-gather ->
- *              unpack -> composite of this rank's rows -> all-gather of the row bands.
+ *   frame k-1: pack the marched faces of the owned cube-map volumes -> all-gather -> unpack -> composite of this rank's rows ->
+ *              all-gather of the row bands.
  * The sizes of frame k-1's collectives come from its cull results, which reached the host a frame ago.  The composite of frame k is
  * therefore complete after the NEXT mv_dist_frame (or mv_dist_flush).  Results equal the single-GPU frame bit for bit.
- * Transport: RCCL (the library opens librccl.so itself; two communicators) or caller-supplied collectives (tests, other fabrics). */
-#define MV_DIST_ID_BYTES 256
+ * Two schedules, chosen by the context's flags:
+ *   MV_FLAG_PIPELINE_FRAMES                               whole frames on three view streams ("chains"): everything of frame k, its
+ *       collectives included, goes on view stream k % 3 with communicator k % 3 -- frames overlap as wholes, which a rank needs once
+ *       its share of a frame no longer fills the GPU (the default of bench.py);
+ *   MV_FLAG_PIPELINE_FRAMES | MV_FLAG_SINGLE_VIEW_STREAM  the view marches on one stream, frame k-1's exchange + composite on a second
+ *       one beside frame k's march; communicator 0 = cube faces / rows, 1 = light maps.
+ * Transport: RCCL (the library opens librccl.so itself; three communicators, two used without chains) or caller-supplied collectives
+ * (tests, other fabrics). */
+#define MV_DIST_ID_BYTES 384	/* three RCCL unique ids (one per communicator) */
 int mv_dist_unique_id(void* out /* MV_DIST_ID_BYTES; call on rank 0, hand the bytes to every rank */);
 int mv_dist_init_rccl(mv_ctx* ctx, const void* id /* MV_DIST_ID_BYTES, the same on every rank */);
 /* all-gather: every rank contributes `bytes` from `send`; `recv` receives shard_count x bytes in rank order.  all-reduce: in-place
- * integer sum of `count` uint32.  `stream` is the hipStream_t the collective must be ordered on; which = 0 (cube faces / rows) or
- * 1 (light maps): the two families run on different streams and need separate communicators.  Return 0 on success. */
+ * integer sum of `count` uint32.  `stream` is the hipStream_t the collective must be ordered on; which = 0, 1 or 2 names the
+ * communicator: collectives with different `which` run on different streams at the same time and need separate communicators
+ * (chains: `which` = frame % 3; single view stream: 0 = cube faces / rows, 1 = light maps).  Return 0 on success. */
 typedef int (*mv_dist_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* stream, int which);
 typedef int (*mv_dist_allreduce_u32_fn)(void* user, void* buf, size_t count, void* stream, int which);
 int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user);
+/* Caller-supplied collectives only: 1 = the all-gather may be called in place (send == recv + rank * bytes, NCCL's convention); the
+ * row bands of the composite are then gathered straight into the frame buffer instead of through staging copies.  Default 0. */
+int mv_dist_set_inplace_gather(mv_ctx* ctx, int enabled);
 int mv_dist_shutdown(mv_ctx* ctx);	/* detach the frame loop (drains it first); mv_dist_init_* may then be called again, e.g. with the other transport. Collective in effect: every rank calls it */
 int mv_dist_selftest(mv_ctx* ctx);	/* one all-gather (plain and in place) and one all-reduce per communicator, verified: call once after init on every rank */
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite);

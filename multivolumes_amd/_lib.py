@@ -28,7 +28,7 @@ MV_FLAG_RAY_QUEUE = 16
 MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
 MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7
 
-MV_DIST_ID_BYTES = 256
+MV_DIST_ID_BYTES = 384
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 
@@ -112,6 +112,7 @@ ABI = {
     "mv_dist_init_callbacks": (C.c_int, [_P, _P, _P, _P]),
     "mv_dist_selftest": (C.c_int, [_P]),
     "mv_dist_shutdown": (C.c_int, [_P]),
+    "mv_dist_set_inplace_gather": (C.c_int, [_P, C.c_int]),
     "mv_dist_frame": (C.c_int, [_P, _P, _P, C.c_int]),
     "mv_dist_flush": (C.c_int, [_P]),
     "mv_dist_exchanged_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),

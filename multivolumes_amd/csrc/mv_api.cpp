@@ -74,6 +74,7 @@ struct OutBufs
 };
 
 // state of the in-library multi-GPU frame loop (mv_dist_*)
+constexpr uint32_t kDistChains = 3;
 struct DistState
 {
 	int transport = 0;				// 1 = RCCL, 2 = caller-supplied collectives
@@ -83,21 +84,30 @@ struct DistState
 	decltype(&ncclAllReduce) allReduce = nullptr;
 	decltype(&ncclCommDestroy) commDestroy = nullptr;
 	decltype(&ncclGetErrorString) errorString = nullptr;
-	ncclComm_t comm[2] = { nullptr, nullptr };	// [0] cube faces + row bands (stream X), [1] light maps (stream L)
+	// Two ways to run the loop (chosen by how the context was created):
+	// * chains (MV_FLAG_PIPELINE_FRAMES alone: three view streams, three output sets): frame k's light march, light-map exchange, view
+	//   march, cube-face exchange, composite and row gather all go on view stream k % 3, with communicator / buffers k % 3 -- whole
+	//   frames overlap, which is what a rank needs once its share of a frame no longer fills the GPU;
+	// * single view stream (| MV_FLAG_SINGLE_VIEW_STREAM: two output sets): the view marches on the context's stream, the exchange and
+	//   composite of frame k - 1 beside frame k's march on stream X; comm [0] = cube faces + row bands, [1] = light maps.
+	bool chains = false;
+	bool inPlaceGather = false;	// the transport's all-gather accepts send == recv + rank * bytes (RCCL does; a caller says so with mv_dist_set_inplace_gather)
+	uint32_t numComm = 2;
+	ncclComm_t comm[kDistChains] = {};
 	mv_dist_allgather_fn cbAllGather = nullptr;
 	mv_dist_allreduce_u32_fn cbAllReduce = nullptr;
 	void* user = nullptr;
-	hipStream_t streamX = nullptr;	// exchange + composite of frame k - 1, beside frame k's view march
-	uint8_t *sendBuf = nullptr, *recvBuf = nullptr;	// one shard / shard_count shards of marched cube faces
+	hipStream_t streamX = nullptr;	// (single view stream) exchange + composite of frame k - 1, beside frame k's view march
+	uint8_t *sendBuf[kDistChains] = {}, *recvBuf[kDistChains] = {};	// one shard / shard_count shards of marched cube faces ([0] only without chains)
 	size_t sendCap = 0;
-	uint32_t* lightWords = nullptr;	// L^3 R11G11B10F words of the relit light map
-	uint8_t *rowSend = nullptr, *rowRecv = nullptr;	// staged row-band gather (unequal bands, or a transport without in-place all-gather)
+	uint32_t* lightWords[kDistChains] = {};	// L^3 R11G11B10F words of the relit light map
+	uint8_t *rowSend[kDistChains] = {}, *rowRecv[kDistChains] = {};	// staged row-band gather (unequal bands, or a transport without in-place all-gather)
 	size_t maxBandBytes = 0;
 	uint8_t* pinnedCull[4] = {};	// per frame slot: counters + VolumeInfo + lists, copied behind the cull
 	hipEvent_t evCullCopied[4] = {};
 	bool pending = false, pendingComposite = false;
 	DeviceState stPending;			// the device state of the frame whose exchange + composite are still to be enqueued
-	uint32_t slotPending = 0;
+	uint32_t slotPending = 0, chainPending = 0;
 	uint64_t bytes = 0;
 };
 
@@ -592,7 +602,7 @@ static void distRelease(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
 	if (!d) return;
-	for (int i = 0; i < 2; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
+	for (uint32_t i = 0; i < kDistChains; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
 	if (d->streamX) (void)hipStreamDestroy(d->streamX);
 	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (d->pinnedCull[i]) (void)hipHostFree(d->pinnedCull[i]); if (d->evCullCopied[i]) (void)hipEventDestroy(d->evCullCopied[i]); }
 	delete d;
@@ -907,13 +917,14 @@ int mv_march_view(mv_ctx* ctx)
 #define MV_COPY_FORWARD 1	// (0: A/B timing only -- the two output sets then drift apart in the faces a frame does not march)
 #endif
 	const uint32_t n = ctx->numOutSets;
-	if (MV_COPY_FORWARD && n >= 2u && !ctx->dist && ctx->lastCompleteFrame != 0u && ctx->lastCompleteFrame + 1u != ctx->frame && !ctx->copiedForward)
+	const bool ownCopy = !ctx->dist || ctx->dist->chains;	// (the single-view-stream multi-GPU loop copies on its stream X)
+	if (MV_COPY_FORWARD && n >= 2u && ownCopy && ctx->lastCompleteFrame != 0u && ctx->lastCompleteFrame + 1u != ctx->frame && !ctx->copiedForward)
 	{
 		// the previous frame left its set untouched (no view march, no composite): it is not the complete history the fast path reads
 		const int rc = copyForwardFromAllSets(ctx, true);
 		if (rc != MV_OK) return rc;
 	}
-	else if (MV_COPY_FORWARD && n >= 2u && !ctx->dist)
+	else if (MV_COPY_FORWARD && n >= 2u && ownCopy)
 	{
 		// (also when a composite of this frame has already copied, without marking the faces this march is about to write)
 		// On the stream of the PREVIOUS frame's view march (and composite): stream order alone puts the copy behind the march that
@@ -1426,20 +1437,23 @@ static int distCommonInit(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
 	const DeviceState& st = ctx->st;
-	MV_REQUIRE(ctx, (ctx->cfg.flags & MV_FLAG_PIPELINE_FRAMES) && (ctx->cfg.flags & MV_FLAG_SINGLE_VIEW_STREAM), MV_ERR_INVALID_ARG,
-		"mv_dist_* needs a context created with MV_FLAG_PIPELINE_FRAMES | MV_FLAG_SINGLE_VIEW_STREAM (two output sets, cull and light march ahead)");
+	MV_REQUIRE(ctx, ctx->cfg.flags & MV_FLAG_PIPELINE_FRAMES, MV_ERR_INVALID_ARG,
+		"mv_dist_* needs a context created with MV_FLAG_PIPELINE_FRAMES (whole frames on three view streams), optionally | MV_FLAG_SINGLE_VIEW_STREAM (two output sets, cull and light march ahead)");
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	MV_HIP(ctx, hipStreamCreateWithFlags(&d->streamX, hipStreamNonBlocking));
+	if (!d->chains) MV_HIP(ctx, hipStreamCreateWithFlags(&d->streamX, hipStreamNonBlocking));
 	const uint32_t world = st.shardCount, perShard = (st.V + world - 1u) / world;
 	d->sendCap = (size_t)perShard * 6u * st.N * st.N * 12u;	// every owned volume at mip 0 with six faces
-	int rc;
-	if ((rc = devAlloc(ctx, &d->sendBuf, d->sendCap, false)) != MV_OK) return rc;
-	if ((rc = devAlloc(ctx, &d->recvBuf, d->sendCap * world, false)) != MV_OK) return rc;
-	if ((rc = devAlloc(ctx, &d->lightWords, (size_t)st.L * st.L * st.L * sizeof(uint32_t), false)) != MV_OK) return rc;
 	const uint32_t tiles = (st.H + 7u) >> 3;
 	d->maxBandBytes = (size_t)(((tiles + world - 1u) / world) * 8u) * st.W * sizeof(uint2);
-	if ((rc = devAlloc(ctx, &d->rowSend, d->maxBandBytes, true)) != MV_OK) return rc;
-	if ((rc = devAlloc(ctx, &d->rowRecv, d->maxBandBytes * world, false)) != MV_OK) return rc;
+	int rc;
+	for (uint32_t c = 0; c < (d->chains ? kDistChains : 1u); ++c)
+	{
+		if ((rc = devAlloc(ctx, &d->sendBuf[c], d->sendCap, false)) != MV_OK) return rc;
+		if ((rc = devAlloc(ctx, &d->recvBuf[c], d->sendCap * world, false)) != MV_OK) return rc;
+		if ((rc = devAlloc(ctx, &d->lightWords[c], (size_t)st.L * st.L * st.L * sizeof(uint32_t), false)) != MV_OK) return rc;
+		if ((rc = devAlloc(ctx, &d->rowSend[c], d->maxBandBytes, true)) != MV_OK) return rc;
+		if ((rc = devAlloc(ctx, &d->rowRecv[c], d->maxBandBytes * world, false)) != MV_OK) return rc;
+	}
 	for (uint32_t i = 0; i < kFrameSlots; ++i)
 	{
 		if (hipHostMalloc(reinterpret_cast<void**>(&d->pinnedCull[i]), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned cull copy");
@@ -1458,9 +1472,9 @@ int mv_dist_unique_id(void* out)
 	if (!lib) return MV_ERR_NOT_READY;
 	auto getId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
 	if (!getId) return MV_ERR_NOT_READY;
-	static_assert(2 * sizeof(ncclUniqueId) == MV_DIST_ID_BYTES, "two RCCL unique ids");
+	static_assert(kDistChains * sizeof(ncclUniqueId) == MV_DIST_ID_BYTES, "one RCCL unique id per communicator");
 	ncclUniqueId* ids = reinterpret_cast<ncclUniqueId*>(out);
-	for (int i = 0; i < 2; ++i) if (getId(&ids[i]) != ncclSuccess) return MV_ERR_HIP;
+	for (uint32_t i = 0; i < kDistChains; ++i) if (getId(&ids[i]) != ncclSuccess) return MV_ERR_HIP;
 	return MV_OK;
 }
 
@@ -1471,7 +1485,9 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
 	MV_REQUIRE(ctx, ctx->st.shardCount >= 1, MV_ERR_INVALID_ARG, "shard_count");
 	DistState* d = new (std::nothrow) DistState();
 	if (!d) return MV_ERR_OUT_OF_MEMORY;
-	d->transport = 1;
+	d->transport = 1; d->inPlaceGather = true;
+	d->chains = ctx->lightOnViewStream && ctx->numViewStreams == kDistChains;
+	d->numComm = d->chains ? kDistChains : 2u;
 	d->rcclLib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
 	if (!d->rcclLib) d->rcclLib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
 	if (d->rcclLib)
@@ -1485,13 +1501,13 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
 	if (!d->rcclLib || !d->commInitRank || !d->allGather || !d->allReduce || !d->commDestroy) { delete d; return fail(ctx, MV_ERR_NOT_READY, "librccl.so could not be opened"); }
 	MV_HIP(ctx, hipSetDevice(ctx->cfg.device));
 	const ncclUniqueId* ids = reinterpret_cast<const ncclUniqueId*>(id);
-	for (int i = 0; i < 2; ++i)
+	for (uint32_t i = 0; i < d->numComm; ++i)
 	{
 		const ncclResult_t r = d->commInitRank(&d->comm[i], (int)ctx->st.shardCount, ids[i], (int)ctx->st.shardIndex);
 		if (r != ncclSuccess)
 		{
 			const int rc = fail(ctx, MV_ERR_HIP, d->errorString ? d->errorString(r) : "ncclCommInitRank failed");
-			if (i == 1 && d->comm[0]) (void)d->commDestroy(d->comm[0]);
+			for (uint32_t j = 0; j < i; ++j) if (d->comm[j]) (void)d->commDestroy(d->comm[j]);
 			delete d;
 			return rc;
 		}
@@ -1507,8 +1523,19 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
 	DistState* d = new (std::nothrow) DistState();
 	if (!d) return MV_ERR_OUT_OF_MEMORY;
 	d->transport = 2; d->cbAllGather = allgather; d->cbAllReduce = allreduce; d->user = user;
+	d->chains = ctx->lightOnViewStream && ctx->numViewStreams == kDistChains;
+	d->numComm = d->chains ? kDistChains : 2u;
 	ctx->dist = d;
 	return distCommonInit(ctx);
+}
+
+int mv_dist_set_inplace_gather(mv_ctx* ctx, int enabled)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
+	MV_REQUIRE(ctx, ctx->dist->transport == 2, MV_ERR_INVALID_ARG, "only for caller-supplied collectives (RCCL gathers in place already)");
+	ctx->dist->inPlaceGather = enabled != 0;
+	return MV_OK;
 }
 
 int mv_dist_shutdown(mv_ctx* ctx)
@@ -1522,13 +1549,18 @@ int mv_dist_shutdown(mv_ctx* ctx)
 	return MV_OK;
 }
 
-// exchange + composite of the pending frame, on stream X (beside the view march of the frame begun after it)
-static int distTail(mv_ctx* ctx)
+// Exchange and composite of the pending frame k - 1, enqueued while frame k is being begun: by then the host has k - 1's cull results
+// (they size the all-gather) without waiting.  Single view stream: both on stream X, beside frame k's view march.  Chains: on frame
+// k - 1's own view stream, behind its view march, with that chain's communicator and buffers.
+static hipStream_t distTailStream(mv_ctx* ctx, uint32_t chain) { return ctx->dist->chains ? ctx->streamB[chain] : ctx->dist->streamX; }
+
+static int distTailExchange(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
 	if (!d->pending) return MV_OK;
 	const DeviceState& st = d->stPending;
-	const uint32_t slot = d->slotPending, world = st.shardCount, rank = st.shardIndex;
+	const uint32_t slot = d->slotPending, world = st.shardCount;
+	const uint32_t chain = d->chains ? d->chainPending : 0u;
 
 	// This frame's cull results were copied to pinned memory behind its cull, at least one mv_dist_frame ago: the wait returns at once
 	// in steady state.  They give the size of the frame's all-gather (the same on every rank: the cull is replicated).
@@ -1549,20 +1581,33 @@ static int distTail(mv_ctx* ctx)
 	for (size_t b : perRank) shardBytes = std::max(shardBytes, (b + 15u) & ~(size_t)15u);
 	MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
 
-	hipStream_t X = d->streamX;
-	MV_HIP(ctx, hipStreamWaitEvent(X, ctx->evMainDone[slot], 0));	// the frame's view march
+	hipStream_t X = distTailStream(ctx, chain);
+	if (!d->chains) MV_HIP(ctx, hipStreamWaitEvent(X, ctx->evMainDone[slot], 0));	// the frame's view march (chains: the same stream)
 	if (world > 1)
 	{
-		mv::launchExchangeCompact(X, st, true, d->sendBuf, shardBytes);
+		mv::launchExchangeCompact(X, st, true, d->sendBuf[chain], shardBytes);
 		MV_HIP(ctx, hipGetLastError());
-		int rc = distAllGather(ctx, d->sendBuf, d->recvBuf, shardBytes, X, 0);
+		int rc = distAllGather(ctx, d->sendBuf[chain], d->recvBuf[chain], shardBytes, X, (int)chain);
 		if (rc != MV_OK) return rc;
-		mv::launchExchangeCompact(X, st, false, d->recvBuf, shardBytes);
+		mv::launchExchangeCompact(X, st, false, d->recvBuf[chain], shardBytes);
 		MV_HIP(ctx, hipGetLastError());
 		d->bytes += shardBytes * world;
 	}
+	return MV_OK;
+}
+
+static int distTailComposite(mv_ctx* ctx)
+{
+	DistState* d = ctx->dist;
+	if (!d->pending) return MV_OK;
+	const DeviceState& st = d->stPending;
+	const uint32_t slot = d->slotPending, world = st.shardCount, rank = st.shardIndex;
+	const uint32_t chain = d->chains ? d->chainPending : 0u;
+	hipStream_t X = distTailStream(ctx, chain);
 	if (d->pendingComposite)
 	{
+		// chains: the copy-forward of this frame's unmarched faces ran on the stream of the frame before it
+		if (d->chains) MV_HIP(ctx, hipStreamWaitEvent(X, ctx->evCopy[slot], 0));
 		mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
 		MV_HIP(ctx, hipGetLastError());
 		if (world > 1)
@@ -1571,24 +1616,24 @@ static int distTail(mv_ctx* ctx)
 			const uint32_t tiles = (st.H + 7u) >> 3;
 			uint8_t* frame = reinterpret_cast<uint8_t*>(st.composite);
 			const bool equalBands = tiles % world == 0u && (tiles / world) * 8u * world == st.H;
-			if (equalBands && d->transport == 1)
+			if (equalBands && d->inPlaceGather)
 			{
 				// the frame buffer is the all-gather's output and this rank's band its input, in place (sendbuff == recvbuff + rank * count)
 				const size_t band = (size_t)(st.bandRow1 - st.bandRow0) * rowBytes;
-				const int rc = distAllGather(ctx, frame + (size_t)st.bandRow0 * rowBytes, frame, band, X, 0);
+				const int rc = distAllGather(ctx, frame + (size_t)st.bandRow0 * rowBytes, frame, band, X, (int)chain);
 				if (rc != MV_OK) return rc;
 			}
 			else
 			{
-				MV_HIP(ctx, hipMemcpyAsync(d->rowSend, frame + (size_t)st.bandRow0 * rowBytes, (size_t)(st.bandRow1 - st.bandRow0) * rowBytes, hipMemcpyDeviceToDevice, X));
-				const int rc = distAllGather(ctx, d->rowSend, d->rowRecv, d->maxBandBytes, X, 0);
+				MV_HIP(ctx, hipMemcpyAsync(d->rowSend[chain], frame + (size_t)st.bandRow0 * rowBytes, (size_t)(st.bandRow1 - st.bandRow0) * rowBytes, hipMemcpyDeviceToDevice, X));
+				const int rc = distAllGather(ctx, d->rowSend[chain], d->rowRecv[chain], d->maxBandBytes, X, (int)chain);
 				if (rc != MV_OK) return rc;
 				for (uint32_t r = 0; r < world; ++r)
 				{
 					if (r == rank) continue;
 					const uint32_t t0 = (uint32_t)(((uint64_t)tiles * r) / world), t1 = (uint32_t)(((uint64_t)tiles * (r + 1u)) / world);
 					const uint32_t r0 = std::min(t0 * 8u, st.H), r1 = std::min(t1 * 8u, st.H);
-					if (r1 > r0) MV_HIP(ctx, hipMemcpyAsync(frame + (size_t)r0 * rowBytes, d->rowRecv + (size_t)r * d->maxBandBytes, (size_t)(r1 - r0) * rowBytes, hipMemcpyDeviceToDevice, X));
+					if (r1 > r0) MV_HIP(ctx, hipMemcpyAsync(frame + (size_t)r0 * rowBytes, d->rowRecv[chain] + (size_t)r * d->maxBandBytes, (size_t)(r1 - r0) * rowBytes, hipMemcpyDeviceToDevice, X));
 				}
 			}
 			d->bytes += (size_t)st.H * rowBytes;
@@ -1598,6 +1643,12 @@ static int distTail(mv_ctx* ctx)
 	MV_HIP(ctx, hipEventRecord(ctx->evMainDone[slot], X));
 	d->pending = false;
 	return MV_OK;
+}
+
+static int distTail(mv_ctx* ctx)
+{
+	const int rc = distTailExchange(ctx);
+	return rc != MV_OK ? rc : distTailComposite(ctx);
 }
 
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite)
@@ -1612,31 +1663,44 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 	MV_HIP(ctx, hipMemcpyAsync(d->pinnedCull[ctx->slot], ctx->fb[ctx->slot].cullBlock, 64 + (size_t)ctx->st.V * 24, hipMemcpyDeviceToHost, ctx->streamA));
 	MV_HIP(ctx, hipEventRecord(d->evCullCopied[ctx->slot], ctx->streamA));
 	if ((rc = mv_march_light(ctx)) != MV_OK) return rc;
+	const uint32_t chain = d->chains ? (uint32_t)(ctx->frame % kDistChains) : 0u;
 	if (ctx->st.shardCount > 1)
 	{
-		// The light-map exchange goes in front of the view march that needs it, on that march's stream -- not behind the light march on
-		// stream L: there it would hold up the NEXT frame's light march (owned by another rank, ready to run beside this one) until this
-		// frame's owner has finished.  Stream L of a rank then only ever carries its own light marches.
-		hipStream_t E = ctx->stream;
-		const size_t words = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
+		// The light-map exchange goes in front of the view march that needs it, on that march's stream (chains: behind the light march,
+		// which is on that stream too).  Single view stream: not behind the light march on stream L, where it would hold up the NEXT
+		// frame's light march (owned by another rank, ready to run beside this one) until this frame's owner has finished.
+		hipStream_t E = d->chains ? streamB(ctx) : ctx->stream;
+		uint32_t* words = d->lightWords[chain];
+		const size_t count = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
 		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evLight[ctx->slot], 0));	// the owner's light march (nothing on the other ranks)
 		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evStageA[ctx->slot], 0));	// this frame's cull: the relit volume, its rotated buffer
 		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));	// frame k - 3, the last reader of the buffer the unpack overwrites
-		mv::launchLightExchange(E, ctx->st, d->lightWords, false);
+		mv::launchLightExchange(E, ctx->st, words, false);
 		MV_HIP(ctx, hipGetLastError());
-		if ((rc = distAllReduceU32(ctx, d->lightWords, words, E, 1)) != MV_OK) return rc;
-		mv::launchLightExchange(E, ctx->st, d->lightWords, true);
+		if ((rc = distAllReduceU32(ctx, words, count, E, d->chains ? (int)chain : 1)) != MV_OK) return rc;
+		mv::launchLightExchange(E, ctx->st, words, true);
 		MV_HIP(ctx, hipGetLastError());
 		MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], E));	// "this frame's light map is current on this rank": the next user of the slot waits for it
-		d->bytes += words * sizeof(uint32_t);
+		d->bytes += count * sizeof(uint32_t);
 	}
-	if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
-	// ---- frame k - 1: exchange + composite, on stream X beside this frame's march ----
-	if ((rc = distTail(ctx)) != MV_OK) return rc;
-	// ---- frame k's unmarched cube faces <- frame k - 1's set, now complete on this rank (stream X is in order); frame k + 1's march waits for it ----
-	MV_HIP(ctx, hipStreamWaitEvent(d->streamX, ctx->evStageA[ctx->slot], 0));
-	if ((rc = copyForward(ctx, d->streamX)) != MV_OK) return rc;
-	d->stPending = ctx->st; d->slotPending = ctx->slot; d->pendingComposite = with_composite != 0; d->pending = true;
+	if (d->chains)
+	{
+		// ---- frame k - 1's cube-face exchange, on ITS stream behind its view march; then frame k's view march, whose copy-forward of the
+		// faces k does not march reads k - 1's set on that same stream, i.e. behind the unpack; then k - 1's composite and row gather ----
+		if ((rc = distTailExchange(ctx)) != MV_OK) return rc;
+		if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
+		if ((rc = distTailComposite(ctx)) != MV_OK) return rc;
+	}
+	else
+	{
+		if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
+		// ---- frame k - 1: exchange + composite, on stream X beside this frame's march ----
+		if ((rc = distTail(ctx)) != MV_OK) return rc;
+		// ---- frame k's unmarched cube faces <- frame k - 1's set, now complete on this rank (stream X is in order); frame k + 1's march waits for it ----
+		MV_HIP(ctx, hipStreamWaitEvent(d->streamX, ctx->evStageA[ctx->slot], 0));
+		if ((rc = copyForward(ctx, d->streamX)) != MV_OK) return rc;
+	}
+	d->stPending = ctx->st; d->slotPending = ctx->slot; d->chainPending = chain; d->pendingComposite = with_composite != 0; d->pending = true;
 	return MV_OK;
 }
 
@@ -1659,27 +1723,29 @@ int mv_dist_selftest(mv_ctx* ctx)
 	MV_REQUIRE(ctx, d->sendCap >= n && d->maxBandBytes >= n, MV_ERR_RANGE, "self-test buffers");
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	std::vector<uint8_t> h(n * world), g(n * world);
-	for (int which = 0; which < 2; ++which)
+	for (int which = 0; which < (int)d->numComm; ++which)
 	{
-		hipStream_t s = which == 0 ? d->streamX : ctx->stream;	// the streams the frame loop uses the two communicators on
+		// the stream the frame loop uses this communicator on, and the buffers it uses there
+		hipStream_t s = d->chains ? ctx->streamB[which] : which == 0 ? d->streamX : ctx->stream;
+		const uint32_t c = d->chains ? (uint32_t)which : 0u;
 		// all-gather, separate buffers
 		for (size_t i = 0; i < n; ++i) h[i] = (uint8_t)(rank * 31u + i * 7u + which);
-		MV_HIP(ctx, hipMemcpyAsync(d->sendBuf, h.data(), n, hipMemcpyHostToDevice, s));
-		int rc = distAllGather(ctx, d->sendBuf, d->recvBuf, n, s, which);
+		MV_HIP(ctx, hipMemcpyAsync(d->sendBuf[c], h.data(), n, hipMemcpyHostToDevice, s));
+		int rc = distAllGather(ctx, d->sendBuf[c], d->recvBuf[c], n, s, which);
 		if (rc != MV_OK) return rc;
-		MV_HIP(ctx, hipMemcpyAsync(g.data(), d->recvBuf, n * world, hipMemcpyDeviceToHost, s));
+		MV_HIP(ctx, hipMemcpyAsync(g.data(), d->recvBuf[c], n * world, hipMemcpyDeviceToHost, s));
 		MV_HIP(ctx, hipStreamSynchronize(s));
 		for (uint32_t r = 0; r < world; ++r)
 			for (size_t i = 0; i < n; ++i)
 				MV_REQUIRE(ctx, g[r * n + i] == (uint8_t)(r * 31u + i * 7u + which), MV_ERR_HIP, "all-gather self-test: wrong bytes");
 		// in place (the row-band gather of equal bands): sendbuff == recvbuff + rank * count
-		if (d->transport == 1)
+		if (d->inPlaceGather)
 		{
-			MV_HIP(ctx, hipMemsetAsync(d->rowRecv, 0, n * world, s));
-			MV_HIP(ctx, hipMemcpyAsync(d->rowRecv + (size_t)rank * n, h.data(), n, hipMemcpyHostToDevice, s));
-			rc = distAllGather(ctx, d->rowRecv + (size_t)rank * n, d->rowRecv, n, s, which);
+			MV_HIP(ctx, hipMemsetAsync(d->rowRecv[c], 0, n * world, s));
+			MV_HIP(ctx, hipMemcpyAsync(d->rowRecv[c] + (size_t)rank * n, h.data(), n, hipMemcpyHostToDevice, s));
+			rc = distAllGather(ctx, d->rowRecv[c] + (size_t)rank * n, d->rowRecv[c], n, s, which);
 			if (rc != MV_OK) return rc;
-			MV_HIP(ctx, hipMemcpyAsync(g.data(), d->rowRecv, n * world, hipMemcpyDeviceToHost, s));
+			MV_HIP(ctx, hipMemcpyAsync(g.data(), d->rowRecv[c], n * world, hipMemcpyDeviceToHost, s));
 			MV_HIP(ctx, hipStreamSynchronize(s));
 			for (uint32_t r = 0; r < world; ++r)
 				for (size_t i = 0; i < n; ++i)
@@ -1688,10 +1754,10 @@ int mv_dist_selftest(mv_ctx* ctx)
 		// all-reduce (integer sum; only one rank contributes non-zero words, like the light-map exchange)
 		std::vector<uint32_t> w(256, 0u);
 		if (rank == world - 1u) for (uint32_t i = 0; i < 256; ++i) w[i] = 0x9e3779b9u * (i + 1u) + which;
-		MV_HIP(ctx, hipMemcpyAsync(d->lightWords, w.data(), 1024, hipMemcpyHostToDevice, s));
-		rc = distAllReduceU32(ctx, d->lightWords, 256, s, which);
+		MV_HIP(ctx, hipMemcpyAsync(d->lightWords[c], w.data(), 1024, hipMemcpyHostToDevice, s));
+		rc = distAllReduceU32(ctx, d->lightWords[c], 256, s, which);
 		if (rc != MV_OK) return rc;
-		MV_HIP(ctx, hipMemcpyAsync(w.data(), d->lightWords, 1024, hipMemcpyDeviceToHost, s));
+		MV_HIP(ctx, hipMemcpyAsync(w.data(), d->lightWords[c], 1024, hipMemcpyDeviceToHost, s));
 		MV_HIP(ctx, hipStreamSynchronize(s));
 		for (uint32_t i = 0; i < 256; ++i) MV_REQUIRE(ctx, w[i] == 0x9e3779b9u * (i + 1u) + which, MV_ERR_HIP, "all-reduce self-test: wrong words");
 	}

@@ -11,6 +11,8 @@ import os
 
 import numpy as np
 
+from . import _lib
+
 NUM_CUBE_MIP = 5
 
 
@@ -94,7 +96,7 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
     if prefer_rccl and backend == "nccl":
         err = None
         try:
-            ids = torch.zeros(256, dtype=torch.uint8, device="cuda")
+            ids = torch.zeros(_lib.MV_DIST_ID_BYTES, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 ids.copy_(torch.frombuffer(bytearray(caster.DistUniqueId()), dtype=torch.uint8))
             dist.broadcast(ids, src=0)
@@ -111,8 +113,10 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
         print(f"[rank {rank}] in-library RCCL transport unavailable ({err if err is not None else 'another rank failed'}); "
               "using torch.distributed callbacks", file=sys.stderr)
         caster.DistShutdown()
+    # one group per communicator index the library uses (`which` = 0..2: include/multivolumes.h)
     groups = [group_main if group_main is not None else dist.new_group(list(range(world))),
-              group_light if group_light is not None else dist.new_group(list(range(world)))]
+              group_light if group_light is not None else dist.new_group(list(range(world))),
+              dist.new_group(list(range(world)))]
 
     def allgather(send, recv, nbytes, stream, which):
         try:

@@ -435,6 +435,10 @@ class MultiRayCaster:
                           _lib.DIST_ALLREDUCE_FN(lambda u, b, n, st, w: allreduce(b, n, st, w)))  # kept alive with the context
         self._check(self._lib.mv_dist_init_callbacks(self._ctx, self._dist_cbs[0], self._dist_cbs[1], None), "mv_dist_init_callbacks")
 
+    def DistSetInPlaceGather(self, enabled=True):
+        """Caller-supplied collectives: the all-gather accepts send == recv + rank * bytes (NCCL's in-place convention)."""
+        self._check(self._lib.mv_dist_set_inplace_gather(self._ctx, 1 if enabled else 0), "mv_dist_set_inplace_gather")
+
     def DistShutdown(self):
         self._check(self._lib.mv_dist_shutdown(self._ctx), "mv_dist_shutdown")
         self._dist_cbs = None

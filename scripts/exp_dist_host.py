@@ -5,11 +5,11 @@ from multivolumes_amd import MultiRayCaster, scene, _lib
 from multivolumes_amd import raycaster as rc
 cfg = dict(scene.CONFIGS["C3"]); V, N, L = cfg["V"], cfg["N"], cfg["L"]
 vols = [rc.synth_volume(N, k) for k in range(V)]
-flags = _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
-for world, rank in ((8, 2), (1, 0)):
+flags = _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if os.environ.get("SINGLE") == "1" else 0)
+for world, rank in (((8, 2), (1, 0)) if os.environ.get("ONLY8") != "1" else ((8, 2),)):
     with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=1024, flags=flags, shard=(rank, world)) as c:
         fr = scene.setup_raycaster(c, cfg, vols)
-        c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0)
+        c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0); c.DistSetInPlaceGather(True)  # like RCCL: no staging copies
         for _ in range(200): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
         c.DistFlush(); c.synchronize()
         # enqueue-only: few enough frames that the host never waits for a slot (4 slots)... measure per call anyway

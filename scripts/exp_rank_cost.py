@@ -11,18 +11,20 @@ from multivolumes_amd import raycaster as rc
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 cfg = dict(scene.CONFIGS[name]); V, N, L = cfg["V"], cfg["N"], cfg["L"]
 vols = [rc.synth_volume(N, k) for k in range(V)]
-flags = _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
 frames = 400
-for world in (1, 2, 4, 8):
-    per_rank = []
-    for rank in range(world):
-        with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=1024, flags=flags, shard=(rank, world)) as c:
-            fr = scene.setup_raycaster(c, cfg, vols)
-            c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0)
-            for _ in range(200): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
-            c.DistFlush(); c.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(frames): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
-            c.DistFlush(); c.synchronize()
-            per_rank.append((time.perf_counter() - t0) / frames * 1e3)
-    print("world %d: ms/frame per rank %s  -> max %.4f" % (world, [round(x, 4) for x in per_rank], max(per_rank)), flush=True)
+for mode, flags in (("chains (whole frames on three view streams)", _lib.MV_FLAG_PIPELINE_FRAMES),
+                    ("single view stream", _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM)):
+    print(mode, flush=True)
+    for world in (1, 2, 4, 8):
+        per_rank = []
+        for rank in range(world):
+            with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=1024, flags=flags, shard=(rank, world)) as c:
+                fr = scene.setup_raycaster(c, cfg, vols)
+                c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0); c.DistSetInPlaceGather(True)  # like RCCL: no staging copies
+                for _ in range(200): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+                c.DistFlush(); c.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(frames): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+                c.DistFlush(); c.synchronize()
+                per_rank.append((time.perf_counter() - t0) / frames * 1e3)
+        print("  world %d: ms/frame per rank %s  -> max %.4f" % (world, [round(x, 4) for x in per_rank], max(per_rank)), flush=True)

@@ -31,20 +31,23 @@ def main():
     from multivolumes_amd import raycaster as rc
     from multivolumes_amd import distributed as D
     out_path, frames, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    mode = sys.argv[4] if len(sys.argv) > 4 else "chains"           # "chains" (three view streams) or "single" (one view stream)
+    static_depth = len(sys.argv) > 5 and sys.argv[5] == "1"          # no setter (= no drain of the frames in flight) inside the sequence
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
     cfg = dict(scene.CONFIGS["T2"], W=256, H=168 if world != 3 else 200)
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
-    flags = _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
+    flags = _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if mode == "single" else 0)
     with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world)) as c:
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         kind = D.init_frame_loop(c)
         assert kind == "torch-callbacks"
         imgs, infos = [], []
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
-            c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+            if not static_depth or f == 0:
+                c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
             c.DistFrame(vp, fr["shadowVP"], e)
             if f % every == every - 1 or f == frames - 1:
                 c.DistFlush()

@@ -36,7 +36,7 @@ def run_group(cmd, timeout, env=None):
 
 
 
-def single_gpu(world, frames, every):
+def single_gpu(world, frames, every, static_depth=False):
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
     from tests.dist_worker import camera_sequence
@@ -47,7 +47,8 @@ def single_gpu(world, frames, every):
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         imgs, infos = [], []
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
-            c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+            if not static_depth or f == 0:
+                c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
             c.UpdateFrame(vp, fr["shadowVP"], e)
             c.Render(composite=True)
             if f % every == every - 1 or f == frames - 1:
@@ -58,20 +59,24 @@ def single_gpu(world, frames, every):
     return np.stack(imgs), np.stack(infos), np.array([st[k] for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples")]), lms
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_dist_frame_loop_matches_single_gpu(tmp_path, world):
-    frames, every = 26, 3
+@pytest.mark.parametrize("world,mode,every,static_depth", [(2, "chains", 3, False), (3, "chains", 13, True), (2, "chains", 26, True),
+                                                           (2, "single", 3, False), (3, "single", 13, True)])
+def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static_depth):
+    """Both schedules of the loop (include/multivolumes.h): whole frames on three view streams with a communicator each ("chains"),
+    and one view stream with the exchange beside it ("single").  With `static_depth` nothing inside the sequence drains the frames
+    in flight (a depth-map setter does), so up to three frames -- collectives included -- really overlap between checkpoints."""
+    frames = 26
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every), mode, "1" if static_depth else "0"]
     r = run_group(cmd, 300, env)
     assert r.returncode == 0, r.stderr[-3000:]
     d = np.load(out)
-    imgs, infos, counts, lms = single_gpu(world, frames, every)
+    imgs, infos, counts, lms = single_gpu(world, frames, every, static_depth)
     assert np.array_equal(d["infos"], infos), "the cull is replicated"
     schemes = {tuple((infos[i][:, 2] & 0x8000).tolist()) for i in range(len(infos))}
-    assert len(schemes) > 1, "the sequence must move volumes between the cube-map and the screen-space scheme"
+    assert len(schemes) > 1 or len(infos) == 1, "the sequence must move volumes between the cube-map and the screen-space scheme"
     for i in range(len(imgs)):
         assert np.array_equal(d["imgs"][i], imgs[i]), f"composite of checkpoint {i} differs ({(d['imgs'][i] != imgs[i]).sum()} halfs)"
     assert np.array_equal(d["lms"], lms), "every rank holds every light map, current"
@@ -97,7 +102,7 @@ def test_rccl_transport_on_one_rank():
         V = cfg["V"]
         vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
         frames = 9
-        flags = _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM
+        flags = _lib.MV_FLAG_PIPELINE_FRAMES  # whole frames on three view streams, three communicators
         with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(0, 1)) as c:
             fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
             assert D.init_frame_loop(c) == "rccl"
@@ -109,6 +114,8 @@ def test_rccl_transport_on_one_rank():
         imgs, _, _, _ = single_gpu(2, frames, frames)
         assert np.array_equal(got, imgs[-1])
         # the fallback init_frame_loop takes when RCCL fails on any rank: detach (mv_dist_shutdown), attach the other transport
+        # (here on the other schedule: one view stream, two communicators)
+        flags |= _lib.MV_FLAG_SINGLE_VIEW_STREAM
         with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(0, 1)) as c:
             fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
             assert D.init_frame_loop(c) == "rccl"
