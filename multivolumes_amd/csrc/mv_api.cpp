@@ -172,6 +172,7 @@ struct mv_ctx
 	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
 
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
+	bool leanEvents = false;			// inside mv_dist_frame on a chains context: event records that a later record of the same call supersedes are left out (the host enqueues a rank's frame in ~100 us: every call counts)
 	bool lightMarched = false, lightTableKept = false;	// this frame: mv_march_light ran / the frame keeps the previous frame's light table (see keepLightTable)
 	bool profiling = false;
 	std::vector<EventPair> pending;
@@ -255,7 +256,7 @@ int syncAll(mv_ctx* ctx)
 
 // stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
 // (every one of these orders streams against each other: a failure must reach the caller, or a later stage reads unfinished data)
-hipError_t stageADone(mv_ctx* ctx) { return hipEventRecord(ctx->evStageA[ctx->slot], ctx->streamA); }
+hipError_t stageADone(mv_ctx* ctx, bool last = true) { return ctx->leanEvents && !last ? hipSuccess : hipEventRecord(ctx->evStageA[ctx->slot], ctx->streamA); }
 hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->frame % ctx->numViewStreams]; }
 hipError_t stageBBegin(mv_ctx* ctx)
 {
@@ -816,7 +817,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
 	MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));
 	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->streamA));
-	MV_HIP(ctx, stageADone(ctx));
+	MV_HIP(ctx, stageADone(ctx, false));
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
 	ctx->lightMarched = false; ctx->lightTableKept = false; ctx->copiedForward = false; ctx->marchedThisFrame = false;
@@ -833,7 +834,7 @@ int mv_cull(mv_ctx* ctx)
 	endStage(ctx, ev, ctx->streamA);
 	mv::launchLightOrder(ctx->streamA, ctx->st);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, stageADone(ctx));
+	MV_HIP(ctx, stageADone(ctx, !ctx->orderTiles));
 	if (ctx->orderTiles)
 	{
 		// Dispatch order of this frame's view march, right behind the cull on stream A (which runs frames ahead), from the cost
@@ -867,7 +868,7 @@ int mv_march_light(mv_ctx* ctx)
 	mv::launchMarchLight(L, ctx->st);
 	endStage(ctx, ev, L);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], L));
+	if (!(ctx->leanEvents && ctx->st.shardCount > 1u)) MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], L));	// (lean: the light-map exchange follows on this stream and records it)
 	ctx->lightMarched = true;
 	return MV_OK;
 }
@@ -981,7 +982,7 @@ int mv_march_view(mv_ctx* ctx)
 	}
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, stageBDone(ctx));
+	if (!ctx->leanEvents) MV_HIP(ctx, stageBDone(ctx));	// (lean: the frame's tail records it behind the composite, on this stream, before anything waits for it)
 	return MV_OK;
 }
 
@@ -1657,7 +1658,9 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
 	DistState* d = ctx->dist;
 	int rc;
-	// ---- frame k: upload, cull, light march + light-map exchange (all ahead, on streams A and L), view march ----
+	struct Lean { mv_ctx* c; ~Lean() { c->leanEvents = false; } } lean = { ctx };
+	ctx->leanEvents = d->chains;
+	// ---- frame k: upload, cull, light march + light-map exchange, view march ----
 	if ((rc = mv_update_frame(ctx, cbPerFrame, perObject)) != MV_OK) return rc;
 	if ((rc = mv_cull(ctx)) != MV_OK) return rc;
 	MV_HIP(ctx, hipMemcpyAsync(d->pinnedCull[ctx->slot], ctx->fb[ctx->slot].cullBlock, 64 + (size_t)ctx->st.V * 24, hipMemcpyDeviceToHost, ctx->streamA));
@@ -1672,7 +1675,7 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 		hipStream_t E = d->chains ? streamB(ctx) : ctx->stream;
 		uint32_t* words = d->lightWords[chain];
 		const size_t count = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
-		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evLight[ctx->slot], 0));	// the owner's light march (nothing on the other ranks)
+		if (!d->chains) MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evLight[ctx->slot], 0));	// the owner's light march (nothing on the other ranks; chains: the same stream)
 		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evStageA[ctx->slot], 0));	// this frame's cull: the relit volume, its rotated buffer
 		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));	// frame k - 3, the last reader of the buffer the unpack overwrites
 		mv::launchLightExchange(E, ctx->st, words, false);

@@ -155,6 +155,8 @@ class MultiRayCaster:
         self.m_volumeWorlds = np.zeros((self.numVolumes, 12), np.float32)
         self.SetVolumesWorld(20.0, (0.0, 0.0, 0.0))  # MultiRayCaster.cpp:141
         self.cbPerFrame = np.zeros(_lib.CB_PER_FRAME_BYTES, np.uint8)
+        self._vp, self._svp, self._eye = np.zeros(16, np.float32), np.zeros(16, np.float32), np.zeros(3, np.float32)
+        self._pcache = {}
         self.perObject = np.zeros(self.numVolumes * _lib.PER_OBJECT_BYTES, np.uint8)
 
     # ---- lifetime ----
@@ -282,13 +284,30 @@ class MultiRayCaster:
     def SetAmbient(self, color, intensity):
         self.m_ambient = np.array([color[0], color[1], color[2], intensity], np.float32)
 
+    def _pp(self, name):
+        """Cached pointer of a persistent member array (rebuilt when the member is replaced): a.ctypes.data_as costs microseconds,
+        and a frame of the multi-GPU loop is enqueued in a hundred."""
+        arr = getattr(self, name)
+        c = self._pcache.get(name)
+        if c is None or c[0] is not arr:
+            c = (arr, _ptr(arr))
+            self._pcache[name] = c
+        return c[1]
+
+    def _frame_constants(self, viewProj, shadowVP, eyePt):
+        """mvh_update_frame into self.cbPerFrame / self.perObject through staging arrays with cached pointers."""
+        np.copyto(self._vp, np.asarray(viewProj, np.float32).reshape(16))
+        np.copyto(self._svp, np.asarray(shadowVP, np.float32).reshape(16))
+        np.copyto(self._eye, np.asarray(eyePt, np.float32).reshape(3))
+        W, H = self.viewport
+        pp = self._pp
+        self._lib.mvh_update_frame(self.numVolumes, pp("m_volumeWorlds"), pp("_vp"), pp("_svp"), pp("_eye"), float(W), float(H),
+                                   pp("m_lightPt"), pp("m_lightColor"), pp("m_ambient"), self.m_frameIdx, pp("cbPerFrame"), pp("perObject"))
+
     def UpdateFrame(self, viewProj, shadowVP, eyePt):
         """UpdateFrame (MultiRayCaster.cpp:316-353). shadowVP is the TRANSPOSED light view-projection (m_shadowVP)."""
-        W, H = self.viewport
-        self._lib.mvh_update_frame(self.numVolumes, _ptr(self.m_volumeWorlds), _ptr(_f32(viewProj, 16)), _ptr(_f32(shadowVP, 16)),
-                                   _ptr(_f32(eyePt, 3)), float(W), float(H), _ptr(self.m_lightPt), _ptr(self.m_lightColor),
-                                   _ptr(self.m_ambient), self.m_frameIdx, _ptr(self.cbPerFrame), _ptr(self.perObject))
-        self.UpdateFrameRaw(self.cbPerFrame, self.perObject)
+        self._frame_constants(viewProj, shadowVP, eyePt)
+        self._check(self._lib.mv_update_frame(self._ctx, self._pp("cbPerFrame"), self._pp("perObject")), "mv_update_frame")
 
     def UpdateFrameRaw(self, cbPerFrame, perObject):
         cb = np.ascontiguousarray(cbPerFrame).view(np.uint8)
@@ -448,11 +467,8 @@ class MultiRayCaster:
 
     def DistFrame(self, viewProj, shadowVP, eyePt, composite=True):
         """One frame of the multi-GPU loop: begins this frame (upload .. view march) and finishes the previous one (exchange, composite)."""
-        W, H = self.viewport
-        self._lib.mvh_update_frame(self.numVolumes, _ptr(self.m_volumeWorlds), _ptr(_f32(viewProj, 16)), _ptr(_f32(shadowVP, 16)),
-                                   _ptr(_f32(eyePt, 3)), float(W), float(H), _ptr(self.m_lightPt), _ptr(self.m_lightColor),
-                                   _ptr(self.m_ambient), self.m_frameIdx, _ptr(self.cbPerFrame), _ptr(self.perObject))
-        self._check(self._lib.mv_dist_frame(self._ctx, _ptr(self.cbPerFrame), _ptr(self.perObject), 1 if composite else 0), "mv_dist_frame")
+        self._frame_constants(viewProj, shadowVP, eyePt)
+        self._check(self._lib.mv_dist_frame(self._ctx, self._pp("cbPerFrame"), self._pp("perObject"), 1 if composite else 0), "mv_dist_frame")
         self.m_frameIdx += 1
 
     def DistFlush(self):
