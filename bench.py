@@ -366,9 +366,8 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     """Time the CPU oracle's marchV on (a bounded part of) the same frame, and check the GPU against it."""
     from oracle import mv_oracle as o
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
-    # rank 0 owns cube[i] with i % world == 0 only when sharded; pick volumes whose cube maps this rank marched
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    mine = [int(v) for v in cube if int(v) % world == 0]
+    # (sharded: after the frame's exchange every rank holds every cube map, whoever marched it -- the check then covers the exchange too)
+    mine = sorted(int(v) for v in cube)
     n = args.cpu_volumes or len(mine)
     sel = mine[:n]
     if not sel:

@@ -194,7 +194,7 @@ int mv_readback_light_map(mv_ctx* ctx, uint32_t volume, uint32_t* dst /* L^3 */)
 int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src /* L^3 */);	/* test/exchange hook */
 int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* dst /* 6 x d x d x 4 */);
 int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* dst /* 6 x d x d */);
-int mv_readback_composite(mv_ctx* ctx, uint16_t* dst /* W x H x 4 */);
+int mv_readback_composite(mv_ctx* ctx, uint16_t* dst /* W x H x 4, rows in screen order (also inside the multi-GPU frame loop, where the device buffer MV_BUF_COMPOSITE keeps them rank-major by 8-row tile row: see mv_dist_frame) */);
 int mv_clear_cube_maps(mv_ctx* ctx);	/* zero every cube map / cube depth (creation state) */
 
 int mv_get_stats(mv_ctx* ctx, mv_stats* out);	/* synchronises the stream */
@@ -245,6 +245,10 @@ int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim);
  *              all-gather of the row bands.
  * The sizes of frame k-1's collectives come from its cull results, which reached the host a frame ago.  The composite of frame k is
  * therefore complete after the NEXT mv_dist_frame (or mv_dist_flush).  Results equal the single-GPU frame bit for bit.
+ * Inside the loop the replicated cull deals the frame's work: cube-map volumes to ranks by estimated march cost (not v % shard_count),
+ * screen rows by 8-row tile row t % shard_count (not mv_shard_rows' contiguous band).  The composite image is stored rank-major --
+ * tile row t at block t % shard_count, row t / shard_count, blocks of ceil(tile rows / shard_count) tile rows -- so that the row gather
+ * is one in-place all-gather; mv_readback_composite returns screen order.
  * Two schedules, chosen by the context's flags:
  *   MV_FLAG_PIPELINE_FRAMES                               whole frames on three view streams ("chains"): everything of frame k, its
  *       collectives included, goes on view stream k % 3 with communicator k % 3 -- frames overlap as wholes, which a rank needs once

@@ -48,6 +48,7 @@ struct FrameBufs
 	uint16_t* volumeRects = nullptr;
 	float4* lightDirs = nullptr;
 	uint32_t* screenSlot = nullptr;
+	uint32_t* exchangeOff = nullptr;
 	uint4** lightTable = nullptr;
 	uint32_t* tileCost = nullptr;
 	uint32_t* lightOrder = nullptr;	// dispatch order of the light march's voxel blocks (launchLightOrder), per slot
@@ -211,6 +212,14 @@ int devAlloc(mv_ctx* ctx, T** out, size_t bytes, bool zero = true)
 	return MV_OK;
 }
 
+// rows of the composite buffer: H, or the padded rank-major layout (kFlagInterleaveRows)
+static size_t compositeRows(const DeviceState& st)
+{
+	const uint32_t sc = st.shardCount ? st.shardCount : 1u;
+	const size_t dealt = (size_t)sc * mv::interleavedRowsPerRank(st.H, sc) * 8u;
+	return sc > 1u && dealt > st.H ? dealt : st.H;
+}
+
 void applyParity(mv_ctx* ctx)
 {
 	const FrameBufs& f = ctx->fb[ctx->slot];
@@ -219,7 +228,7 @@ void applyParity(mv_ctx* ctx)
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
-	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
+	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.exchangeOff = f.exchangeOff; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
 	const OutBufs& o = ctx->ob[ctx->set];
 	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers; st.faceStamps = o.faceStamps;
@@ -479,7 +488,11 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 #endif
 		st.screenSlots = st.V < cap ? st.V : cap;
 	}
-	st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * ((st.bandRow1 - st.bandRow0 + 7u) >> 3);
+	{
+		// tile rows this context can own: its contiguous band, or (multi-GPU frame loop) every shard_count-th tile row
+		const uint32_t bandTiles = (st.bandRow1 - st.bandRow0 + 7u) >> 3, dealt = mv::interleavedRowsPerRank(st.H, st.shardCount ? st.shardCount : 1u);
+		st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * (bandTiles > dealt ? bandTiles : dealt);
+	}
 	// constants + cull outputs, once per frame slot (FrameBufs)
 	{
 		std::vector<uint4*> table(st.V);
@@ -503,6 +516,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			}
 			if ((rc = devAlloc(ctx, &f.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.screenSlot, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.exchangeOff, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.workEntries, ((size_t)st.V * 6 + st.screenSlots) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.workTileStart, ((size_t)st.V * 6 + st.screenSlots + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.cubeOffset, (size_t)st.V * sizeof(uint64_t))) != MV_OK) return bail(rc);
@@ -553,7 +567,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		// cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-121), zero-initialised
 		if ((rc = devAlloc(ctx, &f.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * st.H * sizeof(uint2))) != MV_OK) return bail(rc);
+		// (sharded: room for the rank-major layout of the multi-GPU frame loop, shard_count blocks of ceil(tile rows / shard_count) tile rows)
+		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * compositeRows(st) * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.faceStamps, (size_t)st.V * MV_NUM_CUBE_MIP * 6 * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.waveStats, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
@@ -1141,8 +1156,29 @@ int mv_readback_composite(mv_ctx* ctx, uint16_t* dst)
 {
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the producing frame may have run on another stream
-	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.composite, (size_t)ctx->st.W * ctx->st.H * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	const DeviceState& st = ctx->st;
+	const size_t rowBytes = (size_t)st.W * sizeof(uint2);
+	if (!(st.flags & mv::kFlagInterleaveRows))
+	{
+		MV_HIP(ctx, hipMemcpyAsync(dst, st.composite, rowBytes * st.H, hipMemcpyDeviceToHost, ctx->stream));
+		MV_HIP(ctx, (hipError_t)syncAll(ctx));
+		return MV_OK;
+	}
+	// multi-GPU frame loop: the image is stored rank-major by tile row (mv_kernels.hpp kFlagInterleaveRows); put the rows back in order
+	const uint32_t perRank = mv::interleavedRowsPerRank(st.H, st.shardCount), T = (st.H + 7u) >> 3;
+	const size_t rows = compositeRows(st);
+	uint8_t* tmp = static_cast<uint8_t*>(malloc(rowBytes * rows));
+	if (!tmp) return MV_ERR_OUT_OF_MEMORY;
+	const hipError_t e = hipMemcpy(tmp, st.composite, rowBytes * rows, hipMemcpyDeviceToHost);
+	if (e == hipSuccess)
+		for (uint32_t t = 0; t < T; ++t)
+		{
+			const uint32_t y0 = t * 8u, n = y0 + 8u <= st.H ? 8u : st.H - y0;
+			const size_t stored = ((size_t)(t % st.shardCount) * perRank + t / st.shardCount) * 8u;
+			memcpy(reinterpret_cast<uint8_t*>(dst) + (size_t)y0 * rowBytes, tmp + stored * rowBytes, (size_t)n * rowBytes);
+		}
+	free(tmp);
+	MV_HIP(ctx, e);
 	return MV_OK;
 }
 
@@ -1254,7 +1290,8 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 		MV_REQUIRE(ctx, index < st.V, MV_ERR_RANGE, "volume index out of range");
 		*d_ptr = st.cubeDepths + index * chain; *bytes = chain * sizeof(float); return MV_OK;
 	case MV_BUF_VOLUME_INFO: *d_ptr = st.volumeInfo; *bytes = (size_t)st.V * 8; return MV_OK;
-	case MV_BUF_COMPOSITE: *d_ptr = st.composite; *bytes = (size_t)st.W * st.H * sizeof(uint2); return MV_OK;
+	case MV_BUF_COMPOSITE:	// (inside the multi-GPU frame loop the rows are stored rank-major by tile row: use mv_readback_composite)
+		*d_ptr = st.composite; *bytes = (size_t)st.W * ((st.flags & mv::kFlagInterleaveRows) ? compositeRows(st) : st.H) * sizeof(uint2); return MV_OK;
 	case MV_BUF_DEPTH_MAP: *d_ptr = ctx->ownDepth; *bytes = (size_t)st.W * st.H * sizeof(float); return MV_OK;
 	case MV_BUF_SHADOW_MAP: *d_ptr = ctx->ownShadow; *bytes = (size_t)st.M * st.M * sizeof(uint16_t); return MV_OK;
 	case MV_BUF_TILE_COST:
@@ -1443,9 +1480,8 @@ static int distCommonInit(mv_ctx* ctx)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	if (!d->chains) MV_HIP(ctx, hipStreamCreateWithFlags(&d->streamX, hipStreamNonBlocking));
 	const uint32_t world = st.shardCount, perShard = (st.V + world - 1u) / world;
-	d->sendCap = (size_t)perShard * 6u * st.N * st.N * 12u;	// every owned volume at mip 0 with six faces
-	const uint32_t tiles = (st.H + 7u) >> 3;
-	d->maxBandBytes = (size_t)(((tiles + world - 1u) / world) * 8u) * st.W * sizeof(uint2);
+	d->sendCap = (size_t)(perShard + 1u) * 6u * st.N * st.N * 12u;	// a rank's share of all texels (every volume at mip 0 with six faces) plus one volume: the bound of the cull's balanced deal
+	d->maxBandBytes = (size_t)mv::interleavedRowsPerRank(st.H, world) * 8u * st.W * sizeof(uint2);	// one rank's block of the rank-major composite image
 	int rc;
 	for (uint32_t c = 0; c < (d->chains ? kDistChains : 1u); ++c)
 	{
@@ -1460,6 +1496,10 @@ static int distCommonInit(mv_ctx* ctx)
 		if (hipHostMalloc(reinterpret_cast<void**>(&d->pinnedCull[i]), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned cull copy");
 		MV_HIP(ctx, hipEventCreateWithFlags(&d->evCullCopied[i], hipEventDisableTiming));
 	}
+	if (world > 1u) ctx->st.flags |= mv::kFlagInterleaveRows;	// screen rows dealt by tile row instead of in contiguous bands
+#ifndef MV_DIST_STATIC_OWNERS	// (A/B builds only: v % shard_count inside the loop too)
+	ctx->st.flags |= mv::kFlagBalanceOwners;	// the cube-map volumes of a frame are dealt to the ranks by estimated cost (replicated cull: the same deal everywhere)
+#endif
 	ctx->st.flags |= mv::kFlagRotateAllLightMaps;	// every rank rotates the relit volume's light buffer: the exchange fills it on the non-owners
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
@@ -1546,7 +1586,7 @@ int mv_dist_shutdown(mv_ctx* ctx)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	if (ctx->dist->streamX) MV_HIP(ctx, hipStreamSynchronize(ctx->dist->streamX));
 	distRelease(ctx);
-	ctx->st.flags &= ~mv::kFlagRotateAllLightMaps;
+	ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows);
 	return MV_OK;
 }
 
@@ -1568,18 +1608,8 @@ static int distTailExchange(mv_ctx* ctx)
 	MV_HIP(ctx, hipEventSynchronize(d->evCullCopied[slot]));
 	const uint8_t* p = d->pinnedCull[slot];
 	const uint32_t* counters = reinterpret_cast<const uint32_t*>(p);
-	const uint16_t* info = reinterpret_cast<const uint16_t*>(p + 64);
-	const uint32_t* visible = reinterpret_cast<const uint32_t*>(p + 64 + (size_t)st.V * 8);
-	std::vector<size_t> perRank(world, 0);
-	for (uint32_t k = 0; k < counters[0] && k < st.V; ++k)
-	{
-		const uint32_t v = visible[k];
-		if (v >= st.V || !(info[4 * v + 2] & MV_CUBEMAP_RAYMARCH_BIT)) continue;
-		const size_t dim = st.N >> info[4 * v + 0];
-		perRank[v % world] += (size_t)__builtin_popcount(info[4 * v + 2] & 0x3fu) * dim * dim * 12u;
-	}
-	size_t shardBytes = 16;
-	for (size_t b : perRank) shardBytes = std::max(shardBytes, (b + 15u) & ~(size_t)15u);
+	// counters[12]: texels of the largest shard of this frame's deal (the cull knows who owns what)
+	const size_t shardBytes = std::max<size_t>(16, ((size_t)counters[12] * 12u + 15u) & ~(size_t)15u);
 	MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
 
 	hipStream_t X = distTailStream(ctx, chain);
@@ -1613,29 +1643,21 @@ static int distTailComposite(mv_ctx* ctx)
 		MV_HIP(ctx, hipGetLastError());
 		if (world > 1)
 		{
+			// The image is stored rank-major (kFlagInterleaveRows): every rank's tile rows are one contiguous block of the same size, so
+			// the frame buffer is the all-gather's output and this rank's block its input.
 			const size_t rowBytes = (size_t)st.W * sizeof(uint2);
-			const uint32_t tiles = (st.H + 7u) >> 3;
+			const size_t block = d->maxBandBytes;
 			uint8_t* frame = reinterpret_cast<uint8_t*>(st.composite);
-			const bool equalBands = tiles % world == 0u && (tiles / world) * 8u * world == st.H;
-			if (equalBands && d->inPlaceGather)
+			if (d->inPlaceGather)
 			{
-				// the frame buffer is the all-gather's output and this rank's band its input, in place (sendbuff == recvbuff + rank * count)
-				const size_t band = (size_t)(st.bandRow1 - st.bandRow0) * rowBytes;
-				const int rc = distAllGather(ctx, frame + (size_t)st.bandRow0 * rowBytes, frame, band, X, (int)chain);
+				const int rc = distAllGather(ctx, frame + (size_t)rank * block, frame, block, X, (int)chain);	// sendbuff == recvbuff + rank * count
 				if (rc != MV_OK) return rc;
 			}
 			else
 			{
-				MV_HIP(ctx, hipMemcpyAsync(d->rowSend[chain], frame + (size_t)st.bandRow0 * rowBytes, (size_t)(st.bandRow1 - st.bandRow0) * rowBytes, hipMemcpyDeviceToDevice, X));
-				const int rc = distAllGather(ctx, d->rowSend[chain], d->rowRecv[chain], d->maxBandBytes, X, (int)chain);
+				MV_HIP(ctx, hipMemcpyAsync(d->rowSend[chain], frame + (size_t)rank * block, block, hipMemcpyDeviceToDevice, X));
+				const int rc = distAllGather(ctx, d->rowSend[chain], frame, block, X, (int)chain);
 				if (rc != MV_OK) return rc;
-				for (uint32_t r = 0; r < world; ++r)
-				{
-					if (r == rank) continue;
-					const uint32_t t0 = (uint32_t)(((uint64_t)tiles * r) / world), t1 = (uint32_t)(((uint64_t)tiles * (r + 1u)) / world);
-					const uint32_t r0 = std::min(t0 * 8u, st.H), r1 = std::min(t1 * 8u, st.H);
-					if (r1 > r0) MV_HIP(ctx, hipMemcpyAsync(frame + (size_t)r0 * rowBytes, d->rowRecv[chain] + (size_t)r * d->maxBandBytes, (size_t)(r1 - r0) * rowBytes, hipMemcpyDeviceToDevice, X));
-				}
 			}
 			d->bytes += (size_t)st.H * rowBytes;
 		}

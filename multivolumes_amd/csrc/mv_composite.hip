@@ -71,7 +71,7 @@ void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim
 // Exchange, compact form (mv_dist_frame): a shard's buffer holds ONLY what the other ranks' composites can read -- the marched
 // faces (MaskBits) of its visible volumes on the cube-map scheme, at the selected mip -- back to back in ascending volume order:
 // per volume [k faces x d^2 RGBA16F texels][k faces x d^2 R32F depths], faces in mask order.  Every rank derives the same offsets
-// from the replicated cull (volumeFlags); the host only needs the padded shard size (mv_api.cpp distShardBytes).
+// from the replicated cull (volumeFlags, exchangeOff); the host only needs the size of the largest shard (counters[12]).
 // C4 at the default camera: 10 cube-map volumes x 3 faces x 128^2 x 12 B = 5.9 MB per frame instead of 18.9 MB for whole cubes.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t exchangeFaceTexels(uint32_t info, uint32_t N)
@@ -81,27 +81,19 @@ __device__ __forceinline__ uint32_t exchangeFaceTexels(uint32_t info, uint32_t N
 	return (uint32_t)__popc((info >> 5) & 0x3fu) * d * d;
 }
 
-// texel offset of volume v inside the shard of rank `r` (volumes u < v with u % shardCount == r)
-__device__ __forceinline__ uint32_t exchangeOffsetTexels(const DeviceState& st, uint32_t r, uint32_t v)
-{
-	uint32_t off = 0;
-	for (uint32_t u = r; u < v; u += st.shardCount) off += exchangeFaceTexels(st.volumeFlags[u], st.N);
-	return off;
-}
-
+// One block row per volume.  Owner and offset inside the owner's shard come from the cull (volumeFlags bits 16-31, exchangeOff):
+// v % shardCount, or the cost-balanced deal of the multi-GPU frame loop.
 template <bool PACK>
 __global__ __launch_bounds__(256) void exchangeCompactKernel(DeviceState st, uint8_t* __restrict__ buf, size_t shardBytes)
 {
-	const uint32_t perShard = (st.V + st.shardCount - 1u) / st.shardCount;
-	const uint32_t r = PACK ? st.shardIndex : blockIdx.y / perShard, j = PACK ? blockIdx.y : blockIdx.y % perShard;
-	if (!PACK && r == st.shardIndex) return;	// own volumes are already in place
-	const uint32_t v = j * st.shardCount + r;
-	if (v >= st.V) return;
+	const uint32_t v = blockIdx.y;
 	const uint32_t info = st.volumeFlags[v];
 	const uint32_t n = exchangeFaceTexels(info, st.N);
 	if (!n) return;
+	const uint32_t r = info >> 16;
+	if (PACK ? r != st.shardIndex : r == st.shardIndex) return;	// pack what this rank marched; unpack what the others did
 	const uint32_t d = st.N >> ((info >> 2) & 7u), mask = (info >> 5) & 0x3fu, face2 = d * d;
-	uint8_t* shard = buf + (PACK ? 0 : (size_t)r * shardBytes) + (size_t)exchangeOffsetTexels(st, r, v) * 12u;
+	uint8_t* shard = buf + (PACK ? 0 : (size_t)r * shardBytes) + (size_t)st.exchangeOff[v] * 12u;
 	uint2* colour = reinterpret_cast<uint2*>(shard);
 	float* depth = reinterpret_cast<float*>(shard + (size_t)n * 8u);
 	const size_t cube = (size_t)st.cubeOffset[v];
@@ -118,11 +110,10 @@ __global__ __launch_bounds__(256) void exchangeCompactKernel(DeviceState st, uin
 
 void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes)
 {
-	const uint32_t perShard = (st.V + st.shardCount - 1u) / st.shardCount;
 	const size_t n = (size_t)6 * st.N * st.N;
 	const uint32_t gx = (uint32_t)((n + 2047) / 2048);
-	if (pack) hipLaunchKernelGGL(exchangeCompactKernel<true>, dim3(gx ? gx : 1, perShard), dim3(256), 0, s, st, reinterpret_cast<uint8_t*>(buf), shardBytes);
-	else hipLaunchKernelGGL(exchangeCompactKernel<false>, dim3(gx ? gx : 1, perShard * st.shardCount), dim3(256), 0, s, st, reinterpret_cast<uint8_t*>(buf), shardBytes);
+	if (pack) hipLaunchKernelGGL(exchangeCompactKernel<true>, dim3(gx ? gx : 1, st.V), dim3(256), 0, s, st, reinterpret_cast<uint8_t*>(buf), shardBytes);
+	else hipLaunchKernelGGL(exchangeCompactKernel<false>, dim3(gx ? gx : 1, st.V), dim3(256), 0, s, st, reinterpret_cast<uint8_t*>(buf), shardBytes);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -346,7 +337,12 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 	for (uint32_t item = blockIdx.x; !MARCH || item < nRetry; item += gridDim.x)
 	{
 	const uint32_t tileIndex = MARCH ? retry[2u + item] : blockIdx.x;
-	const uint32_t tileX0 = (tileIndex % tilesX) * 8u, tileY0 = row0 + (tileIndex / tilesX) * 8u;
+	// rows [row0, row1) -- or, in the multi-GPU frame loop, this rank's tile rows (every shardCount-th; stored rank-major, see kFlagInterleaveRows)
+	const bool interleaved = st.flags & kFlagInterleaveRows;
+	const uint32_t tileRow = tileIndex / tilesX;
+	const uint32_t tileX0 = (tileIndex % tilesX) * 8u, tileY0 = interleaved ? (st.shardIndex + tileRow * st.shardCount) * 8u : row0 + tileRow * 8u;
+	const uint32_t storeY0 = interleaved ? (st.shardIndex * interleavedRowsPerRank(st.H, st.shardCount) + tileRow) * 8u : tileY0;
+	if (interleaved) row1 = st.H;
 	const uint32_t px = tileX0 + (lane & 7u), py = tileY0 + (lane >> 3);
 	uint32_t nSamples = 0, nLit = 0;
 	bool deferred = false;
@@ -364,7 +360,7 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 		nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
 		const float depthPix = st.depthMap[(size_t)py * st.W + px];
 		const vec3 dirW = pixelRayWorld(cb, nx, ny);
-		const bool inBand = py >= st.bandRow0 && py < st.bandRow1;
+		const bool inBand = interleaved || (py >= st.bandRow0 && py < st.bandRow1);
 
 		// PSDepthPeel.hlsl:12-24: the NUM_OIT_LAYERS nearest fragments, ascending depth; key = depth bits : list index.
 		// A fragment's colour (PSCube.hlsl:30-60) does not depend on the other fragments, so it is shaded here, where the volume
@@ -485,7 +481,7 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 			uint2 o;
 			o.x = (uint32_t)float_to_half_bits(result.x) | ((uint32_t)float_to_half_bits(result.y) << 16);
 			o.y = (uint32_t)float_to_half_bits(result.z) | ((uint32_t)float_to_half_bits(result.w) << 16);
-			st.composite[(size_t)py * st.W + px] = o;
+			st.composite[(size_t)(storeY0 + (lane >> 3)) * st.W + px] = o;
 		}
 	}
 
@@ -510,11 +506,14 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 
 void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background)
 {
-	const uint32_t tilesX = (st.W + 7u) >> 3, tilesY = (row1 - row0 + 7u) >> 3;
+	const bool interleaved = st.flags & kFlagInterleaveRows;	// (row0 / row1 unused: the rank's own tile rows)
+	const uint32_t tilesX = (st.W + 7u) >> 3, T = (st.H + 7u) >> 3;
+	const uint32_t tilesY = interleaved ? (st.shardIndex < T ? (T - st.shardIndex + st.shardCount - 1u) / st.shardCount : 0u) : (row1 - row0 + 7u) >> 3;
+	if (!tilesY) return;
 	hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 	// The inline march can only be asked for by a screen-space volume without a slot, by rows outside this context's band (what the
 	// view march's screen tiles cover) or by a frame without a view march: when none of them can happen the second launch is left out.
-	if (st.screenSlots < st.V || row0 < st.bandRow0 || row1 > st.bandRow1 || (st.flags & kFlagNoScreenLayers))
+	if (st.screenSlots < st.V || (!interleaved && (row0 < st.bandRow0 || row1 > st.bandRow1)) || (st.flags & kFlagNoScreenLayers))
 		hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 }
 } // namespace mv

@@ -236,6 +236,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 {
 	extern __shared__ uint32_t sInfo[];	// per volume: bit0 visible, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask; then V x 2 words of screen rectangle
 	uint32_t* sRect = sInfo + st.V;
+	uint32_t* sCost = sRect + 2u * st.V;	// the deal below: estimated march cost of a cube-map volume, 0 once dealt
 
 	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
@@ -397,8 +398,88 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	}
 	__syncthreads();
 
-	// ---- list compaction + work list, first wavefront ----
+	// ---- who marches which cube-map volume (sharded contexts): volumeFlags bits 16-31 = the owner ----
+	// Default v % shardCount.  In the multi-GPU frame loop (kFlagBalanceOwners) the volumes of THIS frame are dealt by estimated
+	// march cost -- marched faces x 8x8 tiles per face x SmpCount, all from the replicated VolumeInfo, so every rank makes the same
+	// deal: longest first, each to the rank with the least so far (ties: lowest volume, lowest rank).  With v % shardCount the
+	// slowest rank of C5 on 8 ranks carries 2.2x the mean (the volumes nearest the camera share a residue).  Lane r keeps rank r's
+	// load; up to 64 ranks, else the default.  Also the layout of the frame's cube-face exchange: exchangeOff[v] = texels of the
+	// owner's volumes below v, counters[12] = texels of the largest shard.
 	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
+	if (shardCount > 1u)
+	{
+		const bool balance = (st.flags & kFlagBalanceOwners) && shardCount <= 64u;
+		uint32_t nDeal = 0;
+		for (uint32_t v = lane; v < st.V; v += 64)
+		{
+			const uint32_t info = sInfo[v] & 0xffffu;
+			uint32_t cost = 0;
+			if ((info & 3u) == 3u)
+			{
+				const uint32_t dims = st.N >> ((info >> 2) & 7u), tiles = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
+				const unsigned long long infoBits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(st.volumeInfo) + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t smp = (uint32_t)(infoBits >> 16) & 0xffffu;
+				const unsigned long long c = (unsigned long long)__popc((info >> 5) & 0x3fu) * tiles * (smp ? smp : 1u);
+				cost = c < 0xfffffffeull ? (uint32_t)c + 1u : 0xffffffffu;	// > 0 for every cube-map volume
+			}
+			sCost[v] = balance ? cost : 0u;
+			sInfo[v] = info | ((v % shardCount) << 16);
+			nDeal += cost ? 1u : 0u;
+		}
+		nDeal = waveSumU32(nDeal);
+		__syncthreads();
+		unsigned long long load = 0;
+		for (uint32_t it = 0; balance && it < nDeal; ++it)
+		{
+			// the most expensive volume not dealt yet
+			uint32_t bestCost = 0, bestV = 0xffffffffu;
+			for (uint32_t v = lane; v < st.V; v += 64)
+			{
+				const uint32_t c = sCost[v];
+				if (c > bestCost) { bestCost = c; bestV = v; }	// (ascending v: the first of equals stays)
+			}
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1)
+			{
+				const uint32_t oc = __shfl_xor(bestCost, o), ov = __shfl_xor(bestV, o);
+				if (oc > bestCost || (oc == bestCost && ov < bestV)) { bestCost = oc; bestV = ov; }
+			}
+			// the rank with the least so far
+			unsigned long long minLoad = lane < shardCount ? load : ~0ull;
+			uint32_t minRank = lane;
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1)
+			{
+				const unsigned long long ol = __shfl_xor(minLoad, o);
+				const uint32_t orank = __shfl_xor(minRank, o);
+				if (ol < minLoad || (ol == minLoad && orank < minRank)) { minLoad = ol; minRank = orank; }
+			}
+			if (lane == minRank) load += bestCost;
+			if (lane == 0) { sCost[bestV] = 0u; sInfo[bestV] = (sInfo[bestV] & 0xffffu) | (minRank << 16); }
+			__syncthreads();
+		}
+		// exchange layout: lane r walks rank r's volumes in ascending order (64 ranks at a time)
+		uint32_t maxShard = 0;
+		for (uint32_t r0 = 0; r0 < shardCount; r0 += 64)
+		{
+			uint32_t run = 0;
+			for (uint32_t v = 0; v < st.V; ++v)
+			{
+				const uint32_t info = sInfo[v];
+				if ((info & 3u) != 3u || (info >> 16) != r0 + lane) continue;
+				const uint32_t d = st.N >> ((info >> 2) & 7u);
+				st.exchangeOff[v] = run;
+				run += (uint32_t)__popc((info >> 5) & 0x3fu) * d * d;
+			}
+			maxShard = run > maxShard ? run : maxShard;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxShard, o); maxShard = m > maxShard ? m : maxShard; }
+		if (lane == 0) st.counters[12] = maxShard;
+		for (uint32_t v = lane; v < st.V; v += 64) st.volumeFlags[v] = sInfo[v];
+	}
+
+	// ---- list compaction + work list, first wavefront ----
 	const uint64_t chain = cubeChainTexels(st.N);
 	const uint64_t lower = (1ull << lane) - 1ull;
 	uint32_t nVis = 0, nCube = 0, nOwned = 0, nEntries = 0, nTiles = 0, minMip = 0xffffffffu;
@@ -407,7 +488,8 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		const uint32_t v = base + lane;
 		const uint32_t info = v < st.V ? sInfo[v] : 0u;
 		const bool vis = info & 1u, cube = info & 2u;
-		const bool owned = (v % shardCount) == st.shardIndex;
+		const bool owned = (v % shardCount) == st.shardIndex;	// (the light march's and the whole-cube exchange's notion: fixed)
+		const bool marches = shardCount > 1u ? (info >> 16) == st.shardIndex : true;	// this frame's view march of a cube-map volume
 		const uint32_t mip = (info >> 2) & 7u, mask = (info >> 5) & 0x3fu;
 		const uint64_t bVis = __ballot(vis), bCube = __ballot(cube), bOwn = __ballot(vis && owned);
 		if (vis)
@@ -422,7 +504,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 
 		const uint32_t dims = st.N >> mip;
 		const uint32_t tilesPerFace = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
-		const uint32_t myFaces = (cube && owned) ? (uint32_t)__popc(mask) : 0u;
+		const uint32_t myFaces = (cube && marches) ? (uint32_t)__popc(mask) : 0u;
 		uint32_t totFaces, totTiles;
 		const uint32_t eBase = nEntries + waveExclusiveScanU32(myFaces, lane, totFaces);
 		const uint32_t tBase = nTiles + waveExclusiveScanU32(myFaces * tilesPerFace, lane, totTiles);
@@ -511,9 +593,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			const uint32_t x0 = r0 & 0xffffu, y0 = r0 >> 16;
 			uint32_t x1 = r1 & 0xffffu, y1 = r1 >> 16;
 			x1 = x1 < st.W - 1u ? x1 : st.W - 1u; y1 = y1 < st.H - 1u ? y1 : st.H - 1u;
-			const uint32_t yb0 = y0 > st.bandRow0 ? y0 : st.bandRow0;	// this shard's rows only
-			const uint32_t yb1 = st.bandRow1 ? (y1 < st.bandRow1 - 1u ? y1 : st.bandRow1 - 1u) : 0u;
-			if (x0 <= x1 && yb0 <= yb1 && st.bandRow1 > st.bandRow0) tiles = ((x1 >> 3) - (x0 >> 3) + 1u) * ((yb1 >> 3) - (yb0 >> 3) + 1u);
+			if (x0 <= x1 && y0 <= y1) tiles = ((x1 >> 3) - (x0 >> 3) + 1u) * screenTileRows(st, y0, y1).count;	// this shard's tile rows only
 		}
 		uint32_t totE, totT;
 		const uint32_t eBase = nEntries + waveExclusiveScanU32(take ? 1u : 0u, lane, totE);
@@ -886,9 +966,9 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 		if (faceId == 7u)
 		{
 			const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
-			const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u, y1 = rect.w < st.bandRow1 - 1u ? rect.w : st.bandRow1 - 1u;
-			const uint32_t ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3;
-			tilesX = (x1 >> 3) - (rect.x >> 3) + 1u; tilesY = (y1 >> 3) >= ty0 ? (y1 >> 3) - ty0 + 1u : 1u;
+			const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u, y1 = rect.w < st.H - 1u ? rect.w : st.H - 1u;
+			const ScreenTileRows rows = screenTileRows(st, rect.y, y1);
+			tilesX = (x1 >> 3) - (rect.x >> 3) + 1u; tilesY = rows.count ? rows.count : 1u;
 			stride = (st.W + 7u) >> 3;	// screen keys are absolute: one row of tiles down = one row of the viewport
 		}
 		else
@@ -1076,7 +1156,7 @@ void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, u
 
 void launchCull(hipStream_t s, const DeviceState& st)
 {
-	hipLaunchKernelGGL(cullKernel, dim3((st.V + 7u) / 8u), dim3(kCullThreads), st.V * 3 * sizeof(uint32_t), s, st);
+	hipLaunchKernelGGL(cullKernel, dim3((st.V + 7u) / 8u), dim3(kCullThreads), st.V * 4 * sizeof(uint32_t), s, st);
 }
 
 

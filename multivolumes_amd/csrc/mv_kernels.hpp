@@ -115,7 +115,8 @@ struct DeviceState
 									// transforms, [11] that hash differs from the one of the slot's previous frame (whose march wrote the tile costs)
 	VolumeConsts* volConsts;		// V (written by the cull)
 	uint32_t* queueHeads;			// kRayQueues heads of the march's ray queue, one per 128-byte line (zeroed by the ray setup)
-	uint32_t* ownedVisible;			// V: visible volumes of this shard, ascending
+	uint32_t* ownedVisible;			// V: visible volumes of this shard (v % shardCount), ascending
+	uint32_t* exchangeOff;			// V: texel offset of a volume's marched faces inside its owner's exchange shard (written by the cull)
 	uint32_t* workEntries;			// 6 V + screenSlots: volume | face << 16 (face 7 = screen-space RayCast entry)
 	uint32_t* workTileStart;		// entries + 1 prefix sums of 8x8 tiles
 	uint64_t* cubeOffset;			// V: texel offset of the selected mip of volume v inside cubeMaps / cubeDepths
@@ -149,8 +150,38 @@ __host__ __device__ inline uint32_t tileCostKeyCount(uint32_t V, uint32_t N, uin
 	const uint32_t t = (N + 7u) >> 3;
 	return V * 6u * t * t + maxScreenTiles + 1u;
 }
+constexpr uint32_t kFlagInterleaveRows = 0x10000000u;	// DeviceState.flags (internal, mv_dist_frame contexts): this rank's screen rows are the 8-row tile rows t with t % shardCount == shardIndex (not the contiguous band), and the composite image is stored rank-major: tile row t at (t % shardCount) * ceil(T / shardCount) + t / shardCount
+constexpr uint32_t kFlagBalanceOwners = 0x20000000u;	// DeviceState.flags (internal, mv_dist_frame contexts): the cull deals the cube-map volumes of a frame to the ranks by estimated march cost instead of v % shardCount (volumeFlags bits 16-31 name the owner either way)
+constexpr uint32_t kFlagNoScreenLayers = 0x40000000u;	// DeviceState.flags (internal, per composite launch): this frame has had no view march, so the RayCast layers are not this frame's: the composite marches screen-space volumes itself
+constexpr uint32_t kFlagRotateAllLightMaps = 0x80000000u;	// DeviceState.flags (internal): every rank rotates the relit volume's light buffer, not only its owner
+
+// The 8-row tile rows of a screen rectangle [y0, y1] (pixel rows, y1 already clipped to the viewport) that this context marches and
+// composites: those inside its contiguous band, or -- in the multi-GPU frame loop -- every shardCount-th one.  Work in the middle of
+// the screen (the rectangles of the near volumes, most composite fragments) then spreads over all ranks instead of landing on the
+// two that own the middle bands (C5 on 8 ranks: the slowest rank carried 2.2x the mean).
+struct ScreenTileRows { uint32_t first, count, step; };
+__host__ __device__ inline uint32_t interleavedRowsPerRank(uint32_t H, uint32_t shardCount) { return (((H + 7u) >> 3) + shardCount - 1u) / shardCount; }
+__device__ inline ScreenTileRows screenTileRows(const DeviceState& st, uint32_t y0, uint32_t y1)
+{
+	ScreenTileRows r;
+	if (st.flags & kFlagInterleaveRows)
+	{
+		const uint32_t ty0 = y0 >> 3, ty1 = y1 >> 3, w = st.shardCount;
+		r.first = ty0 + (st.shardIndex + w - ty0 % w) % w;
+		r.count = (y0 <= y1 && r.first <= ty1) ? (ty1 - r.first) / w + 1u : 0u;
+		r.step = w;
+		return r;
+	}
+	const uint32_t yb0 = y0 > st.bandRow0 ? y0 : st.bandRow0;
+	const uint32_t yb1 = st.bandRow1 ? (y1 < st.bandRow1 - 1u ? y1 : st.bandRow1 - 1u) : 0u;
+	r.first = yb0 >> 3;
+	r.count = (yb0 <= yb1 && st.bandRow1 > st.bandRow0) ? (yb1 >> 3) - r.first + 1u : 0u;
+	r.step = 1u;
+	return r;
+}
+
 // Key of a tile in the cost table (the sample count of its longest ray + 1 the last time it was marched; 0 = never): a cube tile by
-// (volume, face, tile of the face), a screen tile by (screen slot, ABSOLUTE 8x8 pixel tile of this context's row band) -- not by its
+// (volume, face, tile of the face), a screen tile by (screen slot, ABSOLUTE 8x8 pixel tile among this context's tile rows) -- not by its
 // index in the volume's rectangle, which changes whenever the rectangle does (a moving camera).
 __device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
 {
@@ -158,10 +189,13 @@ __device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId,
 	if (faceId == 7u)
 	{
 		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
-		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
-		const uint32_t tx0 = rect.x >> 3, ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3, tw = (x1 >> 3) - tx0 + 1u;
-		const uint32_t tilesX = (st.W + 7u) >> 3, bandTilesY = (st.bandRow1 - st.bandRow0 + 7u) >> 3;
-		const uint32_t tx = tx0 + localTile % tw, ty = ty0 + localTile / tw - (st.bandRow0 >> 3);
+		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u, y1 = rect.w < st.H - 1u ? rect.w : st.H - 1u;
+		const ScreenTileRows rows = screenTileRows(st, rect.y, y1);
+		const uint32_t tx0 = rect.x >> 3, tw = (x1 >> 3) - tx0 + 1u;
+		const bool il = st.flags & kFlagInterleaveRows;
+		const uint32_t tilesX = (st.W + 7u) >> 3, bandTilesY = il ? interleavedRowsPerRank(st.H, st.shardCount) : (st.bandRow1 - st.bandRow0 + 7u) >> 3;
+		const uint32_t tyAbs = rows.first + (localTile / tw) * rows.step;
+		const uint32_t tx = tx0 + localTile % tw, ty = il ? tyAbs / st.shardCount : tyAbs - (st.bandRow0 >> 3);
 		const uint32_t slot = st.screenSlot[volumeId];
 		const uint32_t idx = ((slot < st.screenSlots ? slot : 0u) * bandTilesY + (ty < bandTilesY ? ty : bandTilesY - 1u)) * tilesX + (tx < tilesX ? tx : tilesX - 1u);
 		return st.V * 6u * t * t + (idx < st.maxScreenTiles ? idx : st.maxScreenTiles);
@@ -208,6 +242,4 @@ void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim
 void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes);	// marched faces only (mv_dist_frame)
 void launchLightExchange(hipStream_t s, const DeviceState& st, uint32_t* words, bool unpack);
 void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag, bool marchFollows = true);
-constexpr uint32_t kFlagNoScreenLayers = 0x40000000u;	// DeviceState.flags (internal, per composite launch): this frame has had no view march, so the RayCast layers are not this frame's: the composite marches screen-space volumes itself
-constexpr uint32_t kFlagRotateAllLightMaps = 0x80000000u;	// DeviceState.flags (internal): every rank rotates the relit volume's light buffer, not only its owner
 } // namespace mv

@@ -135,8 +135,9 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 		// screen rectangle of the volume, clipped to the viewport, in 8x8 pixel tiles
 		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
 		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
-		const uint32_t tx0 = rect.x >> 3, ty0 = (rect.y > st.bandRow0 ? rect.y : st.bandRow0) >> 3, tw = (x1 >> 3) - tx0 + 1u;
-		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (ty0 + localTile / tw) * 8u + (lane >> 3);
+		const ScreenTileRows rows = screenTileRows(st, rect.y, rect.w < st.H - 1u ? rect.w : st.H - 1u);	// this context's tile rows of the rectangle (its band, or every shardCount-th)
+		const uint32_t tx0 = rect.x >> 3, tw = (x1 >> 3) - tx0 + 1u;
+		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (rows.first + (localTile / tw) * rows.step) * 8u + (lane >> 3);
 		if (px < st.W && py < st.H)
 		{
 			// PSCube.hlsl:37-39, then the fragment the rasteriser would have produced for this volume at this pixel

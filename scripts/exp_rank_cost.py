@@ -11,9 +11,12 @@ from multivolumes_amd import raycaster as rc
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
 cfg = dict(scene.CONFIGS[name]); V, N, L = cfg["V"], cfg["N"], cfg["L"]
 vols = [rc.synth_volume(N, k) for k in range(V)]
-frames = 400
+frames = int(os.environ.get("FRAMES", "400"))
+only = os.environ.get("MODE")  # "chains" / "single": one schedule only
 for mode, flags in (("chains (whole frames on three view streams)", _lib.MV_FLAG_PIPELINE_FRAMES),
                     ("single view stream", _lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_SINGLE_VIEW_STREAM)):
+    if only and not mode.startswith(only):
+        continue
     print(mode, flush=True)
     for world in (1, 2, 4, 8):
         per_rank = []
@@ -21,7 +24,7 @@ for mode, flags in (("chains (whole frames on three view streams)", _lib.MV_FLAG
             with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=1024, flags=flags, shard=(rank, world)) as c:
                 fr = scene.setup_raycaster(c, cfg, vols)
                 c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0); c.DistSetInPlaceGather(True)  # like RCCL: no staging copies
-                for _ in range(200): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+                for _ in range(min(200, frames)): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
                 c.DistFlush(); c.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(frames): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
