@@ -420,6 +420,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.N = cfg->grid_size; st.bricks = (cfg->grid_size + 3u) >> 2; st.L = cfg->light_grid_size;
 	st.V = cfg->num_volumes; st.S = cfg->num_volume_srcs; st.W = cfg->viewport_w; st.H = cfg->viewport_h; st.M = cfg->shadow_map_size;
 	st.flags = cfg->flags; st.shardIndex = cfg->shard_count > 1 ? cfg->shard_index : 0u; st.shardCount = cfg->shard_count > 1 ? cfg->shard_count : 1u;
+	st.shardMagic = st.shardCount > 1u ? (uint32_t)(((1ull << 32) + st.shardCount - 1u) / st.shardCount) : 0xffffffffu;
+	st.rowsPerRank = mv::interleavedRowsPerRank(st.H, st.shardCount);
 	st.maxRaySamples = 256; st.maxLightSamples = 96;	// MultiRayCaster.cpp:65-66
 	st.hasLightProbe = 0;
 

@@ -341,7 +341,7 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 	const bool interleaved = st.flags & kFlagInterleaveRows;
 	const uint32_t tileRow = tileIndex / tilesX;
 	const uint32_t tileX0 = (tileIndex % tilesX) * 8u, tileY0 = interleaved ? (st.shardIndex + tileRow * st.shardCount) * 8u : row0 + tileRow * 8u;
-	const uint32_t storeY0 = interleaved ? (st.shardIndex * interleavedRowsPerRank(st.H, st.shardCount) + tileRow) * 8u : tileY0;
+	const uint32_t storeY0 = interleaved ? (st.shardIndex * st.rowsPerRank + tileRow) * 8u : tileY0;
 	if (interleaved) row1 = st.H;
 	const uint32_t px = tileX0 + (lane & 7u), py = tileY0 + (lane >> 3);
 	uint32_t nSamples = 0, nLit = 0;

@@ -65,6 +65,7 @@ struct DeviceState
 	uint32_t M;				// shadow-map edge
 	uint32_t flags;
 	uint32_t shardIndex, shardCount;
+	uint32_t shardMagic, rowsPerRank;	// ceil(2^32 / shardCount): t / shardCount == umulhi(t, shardMagic) for the tile rows and ranks in question (t < 2^16, shardCount <= 2^10); ceil(tile rows / shardCount)
 	uint32_t bandRow0, bandRow1;	// screen rows [bandRow0, bandRow1) this shard composites (8-row aligned; the whole screen when unsharded):
 									// the screen tiles of the fused RayCast are marched for these rows only, for EVERY screen-space-scheme volume
 	uint32_t maxRaySamples, maxLightSamples;
@@ -161,14 +162,21 @@ constexpr uint32_t kFlagRotateAllLightMaps = 0x80000000u;	// DeviceState.flags (
 // two that own the middle bands (C5 on 8 ranks: the slowest rank carried 2.2x the mean).
 struct ScreenTileRows { uint32_t first, count, step; };
 __host__ __device__ inline uint32_t interleavedRowsPerRank(uint32_t H, uint32_t shardCount) { return (((H + 7u) >> 3) + shardCount - 1u) / shardCount; }
-__device__ inline ScreenTileRows screenTileRows(const DeviceState& st, uint32_t y0, uint32_t y1)
+// t / shardCount without a division (a scalar division is a long dependent chain, and the compiler evaluates both row partitions
+// and selects: with `/` here the view march alone lost 5 % on ONE GPU, where none of this is ever taken)
+__device__ __forceinline__ uint32_t divShards(const DeviceState& st, uint32_t t) { return __umulhi(t, st.shardMagic); }
+// (IL = the interleaved partition, as a template parameter: the tile march is instantiated for both, because with the choice made at
+// run time inside it the compiler evaluates both and selects, and the view march ALONE -- one GPU, nothing interleaved -- lost 5 %.)
+template <bool IL>
+__device__ __forceinline__ ScreenTileRows screenTileRowsT(const DeviceState& st, uint32_t y0, uint32_t y1)
 {
 	ScreenTileRows r;
-	if (st.flags & kFlagInterleaveRows)
+	if (IL)
 	{
 		const uint32_t ty0 = y0 >> 3, ty1 = y1 >> 3, w = st.shardCount;
-		r.first = ty0 + (st.shardIndex + w - ty0 % w) % w;
-		r.count = (y0 <= y1 && r.first <= ty1) ? (ty1 - r.first) / w + 1u : 0u;
+		const uint32_t m = ty0 - divShards(st, ty0) * w;	// ty0 % w
+		r.first = ty0 + (st.shardIndex >= m ? st.shardIndex - m : st.shardIndex + w - m);
+		r.count = (y0 <= y1 && r.first <= ty1) ? divShards(st, ty1 - r.first) + 1u : 0u;
 		r.step = w;
 		return r;
 	}
@@ -179,28 +187,36 @@ __device__ inline ScreenTileRows screenTileRows(const DeviceState& st, uint32_t 
 	r.step = 1u;
 	return r;
 }
+__device__ inline ScreenTileRows screenTileRows(const DeviceState& st, uint32_t y0, uint32_t y1)
+{
+	return (st.flags & kFlagInterleaveRows) ? screenTileRowsT<true>(st, y0, y1) : screenTileRowsT<false>(st, y0, y1);
+}
 
 // Key of a tile in the cost table (the sample count of its longest ray + 1 the last time it was marched; 0 = never): a cube tile by
 // (volume, face, tile of the face), a screen tile by (screen slot, ABSOLUTE 8x8 pixel tile among this context's tile rows) -- not by its
 // index in the volume's rectangle, which changes whenever the rectangle does (a moving camera).
-__device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
+template <bool IL>
+__device__ __forceinline__ uint32_t tileCostKeyT(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
 {
 	const uint32_t t = (st.N + 7u) >> 3;
 	if (faceId == 7u)
 	{
 		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
 		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u, y1 = rect.w < st.H - 1u ? rect.w : st.H - 1u;
-		const ScreenTileRows rows = screenTileRows(st, rect.y, y1);
+		const ScreenTileRows rows = screenTileRowsT<IL>(st, rect.y, y1);
 		const uint32_t tx0 = rect.x >> 3, tw = (x1 >> 3) - tx0 + 1u;
-		const bool il = st.flags & kFlagInterleaveRows;
-		const uint32_t tilesX = (st.W + 7u) >> 3, bandTilesY = il ? interleavedRowsPerRank(st.H, st.shardCount) : (st.bandRow1 - st.bandRow0 + 7u) >> 3;
+		const uint32_t tilesX = (st.W + 7u) >> 3, bandTilesY = IL ? st.rowsPerRank : (st.bandRow1 - st.bandRow0 + 7u) >> 3;
 		const uint32_t tyAbs = rows.first + (localTile / tw) * rows.step;
-		const uint32_t tx = tx0 + localTile % tw, ty = il ? tyAbs / st.shardCount : tyAbs - (st.bandRow0 >> 3);
+		const uint32_t tx = tx0 + localTile % tw, ty = IL ? divShards(st, tyAbs) : tyAbs - (st.bandRow0 >> 3);
 		const uint32_t slot = st.screenSlot[volumeId];
 		const uint32_t idx = ((slot < st.screenSlots ? slot : 0u) * bandTilesY + (ty < bandTilesY ? ty : bandTilesY - 1u)) * tilesX + (tx < tilesX ? tx : tilesX - 1u);
 		return st.V * 6u * t * t + (idx < st.maxScreenTiles ? idx : st.maxScreenTiles);
 	}
 	return (volumeId * 6u + faceId) * t * t + localTile;
+}
+__device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId, uint32_t faceId, uint32_t localTile, uint32_t tile, uint32_t nCubeTiles)
+{
+	return (st.flags & kFlagInterleaveRows) ? tileCostKeyT<true>(st, volumeId, faceId, localTile, tile, nCubeTiles) : tileCostKeyT<false>(st, volumeId, faceId, localTile, tile, nCubeTiles);
 }
 
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)

@@ -40,7 +40,8 @@ static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 // LUT = the volume's per-axis address tables live in LDS (mv_device.hpp "address tables"): used while they leave room for five
 // wavefronts per SIMD (N <= kLutMaxN).
 constexpr uint32_t kLutMaxN = 256;
-template <bool OVERFLOW, bool LUT>
+// IL: the rows of a sharded context are dealt by tile row (kFlagInterleaveRows) -- compile-time, see screenTileRowsT
+template <bool OVERFLOW, bool LUT, bool IL>
 __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesKernel(DeviceState st, uint32_t firstSlot)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 		// screen rectangle of the volume, clipped to the viewport, in 8x8 pixel tiles
 		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
 		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
-		const ScreenTileRows rows = screenTileRows(st, rect.y, rect.w < st.H - 1u ? rect.w : st.H - 1u);	// this context's tile rows of the rectangle (its band, or every shardCount-th)
+		const ScreenTileRows rows = screenTileRowsT<IL>(st, rect.y, rect.w < st.H - 1u ? rect.w : st.H - 1u);	// this context's tile rows of the rectangle (its band, or every shardCount-th)
 		const uint32_t tx0 = rect.x >> 3, tw = (x1 >> 3) - tx0 + 1u;
 		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (rows.first + (localTile / tw) * rows.step) * 8u + (lane >> 3);
 		if (px < st.W && py < st.H)
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 	const uint32_t nCubeTiles = st.counters[6];
 	if (lane == 0)
 	{
-		st.tileCost[tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles)] = maxS + 1u;	// (0 = never marched)
+		st.tileCost[tileCostKeyT<IL>(st, volumeId, faceId, localTile, tile, nCubeTiles)] = maxS + 1u;	// (0 = never marched)
 		// counters: a slot of the wave-stats table shared by the tiles that map to it (no-return atomics, once per tile)
 		unsigned long long* s = reinterpret_cast<unsigned long long*>(st.waveStats) + (size_t)(slot % st.marchWaves) * 8u;
 		if (!screenTile)
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 uint32_t marchTilesResidentWaves(int device)
 {
 	int perCu = 0, cus = 0;
-	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, marchTilesKernel<false, true>, 64 * kTileWaves, 0) != hipSuccess || perCu <= 0) perCu = 8;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, marchTilesKernel<false, true, false>, 64 * kTileWaves, 0) != hipSuccess || perCu <= 0) perCu = 8;
 	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
 	return (uint32_t)perCu * (uint32_t)cus * kTileWaves;
 }
@@ -309,13 +310,20 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
 	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
 	blocks = ((blocks + 7) / 8) * 8;
-	if (st.N <= kLutMaxN) hipLaunchKernelGGL((marchTilesKernel<false, MV_TILE_LUT != 0>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
-	else hipLaunchKernelGGL((marchTilesKernel<false, false>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+	const bool il = st.flags & kFlagInterleaveRows;
+	if (st.N <= kLutMaxN && MV_TILE_LUT != 0)
+	{
+		if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+		else hipLaunchKernelGGL((marchTilesKernel<false, true, false>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+	}
+	else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+	else hipLaunchKernelGGL((marchTilesKernel<false, false, false>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
 	return blocks * kTileWaves < maxTiles ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
 }
 
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot)
 {
-	hipLaunchKernelGGL((marchTilesKernel<true, false>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
+	if (st.flags & kFlagInterleaveRows) hipLaunchKernelGGL((marchTilesKernel<true, false, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
+	else hipLaunchKernelGGL((marchTilesKernel<true, false, false>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
 }
 } // namespace mv
