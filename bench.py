@@ -367,6 +367,7 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     from oracle import mv_oracle as o
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
     # (sharded: after the frame's exchange every rank holds every cube map, whoever marched it -- the check then covers the exchange too)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
     mine = sorted(int(v) for v in cube)
     n = args.cpu_volumes or len(mine)
     sel = mine[:n]
