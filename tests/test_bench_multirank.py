@@ -53,3 +53,20 @@ def test_two_ranks_on_one_gpu(extra):
     s = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     for k in ("view_samples_per_frame", "lit_samples_per_frame", "rays_per_frame", "light_samples_per_frame"):
         assert d["config"][k] == s["config"][k], k
+
+
+@pytest.mark.gpu
+def test_one_rank_bench_line_carries_both_cpu_baselines():
+    """The default (N = 1) bench line: `cpu_baseline` is the reference's compiled shader on the host cores when oracle/_ref travelled
+    with the tree (kind "reference", equal to the oracle and to the GPU), else the oracle ("port") -- never a silently failed leg."""
+    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2"], 300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cb = d["cpu_baseline"]
+    assert "reference_error" not in cb, cb
+    assert cb["gpu_vs_oracle_max_abs_err"] == 0.0
+    if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libmv_dxref.so")):
+        assert cb["kind"] == "reference" and cb["reference_equals_oracle"] and cb["gpu_vs_reference_max_abs_err"] == 0.0
+    else:
+        assert cb["kind"] == "port"
+    assert d["roofline"]["frac"] > 0 and d["n_gpus"] == 1
