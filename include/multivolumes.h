@@ -45,6 +45,7 @@ extern "C" {
 #define MV_PER_OBJECT_BYTES 224		/* MultiRayCaster.cpp:35-41 */
 #define MV_CB_PER_FRAME_BYTES 212	/* MultiRayCaster.cpp:23-33 */
 #define MV_CUBEMAP_RAYMARCH_BIT 0x8000u	/* Common.hlsli:11 */
+#define MV_MAX_SHARDS 1024u		/* mv_config.shard_count limit */
 #define MV_MAX_VOLUMES 1024u		/* mv_config.num_volumes limit (the reference's scenes use 2..64, Bin/all64.bat); volume sources: 16383 (VolTexId:14) */
 
 /* error codes */
@@ -92,7 +93,7 @@ typedef struct mv_config
 	uint32_t flags;				/* MV_FLAG_* */
 	void* stream;				/* hipStream_t to order all work on; NULL = the context creates its own */
 	uint32_t shard_index;		/* multi-GPU: this context marches volumes v with v % shard_count == shard_index */
-	uint32_t shard_count;		/* 0 or 1 = unsharded */
+	uint32_t shard_count;		/* 0 or 1 = unsharded; at most MV_MAX_SHARDS */
 } mv_config;
 
 /* counters accumulated since the last mv_reset_stats (all device-side, exact) */

@@ -350,6 +350,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
 		return MV_ERR_INVALID_ARG;
 	if (cfg->shard_count > 1 && cfg->shard_index >= cfg->shard_count) return MV_ERR_INVALID_ARG;
+	if (cfg->shard_count > MV_MAX_SHARDS) return MV_ERR_INVALID_ARG;	// owner ids travel in 16 bits of a word, rows are dealt through a 32-bit reciprocal
 
 	int nDev = 0;
 	if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0 || cfg->device < 0 || cfg->device >= nDev) return MV_ERR_NO_DEVICE;
