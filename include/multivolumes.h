@@ -113,7 +113,8 @@ typedef struct mv_stats
 
 const char* mv_error_string(int code);
 const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
-uint32_t mv_abi_version(void);
+#define MV_ABI_VERSION 2u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS */
+uint32_t mv_abi_version(void);	/* == MV_ABI_VERSION of the header the library was built from */
 
 /* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,
  * zero-initialised), VolumeDesc[V] = {i % S, 5, N} (:471-479), VolumeInfo[V], visible / cube-map lists + counters. */

@@ -338,7 +338,7 @@ const char* mv_error_string(int code)
 }
 
 const char* mv_last_error(const mv_ctx* ctx) { return ctx ? ctx->lastError.c_str() : ""; }
-uint32_t mv_abi_version(void) { return 1u; }
+uint32_t mv_abi_version(void) { return MV_ABI_VERSION; }
 uint64_t mv_cube_chain_texels(uint32_t N) { return mv::cubeChainTexels(N); }
 uint64_t mv_cube_mip_offset(uint32_t N, uint32_t mip) { return mv::cubeMipOffset(N, mip); }
 
