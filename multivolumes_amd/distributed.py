@@ -85,7 +85,7 @@ def unpack_gathered_numpy(N, V, rank, world, volume_info, visible, gathered, cub
 def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True):
     """Attach the in-library multi-GPU frame loop (mv_dist_frame) to a sharded caster.
 
-    With the NCCL (= RCCL) backend the library opens RCCL itself and creates its own two communicators from ids that rank 0 makes and
+    With the NCCL (= RCCL) backend the library opens RCCL itself and creates its own communicators (three: one per frame chain) from ids that rank 0 makes and
     torch.distributed only broadcasts: no Python and no torch call inside the frame loop.  Otherwise (gloo: CPU-side tests, or RCCL
     could not be initialised) the collectives are torch.distributed calls on tensors that alias the library's buffers, handed to the
     library as callbacks.  Returns "rccl" or "torch-callbacks"."""
