@@ -216,6 +216,8 @@ void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */
 #define MV_BUF_DEPTH_MAP 6
 #define MV_BUF_SHADOW_MAP 7
 #define MV_BUF_TILE_COST 9		/* index = frame slot (0..3): the view march's tile cost table, uint32 per key: longest ray's samples + 1, 0 = never marched (diagnostics) */
+#define MV_BUF_VOLUME_FLAGS 10	/* the cull's per-volume word of the current frame slot, uint32: bit 0 visible, bit 1 cube-map scheme, bits 2-4 mip, bits 5-10 marched faces, bits 16-31 the rank that marches the volume's cube map (sharded contexts; v % shard_count, or the cost deal inside mv_dist_frame) */
+#define MV_BUF_EXCHANGE_OFFSETS 11	/* uint32 per volume: texel offset of its marched faces inside its owner's shard of the frame's cube-face all-gather (sharded contexts) */
 #define MV_BUF_MARCH_TIMELINE 8	/* 8 x uint64 per march wavefront; only diagnostic builds (-DMV_TIMELINE) fill it (scripts/march_timeline.py) */
 int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, size_t* bytes);
 

@@ -1300,6 +1300,8 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 	case MV_BUF_TILE_COST:
 		MV_REQUIRE(ctx, index < kFrameSlots, MV_ERR_RANGE, "frame slot out of range");
 		*d_ptr = ctx->fb[index].tileCost; *bytes = (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t); return MV_OK;
+	case MV_BUF_VOLUME_FLAGS: *d_ptr = st.volumeFlags; *bytes = (size_t)st.V * sizeof(uint32_t); return MV_OK;
+	case MV_BUF_EXCHANGE_OFFSETS: *d_ptr = st.exchangeOff; *bytes = (size_t)st.V * sizeof(uint32_t); return MV_OK;
 	case MV_BUF_MARCH_TIMELINE: *d_ptr = st.timeline; *bytes = (size_t)st.marchWaves * 8 * sizeof(uint64_t); return MV_OK;
 	default: return fail(ctx, MV_ERR_INVALID_ARG, "unknown buffer id");
 	}

@@ -82,6 +82,65 @@ def unpack_gathered_numpy(N, V, rank, world, volume_info, visible, gathered, cub
             cube_depths[v][off:off + n] = gathered[base + n_slot * 8:base + n_slot * 8 + n * 4].view(np.float32)
 
 
+# ---- the work deal of the in-library frame loop (mv_dist_frame), restated on the host ----
+# Inside the loop the replicated cull (csrc/mv_kernels.hip cullKernel, its last workgroup) decides per frame who marches which cube-map
+# volume and who owns which screen rows; every rank derives the same answer from VolumeInfo.  These functions are that rule in numpy:
+# the CPU tests run the protocol with them over gloo, a GPU test compares them with what the kernel wrote.
+def deal_cube_volumes(volume_info, visible, V, N, world):
+    """owner[v] for every volume.  Visible cube-map volumes are dealt by estimated march cost -- marched faces x 8x8 tiles per face x
+    SmpCount (+ 1) -- longest first, each to the rank with the least so far (ties: lowest volume, lowest rank); every other volume
+    keeps v % world.  (world <= 64: beyond that the kernel keeps v % world for all.)"""
+    owner = np.arange(V, dtype=np.uint32) % world
+    if world < 2 or world > 64:
+        return owner
+    vis = set(int(v) for v in visible)
+    cost = np.zeros(V, np.uint64)
+    for v in range(V):
+        mask = int(volume_info[v, 2])
+        if v not in vis or not (mask & 0x8000):
+            continue
+        dims = N >> int(volume_info[v, 0])
+        tiles = ((dims + 7) >> 3) ** 2
+        c = bin(mask & 0x3F).count("1") * tiles * max(int(volume_info[v, 1]), 1)
+        cost[v] = min(c + 1, 0xFFFFFFFF)
+    load = np.zeros(world, np.uint64)
+    left = cost.copy()
+    for _ in range(int((cost > 0).sum())):
+        v = int(np.argmax(left))          # first of the equals = lowest volume
+        r = int(np.argmin(load))          # first of the equals = lowest rank
+        owner[v] = r
+        load[r] += left[v]
+        left[v] = 0
+    return owner
+
+
+def compact_exchange_layout(volume_info, visible, owner, V, N, world):
+    """(texel offset of every volume inside its owner's shard, texels of the largest shard): a shard holds the marched faces of the
+    owner's visible cube-map volumes at their mip, ascending volume order, colour then depth per volume (exchangeCompactKernel)."""
+    vis = set(int(v) for v in visible)
+    off = np.zeros(V, np.uint32)
+    run = np.zeros(world, np.uint64)
+    for v in range(V):
+        mask = int(volume_info[v, 2])
+        if v not in vis or not (mask & 0x8000):
+            continue
+        d = N >> int(volume_info[v, 0])
+        off[v] = run[owner[v]]
+        run[owner[v]] += bin(mask & 0x3F).count("1") * d * d
+    return off, int(run.max()) if world else 0
+
+
+def tile_rows_of_rank(H, rank, world):
+    """8-row tile rows a rank marches (RayCast-scheme volumes) and composites inside the loop: every world-th one."""
+    return list(range(rank, (H + 7) // 8, world))
+
+
+def stored_tile_row(t, H, world):
+    """Where tile row t sits in the loop's composite buffer (rank-major: every rank's rows are one contiguous block)."""
+    per_rank = ((H + 7) // 8 + world - 1) // world
+    return (t % world) * per_rank + t // world
+
+
 def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True):
     """Attach the in-library multi-GPU frame loop (mv_dist_frame) to a sharded caster.
 

@@ -129,3 +129,41 @@ def test_rccl_transport_on_one_rank():
             assert np.array_equal(c.ReadBackComposite(), imgs[-1])
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("V,world", [(16, 4), (64, 8), (64, 3)])
+def test_the_culls_deal_equals_its_host_restatement(V, world):
+    """What cullKernel's last workgroup decides inside the loop -- the owner of every cube-map volume (volumeFlags bits 16-31), the
+    layout of the frame's cube-face exchange (exchangeOff) -- equals multivolumes_amd/distributed.py's numpy restatement of the rule
+    (which tests/test_distributed_cpu.py runs as a protocol over gloo), on every rank."""
+    import torch
+    from multivolumes_amd import MultiRayCaster, _lib, scene
+    from multivolumes_amd import raycaster as rc
+    from multivolumes_amd import distributed as D
+    cfg = dict(scene.CONFIGS["T2"], V=V, W=256, H=168)
+    N, L = cfg["N"], cfg["L"]
+    vols = [rc.synth_volume(N, k % 5) for k in range(V)]
+    owners = []
+    for rank in range(world):
+        flags = _lib.MV_FLAG_PIPELINE_FRAMES
+        with MultiRayCaster(N, L, V, 5, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world)) as c:
+            fr = scene.setup_raycaster(c, cfg, vols[:5])
+            c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0)
+            c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+            c.DistFlush()
+            c.synchronize()
+            info = c.ReadBackVolumeInfo()
+            vis, cube = c.ReadBackVisibleLists()
+            pf, nb = c.GetBuffer(_lib.MV_BUF_VOLUME_FLAGS)
+            po_, nb2 = c.GetBuffer(_lib.MV_BUF_EXCHANGE_OFFSETS)
+            vflags = D._device_view(pf, nb).view(torch.int32).cpu().numpy().view(np.uint32)
+            offs = D._device_view(po_, nb2).view(torch.int32).cpu().numpy().view(np.uint32)
+        owner = D.deal_cube_volumes(info, vis, V, N, world)
+        assert np.array_equal(vflags >> 16, owner), (rank, (vflags >> 16).tolist(), owner.tolist())
+        off, biggest = D.compact_exchange_layout(info, vis, owner, V, N, world)
+        for v in (int(x) for x in cube):
+            assert offs[v] == off[v], (rank, v)
+        owners.append(owner)
+        assert len(cube) >= 2
+    assert all(np.array_equal(owners[0], o) for o in owners), "every rank makes the same deal"
+    assert len(set(int(owners[0][int(v)]) for v in cube)) >= min(world, len(cube)) - 1

@@ -123,3 +123,141 @@ def test_two_rank_gloo_pipeline_matches_single_process(oracle, tmp_path):
                               ref["info"], ref["vis"], ref["cubeMaps"], ref["cubeDepths"])
     assert np.array_equal(got["full"], img)
     assert int(got["samples"][0]) == ref["stats"]["view_samples"] and int(got["samples"][1]) == ref["stats"]["rays"]
+
+
+def test_the_loops_work_deal_pure():
+    """The rule by which the in-library frame loop deals a frame's work (distributed.py mirrors of the cull's last workgroup): every
+    visible cube-map volume to exactly one rank, loads within one volume's cost of each other, the exchange layout dense per owner; every
+    tile row to exactly one rank, and a bijective rank-major storage order."""
+    rng = np.random.default_rng(5)
+    for world in (2, 3, 4, 8):
+        for V, N in ((16, 256), (64, 256), (7, 48)):
+            info = np.zeros((V, 4), np.uint16)
+            info[:, 0] = rng.integers(0, 3, V)                         # mip
+            info[:, 1] = rng.integers(8, 257, V)                       # SmpCount
+            info[:, 2] = rng.integers(1, 64, V) | np.where(rng.random(V) < 0.7, 0x8000, 0)   # face mask | cube-map scheme bit
+            visible = [v for v in range(V) if rng.random() < 0.8]
+            owner = D.deal_cube_volumes(info, visible, V, N, world)
+            cube = [v for v in visible if info[v, 2] & 0x8000]
+            cost = {v: bin(int(info[v, 2]) & 0x3F).count("1") * (((N >> int(info[v, 0])) + 7) // 8) ** 2 * int(info[v, 1]) + 1 for v in cube}
+            load = [sum(cost[v] for v in cube if owner[v] == r) for r in range(world)]
+            assert all(0 <= owner[v] < world for v in range(V))
+            assert all(owner[v] == v % world for v in range(V) if v not in cube)
+            if cube:
+                assert max(load) - min(load) <= max(cost.values()), (world, V, load)     # the greedy bound
+            off, biggest = D.compact_exchange_layout(info, visible, owner, V, N, world)
+            for r in range(world):
+                mine = [v for v in cube if owner[v] == r]
+                run = 0
+                for v in mine:                                            # ascending, back to back
+                    assert off[v] == run
+                    run += bin(int(info[v, 2]) & 0x3F).count("1") * (N >> int(info[v, 0])) ** 2
+                assert run <= biggest
+            assert biggest == max(sum(bin(int(info[v, 2]) & 0x3F).count("1") * (N >> int(info[v, 0])) ** 2 for v in cube if owner[v] == r) for r in range(world))
+        for H in (80, 168, 200, 1024, 1):
+            T = (H + 7) // 8
+            rows = [D.tile_rows_of_rank(H, r, world) for r in range(world)]
+            assert sorted(t for rr in rows for t in rr) == list(range(T))
+            stored = [D.stored_tile_row(t, H, world) for t in range(T)]
+            per_rank = (T + world - 1) // world
+            assert len(set(stored)) == T and max(stored) < world * per_rank
+            for r in range(world):                                        # a rank's rows are one contiguous block, in order
+                assert [D.stored_tile_row(t, H, world) for t in rows[r]] == list(range(r * per_rank, r * per_rank + len(rows[r])))
+
+
+def _worker_dealt(rank, world, port, out_path):
+    """One frame of the loop's protocol on the oracle: cube-map volumes dealt by cost, compact exchange, tile rows dealt round-robin,
+    rank-major image, all over gloo."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multivolumes_amd import scene
+        from multivolumes_amd import raycaster as rc
+        from oracle import mv_oracle as o
+        from tests.helpers import default_descs, host_frame, oracle_pipeline
+        o.load().mvo_set_num_threads(2)
+        cfg = dict(scene.CONFIGS["T1"], W=96, H=88)
+        V, N, L, W, H = cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"]
+        vols = [rc.synth_volume(N, k) for k in range(V)]
+        ref = oracle_pipeline(o, cfg, vols, 32, eye=(24.0, 16.0, -52.0))   # light maps: every rank holds them all (the loop's all-reduce)
+        info, vis, cube, lms = ref["info"], ref["vis"], ref["cube"], ref["lightMaps"]
+        owner = D.deal_cube_volumes(info, vis, V, N, world)
+        mine = [int(v) for v in cube if owner[int(v)] == rank]
+        cm, cd, st = o.march_view(V, N, L, W, H, vols, lms, ref["depth"], ref["po"], ref["cb"], info, mine)
+        # compact exchange: marched faces only, back to back per owner
+        off, biggest = D.compact_exchange_layout(info, vis, owner, V, N, world)
+        shard = np.zeros(max(16, (biggest * 12 + 15) & ~15), np.uint8)
+        chain_off = o.cube_mip_offset
+
+        def faces(v):
+            d = N >> int(info[v, 0])
+            return [f for f in range(6) if int(info[v, 2]) & (1 << f)], d
+
+        for v in mine:
+            fs, d = faces(v)
+            n = len(fs) * d * d
+            base = int(off[v]) * 12
+            col = np.concatenate([cm[v][chain_off(N, int(info[v, 0])) + f * d * d:chain_off(N, int(info[v, 0])) + (f + 1) * d * d] for f in fs])
+            dep = np.concatenate([cd[v][chain_off(N, int(info[v, 0])) + f * d * d:chain_off(N, int(info[v, 0])) + (f + 1) * d * d] for f in fs])
+            shard[base:base + n * 8] = np.ascontiguousarray(col).view(np.uint8).ravel()
+            shard[base + n * 8:base + n * 12] = np.ascontiguousarray(dep).view(np.uint8).ravel()
+        recv = torch.empty(shard.size * world, dtype=torch.uint8)
+        dist.all_gather_into_tensor(recv, torch.from_numpy(shard))
+        recv = recv.numpy()
+        for v in (int(x) for x in cube):
+            r = int(owner[v])
+            if r == rank:
+                continue
+            fs, d = faces(v)
+            n = len(fs) * d * d
+            base = r * shard.size + int(off[v]) * 12
+            col = recv[base:base + n * 8].view(np.uint16).reshape(n, 4)
+            dep = recv[base + n * 8:base + n * 12].view(np.float32)
+            for k, f in enumerate(fs):
+                o0 = chain_off(N, int(info[v, 0])) + f * d * d
+                cm[v][o0:o0 + d * d] = col[k * d * d:(k + 1) * d * d]
+                cd[v][o0:o0 + d * d] = dep[k * d * d:(k + 1) * d * d]
+        # composite of this rank's tile rows into its block of the rank-major image, in-place-style all-gather of equal blocks
+        T = (H + 7) // 8
+        per_rank = (T + world - 1) // world
+        block = np.zeros((per_rank * 8, W, 4), np.uint16)
+        for j, t in enumerate(D.tile_rows_of_rank(H, rank, world)):
+            r0, r1 = t * 8, min(t * 8 + 8, H)
+            img, _ = o.composite(V, N, L, W, H, vols, lms, ref["depth"], ref["po"], ref["cb"], info, vis, cm, cd, r0, r1)
+            block[j * 8:j * 8 + (r1 - r0)] = img[r0:r1]
+        stored = torch.empty(world * block.size * 2, dtype=torch.uint8)
+        dist.all_gather_into_tensor(stored, torch.from_numpy(block.view(np.uint8).ravel().copy()))
+        stored = stored.numpy().view(np.uint16).reshape(world * per_rank * 8, W, 4)
+        full = np.zeros((H, W, 4), np.uint16)
+        for t in range(T):
+            r0, r1 = t * 8, min(t * 8 + 8, H)
+            s0 = D.stored_tile_row(t, H, world) * 8
+            full[r0:r1] = stored[s0:s0 + (r1 - r0)]
+        samples = torch.tensor([st["view_samples"], st["rays"]], dtype=torch.int64)
+        dist.all_reduce(samples)
+        if rank == 0:
+            np.savez(out_path, full=full, cm=cm, cd=cd, samples=samples.numpy(), owner=owner)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_protocol_with_the_loops_work_deal(oracle, tmp_path, world):
+    """The partition mv_dist_frame uses, at protocol level on CPU: `world` gloo ranks march their dealt volumes on the oracle, exchange
+    the marched faces in the compact layout, composite their tile rows and gather the rank-major image -- it equals one process."""
+    from multivolumes_amd import scene
+    from multivolumes_amd import raycaster as rc
+    from tests.helpers import oracle_pipeline
+    out_path = str(tmp_path / "rank0.npz")
+    mp.spawn(_worker_dealt, args=(world, _free_port(), out_path), nprocs=world, join=True)
+    got = np.load(out_path)
+    cfg = dict(scene.CONFIGS["T1"], W=96, H=88)
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    ref = oracle_pipeline(oracle, cfg, vols, 32, eye=(24.0, 16.0, -52.0))
+    assert len(ref["cube"]) >= 2 and len(set(int(got["owner"][int(v)]) for v in ref["cube"])) >= 2, "the frame's volumes must be spread over ranks"
+    assert np.array_equal(got["cm"], ref["cubeMaps"]) and np.array_equal(got["cd"], ref["cubeDepths"])
+    img, _ = oracle.composite(cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"],
+                              ref["info"], ref["vis"], ref["cubeMaps"], ref["cubeDepths"])
+    assert np.array_equal(got["full"], img)
+    assert int(got["samples"][0]) == ref["stats"]["view_samples"] and int(got["samples"][1]) == ref["stats"]["rays"]
