@@ -1,11 +1,14 @@
-"""Multi-GPU plumbing for the path: one process per GPU, volumes sharded v % world, every rank holds
-every volume texture (marchL couples all volumes), cull replicated, marchL / marchV on owned volumes only, one RCCL
-all-gather per frame of the marched cube faces (colour + depth), then each rank composites its band of screen rows.
+"""Multi-GPU plumbing for the path: one process per GPU, every rank holds every volume texture (marchL couples all
+volumes), cull replicated, the frame's work shared out, one all-gather per frame of the marched cube faces (colour + depth), then
+each rank composites its share of the screen rows and the rows are gathered.
 
 The frame loop itself lives in the library (mv_dist_frame, include/multivolumes.h); init_frame_loop() below attaches it, with
-RCCL opened by the library or -- for gloo tests -- torch.distributed collectives handed over as callbacks.
-The pure functions (owned_volumes, exchange_layout, row_range, pack / unpack mirrors) state the slot-based layout of
-mv_exchange_pack / mv_exchange_unpack so that CPU tests can check that protocol over gloo without a GPU.
+RCCL opened by the library or -- for gloo tests -- torch.distributed collectives handed over as callbacks.  Inside the loop the
+cull deals the work per frame (cube-map volumes by estimated cost, screen rows by 8-row tile row): deal_cube_volumes,
+compact_exchange_layout, tile_rows_of_rank and stored_tile_row restate that rule in numpy.
+The other pure functions (owned_volumes, exchange_layout, row_range, pack / unpack mirrors) state the static partition (v % world,
+contiguous row bands) and the slot-based layout of the building blocks mv_exchange_pack / mv_exchange_unpack / mv_shard_rows, so
+that CPU tests can check both protocols over gloo without a GPU.
 """
 import os
 
