@@ -1,0 +1,68 @@
+// dist_rank_cost.cpp -- what one rank of the multi-GPU frame loop costs per frame from a C++ host, WITHOUT a fabric: sharded contexts
+// (rank r of `world`) on the one GPU there is, mv_dist_frame with do-nothing collectives.  The images are wrong (nothing is exchanged);
+// the kernels a rank runs per frame and their scheduling are the real ones, and so is the host cost of the loop -- with no Python in it
+// (scripts/exp_rank_cost.py is the same measurement through the Python mirror).  max over ranks = the frame time an ideal fabric would
+// give; its ratio to world 1 is the ceiling of the strong-scaling curve.
+// Build: g++ -O2 -std=c++17 examples/dist_rank_cost.cpp -Lmultivolumes_amd -lmultivolumes_amd -Wl,-rpath,$PWD/multivolumes_amd -o /tmp/dist_rank_cost
+// Usage: /tmp/dist_rank_cost [frames = 400]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+#include "../multivolumes_amd/csrc/MultiRayCaster.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+static int noGather(void*, const void*, void*, size_t, void*, int) { return 0; }
+static int noReduce(void*, void*, size_t, void*, int) { return 0; }
+
+int main(int argc, char** argv)
+{
+	const uint32_t N = 256, L = 96, V = 16, W = 1024, H = 1024, M = 1024;
+	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
+	std::vector<std::vector<uint16_t>> vols(V, std::vector<uint16_t>((size_t)N * N * N * 4));
+	for (uint32_t k = 0; k < V; ++k) mvh_synth_volume(N, k, vols[k].data());
+
+	const float eye[3] = { 4.0f, 16.0f, -80.0f }, focus[3] = { 0, 0, 0 }, up[3] = { 0, 1, 0 }, light[3] = { 75, 75, -75 };
+	float view[16], proj[16], viewProj[16], shadowVP[16];
+	mvh_look_at_lh(eye, focus, up, view);
+	mvh_perspective_fov_lh(3.14159265f / 4, (float)W / H, 1.0f, 1000.0f, proj);
+	mvh_multiply(view, proj, viewProj);
+	mvh_shadow_view_proj(light, 10.03f * 1.8f, shadowVP);
+	std::vector<float> depth((size_t)W * H);
+	std::vector<uint16_t> shadow((size_t)M * M);
+	mvh_synth_sphere_depth(W, H, viewProj, focus, 8.0f, depth.data());
+	mvh_synth_sphere_shadow(M, shadowVP, focus, 8.0f, shadow.data());
+	const float lc[3] = { 1.0f, 0.7f, 0.3f }, ac[3] = { 0.4f, 0.6f, 1.0f };
+
+	double one = 0.0;
+	for (uint32_t world : { 1u, 2u, 4u, 8u })
+	{
+		double worst = 0.0;
+		std::printf("world %u: ms/frame per rank [", world);
+		for (uint32_t rank = 0; rank < world; ++rank)
+		{
+			mvamd::MultiRayCaster rc;
+			if (!rc.Init(N, L, V, V, W, H, M, 0, nullptr, rank, world, MV_FLAG_PIPELINE_FRAMES)) { std::fprintf(stderr, "Init failed (no gfx950 device?)\n"); return 2; }
+			for (uint32_t k = 0; k < V; ++k) if (!rc.LoadVolumeData(k, vols[k].data())) return 3;
+			if (!rc.SetRenderTargetsHost(depth.data(), shadow.data())) return 4;
+			rc.SetMaxSamples(128, 96);
+			rc.SetLight(light, lc, 3.0f * 3.14159265f);
+			rc.SetAmbient(ac, 2.0f * 3.14159265f);
+			if (mv_dist_init_callbacks(rc.Context(), noGather, noReduce, nullptr) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
+			mv_dist_set_inplace_gather(rc.Context(), 1);	// like RCCL: no staging copies
+			for (int f = 0; f < std::min(200, frames); ++f) if (!rc.DistFrame(viewProj, shadowVP, eye)) { std::fprintf(stderr, "%s\n", rc.LastError()); return 6; }
+			rc.DistFlush(); mv_synchronize(rc.Context());
+			const auto t0 = std::chrono::steady_clock::now();
+			for (int f = 0; f < frames; ++f) if (!rc.DistFrame(viewProj, shadowVP, eye)) return 6;
+			rc.DistFlush(); mv_synchronize(rc.Context());
+			const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
+			std::printf("%s%.4f", rank ? ", " : "", ms);
+			std::fflush(stdout);
+			worst = std::max(worst, ms);
+		}
+		if (world == 1) one = worst;
+		std::printf("]  -> max %.4f  ceiling %.2fx\n", worst, one / worst);
+	}
+	return 0;
+}

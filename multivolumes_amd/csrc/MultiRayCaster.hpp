@@ -29,7 +29,7 @@ public:
 	// Init (MultiRayCaster.cpp:79-166) + SetViewport (:226-241)
 	bool Init(uint32_t gridSize, uint32_t lightGridSize, uint32_t numVolumes, uint32_t numVolumeSrcs,
 		uint32_t width, uint32_t height, uint32_t shadowMapSize = 1024, int device = 0, void* hipStream = nullptr,
-		uint32_t shardIndex = 0, uint32_t shardCount = 1)
+		uint32_t shardIndex = 0, uint32_t shardCount = 1, uint32_t flags = 0)
 	{
 		mv_config cfg;
 		std::memset(&cfg, 0, sizeof(cfg));
@@ -37,7 +37,7 @@ public:
 		cfg.grid_size = gridSize; cfg.light_grid_size = lightGridSize;
 		cfg.num_volumes = numVolumes; cfg.num_volume_srcs = numVolumeSrcs;
 		cfg.viewport_w = width; cfg.viewport_h = height; cfg.shadow_map_size = shadowMapSize;
-		cfg.device = device; cfg.stream = hipStream; cfg.shard_index = shardIndex; cfg.shard_count = shardCount;
+		cfg.device = device; cfg.stream = hipStream; cfg.shard_index = shardIndex; cfg.shard_count = shardCount; cfg.flags = flags;
 		if (mv_create(&cfg, &m_ctx) != MV_OK) return false;
 		m_numVolumes = numVolumes; m_width = width; m_height = height;
 		m_volumeWorlds.assign((size_t)numVolumes * 12, 0.0f);
@@ -93,6 +93,18 @@ public:
 		++m_frameIdx;	// :384
 		return ok;
 	}
+
+	// One frame of the multi-GPU loop (include/multivolumes.h mv_dist_frame; after mv_dist_init_rccl / mv_dist_init_callbacks on Context()):
+	// begins this frame (upload .. view march) and finishes the previous one (exchange, composite); DistFlush finishes the last.
+	bool DistFrame(const float viewProj[16], const float shadowVP[16], const float eyePt[3], bool composite = true)
+	{
+		mvh_update_frame(m_numVolumes, m_volumeWorlds.data(), viewProj, shadowVP, eyePt, (float)m_width, (float)m_height,
+			m_lightPt, m_lightColor, m_ambient, m_frameIdx, m_cb.data(), m_perObject.data());
+		const bool ok = mv_dist_frame(m_ctx, m_cb.data(), m_perObject.data(), composite ? 1 : 0) == MV_OK;
+		++m_frameIdx;
+		return ok;
+	}
+	bool DistFlush() { return mv_dist_flush(m_ctx) == MV_OK; }
 
 	mv_ctx* Context() const { return m_ctx; }
 	const char* LastError() const { return mv_last_error(m_ctx); }

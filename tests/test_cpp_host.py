@@ -46,3 +46,16 @@ def test_cpp_host_renders_a_frame(tmp_path):
             c.Render(composite=True)
         st = c.GetStats()
         assert st["view_samples"] == int(samples) and st["rays"] == int(rays)
+
+
+def test_cpp_dist_example_compiles(tmp_path):
+    """examples/dist_rank_cost.cpp (the multi-GPU frame loop driven from C++: MultiRayCaster::DistFrame, mv_dist_init_callbacks) builds
+    against the C ABI; without a GPU it fails loudly."""
+    import multivolumes_amd
+    import torch
+    multivolumes_amd.load()
+    exe = str(tmp_path / "dist_rank_cost")
+    libdir = os.path.join(ROOT, "multivolumes_amd")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-Wall", os.path.join(ROOT, "examples", "dist_rank_cost.cpp"), "-L" + libdir,
+                    "-lmultivolumes_amd", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    assert os.path.exists(exe)
