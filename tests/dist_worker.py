@@ -36,7 +36,7 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
-    cfg = dict(scene.CONFIGS["T2"], W=256, H=168 if world != 3 else 200)
+    cfg = dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))  # (MV_TEST_W / MV_TEST_H: scripts/soak_dist.py with odd viewports)
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
     flags = _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if mode == "single" else 0)

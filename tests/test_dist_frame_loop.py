@@ -40,7 +40,7 @@ def single_gpu(world, frames, every, static_depth=False):
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
     from tests.dist_worker import camera_sequence
-    cfg = dict(scene.CONFIGS["T2"], W=256, H=168 if world != 3 else 200)
+    cfg = dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))  # (MV_TEST_W / MV_TEST_H: scripts/soak_dist.py with odd viewports)
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
     with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64) as c:
