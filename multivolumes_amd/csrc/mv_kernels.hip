@@ -429,6 +429,35 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		nDeal = waveSumU32(nDeal);
 		__syncthreads();
 		unsigned long long load = 0;
+		if (balance && st.V <= 64u)
+		{
+			// Up to 64 volumes (every scene of the reference): volume v's cost lives in lane v, rank r's load in lane r, and the deal is
+			// a scalar loop over v_readlane -- no cross-lane reduction, no LDS (the reductions of the general path below cost ~2 us per
+			// volume dealt, 20 us of a 12 us kernel at C3).
+			uint32_t myCost = lane < st.V ? sCost[lane] : 0u, myOwner = lane % shardCount;
+			uint32_t loadLo = 0, loadHi = 0;
+			for (uint32_t it = 0; it < nDeal; ++it)
+			{
+				uint32_t bestCost = 0, bestV = 0;
+				for (uint32_t v = 0; v < st.V; ++v)
+				{
+					const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)myCost, (int)v);
+					if (c > bestCost) { bestCost = c; bestV = v; }	// (ascending v: the first of equals stays)
+				}
+				unsigned long long minLoad = ~0ull;
+				uint32_t minRank = 0;
+				for (uint32_t r = 0; r < shardCount; ++r)
+				{
+					const unsigned long long l = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)loadHi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)loadLo, (int)r);
+					if (l < minLoad) { minLoad = l; minRank = r; }
+				}
+				if (lane == minRank) { const unsigned long long l = (((unsigned long long)loadHi << 32) | loadLo) + bestCost; loadLo = (uint32_t)l; loadHi = (uint32_t)(l >> 32); }
+				if (lane == bestV) { myCost = 0u; myOwner = minRank; }
+			}
+			if (lane < st.V) sInfo[lane] = (sInfo[lane] & 0xffffu) | (myOwner << 16);
+			__syncthreads();
+		}
+		else
 		for (uint32_t it = 0; balance && it < nDeal; ++it)
 		{
 			// the most expensive volume not dealt yet
