@@ -30,6 +30,7 @@ MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5
 MV_BUF_VOLUME_FLAGS, MV_BUF_EXCHANGE_OFFSETS = 10, 11
 
 MV_DIST_ID_BYTES = 384
+MV_ABI_VERSION = 2  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 
