@@ -64,17 +64,142 @@ def parse():
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
     p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
+    p.add_argument("--transport", default="auto", choices=["auto", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
+                   help="--gpus > 1: auto = the library's own RCCL communicators with whole frames on three view streams, and -- only if that "
+                        "fails or stops making progress -- the next of: RCCL with one view stream, torch.distributed's NCCL group through "
+                        "callbacks, gloo through host memory (the line says which one ran: config.transport, config.fallback_level)")
     return p.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Launching and supervising the ranks of a multi-GPU run.
+#
+# `python bench.py --gpus N` (no WORLD_SIZE in the environment) starts N ranks itself, as CHILD processes
+# (`python -m torch.distributed.run ...`), before anything here touches the GPU, relays rank 0's JSON line and exits with the
+# ranks' status.  Under torch.distributed.run (the driver's command, or the one just described) every rank process is a SUPERVISOR:
+# it never initialises the GPU, it starts the measuring process as a child and watches its progress marks.  The in-library
+# multi-GPU loop keeps three RCCL communicators busy on three streams per device, which no box with more than one GPU was available
+# to exercise while it was written: if a rank dies or stops making progress, every supervisor kills its child (a fresh process each
+# time: nothing is exec'ed from a process that has touched the GPU) and all move to the next, more conservative transport together.
+# ---------------------------------------------------------------------------------------------------------------------
+LEVELS = ["rccl", "rccl-single-stream", "torch-nccl", "gloo"]
+PHASE_TIMEOUT_S = {"start": 420.0, "setup": 420.0, "dist-init": 180.0, "warmup": 240.0, "timed": 240.0, "roofline": 240.0, "report": 600.0}
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _kill_group(proc):
+    import signal
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)  # the exact process group this supervisor started (start_new_session below)
+    except ProcessLookupError:
+        pass
+    try:
+        proc.wait(timeout=30)
+    except Exception:
+        pass
+
+
+def launch_ranks(args):
+    """No WORLD_SIZE: start --gpus ranks as child processes and relay rank 0's line."""
+    import subprocess
+    import torch
+    if os.environ.get("MV_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < args.gpus:  # (counting devices does not initialise the GPU)
+        print(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s)", file=sys.stderr)
+        return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), start_new_session=True)
+    try:
+        return proc.wait()
+    except KeyboardInterrupt:
+        _kill_group(proc)
+        return 130
+
+
+def supervise(args, world, rank):
+    """One rank's supervisor (see above).  CPU only: gloo between the supervisors, the measuring process is a child."""
+    import subprocess
+    import threading
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    share = os.environ.get("MV_BENCH_SHARE_GPU") == "1"
+    levels = ["gloo"] if share else LEVELS if args.transport == "auto" else [args.transport]
+    rc = 1
+    for level, transport in enumerate(levels):
+        port = [_free_port() if rank == 0 else 0]
+        dist.broadcast_object_list(port, src=0)
+        env = dict(os.environ, MV_BENCH_WORKER="1", MV_BENCH_TRANSPORT=transport, MV_BENCH_LEVEL=str(level), MASTER_PORT=str(port[0]),
+                   TORCHELASTIC_USE_AGENT_STORE="False", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        proc = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stderr=subprocess.PIPE, text=True, start_new_session=True)
+        state = {"phase": "start", "since": time.monotonic()}
+
+        def pump():
+            for line in proc.stderr:
+                if line.startswith("MV_PHASE "):
+                    state["phase"], state["since"] = line.split()[1], time.monotonic()
+                else:
+                    sys.stderr.write(line)
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        # Every few seconds the supervisors agree on what they see: everybody done, somebody failed or stuck, or keep waiting.
+        while True:
+            time.sleep(0.5 if proc.poll() is not None else 2.0)
+            code = proc.poll()
+            stuck = code is None and time.monotonic() - state["since"] > PHASE_TIMEOUT_S.get(state["phase"], 240.0)
+            mine = 0 if code == 0 else 2 if (stuck or (code is not None and code != 0)) else 1  # 0 done, 1 running, 2 failed
+            seen = [None] * world
+            dist.all_gather_object(seen, (mine, state["phase"]))
+            if any(m == 2 for m, _ in seen):
+                if rank == 0:
+                    print(f"bench.py: transport '{transport}' failed or stopped making progress (rank states {seen}); "
+                          + ("trying the next one" if level + 1 < len(levels) else "no transport left"), file=sys.stderr)
+                _kill_group(proc)
+                rc = 1
+                break
+            if all(m == 0 for m, _ in seen):
+                rc = 0
+                break
+        th.join(timeout=5)
+        if rc == 0:
+            break
+    dist.barrier()
+    dist.destroy_process_group()
+    return rc
+
+
+def phase(name):
+    """Progress mark for the supervisor (stderr; a plain run ignores it)."""
+    if os.environ.get("MV_BENCH_WORKER") == "1":
+        print(f"MV_PHASE {name}", file=sys.stderr, flush=True)
 
 
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: refusing to print a line for another rank count", file=sys.stderr)
+        return 2
+    if world > 1 and os.environ.get("MV_BENCH_WORKER") != "1":
+        return supervise(args, world, rank)
+    import torch
+    import torch.distributed as dist
+
+    transport = os.environ.get("MV_BENCH_TRANSPORT", "rccl" if args.transport == "auto" else args.transport)
+    if transport == "rccl-single-stream":
+        args.dist_single_stream = True
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the ray-march path has no CPU fallback")
     # MV_BENCH_SHARE_GPU=1 is a functional test mode for boxes with fewer GPUs than ranks: every rank uses cuda:0 and the
@@ -85,12 +210,11 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
+        if share_gpu or transport == "gloo":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using {world}", file=sys.stderr)
+    phase("setup")
 
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
@@ -162,7 +286,9 @@ def main():
 
     from multivolumes_amd import distributed as D
     # N > 1: the per-frame protocol runs inside the library (mv_dist_frame); torch.distributed only distributes the RCCL ids
-    exchange = D.init_frame_loop(caster) if world > 1 else None
+    phase("dist-init")
+    exchange = D.init_frame_loop(caster, prefer_rccl=transport in ("rccl", "rccl-single-stream")) if world > 1 else None
+    phase("warmup")
     H, W = cfg["H"], cfg["W"]
     band = D.row_range(H, rank, world)
     assert band == caster.ShardRows()
@@ -216,6 +342,7 @@ def main():
         caster.synchronize()
         caster.DistExchangedBytes(reset=True)  # exchange bytes of the timed frames only
     barrier()
+    phase("timed")
     t0 = time.perf_counter()
     trace = [] if os.environ.get("MV_BENCH_TRACE") else None
     for i in range(args.steps):
@@ -235,6 +362,7 @@ def main():
     st = caster.GetStats()
 
     # roofline pass: the same frames, one at a time, so that a launch's HIP-event duration is the kernel's own time
+    phase("roofline")
     st_iso = None
     if pipelined and args.roofline_frames > 0:
         caster.ResetStats()
@@ -248,6 +376,7 @@ def main():
         st_iso = caster.GetStats()
 
     # max time over ranks, sum of samples over ranks
+    phase("report")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -329,6 +458,8 @@ def main():
                                      else "up to 3 whole frames (light march + light-map all-reduce, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes_timed // max(1, K),
+                "transport": exchange, "fallback_level": int(os.environ.get("MV_BENCH_LEVEL", "0")),
+                "rccl_ranks": caster.DistInfo()["ranks"] if world > 1 else None,
             },
             "kernel_ms": k_alone, "kernel_ms_in_flight": k_in_flight,
             "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,
@@ -425,4 +556,4 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

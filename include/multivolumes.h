@@ -113,7 +113,7 @@ typedef struct mv_stats
 
 const char* mv_error_string(int code);
 const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
-#define MV_ABI_VERSION 2u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS */
+#define MV_ABI_VERSION 3u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available */
 uint32_t mv_abi_version(void);	/* == MV_ABI_VERSION of the header the library was built from */
 
 /* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,
@@ -132,10 +132,22 @@ int mv_volume_load_r32f(mv_ctx* ctx, uint32_t src, const float* a, uint32_t w, u
 /* createVolumeInfoBuffers (MultiRayCaster.cpp:471-488): replace the packed VolumeDesc[V]. */
 int mv_set_volume_descs(mv_ctx* ctx, const uint32_t* packed);
 
-/* SetRenderTargets (MultiRayCaster.cpp:211-224) hands the path DEPTH_MAP and SHADOW_MAP. Host copies: */
+/* SetViewport (MultiRayCaster.cpp:226-241; from SetRenderTargets :211-224 and on a window resize, MultiVolumes.cpp:382): the reference
+ * re-creates its K-buffers and keeps everything else.  Here: the composite image, the RayCast layers and the context's own depth
+ * map are re-created for w x h (the depth map must be supplied again); volumes, light maps, cube maps and counters stay, and the next
+ * frame (mv_update_frame) renders exactly what a context created with w x h and the same history of cube maps would.
+ * Not inside the multi-GPU frame loop (mv_dist_shutdown first). */
+int mv_set_viewport(mv_ctx* ctx, uint32_t w, uint32_t h);
+
+/* SetRenderTargets (MultiRayCaster.cpp:211-224) hands the path DEPTH_MAP and SHADOW_MAP. Host copies.
+ * These and every other input setter / producer below (volumes, VolumeDesc, SH, light-map upload, mesh rasteriser) wait for the frames
+ * in flight BEFORE they write.  Inside the multi-GPU frame loop they first enqueue the pending tail of the last mv_dist_frame (its
+ * exchange, composite and row gather: collectives), so there they are collective calls: every rank makes them between the same frames. */
 int mv_set_depth_map(mv_ctx* ctx, const float* d32);		/* W x H */
 int mv_set_shadow_map(mv_ctx* ctx, const uint16_t* d16);	/* M x M */
-/* ...or borrowed device pointers, as the reference borrows ObjectRenderer's depth buffers (NULL = back to own copy) */
+/* ...or borrowed device pointers, as the reference borrows ObjectRenderer's depth buffers (NULL = back to own copy).  A borrowed
+ * buffer is read by every frame begun while it is set, until that frame's composite has run: with frames in flight, and inside
+ * mv_dist_frame (whose composite of frame k is enqueued by call k + 1), keep it alive and unchanged for three more frames. */
 int mv_set_depth_map_device(mv_ctx* ctx, const float* d_d32);
 int mv_set_shadow_map_device(mv_ctx* ctx, const uint16_t* d_d16);
 /* SetSH (MultiRayCaster.cpp:266-269): 9 x float3; NULL -> g_hasLightProbe = 0 (MultiRayCaster.cpp:1321). */
@@ -262,6 +274,9 @@ int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim);
  * Transport: RCCL (the library opens librccl.so itself; three communicators, two used without chains) or caller-supplied collectives
  * (tests, other fabrics). */
 #define MV_DIST_ID_BYTES 384	/* three RCCL unique ids (one per communicator) */
+int mv_dist_rccl_available(void);	/* 1 if librccl.so and every entry point the loop needs can be opened in this process: a LOCAL check, so that the ranks can
+									   agree on the transport before any of them enters mv_dist_init_rccl (ncclCommInitRank is collective: a rank that
+									   cannot open the library would leave the others waiting inside it) */
 int mv_dist_unique_id(void* out /* MV_DIST_ID_BYTES; call on rank 0, hand the bytes to every rank */);
 int mv_dist_init_rccl(mv_ctx* ctx, const void* id /* MV_DIST_ID_BYTES, the same on every rank */);
 /* all-gather: every rank contributes `bytes` from `send`; `recv` receives shard_count x bytes in rank order.  all-reduce: in-place
@@ -279,6 +294,9 @@ int mv_dist_selftest(mv_ctx* ctx);	/* one all-gather (plain and in place) and on
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite);
 int mv_dist_flush(mv_ctx* ctx);	/* enqueue the exchange + composite of the last frame begun (then mv_synchronize / readbacks see it) */
 int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset);	/* bytes this rank received through the collectives */
+/* transport: 0 none, 1 RCCL, 2 caller-supplied collectives; ranks: the size of the communicator as RCCL reports it (ncclCommCount), or
+ * shard_count for caller-supplied collectives; communicators: how many the loop keeps busy (3 with whole-frame chains, else 2) */
+int mv_dist_info(mv_ctx* ctx, uint32_t* transport, uint32_t* ranks, uint32_t* communicators);
 
 #ifdef __cplusplus
 }

@@ -30,7 +30,7 @@ MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5
 MV_BUF_VOLUME_FLAGS, MV_BUF_EXCHANGE_OFFSETS = 10, 11
 
 MV_DIST_ID_BYTES = 384
-MV_ABI_VERSION = 2  # include/multivolumes.h
+MV_ABI_VERSION = 3  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 
@@ -118,6 +118,9 @@ ABI = {
     "mv_dist_frame": (C.c_int, [_P, _P, _P, C.c_int]),
     "mv_dist_flush": (C.c_int, [_P]),
     "mv_dist_exchanged_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
+    "mv_dist_rccl_available": (C.c_int, []),
+    "mv_dist_info": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
+    "mv_set_viewport": (C.c_int, [_P, _U32, _U32]),
     "mv_mesh_upload": (C.c_int, [_P, _P, _U32, _P, _U32]),
     "mv_mesh_render_depth": (C.c_int, [_P, _P, _P]),
     "mv_mesh_render_shadow": (C.c_int, [_P, _P]),

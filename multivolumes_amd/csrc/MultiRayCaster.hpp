@@ -54,6 +54,14 @@ public:
 	// InitVolumeData (MultiRayCaster.cpp:243-264)
 	bool InitVolumeData(uint32_t i) { return mv_volume_init_procedural(m_ctx, i) == MV_OK; }
 
+	// SetViewport (MultiRayCaster.cpp:226-241): re-creates what is W x H (composite image, RayCast layers, own depth map), keeps the rest
+	bool SetViewport(uint32_t width, uint32_t height)
+	{
+		if (mv_set_viewport(m_ctx, width, height) != MV_OK) return false;
+		m_width = width; m_height = height;
+		return true;
+	}
+
 	// SetRenderTargets (MultiRayCaster.cpp:211-224): DEPTH_MAP / SHADOW_MAP as borrowed device pointers
 	bool SetRenderTargets(const float* d_depthMap, const uint16_t* d_shadowMap)
 	{

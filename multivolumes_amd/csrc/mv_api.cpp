@@ -110,6 +110,7 @@ struct DistState
 	DeviceState stPending;			// the device state of the frame whose exchange + composite are still to be enqueued
 	uint32_t slotPending = 0, chainPending = 0;
 	uint64_t bytes = 0;
+	std::vector<void*> allocs;		// device buffers of the loop (freed by distRelease: a shutdown followed by another init allocates afresh)
 };
 
 struct mv_ctx
@@ -212,12 +213,53 @@ int devAlloc(mv_ctx* ctx, T** out, size_t bytes, bool zero = true)
 	return MV_OK;
 }
 
+// replace a buffer devAlloc made by one of another size (mv_set_viewport)
+template <typename T>
+int devRealloc(mv_ctx* ctx, T** p, size_t bytes, bool zero = true)
+{
+	void* fresh = nullptr;
+	MV_HIP(ctx, hipMalloc(&fresh, bytes ? bytes : 16));
+	if (zero) MV_HIP(ctx, hipMemsetAsync(fresh, 0, bytes ? bytes : 16, ctx->stream));
+	for (void*& a : ctx->allocs)
+		if (a == static_cast<void*>(*p)) { (void)hipFree(a); a = fresh; *p = reinterpret_cast<T*>(fresh); return MV_OK; }
+	ctx->allocs.push_back(fresh);
+	*p = reinterpret_cast<T*>(fresh);
+	return MV_OK;
+}
+
 // rows of the composite buffer: H, or the padded rank-major layout (kFlagInterleaveRows)
 static size_t compositeRows(const DeviceState& st)
 {
 	const uint32_t sc = st.shardCount ? st.shardCount : 1u;
 	const size_t dealt = (size_t)sc * mv::interleavedRowsPerRank(st.H, sc) * 8u;
 	return sc > 1u && dealt > st.H ? dealt : st.H;
+}
+
+// everything of DeviceState that follows from W x H (mv_create, mv_set_viewport)
+void viewportDerived(DeviceState& st)
+{
+	st.rowsPerRank = mv::interleavedRowsPerRank(st.H, st.shardCount);
+	// Rows this shard composites (multivolumes_amd/distributed.py::row_range states the same rule): whole 8-row tiles, split evenly.
+	{
+		const uint32_t tiles = (st.H + 7u) >> 3;
+		const uint32_t t0 = (uint32_t)(((uint64_t)tiles * st.shardIndex) / st.shardCount), t1 = (uint32_t)(((uint64_t)tiles * (st.shardIndex + 1u)) / st.shardCount);
+		st.bandRow0 = t0 * 8u < st.H ? t0 * 8u : st.H;
+		st.bandRow1 = t1 * 8u < st.H ? t1 * 8u : st.H;
+	}
+	// Screen-space-scheme volumes are marched inside the view-march launch (up to kMaxScreenSlots of them), by every shard for ITS rows
+	{
+		uint32_t cap = kMaxScreenSlots;
+#ifdef MV_DIAGNOSTICS
+		{ const char* e = getenv("MV_SCREEN_SLOTS"); if (e) cap = (uint32_t)atoi(e); }
+#endif
+		st.screenSlots = st.V < cap ? st.V : cap;
+	}
+	{
+		// tile rows this context can own: its contiguous band, or (multi-GPU frame loop) every shard_count-th tile row
+		const uint32_t bandTiles = (st.bandRow1 - st.bandRow0 + 7u) >> 3, dealt = mv::interleavedRowsPerRank(st.H, st.shardCount ? st.shardCount : 1u);
+		st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * (bandTiles > dealt ? bandTiles : dealt);
+	}
+	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
 }
 
 void applyParity(mv_ctx* ctx)
@@ -301,6 +343,23 @@ void endStage(mv_ctx* ctx, EventPair& ev, hipStream_t stream)
 	if (hipEventRecord(ev.b, stream) != hipSuccess) { ctx->freeEvents.push_back(ev); return; }
 	ctx->pending.push_back(ev);
 }
+
+// Inside the multi-GPU frame loop the exchange, composite and row gather of the last frame begun are still to be enqueued (they go out
+// with the next mv_dist_frame).  Anything that is about to overwrite an input that tail reads -- depth / shadow map, SH, volumes, light
+// maps, VolumeDesc -- enqueues it first, then waits for every stream: the pending frame is composited against the inputs it was begun
+// with.  (The tail contains collectives: inside the loop these setters are collective calls, every rank makes them at the same point.)
+int distTail(mv_ctx* ctx);
+int drainForWrite(mv_ctx* ctx)
+{
+	if (ctx->dist && ctx->dist->pending)
+	{
+		const int rc = distTail(ctx);
+		if (rc != MV_OK) return rc;
+	}
+	const hipError_t e = (hipError_t)syncAll(ctx);
+	return e == hipSuccess ? MV_OK : fail(ctx, MV_ERR_HIP, "synchronising the frames in flight", e);
+}
+#define MV_DRAIN(ctx) do { const int rc_ = drainForWrite(ctx); if (rc_ != MV_OK) return rc_; } while (0)
 
 void foldEvents(mv_ctx* ctx)
 {
@@ -422,7 +481,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.V = cfg->num_volumes; st.S = cfg->num_volume_srcs; st.W = cfg->viewport_w; st.H = cfg->viewport_h; st.M = cfg->shadow_map_size;
 	st.flags = cfg->flags; st.shardIndex = cfg->shard_count > 1 ? cfg->shard_index : 0u; st.shardCount = cfg->shard_count > 1 ? cfg->shard_count : 1u;
 	st.shardMagic = st.shardCount > 1u ? (uint32_t)(((1ull << 32) + st.shardCount - 1u) / st.shardCount) : 0xffffffffu;
-	st.rowsPerRank = mv::interleavedRowsPerRank(st.H, st.shardCount);
 	st.maxRaySamples = 256; st.maxLightSamples = 96;	// MultiRayCaster.cpp:65-66
 	st.hasLightProbe = 0;
 
@@ -476,26 +534,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &ctx->dSh, 27 * sizeof(float))) != MV_OK) return bail(rc);
 	// RayCast layers of screen-space-scheme volumes are marched inside the view-march launch into fp32 RGBA layers; volumes
 	// beyond the slot capacity fall back to marching inside the composite.
-	// Rows this shard composites (multivolumes_amd/distributed.py::row_range states the same rule): whole 8-row tiles, split evenly.
-	{
-		const uint32_t tiles = (st.H + 7u) >> 3;
-		const uint32_t t0 = (uint32_t)(((uint64_t)tiles * st.shardIndex) / st.shardCount), t1 = (uint32_t)(((uint64_t)tiles * (st.shardIndex + 1u)) / st.shardCount);
-		st.bandRow0 = t0 * 8u < st.H ? t0 * 8u : st.H;
-		st.bandRow1 = t1 * 8u < st.H ? t1 * 8u : st.H;
-	}
-	// Screen-space-scheme volumes are marched inside the view-march launch (up to kMaxScreenSlots of them), by every shard for ITS rows
-	{
-		uint32_t cap = kMaxScreenSlots;
-#ifdef MV_DIAGNOSTICS
-		{ const char* e = getenv("MV_SCREEN_SLOTS"); if (e) cap = (uint32_t)atoi(e); }
-#endif
-		st.screenSlots = st.V < cap ? st.V : cap;
-	}
-	{
-		// tile rows this context can own: its contiguous band, or (multi-GPU frame loop) every shard_count-th tile row
-		const uint32_t bandTiles = (st.bandRow1 - st.bandRow0 + 7u) >> 3, dealt = mv::interleavedRowsPerRank(st.H, st.shardCount ? st.shardCount : 1u);
-		st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * (bandTiles > dealt ? bandTiles : dealt);
-	}
+	viewportDerived(st);
 	// constants + cull outputs, once per frame slot (FrameBufs)
 	{
 		std::vector<uint4*> table(st.V);
@@ -550,7 +589,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if (st.marchWaves < 64u) st.marchWaves = 64u;
 	}
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
-	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
 	ctx->orderTiles = !(cfg->flags & MV_FLAG_LIST_ORDER);
 	for (uint32_t p = 0; p < kFrameSlots; ++p)
 	{
@@ -624,6 +662,7 @@ static void distRelease(mv_ctx* ctx)
 	for (uint32_t i = 0; i < kDistChains; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
 	if (d->streamX) (void)hipStreamDestroy(d->streamX);
 	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (d->pinnedCull[i]) (void)hipHostFree(d->pinnedCull[i]); if (d->evCullCopied[i]) (void)hipEventDestroy(d->evCullCopied[i]); }
+	for (void* p : d->allocs) (void)hipFree(p);
 	delete d;
 	ctx->dist = nullptr;
 }
@@ -658,7 +697,7 @@ int mv_volume_upload_rgba16f(mv_ctx* ctx, uint32_t src, const uint16_t* rgba)
 {
 	if (!ctx || !rgba) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight on the internal streams may still read this volume and the staging buffer
+	MV_DRAIN(ctx);	// frames in flight on the internal streams may still read this volume and the staging buffer
 	MV_HIP(ctx, hipMemcpyAsync(ctx->staging, rgba, ctx->stagingBytes, hipMemcpyHostToDevice, ctx->stream));
 	mv::launchRetile(ctx->stream, ctx->staging, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
@@ -672,7 +711,7 @@ int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgb
 {
 	if (!ctx || !d_rgba) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may still read this volume
+	MV_DRAIN(ctx);	// frames in flight may still read this volume
 	mv::launchRetile(ctx->stream, reinterpret_cast<const uint2*>(d_rgba), ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
@@ -686,7 +725,7 @@ int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may still read this volume
+	MV_DRAIN(ctx);	// frames in flight may still read this volume
 	mv::launchInitGridData(ctx->stream, ctx->volumes[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
@@ -702,7 +741,7 @@ int mv_volume_load_r32f(mv_ctx* ctx, uint32_t src, const float* a, uint32_t w, u
 	MV_REQUIRE(ctx, src < ctx->st.S, MV_ERR_RANGE, "volume source index out of range");
 	float* dSrc = nullptr;
 	const size_t bytes = (size_t)w * h * d * sizeof(float);
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may still read this volume
+	MV_DRAIN(ctx);	// frames in flight may still read this volume
 	MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&dSrc), bytes));
 	hipError_t e = hipMemcpyAsync(dSrc, a, bytes, hipMemcpyHostToDevice, ctx->stream);
 	if (e == hipSuccess)
@@ -729,8 +768,58 @@ int mv_set_volume_descs(mv_ctx* ctx, const uint32_t* packed)
 		const uint32_t mips = (packed[i] >> 14) & 0xfu;
 		MV_REQUIRE(ctx, mips >= 1 && mips <= MV_NUM_CUBE_MIP, MV_ERR_INVALID_ARG, "VolumeDesc.NumMips must be 1..5");
 	}
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the cull / marches of frames in flight read VolumeDesc[V]
+	MV_DRAIN(ctx);	// the cull / marches of frames in flight read VolumeDesc[V]
 	MV_HIP(ctx, hipMemcpyAsync(ctx->dDescs, packed, (size_t)ctx->st.V * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	return MV_OK;
+}
+
+// SetViewport (MultiRayCaster.cpp:226-241; called by SetRenderTargets :211-224 and on a resize, MultiVolumes.cpp:382): the reference
+// re-creates its K-buffers and nothing else.  Here everything that is W x H goes -- the composite image, the RayCast layers, the
+// context's own depth map, the composite's counters, the screen-tile part of the tile order -- and the volumes, light maps, cube maps
+// (with their stamps) and the frame counters stay.
+int mv_set_viewport(mv_ctx* ctx, uint32_t w, uint32_t h)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, w >= 1 && h >= 1 && w <= 65535u && h <= 65535u, MV_ERR_INVALID_ARG, "viewport out of range");
+	MV_REQUIRE(ctx, !ctx->dist, MV_ERR_INVALID_ARG, "detach the multi-GPU frame loop (mv_dist_shutdown) before changing the viewport: its row buffers are sized for it");
+	DeviceState& st = ctx->st;
+	if (w == st.W && h == st.H) return MV_OK;
+	MV_DRAIN(ctx);
+	MV_REQUIRE(ctx, (uint64_t)st.screenSlots * w * h < (1ull << 31), MV_ERR_INVALID_ARG, "viewport too large for the RayCast layers' 31-bit element index");
+	st.W = w; st.H = h;
+	ctx->cfg.viewport_w = w; ctx->cfg.viewport_h = h;
+	viewportDerived(st);
+	int rc;
+	if ((rc = devRealloc(ctx, &ctx->ownDepth, (size_t)w * h * sizeof(float))) != MV_OK) return rc;
+	st.depthMap = ctx->ownDepth;	// (a borrowed depth map was the old viewport's: the caller hands over the new one)
+	ctx->haveDepth = false;
+	for (uint32_t p = 0; p < kFrameSlots; ++p)
+	{
+		if ((rc = devRealloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return rc;
+		if ((rc = devRealloc(ctx, &ctx->fb[p].tileCost, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return rc;
+	}
+	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
+	{
+		OutBufs& f = ctx->ob[p];
+		if ((rc = devRealloc(ctx, &f.composite, (size_t)st.W * compositeRows(st) * sizeof(uint2))) != MV_OK) return rc;
+		if ((rc = devRealloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return rc;
+		if ((rc = devRealloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return rc;
+		if ((rc = devRealloc(ctx, &f.compositeRetry, ((size_t)st.compositeSlots + 2u) * sizeof(uint32_t))) != MV_OK) return rc;
+		if (ctx->rayQueue)
+		{
+			if ((rc = devRealloc(ctx, &f.rayRecords, ((size_t)st.maxTiles + st.maxScreenTiles) * 64 * sizeof(mv::RayRecord), false)) != MV_OK) return rc;
+			if ((rc = devRealloc(ctx, &f.tileInfo, ((size_t)st.maxTiles + st.maxScreenTiles) * sizeof(mv::TileInfo), false)) != MV_OK) return rc;
+		}
+	}
+	if (ctx->rasterBits)
+	{
+		(void)hipFree(ctx->rasterBits); ctx->rasterBits = nullptr;
+		MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->rasterBits), std::max((size_t)w * h, (size_t)st.M * st.M) * sizeof(uint32_t)));
+	}
+	applyParity(ctx);
+	ctx->haveCull = false;	// the frame in progress (if any) was culled for the old viewport: mv_update_frame begins the next one
+	ctx->haveFrame = false;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
@@ -741,7 +830,7 @@ int mv_set_depth_map(mv_ctx* ctx, const float* d32)
 	// Frames in flight (view march / composite on the internal streams) still read the depth map: wait for them BEFORE the
 	// copy overwrites it.  Callers that change the depth every frame and want to keep frames in flight hand over a device
 	// pointer per frame instead (mv_set_depth_map_device: borrowed, never written by the context).
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	MV_DRAIN(ctx);
 	MV_HIP(ctx, hipMemcpyAsync(ctx->ownDepth, d32, (size_t)ctx->st.W * ctx->st.H * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	ctx->st.depthMap = ctx->ownDepth;
@@ -752,7 +841,7 @@ int mv_set_depth_map(mv_ctx* ctx, const float* d32)
 int mv_set_shadow_map(mv_ctx* ctx, const uint16_t* d16)
 {
 	if (!ctx || !d16) return MV_ERR_INVALID_ARG;
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the light march of a frame in flight may still read the shadow map
+	MV_DRAIN(ctx);	// the light march of a frame in flight may still read the shadow map
 	MV_HIP(ctx, hipMemcpyAsync(ctx->ownShadow, d16, (size_t)ctx->st.M * ctx->st.M * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	ctx->st.shadowMap = ctx->ownShadow;
@@ -781,7 +870,7 @@ int mv_set_sh(mv_ctx* ctx, const float* sh27)
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	if (sh27)
 	{
-		MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the light march of a frame in flight may still read the coefficients
+		MV_DRAIN(ctx);	// the light march of a frame in flight may still read the coefficients
 		MV_HIP(ctx, hipMemcpyAsync(ctx->dSh, sh27, 27 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
 		MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	}
@@ -1121,7 +1210,7 @@ int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src)
 	MV_REQUIRE(ctx, volume < ctx->st.V, MV_ERR_RANGE, "volume index out of range");
 	const size_t L3 = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
 	uint4* buf = nullptr;
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// frames in flight may read this buffer (and the shared staging buffer)
+	MV_DRAIN(ctx);	// frames in flight may read this buffer (and the shared staging buffer)
 	const int rc = currentLightBuffer(ctx, volume, &buf);
 	if (rc != MV_OK) return rc;
 	MV_HIP(ctx, hipMemcpyAsync(ctx->lightStaging, src, L3 * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1189,7 +1278,7 @@ int mv_clear_cube_maps(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	const size_t chain = mv::cubeChainTexels(ctx->st.N);
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	MV_DRAIN(ctx);
 	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
 	{
 		MV_HIP(ctx, hipMemsetAsync(ctx->ob[p].cubeMaps, 0, (size_t)ctx->st.V * chain * sizeof(uint2), ctx->stream));
@@ -1332,7 +1421,7 @@ int mv_mesh_upload(mv_ctx* ctx, const float* positions, uint32_t numVerts, const
 static int rasterInto(mv_ctx* ctx, const float matT[16], float bx, float by, uint32_t W, uint32_t H)
 {
 	MV_REQUIRE(ctx, ctx->meshTris > 0, MV_ERR_NOT_READY, "no mesh (mv_mesh_upload)");
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// depth / shadow maps may still be read by frames in flight
+	MV_DRAIN(ctx);	// depth / shadow maps may still be read by frames in flight
 	MV_HIP(ctx, hipMemcpyAsync(ctx->dMeshMatrix, matT, 16 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
 	mv::launchFillU32(ctx->stream, ctx->rasterBits, 0x3f800000u, (size_t)W * H);	// cleared to 1.0
 	mv::launchRasterDepthBits(ctx->stream, ctx->meshPositions, ctx->meshIndices, ctx->meshTris, ctx->dMeshMatrix, bx, by, W, H, ctx->rasterBits);
@@ -1476,7 +1565,17 @@ static int distAllReduceU32(mv_ctx* ctx, uint32_t* buf, size_t count, hipStream_
 }
 
 // buffers, streams and events shared by both transports
-static int distCommonInit(mv_ctx* ctx)
+static int distAlloc(mv_ctx* ctx, uint8_t** out, size_t bytes, hipStream_t zeroOn = nullptr)
+{
+	void* p = nullptr;
+	MV_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
+	ctx->dist->allocs.push_back(p);
+	if (zeroOn) MV_HIP(ctx, hipMemsetAsync(p, 0, bytes ? bytes : 16, zeroOn));
+	*out = static_cast<uint8_t*>(p);
+	return MV_OK;
+}
+
+static int distCommonInitBody(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
 	const DeviceState& st = ctx->st;
@@ -1484,17 +1583,22 @@ static int distCommonInit(mv_ctx* ctx)
 		"mv_dist_* needs a context created with MV_FLAG_PIPELINE_FRAMES (whole frames on three view streams), optionally | MV_FLAG_SINGLE_VIEW_STREAM (two output sets, cull and light march ahead)");
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	if (!d->chains) MV_HIP(ctx, hipStreamCreateWithFlags(&d->streamX, hipStreamNonBlocking));
-	const uint32_t world = st.shardCount, perShard = (st.V + world - 1u) / world;
-	d->sendCap = (size_t)(perShard + 1u) * 6u * st.N * st.N * 12u;	// a rank's share of all texels (every volume at mip 0 with six faces) plus one volume: the bound of the cull's balanced deal
+	const uint32_t world = st.shardCount;
+	// One rank's shard of a frame's cube-face all-gather: the marched faces of the volumes the cull dealt to it.  The deal balances
+	// estimated march cost, not texels -- a rank may be handed every cheap (low SmpCount) volume of a frame -- so the buffers hold the
+	// worst case: every volume at mip 0 with six faces (C3: 75 MB per shard; 288 GB of HBM make that affordable).
+	d->sendCap = (size_t)st.V * 6u * st.N * st.N * 12u;
 	d->maxBandBytes = (size_t)mv::interleavedRowsPerRank(st.H, world) * 8u * st.W * sizeof(uint2);	// one rank's block of the rank-major composite image
 	int rc;
 	for (uint32_t c = 0; c < (d->chains ? kDistChains : 1u); ++c)
 	{
-		if ((rc = devAlloc(ctx, &d->sendBuf[c], d->sendCap, false)) != MV_OK) return rc;
-		if ((rc = devAlloc(ctx, &d->recvBuf[c], d->sendCap * world, false)) != MV_OK) return rc;
-		if ((rc = devAlloc(ctx, &d->lightWords[c], (size_t)st.L * st.L * st.L * sizeof(uint32_t), false)) != MV_OK) return rc;
-		if ((rc = devAlloc(ctx, &d->rowSend[c], d->maxBandBytes, true)) != MV_OK) return rc;
-		if ((rc = devAlloc(ctx, &d->rowRecv[c], d->maxBandBytes * world, false)) != MV_OK) return rc;
+		if ((rc = distAlloc(ctx, &d->sendBuf[c], d->sendCap)) != MV_OK) return rc;
+		if ((rc = distAlloc(ctx, &d->recvBuf[c], d->sendCap * world)) != MV_OK) return rc;
+		uint8_t* w = nullptr;
+		if ((rc = distAlloc(ctx, &w, (size_t)st.L * st.L * st.L * sizeof(uint32_t))) != MV_OK) return rc;
+		d->lightWords[c] = reinterpret_cast<uint32_t*>(w);
+		if ((rc = distAlloc(ctx, &d->rowSend[c], d->maxBandBytes, ctx->stream)) != MV_OK) return rc;
+		if ((rc = distAlloc(ctx, &d->rowRecv[c], d->maxBandBytes * world)) != MV_OK) return rc;
 	}
 	for (uint32_t i = 0; i < kFrameSlots; ++i)
 	{
@@ -1510,11 +1614,38 @@ static int distCommonInit(mv_ctx* ctx)
 	return MV_OK;
 }
 
+// (a failure leaves the context without a frame loop, never with half of one)
+static int distCommonInit(mv_ctx* ctx)
+{
+	const int rc = distCommonInitBody(ctx);
+	if (rc != MV_OK)
+	{
+		(void)syncAll(ctx);
+		distRelease(ctx);
+		ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows);
+	}
+	return rc;
+}
+
+static void* openRccl()
+{
+	void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+	return lib ? lib : dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+}
+
+int mv_dist_rccl_available(void)
+{
+	void* lib = openRccl();
+	if (!lib) return 0;
+	for (const char* name : { "ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclAllReduce", "ncclBroadcast", "ncclCommDestroy", "ncclCommCount", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv" })
+		if (!dlsym(lib, name)) return 0;
+	return 1;
+}
+
 int mv_dist_unique_id(void* out)
 {
 	if (!out) return MV_ERR_INVALID_ARG;
-	void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-	if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	void* lib = openRccl();
 	if (!lib) return MV_ERR_NOT_READY;
 	auto getId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
 	if (!getId) return MV_ERR_NOT_READY;
@@ -1534,8 +1665,7 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
 	d->transport = 1; d->inPlaceGather = true;
 	d->chains = ctx->lightOnViewStream && ctx->numViewStreams == kDistChains;
 	d->numComm = d->chains ? kDistChains : 2u;
-	d->rcclLib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-	if (!d->rcclLib) d->rcclLib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	d->rcclLib = openRccl();
 	if (d->rcclLib)
 	{
 		d->commInitRank = reinterpret_cast<decltype(d->commInitRank)>(dlsym(d->rcclLib, "ncclCommInitRank"));
@@ -1545,7 +1675,7 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
 		d->errorString = reinterpret_cast<decltype(d->errorString)>(dlsym(d->rcclLib, "ncclGetErrorString"));
 	}
 	if (!d->rcclLib || !d->commInitRank || !d->allGather || !d->allReduce || !d->commDestroy) { delete d; return fail(ctx, MV_ERR_NOT_READY, "librccl.so could not be opened"); }
-	MV_HIP(ctx, hipSetDevice(ctx->cfg.device));
+	{ const hipError_t e = hipSetDevice(ctx->cfg.device); if (e != hipSuccess) { delete d; return fail(ctx, MV_ERR_HIP, "hipSetDevice", e); } }
 	const ncclUniqueId* ids = reinterpret_cast<const ncclUniqueId*>(id);
 	for (uint32_t i = 0; i < d->numComm; ++i)
 	{
@@ -1673,11 +1803,11 @@ static int distTailComposite(mv_ctx* ctx)
 	return MV_OK;
 }
 
-static int distTail(mv_ctx* ctx)
+namespace { int distTail(mv_ctx* ctx)
 {
 	const int rc = distTailExchange(ctx);
 	return rc != MV_OK ? rc : distTailComposite(ctx);
-}
+} }
 
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite)
 {
@@ -1790,6 +1920,25 @@ int mv_dist_selftest(mv_ctx* ctx)
 		MV_HIP(ctx, hipMemcpyAsync(w.data(), d->lightWords[c], 1024, hipMemcpyDeviceToHost, s));
 		MV_HIP(ctx, hipStreamSynchronize(s));
 		for (uint32_t i = 0; i < 256; ++i) MV_REQUIRE(ctx, w[i] == 0x9e3779b9u * (i + 1u) + which, MV_ERR_HIP, "all-reduce self-test: wrong words");
+	}
+	return MV_OK;
+}
+
+int mv_dist_info(mv_ctx* ctx, uint32_t* transport, uint32_t* ranks, uint32_t* communicators)
+{
+	if (!ctx || !transport || !ranks || !communicators) return MV_ERR_INVALID_ARG;
+	*transport = 0; *ranks = 0; *communicators = 0;
+	const DistState* d = ctx->dist;
+	if (!d) return MV_OK;
+	*transport = (uint32_t)d->transport; *communicators = d->numComm;
+	*ranks = ctx->st.shardCount;
+	if (d->transport == 1)
+	{
+		// what RCCL itself says about the communicator (ncclCommCount), not what the context was told
+		auto commCount = reinterpret_cast<decltype(&ncclCommCount)>(dlsym(d->rcclLib, "ncclCommCount"));
+		int n = 0;
+		MV_REQUIRE(ctx, commCount && commCount(d->comm[0], &n) == ncclSuccess, MV_ERR_HIP, "ncclCommCount failed");
+		*ranks = (uint32_t)n;
 	}
 	return MV_OK;
 }

@@ -156,21 +156,35 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()
     if prefer_rccl and backend == "nccl":
+        # Every step below is unconditional and collective, whatever failed locally: a rank never leaves the others waiting in a
+        # collective it skips.  (1) rank 0 makes the ids -- zeros and a flag if it cannot -- and ALWAYS broadcasts them;
+        # (2) the ranks vote (MIN) on "I can open RCCL and got valid ids" BEFORE anyone enters ncclCommInitRank, which is collective;
+        # (3) init + self-test; (4) a second vote: one rank's failure moves them all to the callbacks.
         err = None
-        try:
-            ids = torch.zeros(_lib.MV_DIST_ID_BYTES, dtype=torch.uint8, device="cuda")
-            if rank == 0:
-                ids.copy_(torch.frombuffer(bytearray(caster.DistUniqueId()), dtype=torch.uint8))
-            dist.broadcast(ids, src=0)
-            caster.DistInitRccl(bytes(ids.cpu().numpy().tobytes()))
-            caster.DistSelfTest()  # every collective the frame loop uses, verified once, before any frame
-        except Exception as e:
-            err = e
-        # every rank takes the same transport: one rank's failure moves them all to the callbacks
-        ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device="cuda")
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) == 1:
-            return "rccl"
+        msg = torch.zeros(_lib.MV_DIST_ID_BYTES + 1, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            try:
+                msg[:_lib.MV_DIST_ID_BYTES].copy_(torch.frombuffer(bytearray(caster.DistUniqueId()), dtype=torch.uint8))
+                msg[_lib.MV_DIST_ID_BYTES] = 1
+            except Exception as e:
+                err = e
+        dist.broadcast(msg, src=0)
+        host = msg.cpu().numpy()
+        can = 1 if (int(host[_lib.MV_DIST_ID_BYTES]) == 1 and err is None and caster.DistRcclAvailable()) else 0
+        vote = torch.tensor([can], dtype=torch.int32, device="cuda")
+        dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+        if int(vote.item()) == 1:
+            try:
+                caster.DistInitRccl(bytes(host[:_lib.MV_DIST_ID_BYTES].tobytes()))
+                caster.DistSelfTest()  # every collective the frame loop uses, verified once, before any frame
+            except Exception as e:
+                err = e
+            ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                return "rccl"
+        elif err is None and not can:
+            err = "librccl.so could not be opened here" if int(host[_lib.MV_DIST_ID_BYTES]) == 1 else "rank 0 could not make the RCCL ids"
         import sys  # loud, and visible in the bench line ("transport: torch-callbacks")
         print(f"[rank {rank}] in-library RCCL transport unavailable ({err if err is not None else 'another rank failed'}); "
               "using torch.distributed callbacks", file=sys.stderr)

@@ -216,6 +216,12 @@ class MultiRayCaster:
         self._check(self._lib.mv_set_volume_descs(self._ctx, _ptr(a)), "mv_set_volume_descs")
 
     # ---- inputs ----
+    def SetViewport(self, width, height):
+        """SetViewport (MultiRayCaster.cpp:226-241): the W x H buffers (composite image, RayCast layers, own depth map) are
+        re-created; volumes, light maps and cube maps stay.  The depth map has to be supplied again."""
+        self._check(self._lib.mv_set_viewport(self._ctx, int(width), int(height)), "mv_set_viewport")
+        self.viewport = (int(width), int(height))
+
     def SetRenderTargets(self, depthMap=None, shadowMap=None, depthMapDevice=None, shadowMapDevice=None):
         """SetRenderTargets (MultiRayCaster.cpp:211-224): the DEPTH_MAP / SHADOW_MAP the path reads."""
         W, H = self.viewport
@@ -444,6 +450,11 @@ class MultiRayCaster:
             raise _lib.MVError(rc_, "mv_dist_unique_id")
         return bytes(buf)
 
+    @staticmethod
+    def DistRcclAvailable():
+        """librccl.so and the entry points the frame loop needs can be opened in this process (a local check: no collective)."""
+        return _lib.load().mv_dist_rccl_available() == 1
+
     def DistInitRccl(self, id_bytes):
         buf = (C.c_uint8 * _lib.MV_DIST_ID_BYTES).from_buffer_copy(id_bytes)
         self._check(self._lib.mv_dist_init_rccl(self._ctx, buf), "mv_dist_init_rccl")
@@ -473,6 +484,12 @@ class MultiRayCaster:
 
     def DistFlush(self):
         self._check(self._lib.mv_dist_flush(self._ctx), "mv_dist_flush")
+
+    def DistInfo(self):
+        """{"transport": "none" | "rccl" | "callbacks", "ranks": communicator size as RCCL reports it, "communicators": n}"""
+        t, r, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self._lib.mv_dist_info(self._ctx, C.byref(t), C.byref(r), C.byref(c)), "mv_dist_info")
+        return {"transport": ("none", "rccl", "callbacks")[t.value], "ranks": r.value, "communicators": c.value}
 
     def DistExchangedBytes(self, reset=False):
         n = C.c_uint64()

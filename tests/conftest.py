@@ -21,17 +21,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
-def _gpu_present():
-    try:
-        import torch
-        return torch.cuda.is_available()
-    except Exception:
-        return False
-
-
-def pytest_collection_modifyitems(config, items):
-    # -m gpu on a box without a GPU must fail loudly, not skip: the product has no CPU fallback.
-    pass
+# (-m gpu on a box without a GPU fails loudly by itself: mv_create returns MV_ERR_NO_DEVICE, the product has no CPU fallback)
 
 
 @pytest.fixture(scope="session")

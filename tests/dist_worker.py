@@ -33,6 +33,7 @@ def main():
     out_path, frames, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     mode = sys.argv[4] if len(sys.argv) > 4 else "chains"           # "chains" (three view streams) or "single" (one view stream)
     static_depth = len(sys.argv) > 5 and sys.argv[5] == "1"          # no setter (= no drain of the frames in flight) inside the sequence
+    after_setter = len(sys.argv) > 5 and sys.argv[5] == "2"          # a new host depth map every frame and NO flush: frame f - 1 is read back right after the setter of frame f
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo")
@@ -47,8 +48,15 @@ def main():
         imgs, infos = [], []
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
             if not static_depth or f == 0:
+                # (inside the loop the setter first enqueues the pending tail of frame f - 1 -- its exchange, composite and row gather --
+                # so that frame is composited against ITS depth map, not this one; a collective call, made by every rank)
                 c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
+                if after_setter and f > 0:
+                    imgs.append(c.ReadBackComposite())
+                    infos.append(c.ReadBackVolumeInfo())
             c.DistFrame(vp, fr["shadowVP"], e)
+            if after_setter and f != frames - 1:
+                continue
             if f % every == every - 1 or f == frames - 1:
                 c.DistFlush()
                 imgs.append(c.ReadBackComposite())

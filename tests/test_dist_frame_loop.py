@@ -36,7 +36,7 @@ def run_group(cmd, timeout, env=None):
 
 
 
-def single_gpu(world, frames, every, static_depth=False):
+def single_gpu(world, frames, every, static_depth=False, all_frames=False):
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
     from tests.dist_worker import camera_sequence
@@ -51,7 +51,7 @@ def single_gpu(world, frames, every, static_depth=False):
                 c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
             c.UpdateFrame(vp, fr["shadowVP"], e)
             c.Render(composite=True)
-            if f % every == every - 1 or f == frames - 1:
+            if all_frames or f % every == every - 1 or f == frames - 1:
                 imgs.append(c.ReadBackComposite())
                 infos.append(c.ReadBackVolumeInfo())
         st = c.GetStats()
@@ -82,6 +82,28 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     assert np.array_equal(d["lms"], lms), "every rank holds every light map, current"
     assert np.array_equal(d["counts"], counts), "the ranks together march exactly the single-GPU samples"
     assert int(d["nbytes"]) > 0
+
+
+@pytest.mark.parametrize("mode", ["chains", "single"])
+def test_input_setters_inside_the_loop_leave_the_pending_frame_its_inputs(tmp_path, mode):
+    """mv_dist_frame(k) defers frame k - 1's exchange, composite and row gather to the next call.  A caller that hands over a new host
+    depth map before every frame (SetRenderTargets(depth_k); DistFrame(k)) must still get frame k - 1 composited against depth_{k-1}:
+    the setter enqueues the pending tail before it overwrites the map.  Every frame is read back right after the NEXT frame's setter,
+    with no flush anywhere, and compared with the single-GPU frame."""
+    frames, world = 12, 2
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), "1", mode, "2"]
+    r = run_group(cmd, 300, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    imgs, infos, counts, lms = single_gpu(world, frames, 1, all_frames=True)
+    assert len(d["imgs"]) == frames == len(imgs)
+    for i in range(frames):
+        assert np.array_equal(d["infos"][i], infos[i])
+        assert np.array_equal(d["imgs"][i], imgs[i]), f"frame {i} was not composited against its own depth map ({(d['imgs'][i] != imgs[i]).sum()} halfs differ)"
+    assert np.array_equal(d["lms"], lms) and np.array_equal(d["counts"], counts)
 
 
 def test_rccl_transport_on_one_rank():

@@ -28,12 +28,15 @@ def relight_all(c, fr, frames):
         c.rayMarchL()
 
 
-def test_c5_full_size_properties(oracle):
-    """BASELINE.json configs[4]: 64 volumes of 256^3, 2048^2 viewport, 256 steps/ray, early termination + OIT composite."""
+@pytest.mark.parametrize("flags", [0, _lib.MV_FLAG_RAY_QUEUE], ids=["tiles", "ray_queue_wide"])
+def test_c5_full_size_properties(oracle, flags):
+    """BASELINE.json configs[4]: 64 volumes of 256^3, 2048^2 viewport, 256 steps/ray, early termination + OIT composite.
+    With MV_FLAG_RAY_QUEUE the march is the ray-queue form with 64-bit pool pointers (`WIDE`: 64 x 130 MiB of texels exceed
+    the 4 GiB a 32-bit offset reaches) -- the same oracle checks."""
     cfg = scene.CONFIGS["C5"]
     V, N, L, W, H = cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"]
     M = 1024
-    with make_caster(cfg, M) as c:
+    with make_caster(cfg, M, flags=flags) as c:
         for k in range(V):
             c.LoadVolumeData(k, rc.synth_volume(N, k))
         fr = scene.setup_raycaster(c, cfg)
@@ -480,3 +483,52 @@ def test_frames_that_skip_the_view_march_or_only_composite():
     finally:
         for c in cs:
             c.close()
+
+
+def test_set_viewport_mid_sequence_equals_a_fresh_context(oracle):
+    """SetViewport (MultiRayCaster.cpp:226-241, from SetRenderTargets :211-224 and MultiVolumes.cpp:382 on a resize) re-creates what
+    is W x H and keeps volumes, light maps and cube maps: after a resize the context renders what a context created at the new size
+    renders (cull decisions, mips and RayCast rectangles follow the viewport), and a second resize back gives the first image again."""
+    base = scene.CONFIGS["T2"]
+    cfg_a, cfg_b = dict(base, W=320, H=200), dict(base, W=200, H=136)   # (the smaller one moves volumes to another mip / scheme)
+    V, N = base["V"], base["N"]
+    M = 128
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+
+    def frames(c, cfg, fr):
+        relight_all(c, fr, V)
+        c.rayMarchV()
+        c.composite()
+        info = c.ReadBackVolumeInfo()
+        vis, cube = c.ReadBackVisibleLists()
+        return dict(img=c.ReadBackComposite(), info=info, vis=vis, cube=cube,
+                    cms=[c.ReadBackCubeMap(int(v), int(info[v, 0])) for v in cube], lms=[c.ReadBackLightMap(int(v)) for v in vis])
+
+    def fresh(cfg):
+        with make_caster(cfg, M) as c:
+            return frames(c, cfg, scene.setup_raycaster(c, cfg, vols))
+
+    want_a, want_b = fresh(cfg_a), fresh(cfg_b)
+    assert not np.array_equal(want_a["info"], want_b["info"]), "the two viewports must lead to different cull decisions"
+    with make_caster(cfg_a, M) as c:
+        fr = scene.setup_raycaster(c, cfg_a, vols)
+        got = frames(c, cfg_a, fr)
+        assert np.array_equal(got["img"], want_a["img"])
+        for cfg, want in ((cfg_b, want_b), (cfg_a, want_a), (cfg_b, want_b)):
+            c.SetViewport(cfg["W"], cfg["H"])
+            c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+            c.cullVolumes()
+            with pytest.raises(Exception):
+                c.rayMarchV()   # the depth map has to be supplied again
+            eye, vp = scene.camera(cfg)
+            fr = dict(fr, eye=eye, viewProj=vp)
+            c.SetRenderTargets(scene.depth_and_shadow(cfg, vp, fr["shadowVP"], M)[0])
+            got = frames(c, cfg, fr)
+            assert np.array_equal(got["info"], want["info"]) and np.array_equal(got["vis"], want["vis"]) and np.array_equal(got["cube"], want["cube"])
+            assert got["img"].shape == (cfg["H"], cfg["W"], 4) and np.array_equal(got["img"], want["img"]), "composite after the resize"
+            for x, y in zip(got["cms"], want["cms"]):
+                assert np.array_equal(x, y)
+            for x, y in zip(got["lms"], want["lms"]):
+                assert np.array_equal(x, y)
+        # the volumes themselves were never uploaded again
+        assert np.array_equal(c.ReadBackVolume(3), vols[3].reshape(c.ReadBackVolume(3).shape))
