@@ -277,6 +277,8 @@ void applyParity(mv_ctx* ctx)
 	st.waveStats = o.waveStats; st.compositeStats = o.compositeStats; st.compositeRetry = o.compositeRetry; st.tileCost = f.tileCost;
 	st.rayRecords = o.rayRecords; st.tileInfo = o.tileInfo;
 	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
+	st.binCursor = ctx->orderTiles ? f.binCounts : nullptr;
+	st.orderCap = st.maxTiles + st.maxScreenTiles + 1u;
 }
 
 int syncAll(mv_ctx* ctx)
@@ -592,8 +594,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	ctx->orderTiles = !(cfg->flags & MV_FLAG_LIST_ORDER);
 	for (uint32_t p = 0; p < kFrameSlots; ++p)
 	{
-		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 256 * 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, 8u * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);	// a region per cost bin
+		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		// per-tile cost table, one per slot: the view march of frame i writes it, the tile order of frame i + 4 reads it
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileCost, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	}
@@ -796,7 +798,7 @@ int mv_set_viewport(mv_ctx* ctx, uint32_t w, uint32_t h)
 	ctx->haveDepth = false;
 	for (uint32_t p = 0; p < kFrameSlots; ++p)
 	{
-		if ((rc = devRealloc(ctx, &ctx->fb[p].tileOrder, ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return rc;
+		if ((rc = devRealloc(ctx, &ctx->fb[p].tileOrder, 8u * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return rc;
 		if ((rc = devRealloc(ctx, &ctx->fb[p].tileCost, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return rc;
 	}
 	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
@@ -939,17 +941,12 @@ int mv_cull(mv_ctx* ctx)
 	beginStage(ctx, 0, ev, ctx->streamA);
 	mv::launchCull(ctx->streamA, ctx->st);
 	endStage(ctx, ev, ctx->streamA);
-	mv::launchLightOrder(ctx->streamA, ctx->st);
+	// Behind the cull on stream A (which runs frames ahead), one launch: the dispatch order of this frame's view march, from the cost
+	// table the view march of the slot's previous user wrote (mv_update_frame already made stream A wait for that frame), and the
+	// order of the light march's voxel blocks.
+	mv::launchOrders(ctx->streamA, ctx->st);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, stageADone(ctx, !ctx->orderTiles));
-	if (ctx->orderTiles)
-	{
-		// Dispatch order of this frame's view march, right behind the cull on stream A (which runs frames ahead), from the cost
-		// table the view march of the slot's previous user wrote (mv_update_frame already made stream A wait for that frame).
-		mv::launchTileOrder(ctx->streamA, ctx->st, ctx->fb[ctx->slot].binCounts, ctx->fb[ctx->slot].tileOrder);
-		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, stageADone(ctx));
-	}
+	MV_HIP(ctx, stageADone(ctx));
 	ctx->haveCull = true;
 	return MV_OK;
 }

@@ -663,6 +663,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		}
 		st.counters[7] = nTiles < 2u ? 1u : stride;
 		st.counters[8] = 0u;	// the ticket, for the next cull that uses this slot
+		if (st.binCursor) { for (uint32_t b = 0; b < 8u; ++b) st.binCursor[b] = 0u; }	// room taken in every bin of the tile order (ordersKernel follows)
 		// [10] a hash of this frame's camera and volume transforms, [11] "it differs from the hash of this slot's previous frame",
 		// i.e. of the frame whose view march wrote the tile cost table this frame's tile order reads (tileBinOf)
 		st.counters[11] = st.counters[10] != viewHash ? 1u : 0u;
@@ -851,6 +852,54 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 	const uint32_t xx = bx * 4 + (lane & 3u), yy = by * 4 + ((lane >> 2) & 3u), zz = bz * 4 + (lane >> 4);
 	const bool inRange = xx < L && yy < L && zz < L;
 
+#ifndef MV_LIGHT_CANDIDATES
+#define MV_LIGHT_CANDIDATES 0	// measured (round 3, profiles/r03_light_candidates.txt): no gain -- the loop's instructions are its samples, not its rejections
+#endif
+	// ---- candidate volumes of this voxel block (round 3 experiment, off) ----
+	// CSRayMarchL.hlsl:77-110 walks ALL V volumes for every voxel and ComputeRayOrigin rejects nearly all of them (a voxel's light ray
+	// touches two or three boxes of a 4 x 4 grid).  The light is directional: the rays of a block's 64 voxels towards the light are
+	// parallel in every volume's space and start inside the image of the block, so one conservative test per (block, volume) -- lane n
+	// tests volume n: the line through the block's centre against the box's circumscribed sphere grown by the block's radius there --
+	// decides for the whole wavefront which volumes a light ray of the block can touch at all.  A clear bit means that every voxel's
+	// ComputeRayOrigin (RayMarch.hlsli:128-155) would return false: the loop below then `continue`s exactly as the reference does
+	// (which also skips that volume's AO ray, CSRayMarchL.hlsl:95).  Results are unchanged by construction; the per-voxel tests stay.
+	__shared__ unsigned long long sCand[kLightWaves][(1024u + 63u) / 64u];	// (volumes beyond the first 64: MV_MAX_VOLUMES = 1024)
+	unsigned long long cand0 = ~0ull;
+	if (MV_LIGHT_CANDIDATES)
+	{
+		const PerObject& pb = perObjects[volumeId];
+		const float h = 4.0f / (float)L;	// half extent of the block in the relit volume's [-1, 1] space
+		const vec3 cw = mul43(v3(((float)(bx * 4u) + 2.0f) / (float)L * 2.0f - 1.0f, ((float)(by * 4u) + 2.0f) / (float)L * 2.0f - 1.0f, ((float)(bz * 4u) + 2.0f) / (float)L * 2.0f - 1.0f), pb.world);
+		for (uint32_t n0 = 0; n0 < st.V; n0 += 64u)
+		{
+			const uint32_t n = n0 + lane;
+			bool cand = false;
+			if (n < st.V)
+			{
+				const float* wi = perObjects[n].worldI;
+				const vec3 c = mul43(cw, wi);
+				// images of the block's three half axes in volume n's space: columns of (WorldI_n) (World_0), times h
+				float R = 0.0f;
+#pragma unroll
+				for (int i = 0; i < 3; ++i)
+				{
+					const vec3 a = v3(pb.world[i], pb.world[4 + i], pb.world[8 + i]);	// World_0 applied to unit axis i (linear part)
+					const vec3 m = mul33(a, wi);
+					R += __builtin_sqrtf(dot3(m, m));
+				}
+				R *= h;
+				const float4 ld = st.lightDirs[n];
+				const float oo = dot3(c, c), od = c.x * ld.x + c.y * ld.y + c.z * ld.z;
+				const float d2 = __builtin_fmaxf(oo - od * od, 0.0f);
+				const float reach = 1.7607f + R + 1e-3f * (1.0f + __builtin_sqrtf(oo));	// sqrt(3.1): the margin of missesUnitBox, + the block, + rounding
+				cand = !(d2 > reach * reach + 1e-5f * oo);	// (NaN: candidate)
+			}
+			const unsigned long long m = __ballot(cand);
+			if (n0 == 0u) cand0 = m;
+			else *(volatile unsigned long long*)&sCand[threadIdx.x >> 6][n0 >> 6] = m;	// (every lane stores the same word)
+		}
+	}
+
 	uint32_t nS = 0;
 	if (inRange)
 	{
@@ -901,6 +950,9 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 
 			for (uint32_t n = 0; n < st.V; ++n)	// :77-110
 			{
+				// (wave-uniform) can a light ray of this block touch volume n at all?
+				const bool cand = !MV_LIGHT_CANDIDATES || (((n < 64u ? cand0 : *(volatile unsigned long long*)&sCand[threadIdx.x >> 6][n >> 6]) >> (n & 63u)) & 1ull);
+				if (!cand && !st.hasLightProbe) continue;	// no light ray (it misses, or the voxel is in shadow already) and no AO ray: nothing happens for n
 				const uint32_t volTexId = st.volumeDescs[n] & 0x3fffu;
 				const PerObject& po = perObjects[n];
 				const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
@@ -908,6 +960,7 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 
 				if (shadow >= kZeroThreshold)
 				{
+					if (!cand) continue;	// what missesUnitBox / ComputeRayOrigin below would conclude for every voxel of the block
 					const float4 ld = st.lightDirs[n];	// = normalize(mul(lightPos, (float3x3)WorldI_n)), :88-89, evaluated once by the cull
 					const vec3 rayDir = v3(ld.x, ld.y, ld.z);
 					if (missesUnitBox(localRayOrigin, rayDir)) continue;	// what ComputeRayOrigin would conclude, at a fifth of the cost
@@ -1021,75 +1074,64 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 	return kOrderBins - 1u - (b < kOrderBins - 1u ? b : kOrderBins - 1u);
 }
 
-template <bool SCATTER>
-__global__ __launch_bounds__(64) void tileOrderKernel(DeviceState st, uint32_t* binCounts, uint32_t* order)
+// One pass (round 3; two launches with a 256 x 8 histogram between them before): every wavefront bins the tiles of its chunk (the bins
+// of up to eight batches stay in one register, four bits each), reserves room for them in every bin with one returning atomic per
+// bin (binCursor[b], zeroed by the cull), and scatters them.  Each bin has a region of its own in `order` (orderCap entries apart),
+// so nobody needs the totals of the other wavefronts: the march derives dispatch slot -> (bin, index) from the eight cursors, which
+// are the bin totals once this kernel has finished (orderedTile, mv_kernels.hpp).  Inside a bin the chunks follow each other in
+// the order their wavefronts arrived; the tiles of a chunk stay in list order.
+__device__ __forceinline__ void tileOrderRole(const DeviceState& st, uint32_t* sWork, uint32_t chunkIndex, uint32_t numChunks)
 {
-	extern __shared__ uint32_t sWork[];	// tile starts (nEntries + 1), then entries (nEntries)
-	const uint32_t lane = threadIdx.x;
+	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3], nCubeTiles = st.counters[6];
 	uint32_t* sStart = sWork;
 	uint32_t* sEntry = sWork + nEntries + 1u;
-	for (uint32_t i = lane; i <= nEntries; i += 64u) sStart[i] = st.workTileStart[i];
-	for (uint32_t i = lane; i < nEntries; i += 64u) sEntry[i] = st.workEntries[i];
+	for (uint32_t i = threadIdx.x; i <= nEntries; i += blockDim.x) sStart[i] = st.workTileStart[i];
+	for (uint32_t i = threadIdx.x; i < nEntries; i += blockDim.x) sEntry[i] = st.workEntries[i];
 	__syncthreads();
 
-	const uint32_t chunk = (nTiles + kOrderWaves - 1u) / kOrderWaves;
-	const uint32_t begin = blockIdx.x * chunk;
+	const uint32_t chunk = (nTiles + numChunks - 1u) / numChunks;
+	const uint32_t begin = chunkIndex * chunk;
 	const uint32_t end = begin + chunk < nTiles ? begin + chunk : nTiles;
+	if (begin >= end) return;
+	uint32_t* order = const_cast<uint32_t*>(st.tileOrder);
 
-	uint32_t base[kOrderBins];
-	if (SCATTER)
-	{
-		// base[b] = tiles of longer bins + tiles of bin b owned by earlier waves
-		uint32_t tot[kOrderBins], pre[kOrderBins];
+	uint32_t count[kOrderBins];
 #pragma unroll
-		for (uint32_t b = 0; b < kOrderBins; ++b) { tot[b] = 0; pre[b] = 0; }
-		for (uint32_t g = lane; g < kOrderWaves; g += 64u)
-		{
-			const u32x4 c0 = reinterpret_cast<const u32x4*>(binCounts)[2u * g], c1 = reinterpret_cast<const u32x4*>(binCounts)[2u * g + 1u];
-			const uint32_t c[kOrderBins] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
-#pragma unroll
-			for (uint32_t b = 0; b < kOrderBins; ++b) { tot[b] += c[b]; pre[b] += g < blockIdx.x ? c[b] : 0u; }
-		}
-		uint32_t run = 0;
-#pragma unroll
-		for (uint32_t b = 0; b < kOrderBins; ++b)
-		{
-			base[b] = run + waveSumU32(pre[b]);
-			run += waveSumU32(tot[b]);
-		}
-	}
-	else
-	{
-#pragma unroll
-		for (uint32_t b = 0; b < kOrderBins; ++b) base[b] = 0;
-	}
-
-	for (uint32_t first = begin; first < end; first += 64u)
+	for (uint32_t b = 0; b < kOrderBins; ++b) count[b] = 0;
+	uint32_t cached = 0;	// bins of this lane's tile in batches 0..7, four bits each (8 = no tile)
+	uint32_t batch = 0;
+	for (uint32_t first = begin; first < end; first += 64u, ++batch)
 	{
 		const uint32_t tile = first + lane;
 		const uint32_t bin = tile < end ? tileBinOf(st, sStart, sEntry, nEntries, nCubeTiles, tile) : kOrderBins;
+		if (batch < 8u) cached |= bin << (4u * batch);
+#pragma unroll
+		for (uint32_t b = 0; b < kOrderBins; ++b) count[b] += (uint32_t)__popcll(__ballot(bin == b));
+	}
+	// lane b reserves this chunk's room in bin b
+	uint32_t mine = 0;
+#pragma unroll
+	for (uint32_t b = 0; b < kOrderBins; ++b) mine = lane == b ? count[b] : mine;
+	uint32_t got = 0;
+	if (lane < kOrderBins && mine) got = atomicAdd(&st.binCursor[lane], mine);
+	uint32_t base[kOrderBins];
+#pragma unroll
+	for (uint32_t b = 0; b < kOrderBins; ++b) base[b] = __shfl(got, (int)b) + b * st.orderCap;
+
+	batch = 0;
+	for (uint32_t first = begin; first < end; first += 64u, ++batch)
+	{
+		const uint32_t tile = first + lane;
+		const uint32_t bin = batch < 8u ? (cached >> (4u * batch)) & 0xfu : tile < end ? tileBinOf(st, sStart, sEntry, nEntries, nCubeTiles, tile) : kOrderBins;
 #pragma unroll
 		for (uint32_t b = 0; b < kOrderBins; ++b)
 		{
 			const uint64_t m = __ballot(bin == b);
-			if (SCATTER && bin == b) order[base[b] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = tile;
+			if (bin == b) order[base[b] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = tile;
 			base[b] += (uint32_t)__popcll(m);
 		}
 	}
-	if (!SCATTER)
-	{
-#pragma unroll
-		for (uint32_t b = 0; b < kOrderBins; ++b)
-			if (lane == b) binCounts[blockIdx.x * kOrderBins + b] = base[b];
-	}
-}
-
-void launchTileOrder(hipStream_t s, const DeviceState& st, uint32_t* binCounts, uint32_t* order)
-{
-	const size_t lds = (2 * ((size_t)st.V * 6 + st.screenSlots) + 1) * sizeof(uint32_t);
-	hipLaunchKernelGGL(tileOrderKernel<false>, dim3(kOrderWaves), dim3(64), lds, s, st, binCounts, order);
-	hipLaunchKernelGGL(tileOrderKernel<true>, dim3(kOrderWaves), dim3(64), lds, s, st, binCounts, order);
 }
 
 // Sums the per-wavefront counter slots into st.stats (run by mv_get_stats, not per frame).
@@ -1200,10 +1242,11 @@ void launchCull(hipStream_t s, const DeviceState& st)
 // One small workgroup, a counting sort over at most (2 B)^2 tubes in LDS (B = blocks per axis <= kLightOrderMaxB), behind the cull.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kLightOrderMaxB = 32, kLightOrderThreads = 256;	// (four wavefronts: a 1024-thread workgroup waited 80-160 us for sixteen free wave slots on one CU of a GPU the view marches fill)
-__global__ __launch_bounds__(kLightOrderThreads) void lightOrderKernel(DeviceState st)
+constexpr uint32_t kLightOrderLdsWords = 4u * kLightOrderMaxB * kLightOrderMaxB + kLightOrderThreads / 64u;
+__device__ __forceinline__ void lightOrderRole(const DeviceState& st, uint32_t* sMem)
 {
-	__shared__ uint32_t sCursor[4u * kLightOrderMaxB * kLightOrderMaxB];
-	__shared__ uint32_t sWave[kLightOrderThreads / 64u];
+	uint32_t* sCursor = sMem;	// 4 kLightOrderMaxB^2 tube cursors
+	uint32_t* sWave = sMem + 4u * kLightOrderMaxB * kLightOrderMaxB;
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 	const uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
 	const uint32_t B = (st.L + 3u) >> 2, T = 2u * B, total = B * B * B, tubes = T * T;
@@ -1260,10 +1303,26 @@ __global__ __launch_bounds__(kLightOrderThreads) void lightOrderKernel(DeviceSta
 	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) st.lightOrder[atomicAdd(&sCursor[tubeOf(b)], 1u)] = b;
 }
 
-void launchLightOrder(hipStream_t s, const DeviceState& st)
+// The two orders a frame needs -- the dispatch order of the view march's tiles and (when the light direction has changed) of the light
+// march's voxel blocks -- in ONE launch behind the cull: workgroups 0 .. kOrderGroups - 1 order the tiles, four chunks each (one
+// per wavefront); the last workgroup orders the voxel blocks.  (Three launches before: every launch of a frame's prologue is ~4 us
+// of host time and ~5 us of latency in front of the marches, which is what a rank of the multi-GPU loop is made of.)
+constexpr uint32_t kOrderGroups = kOrderWaves * 64u / kLightOrderThreads;
+__global__ __launch_bounds__(kLightOrderThreads) void ordersKernel(DeviceState st, uint32_t tileGroups)
 {
-	if (!st.lightOrder || ((st.L + 3u) >> 2) > kLightOrderMaxB) return;
-	hipLaunchKernelGGL(lightOrderKernel, dim3(1), dim3(kLightOrderThreads), 0, s, st);
+	extern __shared__ uint32_t sOrders[];
+	if (blockIdx.x < tileGroups) tileOrderRole(st, sOrders, blockIdx.x * (kLightOrderThreads / 64u) + (threadIdx.x >> 6), tileGroups * (kLightOrderThreads / 64u));
+	else lightOrderRole(st, sOrders);
+}
+
+void launchOrders(hipStream_t s, const DeviceState& st)
+{
+	const bool tiles = st.tileOrder != nullptr;
+	const bool light = st.lightOrder && ((st.L + 3u) >> 2) <= kLightOrderMaxB;
+	if (!tiles && !light) return;
+	const size_t tileLds = (2 * ((size_t)st.V * 6 + st.screenSlots) + 1) * sizeof(uint32_t), lightLds = (size_t)kLightOrderLdsWords * sizeof(uint32_t);
+	const uint32_t tileGroups = tiles ? kOrderGroups : 0u;
+	hipLaunchKernelGGL(ordersKernel, dim3(tileGroups + (light ? 1u : 0u)), dim3(kLightOrderThreads), tileLds > lightLds ? tileLds : lightLds, s, st, tileGroups);
 }
 
 #ifndef MV_LIGHT_ORDER

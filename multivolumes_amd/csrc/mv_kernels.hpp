@@ -136,7 +136,9 @@ struct DeviceState
 	uint64_t* compositeStats;		// compositeSlots: RayCast samples per composite wavefront
 	uint32_t* compositeRetry;		// 2 + compositeSlots: {count, finished workgroups, tiles the composite's second launch has to march inline}
 	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles, marchWaves;
-	const uint32_t* tileOrder;		// permutation of the tile list (dispatch slot -> tile), longest bins first (launchTileOrder); NULL = list order
+	const uint32_t* tileOrder;		// dispatch order of the tile list, longest bins first (launchOrders): bin b's tiles at [b * orderCap, b * orderCap + binCursor[b]); NULL = list order
+	uint32_t* binCursor;			// 8: tiles in every bin (zeroed by the cull, counted up by the order kernel)
+	uint32_t orderCap;				// entries between the bins' regions of tileOrder
 	uint32_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch, by stable tile key
 	// ray queue of the view march (per output set: two frames may be between setup and march at the same time)
 	RayRecord* rayRecords;			// (maxTiles + maxScreenTiles) x 64, in dispatch order: slot s holds the rays of tile tileOrder[s]
@@ -219,6 +221,22 @@ __device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId,
 	return (st.flags & kFlagInterleaveRows) ? tileCostKeyT<true>(st, volumeId, faceId, localTile, tile, nCubeTiles) : tileCostKeyT<false>(st, volumeId, faceId, localTile, tile, nCubeTiles);
 }
 
+// dispatch slot -> tile (wave-uniform: scalar loads and compares).  The eight cursors are the bin totals once the order kernel has run.
+__device__ __forceinline__ uint32_t orderedTile(const DeviceState& st, uint32_t slot)
+{
+	if (!st.tileOrder) return slot;
+	uint32_t base = 0, at = slot;	// (a slot beyond the total -- never dispatched -- maps to itself)
+	bool found = false;
+#pragma unroll
+	for (uint32_t b = 0; b < 8u; ++b)
+	{
+		const uint32_t n = st.binCursor[b];
+		if (!found && slot < base + n) { at = b * st.orderCap + (slot - base); found = true; }
+		base += n;
+	}
+	return found ? st.tileOrder[at] : slot;
+}
+
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)
 {
 	uint64_t s = 0;
@@ -241,7 +259,7 @@ void launchBuildOccupancy(hipStream_t s, const uint2* bricked, uint64_t* words, 
 void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uint32_t L);
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
-void launchLightOrder(hipStream_t s, const DeviceState& st);	// behind the cull: XCD-aware order of the light march's voxel blocks
+void launchOrders(hipStream_t s, const DeviceState& st);	// behind the cull, one launch: the cost-binned dispatch order of the view march's tiles + the XCD-aware order of the light march's voxel blocks
 void launchMarchLight(hipStream_t s, const DeviceState& st);
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// returns the first slot its grid does not cover (0xffffffff: none)
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
@@ -249,7 +267,6 @@ uint32_t marchTilesResidentWaves(int device);
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
 uint32_t marchViewResidentWaves(int device, bool wideAddressing);	// wavefronts of the march kernel the device holds at once (occupancy query)
-void launchTileOrder(hipStream_t s, const DeviceState& st, uint32_t* binCounts, uint32_t* order);	// binCounts: 256 x 8 scratch; order: maxTiles + maxScreenTiles
 void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight);
 uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
 void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background = nullptr);	// background: W x H RGBA16F (device) or NULL

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64 * kSetupWaves) void raySetupKernel(DeviceState s
 	for (uint32_t slot = blockIdx.x * kSetupWaves + (threadIdx.x >> 6); slot < nTiles; slot += nWaves)
 	{
 		// Dispatch slot -> tile: cost-binned order (tileOrderKernel), or plain list order
-		uint32_t tile = st.tileOrder ? st.tileOrder[slot] : slot;
+		uint32_t tile = orderedTile(st, slot);
 		tile = __builtin_amdgcn_readfirstlane(tile);
 
 		// the work entry that owns this tile (wave-uniform)

@@ -65,9 +65,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 	// follows marches the rest.
 	for (uint32_t slot = firstSlot + blockIdx.x * kTileWaves + wave; slot < nTiles; slot += OVERFLOW ? gridDim.x * kTileWaves : 0xffffffffu - slot)
 	{
-	uint32_t tile = slot;
-	tile = __builtin_amdgcn_readfirstlane(tile);
-	if (st.tileOrder) tile = __builtin_amdgcn_readfirstlane(st.tileOrder[slot]);
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(slot)));
 
 	// find the work entry that owns this tile (wave-uniform)
 	uint32_t entry = 0;

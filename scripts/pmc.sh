@@ -15,7 +15,7 @@ v = collections.defaultdict(list)
 for r in csv.DictReader(open(f[0])):
     if r["Counter_Name"] == c: v[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
 for k, x in v.items():
-    if k.startswith("mv::march") or k.startswith("mv::composite") or k.startswith("mv::cull") or k.startswith("mv::tileOrder") or k.startswith("mv::raySetup") or k.startswith("mv::copyForward"):
+    if k.startswith("mv::march") or k.startswith("mv::composite") or k.startswith("mv::cull") or k.startswith("mv::orders") or k.startswith("mv::light") or k.startswith("mv::exchange") or k.startswith("mv::raySetup") or k.startswith("mv::copyForward"):
         t = x[-8:]
         print("%-14s %-28s n %3d  mean(last 8) %.6g" % (c, k, len(x), sum(t) / len(t)))
 PY
