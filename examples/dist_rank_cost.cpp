@@ -4,7 +4,8 @@
 // (scripts/exp_rank_cost.py is the same measurement through the Python mirror).  max over ranks = the frame time an ideal fabric would
 // give; its ratio to world 1 is the ceiling of the strong-scaling curve.
 // Build: g++ -O2 -std=c++17 examples/dist_rank_cost.cpp -Lmultivolumes_amd -lmultivolumes_amd -Wl,-rpath,$PWD/multivolumes_amd -o /tmp/dist_rank_cost
-// Usage: /tmp/dist_rank_cost [frames = 400]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// Prints per rank: ms per frame, and in brackets the host's share (time spent inside DistFrame: constants + every HIP call of the frame).
 #include "../multivolumes_amd/csrc/MultiRayCaster.hpp"
 
 #include <algorithm>
@@ -20,6 +21,7 @@ int main(int argc, char** argv)
 {
 	const uint32_t N = 256, L = 96, V = 16, W = 1024, H = 1024, M = 1024;
 	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
+	const unsigned worlds = argc > 2 ? (unsigned)std::atoi(argv[2]) : 15u;
 	std::vector<std::vector<uint16_t>> vols(V, std::vector<uint16_t>((size_t)N * N * N * 4));
 	for (uint32_t k = 0; k < V; ++k) mvh_synth_volume(N, k, vols[k].data());
 
@@ -38,6 +40,7 @@ int main(int argc, char** argv)
 	double one = 0.0;
 	for (uint32_t world : { 1u, 2u, 4u, 8u })
 	{
+		if (!(worlds & world)) continue;
 		double worst = 0.0;
 		std::printf("world %u: ms/frame per rank [", world);
 		for (uint32_t rank = 0; rank < world; ++rank)
@@ -53,11 +56,15 @@ int main(int argc, char** argv)
 			mv_dist_set_inplace_gather(rc.Context(), 1);	// like RCCL: no staging copies
 			for (int f = 0; f < std::min(200, frames); ++f) if (!rc.DistFrame(viewProj, shadowVP, eye)) { std::fprintf(stderr, "%s\n", rc.LastError()); return 6; }
 			rc.DistFlush(); mv_synchronize(rc.Context());
+			double waited = 0.0;
+			mv_host_wait_ms(rc.Context(), &waited, 1);
 			const auto t0 = std::chrono::steady_clock::now();
 			for (int f = 0; f < frames; ++f) if (!rc.DistFrame(viewProj, shadowVP, eye)) return 6;
+			mv_host_wait_ms(rc.Context(), &waited, 1);
+			const double host = (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - waited) / frames;	// enqueueing, without the waits for a free frame slot
 			rc.DistFlush(); mv_synchronize(rc.Context());
 			const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
-			std::printf("%s%.4f", rank ? ", " : "", ms);
+			std::printf("%s%.4f (host %.4f)", rank ? ", " : "", ms, host);
 			std::fflush(stdout);
 			worst = std::max(worst, ms);
 		}

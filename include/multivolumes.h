@@ -113,7 +113,7 @@ typedef struct mv_stats
 
 const char* mv_error_string(int code);
 const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
-#define MV_ABI_VERSION 3u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available */
+#define MV_ABI_VERSION 3u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms */
 uint32_t mv_abi_version(void);	/* == MV_ABI_VERSION of the header the library was built from */
 
 /* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,
@@ -215,6 +215,9 @@ int mv_get_stats(mv_ctx* ctx, mv_stats* out);	/* synchronises the stream */
 int mv_reset_stats(mv_ctx* ctx);
 int mv_set_profiling(mv_ctx* ctx, int on);		/* record HIP events around every stage launch (adds host syncs in mv_get_stats only) */
 int mv_synchronize(mv_ctx* ctx);
+/* Time (ms) mv_update_frame has spent waiting for the GPU to free a frame slot (four frames of constants are in flight at most, as the
+ * reference waits on its fence with FrameCount = 3, MultiVolumes.cpp MoveToNextFrame): 0 while the host is the slower side. */
+int mv_host_wait_ms(mv_ctx* ctx, double* ms, int reset);
 
 /* Raw handles for callers that keep data resident (torch / RCCL plumbing): */
 void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */

@@ -120,6 +120,7 @@ ABI = {
     "mv_dist_exchanged_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),
     "mv_dist_rccl_available": (C.c_int, []),
     "mv_dist_info": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
+    "mv_host_wait_ms": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
     "mv_set_viewport": (C.c_int, [_P, _U32, _U32]),
     "mv_mesh_upload": (C.c_int, [_P, _P, _U32, _P, _U32]),
     "mv_mesh_render_depth": (C.c_int, [_P, _P, _P]),

@@ -18,7 +18,7 @@ $HIPCC $FLAGS -c mv_march_tiles.hip -o $OBJ/mv_march_tiles.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_composite.hip -o $OBJ/mv_composite.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_mesh.hip -o $OBJ/mv_mesh.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_api.cpp -o $OBJ/mv_api.o "$@" & pids+=($!)
-g++ -O2 -std=c++17 -fPIC -Wall -c mv_host.cpp -o $OBJ/mv_host.o & pids+=($!)
+g++ -O3 -ffp-contract=off -std=c++17 -fPIC -Wall -c mv_host.cpp -o $OBJ/mv_host.o & pids+=($!)
 rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=1; done
 if [ $rc -ne 0 ]; then echo "build.sh: a compile job failed" >&2; rm -rf "$OBJ"; exit 1; fi

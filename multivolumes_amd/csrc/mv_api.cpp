@@ -10,6 +10,7 @@
 #include "mv_mesh.hpp"
 
 #include <algorithm>
+#include <chrono>
 
 #include <hip/hip_runtime.h>
 #include <string.h>
@@ -22,11 +23,20 @@
 
 using mv::DeviceState;
 
+#ifdef MV_HOST_PROFILE	// (diagnostic builds: where the host's time inside mv_dist_frame goes; printed by mv_dist_shutdown / mv_destroy)
+static double gSection[12]; static uint64_t gSectionCalls;
+struct SectionTimer { int i; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~SectionTimer() { gSection[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } };
+#define MV_SECTION(i) SectionTimer section_##i{ i }
+#else
+#define MV_SECTION(i)
+#endif
+
+
 namespace
 {
 constexpr uint32_t kMaxScreenSlots = 32;	// screen-space-scheme volumes whose RayCast joins the view-march launch (16 B x W x H of layer each, per output set)
 constexpr uint32_t kFrameSlots = 4;	// constants + cull outputs in flight: the cull of frame i+2 may run while frame i is still marching
-constexpr uint32_t kFrameSlices = 3;	// MultiRayCaster::FrameCount (MultiRayCaster.h:52): upload slices in flight
+constexpr uint32_t kFrameSlices = 4;	// upload slices in flight, one per frame slot (the reference keeps FrameCount = 3 of them, MultiRayCaster.h:52)
 constexpr uint32_t kNumCounters = 8;	// read back; counters[8] (the cull's ticket) is device-only
 constexpr uint32_t kNumStats = 8;
 
@@ -101,11 +111,12 @@ struct DistState
 	hipStream_t streamX = nullptr;	// (single view stream) exchange + composite of frame k - 1, beside frame k's view march
 	uint8_t *sendBuf[kDistChains] = {}, *recvBuf[kDistChains] = {};	// one shard / shard_count shards of marched cube faces ([0] only without chains)
 	size_t sendCap = 0;
-	uint32_t* lightWords[kDistChains] = {};	// L^3 R11G11B10F words of the relit light map
+	uint32_t* lightWords[kDistChains] = {};	// the relit light map as every rank's share of its voxel blocks: shard_count x lightShareBytes (plain R11G11B10F words, 64 per block)
+	uint8_t* lightSend[kDistChains] = {};	// this rank's share when the transport cannot gather in place
+	size_t lightShareBytes = 0;
 	uint8_t *rowSend[kDistChains] = {}, *rowRecv[kDistChains] = {};	// staged row-band gather (unequal bands, or a transport without in-place all-gather)
 	size_t maxBandBytes = 0;
-	uint8_t* pinnedCull[4] = {};	// per frame slot: counters + VolumeInfo + lists, copied behind the cull
-	hipEvent_t evCullCopied[4] = {};
+	unsigned long long* reports = nullptr;	// pinned, one word per frame slot: {frame tag : texels of the largest exchange shard}, written by the cull
 	bool pending = false, pendingComposite = false;
 	DeviceState stPending;			// the device state of the frame whose exchange + composite are still to be enqueued
 	uint32_t slotPending = 0, chainPending = 0;
@@ -161,10 +172,9 @@ struct mv_ctx
 	std::vector<void*> allocs;			// everything to hipFree
 
 	// pinned upload ring (the reference's upload-heap slices, MultiRayCaster.cpp:128-130, 461-467)
-	uint8_t* pinned = nullptr;
+	uint8_t* pinned = nullptr;			// kFrameSlices slices: frame i's constants in slice i % kFrameSlots, read by that frame's cull where they lie
+	uint8_t* pinnedDev = nullptr;		// the same memory as the device addresses it
 	size_t sliceBytes = 0;
-	uint32_t slice = 0;
-	hipEvent_t sliceDone[kFrameSlices] = {};
 	uint64_t* pinnedStats = nullptr;
 	uint32_t* pinnedCounters = nullptr;
 	unsigned long long* pinnedTiles = nullptr;	// written by the cull kernel: {frame tag : tile count} of the most recent cull that has run (a hint, never waited for)
@@ -183,6 +193,7 @@ struct mv_ctx
 	uint64_t nStage[4] = { 0, 0, 0, 0 };
 	std::string lastError;
 	DistState* dist = nullptr;
+	double hostWaitMs = 0.0;			// time mv_update_frame spent waiting for the GPU to free a frame slot (mv_host_wait_ms)
 };
 
 namespace
@@ -268,6 +279,9 @@ void applyParity(mv_ctx* ctx)
 	const FrameBufs& q = ctx->fb[(ctx->slot + kFrameSlots - 1u) % kFrameSlots];	// the previous frame's
 	DeviceState& st = ctx->st;
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
+	st.exchangeReport = (ctx->dist && ctx->dist->reports) ? ctx->dist->reports + (size_t)ctx->slot * 8u : nullptr;
+	st.cbHost = ctx->pinnedDev ? ctx->pinnedDev + (size_t)ctx->slot * ctx->sliceBytes : nullptr;
+	st.perObjectHost = ctx->pinnedDev ? ctx->pinnedDev + (size_t)ctx->slot * ctx->sliceBytes + 256 : nullptr;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.exchangeOff = f.exchangeOff; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
@@ -630,8 +644,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	applyParity(ctx);
 
 	// pinned upload ring + readback scratch
+	static_assert(kFrameSlices == kFrameSlots, "a slice per frame slot");
 	ctx->sliceBytes = 256 + (size_t)st.V * MV_PER_OBJECT_BYTES;
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kFrameSlices + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
+	if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->pinnedDev), ctx->pinned, 0) != hipSuccess) return bail(MV_ERR_HIP);
 	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices);
 	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices + 128);
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedTiles), 64, hipHostMallocCoherent) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
@@ -639,8 +655,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	st.tilesReport = ctx->pinnedTiles;
 	ctx->rayQueue = (cfg->flags & MV_FLAG_RAY_QUEUE) != 0;
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
-	for (uint32_t i = 0; i < kFrameSlices; ++i)
-		if (hipEventCreateWithFlags(&ctx->sliceDone[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 
 	// default VolumeDesc[V] = { i % S, NUM_CUBE_MIP, N } (MultiRayCaster.cpp:471-479)
 	{
@@ -663,7 +677,7 @@ static void distRelease(mv_ctx* ctx)
 	if (!d) return;
 	for (uint32_t i = 0; i < kDistChains; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
 	if (d->streamX) (void)hipStreamDestroy(d->streamX);
-	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (d->pinnedCull[i]) (void)hipHostFree(d->pinnedCull[i]); if (d->evCullCopied[i]) (void)hipEventDestroy(d->evCullCopied[i]); }
+	if (d->reports) (void)hipHostFree(d->reports);
 	for (void* p : d->allocs) (void)hipFree(p);
 	delete d;
 	ctx->dist = nullptr;
@@ -672,6 +686,16 @@ static void distRelease(mv_ctx* ctx)
 void mv_destroy(mv_ctx* ctx)
 {
 	if (!ctx) return;
+#ifdef MV_HOST_PROFILE
+	if (gSectionCalls)
+	{
+		static const char* names[12] = { "update_frame", "cull + orders", "tail: exchange", "copy-forward", "tail: composite + rows", "light + exchange", "view march", "bookkeeping", "(report)", "(pack)", "(all-gather)", "(unpack)" };
+		fprintf(stderr, "\nmv_dist_frame host time per call (us), %llu calls:", (unsigned long long)gSectionCalls);
+		for (int i = 0; i < 12; ++i) { fprintf(stderr, "  %s %.2f", names[i], gSection[i] / gSectionCalls); gSection[i] = 0.0; }
+		fprintf(stderr, "\n");
+		gSectionCalls = 0;
+	}
+#endif
 	if (ctx->stream) (void)syncAll(ctx);
 	foldEvents(ctx);
 	distRelease(ctx);
@@ -682,7 +706,6 @@ void mv_destroy(mv_ctx* ctx)
 	if (ctx->ownStreamL && ctx->streamL) (void)hipStreamDestroy(ctx->streamL);
 	for (uint32_t i = 1; i < kMaxOutSets; ++i) if (ctx->ownStreamB1 && ctx->streamB[i] && ctx->streamB[i] != ctx->stream) (void)hipStreamDestroy(ctx->streamB[i]);
 	for (EventPair& ev : ctx->freeEvents) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
-	for (uint32_t i = 0; i < kFrameSlices; ++i) if (ctx->sliceDone[i]) (void)hipEventDestroy(ctx->sliceDone[i]);
 	for (void* p : ctx->allocs) (void)hipFree(p);
 	if (ctx->meshPositions) (void)hipFree(ctx->meshPositions);
 	if (ctx->meshIndices) (void)hipFree(ctx->meshIndices);
@@ -918,15 +941,18 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->slot], 0));
 	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evLight[ctx->slot], 0));
 	if (ctx->producersDirty) { MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evProducers, 0)); ctx->producersDirty = false; }
-	const uint32_t k = ctx->slice;
-	ctx->slice = (k + 1) % kFrameSlices;
-	MV_HIP(ctx, hipEventSynchronize(ctx->sliceDone[k]));	// slice k was last used three frames ago
-	uint8_t* s = ctx->pinned + (size_t)k * ctx->sliceBytes;
+	// The constants go into this slot's pinned slice, where the frame's cull reads them (no upload copy: the cull writes the device
+	// copies the other kernels read).  The slice's previous user is the frame kFrameSlots back: its cull must have run -- in steady
+	// state it has, long ago; a host that runs more than three frames ahead of the GPU waits here, as the reference's does on its fence.
+	if (hipEventQuery(ctx->evStageA[ctx->slot]) != hipSuccess)
+	{
+		const auto t0 = std::chrono::steady_clock::now();
+		MV_HIP(ctx, hipEventSynchronize(ctx->evStageA[ctx->slot]));
+		ctx->hostWaitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+	}
+	uint8_t* s = ctx->pinned + (size_t)ctx->slot * ctx->sliceBytes;
 	memcpy(s, cbPerFrame, MV_CB_PER_FRAME_BYTES);
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
-	MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));
-	MV_HIP(ctx, hipEventRecord(ctx->sliceDone[k], ctx->streamA));
-	MV_HIP(ctx, stageADone(ctx, false));
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
 	ctx->lightMarched = false; ctx->lightTableKept = false; ctx->copiedForward = false; ctx->marchedThisFrame = false;
@@ -951,9 +977,12 @@ int mv_cull(mv_ctx* ctx)
 	return MV_OK;
 }
 
-int mv_march_light(mv_ctx* ctx)
+static int marchLight(mv_ctx* ctx, uint32_t* wordsOut);
+int mv_march_light(mv_ctx* ctx) { return ctx ? marchLight(ctx, nullptr) : MV_ERR_INVALID_ARG; }
+
+// wordsOut: inside the multi-GPU frame loop, where this rank's share of the relit map goes for the all-gather
+static int marchLight(mv_ctx* ctx, uint32_t* wordsOut)
 {
-	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
 	MV_REQUIRE(ctx, !ctx->lightTableKept, MV_ERR_NOT_READY, "mv_march_light must come before the frame's mv_march_view / mv_composite");
@@ -969,7 +998,7 @@ int mv_march_light(mv_ctx* ctx)
 	MV_HIP(ctx, hipStreamWaitEvent(L, ctx->evStageA[ctx->slot], 0));	// this frame's upload + cull
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 1, ev, L);
-	mv::launchMarchLight(L, ctx->st);
+	mv::launchMarchLight(L, ctx->st, wordsOut);
 	endStage(ctx, ev, L);
 	MV_HIP(ctx, hipGetLastError());
 	if (!(ctx->leanEvents && ctx->st.shardCount > 1u)) MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], L));	// (lean: the light-map exchange follows on this stream and records it)
@@ -1011,16 +1040,15 @@ static int copyForwardFromAllSets(mv_ctx* ctx, bool marchFollows)
 	return MV_OK;
 }
 
-int mv_march_view(mv_ctx* ctx)
-{
-	if (!ctx) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
-	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
-	{ const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
-	const uint32_t prevSlot = (ctx->slot + kFrameSlots - 1u) % kFrameSlots;
 #ifndef MV_COPY_FORWARD
 #define MV_COPY_FORWARD 1	// (0: A/B timing only -- the two output sets then drift apart in the faces a frame does not march)
 #endif
+// First half of mv_march_view: bring the faces this frame does not march up to date in its output set (see copyForward above).
+static int viewCopyForward(mv_ctx* ctx)
+{
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
+	const uint32_t prevSlot = (ctx->slot + kFrameSlots - 1u) % kFrameSlots;
 	const uint32_t n = ctx->numOutSets;
 	const bool ownCopy = !ctx->dist || ctx->dist->chains;	// (the single-view-stream multi-GPU loop copies on its stream X)
 	if (MV_COPY_FORWARD && n >= 2u && ownCopy && ctx->lastCompleteFrame != 0u && ctx->lastCompleteFrame + 1u != ctx->frame && !ctx->copiedForward)
@@ -1045,6 +1073,13 @@ int mv_march_view(mv_ctx* ctx)
 		if (rc != MV_OK) return rc;
 	}
 	ctx->lastCompleteFrame = ctx->frame;
+	return MV_OK;
+}
+
+// Second half: the march itself.
+static int viewMarch(mv_ctx* ctx)
+{
+	const uint32_t n = ctx->numOutSets;
 	ctx->marchedThisFrame = true;
 	MV_HIP(ctx, stageBBegin(ctx));
 	// the set this march writes was read by the copy-forward of frame k - n + 1 (as the set before its own) ...
@@ -1088,6 +1123,15 @@ int mv_march_view(mv_ctx* ctx)
 	MV_HIP(ctx, hipGetLastError());
 	if (!ctx->leanEvents) MV_HIP(ctx, stageBDone(ctx));	// (lean: the frame's tail records it behind the composite, on this stream, before anything waits for it)
 	return MV_OK;
+}
+
+int mv_march_view(mv_ctx* ctx)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
+	int rc = keepLightTable(ctx);	// (a frame without mv_march_light reads the previous frame's light maps)
+	if (rc == MV_OK) rc = viewCopyForward(ctx);
+	return rc != MV_OK ? rc : viewMarch(ctx);
 }
 
 int mv_composite(mv_ctx* ctx, uint32_t row0, uint32_t row1) { return mv_composite_over(ctx, row0, row1, nullptr); }
@@ -1343,6 +1387,14 @@ int mv_set_profiling(mv_ctx* ctx, int on)
 	return MV_OK;
 }
 
+int mv_host_wait_ms(mv_ctx* ctx, double* ms, int reset)
+{
+	if (!ctx || !ms) return MV_ERR_INVALID_ARG;
+	*ms = ctx->hostWaitMs;
+	if (reset) ctx->hostWaitMs = 0.0;
+	return MV_OK;
+}
+
 int mv_synchronize(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
@@ -1586,22 +1638,26 @@ static int distCommonInitBody(mv_ctx* ctx)
 	// worst case: every volume at mip 0 with six faces (C3: 75 MB per shard; 288 GB of HBM make that affordable).
 	d->sendCap = (size_t)st.V * 6u * st.N * st.N * 12u;
 	d->maxBandBytes = (size_t)mv::interleavedRowsPerRank(st.H, world) * 8u * st.W * sizeof(uint2);	// one rank's block of the rank-major composite image
+	{
+		// the light march of a frame is shared out by voxel blocks (mv_kernels.hip lightShare): 64 words per block, the same number of blocks per rank
+		DeviceState split = st;
+		split.flags |= mv::kFlagRotateAllLightMaps;
+		d->lightShareBytes = (size_t)mv::lightSharePerRank(split) * 64u * sizeof(uint32_t);
+	}
 	int rc;
 	for (uint32_t c = 0; c < (d->chains ? kDistChains : 1u); ++c)
 	{
 		if ((rc = distAlloc(ctx, &d->sendBuf[c], d->sendCap)) != MV_OK) return rc;
 		if ((rc = distAlloc(ctx, &d->recvBuf[c], d->sendCap * world)) != MV_OK) return rc;
 		uint8_t* w = nullptr;
-		if ((rc = distAlloc(ctx, &w, (size_t)st.L * st.L * st.L * sizeof(uint32_t))) != MV_OK) return rc;
+		if ((rc = distAlloc(ctx, &w, std::max<size_t>(d->lightShareBytes * world, 4096), ctx->stream)) != MV_OK) return rc;
 		d->lightWords[c] = reinterpret_cast<uint32_t*>(w);
+		if ((rc = distAlloc(ctx, &d->lightSend[c], std::max<size_t>(d->lightShareBytes, 4096), ctx->stream)) != MV_OK) return rc;
 		if ((rc = distAlloc(ctx, &d->rowSend[c], d->maxBandBytes, ctx->stream)) != MV_OK) return rc;
 		if ((rc = distAlloc(ctx, &d->rowRecv[c], d->maxBandBytes * world)) != MV_OK) return rc;
 	}
-	for (uint32_t i = 0; i < kFrameSlots; ++i)
-	{
-		if (hipHostMalloc(reinterpret_cast<void**>(&d->pinnedCull[i]), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned cull copy");
-		MV_HIP(ctx, hipEventCreateWithFlags(&d->evCullCopied[i], hipEventDisableTiming));
-	}
+	if (hipHostMalloc(reinterpret_cast<void**>(&d->reports), kFrameSlots * 64, hipHostMallocCoherent) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned exchange reports");
+	for (uint32_t i = 0; i < kFrameSlots; ++i) d->reports[i * 8u] = ~0ull;
 	if (world > 1u) ctx->st.flags |= mv::kFlagInterleaveRows;	// screen rows dealt by tile row instead of in contiguous bands
 #ifndef MV_DIST_STATIC_OWNERS	// (A/B builds only: v % shard_count inside the loop too)
 	ctx->st.flags |= mv::kFlagBalanceOwners;	// the cube-map volumes of a frame are dealt to the ranks by estimated cost (replicated cull: the same deal everywhere)
@@ -1735,24 +1791,29 @@ static int distTailExchange(mv_ctx* ctx)
 	const uint32_t slot = d->slotPending, world = st.shardCount;
 	const uint32_t chain = d->chains ? d->chainPending : 0u;
 
-	// This frame's cull results were copied to pinned memory behind its cull, at least one mv_dist_frame ago: the wait returns at once
-	// in steady state.  They give the size of the frame's all-gather (the same on every rank: the cull is replicated).
-	MV_HIP(ctx, hipEventSynchronize(d->evCullCopied[slot]));
-	const uint8_t* p = d->pinnedCull[slot];
-	const uint32_t* counters = reinterpret_cast<const uint32_t*>(p);
-	// counters[12]: texels of the largest shard of this frame's deal (the cull knows who owns what)
-	const size_t shardBytes = std::max<size_t>(16, ((size_t)counters[12] * 12u + 15u) & ~(size_t)15u);
-	MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
-
 	hipStream_t X = distTailStream(ctx, chain);
 	if (!d->chains) MV_HIP(ctx, hipStreamWaitEvent(X, ctx->evMainDone[slot], 0));	// the frame's view march (chains: the same stream)
 	if (world > 1)
 	{
-		mv::launchExchangeCompact(X, st, true, d->sendBuf[chain], shardBytes);
+		// The frame's cull left {frame tag : texels of the largest shard of its deal} in pinned memory at least one mv_dist_frame ago: a
+		// plain read in steady state (the wait only happens if the host is that far ahead of the GPU).  It gives the size of the frame's
+		// all-gather, the same on every rank: the cull is replicated.
+		volatile unsigned long long* report = d->reports + (size_t)slot * 8u;
+		unsigned long long rep;
+		{
+			MV_SECTION(8);
+			if ((uint32_t)(*report >> 32) != st.frameTag) MV_HIP(ctx, hipEventSynchronize(ctx->evStageA[slot]));
+			rep = *report;
+		}
+		MV_REQUIRE(ctx, (uint32_t)(rep >> 32) == st.frameTag, MV_ERR_HIP, "the cull's exchange report is missing");
+		const size_t shardBytes = std::max<size_t>(16, ((size_t)(uint32_t)rep * 12u + 15u) & ~(size_t)15u);
+		MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
+		{ MV_SECTION(9); mv::launchExchangeCompact(X, st, true, d->sendBuf[chain], shardBytes); }
 		MV_HIP(ctx, hipGetLastError());
-		int rc = distAllGather(ctx, d->sendBuf[chain], d->recvBuf[chain], shardBytes, X, (int)chain);
+		int rc;
+		{ MV_SECTION(10); rc = distAllGather(ctx, d->sendBuf[chain], d->recvBuf[chain], shardBytes, X, (int)chain); }
 		if (rc != MV_OK) return rc;
-		mv::launchExchangeCompact(X, st, false, d->recvBuf[chain], shardBytes);
+		{ MV_SECTION(11); mv::launchExchangeCompact(X, st, false, d->recvBuf[chain], shardBytes); }
 		MV_HIP(ctx, hipGetLastError());
 		d->bytes += shardBytes * world;
 	}
@@ -1806,6 +1867,36 @@ namespace { int distTail(mv_ctx* ctx)
 	return rc != MV_OK ? rc : distTailComposite(ctx);
 } }
 
+// The light march of frame k, shared out over the ranks by voxel blocks (every rank holds every volume): this rank marches its
+// 1 / shard_count of the blocks, into its own copy of the relit volume's fresh light buffer and, as plain words, into its share of the
+// all-gather; the other ranks' shares are then unpacked into the local copy.  Every rank keeps every light map current, because
+// every rank marches its own screen rows of every volume on the screen-space scheme.
+static int distLight(mv_ctx* ctx, uint32_t chain)
+{
+	DistState* d = ctx->dist;
+	const uint32_t world = ctx->st.shardCount, rank = ctx->st.shardIndex;
+	uint8_t* lightAll = reinterpret_cast<uint8_t*>(d->lightWords[chain]);
+	uint8_t* lightMine = d->inPlaceGather ? lightAll + (size_t)rank * d->lightShareBytes : d->lightSend[chain];
+	int rc;
+	if ((rc = marchLight(ctx, world > 1u ? reinterpret_cast<uint32_t*>(lightMine) : nullptr)) != MV_OK) return rc;
+	if (world > 1u)
+	{
+		// The exchange goes in front of the view march that needs it, on that march's stream (chains: behind the light march, which is
+		// on that stream too).  Single view stream: not behind the light march on stream L, where it would hold up the NEXT frame's
+		// light march.
+		hipStream_t E = d->chains ? streamB(ctx) : ctx->stream;
+		if (!d->chains) MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evLight[ctx->slot], 0));	// this rank's light march (chains: the same stream)
+		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evStageA[ctx->slot], 0));	// this frame's cull: the relit volume, its rotated buffer
+		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));	// frame k - 3, the last reader of the buffer the unpack overwrites
+		if ((rc = distAllGather(ctx, lightMine, lightAll, d->lightShareBytes, E, d->chains ? (int)chain : 1)) != MV_OK) return rc;
+		mv::launchLightUnpack(E, ctx->st, d->lightWords[chain]);
+		MV_HIP(ctx, hipGetLastError());
+		MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], E));	// "this frame's light map is current on this rank": the next user of the slot waits for it
+		d->bytes += d->lightShareBytes * world;
+	}
+	return MV_OK;
+}
+
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite)
 {
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
@@ -1814,42 +1905,40 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 	int rc;
 	struct Lean { mv_ctx* c; ~Lean() { c->leanEvents = false; } } lean = { ctx };
 	ctx->leanEvents = d->chains;
-	// ---- frame k: upload, cull, light march + light-map exchange, view march ----
-	if ((rc = mv_update_frame(ctx, cbPerFrame, perObject)) != MV_OK) return rc;
-	if ((rc = mv_cull(ctx)) != MV_OK) return rc;
-	MV_HIP(ctx, hipMemcpyAsync(d->pinnedCull[ctx->slot], ctx->fb[ctx->slot].cullBlock, 64 + (size_t)ctx->st.V * 24, hipMemcpyDeviceToHost, ctx->streamA));
-	MV_HIP(ctx, hipEventRecord(d->evCullCopied[ctx->slot], ctx->streamA));
-	if ((rc = mv_march_light(ctx)) != MV_OK) return rc;
-	const uint32_t chain = d->chains ? (uint32_t)(ctx->frame % kDistChains) : 0u;
-	if (ctx->st.shardCount > 1)
+	// ---- frame k: constants + cull (stream A) ----
+	{ MV_SECTION(0); if ((rc = mv_update_frame(ctx, cbPerFrame, perObject)) != MV_OK) return rc; }
+	{ MV_SECTION(1); if ((rc = mv_cull(ctx)) != MV_OK) return rc; }
+#ifdef MV_HOST_PROFILE
+	++gSectionCalls;
+	if (getenv("MV_PROFILE_CULL_LATENCY"))	// how long after its enqueue the cull's report reaches pinned memory (spins: perturbs the loop)
 	{
-		// The light-map exchange goes in front of the view march that needs it, on that march's stream (chains: behind the light march,
-		// which is on that stream too).  Single view stream: not behind the light march on stream L, where it would hold up the NEXT
-		// frame's light march (owned by another rank, ready to run beside this one) until this frame's owner has finished.
-		hipStream_t E = d->chains ? streamB(ctx) : ctx->stream;
-		uint32_t* words = d->lightWords[chain];
-		const size_t count = (size_t)ctx->st.L * ctx->st.L * ctx->st.L;
-		if (!d->chains) MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evLight[ctx->slot], 0));	// the owner's light march (nothing on the other ranks; chains: the same stream)
-		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evStageA[ctx->slot], 0));	// this frame's cull: the relit volume, its rotated buffer
-		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));	// frame k - 3, the last reader of the buffer the unpack overwrites
-		mv::launchLightExchange(E, ctx->st, words, false);
-		MV_HIP(ctx, hipGetLastError());
-		if ((rc = distAllReduceU32(ctx, words, count, E, d->chains ? (int)chain : 1)) != MV_OK) return rc;
-		mv::launchLightExchange(E, ctx->st, words, true);
-		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], E));	// "this frame's light map is current on this rank": the next user of the slot waits for it
-		d->bytes += count * sizeof(uint32_t);
+		const auto t0 = std::chrono::steady_clock::now();
+		while ((uint32_t)(*reinterpret_cast<const volatile unsigned long long*>(ctx->pinnedTiles) >> 32) != (uint32_t)ctx->frame) {}
+		const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+		static double sum = 0, worst = 0; static int n = 0;
+		sum += us; worst = us > worst ? us : worst;
+		if (++n % 200 == 0) { fprintf(stderr, " [cull latency after enqueue: avg %.1f us, max %.1f us]", sum / n, worst); sum = 0; worst = 0; n = 0; }
 	}
+#endif
+	const uint32_t chain = d->chains ? (uint32_t)(ctx->frame % kDistChains) : 0u;
 	if (d->chains)
 	{
-		// ---- frame k - 1's cube-face exchange, on ITS stream behind its view march; then frame k's view march, whose copy-forward of the
-		// faces k does not march reads k - 1's set on that same stream, i.e. behind the unpack; then k - 1's composite and row gather ----
-		if ((rc = distTailExchange(ctx)) != MV_OK) return rc;
-		if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
-		if ((rc = distTailComposite(ctx)) != MV_OK) return rc;
+		// Whole frames on three view streams.  The ORDER OF THE CALLS is chosen for the two things the host reads from pinned memory
+		// without waiting: the size of frame k - 1's cube-face all-gather (its cull's report: the later the host asks, the surer it is
+		// there) and this frame's tile count (an exact grid for the view march, no overflow launch behind it).  So: this frame's light
+		// march and its exchange first (stream k % 3), then frame k - 1's tail (stream (k - 1) % 3), this frame's view march last.  The
+		// streams are independent, so the order costs the GPU nothing.
+		{ MV_SECTION(5); if ((rc = distLight(ctx, chain)) != MV_OK) return rc; }
+		// ---- frame k - 1's cube-face exchange, on ITS stream behind its view march; then the copy-forward of the faces frame k does not
+		// march, which reads k - 1's set on that same stream, i.e. behind the unpack; then k - 1's composite and row gather ----
+		{ MV_SECTION(2); if ((rc = distTailExchange(ctx)) != MV_OK) return rc; }
+		{ MV_SECTION(3); if ((rc = viewCopyForward(ctx)) != MV_OK) return rc; }
+		{ MV_SECTION(4); if ((rc = distTailComposite(ctx)) != MV_OK) return rc; }
+		{ MV_SECTION(6); if ((rc = viewMarch(ctx)) != MV_OK) return rc; }
 	}
 	else
 	{
+		if ((rc = distLight(ctx, chain)) != MV_OK) return rc;
 		if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
 		// ---- frame k - 1: exchange + composite, on stream X beside this frame's march ----
 		if ((rc = distTail(ctx)) != MV_OK) return rc;
@@ -1857,7 +1946,7 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 		MV_HIP(ctx, hipStreamWaitEvent(d->streamX, ctx->evStageA[ctx->slot], 0));
 		if ((rc = copyForward(ctx, d->streamX)) != MV_OK) return rc;
 	}
-	d->stPending = ctx->st; d->slotPending = ctx->slot; d->chainPending = chain; d->pendingComposite = with_composite != 0; d->pending = true;
+	{ MV_SECTION(7); d->stPending = ctx->st; d->slotPending = ctx->slot; d->chainPending = chain; d->pendingComposite = with_composite != 0; d->pending = true; }
 	return MV_OK;
 }
 

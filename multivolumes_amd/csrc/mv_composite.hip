@@ -158,39 +158,6 @@ void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherM
 	hipLaunchKernelGGL(copyForwardKernel, dim3(st.V * kNumCubeMip * 6u), dim3(256), 0, s, st, otherMaps, otherDepths, otherStamps, tag, marchFollows ? 1 : 0);
 }
 
-// Light map of the volume relit this frame (CSRayMarchL.hlsl:29-33: ONE volume per frame, marched by its owner), for the ranks that
-// do not own it: every rank marches its own screen rows of every volume on the screen-space scheme (RayCast.hlsli:76 reads GetLight),
-// and which volumes are on that scheme changes with the camera, so every rank keeps every light map current.  The map travels as
-// plain R11G11B10F words (4 B per texel) through an all-reduce (integer sum) in which only the owner contributes non-zero words:
-// no rank needs to know the root on the host.
-__global__ __launch_bounds__(256) void lightExchangeKernel(DeviceState st, uint32_t* __restrict__ words, int unpack)
-{
-	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
-	const uint32_t visibleCount = st.counters[0];
-	const uint32_t relit = visibleCount ? st.visibleVolumes[cb->frameIdx % visibleCount] : cb->frameIdx % st.V;
-	const bool owner = relit % st.shardCount == st.shardIndex;
-	const uint32_t L = st.L, total = L * L * L;
-	uint4* quads = st.lightTable[relit];
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
-	{
-		if (!unpack) words[i] = owner ? quads[i].x : 0u;
-		else if (!owner)
-		{
-			const uint32_t x = i % L, y = (i / L) % L;
-			const uint32_t x1 = x + 1 < L ? x + 1 : L - 1, y1 = y + 1 < L ? y + 1 : L - 1;
-			const uint32_t* sl = words + (size_t)(i / (L * L)) * L * L;
-			quads[i] = make_uint4(sl[y * L + x], sl[y * L + x1], sl[y1 * L + x], sl[y1 * L + x1]);
-		}
-	}
-}
-
-void launchLightExchange(hipStream_t s, const DeviceState& st, uint32_t* words, bool unpack)
-{
-	const size_t total = (size_t)st.L * st.L * st.L;
-	const size_t g = (total + 255) / 256;
-	hipLaunchKernelGGL(lightExchangeKernel, dim3((uint32_t)(g < 4096 ? g : 4096)), dim3(256), 0, s, st, words, unpack ? 1 : 0);
-}
-
 // ---------------------------------------------------------------------------------------------
 // a7: K-buffer OIT composite = VSCube.hlsl:51-76 + PSDepthPeel.hlsl:12-24 + PSCube.hlsl:30-60 (CubeCast, PSCube.hlsli:51-108,
 // or the screen-space RayCast, RayCast.hlsli:43-108) + PSResolveOIT.hlsl:12-26.

@@ -275,18 +275,33 @@ void mvh_update_frame(uint32_t V, const float* worlds, const float viewProj[16],
 		memcpy(cb + 52, &frameIdx, 4);
 		memcpy(cbPerFrame, cb, 212);
 	}
+	// The inverse world matrices only change when a volume is moved (SetVolumesWorld / SetVolumeWorld): the last set is kept per calling
+	// thread and reused while the world matrices compare equal (the same arithmetic either way -- a rank of the multi-GPU loop enqueues a
+	// whole frame in ~50 us of host time, of which sixteen 4 x 4 inversions were a tenth).
+	thread_local std::vector<float> cachedWorlds;
+	thread_local std::vector<M4> cachedWorldI;
+	const size_t nw = (size_t)V * 12;
+	if (cachedWorlds.size() != nw || memcmp(cachedWorlds.data(), worlds, nw * sizeof(float)) != 0)
+	{
+		cachedWorlds.assign(worlds, worlds + nw);
+		cachedWorldI.resize(V);
+		for (uint32_t i = 0; i < V; ++i)
+		{
+			memset(&cachedWorldI[i], 0, sizeof(M4));
+			inverse(worldFrom3x4(worlds + 12 * (size_t)i), cachedWorldI[i]);	// singular (unplaced) volumes keep zeros
+		}
+	}
 	for (uint32_t i = 0; i < V; ++i)
 	{
 		float* po = reinterpret_cast<float*>(static_cast<uint8_t*>(perObject) + (size_t)i * 224);
 		const M4 world = worldFrom3x4(worlds + 12 * (size_t)i);
 		const M4 wvp = mul(world, vp);
-		M4 worldI, wvpI;
-		memset(&worldI, 0, sizeof(worldI)); memset(&wvpI, 0, sizeof(wvpI));
-		inverse(world, worldI);	// singular (unplaced) volumes keep zeros
+		M4 wvpI;
+		memset(&wvpI, 0, sizeof(wvpI));
 		inverse(wvp, wvpI);
 		storeT(wvp, po, 4);
 		storeT(wvpI, po + 16, 4);
-		storeT(worldI, po + 32, 3);
+		storeT(cachedWorldI[i], po + 32, 3);
 		storeT(world, po + 44, 3);
 	}
 }

@@ -238,12 +238,25 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	uint32_t* sRect = sInfo + st.V;
 	uint32_t* sCost = sRect + 2u * st.V;	// the deal below: estimated march cost of a cube-map volume, 0 once dealt
 
-	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
-	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	// The frame's constants -- CBPerFrame and PerObject[V], what MultiRayCaster::UpdateFrame writes into its upload-heap slice
+	// (MultiRayCaster.cpp:316-353) -- are read HERE from the pinned slice the host filled (device-visible host memory), and this
+	// kernel writes the device copies every later kernel of the frame reads: there is no upload copy in front of the cull (round 3:
+	// a copy engine launch is ~3 us of host time and ~6 us of latency at the head of every frame).  Every read of the constants in
+	// this kernel, the last wavefront's included, goes to the host slice (uncached, coherent); the device copies are only written.
+	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObjectHost);
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbHost);
 	const float vpW = cb->viewport[0], vpH = cb->viewport[1];
 	const vec3 eyePt = v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]);
 
 	const uint32_t lane = threadIdx.x & 63u;
+	{
+		// device copies: this wavefront's eight PerObjects (8 x 56 words), and CBPerFrame (53 words) by the first one
+		const uint32_t first = blockIdx.x * (kCullThreads / 8), n = first < st.V ? (st.V - first < 8u ? st.V - first : 8u) : 0u;
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(st.perObjectHost) + (size_t)first * (sizeof(PerObject) / 4u);
+		uint32_t* dst = reinterpret_cast<uint32_t*>(st.perObject) + (size_t)first * (sizeof(PerObject) / 4u);
+		for (uint32_t i = lane; i < n * (uint32_t)(sizeof(PerObject) / 4u); i += 64u) dst[i] = src[i];
+		if (blockIdx.x == 0 && lane < (uint32_t)(sizeof(CBPerFrame) / 4u)) reinterpret_cast<uint32_t*>(st.cbPerFrame)[lane] = reinterpret_cast<const uint32_t*>(st.cbHost)[lane];
+	}
 	const uint32_t li = lane & 7u;			// wTid.x: cube vertex / edge-pair / face index
 	const uint32_t baseLane = lane & ~7u;	// 8 * wTid.y
 	const uint32_t l6 = li < 6u ? li : 5u;	// lanes 6-7 shadow lane 5 so that every shuffle is executed wave-wide
@@ -504,7 +517,13 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		}
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxShard, o); maxShard = m > maxShard ? m : maxShard; }
-		if (lane == 0) st.counters[12] = maxShard;
+		if (lane == 0)
+		{
+			st.counters[12] = maxShard;
+			// host-visible {frame tag : texels of the largest shard}: the size of this frame's cube-face all-gather, read by the host a call
+			// later (mv_dist_frame) from pinned memory -- no copy behind the cull, no event
+			if (st.exchangeReport) *st.exchangeReport = ((unsigned long long)st.frameTag << 32) | maxShard;
+		}
 		for (uint32_t v = lane; v < st.V; v += 64) st.volumeFlags[v] = sInfo[v];
 	}
 
@@ -637,8 +656,8 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	// what the tile costs of a frame depend on besides the volumes' contents: CBPerFrame's eye / viewport / screenToWorld and every PerObject
 	uint32_t viewHash = 0u;
 	{
-		const uint32_t* cbWords = reinterpret_cast<const uint32_t*>(st.cbPerFrame);
-		const uint32_t* poWords = reinterpret_cast<const uint32_t*>(st.perObject);
+		const uint32_t* cbWords = reinterpret_cast<const uint32_t*>(st.cbHost);
+		const uint32_t* poWords = reinterpret_cast<const uint32_t*>(st.perObjectHost);
 		const uint32_t nCb = 24u, nPo = st.V * (uint32_t)(sizeof(PerObject) / 4u);
 		if (lane < nCb) viewHash = (cbWords[lane] + 0x9e3779b9u * (lane + 1u)) * 0x85ebca6bu;
 #pragma unroll 4
@@ -811,17 +830,50 @@ __device__ __forceinline__ vec3 EvaluateSHIrradiance(const float* sh, vec3 norm)
 #endif
 // kLightWaves voxel blocks per workgroup: they share the per-axis address tables of the volumes in LDS (LUT, N <= 256; every
 // volume source has the same N and pitches).
+// Which voxel blocks a context marches: all of them -- or, inside the multi-GPU frame loop (kFlagRotateAllLightMaps: every rank keeps
+// every light map), its 1 / shardCount share of the dispatch order, entries [lo, hi).  Every rank holds every volume, so any rank can
+// march any block; the shares are all-gathered as plain R11G11B10F words and unpacked by lightUnpackKernel below.  (Round 2 let the
+// relit volume's owner march the whole map while the other ranks waited for it, and all-reduced it.)
+struct LightShare { uint32_t lo, hi, per; };
+__host__ __device__ inline LightShare lightShare(const DeviceState& st, uint32_t totalBlocks)
+{
+	LightShare r;
+	const bool split = (st.flags & kFlagRotateAllLightMaps) && st.shardCount > 1u;
+	r.per = split ? (totalBlocks + st.shardCount - 1u) / st.shardCount : totalBlocks;
+	r.lo = split ? st.shardIndex * r.per : 0u;
+	r.lo = r.lo < totalBlocks ? r.lo : totalBlocks;
+	r.hi = r.lo + r.per < totalBlocks ? r.lo + r.per : totalBlocks;
+	return r;
+}
+
+// quad-replicated store of one light-map texel (see mv_device.hpp "light maps"): texel (x, y) is slot (sx, sy) of every cell (cx, cy)
+// with min(cx + sx, L-1) == x and min(cy + sy, L-1) == y
+__device__ __forceinline__ void storeLightTexel(uint32_t* quads, uint32_t L, uint32_t xx, uint32_t yy, uint32_t zz, uint32_t packed)
+{
+	const uint32_t cxs[3] = { xx, xx - 1u, xx }, sxs[3] = { 0u, 1u, 1u };
+	const bool vx[3] = { true, xx >= 1u, xx == L - 1u };
+	const uint32_t cys[3] = { yy, yy - 1u, yy };
+	const bool vy[3] = { true, yy >= 1u, yy == L - 1u };
+#pragma unroll
+	for (int b = 0; b < 3; ++b)
+#pragma unroll
+		for (int a = 0; a < 3; ++a)
+			if (vx[a] && vy[b])
+				quads[((((size_t)zz * L + cys[b]) * L + cxs[a]) << 2) + sxs[a] + 2u * sxs[b]] = packed;
+}
+
+// wordsOut: NULL, or where this context's share of the map goes as plain words, 64 per block in dispatch order from entry `lo` on
 template <bool LUT, bool ORDERED>
-__global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st)
+__global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st, uint32_t* __restrict__ wordsOut)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLightLutMaxN + 1) : 1];
 	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 
-	// CSRayMarchL.hlsl:29-33; on a sharded context only the owner of that volume marches
+	// CSRayMarchL.hlsl:29-33; on a sharded context only the owner of that volume marches -- or every rank its share of the blocks
 	uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
 	volumeId = __builtin_amdgcn_readfirstlane(volumeId);
-	if (!ownsVolume(st, volumeId)) return;
+	if (!(st.flags & kFlagRotateAllLightMaps) && !ownsVolume(st, volumeId)) return;
 
 	const u32x4* axisTables = nullptr;
 	if (LUT)
@@ -837,16 +889,18 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 	const uint32_t L = st.L;
 	const uint32_t blocksPerAxis = (L + 3u) >> 2;
 	const uint32_t totalBlocks = blocksPerAxis * blocksPerAxis * blocksPerAxis;
-	uint32_t b = blockIdx.x * kLightWaves + (threadIdx.x >> 6);
+	const LightShare share = lightShare(st, totalBlocks);
+	uint32_t e = share.lo + blockIdx.x * kLightWaves + (threadIdx.x >> 6);	// entry of the dispatch order
 	if (ORDERED)
 	{
-		// workgroup i runs on XCD i % 8: it takes the next kLightWaves blocks of that XCD's eighth of the tube order (lightOrderKernel)
-		const uint32_t perXcd = (totalBlocks + 7u) >> 3, xcd = blockIdx.x & 7u;
-		const uint32_t e = xcd * perXcd + (blockIdx.x >> 3) * kLightWaves + (threadIdx.x >> 6);
-		if (e >= (xcd + 1u) * perXcd || e >= totalBlocks) return;
-		b = st.lightOrder[e];
+		// workgroup i runs on XCD i % 8: it takes the next kLightWaves blocks of that XCD's eighth of (this context's share of) the tube order (lightOrderKernel)
+		const uint32_t perXcd = (share.hi - share.lo + 7u) >> 3, xcd = blockIdx.x & 7u;
+		const uint32_t k = xcd * perXcd + (blockIdx.x >> 3) * kLightWaves + (threadIdx.x >> 6);
+		if (k >= (xcd + 1u) * perXcd) return;
+		e = share.lo + k;
 	}
-	if (b >= totalBlocks) return;
+	if (e >= share.hi) return;
+	const uint32_t b = ORDERED ? st.lightOrder[e] : e;
 	const uint32_t bx = b % blocksPerAxis, by = (b / blocksPerAxis) % blocksPerAxis, bz = b / (blocksPerAxis * blocksPerAxis);
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t xx = bx * 4 + (lane & 3u), yy = by * 4 + ((lane >> 2) & 3u), zz = bz * 4 + (lane >> 4);
@@ -900,7 +954,7 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 		}
 	}
 
-	uint32_t nS = 0;
+	uint32_t nS = 0, packed = 0u;
 	if (inRange)
 	{
 		const float gridSize = (float)L;
@@ -985,21 +1039,10 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 		if (st.hasLightProbe) ambient = v3(ao * irradiance.x, ao * irradiance.y, ao * irradiance.z);
 
 		const vec3 result = v3(shadow * lightColor.x + ambient.x, shadow * lightColor.y + ambient.y, shadow * lightColor.z + ambient.z);
-		// quad-replicated store (see mv_device.hpp "light maps"): texel (x, y) is slot (sx, sy) of every cell (cx, cy)
-		// with min(cx + sx, L-1) == x and min(cy + sy, L-1) == y
-		const uint32_t packed = pack_r11g11b10f(result.x, result.y, result.z);
-		uint32_t* quads = reinterpret_cast<uint32_t*>(st.lightTable[volumeId]);
-		const uint32_t cxs[3] = { xx, xx - 1u, xx }, sxs[3] = { 0u, 1u, 1u };
-		const bool vx[3] = { true, xx >= 1u, xx == L - 1u };
-		const uint32_t cys[3] = { yy, yy - 1u, yy };
-		const bool vy[3] = { true, yy >= 1u, yy == L - 1u };
-#pragma unroll
-		for (int b = 0; b < 3; ++b)
-#pragma unroll
-			for (int a = 0; a < 3; ++a)
-				if (vx[a] && vy[b])
-					quads[((((size_t)zz * L + cys[b]) * L + cxs[a]) << 2) + sxs[a] + 2u * sxs[b]] = packed;
+		packed = pack_r11g11b10f(result.x, result.y, result.z);
+		storeLightTexel(reinterpret_cast<uint32_t*>(st.lightTable[volumeId]), L, xx, yy, zz, packed);
 	}
+	if (wordsOut) wordsOut[(size_t)(e - share.lo) * 64u + lane] = packed;
 
 	const uint32_t tot = waveSumU32(nS);
 	// this voxel block's own slot; an atomic because light marches of consecutive frames may run side by side
@@ -1301,6 +1344,31 @@ __device__ __forceinline__ void lightOrderRole(const DeviceState& st, uint32_t* 
 	}
 	__syncthreads();
 	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) st.lightOrder[atomicAdd(&sCursor[tubeOf(b)], 1u)] = b;
+	// Inside a tube the atomics above leave the blocks in arrival order.  The order must be the same on every rank of the multi-GPU loop
+	// (ranks march disjoint ranges of it) and in every frame slot, so every tube is put into a defined order: along the light's dominant
+	// axis, then by block index (a tube holds at most B blocks, one per step along that axis; an insertion sort in place).
+	__threadfence_block();
+	__syncthreads();
+	for (uint32_t i = threadIdx.x; i < tubes; i += kLightOrderThreads)
+	{
+		const uint32_t begin = i ? sCursor[i - 1u] : 0u, end = sCursor[i];
+		for (uint32_t j = begin + 1u; j < end; ++j)
+		{
+			const uint32_t b = st.lightOrder[j];
+			const uint32_t cb[3] = { b % B, (b / B) % B, b / (B * B) };
+			const uint32_t key = (cb[a] << 20) | b;
+			uint32_t k = j;
+			while (k > begin)
+			{
+				const uint32_t o = st.lightOrder[k - 1u];
+				const uint32_t co[3] = { o % B, (o / B) % B, o / (B * B) };
+				if (((co[a] << 20) | o) <= key) break;
+				st.lightOrder[k] = o;
+				--k;
+			}
+			st.lightOrder[k] = b;
+		}
+	}
 }
 
 // The two orders a frame needs -- the dispatch order of the view march's tiles and (when the light direction has changed) of the light
@@ -1325,26 +1393,57 @@ void launchOrders(hipStream_t s, const DeviceState& st)
 	hipLaunchKernelGGL(ordersKernel, dim3(tileGroups + (light ? 1u : 0u)), dim3(kLightOrderThreads), tileLds > lightLds ? tileLds : lightLds, s, st, tileGroups);
 }
 
+// The other ranks' shares of the relit light map, all-gathered as plain words (64 per voxel block, dispatch order, `per` blocks per
+// rank), into this rank's copy of the map: one wavefront per block, the same store as the march's.
+__global__ __launch_bounds__(256) void lightUnpackKernel(DeviceState st, const uint32_t* __restrict__ words, int ordered)
+{
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	const uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
+	const uint32_t L = st.L, B = (L + 3u) >> 2, total = B * B * B;
+	const LightShare share = lightShare(st, total);
+	const uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+	if (e >= total || (e >= share.lo && e < share.hi)) return;	// (its own share is in place already)
+	const uint32_t b = ordered ? st.lightOrder[e] : e;
+	const uint32_t xx = (b % B) * 4u + (lane & 3u), yy = ((b / B) % B) * 4u + ((lane >> 2) & 3u), zz = (b / (B * B)) * 4u + (lane >> 4);
+	if (xx < L && yy < L && zz < L) storeLightTexel(reinterpret_cast<uint32_t*>(st.lightTable[volumeId]), L, xx, yy, zz, words[(size_t)e * 64u + lane]);
+}
+
 #ifndef MV_LIGHT_ORDER
 #define MV_LIGHT_ORDER 1	// XCD-aware tube order of the light march's voxel blocks (lightOrderKernel); 0 = x-y-z order (A/B timing)
 #endif
 #ifndef MV_LIGHT_LUT
 #define MV_LIGHT_LUT 1	// per-axis address tables in LDS for the light march (N <= 256); 0 = compute every tap's offsets (A/B timing)
 #endif
-void launchMarchLight(hipStream_t s, const DeviceState& st)
+static bool lightOrdered(const DeviceState& st) { return MV_LIGHT_ORDER && st.lightOrder && ((st.L + 3u) >> 2) <= kLightOrderMaxB; }
+
+uint32_t lightSharePerRank(const DeviceState& st)
+{
+	const uint32_t b = (st.L + 3u) >> 2;
+	return lightShare(st, b * b * b).per;
+}
+
+void launchMarchLight(hipStream_t s, const DeviceState& st, uint32_t* wordsOut)
 {
 	const uint32_t b = (st.L + 3u) >> 2, total = b * b * b;
-	if (MV_LIGHT_ORDER && st.lightOrder && b <= kLightOrderMaxB)
+	const LightShare share = lightShare(st, total);
+	const uint32_t count = share.per;	// (the same grid on every rank; the last rank's share may be shorter)
+	if (lightOrdered(st))
 	{
-		const uint32_t perXcd = (total + 7u) >> 3;
+		const uint32_t perXcd = (count + 7u) >> 3;
 		const uint32_t groups = 8u * ((perXcd + kLightWaves - 1u) / kLightWaves);
-		if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
-		else hipLaunchKernelGGL((marchLightKernel<false, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
+		if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+		else hipLaunchKernelGGL((marchLightKernel<false, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
 		return;
 	}
-	const uint32_t groups = (total + kLightWaves - 1u) / kLightWaves;
-	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
-	else hipLaunchKernelGGL((marchLightKernel<false, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st);
+	const uint32_t groups = (count + kLightWaves - 1u) / kLightWaves;
+	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+	else hipLaunchKernelGGL((marchLightKernel<false, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+}
+
+void launchLightUnpack(hipStream_t s, const DeviceState& st, const uint32_t* words)
+{
+	const uint32_t b = (st.L + 3u) >> 2, total = b * b * b;
+	hipLaunchKernelGGL(lightUnpackKernel, dim3((total + 3u) / 4u), dim3(256), 0, s, st, words, lightOrdered(st) ? 1 : 0);
 }
 
 } // namespace mv

@@ -72,8 +72,10 @@ struct DeviceState
 	uint32_t hasLightProbe;
 
 	// per-frame constants (device copies of the reference's upload-heap slices)
-	const void* cbPerFrame;			// CBPerFrame, 212 B
-	const void* perObject;			// PerObject[V]
+	void* cbPerFrame;				// CBPerFrame, 212 B: device copy, written by the cull from cbHost
+	void* perObject;				// PerObject[V]: device copy, written by the cull from perObjectHost
+	const void* cbHost;				// this frame's pinned upload slice (device-visible host memory; the reference's upload-heap slice,
+	const void* perObjectHost;		//   MultiRayCaster.cpp:128-130, 461-467): only the cull reads it
 	const uint32_t* volumeDescs;	// VolumeDesc[V]
 	const float* sh;				// 27 floats
 
@@ -109,6 +111,7 @@ struct DeviceState
 	uint32_t* cubeMapVolumes;		// V
 	unsigned long long* tilesReport;	// pinned host memory (may be NULL): the cull stores {frameTag : tile count} here -- a HINT for the host's
 									// next grid sizes, read without ever waiting for it
+	unsigned long long* exchangeReport;	// pinned host memory (NULL outside the multi-GPU frame loop): {frameTag : texels of the largest shard of this frame's cube-face exchange}
 	uint32_t frameTag;				// low 32 bits of the context's frame counter
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
 									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow),
@@ -260,7 +263,9 @@ void launchLightToQuads(hipStream_t s, const uint32_t* linear, uint4* quads, uin
 void launchLightFromQuads(hipStream_t s, const uint4* quads, uint32_t* linear, uint32_t L);
 void launchCull(hipStream_t s, const DeviceState& st);
 void launchOrders(hipStream_t s, const DeviceState& st);	// behind the cull, one launch: the cost-binned dispatch order of the view march's tiles + the XCD-aware order of the light march's voxel blocks
-void launchMarchLight(hipStream_t s, const DeviceState& st);
+void launchMarchLight(hipStream_t s, const DeviceState& st, uint32_t* wordsOut = nullptr);	// wordsOut: this context's share of the relit map as plain words (multi-GPU frame loop), or NULL
+uint32_t lightSharePerRank(const DeviceState& st);	// voxel blocks per rank of the light march's share-out (all of them outside the multi-GPU frame loop)
+void launchLightUnpack(hipStream_t s, const DeviceState& st, const uint32_t* words);	// the all-gathered shares (64 words per block, lightSharePerRank blocks per rank) into the relit volume's light map
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// returns the first slot its grid does not cover (0xffffffff: none)
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
 uint32_t marchTilesResidentWaves(int device);
@@ -273,6 +278,5 @@ void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32
 void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, void* dst);
 void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim, const void* src);
 void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes);	// marched faces only (mv_dist_frame)
-void launchLightExchange(hipStream_t s, const DeviceState& st, uint32_t* words, bool unpack);
 void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag, bool marchFollows = true);
 } // namespace mv
