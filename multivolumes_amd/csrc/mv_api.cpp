@@ -193,6 +193,14 @@ struct mv_ctx
 	uint64_t nStage[4] = { 0, 0, 0, 0 };
 	std::string lastError;
 	DistState* dist = nullptr;
+	// Cross-stream ordering goes through evRecord / evWait below, which leave out the waits that are redundant: an event recorded on the
+	// very stream that is asked to wait for it (stream order already says so), and a wait the stream has already made for the same
+	// record.  With whole frames on three view streams frame k - 3 sits on frame k's stream, so half of a frame's waits are of the
+	// first kind (a stream wait is ~1 us of host time on a pending event; a rank of the multi-GPU loop issued sixteen per frame).
+	struct EvTrack { hipEvent_t e = nullptr; hipStream_t on = nullptr; uint64_t seq = 0; uint64_t waited[8] = {}; };
+	EvTrack evTrack[24];
+	hipStream_t evStreams[8] = {};
+	uint64_t evSeq = 0;
 	double hostWaitMs = 0.0;			// time mv_update_frame spent waiting for the GPU to free a frame slot (mv_host_wait_ms)
 };
 
@@ -321,26 +329,61 @@ int syncAll(mv_ctx* ctx)
 	return (int)hipStreamSynchronize(ctx->stream);
 }
 
+mv_ctx::EvTrack* evFind(mv_ctx* ctx, hipEvent_t e)
+{
+	for (auto& t : ctx->evTrack) { if (t.e == e) return &t; if (!t.e) { t.e = e; return &t; } }
+	return nullptr;	// (more events than slots: untracked, every wait is issued)
+}
+int evStreamIndex(mv_ctx* ctx, hipStream_t s)
+{
+	for (int i = 0; i < 8; ++i) { if (ctx->evStreams[i] == s) return i; if (!ctx->evStreams[i]) { ctx->evStreams[i] = s; return i; } }
+	return -1;
+}
+void evForget(mv_ctx* ctx)	// streams were destroyed or created: nothing recorded so far may be relied on by address
+{
+	for (auto& t : ctx->evTrack) { t.on = nullptr; for (auto& w : t.waited) w = 0; }
+	for (auto& x : ctx->evStreams) x = nullptr;
+}
+hipError_t evRecord(mv_ctx* ctx, hipEvent_t e, hipStream_t s)
+{
+	const hipError_t r = hipEventRecord(e, s);
+	if (mv_ctx::EvTrack* t = evFind(ctx, e)) { t->on = r == hipSuccess ? s : nullptr; t->seq = ++ctx->evSeq; }
+	return r;
+}
+hipError_t evWait(mv_ctx* ctx, hipStream_t s, hipEvent_t e)
+{
+	mv_ctx::EvTrack* t = evFind(ctx, e);
+	const int si = evStreamIndex(ctx, s);
+	if (t && si >= 0)
+	{
+		if (t->seq == 0) return hipSuccess;				// never recorded: nothing to wait for
+		if (t->on == s) return hipSuccess;				// recorded on this stream: stream order
+		if (t->waited[si] == t->seq) return hipSuccess;	// this stream has already waited for this record
+		t->waited[si] = t->seq;
+	}
+	return hipStreamWaitEvent(s, e, 0);
+}
+
 // stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
 // (every one of these orders streams against each other: a failure must reach the caller, or a later stage reads unfinished data)
-hipError_t stageADone(mv_ctx* ctx, bool last = true) { return ctx->leanEvents && !last ? hipSuccess : hipEventRecord(ctx->evStageA[ctx->slot], ctx->streamA); }
+hipError_t stageADone(mv_ctx* ctx, bool last = true) { return ctx->leanEvents && !last ? hipSuccess : evRecord(ctx, ctx->evStageA[ctx->slot], ctx->streamA); }
 hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->frame % ctx->numViewStreams]; }
 hipError_t stageBBegin(mv_ctx* ctx)
 {
-	const hipError_t e = hipStreamWaitEvent(streamB(ctx), ctx->evStageA[ctx->slot], 0);
+	const hipError_t e = evWait(ctx, streamB(ctx), ctx->evStageA[ctx->slot]);
 	if (e != hipSuccess) return e;
 	// this frame's light march, if one has been enqueued (and, when light marches run on their frames' view streams, those of the
 	// frames before it on the OTHER view streams: a view march reads every visible volume's light map)
 	const uint32_t others = ctx->lightOnViewStream ? ctx->numViewStreams - 1u : 0u;
 	for (uint32_t j = 0; j <= others; ++j)
 	{
-		const hipError_t e2 = hipStreamWaitEvent(streamB(ctx), ctx->evLight[(ctx->slot + kFrameSlots - j) % kFrameSlots], 0);
+		const hipError_t e2 = evWait(ctx, streamB(ctx), ctx->evLight[(ctx->slot + kFrameSlots - j) % kFrameSlots]);
 		if (e2 != hipSuccess) return e2;
 	}
 	return hipSuccess;
 }
 // stage of stream B finished being enqueued: the next user of this slot's buffers (kFrameSlots frames on) and the light march two frames on wait for it
-hipError_t stageBDone(mv_ctx* ctx) { return hipEventRecord(ctx->evMainDone[ctx->slot], streamB(ctx)); }
+hipError_t stageBDone(mv_ctx* ctx) { return evRecord(ctx, ctx->evMainDone[ctx->slot], streamB(ctx)); }
 
 void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
 {
@@ -677,6 +720,7 @@ static void distRelease(mv_ctx* ctx)
 	if (!d) return;
 	for (uint32_t i = 0; i < kDistChains; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
 	if (d->streamX) (void)hipStreamDestroy(d->streamX);
+	evForget(ctx);
 	if (d->reports) (void)hipHostFree(d->reports);
 	for (void* p : d->allocs) (void)hipFree(p);
 	delete d;
@@ -741,7 +785,7 @@ int mv_volume_upload_rgba16f_device(mv_ctx* ctx, uint32_t src, const void* d_rgb
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, hipEventRecord(ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
+	MV_HIP(ctx, evRecord(ctx, ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
 	ctx->producersDirty = true;
 	return MV_OK;
 }
@@ -755,7 +799,7 @@ int mv_volume_init_procedural(mv_ctx* ctx, uint32_t src)
 	mv::launchBuildAlphaCells(ctx->stream, ctx->volumes[src], ctx->cells[src], ctx->st.N, ctx->st.bricks);
 	mv::launchBuildOccupancy(ctx->stream, ctx->volumes[src], ctx->occupancy[src], ctx->st.N, ctx->st.bricks);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, hipEventRecord(ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
+	MV_HIP(ctx, evRecord(ctx, ctx->evProducers, ctx->stream));	// stream A must not read this volume before it is complete
 	ctx->producersDirty = true;
 	return MV_OK;
 }
@@ -938,9 +982,9 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);
 	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
-	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evMainDone[ctx->slot], 0));
-	MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evLight[ctx->slot], 0));
-	if (ctx->producersDirty) { MV_HIP(ctx, hipStreamWaitEvent(ctx->streamA, ctx->evProducers, 0)); ctx->producersDirty = false; }
+	MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evMainDone[ctx->slot]));
+	MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evLight[ctx->slot]));
+	if (ctx->producersDirty) { MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evProducers)); ctx->producersDirty = false; }
 	// The constants go into this slot's pinned slice, where the frame's cull reads them (no upload copy: the cull writes the device
 	// copies the other kernels read).  The slice's previous user is the frame kFrameSlots back: its cull must have run -- in steady
 	// state it has, long ago; a host that runs more than three frames ahead of the GPU waits here, as the reference's does on its fence.
@@ -994,14 +1038,14 @@ static int marchLight(mv_ctx* ctx, uint32_t* wordsOut)
 	// light marches serialises them at the share of the GPU one kernel gets beside two view marches, which made them the chain
 	// every frame waited for: 0.349 -> 0.331 ms per frame at C3 with two output sets, 0.311 ms with three.)
 	hipStream_t L = ctx->lightOnViewStream ? streamB(ctx) : ctx->streamL;
-	MV_HIP(ctx, hipStreamWaitEvent(L, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));
-	MV_HIP(ctx, hipStreamWaitEvent(L, ctx->evStageA[ctx->slot], 0));	// this frame's upload + cull
+	MV_HIP(ctx, evWait(ctx, L, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots]));
+	MV_HIP(ctx, evWait(ctx, L, ctx->evStageA[ctx->slot]));	// this frame's upload + cull
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 1, ev, L);
 	mv::launchMarchLight(L, ctx->st, wordsOut);
 	endStage(ctx, ev, L);
 	MV_HIP(ctx, hipGetLastError());
-	if (!(ctx->leanEvents && ctx->st.shardCount > 1u)) MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], L));	// (lean: the light-map exchange follows on this stream and records it)
+	if (!(ctx->leanEvents && ctx->st.shardCount > 1u)) MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], L));	// (lean: the light-map exchange follows on this stream and records it)
 	ctx->lightMarched = true;
 	return MV_OK;
 }
@@ -1015,7 +1059,7 @@ static int copyForward(mv_ctx* ctx, hipStream_t s)
 	const OutBufs& other = ctx->ob[(ctx->set + ctx->numOutSets - 1u) % ctx->numOutSets];
 	mv::launchCopyForward(s, ctx->st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)ctx->frame, true);
 	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, hipEventRecord(ctx->evCopy[ctx->slot], s));
+	MV_HIP(ctx, evRecord(ctx, ctx->evCopy[ctx->slot], s));
 	ctx->copiedForward = true;
 	return MV_OK;
 }
@@ -1035,7 +1079,7 @@ static int copyForwardFromAllSets(mv_ctx* ctx, bool marchFollows)
 		mv::launchCopyForward(s, ctx->st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)ctx->frame, marchFollows);
 		MV_HIP(ctx, hipGetLastError());
 	}
-	MV_HIP(ctx, hipEventRecord(ctx->evCopy[ctx->slot], s));
+	MV_HIP(ctx, evRecord(ctx, ctx->evCopy[ctx->slot], s));
 	ctx->copiedForward = true;
 	return MV_OK;
 }
@@ -1065,10 +1109,10 @@ static int viewCopyForward(mv_ctx* ctx)
 		// each other: measured).  It writes this frame's set, so the set's last reader (the composite of frame k - n) must be
 		// over, and it reads what the previous frame's copy wrote (a face nobody has marched for two frames travels set to set).
 		hipStream_t s = ctx->streamB[(ctx->frame + ctx->numViewStreams - 1u) % ctx->numViewStreams];
-		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evMainDone[(ctx->slot + kFrameSlots - n) % kFrameSlots], 0));
-		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evCopy[prevSlot], 0));
-		if (ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evCopy[ctx->slot], 0));
-		MV_HIP(ctx, hipStreamWaitEvent(s, ctx->evStageA[ctx->slot], 0));	// this frame's cull
+		MV_HIP(ctx, evWait(ctx, s, ctx->evMainDone[(ctx->slot + kFrameSlots - n) % kFrameSlots]));
+		MV_HIP(ctx, evWait(ctx, s, ctx->evCopy[prevSlot]));
+		if (ctx->copiedForward) MV_HIP(ctx, evWait(ctx, s, ctx->evCopy[ctx->slot]));
+		MV_HIP(ctx, evWait(ctx, s, ctx->evStageA[ctx->slot]));	// this frame's cull
 		const int rc = copyForward(ctx, s);
 		if (rc != MV_OK) return rc;
 	}
@@ -1083,9 +1127,9 @@ static int viewMarch(mv_ctx* ctx)
 	ctx->marchedThisFrame = true;
 	MV_HIP(ctx, stageBBegin(ctx));
 	// the set this march writes was read by the copy-forward of frame k - n + 1 (as the set before its own) ...
-	if (n >= 2u) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[(ctx->slot + kFrameSlots - (n - 1u)) % kFrameSlots], 0));
+	if (n >= 2u) MV_HIP(ctx, evWait(ctx, streamB(ctx), ctx->evCopy[(ctx->slot + kFrameSlots - (n - 1u)) % kFrameSlots]));
 	// ... and by the composite of frame k - n, its previous user (with SINGLE_VIEW_STREAM / one stream that is on this stream anyway)
-	MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (n % kFrameSlots)) % kFrameSlots], 0));
+	MV_HIP(ctx, evWait(ctx, streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (n % kFrameSlots)) % kFrameSlots]));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 2, ev, streamB(ctx));
 	// Nothing between the cull and the march waits for the host (the shape of the work-graph variant, Sh/LibRayMarch.hlsl:39-134).
@@ -1152,7 +1196,7 @@ int mv_composite_over(mv_ctx* ctx, uint32_t row0, uint32_t row1, const void* d_b
 		if (rc != MV_OK) return rc;
 		ctx->lastCompleteFrame = ctx->frame;
 	}
-	if (ctx->numOutSets >= 2u && ctx->copiedForward) MV_HIP(ctx, hipStreamWaitEvent(streamB(ctx), ctx->evCopy[ctx->slot], 0));
+	if (ctx->numOutSets >= 2u && ctx->copiedForward) MV_HIP(ctx, evWait(ctx, streamB(ctx), ctx->evCopy[ctx->slot]));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 3, ev, streamB(ctx));
 	if (ctx->marchedThisFrame) mv::launchComposite(streamB(ctx), ctx->st, row0, row1, d_background);
@@ -1221,8 +1265,8 @@ static int currentLightBuffer(mv_ctx* ctx, uint32_t volume, uint4** out)
 		// this frame's table came back with mv_readback_cull: no host synchronisation, the context's stream waits for the
 		// frame's light march instead (work the caller orders on that stream then sees the relit map)
 		*out = reinterpret_cast<uint4* const*>(ctx->pinnedCull + 64 + (size_t)ctx->st.V * 16)[volume];
-		MV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evStageA[ctx->slot], 0));
-		MV_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->evLight[ctx->slot], 0));
+		MV_HIP(ctx, evWait(ctx, ctx->stream, ctx->evStageA[ctx->slot]));
+		MV_HIP(ctx, evWait(ctx, ctx->stream, ctx->evLight[ctx->slot]));
 		return MV_OK;
 	}
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
@@ -1632,6 +1676,7 @@ static int distCommonInitBody(mv_ctx* ctx)
 		"mv_dist_* needs a context created with MV_FLAG_PIPELINE_FRAMES (whole frames on three view streams), optionally | MV_FLAG_SINGLE_VIEW_STREAM (two output sets, cull and light march ahead)");
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	if (!d->chains) MV_HIP(ctx, hipStreamCreateWithFlags(&d->streamX, hipStreamNonBlocking));
+	evForget(ctx);
 	const uint32_t world = st.shardCount;
 	// One rank's shard of a frame's cube-face all-gather: the marched faces of the volumes the cull dealt to it.  The deal balances
 	// estimated march cost, not texels -- a rank may be handed every cheap (low SmpCount) volume of a frame -- so the buffers hold the
@@ -1792,7 +1837,7 @@ static int distTailExchange(mv_ctx* ctx)
 	const uint32_t chain = d->chains ? d->chainPending : 0u;
 
 	hipStream_t X = distTailStream(ctx, chain);
-	if (!d->chains) MV_HIP(ctx, hipStreamWaitEvent(X, ctx->evMainDone[slot], 0));	// the frame's view march (chains: the same stream)
+	if (!d->chains) MV_HIP(ctx, evWait(ctx, X, ctx->evMainDone[slot]));	// the frame's view march (chains: the same stream)
 	if (world > 1)
 	{
 		// The frame's cull left {frame tag : texels of the largest shard of its deal} in pinned memory at least one mv_dist_frame ago: a
@@ -1831,7 +1876,7 @@ static int distTailComposite(mv_ctx* ctx)
 	if (d->pendingComposite)
 	{
 		// chains: the copy-forward of this frame's unmarched faces ran on the stream of the frame before it
-		if (d->chains) MV_HIP(ctx, hipStreamWaitEvent(X, ctx->evCopy[slot], 0));
+		if (d->chains) MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[slot]));
 		mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
 		MV_HIP(ctx, hipGetLastError());
 		if (world > 1)
@@ -1856,7 +1901,7 @@ static int distTailComposite(mv_ctx* ctx)
 		}
 	}
 	// everything that reads this frame's buffers has been enqueued: the next users of its slot / output set / light buffers wait for this
-	MV_HIP(ctx, hipEventRecord(ctx->evMainDone[slot], X));
+	MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[slot], X));
 	d->pending = false;
 	return MV_OK;
 }
@@ -1885,13 +1930,13 @@ static int distLight(mv_ctx* ctx, uint32_t chain)
 		// on that stream too).  Single view stream: not behind the light march on stream L, where it would hold up the NEXT frame's
 		// light march.
 		hipStream_t E = d->chains ? streamB(ctx) : ctx->stream;
-		if (!d->chains) MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evLight[ctx->slot], 0));	// this rank's light march (chains: the same stream)
-		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evStageA[ctx->slot], 0));	// this frame's cull: the relit volume, its rotated buffer
-		MV_HIP(ctx, hipStreamWaitEvent(E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots], 0));	// frame k - 3, the last reader of the buffer the unpack overwrites
+		if (!d->chains) MV_HIP(ctx, evWait(ctx, E, ctx->evLight[ctx->slot]));	// this rank's light march (chains: the same stream)
+		MV_HIP(ctx, evWait(ctx, E, ctx->evStageA[ctx->slot]));	// this frame's cull: the relit volume, its rotated buffer
+		MV_HIP(ctx, evWait(ctx, E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots]));	// frame k - 3, the last reader of the buffer the unpack overwrites
 		if ((rc = distAllGather(ctx, lightMine, lightAll, d->lightShareBytes, E, d->chains ? (int)chain : 1)) != MV_OK) return rc;
 		mv::launchLightUnpack(E, ctx->st, d->lightWords[chain]);
 		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, hipEventRecord(ctx->evLight[ctx->slot], E));	// "this frame's light map is current on this rank": the next user of the slot waits for it
+		MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], E));	// "this frame's light map is current on this rank": the next user of the slot waits for it
 		d->bytes += d->lightShareBytes * world;
 	}
 	return MV_OK;
@@ -1929,11 +1974,13 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 		// march and its exchange first (stream k % 3), then frame k - 1's tail (stream (k - 1) % 3), this frame's view march last.  The
 		// streams are independent, so the order costs the GPU nothing.
 		{ MV_SECTION(5); if ((rc = distLight(ctx, chain)) != MV_OK) return rc; }
-		// ---- frame k - 1's cube-face exchange, on ITS stream behind its view march; then the copy-forward of the faces frame k does not
-		// march, which reads k - 1's set on that same stream, i.e. behind the unpack; then k - 1's composite and row gather ----
+		// ---- frame k - 1's cube-face exchange, on ITS stream behind its view march; then k - 1's composite and row gather; then the
+		// copy-forward of the faces frame k does not march, which reads k - 1's set on that same stream, i.e. behind the unpack ----
 		{ MV_SECTION(2); if ((rc = distTailExchange(ctx)) != MV_OK) return rc; }
-		{ MV_SECTION(3); if ((rc = viewCopyForward(ctx)) != MV_OK) return rc; }
 		{ MV_SECTION(4); if ((rc = distTailComposite(ctx)) != MV_OK) return rc; }
+		// (the copy-forward behind the composite: the composite has already made this stream wait for frame k - 1's copy, which this
+		// one builds on, and nothing needs frame k's copy before frame k's own composite, a call from now)
+		{ MV_SECTION(3); if ((rc = viewCopyForward(ctx)) != MV_OK) return rc; }
 		{ MV_SECTION(6); if ((rc = viewMarch(ctx)) != MV_OK) return rc; }
 	}
 	else
@@ -1943,7 +1990,7 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 		// ---- frame k - 1: exchange + composite, on stream X beside this frame's march ----
 		if ((rc = distTail(ctx)) != MV_OK) return rc;
 		// ---- frame k's unmarched cube faces <- frame k - 1's set, now complete on this rank (stream X is in order); frame k + 1's march waits for it ----
-		MV_HIP(ctx, hipStreamWaitEvent(d->streamX, ctx->evStageA[ctx->slot], 0));
+		MV_HIP(ctx, evWait(ctx, d->streamX, ctx->evStageA[ctx->slot]));
 		if ((rc = copyForward(ctx, d->streamX)) != MV_OK) return rc;
 	}
 	{ MV_SECTION(7); d->stPending = ctx->st; d->slotPending = ctx->slot; d->chainPending = chain; d->pendingComposite = with_composite != 0; d->pending = true; }

@@ -239,24 +239,47 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	uint32_t* sCost = sRect + 2u * st.V;	// the deal below: estimated march cost of a cube-map volume, 0 once dealt
 
 	// The frame's constants -- CBPerFrame and PerObject[V], what MultiRayCaster::UpdateFrame writes into its upload-heap slice
-	// (MultiRayCaster.cpp:316-353) -- are read HERE from the pinned slice the host filled (device-visible host memory), and this
-	// kernel writes the device copies every later kernel of the frame reads: there is no upload copy in front of the cull (round 3:
-	// a copy engine launch is ~3 us of host time and ~6 us of latency at the head of every frame).  Every read of the constants in
-	// this kernel, the last wavefront's included, goes to the host slice (uncached, coherent); the device copies are only written.
-	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObjectHost);
-	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbHost);
+	// (MultiRayCaster.cpp:316-353) -- are fetched HERE from the pinned slice the host filled (device-visible host memory): every
+	// wavefront copies CBPerFrame and its own eight PerObjects into LDS with one batch of loads (one trip over PCIe), computes from the
+	// LDS copy, and writes the device copies every later kernel of the frame reads.  There is no upload copy in front of the cull
+	// (round 3: a copy-engine launch was ~3 us of host time and ~6 us of latency at the head of every frame).
+	__shared__ uint32_t sConst[8u * (sizeof(PerObject) / 4u) + 56u];
+	const uint32_t lane = threadIdx.x & 63u;
+	constexpr uint32_t kPoWords = sizeof(PerObject) / 4u, kCbWords = sizeof(CBPerFrame) / 4u;
+	const uint32_t firstVolume = blockIdx.x * (kCullThreads / 8);
+	uint32_t partialHash = 0u;
+	{
+		const uint32_t n = firstVolume < st.V ? (st.V - firstVolume < 8u ? st.V - firstVolume : 8u) : 0u;
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(st.perObjectHost) + (size_t)firstVolume * kPoWords;
+		uint32_t* dst = reinterpret_cast<uint32_t*>(st.perObject) + (size_t)firstVolume * kPoWords;
+		uint32_t w[7];
+#pragma unroll
+		for (uint32_t k = 0; k < 7u; ++k) { const uint32_t i = lane + 64u * k; w[k] = i < n * kPoWords ? src[i] : 0u; }
+		const uint32_t c = lane < kCbWords ? reinterpret_cast<const uint32_t*>(st.cbHost)[lane] : 0u;
+#pragma unroll
+		for (uint32_t k = 0; k < 7u; ++k)
+		{
+			const uint32_t i = lane + 64u * k;
+			sConst[i] = w[k];
+			if (i < n * kPoWords)
+			{
+				dst[i] = w[k];
+				// this wavefront's share of the hash of the frame's transforms (see below): word j of PerObject[V] contributes (w + g (j + 25)) m
+				partialHash ^= (w[k] + 0x9e3779b9u * ((uint32_t)firstVolume * kPoWords + i + 25u)) * 0x85ebca6bu;
+			}
+		}
+		if (lane < 56u) sConst[8u * kPoWords + lane] = c;
+		if (blockIdx.x == 0 && lane < kCbWords) reinterpret_cast<uint32_t*>(st.cbPerFrame)[lane] = c;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) partialHash ^= __shfl_xor(partialHash, o);
+		if (lane == 0 && partialHash) atomicXor(&st.counters[13], partialHash);	// (before this wavefront's ticket; the last one reads the total)
+	}
+	__syncthreads();
+	const PerObject* perObjects = reinterpret_cast<const PerObject*>(sConst) - firstVolume;	// indexed by volume, valid for this wavefront's eight
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(sConst + 8u * kPoWords);
 	const float vpW = cb->viewport[0], vpH = cb->viewport[1];
 	const vec3 eyePt = v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]);
 
-	const uint32_t lane = threadIdx.x & 63u;
-	{
-		// device copies: this wavefront's eight PerObjects (8 x 56 words), and CBPerFrame (53 words) by the first one
-		const uint32_t first = blockIdx.x * (kCullThreads / 8), n = first < st.V ? (st.V - first < 8u ? st.V - first : 8u) : 0u;
-		const uint32_t* src = reinterpret_cast<const uint32_t*>(st.perObjectHost) + (size_t)first * (sizeof(PerObject) / 4u);
-		uint32_t* dst = reinterpret_cast<uint32_t*>(st.perObject) + (size_t)first * (sizeof(PerObject) / 4u);
-		for (uint32_t i = lane; i < n * (uint32_t)(sizeof(PerObject) / 4u); i += 64u) dst[i] = src[i];
-		if (blockIdx.x == 0 && lane < (uint32_t)(sizeof(CBPerFrame) / 4u)) reinterpret_cast<uint32_t*>(st.cbPerFrame)[lane] = reinterpret_cast<const uint32_t*>(st.cbHost)[lane];
-	}
 	const uint32_t li = lane & 7u;			// wTid.x: cube vertex / edge-pair / face index
 	const uint32_t baseLane = lane & ~7u;	// 8 * wTid.y
 	const uint32_t l6 = li < 6u ? li : 5u;	// lanes 6-7 shadow lane 5 so that every shuffle is executed wave-wide
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	{
 		const uint32_t volumeId = blockIdx.x * (kCullThreads / 8) + (threadIdx.x >> 3);
 		const bool valid = volumeId < st.V;
-		const PerObject& po = perObjects[valid ? volumeId : 0u];
+		const PerObject& po = perObjects[valid ? volumeId : firstVolume];
 
 		// ProjectToViewport (VolumeCull.hlsli:27-41)
 		vec4 p;
@@ -654,16 +677,14 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		nEntries += totE; nTiles += totT; nScreen += (uint32_t)__popcll(bScr);
 	}
 	// what the tile costs of a frame depend on besides the volumes' contents: CBPerFrame's eye / viewport / screenToWorld and every PerObject
+	// (the PerObject words were hashed by the wavefronts that fetched them; XOR of per-word terms: the order does not matter)
 	uint32_t viewHash = 0u;
 	{
-		const uint32_t* cbWords = reinterpret_cast<const uint32_t*>(st.cbHost);
-		const uint32_t* poWords = reinterpret_cast<const uint32_t*>(st.perObjectHost);
-		const uint32_t nCb = 24u, nPo = st.V * (uint32_t)(sizeof(PerObject) / 4u);
-		if (lane < nCb) viewHash = (cbWords[lane] + 0x9e3779b9u * (lane + 1u)) * 0x85ebca6bu;
-#pragma unroll 4
-		for (uint32_t i = lane; i < nPo; i += 64u) viewHash ^= (poWords[i] + 0x9e3779b9u * (i + 25u)) * 0x85ebca6bu;
+		const uint32_t* cbWords = sConst + 8u * kPoWords;
+		if (lane < 24u) viewHash = (cbWords[lane] + 0x9e3779b9u * (lane + 1u)) * 0x85ebca6bu;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) viewHash ^= __shfl_xor(viewHash, o);
+		viewHash ^= __hip_atomic_load(&st.counters[13], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		viewHash |= 1u;	// never 0, the value of a slot no frame has used yet
 	}
 	if (lane == 0)
@@ -682,6 +703,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		}
 		st.counters[7] = nTiles < 2u ? 1u : stride;
 		st.counters[8] = 0u;	// the ticket, for the next cull that uses this slot
+		st.counters[13] = 0u;	// and the hash accumulator
 		if (st.binCursor) { for (uint32_t b = 0; b < 8u; ++b) st.binCursor[b] = 0u; }	// room taken in every bin of the tile order (ordersKernel follows)
 		// [10] a hash of this frame's camera and volume transforms, [11] "it differs from the hash of this slot's previous frame",
 		// i.e. of the frame whose view march wrote the tile cost table this frame's tile order reads (tileBinOf)
@@ -721,13 +743,15 @@ __device__ __forceinline__ FootprintAddr densityFootprint(const VolumeView& vol,
 #endif
 constexpr uint32_t kLightLutMaxN = 256, kLightWaves = MV_LIGHT_WAVES;
 
+template <int K>
 __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vol, vec3 rayOrigin, vec3 rayDir,
 	float stepScale, uint32_t numSamples, uint32_t& samples, const u32x4* axisTables = nullptr)
 {
 	float t = stepScale;
 	float step = stepScale;
 	float prevDensity = 0.0f;
-#if MV_LIGHT_SPECULATE
+	if constexpr (K > 0)
+	{
 	// The loop in batches of MV_LIGHT_SPECULATE samples whose alpha footprints are requested together, at t, t + stepScale,
 	// t + 2 stepScale ... (the very additions the loop performs while the step stays stepScale; GetStep returns exactly
 	// stepScale until the light is noticeably attenuated, 1.5 * factorEv * factorUi * (1 - transm) <= 1).  A wrong guess
@@ -735,8 +759,10 @@ __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vo
 	// sampler, so every address is valid.  Arithmetic and order are the reference's.
 	// Measured at C3 (8.4 M light samples): batch 1 -> 0.128 ms, 2 -> 0.136, 3 -> 0.144, 4 -> 0.159, 8 -> 0.200: the launch
 	// is bound by request throughput plus one ~0.055 ms longest-ray tail (scripts/exp_lightscale.py), not by the latency of
-	// a ray's dependent samples, so requests that may be discarded only cost.  Hence 1.
-	constexpr int K = MV_LIGHT_SPECULATE;
+	// a ray's dependent samples, so requests that may be discarded only cost.  Hence 1 -- for a launch that fills the GPU.  A rank of the
+	// multi-GPU loop marches 1 / shard_count of the voxel blocks, a wavefront or two per SIMD, where the launch lasts as long as its
+	// longest ray's chain of dependent samples: a batch of 4 was tried there too (K is a template parameter of the kernel, chosen per
+	// launch by MV_LIGHT_SPECULATE_BELOW) and is slower as well -- the chain is the ~190 dependent VALU instructions of an iteration.
 	if (numSamples == 0u || outsideBox(rayAt(rayOrigin, rayDir, t))) return;
 	for (uint32_t i = 0;;)
 	{
@@ -773,7 +799,9 @@ __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vo
 			restart = newStep != stepScale;
 		}
 	}
-#else
+	}
+	else
+	{
 	for (uint32_t i = 0; i < numSamples; ++i)
 	{
 		const vec3 pos = rayAt(rayOrigin, rayDir, t);
@@ -794,7 +822,7 @@ __device__ __forceinline__ void CastLightRay(float& transm, const VolumeView& vo
 		step = newStep;
 		t += step;
 	}
-#endif
+	}
 }
 
 // XUSG/Shaders/SHIrradianceTypeless.hlsli:15-36
@@ -863,7 +891,7 @@ __device__ __forceinline__ void storeLightTexel(uint32_t* quads, uint32_t L, uin
 }
 
 // wordsOut: NULL, or where this context's share of the map goes as plain words, 64 per block in dispatch order from entry `lo` on
-template <bool LUT, bool ORDERED>
+template <bool LUT, bool ORDERED, int K>
 __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st, uint32_t* __restrict__ wordsOut)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLightLutMaxN + 1) : 1];
@@ -1019,7 +1047,7 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 					const vec3 rayDir = v3(ld.x, ld.y, ld.z);
 					if (missesUnitBox(localRayOrigin, rayDir)) continue;	// what ComputeRayOrigin would conclude, at a fifth of the cost
 					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
-					CastLightRay(shadow, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS, axisTables);
+					CastLightRay<K>(shadow, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS, axisTables);
 				}
 
 				if (st.hasLightProbe)
@@ -1028,7 +1056,7 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 					if (missesUnitBox(localRayOrigin, rayDir)) continue;
 					if (!ComputeRayOrigin(localRayOrigin, rayDir)) continue;
 					float transm = 1.0f;
-					CastLightRay(transm, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS, axisTables);
+					CastLightRay<K>(transm, vol, localRayOrigin, rayDir, gStep, st.maxLightSamples, nS, axisTables);
 					ao *= n == volumeId ? transm : __builtin_sqrtf(__builtin_sqrtf(saturatef(transm + 0.5f)));	// pow(x, 0.25)
 				}
 			}
@@ -1422,22 +1450,32 @@ uint32_t lightSharePerRank(const DeviceState& st)
 	return lightShare(st, b * b * b).per;
 }
 
-void launchMarchLight(hipStream_t s, const DeviceState& st, uint32_t* wordsOut)
+template <int K>
+static void launchMarchLightK(hipStream_t s, const DeviceState& st, uint32_t* wordsOut, uint32_t count)
 {
-	const uint32_t b = (st.L + 3u) >> 2, total = b * b * b;
-	const LightShare share = lightShare(st, total);
-	const uint32_t count = share.per;	// (the same grid on every rank; the last rank's share may be shorter)
 	if (lightOrdered(st))
 	{
 		const uint32_t perXcd = (count + 7u) >> 3;
 		const uint32_t groups = 8u * ((perXcd + kLightWaves - 1u) / kLightWaves);
-		if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
-		else hipLaunchKernelGGL((marchLightKernel<false, true>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+		if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, true, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+		else hipLaunchKernelGGL((marchLightKernel<false, true, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
 		return;
 	}
 	const uint32_t groups = (count + kLightWaves - 1u) / kLightWaves;
-	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
-	else hipLaunchKernelGGL((marchLightKernel<false, false>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, false, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+	else hipLaunchKernelGGL((marchLightKernel<false, false, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+}
+
+#ifndef MV_LIGHT_SPECULATE_BELOW
+#define MV_LIGHT_SPECULATE_BELOW 0	// voxel blocks per launch under which alpha footprints are requested four samples ahead.  0 = never: measured (round 3,
+									// profiles/r03_speculation.txt) on a rank's eighth of the C3 light march: 46 us -> 52 us with it
+#endif
+void launchMarchLight(hipStream_t s, const DeviceState& st, uint32_t* wordsOut)
+{
+	const uint32_t b = (st.L + 3u) >> 2, total = b * b * b;
+	const uint32_t count = lightShare(st, total).per;	// (the same grid on every rank; the last rank's share may be shorter)
+	if (MV_LIGHT_SPECULATE && count < MV_LIGHT_SPECULATE_BELOW) launchMarchLightK<4>(s, st, wordsOut, count);
+	else launchMarchLightK<MV_LIGHT_SPECULATE ? 1 : 0>(s, st, wordsOut, count);
 }
 
 void launchLightUnpack(hipStream_t s, const DeviceState& st, const uint32_t* words)

@@ -41,7 +41,9 @@ static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 // wavefronts per SIMD (N <= kLutMaxN).
 constexpr uint32_t kLutMaxN = 256;
 // IL: the rows of a sharded context are dealt by tile row (kFlagInterleaveRows) -- compile-time, see screenTileRowsT
-template <bool OVERFLOW, bool LUT, bool IL>
+// SPEC: the texels of the NEXT sample are requested before the current one is resolved (see "speculation" inside): for launches that
+// leave most of the GPU's wavefront slots empty, where a tile lasts as long as its longest ray's chain of dependent samples.
+template <bool OVERFLOW, bool LUT, bool IL, bool SPEC = false>
 __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesKernel(DeviceState st, uint32_t firstSlot)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
@@ -179,6 +181,100 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 			uint32_t occIndex = 0xffffffffu;
 			uint64_t occWord = 0;
 #endif
+			if constexpr (SPEC)
+			{
+				// ---- speculation (round 3) ----
+				// A ray is a chain of dependent samples: the next position needs this sample's step, which needs its alpha, which needs
+				// its texels.  While the accumulated alpha is small -- and through empty space always -- the step is exactly stepScale
+				// (GetStep, RayMarch.hlsli:182-192: max(1.5 scatter.w factorEv factorUi, 1) stepScale), so the footprint at t + stepScale is
+				// requested BEFORE this sample is resolved and is there when the loop arrives; a wrong guess (t advanced by a longer step)
+				// discards it and fetches at the real t.  `t + stepScale` is the very addition the loop performs, so a right guess is the
+				// same float: arithmetic, order and results are the reference's, only requests are issued earlier (and some in vain).
+				// It costs 40 registers (92 -> 132) and wasted requests.  MEASURED SLOWER in both regimes it was meant for -- a launch that fills
+				// the GPU (a wavefront per SIMD less) and a launch that leaves it nearly empty (a rank's share of a frame in the multi-GPU
+				// loop: 116 -> 158 us) -- so no launch selects it (MV_TILE_SPECULATE_BELOW = 0); kept as the experiment it was.
+				struct Prepared { ColourFootprint cf; vec3 uvw; float t; bool outside, skip; };
+				auto prepare = [&](float tt) -> Prepared
+				{
+					Prepared p;
+					p.t = tt;
+					const vec3 pos = rayAt(rayOrigin, rayDir, tt);
+					p.outside = outsideBox(pos);
+					p.skip = false;
+					p.uvw = LocalToTex3DSpace(pos);
+					if (p.outside) return p;
+					FootprintAddr fa;
+					uint32_t occSum = 0u;
+					if (LUT)
+					{
+						const u32x4 ex = sAxis[axisTableIndex(p.uvw.x, vol.N, fa.fx)];
+						const u32x4 ey = sAxis[(kLutMaxN + 1u) + axisTableIndex(p.uvw.y, vol.N, fa.fy)];
+						const u32x4 ez = sAxis[2u * (kLutMaxN + 1u) + axisTableIndex(p.uvw.z, vol.N, fa.fz)];
+						fa.x0 = ex.x; fa.x1 = ex.y;
+						fa.r00 = ey.x + ez.x; fa.r10 = ey.y + ez.x; fa.r01 = ey.x + ez.y; fa.r11 = ey.y + ez.y;
+						occSum = ex.z + ey.z + ez.z;
+					}
+					else fa = footprintAddr(vol, p.uvw);
+#if MV_OCCUPANCY
+					{
+						const uint32_t w = LUT ? occSum & 0xffffffu : occupancyWord(fa.ix, fa.iy, fa.iz, regions);
+						if (w != occIndex) { occWord = occupancy[w]; occIndex = w; }
+						p.skip = !((occWord >> (LUT ? occSum >> 24 : occupancyBit(fa.ix, fa.iy, fa.iz))) & 1ull);
+					}
+#endif
+					if (!p.skip) p.cf = fetchColour(vol, fa);
+					else { p.cf.fx = fa.fx; p.cf.fy = fa.fy; p.cf.fz = fa.fz; }
+					return p;
+				};
+				Prepared cur = prepare(t);
+				for (uint32_t i = 0; i < smpCount; ++i)
+				{
+					if (cur.outside) break;	// :120
+					const float tGuess = t + stepScale;
+					const bool last = i + 1u >= smpCount || tGuess > tMax;	// (nothing follows this sample if the step is stepScale: no request)
+					Prepared nxt;
+					if (!last) nxt = prepare(tGuess);
+					float newStep = stepScale;
+					if (cur.skip)
+					{
+						++nSamples;
+						++nSkipped;
+						prevLit = false;
+					}
+					else
+					{
+						LightFootprint lf;
+						const bool early = MV_PREDICT_LIT && prevLit;
+						if (early) lf = fetchLightFootprint(lightQuads, st.L, cur.uvw);
+						const float alpha = resolveAlphaFromTexels(cur.cf);
+						++nSamples;
+						const bool lit = alpha > kZeroThreshold;	// :128
+						prevLit = lit;
+						if (lit)
+						{
+							if (!early) lf = fetchLightFootprint(lightQuads, st.L, cur.uvw);
+							const vec3 light = resolveLight(lf);
+							vec3 color = resolveRGB(cur.cf);
+							++nLit;
+							const float transm = 1.0f - scatter.w;
+							const float dDensity = alpha - prevDensity;
+							newStep = GetViewStep(dDensity, scatter.w, alpha, stepScale);
+							prevDensity = alpha;
+							const float a = transm * kAbsorption * alpha;
+							scatter.x += a * color.x * light.x;
+							scatter.y += a * color.y * light.y;
+							scatter.z += a * color.z * light.z;
+							scatter.w += a;
+							if (transm < kZeroThreshold) break;	// :146
+						}
+					}
+					t += newStep;
+					if (t > tMax) break;	// :152
+					if (!last && t == tGuess) cur = nxt;
+					else if (i + 1u < smpCount) cur = prepare(t);
+				}
+			}
+			else
 			for (uint32_t i = 0; i < smpCount; ++i)
 			{
 				const vec3 pos = rayAt(rayOrigin, rayDir, t);
@@ -299,6 +395,11 @@ uint32_t marchTilesResidentWaves(int device)
 	return (uint32_t)perCu * (uint32_t)cus * kTileWaves;
 }
 
+#ifndef MV_TILE_SPECULATE_BELOW
+#define MV_TILE_SPECULATE_BELOW 0	// tiles per launch under which the next sample's texels are requested ahead (SPEC).  0 = never: measured (round 3,
+										// profiles/r03_speculation.txt) a rank's share of C3 on 8 ranks, 1.5 k tiles, 116 us -> 158 us with it -- a lone wavefront's
+										// iteration is its ~230 dependent VALU instructions, not the wait for its texels
+#endif
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
 {
 	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has
@@ -309,13 +410,20 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
 	blocks = ((blocks + 7) / 8) * 8;
 	const bool il = st.flags & kFlagInterleaveRows;
+	const bool spec = tiles < (uint64_t)MV_TILE_SPECULATE_BELOW;
+	const dim3 grid((uint32_t)blocks), block(64 * kTileWaves);
 	if (st.N <= kLutMaxN && MV_TILE_LUT != 0)
 	{
-		if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
-		else hipLaunchKernelGGL((marchTilesKernel<false, true, false>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+		if (spec)
+		{
+			if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true, true>), grid, block, 0, s, st, 0u);
+			else hipLaunchKernelGGL((marchTilesKernel<false, true, false, true>), grid, block, 0, s, st, 0u);
+		}
+		else if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true>), grid, block, 0, s, st, 0u);
+		else hipLaunchKernelGGL((marchTilesKernel<false, true, false>), grid, block, 0, s, st, 0u);
 	}
-	else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
-	else hipLaunchKernelGGL((marchTilesKernel<false, false, false>), dim3((uint32_t)blocks), dim3(64 * kTileWaves), 0, s, st, 0u);
+	else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true>), grid, block, 0, s, st, 0u);
+	else hipLaunchKernelGGL((marchTilesKernel<false, false, false>), grid, block, 0, s, st, 0u);
 	return blocks * kTileWaves < maxTiles ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
 }
 

@@ -24,6 +24,15 @@ def camera_sequence(cfg, frames):
     return out
 
 
+def test_config(world):
+    """T2 at a small viewport (MV_TEST_W / MV_TEST_H: scripts/soak_dist.py with odd viewports), or a whole BASELINE config (MV_TEST_CONFIG=C3)."""
+    from multivolumes_amd import scene
+    name = os.environ.get("MV_TEST_CONFIG")
+    if name:
+        return dict(scene.CONFIGS[name])
+    return dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))
+
+
 def main():
     import torch
     import torch.distributed as dist
@@ -35,16 +44,24 @@ def main():
     static_depth = len(sys.argv) > 5 and sys.argv[5] == "1"          # no setter (= no drain of the frames in flight) inside the sequence
     after_setter = len(sys.argv) > 5 and sys.argv[5] == "2"          # a new host depth map every frame and NO flush: frame f - 1 is read back right after the setter of frame f
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
-    cfg = dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))  # (MV_TEST_W / MV_TEST_H: scripts/soak_dist.py with odd viewports)
+    rccl = os.environ.get("MV_TEST_RCCL") == "1"  # one GPU per rank and the library's own RCCL communicators (boxes with >= world GPUs)
+    device = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
+    torch.cuda.set_device(device)
+    if rccl:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    else:
+        dist.init_process_group("gloo")
+    cfg = test_config(world)
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
     flags = _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if mode == "single" else 0)
-    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world)) as c:
+    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world), device=device) as c:
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         kind = D.init_frame_loop(c)
-        assert kind == "torch-callbacks"
+        assert kind == ("rccl" if rccl else "torch-callbacks"), kind
+        if rccl:
+            info = c.DistInfo()
+            assert info["transport"] == "rccl" and info["ranks"] == world and info["communicators"] == (2 if mode == "single" else 3), info
         imgs, infos = [], []
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
             if not static_depth or f == 0:

@@ -56,6 +56,22 @@ def test_two_ranks_on_one_gpu(extra):
 
 
 @pytest.mark.gpu
+def test_bench_starts_and_supervises_its_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the bench starts two ranks as child processes (torch.distributed.run), every rank is a
+    supervisor that starts the measuring process and watches its progress marks, rank 0's line comes back with n_gpus 2 (here the two
+    ranks share cuda:0 over gloo, MV_BENCH_SHARE_GPU=1).  And a WORLD_SIZE that contradicts --gpus is an error, not a warning."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2"], 400, env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["transport"] == "torch-callbacks"
+    bad = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "T2", "--steps", "2", "--warmup", "1"], 120,
+                    dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
 def test_one_rank_bench_line_carries_both_cpu_baselines():
     """The default (N = 1) bench line: `cpu_baseline` is the reference's compiled shader on the host cores when oracle/_ref travelled
     with the tree (kind "reference", equal to the oracle and to the GPU), else the oracle ("port") -- never a silently failed leg."""

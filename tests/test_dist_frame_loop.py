@@ -39,8 +39,8 @@ def run_group(cmd, timeout, env=None):
 def single_gpu(world, frames, every, static_depth=False, all_frames=False):
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
-    from tests.dist_worker import camera_sequence
-    cfg = dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))  # (MV_TEST_W / MV_TEST_H: scripts/soak_dist.py with odd viewports)
+    from tests.dist_worker import camera_sequence, test_config
+    cfg = test_config(world)
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
     with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64) as c:
@@ -82,6 +82,32 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     assert np.array_equal(d["lms"], lms), "every rank holds every light map, current"
     assert np.array_equal(d["counts"], counts), "the ranks together march exactly the single-GPU samples"
     assert int(d["nbytes"]) > 0
+
+
+@pytest.mark.parametrize("mode", ["chains", "single"])
+def test_eight_ranks_at_c3_size_match_single_gpu(tmp_path, mode, monkeypatch):
+    """BASELINE.json configs[3] (C4) at its real shape: the full C3 frame -- 16 x 256^3, 1024^2, 128 steps/ray, mesh depth -- through
+    mv_dist_frame on EIGHT ranks (sharing cuda:0, gloo callbacks: RCCL refuses two ranks on one device; 8 x ~7 GiB of the 288 GB), both
+    schedules, a 14-frame orbit + dolly with nothing that drains the frames in flight: composites, every light map (each marched by
+    all eight ranks, an eighth of the voxel blocks each), VolumeInfo and the summed counters equal the single-GPU run bit for bit."""
+    monkeypatch.setenv("MV_TEST_CONFIG", "C3")
+    world, frames, every = 8, 14, 7
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_CONFIG="C3", OMP_NUM_THREADS="4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every), mode, "1"]
+    r = run_group(cmd, 900, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    imgs, infos, counts, lms = single_gpu(world, frames, every, True)
+    assert np.array_equal(d["infos"], infos), "the cull is replicated"
+    for i in range(len(imgs)):
+        assert imgs[i].shape == (1024, 1024, 4)
+        assert np.array_equal(d["imgs"][i], imgs[i]), f"composite of checkpoint {i} differs ({(d['imgs'][i] != imgs[i]).sum()} halfs)"
+    assert np.array_equal(d["lms"], lms), "every rank holds every light map, current"
+    assert np.array_equal(d["counts"], counts) and counts[0] > 10_000_000 * frames, "the ranks together march exactly the single-GPU samples"
+    # per frame: the light shares (8 x 1 728 blocks x 256 B), the marched cube faces, the rows of the image
+    assert int(d["nbytes"]) // frames > 8 * 1024 * 1024
 
 
 @pytest.mark.parametrize("mode", ["chains", "single"])
