@@ -25,6 +25,10 @@ import os
 import sys
 import time
 
+# more than three whole frames in flight need more than the HIP runtime's default of four hardware queues per process: must be in
+# the environment before the runtime starts (torch starts it), so before anything else (include/multivolumes.h, mv_config.frames_in_flight)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -64,6 +68,7 @@ def parse():
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
     p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
+    p.add_argument("--frames-in-flight", type=int, default=0, help="whole frames in flight = view streams = output sets (2..5; 0 = the library's default, 3)")
     p.add_argument("--transport", default="auto", choices=["auto", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
                    help="--gpus > 1: auto = the library's own RCCL communicators with whole frames on three view streams, and -- only if that "
                         "fails or stops making progress -- the next of: RCCL with one view stream, torch.distributed's NCCL group through "
@@ -241,7 +246,7 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
     stream = torch.cuda.current_stream().cuda_stream
     caster = MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=M, device=local_rank,
-                            stream=stream, flags=flags, shard=(rank, world))
+                            stream=stream, flags=flags, shard=(rank, world), framesInFlight=args.frames_in_flight)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     t0 = time.time()

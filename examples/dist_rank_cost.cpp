@@ -4,7 +4,7 @@
 // (scripts/exp_rank_cost.py is the same measurement through the Python mirror).  max over ranks = the frame time an ideal fabric would
 // give; its ratio to world 1 is the ceiling of the strong-scaling curve.
 // Build: g++ -O2 -std=c++17 examples/dist_rank_cost.cpp -Lmultivolumes_amd -lmultivolumes_amd -Wl,-rpath,$PWD/multivolumes_amd -o /tmp/dist_rank_cost
-// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
 // Prints per rank: ms per frame, and in brackets the host's share (time spent inside DistFrame: constants + every HIP call of the frame).
 #include "../multivolumes_amd/csrc/MultiRayCaster.hpp"
 
@@ -23,6 +23,7 @@ int main(int argc, char** argv)
 	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
 	const unsigned worlds = argc > 2 ? (unsigned)std::atoi(argv[2]) : 15u;
 	const int onlyRank = argc > 3 ? std::atoi(argv[3]) : -1;	// (one rank only: for a kernel trace)
+	const uint32_t inFlight = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 0u;	// mv_config.frames_in_flight (0 = 3)
 	std::vector<std::vector<uint16_t>> vols(V, std::vector<uint16_t>((size_t)N * N * N * 4));
 	for (uint32_t k = 0; k < V; ++k) mvh_synth_volume(N, k, vols[k].data());
 
@@ -48,7 +49,7 @@ int main(int argc, char** argv)
 		{
 			if (onlyRank >= 0 && (uint32_t)onlyRank != rank) continue;
 			mvamd::MultiRayCaster rc;
-			if (!rc.Init(N, L, V, V, W, H, M, 0, nullptr, rank, world, MV_FLAG_PIPELINE_FRAMES)) { std::fprintf(stderr, "Init failed (no gfx950 device?)\n"); return 2; }
+			if (!rc.Init(N, L, V, V, W, H, M, 0, nullptr, rank, world, MV_FLAG_PIPELINE_FRAMES, inFlight)) { std::fprintf(stderr, "Init failed (no gfx950 device?)\n"); return 2; }
 			for (uint32_t k = 0; k < V; ++k) if (!rc.LoadVolumeData(k, vols[k].data())) return 3;
 			if (!rc.SetRenderTargetsHost(depth.data(), shadow.data())) return 4;
 			rc.SetMaxSamples(128, 96);

@@ -94,6 +94,11 @@ typedef struct mv_config
 	void* stream;				/* hipStream_t to order all work on; NULL = the context creates its own */
 	uint32_t shard_index;		/* multi-GPU: this context marches volumes v with v % shard_count == shard_index */
 	uint32_t shard_count;		/* 0 or 1 = unsharded; at most MV_MAX_SHARDS */
+	uint32_t frames_in_flight;	/* with MV_FLAG_PIPELINE_FRAMES (and not MV_FLAG_SINGLE_VIEW_STREAM): whole frames in flight = view streams = output sets,
+								   2..5; 0 = 3, the reference's FrameCount (MultiRayCaster.h:52).  More than 3 need more than the four hardware
+								   queues a HIP process has by default: GPU_MAX_HW_QUEUES >= frames_in_flight + 1 in the environment before the HIP
+								   runtime initialises (the library sets GPU_MAX_HW_QUEUES=8 when it is loaded if the variable is unset).
+								   (ABI 4; a struct_size without this field is accepted and means 0.) */
 } mv_config;
 
 /* counters accumulated since the last mv_reset_stats (all device-side, exact) */
@@ -113,7 +118,7 @@ typedef struct mv_stats
 
 const char* mv_error_string(int code);
 const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
-#define MV_ABI_VERSION 3u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms */
+#define MV_ABI_VERSION 4u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms; 4: mv_config.frames_in_flight, MV_DIST_ID_BYTES 640 (up to five communicators), light march shared out over the ranks */
 uint32_t mv_abi_version(void);	/* == MV_ABI_VERSION of the header the library was built from */
 
 /* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,
@@ -276,7 +281,7 @@ int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim);
  *       one beside frame k's march; communicator 0 = cube faces / rows, 1 = light maps.
  * Transport: RCCL (the library opens librccl.so itself; three communicators, two used without chains) or caller-supplied collectives
  * (tests, other fabrics). */
-#define MV_DIST_ID_BYTES 384	/* three RCCL unique ids (one per communicator) */
+#define MV_DIST_ID_BYTES 640	/* five RCCL unique ids (one per communicator; the loop uses as many as the context has frames in flight) */
 int mv_dist_rccl_available(void);	/* 1 if librccl.so and every entry point the loop needs can be opened in this process: a LOCAL check, so that the ranks can
 									   agree on the transport before any of them enters mv_dist_init_rccl (ncclCommInitRank is collective: a rank that
 									   cannot open the library would leave the others waiting inside it) */

@@ -29,8 +29,8 @@ MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
 MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7
 MV_BUF_VOLUME_FLAGS, MV_BUF_EXCHANGE_OFFSETS = 10, 11
 
-MV_DIST_ID_BYTES = 384
-MV_ABI_VERSION = 3  # include/multivolumes.h
+MV_DIST_ID_BYTES = 640
+MV_ABI_VERSION = 4  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 
@@ -45,7 +45,7 @@ class mv_config(C.Structure):
         ("num_volumes", C.c_uint32), ("num_volume_srcs", C.c_uint32),
         ("viewport_w", C.c_uint32), ("viewport_h", C.c_uint32), ("shadow_map_size", C.c_uint32),
         ("device", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p),
-        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32),
+        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("frames_in_flight", C.c_uint32),
     ]
 
 

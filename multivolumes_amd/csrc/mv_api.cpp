@@ -35,8 +35,13 @@ struct SectionTimer { int i; std::chrono::steady_clock::time_point t0 = std::chr
 namespace
 {
 constexpr uint32_t kMaxScreenSlots = 32;	// screen-space-scheme volumes whose RayCast joins the view-march launch (16 B x W x H of layer each, per output set)
-constexpr uint32_t kFrameSlots = 4;	// constants + cull outputs in flight: the cull of frame i+2 may run while frame i is still marching
-constexpr uint32_t kFrameSlices = 4;	// upload slices in flight, one per frame slot (the reference keeps FrameCount = 3 of them, MultiRayCaster.h:52)
+// Frames in flight (MV_FLAG_PIPELINE_FRAMES; mv_config.frames_in_flight, default 3 like the reference's FrameCount, MultiRayCaster.h:52): C whole
+// frames on C view streams with C output sets.  What follows from C: light buffers per volume = max(3, C) (the light march of frame i
+// writes the buffer the relit volume held that many relights ago: frame i - lightBufs is the last that can still read it), frame slots
+// (constants + cull outputs; also the pinned upload slices) = light buffers + 1 (the cull of frame i + 1 runs while frame i - lightBufs + 1
+// is still marching).  With C = 3: 3 light buffers, 4 slots -- the numbers of rounds 1 and 2.
+constexpr uint32_t kMaxChains = 5;
+constexpr uint32_t kMaxFrameSlots = kMaxChains + 1;
 constexpr uint32_t kNumCounters = 8;	// read back; counters[8] (the cull's ticket) is device-only
 constexpr uint32_t kNumStats = 8;
 
@@ -70,7 +75,7 @@ struct FrameBufs
 // Outputs of the view march / composite and their counters: one set, or kMaxOutSets-or-fewer rotating sets with
 // MV_FLAG_PIPELINE_FRAMES (frame i uses set i % numOutSets and view stream i % numOutSets), so that the view marches of
 // consecutive frames may overlap on the GPU.
-constexpr uint32_t kMaxOutSets = 3;
+constexpr uint32_t kMaxOutSets = kMaxChains;
 struct OutBufs
 {
 	uint2* cubeMaps = nullptr;
@@ -85,7 +90,7 @@ struct OutBufs
 };
 
 // state of the in-library multi-GPU frame loop (mv_dist_*)
-constexpr uint32_t kDistChains = 3;
+constexpr uint32_t kDistChains = kMaxChains;	// (array sizes; the loop uses as many chains as the context has view streams)
 struct DistState
 {
 	int transport = 0;				// 1 = RCCL, 2 = caller-supplied collectives
@@ -104,6 +109,7 @@ struct DistState
 	bool chains = false;
 	bool inPlaceGather = false;	// the transport's all-gather accepts send == recv + rank * bytes (RCCL does; a caller says so with mv_dist_set_inplace_gather)
 	uint32_t numComm = 2;
+	uint32_t numChains = 1;			// chains: one per view stream of the context (3 by default), each with its communicator and buffers; else 1
 	ncclComm_t comm[kDistChains] = {};
 	mv_dist_allgather_fn cbAllGather = nullptr;
 	mv_dist_allreduce_u32_fn cbAllReduce = nullptr;
@@ -137,10 +143,11 @@ struct mv_ctx
 	bool ownStream = false, ownStreamA = false, ownStreamL = false, ownStreamB1 = false;
 	bool lightOnViewStream = false;		// pipelined with several view streams: a frame's light march runs on that frame's view stream
 	DeviceState st;						// always holds the CURRENT frame slot's pointers (applyParity)
-	FrameBufs fb[kFrameSlots];			// constants + cull outputs per slot; march / composite outputs per PARITY (slot & 1), aliased
-	uint32_t slot = 0;					// frame counter mod kFrameSlots
-	hipEvent_t evStageA[kFrameSlots] = {}, evLight[kFrameSlots] = {}, evMainDone[kFrameSlots] = {}, evProducers = nullptr;
-	hipEvent_t evCopy[kFrameSlots] = {};	// a frame's unmarched cube faces are up to date (copyForward)
+	FrameBufs fb[kMaxFrameSlots];		// constants + cull outputs per slot (numSlots of them in use)
+	uint32_t numSlots = 4;				// light buffers per volume + 1
+	uint32_t slot = 0;					// frame counter mod numSlots
+	hipEvent_t evStageA[kMaxFrameSlots] = {}, evLight[kMaxFrameSlots] = {}, evMainDone[kMaxFrameSlots] = {}, evProducers = nullptr;
+	hipEvent_t evCopy[kMaxFrameSlots] = {};	// a frame's unmarched cube faces are up to date (copyForward)
 	bool copiedForward = false;			// this frame's copy-forward has been enqueued
 	bool marchedThisFrame = false;		// mv_march_view has run for the current frame (its RayCast layers are this frame's)
 	uint64_t lastCompleteFrame = 0;		// the last frame whose output set was completed (view march, or a composite-only frame's copy from every set)
@@ -172,8 +179,7 @@ struct mv_ctx
 	std::vector<void*> allocs;			// everything to hipFree
 
 	// pinned upload ring (the reference's upload-heap slices, MultiRayCaster.cpp:128-130, 461-467)
-	uint8_t* pinned = nullptr;			// kFrameSlices slices: frame i's constants in slice i % kFrameSlots, read by that frame's cull where they lie
-	uint8_t* pinnedDev = nullptr;		// the same memory as the device addresses it
+	uint8_t* pinned = nullptr;			// numSlots slices: frame i's constants in slice i % numSlots, read by that frame's cull where they lie
 	size_t sliceBytes = 0;
 	uint64_t* pinnedStats = nullptr;
 	uint32_t* pinnedCounters = nullptr;
@@ -284,12 +290,10 @@ void viewportDerived(DeviceState& st)
 void applyParity(mv_ctx* ctx)
 {
 	const FrameBufs& f = ctx->fb[ctx->slot];
-	const FrameBufs& q = ctx->fb[(ctx->slot + kFrameSlots - 1u) % kFrameSlots];	// the previous frame's
+	const FrameBufs& q = ctx->fb[(ctx->slot + ctx->numSlots - 1u) % ctx->numSlots];	// the previous frame's
 	DeviceState& st = ctx->st;
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
 	st.exchangeReport = (ctx->dist && ctx->dist->reports) ? ctx->dist->reports + (size_t)ctx->slot * 8u : nullptr;
-	st.cbHost = ctx->pinnedDev ? ctx->pinnedDev + (size_t)ctx->slot * ctx->sliceBytes : nullptr;
-	st.perObjectHost = ctx->pinnedDev ? ctx->pinnedDev + (size_t)ctx->slot * ctx->sliceBytes + 256 : nullptr;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
 	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.exchangeOff = f.exchangeOff; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
@@ -377,12 +381,12 @@ hipError_t stageBBegin(mv_ctx* ctx)
 	const uint32_t others = ctx->lightOnViewStream ? ctx->numViewStreams - 1u : 0u;
 	for (uint32_t j = 0; j <= others; ++j)
 	{
-		const hipError_t e2 = evWait(ctx, streamB(ctx), ctx->evLight[(ctx->slot + kFrameSlots - j) % kFrameSlots]);
+		const hipError_t e2 = evWait(ctx, streamB(ctx), ctx->evLight[(ctx->slot + ctx->numSlots - j) % ctx->numSlots]);
 		if (e2 != hipSuccess) return e2;
 	}
 	return hipSuccess;
 }
-// stage of stream B finished being enqueued: the next user of this slot's buffers (kFrameSlots frames on) and the light march two frames on wait for it
+// stage of stream B finished being enqueued: the next user of this slot's buffers (ctx->numSlots frames on) and the light march two frames on wait for it
 hipError_t stageBDone(mv_ctx* ctx) { return evRecord(ctx, ctx->evMainDone[ctx->slot], streamB(ctx)); }
 
 void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
@@ -438,6 +442,12 @@ void foldEvents(mv_ctx* ctx)
 
 } // namespace
 
+// More than three whole frames in flight need more than the four hardware queues the HIP runtime gives a process by default (streams
+// that share a queue wait for each other: scripts/micro/hw_queues.cpp): when this library is loaded before the runtime has started --
+// a C++ host that links it, a Python process that imports it before touching the GPU -- it asks for eight, unless the caller has said
+// otherwise.  A process whose runtime is already up keeps what it has; mv_config.frames_in_flight > 3 then shares queues (slower, correct).
+__attribute__((constructor)) static void mvAskForHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" {
 
 const char* mv_error_string(int code)
@@ -462,8 +472,12 @@ uint64_t mv_cube_mip_offset(uint32_t N, uint32_t mip) { return mv::cubeMipOffset
 
 int mv_create(const mv_config* cfg, mv_ctx** out)
 {
-	if (!cfg || !out || cfg->struct_size != sizeof(mv_config)) return MV_ERR_INVALID_ARG;
+	// (struct_size names the caller's version of mv_config: the one without frames_in_flight, ABI <= 3's, is accepted too)
+	constexpr uint32_t kConfigV1Size = offsetof(mv_config, frames_in_flight);
+	if (!cfg || !out || (cfg->struct_size != sizeof(mv_config) && cfg->struct_size != kConfigV1Size && cfg->struct_size != ((kConfigV1Size + 7u) & ~7u))) return MV_ERR_INVALID_ARG;
 	*out = nullptr;
+	const uint32_t wantChains = cfg->struct_size == sizeof(mv_config) && cfg->frames_in_flight ? cfg->frames_in_flight : 3u;
+	if (wantChains < 2u || wantChains > kMaxChains) return MV_ERR_INVALID_ARG;
 	if (cfg->grid_size < 2 || cfg->grid_size > 640 /* bricked alpha cells (16 B/texel) must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->light_grid_size > 640 /* 32-bit offsets into the 16 B/texel light quads */ || cfg->num_volumes < 1 || cfg->num_volumes > MV_MAX_VOLUMES /* the cull and the tile order keep per-volume tables in LDS (12 V and 48 V + 132 bytes of the 64 KiB a launch gets by default) */ ||
 		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
 		return MV_ERR_INVALID_ARG;
@@ -479,7 +493,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 
 	mv_ctx* ctx = new (std::nothrow) mv_ctx();
 	if (!ctx) return MV_ERR_OUT_OF_MEMORY;
-	ctx->cfg = *cfg;
+	memset(&ctx->cfg, 0, sizeof(ctx->cfg));
+	memcpy(&ctx->cfg, cfg, cfg->struct_size < sizeof(mv_config) ? cfg->struct_size : sizeof(mv_config));
 	memset(&ctx->st, 0, sizeof(ctx->st));
 
 	int rc = MV_OK;
@@ -504,8 +519,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
 		ctx->ownStreamA = true;
 		// One view stream (MV_FLAG_SINGLE_VIEW_STREAM, the multi-GPU loop): the light marches get a stream of their own and two
-		// output sets rotate.  Otherwise three output sets on three view streams, each frame's light march on its view stream:
-		// four streams in all either way -- a HIP process has four hardware queues, and streams that share one wait for each other.
+		// output sets rotate.  Otherwise C output sets on C view streams (mv_config.frames_in_flight, default 3), each frame's light
+		// march on its view stream.  A HIP process has four hardware queues by default, and streams that share one wait for each
+		// other: with three chains that is four streams; more chains need GPU_MAX_HW_QUEUES >= C + 1 in the environment before the HIP
+		// runtime starts (this library sets it to 8 when it is loaded, if the variable is not set -- see the constructor below).
 		if (cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM)
 		{
 			if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
@@ -515,7 +532,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		else
 		{
 			ctx->lightOnViewStream = true;
-			ctx->numOutSets = 3u;
+			ctx->numOutSets = wantChains;
 		}
 #ifdef MV_DIAGNOSTICS	// A/B measurements only (csrc/build.sh -DMV_DIAGNOSTICS); the shipped library reads no environment variable
 		{ const char* e = getenv("MV_OUT_SETS"); if (e) ctx->numOutSets = (uint32_t)atoi(e); if (ctx->numOutSets < 2u || ctx->numOutSets > kMaxOutSets) ctx->numOutSets = 2u; }
@@ -528,11 +545,13 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			ctx->ownStreamB1 = true;
 		}
 	}
-	for (uint32_t i = 0; i < kFrameSlots; ++i)
+	ctx->st.lightBufs = ctx->numOutSets > 3u ? ctx->numOutSets : 3u;
+	ctx->numSlots = ctx->st.lightBufs + 1u;
+	for (uint32_t i = 0; i < ctx->numSlots; ++i)
 		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->evLight[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->evProducers, hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
-	for (uint32_t i = 0; i < kFrameSlots; ++i)
+	for (uint32_t i = 0; i < ctx->numSlots; ++i)
 		if (hipEventCreateWithFlags(&ctx->evCopy[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 
 	DeviceState& st = ctx->st;
@@ -582,7 +601,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &ctx->staging, ctx->stagingBytes, false)) != MV_OK) return bail(rc);
 
 	// lightMaps[V], cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-126), all zero-initialised
-	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * mv::kLightBuffers * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
+	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * st.lightBufs * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->lightStaging, L3 * sizeof(uint32_t), false)) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownDepth, (size_t)st.W * st.H * sizeof(float))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownShadow, (size_t)st.M * st.M * sizeof(uint16_t))) != MV_OK) return bail(rc);
@@ -597,8 +616,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	// constants + cull outputs, once per frame slot (FrameBufs)
 	{
 		std::vector<uint4*> table(st.V);
-		for (uint32_t v = 0; v < st.V; ++v) table[v] = st.lightBuffers + (size_t)(mv::kLightBuffers * v) * L3;
-		for (uint32_t p = 0; p < kFrameSlots; ++p)
+		for (uint32_t v = 0; v < st.V; ++v) table[v] = st.lightBuffers + (size_t)(st.lightBufs * v) * L3;
+		for (uint32_t p = 0; p < ctx->numSlots; ++p)
 		{
 			FrameBufs& f = ctx->fb[p];
 			if ((rc = devAlloc(ctx, &f.dCb, 256 + (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);	// one upload: CBPerFrame, then PerObject[V]
@@ -649,7 +668,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	}
 	st.lightBlocks = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
 	ctx->orderTiles = !(cfg->flags & MV_FLAG_LIST_ORDER);
-	for (uint32_t p = 0; p < kFrameSlots; ++p)
+	for (uint32_t p = 0; p < ctx->numSlots; ++p)
 	{
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, 8u * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);	// a region per cost bin
 		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
@@ -687,12 +706,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	applyParity(ctx);
 
 	// pinned upload ring + readback scratch
-	static_assert(kFrameSlices == kFrameSlots, "a slice per frame slot");
 	ctx->sliceBytes = 256 + (size_t)st.V * MV_PER_OBJECT_BYTES;
-	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kFrameSlices + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
-	if (hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->pinnedDev), ctx->pinned, 0) != hipSuccess) return bail(MV_ERR_HIP);
-	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices);
-	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kFrameSlices + 128);
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kMaxFrameSlots + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
+	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kMaxFrameSlots);
+	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kMaxFrameSlots + 128);
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedTiles), 64, hipHostMallocCoherent) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	*ctx->pinnedTiles = ~0ull;
 	st.tilesReport = ctx->pinnedTiles;
@@ -743,8 +760,8 @@ void mv_destroy(mv_ctx* ctx)
 	if (ctx->stream) (void)syncAll(ctx);
 	foldEvents(ctx);
 	distRelease(ctx);
-	for (uint32_t i = 0; i < kFrameSlots; ++i) if (ctx->evCopy[i]) (void)hipEventDestroy(ctx->evCopy[i]);
-	for (uint32_t i = 0; i < kFrameSlots; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); if (ctx->evLight[i]) (void)hipEventDestroy(ctx->evLight[i]); }
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) if (ctx->evCopy[i]) (void)hipEventDestroy(ctx->evCopy[i]);
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); if (ctx->evLight[i]) (void)hipEventDestroy(ctx->evLight[i]); }
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
 	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
 	if (ctx->ownStreamL && ctx->streamL) (void)hipStreamDestroy(ctx->streamL);
@@ -863,7 +880,7 @@ int mv_set_viewport(mv_ctx* ctx, uint32_t w, uint32_t h)
 	if ((rc = devRealloc(ctx, &ctx->ownDepth, (size_t)w * h * sizeof(float))) != MV_OK) return rc;
 	st.depthMap = ctx->ownDepth;	// (a borrowed depth map was the old viewport's: the caller hands over the new one)
 	ctx->haveDepth = false;
-	for (uint32_t p = 0; p < kFrameSlots; ++p)
+	for (uint32_t p = 0; p < ctx->numSlots; ++p)
 	{
 		if ((rc = devRealloc(ctx, &ctx->fb[p].tileOrder, 8u * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return rc;
 		if ((rc = devRealloc(ctx, &ctx->fb[p].tileCost, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return rc;
@@ -965,7 +982,7 @@ static int keepLightTable(mv_ctx* ctx)
 {
 	if (ctx->lightMarched || ctx->lightTableKept) return MV_OK;
 	const FrameBufs& f = ctx->fb[ctx->slot];
-	const FrameBufs& q = ctx->fb[(ctx->slot + kFrameSlots - 1u) % kFrameSlots];
+	const FrameBufs& q = ctx->fb[(ctx->slot + ctx->numSlots - 1u) % ctx->numSlots];
 	MV_HIP(ctx, hipMemcpyAsync(f.lightTable, q.lightTable, (size_t)ctx->st.V * sizeof(uint4*), hipMemcpyDeviceToDevice, ctx->streamA));
 	MV_HIP(ctx, stageADone(ctx));
 	ctx->lightTableKept = true;
@@ -976,18 +993,19 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 {
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
 	// a new frame: the next slot of constants / cull buffers (and the other parity's march outputs)
-	ctx->slot = (ctx->slot + 1u) % kFrameSlots;
+	ctx->slot = (ctx->slot + 1u) % ctx->numSlots;
 	++ctx->frame;
 	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
 	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);
-	// the slot's previous user (kFrameSlots frames ago) must be done with it; volume producers on stream B must have finished
+	// the slot's previous user (ctx->numSlots frames ago) must be done with it; volume producers on stream B must have finished
 	MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evMainDone[ctx->slot]));
 	MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evLight[ctx->slot]));
 	if (ctx->producersDirty) { MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evProducers)); ctx->producersDirty = false; }
-	// The constants go into this slot's pinned slice, where the frame's cull reads them (no upload copy: the cull writes the device
-	// copies the other kernels read).  The slice's previous user is the frame kFrameSlots back: its cull must have run -- in steady
-	// state it has, long ago; a host that runs more than three frames ahead of the GPU waits here, as the reference's does on its fence.
+	// The constants go into this slot's pinned slice (the reference's upload-heap slices, MultiRayCaster.cpp:128-130, 461-467) and from
+	// there to the device in one copy on stream A.  The slice's previous user is the frame numSlots back: its copy must have run --
+	// in steady state it has, long ago (the slot's stage-A event covers it: no event of its own); a host that runs more than that many
+	// frames ahead of the GPU waits here, as the reference's does on its fence.
 	if (hipEventQuery(ctx->evStageA[ctx->slot]) != hipSuccess)
 	{
 		const auto t0 = std::chrono::steady_clock::now();
@@ -997,6 +1015,8 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	uint8_t* s = ctx->pinned + (size_t)ctx->slot * ctx->sliceBytes;
 	memcpy(s, cbPerFrame, MV_CB_PER_FRAME_BYTES);
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
+	MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));
+	MV_HIP(ctx, stageADone(ctx, false));	// (a frame that never culls still marks its copy; inside the multi-GPU loop the cull's record follows at once)
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
 	ctx->lightMarched = false; ctx->lightTableKept = false; ctx->copiedForward = false; ctx->marchedThisFrame = false;
@@ -1030,15 +1050,16 @@ static int marchLight(mv_ctx* ctx, uint32_t* wordsOut)
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
 	MV_REQUIRE(ctx, !ctx->lightTableKept, MV_ERR_NOT_READY, "mv_march_light must come before the frame's mv_march_view / mv_composite");
-	// The light buffer this launch writes was last read by a frame at least kLightBuffers (3) frames back (the relit volume's
+	// The light buffer this launch writes was last read by a frame at least lightBufs (3 by default) frames back (the relit volume's
 	// table entry has rotated since): that frame's view march / composite must be over.  Older ones are, by stream order.
-	static_assert(mv::kLightBuffers == 3 && kFrameSlots == 4 && kMaxOutSets < kFrameSlots, "the wait below names frame i - 3");
+	// (slot + 1) mod numSlots is the slot of frame i - (numSlots - 1) = i - lightBufs; with three chains and three buffers that frame sits
+	// on this frame's own stream and the wait is left out (evWait)
 	// With several view streams the light march goes in front of its frame's view march on that frame's stream: every stream then
 	// carries a whole frame (light march, view march, composite) and the frames overlap as wholes.  (A stream of its own for the
 	// light marches serialises them at the share of the GPU one kernel gets beside two view marches, which made them the chain
 	// every frame waited for: 0.349 -> 0.331 ms per frame at C3 with two output sets, 0.311 ms with three.)
 	hipStream_t L = ctx->lightOnViewStream ? streamB(ctx) : ctx->streamL;
-	MV_HIP(ctx, evWait(ctx, L, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots]));
+	MV_HIP(ctx, evWait(ctx, L, ctx->evMainDone[(ctx->slot + 1u) % ctx->numSlots]));
 	MV_HIP(ctx, evWait(ctx, L, ctx->evStageA[ctx->slot]));	// this frame's upload + cull
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 1, ev, L);
@@ -1092,7 +1113,7 @@ static int viewCopyForward(mv_ctx* ctx)
 {
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
-	const uint32_t prevSlot = (ctx->slot + kFrameSlots - 1u) % kFrameSlots;
+	const uint32_t prevSlot = (ctx->slot + ctx->numSlots - 1u) % ctx->numSlots;
 	const uint32_t n = ctx->numOutSets;
 	const bool ownCopy = !ctx->dist || ctx->dist->chains;	// (the single-view-stream multi-GPU loop copies on its stream X)
 	if (MV_COPY_FORWARD && n >= 2u && ownCopy && ctx->lastCompleteFrame != 0u && ctx->lastCompleteFrame + 1u != ctx->frame && !ctx->copiedForward)
@@ -1109,7 +1130,7 @@ static int viewCopyForward(mv_ctx* ctx)
 		// each other: measured).  It writes this frame's set, so the set's last reader (the composite of frame k - n) must be
 		// over, and it reads what the previous frame's copy wrote (a face nobody has marched for two frames travels set to set).
 		hipStream_t s = ctx->streamB[(ctx->frame + ctx->numViewStreams - 1u) % ctx->numViewStreams];
-		MV_HIP(ctx, evWait(ctx, s, ctx->evMainDone[(ctx->slot + kFrameSlots - n) % kFrameSlots]));
+		MV_HIP(ctx, evWait(ctx, s, ctx->evMainDone[(ctx->slot + ctx->numSlots - n) % ctx->numSlots]));
 		MV_HIP(ctx, evWait(ctx, s, ctx->evCopy[prevSlot]));
 		if (ctx->copiedForward) MV_HIP(ctx, evWait(ctx, s, ctx->evCopy[ctx->slot]));
 		MV_HIP(ctx, evWait(ctx, s, ctx->evStageA[ctx->slot]));	// this frame's cull
@@ -1127,9 +1148,9 @@ static int viewMarch(mv_ctx* ctx)
 	ctx->marchedThisFrame = true;
 	MV_HIP(ctx, stageBBegin(ctx));
 	// the set this march writes was read by the copy-forward of frame k - n + 1 (as the set before its own) ...
-	if (n >= 2u) MV_HIP(ctx, evWait(ctx, streamB(ctx), ctx->evCopy[(ctx->slot + kFrameSlots - (n - 1u)) % kFrameSlots]));
+	if (n >= 2u) MV_HIP(ctx, evWait(ctx, streamB(ctx), ctx->evCopy[(ctx->slot + ctx->numSlots - (n - 1u)) % ctx->numSlots]));
 	// ... and by the composite of frame k - n, its previous user (with SINGLE_VIEW_STREAM / one stream that is on this stream anyway)
-	MV_HIP(ctx, evWait(ctx, streamB(ctx), ctx->evMainDone[(ctx->slot + kFrameSlots - (n % kFrameSlots)) % kFrameSlots]));
+	MV_HIP(ctx, evWait(ctx, streamB(ctx), ctx->evMainDone[(ctx->slot + ctx->numSlots - (n % ctx->numSlots)) % ctx->numSlots]));
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 2, ev, streamB(ctx));
 	// Nothing between the cull and the march waits for the host (the shape of the work-graph variant, Sh/LibRayMarch.hlsl:39-134).
@@ -1480,7 +1501,7 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 	case MV_BUF_DEPTH_MAP: *d_ptr = ctx->ownDepth; *bytes = (size_t)st.W * st.H * sizeof(float); return MV_OK;
 	case MV_BUF_SHADOW_MAP: *d_ptr = ctx->ownShadow; *bytes = (size_t)st.M * st.M * sizeof(uint16_t); return MV_OK;
 	case MV_BUF_TILE_COST:
-		MV_REQUIRE(ctx, index < kFrameSlots, MV_ERR_RANGE, "frame slot out of range");
+		MV_REQUIRE(ctx, index < ctx->numSlots, MV_ERR_RANGE, "frame slot out of range");
 		*d_ptr = ctx->fb[index].tileCost; *bytes = (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t); return MV_OK;
 	case MV_BUF_VOLUME_FLAGS: *d_ptr = st.volumeFlags; *bytes = (size_t)st.V * sizeof(uint32_t); return MV_OK;
 	case MV_BUF_EXCHANGE_OFFSETS: *d_ptr = st.exchangeOff; *bytes = (size_t)st.V * sizeof(uint32_t); return MV_OK;
@@ -1690,7 +1711,7 @@ static int distCommonInitBody(mv_ctx* ctx)
 		d->lightShareBytes = (size_t)mv::lightSharePerRank(split) * 64u * sizeof(uint32_t);
 	}
 	int rc;
-	for (uint32_t c = 0; c < (d->chains ? kDistChains : 1u); ++c)
+	for (uint32_t c = 0; c < d->numChains; ++c)
 	{
 		if ((rc = distAlloc(ctx, &d->sendBuf[c], d->sendCap)) != MV_OK) return rc;
 		if ((rc = distAlloc(ctx, &d->recvBuf[c], d->sendCap * world)) != MV_OK) return rc;
@@ -1701,8 +1722,8 @@ static int distCommonInitBody(mv_ctx* ctx)
 		if ((rc = distAlloc(ctx, &d->rowSend[c], d->maxBandBytes, ctx->stream)) != MV_OK) return rc;
 		if ((rc = distAlloc(ctx, &d->rowRecv[c], d->maxBandBytes * world)) != MV_OK) return rc;
 	}
-	if (hipHostMalloc(reinterpret_cast<void**>(&d->reports), kFrameSlots * 64, hipHostMallocCoherent) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned exchange reports");
-	for (uint32_t i = 0; i < kFrameSlots; ++i) d->reports[i * 8u] = ~0ull;
+	if (hipHostMalloc(reinterpret_cast<void**>(&d->reports), kMaxFrameSlots * 64, hipHostMallocCoherent) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned exchange reports");
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) d->reports[i * 8u] = ~0ull;
 	if (world > 1u) ctx->st.flags |= mv::kFlagInterleaveRows;	// screen rows dealt by tile row instead of in contiguous bands
 #ifndef MV_DIST_STATIC_OWNERS	// (A/B builds only: v % shard_count inside the loop too)
 	ctx->st.flags |= mv::kFlagBalanceOwners;	// the cube-map volumes of a frame are dealt to the ranks by estimated cost (replicated cull: the same deal everywhere)
@@ -1761,8 +1782,9 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
 	DistState* d = new (std::nothrow) DistState();
 	if (!d) return MV_ERR_OUT_OF_MEMORY;
 	d->transport = 1; d->inPlaceGather = true;
-	d->chains = ctx->lightOnViewStream && ctx->numViewStreams == kDistChains;
-	d->numComm = d->chains ? kDistChains : 2u;
+	d->chains = ctx->lightOnViewStream && ctx->numViewStreams >= 2u;
+	d->numChains = d->chains ? ctx->numViewStreams : 1u;
+	d->numComm = d->chains ? d->numChains : 2u;
 	d->rcclLib = openRccl();
 	if (d->rcclLib)
 	{
@@ -1797,8 +1819,9 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
 	DistState* d = new (std::nothrow) DistState();
 	if (!d) return MV_ERR_OUT_OF_MEMORY;
 	d->transport = 2; d->cbAllGather = allgather; d->cbAllReduce = allreduce; d->user = user;
-	d->chains = ctx->lightOnViewStream && ctx->numViewStreams == kDistChains;
-	d->numComm = d->chains ? kDistChains : 2u;
+	d->chains = ctx->lightOnViewStream && ctx->numViewStreams >= 2u;
+	d->numChains = d->chains ? ctx->numViewStreams : 1u;
+	d->numComm = d->chains ? d->numChains : 2u;
 	ctx->dist = d;
 	return distCommonInit(ctx);
 }
@@ -1932,7 +1955,7 @@ static int distLight(mv_ctx* ctx, uint32_t chain)
 		hipStream_t E = d->chains ? streamB(ctx) : ctx->stream;
 		if (!d->chains) MV_HIP(ctx, evWait(ctx, E, ctx->evLight[ctx->slot]));	// this rank's light march (chains: the same stream)
 		MV_HIP(ctx, evWait(ctx, E, ctx->evStageA[ctx->slot]));	// this frame's cull: the relit volume, its rotated buffer
-		MV_HIP(ctx, evWait(ctx, E, ctx->evMainDone[(ctx->slot + 1u) % kFrameSlots]));	// frame k - 3, the last reader of the buffer the unpack overwrites
+		MV_HIP(ctx, evWait(ctx, E, ctx->evMainDone[(ctx->slot + 1u) % ctx->numSlots]));	// frame k - 3, the last reader of the buffer the unpack overwrites
 		if ((rc = distAllGather(ctx, lightMine, lightAll, d->lightShareBytes, E, d->chains ? (int)chain : 1)) != MV_OK) return rc;
 		mv::launchLightUnpack(E, ctx->st, d->lightWords[chain]);
 		MV_HIP(ctx, hipGetLastError());
@@ -1965,7 +1988,7 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 		if (++n % 200 == 0) { fprintf(stderr, " [cull latency after enqueue: avg %.1f us, max %.1f us]", sum / n, worst); sum = 0; worst = 0; n = 0; }
 	}
 #endif
-	const uint32_t chain = d->chains ? (uint32_t)(ctx->frame % kDistChains) : 0u;
+	const uint32_t chain = d->chains ? (uint32_t)(ctx->frame % d->numChains) : 0u;
 	if (d->chains)
 	{
 		// Whole frames on three view streams.  The ORDER OF THE CALLS is chosen for the two things the host reads from pinned memory

@@ -239,10 +239,10 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	uint32_t* sCost = sRect + 2u * st.V;	// the deal below: estimated march cost of a cube-map volume, 0 once dealt
 
 	// The frame's constants -- CBPerFrame and PerObject[V], what MultiRayCaster::UpdateFrame writes into its upload-heap slice
-	// (MultiRayCaster.cpp:316-353) -- are fetched HERE from the pinned slice the host filled (device-visible host memory): every
-	// wavefront copies CBPerFrame and its own eight PerObjects into LDS with one batch of loads (one trip over PCIe), computes from the
-	// LDS copy, and writes the device copies every later kernel of the frame reads.  There is no upload copy in front of the cull
-	// (round 3: a copy-engine launch was ~3 us of host time and ~6 us of latency at the head of every frame).
+	// (MultiRayCaster.cpp:316-353), uploaded in front of this kernel -- go into LDS first: every wavefront fetches CBPerFrame and its own
+	// eight PerObjects with one batch of coalesced loads and computes from the LDS copy.  (Round 3 also tried fetching them straight
+	// from the pinned host slice, without the upload copy: the cull went from 15 to 30-45 us -- a wavefront's ~30 reads of 64 bytes over
+	// PCIe are served one after the other -- and the cull heads every frame's chain of kernels; the copy engine moves the 4 KB in 4 us.)
 	__shared__ uint32_t sConst[8u * (sizeof(PerObject) / 4u) + 56u];
 	const uint32_t lane = threadIdx.x & 63u;
 	constexpr uint32_t kPoWords = sizeof(PerObject) / 4u, kCbWords = sizeof(CBPerFrame) / 4u;
@@ -250,12 +250,11 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	uint32_t partialHash = 0u;
 	{
 		const uint32_t n = firstVolume < st.V ? (st.V - firstVolume < 8u ? st.V - firstVolume : 8u) : 0u;
-		const uint32_t* src = reinterpret_cast<const uint32_t*>(st.perObjectHost) + (size_t)firstVolume * kPoWords;
-		uint32_t* dst = reinterpret_cast<uint32_t*>(st.perObject) + (size_t)firstVolume * kPoWords;
+		const uint32_t* src = reinterpret_cast<const uint32_t*>(st.perObject) + (size_t)firstVolume * kPoWords;
 		uint32_t w[7];
 #pragma unroll
 		for (uint32_t k = 0; k < 7u; ++k) { const uint32_t i = lane + 64u * k; w[k] = i < n * kPoWords ? src[i] : 0u; }
-		const uint32_t c = lane < kCbWords ? reinterpret_cast<const uint32_t*>(st.cbHost)[lane] : 0u;
+		const uint32_t c = lane < kCbWords ? reinterpret_cast<const uint32_t*>(st.cbPerFrame)[lane] : 0u;
 #pragma unroll
 		for (uint32_t k = 0; k < 7u; ++k)
 		{
@@ -263,13 +262,11 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			sConst[i] = w[k];
 			if (i < n * kPoWords)
 			{
-				dst[i] = w[k];
 				// this wavefront's share of the hash of the frame's transforms (see below): word j of PerObject[V] contributes (w + g (j + 25)) m
 				partialHash ^= (w[k] + 0x9e3779b9u * ((uint32_t)firstVolume * kPoWords + i + 25u)) * 0x85ebca6bu;
 			}
 		}
 		if (lane < 56u) sConst[8u * kPoWords + lane] = c;
-		if (blockIdx.x == 0 && lane < kCbWords) reinterpret_cast<uint32_t*>(st.cbPerFrame)[lane] = c;
 #pragma unroll
 		for (int o = 32; o > 0; o >>= 1) partialHash ^= __shfl_xor(partialHash, o);
 		if (lane == 0 && partialHash) atomicXor(&st.counters[13], partialHash);	// (before this wavefront's ticket; the last one reads the total)
@@ -621,10 +618,10 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 			uint4* p = st.lightTablePrev[v];
 			if (v == relit)
 			{
-				// next of the volume's kLightBuffers buffers, in rotation
-				uint4* first = st.lightBuffers + (size_t)(kLightBuffers * v) * L3;
+				// next of the volume's lightBufs buffers, in rotation
+				uint4* first = st.lightBuffers + (size_t)(st.lightBufs * v) * L3;
 				const uint32_t k = (uint32_t)((size_t)(p - first) / L3);
-				p = first + (size_t)((k + 1u) % kLightBuffers) * L3;
+				p = first + (size_t)((k + 1u) % st.lightBufs) * L3;
 			}
 			st.lightTable[v] = p;
 

@@ -7,9 +7,8 @@
 
 namespace mv
 {
-// Light-map buffers per volume.  The light march of frame i writes the buffer the relit volume's table entry held
-// kLightBuffers relights ago, which no frame after i - kLightBuffers can still be reading.
-constexpr uint32_t kLightBuffers = 3;
+// Light-map buffers per volume: DeviceState.lightBufs (3, or as many as there are frames in flight).  The light march of frame i writes the
+// buffer the relit volume's table entry held lightBufs relights ago, which no frame after i - lightBufs can still be reading.
 
 // One ray of the view march, ready to be marched: the record the ray-setup stage emits and the march stage consumes -- the
 // counterpart of the work-graph variant's RayMarchRecord (Sh/LibRayMarch.hlsl:39-134), at ray instead of tile granularity.
@@ -70,12 +69,11 @@ struct DeviceState
 									// the screen tiles of the fused RayCast are marched for these rows only, for EVERY screen-space-scheme volume
 	uint32_t maxRaySamples, maxLightSamples;
 	uint32_t hasLightProbe;
+	uint32_t lightBufs;				// light-map buffers per volume (see above)
 
 	// per-frame constants (device copies of the reference's upload-heap slices)
-	void* cbPerFrame;				// CBPerFrame, 212 B: device copy, written by the cull from cbHost
-	void* perObject;				// PerObject[V]: device copy, written by the cull from perObjectHost
-	const void* cbHost;				// this frame's pinned upload slice (device-visible host memory; the reference's upload-heap slice,
-	const void* perObjectHost;		//   MultiRayCaster.cpp:128-130, 461-467): only the cull reads it
+	const void* cbPerFrame;			// CBPerFrame, 212 B
+	const void* perObject;			// PerObject[V]
 	const uint32_t* volumeDescs;	// VolumeDesc[V]
 	const float* sh;				// 27 floats
 
@@ -88,10 +86,10 @@ struct DeviceState
 	const uint4* const* alphaCells;	// S pointers to the bricked alpha cells (8 halfs per texel: its 2x2x2 footprint)
 	const uint64_t* const* occupancy;	// S pointers to the brick occupancy words (mv_device.hpp), ceil(bricks / 4)^3 each
 	// Light maps: L^3 quad-replicated R11G11B10F cells {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)} per volume.  Every volume
-	// has kLightBuffers buffers; lightTable[v] is the one this frame reads (and, for the volume relit this frame, writes).
+	// has lightBufs buffers; lightTable[v] is the one this frame reads (and, for the volume relit this frame, writes).
 	// The cull derives it from the previous frame's table and rotates the relit volume's entry, so that the light march
 	// of frames i+1, i+2 can run while the view march / composite of frame i still read frame i's light maps.
-	uint4* lightBuffers;			// kLightBuffers V x L^3 cells: buffer k of volume v at index kLightBuffers v + k
+	uint4* lightBuffers;			// lightBufs V x L^3 cells: buffer k of volume v at index lightBufs v + k
 	uint4** lightTable;				// V pointers (this frame)
 	uint4* const* lightTablePrev;	// V pointers (previous frame)
 	const uint16_t* volumeInfoPrev;	// previous frame's VolumeInfo (rows of culled volumes are carried over: the reference never clears them)

@@ -131,7 +131,7 @@ class MultiRayCaster:
     FrameCount = 3  # MultiRayCaster.h:52
 
     def __init__(self, gridSize, lightGridSize, numVolumes, numVolumeSrcs, viewport, shadowMapSize=1024,
-                 device=0, stream=None, flags=0, shard=(0, 1)):
+                 device=0, stream=None, flags=0, shard=(0, 1), framesInFlight=0):
         """MultiRayCaster::Init (MultiRayCaster.cpp:79-166) + SetViewport (:226-241)."""
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
@@ -141,7 +141,7 @@ class MultiRayCaster:
         self.shadowMapSize = int(shadowMapSize)
         cfg = mv_config(C.sizeof(mv_config), self.gridSize, self.lightGridSize, self.numVolumes, self.numVolumeSrcs,
                         self.viewport[0], self.viewport[1], self.shadowMapSize, int(device), int(flags),
-                        C.c_void_p(stream) if stream else None, int(shard[0]), int(shard[1]))
+                        C.c_void_p(stream) if stream else None, int(shard[0]), int(shard[1]), int(framesInFlight))
         rc = self._lib.mv_create(C.byref(cfg), C.byref(self._ctx))
         if rc != 0:
             self._ctx = C.c_void_p()
