@@ -133,6 +133,7 @@ void  mvo_set_options(int weightBits, int libRayMarch);
 
 int mvo_num_threads(void);
 void mvo_set_num_threads(int n);
+void mvo_parallel_copy(void* dst, const void* src, size_t bytes);	/* first-touch spread of a freshly allocated array over the sockets' memory */
 
 #ifdef __cplusplus
 }

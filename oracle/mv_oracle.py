@@ -55,6 +55,7 @@ def load():
         "mvo_march_light": (_U32, [_U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _U32, _P, _P]),
         "mvo_march_view": (None, [_U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P]),
         "mvo_num_threads": (C.c_int, []), "mvo_set_num_threads": (None, [C.c_int]),
+        "mvo_parallel_copy": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "mvo_unproject_z": (_F, [_F]), "mvo_cube_cast": (None, [_P, _P, _U32, _F, _P, _P, _P]),
         "mvo_cube_face_coords": (None, [_P, C.POINTER(_U32), _P]), "mvo_cube_texel_index": (C.c_uint64, [_U32, C.c_int32, C.c_int32, _U32]),
         "mvo_set_options": (None, [C.c_int, C.c_int]),
@@ -160,6 +161,14 @@ def march_view(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFram
     load().mvo_march_view(V, N, L, W, H, arr, _ptr(lm), _ptr(dm), _ptr(po), _ptr(cb), _ptr(vi), _ptr(cl), len(cl),
                           _ptr(cm), _ptr(cd), C.byref(st))
     return cm, cd, dict(view_samples=int(st.view_samples), lit_samples=int(st.lit_samples), rays=int(st.rays))
+
+
+def spread(a):
+    """A copy of `a` whose pages were first touched by all OpenMP threads (spread over the sockets' memory): for timing runs."""
+    a = np.ascontiguousarray(a)
+    out = np.empty(a.shape, a.dtype)
+    load().mvo_parallel_copy(_ptr(out), _ptr(a), a.nbytes)
+    return out
 
 
 def cube_face_view(chain_array, N, mip):

@@ -55,4 +55,4 @@ for f in $OUT/*bench*.json; do tail -1 $f > $f.tmp 2>/dev/null && mv $f.tmp $f; 
 bash scripts/exp_stage_cost.sh > $OUT/${R}_stage_cost.txt 2>&1
 bash scripts/prof_timeline.sh > $OUT/${R}_timeline_pipelined.txt 2>&1
 grep -h "march" $OUT/${R}_C3_kernel_stats*.csv | cut -d, -f1-4
-for f in $OUT/*bench*.json; do python3 -c "import sys,json; d=json.loads(open('$f').read()); r=d['roofline']; print('$f'.split('/')[-1], round(d['ms_per_step'],4), round(d['value']), 'frac', round(r['frac'],3), 'frac_a3', round(r['frac_a3'],3), 'hbm_frac', r['hbm_frac'] and round(r['hbm_frac'],3), 'launch', round(r['launch_ms'],4), 'in flight', round(r['launch_ms_in_flight'],4))"; done
+for f in $OUT/*bench*.json; do python3 -c "import sys,json; d=json.loads(open('$f').read()); r=d['roofline']; print('$f'.split('/')[-1], round(d['ms_per_step'],4), round(d['value']), 'frac', round(r['frac'],3), 'with fused RayCast', round(r['frac_with_fused_raycast'],3), 'hbm_frac', r['hbm_frac'] and round(r['hbm_frac'],3), 'launch', round(r['launch_ms'],4), 'in flight', round(r['launch_ms_in_flight'],4))"; done

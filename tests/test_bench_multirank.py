@@ -85,4 +85,7 @@ def test_one_rank_bench_line_carries_both_cpu_baselines():
         assert cb["kind"] == "reference" and cb["reference_equals_oracle"] and cb["gpu_vs_reference_max_abs_err"] == 0.0
     else:
         assert cb["kind"] == "port"
-    assert d["roofline"]["frac"] > 0 and d["n_gpus"] == 1
+    r = d["roofline"]
+    assert 0 < r["frac"] <= r["frac_with_fused_raycast"] and 0 <= r["fetch_free_share"] < 1 and d["n_gpus"] == 1
+    assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9, "frac is achieved / peak: SURVEY 8(d)'s algorithmic bytes of the a3 loop over the launch time"
+    assert cb["single_thread"] > 0 and 0 < cb["parallel_efficiency"] <= 1.5
