@@ -223,8 +223,10 @@ __device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId,
 }
 
 // dispatch slot -> tile (wave-uniform: scalar loads and compares).  The eight cursors are the bin totals once the order kernel has run.
-__device__ __forceinline__ uint32_t orderedTile(const DeviceState& st, uint32_t slot)
+// `bin` (optional): the cost bin of the slot, 0 = the longest rays (or tiles never marched before) .. 7 = the shortest; 8 in list order.
+__device__ __forceinline__ uint32_t orderedTile(const DeviceState& st, uint32_t slot, uint32_t* bin = nullptr)
 {
+	if (bin) *bin = 8u;
 	if (!st.tileOrder) return slot;
 	uint32_t base = 0, at = slot;	// (a slot beyond the total -- never dispatched -- maps to itself)
 	bool found = false;
@@ -232,7 +234,7 @@ __device__ __forceinline__ uint32_t orderedTile(const DeviceState& st, uint32_t 
 	for (uint32_t b = 0; b < 8u; ++b)
 	{
 		const uint32_t n = st.binCursor[b];
-		if (!found && slot < base + n) { at = b * st.orderCap + (slot - base); found = true; }
+		if (!found && slot < base + n) { at = b * st.orderCap + (slot - base); found = true; if (bin) *bin = b; }
 		base += n;
 	}
 	return found ? st.tileOrder[at] : slot;

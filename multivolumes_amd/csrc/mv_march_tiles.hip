@@ -31,6 +31,13 @@ constexpr uint32_t kTileWaves = MV_TILE_WAVES;
 typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
 typedef __attribute__((address_space(3))) void* LdsVoidPtr;
 
+#ifndef MV_TILE_PRIORITY
+#define MV_TILE_PRIORITY 0	// s_setprio by cost bin: measured (profiles/r03_view_march_tail.txt), no effect -- the long tiles wait for memory, not for issue slots
+#endif
+#ifndef MV_TILE_PRIORITY_BINS
+#define MV_TILE_PRIORITY_BINS 2	// bins 0 .. n - 1 at priority 3, the next n at 1, the rest at 0
+#endif
+
 static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 {
 #pragma unroll
@@ -75,7 +82,16 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 	// follows marches the rest.
 	for (uint32_t slot = firstSlot + blockIdx.x * kTileWaves + wave; slot < nTiles; slot += OVERFLOW ? gridDim.x * kTileWaves : 0xffffffffu - slot)
 	{
-	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(slot)));
+	uint32_t costBin = 8u;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(slot), &costBin));
+#if MV_TILE_PRIORITY
+	// The launch lasts as long as its longest rays: the tiles of the first cost bins (dispatched first) are on its critical path from
+	// the first microsecond, while the short tiles only have to fit in somewhere.  A wavefront of a long tile therefore raises its
+	// issue priority (s_setprio): on a SIMD shared by five wavefronts its instructions go first, the others fill the gaps.
+	if (costBin < (uint32_t)MV_TILE_PRIORITY_BINS) __builtin_amdgcn_s_setprio(3);
+	else if (costBin < 2u * (uint32_t)MV_TILE_PRIORITY_BINS) __builtin_amdgcn_s_setprio(1);
+	else __builtin_amdgcn_s_setprio(0);
+#endif
 
 	// find the work entry that owns this tile (wave-uniform)
 	uint32_t entry = 0;
