@@ -7,15 +7,15 @@ cd "$(dirname "$0")/.."
 REF=${MV_REFERENCE:-/root/reference}
 CLANG=${CLANG:-/opt/rocm/lib/llvm/bin/clang}
 [ -d "$REF/Bin" ] || { echo "build_ref.sh: $REF/Bin not found: nothing to build"; exit 0; }
-[ -f libmv_oracle.so ] || make libmv_oracle.so
 mkdir -p _ref
 objs=""
-for s in CSRayMarchV CSRayMarchL CSVolumeCull CSInitGridData CSR32FToRGBA16F VSCube PSDepthPeel PSCube PSResolveOIT; do
+for s in CSRayMarchV CSRayMarchL CSVolumeCull CSInitGridData CSR32FToRGBA16F VSCube PSDepthPeel PSCube PSResolveOIT VSDepth VSBasePass; do
   for mode in fp32 fp16; do
     python3 dxil/cso2ll.py "$REF/Bin/$s.cso" "dxil_${s}_${mode}" $mode "_ref/${s}_${mode}.ll" "_ref/${s}.dxil.ll"
     "$CLANG" -O1 -fPIC -mf16c -c "_ref/${s}_${mode}.ll" -o "_ref/${s}_${mode}.o" -Wno-override-module
     objs="$objs _ref/${s}_${mode}.o"
   done
 done
-"$CLANG" -O2 -fPIC -shared -o _ref/libmv_dxref.so dxil/dxil_rt.c $objs -L. -lmv_oracle -Wl,-rpath,'$ORIGIN/..' -lm -lpthread
+# (no -lmv_oracle: the runtime answers every resource intrinsic itself, dxil/d3d_sampler.c)
+"$CLANG" -O2 -fPIC -ffp-contract=off -shared -o _ref/libmv_dxref.so dxil/dxil_rt.c dxil/d3d_sampler.c $objs -lm -lpthread
 echo "built oracle/_ref/libmv_dxref.so"

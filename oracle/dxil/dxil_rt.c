@@ -3,10 +3,10 @@
  *   - thread / group ids, resource handles, raw / structured / typed / constant buffer loads and stores: plain memory semantics;
  *   - dx.op.unary / binary / tertiary / dot: IEEE fp32, one operation = one rounding (FMad: see dxref_set_fused_mad);
  *   - wave intrinsics: the lanes of a wavefront run as threads that meet at every wave operation (dxref_dispatch);
- *   - texture sampling, typed texture loads / stores and their format conversion: THE ORACLE'S sampler / format contract
- *     (mvo_sample_*, mvo_f32_to_f16, mvo_pack_r11g11b10f from oracle/mv_oracle.cpp).  This is hardware behaviour that the bytecode
- *     does not contain; comparing the oracle with this library therefore pins the oracle's SHADER LOGIC to the reference's compiled
- *     code, not its sampler model.
+ *   - texture sampling, typed texture loads / stores and their format conversion: oracle/dxil/d3d_sampler.c, a statement of the D3D11.3
+ *     functional specification's addressing / filtering / conversion rules written independently of the oracle's sampler (round 2 answered
+ *     these with the oracle's own mvo_sample_*: oracle-vs-_ref then compared that sampler with itself).  It is still a builder-written
+ *     stand-in for hardware the bytecode does not contain; what it adds is that the oracle's sampler is now checked by a second statement.
  * Only tests/ (and scripts that make fixtures) may use this library. */
 #include <math.h>
 #include <pthread.h>
@@ -15,7 +15,17 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "../mv_oracle.h"
+/* the fixed-function stages: oracle/dxil/d3d_sampler.c, an independent statement of the D3D11.3 functional specification (NOT the oracle's sampler) */
+void d3ds_options(int frac_bits, int r11_truncate);
+float d3ds_f16_to_f32(uint16_t h);
+uint16_t d3ds_f32_to_f16(float f);
+uint32_t d3ds_pack_r11g11b10f(float r, float g, float b);
+void d3ds_sample3d_rgba16f(const uint16_t* tex, uint32_t w, uint32_t h, uint32_t d, const float uvw[3], const int32_t off[3], float out[4]);
+void d3ds_sample3d_r11g11b10f(const uint32_t* tex, uint32_t w, uint32_t h, uint32_t d, const float uvw[3], float out[3]);
+float d3ds_sample3d_r32f(const float* tex, uint32_t w, uint32_t h, uint32_t d, const float uvw[3]);
+float d3ds_point2d_r32f(const float* tex, uint32_t w, uint32_t h, float u, float v);
+float d3ds_cmp2d_d16(const uint16_t* tex, uint32_t w, uint32_t h, float u, float v, float ref);
+void d3ds_cube_footprint(const float dir[3], uint32_t d, uint64_t idx[4], float wgt[4]);
 
 enum { DXR_RAW = 1, DXR_TYPED_BUF = 2, DXR_CBUF = 3, DXR_TEX2D = 4, DXR_TEX3D = 5, DXR_TEX2DARRAY = 6, DXR_SAMPLER = 7, DXR_TEXCUBE = 8 };
 enum { DXF_NONE = 0, DXF_RGBA16F = 1, DXF_R11G11B10F = 2, DXF_R32F = 3, DXF_D16 = 4, DXF_RGBA16U = 5, DXF_R32U = 6, DXF_RGBA32F = 7 };
@@ -150,6 +160,9 @@ static void wave_lane_exit(dxr_wave* w)
 /* ---------------- binding ---------------- */
 void dxref_reset(void) { g_nbind = 0; }
 void dxref_set_fused_mad(int on) { g_fused_mad = on; }
+/* what the specification lets a device do differently in the fixed-function stages: texel coordinates snapped to `frac_bits` fractional
+ * bits (>= 8 allowed; 0 = none), float11 / float10 stores by truncation instead of round-to-nearest-even */
+void dxref_set_sampler_options(int frac_bits, int r11_truncate) { d3ds_options(frac_bits, r11_truncate); }
 int dxref_bind(uint32_t cls, uint32_t range, uint32_t index, int kind, int fmt, void* data, uint32_t w, uint32_t h, uint32_t d, uint32_t stride)
 {
 	if (g_nbind == DXR_MAX_BINDINGS) return -1;
@@ -252,7 +265,7 @@ void rt_getDimensions(dims_t* out, int32_t op, dxr_res* r, int32_t mip)
 	if (r->kind == DXR_RAW) { out->v[0] = (int32_t)r->w; out->v[1] = (int32_t)r->stride; }	/* element count, stride */
 }
 
-/* ---------------- textures: the oracle's sampler / format contract ---------------- */
+/* ---------------- textures: d3d_sampler.c (an independent statement of the D3D11.3 sampler / format rules) ---------------- */
 static void cube_taps(const dxr_res* t, float x, float y, float z, uint64_t idx[4], float w[4]);
 static float cube_texel(const dxr_res* t, uint64_t i, int ch);
 void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, float c0, float c1, float c2, float c3, int32_t o0, int32_t o1, int32_t o2, float lod)
@@ -264,18 +277,18 @@ void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, floa
 	{
 		const float uvw[3] = { c0, c1, c2 };
 		const int32_t off[3] = { o0, o1, o2 };
-		mvo_sample_rgba16f((const uint16_t*)t->data, t->w, uvw, off, out->v);
+		d3ds_sample3d_rgba16f((const uint16_t*)t->data, t->w, t->h, t->d, uvw, off, out->v);
 	}
 	else if (t->kind == DXR_TEX3D && t->fmt == DXF_R11G11B10F)
 	{
 		const float uvw[3] = { c0, c1, c2 };
-		mvo_sample_r11g11b10f((const uint32_t*)t->data, t->w, uvw, out->v);
+		d3ds_sample3d_r11g11b10f((const uint32_t*)t->data, t->w, t->h, t->d, uvw, out->v);
 		out->v[3] = 1.0f;
 	}
 	else if (t->kind == DXR_TEX3D && t->fmt == DXF_R32F)
 	{
 		const float uvw[3] = { c0, c1, c2 };
-		out->v[0] = mvo_sample_r32f_3d((const float*)t->data, t->w, t->h, t->d, uvw);
+		out->v[0] = d3ds_sample3d_r32f((const float*)t->data, t->w, t->h, t->d, uvw);
 		out->v[3] = 1.0f;
 	}
 	else if (t->kind == DXR_TEXCUBE)
@@ -288,7 +301,7 @@ void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, floa
 	}
 	else if (t->kind == DXR_TEX2D && t->fmt == DXF_R32F)
 	{
-		const float v = mvo_sample_point_r32f((const float*)t->data, t->w, t->h, c0, c1);
+		const float v = d3ds_point2d_r32f((const float*)t->data, t->w, t->h, c0, c1);
 		out->v[0] = out->v[1] = out->v[2] = out->v[3] = v;	/* R32F: (r, 0, 0, 1); the shaders read .x only */
 		out->v[1] = out->v[2] = 0.0f; out->v[3] = 1.0f;
 	}
@@ -297,7 +310,7 @@ void rt_sampleLevel_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, floa
 float rt_sampleCmpLevelZero_f32_scalar(dxr_res* t, float u, float v, float ref)
 {
 	if (!t->data) return 0.0f;
-	if (t->kind == DXR_TEX2D && t->fmt == DXF_D16) return mvo_sample_cmp_d16((const uint16_t*)t->data, t->w, u, v, ref);
+	if (t->kind == DXR_TEX2D && t->fmt == DXF_D16) return d3ds_cmp2d_d16((const uint16_t*)t->data, t->w, t->h, u, v, ref);
 	fprintf(stderr, "dxil_rt: sampleCmpLevelZero on kind %d format %d\n", t->kind, t->fmt); abort();
 }
 void rt_sampleCmpLevelZero_f32(ret_f32* out, int32_t op, dxr_res* t, dxr_res* smp, float c0, float c1, float c2, float c3, int32_t o0, int32_t o1, int32_t o2, float ref)
@@ -316,8 +329,8 @@ void rt_textureStore_f32(int32_t op, dxr_res* t, int32_t x, int32_t y, int32_t z
 	const size_t i = ((size_t)(t->kind == DXR_TEX2D ? 0u : uz) * t->h + uy) * t->w + ux;
 	switch (t->fmt)
 	{
-	case DXF_RGBA16F: { uint16_t* p = (uint16_t*)t->data + 4 * i; p[0] = mvo_f32_to_f16(v0); p[1] = mvo_f32_to_f16(v1); p[2] = mvo_f32_to_f16(v2); p[3] = mvo_f32_to_f16(v3); break; }
-	case DXF_R11G11B10F: ((uint32_t*)t->data)[i] = mvo_pack_r11g11b10f(v0, v1, v2); break;
+	case DXF_RGBA16F: { uint16_t* p = (uint16_t*)t->data + 4 * i; p[0] = d3ds_f32_to_f16(v0); p[1] = d3ds_f32_to_f16(v1); p[2] = d3ds_f32_to_f16(v2); p[3] = d3ds_f32_to_f16(v3); break; }
+	case DXF_R11G11B10F: ((uint32_t*)t->data)[i] = d3ds_pack_r11g11b10f(v0, v1, v2); break;
 	case DXF_R32F: ((float*)t->data)[i] = v0; break;
 	default: fprintf(stderr, "dxil_rt: textureStore on format %d\n", t->fmt); abort();
 	}
@@ -354,7 +367,7 @@ void rt_textureLoad_f32(ret_f32* out, int32_t op, dxr_res* t, int32_t mip, int32
 	switch (t->fmt)
 	{
 	case DXF_R32F: out->v[0] = ((const float*)t->data)[i]; out->v[3] = 1.0f; break;
-	case DXF_RGBA16F: { const uint16_t* p = (const uint16_t*)t->data + 4 * i; for (int c = 0; c < 4; ++c) out->v[c] = mvo_f16_to_f32(p[c]); break; }
+	case DXF_RGBA16F: { const uint16_t* p = (const uint16_t*)t->data + 4 * i; for (int c = 0; c < 4; ++c) out->v[c] = d3ds_f16_to_f32(p[c]); break; }
 	default: fprintf(stderr, "dxil_rt: textureLoad.f32 on format %d\n", t->fmt); abort();
 	}
 }
@@ -383,15 +396,16 @@ int32_t rt_atomicBinOp_i32(int32_t op, dxr_res* t, int32_t aop, int32_t c0, int3
 	}
 	return (int32_t)old;
 }
-/* TextureCube: the oracle's contract for the footprint (face selection, the texel a tap across a face edge resolves to, bilinear weights) */
+/* TextureCube: d3d_sampler.c's statement of the footprint (face selection, bilinear weights; the texel a tap across a face edge resolves to
+ * is implementation-defined in D3D: the contract's rule, restated there) */
 static void cube_taps(const dxr_res* t, float x, float y, float z, uint64_t idx[4], float w[4])
 {
 	const float dir[3] = { x, y, z };
-	mvo_cube_footprint(dir, t->w, idx, w);
+	d3ds_cube_footprint(dir, t->w, idx, w);
 }
 static float cube_texel(const dxr_res* t, uint64_t i, int ch)
 {
-	if (t->fmt == DXF_RGBA16F) return mvo_f16_to_f32(((const uint16_t*)t->data)[4 * i + ch]);
+	if (t->fmt == DXF_RGBA16F) return d3ds_f16_to_f32(((const uint16_t*)t->data)[4 * i + ch]);
 	if (t->fmt == DXF_R32F) return ch == 0 ? ((const float*)t->data)[i] : (ch == 3 ? 1.0f : 0.0f);
 	fprintf(stderr, "dxil_rt: cube map format %d\n", t->fmt); abort();
 }

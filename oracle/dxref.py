@@ -3,7 +3,8 @@ oracle/dxil/cso2ll.py into oracle/_ref/libmv_dxref.so) on the same inputs as the
 that tests can compare the oracle's restatement with the reference's own compiled code.
 
 What is the reference's: control flow, arithmetic, constants, order of operations, early-outs of every shader.
-What is NOT (oracle/dxil/dxil_rt.c): the sampler and the format conversion of typed loads / stores -- the oracle's contract, shared.
+What is NOT: the fixed-function stages -- sampler, format conversion of typed loads / stores -- answered by oracle/dxil/d3d_sampler.c, a
+statement of the D3D11.3 rules written independently of the oracle's sampler (the library does not link libmv_oracle.so).
 Register ranges below are the shaders' own (dx.resources metadata of each .cso, printed by `python oracle/dxil/cso2ll.py`).
 """
 import ctypes as C
@@ -29,8 +30,9 @@ def available():
 def load():
     global _lib
     if _lib is None:
-        O.load()  # libmv_oracle.so first (the runtime links against it)
         lib = C.CDLL(_PATH, mode=C.RTLD_GLOBAL)
+        lib.dxref_set_sampler_options.restype = None
+        lib.dxref_set_sampler_options.argtypes = [C.c_int, C.c_int]
         lib.dxref_bind.restype = C.c_int
         lib.dxref_bind.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.dxref_dispatch.restype = C.c_int
@@ -39,6 +41,12 @@ def load():
         lib.dxref_counter.argtypes = [C.c_uint32] * 3
         _lib = lib
     return _lib
+
+
+def set_sampler_options(frac_bits=0, r11_truncate=False):
+    """What D3D lets a device do differently in the fixed-function stages: texel coordinates snapped to `frac_bits` fractional bits
+    (the specification requires >= 8; 0 = exact fp32 weights, the contract), float11 / float10 stores truncated instead of rounded."""
+    load().dxref_set_sampler_options(int(frac_bits), 1 if r11_truncate else 0)
 
 
 def _bind(cls, rng, index, kind, fmt, arr, w=0, h=0, d=0, stride=0):
@@ -321,6 +329,49 @@ def vs_cube(V, perObject, volumeInfo, visible, mode="fp32"):
     out = np.zeros((n, 8, 4), np.float32)
     assert lib.dxref_run_invocations_full(_entry("VSCube", mode), n, inputs.ctypes.data, out.ctypes.data) == 0
     return out.view(np.uint32).reshape(len(vis), 24, 8, 4)
+
+
+def vs_depth(positions, wvp_t, mode="fp32", fused_mad=False):
+    """VSDepth.cso (the shadow pass's vertex shader, VSDepth.hlsl:24-27) for every vertex: SV_Position [n, 4] float32.
+    wvp_t: the 16 floats the reference stores in cbPerObject (ObjectRenderer.cpp:186: XMStoreFloat4x4 of the TRANSPOSED world x lightViewProj)."""
+    lib = load()
+    lib.dxref_reset()
+    lib.dxref_set_fused_mad(1 if fused_mad else 0)
+    lib.dxref_run_invocations_full.restype = C.c_int
+    lib.dxref_run_invocations_full.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    cb = np.ascontiguousarray(wvp_t, np.float32).reshape(16).view(np.uint8).copy()
+    _bind(CBV, 0, 0, CBUF, F_NONE, cb, len(cb))
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    n = len(pos)
+    inputs = np.zeros((n, 8, 4), np.uint32)
+    inputs[:, 0, :3] = pos.view(np.uint32)  # POSITION; NORMAL (element 1) is not read
+    out = np.zeros((n, 8, 4), np.float32)
+    assert lib.dxref_run_invocations_full(_entry("VSDepth", mode), n, inputs.ctypes.data, out.ctypes.data) == 0
+    return out[:, 0, :].copy()
+
+
+def vs_base_pass(positions, wvp_t, proj_bias=(0.0, 0.0), mode="fp32", fused_mad=False):
+    """VSBasePass.cso (the depth / colour pass's vertex shader, VSBasePass.hlsl:44-60) for every vertex: SV_Position [n, 4] float32 --
+    mul(pos, g_worldViewProj) with `Pos.xy += g_projBias * Pos.w` (the TAA jitter).  cbPerObject (VSBasePass.hlsl:27-34): g_worldViewProj
+    (c0-3), g_worldViewProjPrev (c4-7), g_world float4x3 (c8-10), g_shadowWVP (c11-14), g_projBias (c15.xy); only the first and the last
+    reach SV_Position."""
+    lib = load()
+    lib.dxref_reset()
+    lib.dxref_set_fused_mad(1 if fused_mad else 0)
+    lib.dxref_run_invocations_full.restype = C.c_int
+    lib.dxref_run_invocations_full.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    cbf = np.zeros(64, np.float32)
+    cbf[0:16] = np.asarray(wvp_t, np.float32).reshape(16)
+    cbf[60:62] = proj_bias
+    cb = cbf.view(np.uint8).copy()
+    _bind(CBV, 0, 0, CBUF, F_NONE, cb, len(cb))
+    pos = np.ascontiguousarray(positions, np.float32).reshape(-1, 3)
+    n = len(pos)
+    inputs = np.zeros((n, 8, 4), np.uint32)
+    inputs[:, 0, :3] = pos.view(np.uint32)
+    out = np.zeros((n, 8, 4), np.float32)
+    assert lib.dxref_run_invocations_full(_entry("VSBasePass", mode), n, inputs.ctypes.data, out.ctypes.data) == 0
+    return out[:, 0, :].copy()
 
 
 def rasterised_fragments(V, W, H, perObject, volumeInfo, visible, mode="fp32", subpixel_bits=8):

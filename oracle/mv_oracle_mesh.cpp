@@ -1,8 +1,11 @@
 /*
  * mv_oracle_mesh.cpp -- CPU ORACLE of the mesh depth / shadow rasteriser (test infrastructure, NOT product code).
- * PARITY UNPINNED: the reference draws the mesh with the D3D12 rasteriser (ObjectRenderer.cpp:209-262, VSDepth.hlsl:24-27,
- * VSBasePass.hlsl:44-60); no reference output exists.  Same rules as multivolumes_amd/csrc/mv_mesh.hip: 1/256-pixel
- * snapping, pixel centres at +0.5, top-left rule, both windings, fp32 barycentric z, LESS test on a buffer cleared to 1.0.
+ * PARITY: the VERTEX stage (clipPosition below) is pinned to the reference's shipped compiled vertex shaders -- Bin/VSDepth.cso and
+ * Bin/VSBasePass.cso run on the CPU through oracle/dxil give the same SV_Position bit for bit for every vertex of the reference scene's
+ * mesh (tests/test_oracle_vs_reference_dxil.py::test_mesh_vertex_stage_equals_the_compiled_vertex_shaders).  The RASTER stage is
+ * UNPINNED: the reference draws the mesh with the D3D12 rasteriser (ObjectRenderer.cpp:209-262); no reference output exists.  Its rules
+ * here, the same as multivolumes_amd/csrc/mv_mesh.hip: 1/256-pixel snapping, pixel centres at +0.5, top-left rule, both windings,
+ * fp32 barycentric z, LESS test on a buffer cleared to 1.0.
  */
 #include <math.h>
 #include <stdint.h>
@@ -11,6 +14,26 @@
 extern "C" {
 
 static inline bool topLeft(long long ex, long long ey) { return ey < 0 || (ey == 0 && ex > 0); }
+
+/* VSDepth.hlsl:24-27 / VSBasePass.hlsl:44-60: mul(float4(Pos, 1), g_worldViewProj), then Pos.xy += g_projBias * Pos.w.  As compiled
+ * (Bin/VSDepth.cso, Bin/VSBasePass.cso): m0 x, FMad(y, m1, .), FMad(z, m2, .), + m3 -- with FMad as a multiply and an add that is the
+ * left-to-right sum below; the bias as bias w + xy.  wvpT: the transposed 4x4 the reference stores in cbPerObject. */
+static inline void clipPosition(const float* p, const float* wvpT, float biasX, float biasY, float out[4])
+{
+	const float px = p[0], py = p[1], pz = p[2];
+	float cx = px * wvpT[0] + py * wvpT[1] + pz * wvpT[2] + wvpT[3];
+	float cy = px * wvpT[4] + py * wvpT[5] + pz * wvpT[6] + wvpT[7];
+	const float cz = px * wvpT[8] + py * wvpT[9] + pz * wvpT[10] + wvpT[11];
+	const float cw = px * wvpT[12] + py * wvpT[13] + pz * wvpT[14] + wvpT[15];
+	cx = biasX * cw + cx; cy = biasY * cw + cy;
+	out[0] = cx; out[1] = cy; out[2] = cz; out[3] = cw;
+}
+
+/* the vertex stage alone: SV_Position of every vertex (what VSDepth / VSBasePass output), for the check against the compiled shaders */
+void mvo_mesh_clip_positions(const float* positions, uint32_t numVerts, const float* wvpT, float biasX, float biasY, float* out4)
+{
+	for (uint32_t i = 0; i < numVerts; ++i) clipPosition(positions + 3 * (size_t)i, wvpT, biasX, biasY, out4 + 4 * (size_t)i);
+}
 
 /* depth: W x H floats, pre-cleared by the caller (1.0f); wvpT: transposed 4x4 as the reference stores it */
 void mvo_raster_depth(const float* positions, const uint32_t* indices, uint32_t numTris, const float* wvpT,
@@ -23,13 +46,10 @@ void mvo_raster_depth(const float* positions, const uint32_t* indices, uint32_t 
 		for (int k = 0; k < 3; ++k)
 		{
 			const uint32_t vi = indices[3 * t + k];
-			const float px = positions[3 * vi], py = positions[3 * vi + 1], pz = positions[3 * vi + 2];
-			float cx = px * wvpT[0] + py * wvpT[1] + pz * wvpT[2] + wvpT[3];
-			float cy = px * wvpT[4] + py * wvpT[5] + pz * wvpT[6] + wvpT[7];
-			const float cz = px * wvpT[8] + py * wvpT[9] + pz * wvpT[10] + wvpT[11];
-			const float cw = px * wvpT[12] + py * wvpT[13] + pz * wvpT[14] + wvpT[15];
+			float c[4];
+			clipPosition(positions + 3 * (size_t)vi, wvpT, biasX, biasY, c);
+			const float cx = c[0], cy = c[1], cz = c[2], cw = c[3];
 			if (!(cw > 0.0f)) { drop = true; break; }
-			cx += biasX * cw; cy += biasY * cw;
 			const float nx = cx / cw, ny = cy / cw;
 			sx[k] = (nx * 0.5f + 0.5f) * (float)W;
 			sy[k] = (1.0f - (ny * 0.5f + 0.5f)) * (float)H;

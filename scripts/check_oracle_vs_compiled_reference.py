@@ -1,5 +1,8 @@
 """The oracle against the reference's shipped compiled shaders (oracle/_ref, see oracle/dxil) at the BASELINE configs' full sizes, on the
-CPU: run where /root/reference exists (`make -C oracle ref` first).  tests/test_oracle_vs_reference_dxil.py holds the small cases."""
+CPU: run where /root/reference exists (`make -C oracle ref` first).  tests/test_oracle_vs_reference_dxil.py holds the small cases.
+Since round 3 the fixed-function stages inside oracle/_ref are oracle/dxil/d3d_sampler.c, a statement independent of the oracle's
+sampler: "identical" below therefore also says that the two sampler statements agree on every fetch of the frame.  The last lines
+report what the device-dependent switches of that statement move (8-bit texel coordinates, truncating float11 / float10 stores)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -41,3 +44,20 @@ for name in sys.argv[1:] or ["C2", "C3"]:
     img, _ = o.composite(*args)
     got = dxref.composite(*args)
     print(f"{name}: composite at {W2}x{H2}: {int((got != img).sum())} of {img.size} halves differ, {int((img[..., 3] != 0).sum())} covered pixels  ({time.time() - t0:.0f} s)", flush=True)
+    # what D3D lets a device do differently in the fixed-function stages, through the reference's compiled shaders
+    dxref.set_sampler_options(frac_bits=8)
+    sm, _ = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, i0, c0)
+    dxref.set_sampler_options()
+    a = np.concatenate([o.cube_face_view(rm[v], N, int(i0[v, 0])).reshape(-1) for v in c0]).view(np.float16).astype(np.float32)
+    b = np.concatenate([o.cube_face_view(sm[v], N, int(i0[v, 0])).reshape(-1) for v in c0]).view(np.float16).astype(np.float32)
+    dd = np.abs(a - b)
+    print(f"{name}: texel coordinates snapped to 8 fractional bits (the D3D minimum): max |d| {dd.max():.3g}, mean {dd.mean():.3g}, {100.0 * (dd > 1e-3).mean():.2f} % of the marched halves beyond 1e-3, {100.0 * (dd > 0).mean():.1f} % moved at all", flush=True)
+    dxref.set_sampler_options(r11_truncate=True)
+    _, _, _, cbf, pof = host_frame(cfg, 0)
+    lt = dxref.march_light(V, N, L, M, vols, descs, pof, cbf, shadow, None, v0, cfg["maxLight"], np.zeros((V, L, L, L), np.uint32))
+    dxref.set_sampler_options()
+    lr = dxref.march_light(V, N, L, M, vols, descs, pof, cbf, shadow, None, v0, cfg["maxLight"], np.zeros((V, L, L, L), np.uint32))
+    vid = int(v0[0])
+    t_, r_ = lt[vid].astype(np.int64), lr[vid].astype(np.int64)
+    moved = [float((((r_ >> sh) & ((1 << bits) - 1)) != ((t_ >> sh) & ((1 << bits) - 1))).mean()) for sh, bits in ((0, 11), (11, 11), (22, 10))]
+    print(f"{name}: float11 / float10 stores truncated instead of rounded to nearest even: {100 * moved[0]:.0f} % / {100 * moved[1]:.0f} % / {100 * moved[2]:.0f} % of the R / G / B fields of a light map one unit lower  ({time.time() - t0:.0f} s)", flush=True)

@@ -3,8 +3,10 @@ by oracle/dxil into oracle/_ref/libmv_dxref.so; `make -C oracle ref`, also run b
 
 What this pins: the oracle's SHADER LOGIC -- control flow, arithmetic, constants (min16float constants as the compiler folded them),
 order of operations, early-outs -- to the reference's own compiled code for a1 (CSVolumeCull), a2 (CSRayMarchL) and a3 (CSRayMarchV).
-What it does not: the fixed-function sampler and the format conversion of typed loads / stores, which the bytecode does not contain and
-which oracle/dxil/dxil_rt.c answers with the oracle's own contract.  The translation runs the shaders in IEEE fp32 with min16float
+What it does not pin to the reference: the fixed-function sampler and the format conversion of typed loads / stores, which the bytecode
+does not contain.  Inside the library they are answered by oracle/dxil/d3d_sampler.c -- a statement of the D3D11.3 rules written
+independently of the oracle's sampler (round 3; round 2 used the oracle's own functions there) -- so every comparison below also checks
+the oracle's sampler against a second statement; test_sampler_statements_* compare the two directly.  The translation runs the shaders in IEEE fp32 with min16float
 values carried at 32 bits (as WARP and most GPUs do), FMad with two roundings, no reassociation.
 
 Skipped when oracle/_ref is absent (it cannot be built without /root/reference); tests/test_golden.py::test_oracle_reproduces_dxil_golden
@@ -249,3 +251,167 @@ def test_random_close_cameras_against_the_compiled_shaders(oracle, seed):
         schemes |= {bool(int(info[v, 2]) & 0x8000) for v in vis}
         inside += r < 14.0
     print(f"seed {seed}: schemes seen (cube map = True) {sorted(schemes)}, close-up cameras {inside}")
+
+
+# ---- the two statements of the fixed-function stages, compared directly: oracle/mv_oracle.cpp (mvo_*) and oracle/dxil/d3d_sampler.c (d3ds_*) ----
+import ctypes as C
+
+
+def _d3ds():
+    lib = dxref.load()
+    lib.d3ds_sample3d_rgba16f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.d3ds_sample3d_r11g11b10f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    lib.d3ds_point2d_r32f.restype = C.c_float
+    lib.d3ds_point2d_r32f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+    lib.d3ds_cmp2d_d16.restype = C.c_float
+    lib.d3ds_cmp2d_d16.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_float]
+    lib.d3ds_f32_to_f16.restype = C.c_uint16
+    lib.d3ds_f32_to_f16.argtypes = [C.c_float]
+    lib.d3ds_f16_to_f32.restype = C.c_float
+    lib.d3ds_f16_to_f32.argtypes = [C.c_uint16]
+    lib.d3ds_pack_r11g11b10f.restype = C.c_uint32
+    lib.d3ds_pack_r11g11b10f.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.d3ds_cube_footprint.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _bits(x):
+    return np.asarray(x, np.float32).view(np.uint32)
+
+
+def test_sampler_statements_agree_on_formats(oracle):
+    """fp16 <-> fp32 over every half and over floats around every rounding boundary; R11G11B10F packing of values across the range
+    (denormals, halfway cases, overflow, negative, inf, NaN): the two statements give the same bits."""
+    d, o = _d3ds(), oracle.load()
+    o.mvo_f16_to_f32.restype = C.c_float
+    o.mvo_f16_to_f32.argtypes = [C.c_uint16]
+    o.mvo_f32_to_f16.restype = C.c_uint16
+    o.mvo_f32_to_f16.argtypes = [C.c_float]
+    o.mvo_pack_r11g11b10f.restype = C.c_uint32
+    o.mvo_pack_r11g11b10f.argtypes = [C.c_float, C.c_float, C.c_float]
+    for h in range(0, 65536, 3):
+        a, b = d.d3ds_f16_to_f32(h), o.mvo_f16_to_f32(h)
+        assert _bits(a) == _bits(b) or (a != a and b != b), h
+        if a == a:
+            # the half itself, the float just below / above it, and the midpoint to the next half
+            for f in (a, np.nextafter(np.float32(a), np.float32(np.inf)), np.nextafter(np.float32(a), np.float32(-np.inf)),
+                      np.float32((np.float64(a) + np.float64(d.d3ds_f16_to_f32((h + 1) & 0xffff))) / 2) if (h & 0x7c00) != 0x7c00 and ((h + 1) & 0x7c00) != 0x7c00 else np.float32(a)):
+                assert d.d3ds_f32_to_f16(float(f)) == o.mvo_f32_to_f16(float(f)), (h, float(f))
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([rng.uniform(-2, 70000, 4000), 10.0 ** rng.uniform(-9, 5, 4000), [0.0, -0.0, np.inf, -np.inf, np.nan, 65024.0, 65025.0, 64512.0, 6.1e-5, 3.0e-5, 1e-7]]).astype(np.float32)
+    for i in range(0, len(vals) - 2):
+        r, g, b = float(vals[i]), float(vals[i + 1]), float(vals[i + 2])
+        assert d.d3ds_pack_r11g11b10f(r, g, b) == o.mvo_pack_r11g11b10f(r, g, b), (r, g, b)
+
+
+def test_sampler_statements_agree_on_fetches(oracle):
+    """Trilinear RGBA16F (with the gradient taps' texel offsets) and R11G11B10F fetches, the point fetch, the D16 comparison fetch and
+    the cube-map footprint at random coordinates -- inside, on texel centres and edges, outside [0, 1] -- on random textures: the
+    oracle's sampler and the independent statement return the same bits."""
+    d, o = _d3ds(), oracle.load()
+    o.mvo_sample_rgba16f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+    o.mvo_sample_r11g11b10f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    o.mvo_sample_point_r32f.restype = C.c_float
+    o.mvo_sample_point_r32f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float]
+    o.mvo_sample_cmp_d16.restype = C.c_float
+    o.mvo_sample_cmp_d16.argtypes = [C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_float]
+    o.mvo_cube_footprint.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(9)
+    for N in (5, 16, 33):
+        vol = rng.uniform(0, 4, (N, N, N, 4)).astype(np.float16).view(np.uint16)
+        vol[rng.integers(0, N, 20), rng.integers(0, N, 20), rng.integers(0, N, 20)] = rng.integers(0, 0x0400, (20, 4))  # denormal halves
+        lm = rng.integers(0, 2 ** 32, (N, N, N), dtype=np.uint64).astype(np.uint32) & 0x7FDFFBFF  # (top exponent bit of every field clear: finite values)
+        coords = np.concatenate([rng.uniform(-0.3, 1.3, (600, 3)), (rng.integers(0, N + 1, (200, 3)) + rng.choice([0.0, 0.5], (200, 3))) / N]).astype(np.float32)
+        for k, uvw in enumerate(coords):
+            off = np.array([[0, 0, 0], [1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]][k % 7], np.int32)
+            a, b = np.zeros(4, np.float32), np.zeros(4, np.float32)
+            o.mvo_sample_rgba16f(vol.ctypes.data, N, uvw.ctypes.data, off.ctypes.data, a.ctypes.data)
+            d.d3ds_sample3d_rgba16f(vol.ctypes.data, N, N, N, uvw.ctypes.data, off.ctypes.data, b.ctypes.data)
+            assert np.array_equal(_bits(a), _bits(b)), (N, uvw, off, a, b)
+            a3, b3 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+            o.mvo_sample_r11g11b10f(lm.ctypes.data, N, uvw.ctypes.data, a3.ctypes.data)
+            d.d3ds_sample3d_r11g11b10f(lm.ctypes.data, N, N, N, uvw.ctypes.data, b3.ctypes.data)
+            assert np.array_equal(_bits(a3), _bits(b3)), (N, uvw, a3, b3)
+    W, H, M = 37, 21, 19
+    depth = rng.uniform(0, 1, (H, W)).astype(np.float32)
+    shadow = rng.integers(0, 65536, (M, M)).astype(np.uint16)
+    for _ in range(800):
+        u, v, ref = (float(np.float32(x)) for x in rng.uniform(-0.2, 1.2, 3))
+        assert _bits(o.mvo_sample_point_r32f(depth.ctypes.data, W, H, u, v)) == _bits(d.d3ds_point2d_r32f(depth.ctypes.data, W, H, u, v))
+        assert _bits(o.mvo_sample_cmp_d16(shadow.ctypes.data, M, u, v, ref)) == _bits(d.d3ds_cmp2d_d16(shadow.ctypes.data, M, M, u, v, ref))
+    for dsz in (4, 32):
+        for _ in range(600):
+            dirv = rng.normal(size=3).astype(np.float32)
+            if rng.random() < 0.3:
+                dirv[rng.integers(0, 3)] = np.float32(rng.choice([-1.0, 1.0])) * np.abs(dirv).max()  # on / near a cube edge
+            i0, i1 = np.zeros(4, np.uint64), np.zeros(4, np.uint64)
+            w0, w1 = np.zeros(4, np.float32), np.zeros(4, np.float32)
+            o.mvo_cube_footprint(dirv.ctypes.data, dsz, i0.ctypes.data, w0.ctypes.data)
+            d.d3ds_cube_footprint(dirv.ctypes.data, dsz, i1.ctypes.data, w1.ctypes.data)
+            assert np.array_equal(i0, i1) and np.array_equal(_bits(w0), _bits(w1)), (dsz, dirv)
+
+
+def test_what_the_device_switches_of_the_sampler_move(oracle):
+    """What D3D allows a device to do differently in the fixed-function stages, measured through the reference's compiled shaders on the
+    T1 frame: (a) texel coordinates snapped to 8 fractional bits (the specification's minimum precision) -- single rays take other
+    samples, the bulk does not move; (b) float11 / float10 stores truncated instead of rounded to nearest even -- light-map words drop
+    by at most one unit in the last place, never rise."""
+    cfg = dict(scene.CONFIGS["T1"])
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    ref = oracle_pipeline(oracle, cfg, vols, 32)
+    args = (V, N, L, cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], ref["info"], ref["cube"])
+    try:
+        base, _ = dxref.march_view(*args)
+        dxref.set_sampler_options(frac_bits=8)
+        snapped, _ = dxref.march_view(*args)
+        dxref.set_sampler_options(r11_truncate=True)
+        lm_t = dxref.march_light(V, N, L, 32, vols, ref["descs"], ref["po"], ref["cb"], ref["shadow"], None, ref["vis"], cfg["maxLight"], None)
+        dxref.set_sampler_options()
+        lm_r = dxref.march_light(V, N, L, 32, vols, ref["descs"], ref["po"], ref["cb"], ref["shadow"], None, ref["vis"], cfg["maxLight"], None)
+    finally:
+        dxref.set_sampler_options()
+    v = int(ref["cube"][0])
+    mip = int(ref["info"][v, 0])
+    a = half_to_float(oracle.cube_face_view(base[v], N, mip)); b = half_to_float(oracle.cube_face_view(snapped[v], N, mip))
+    diff = np.abs(a - b)
+    assert 0 < (diff > 0).mean() and np.median(diff) < 1e-3, "8-bit texel coordinates move texels, by little"
+    frame_idx = int(np.frombuffer(np.ascontiguousarray(ref["cb"]).tobytes()[208:212], np.uint32)[0])
+    relit = int(ref["vis"][frame_idx % len(ref["vis"])])  # CSRayMarchL.hlsl:29-33
+    t, r = lm_t[relit].astype(np.int64), lm_r[relit].astype(np.int64)
+    for shift, bits in ((0, 11), (11, 11), (22, 10)):
+        ct, cr = (t >> shift) & ((1 << bits) - 1), (r >> shift) & ((1 << bits) - 1)
+        assert np.all((cr - ct >= 0) & (cr - ct <= 1)), "truncation never rounds up, and differs from nearest-even by at most one unit"
+        assert (cr != ct).any()
+
+
+def test_mesh_vertex_stage_equals_the_compiled_vertex_shaders(oracle):
+    """Row f2's vertex math pinned like VSCube pinned the composite's: Bin/VSDepth.cso (shadow pass) and Bin/VSBasePass.cso (depth pass,
+    with and without the TAA jitter g_projBias) run for every vertex of the reference scene's mesh (bunny.obj at 0 -9 0 x 1.8,
+    Bin/all16.bat:1) give the SV_Position of the oracle's vertex stage (oracle/mv_oracle_mesh.cpp clipPosition, what mvo_raster_depth
+    and -- bit for bit, tests/test_mesh.py -- the HIP rasteriser transform with) bit for bit."""
+    import ctypes as C
+    mesh = scene.load_bunny()
+    pos = np.ascontiguousarray(mesh[0], np.float32).reshape(-1, 3)
+    assert len(pos) > 30000
+    lib = oracle.load()
+    lib.mvo_mesh_clip_positions.restype = None
+    lib.mvo_mesh_clip_positions.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_float, C.c_float, C.c_void_p]
+    cfg = scene.CONFIGS["C3"]
+    _, vp = scene.camera(cfg)
+    wvp, swvp = scene.mesh_matrices(cfg, vp)   # row-major world x viewProj, world x lightViewProj (ObjectRenderer.cpp:171-207)
+    wvp_depth = np.ascontiguousarray(rc.transpose_store(wvp), np.float32).reshape(16)    # as stored in cbPerObject (transposed)
+    wvp_shadow = np.ascontiguousarray(rc.transpose_store(swvp), np.float32).reshape(16)
+
+    def oracle_clip(m, bias):
+        out = np.zeros((len(pos), 4), np.float32)
+        lib.mvo_mesh_clip_positions(pos.ctypes.data, len(pos), m.ctypes.data, bias[0], bias[1], out.ctypes.data)
+        return out
+
+    got = dxref.vs_depth(pos, wvp_shadow)
+    assert np.array_equal(got.view(np.uint32), oracle_clip(wvp_shadow, (0.0, 0.0)).view(np.uint32)), "VSDepth.cso"
+    for bias in ((0.0, 0.0), (0.5 / cfg["W"], -0.25 / cfg["H"])):
+        got = dxref.vs_base_pass(pos, wvp_depth, bias)
+        want = oracle_clip(wvp_depth, bias)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"VSBasePass.cso, projBias {bias}: {(got != want).sum()} components differ"
+    assert (got[:, 3] > 0).all(), "the mesh is in front of the camera"
