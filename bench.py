@@ -458,10 +458,10 @@ def main():
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
-                "parallelism": f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, one light map all-reduced per frame; frame loop inside the library (mv_dist_frame), transport: {exchange}" if world > 1 else "single GPU",
+                "parallelism": f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, the frame's light march shared out by voxel blocks + all-gather of the shares; frame loop inside the library (mv_dist_frame), transport: {exchange}" if world > 1 else "single GPU",
                 "frames_in_flight": ("up to 3 whole frames (light march, view march, composite) on 3 view streams; constants / cull 4 slots, march outputs 3 sets, light maps 3 buffers per volume" if world == 1
                                      else "upload + cull + light march ahead of the view march / exchange / composite stream" if args.dist_single_stream
-                                     else "up to 3 whole frames (light march + light-map all-reduce, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
+                                     else "up to 3 whole frames (light-march share + all-gather, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes_timed // max(1, K),
                 "transport": exchange, "fallback_level": int(os.environ.get("MV_BENCH_LEVEL", "0")),

@@ -262,24 +262,29 @@ int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim);
 
 /* ---- multi-GPU frame loop inside the library: one process per GPU, context r of `shard_count` = rank r ----
  * mv_dist_frame runs the whole per-frame protocol without Python and without a host wait on work of the current frame:
- *   frame k:   constant upload, cull, light march (owner of the relit volume), light-map exchange (an all-reduce of that ONE map as
- *              R11G11B10F words, 4 L^3 bytes: every rank keeps every light map current, because every rank marches its own screen
- *              rows of every volume on the screen-space scheme), view march of the owned volumes;
- *   frame k-1: pack the marched faces of the owned cube-map volumes -> all-gather -> unpack -> composite of this rank's rows ->
+ *   frame k:   constant upload, cull; the light march of the ONE volume relit this frame (CSRayMarchL.hlsl:29-33) SHARED OUT over the ranks
+ *              by 4x4x4 voxel blocks -- every rank holds every volume and marches 1 / shard_count of the blocks of the march's dispatch
+ *              order -- and the shares all-gathered as plain R11G11B10F words (4 L^3 bytes in all), so that every rank keeps every light
+ *              map current (every rank marches its own screen rows of every volume on the screen-space scheme); the view march of the
+ *              cube-map volumes the cull dealt to this rank and of its rows of the screen-space volumes;
+ *   frame k-1: pack the marched faces of this rank's cube-map volumes -> all-gather -> unpack -> composite of this rank's rows ->
  *              all-gather of the row bands.
- * The sizes of frame k-1's collectives come from its cull results, which reached the host a frame ago.  The composite of frame k is
- * therefore complete after the NEXT mv_dist_frame (or mv_dist_flush).  Results equal the single-GPU frame bit for bit.
+ * The size of frame k-1's cube-face all-gather comes from its cull, which left it in pinned host memory a call ago (no copy, no event).
+ * The composite of frame k is therefore complete after the NEXT mv_dist_frame (or mv_dist_flush).  Results equal the single-GPU frame
+ * bit for bit.
  * Inside the loop the replicated cull deals the frame's work: cube-map volumes to ranks by estimated march cost (not v % shard_count),
  * screen rows by 8-row tile row t % shard_count (not mv_shard_rows' contiguous band).  The composite image is stored rank-major --
  * tile row t at block t % shard_count, row t / shard_count, blocks of ceil(tile rows / shard_count) tile rows -- so that the row gather
  * is one in-place all-gather; mv_readback_composite returns screen order.
  * Two schedules, chosen by the context's flags:
- *   MV_FLAG_PIPELINE_FRAMES                               whole frames on three view streams ("chains"): everything of frame k, its
- *       collectives included, goes on view stream k % 3 with communicator k % 3 -- frames overlap as wholes, which a rank needs once
- *       its share of a frame no longer fills the GPU (the default of bench.py);
+ *   MV_FLAG_PIPELINE_FRAMES                               whole frames on C view streams ("chains"; C = mv_config.frames_in_flight, 3 by
+ *       default): everything of frame k, its collectives included, goes on view stream k % C with communicator k % C -- frames overlap
+ *       as wholes, which a rank needs once its share of a frame no longer fills the GPU (the default of bench.py);
  *   MV_FLAG_PIPELINE_FRAMES | MV_FLAG_SINGLE_VIEW_STREAM  the view marches on one stream, frame k-1's exchange + composite on a second
  *       one beside frame k's march; communicator 0 = cube faces / rows, 1 = light maps.
- * Transport: RCCL (the library opens librccl.so itself; three communicators, two used without chains) or caller-supplied collectives
+ * Input setters called between two mv_dist_frame calls first enqueue the pending tail of the last frame (collectives: every rank must
+ * make the same calls at the same point), so that frame is composited against the inputs it was begun with.
+ * Transport: RCCL (the library opens librccl.so itself; one communicator per chain, two without chains) or caller-supplied collectives
  * (tests, other fabrics). */
 #define MV_DIST_ID_BYTES 640	/* five RCCL unique ids (one per communicator; the loop uses as many as the context has frames in flight) */
 int mv_dist_rccl_available(void);	/* 1 if librccl.so and every entry point the loop needs can be opened in this process: a LOCAL check, so that the ranks can
@@ -288,9 +293,10 @@ int mv_dist_rccl_available(void);	/* 1 if librccl.so and every entry point the l
 int mv_dist_unique_id(void* out /* MV_DIST_ID_BYTES; call on rank 0, hand the bytes to every rank */);
 int mv_dist_init_rccl(mv_ctx* ctx, const void* id /* MV_DIST_ID_BYTES, the same on every rank */);
 /* all-gather: every rank contributes `bytes` from `send`; `recv` receives shard_count x bytes in rank order.  all-reduce: in-place
- * integer sum of `count` uint32.  `stream` is the hipStream_t the collective must be ordered on; which = 0, 1 or 2 names the
- * communicator: collectives with different `which` run on different streams at the same time and need separate communicators
- * (chains: `which` = frame % 3; single view stream: 0 = cube faces / rows, 1 = light maps).  Return 0 on success. */
+ * integer sum of `count` uint32 (the frame loop itself only gathers since ABI 4; the self-test still checks it).  `stream` is the
+ * hipStream_t the collective must be ordered on; which = 0 .. frames_in_flight - 1 names the communicator: collectives with different
+ * `which` run on different streams at the same time and need separate communicators (chains: `which` = frame % frames_in_flight;
+ * single view stream: 0 = cube faces / rows, 1 = light maps).  Return 0 on success. */
 typedef int (*mv_dist_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* stream, int which);
 typedef int (*mv_dist_allreduce_u32_fn)(void* user, void* buf, size_t count, void* stream, int which);
 int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user);

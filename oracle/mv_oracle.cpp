@@ -837,6 +837,11 @@ void mvo_cull(uint32_t V, const void* perObjectBytes, const uint32_t* volumeDesc
 // ---------------------------------------------------------------------------------------------
 // a2: CSRayMarchL.hlsl:20-121
 // ---------------------------------------------------------------------------------------------
+// Share of the light march a caller wants (the multi-GPU loop shares the voxel blocks of the relit map out over the ranks): only voxels of
+// the 4x4x4 blocks [lo, hi), numbered x fastest, are marched and written.  Default: all.
+static uint32_t g_lightBlockLo = 0u, g_lightBlockHi = 0xffffffffu;
+void mvo_set_light_block_range(uint32_t lo, uint32_t hi) { g_lightBlockLo = lo; g_lightBlockHi = hi; }
+
 uint32_t mvo_march_light(uint32_t V, uint32_t N, uint32_t L, uint32_t M,
 	const uint16_t* const* volumes, const uint32_t* volumeDescs,
 	const void* perObjectBytes, const void* cbBytes, const uint16_t* shadowMap,
@@ -865,6 +870,10 @@ uint32_t mvo_march_light(uint32_t V, uint32_t N, uint32_t L, uint32_t M,
 		for (uint32_t yy = 0; yy < L; ++yy)
 			for (uint32_t xx = 0; xx < L; ++xx)
 			{
+				{
+					const uint32_t B = (L + 3u) >> 2, b = (((uint32_t)zz >> 2) * B + (yy >> 2)) * B + (xx >> 2);
+					if (b < g_lightBlockLo || b >= g_lightBlockHi) continue;
+				}
 				uint64_t nS = 0;
 				float3 rayOrigin = f3(((float)xx + 0.5f) / gridSize * 2.0f - 1.0f,
 					((float)yy + 0.5f) / gridSize * 2.0f - 1.0f,

@@ -133,6 +133,7 @@ void  mvo_set_options(int weightBits, int libRayMarch);
 
 int mvo_num_threads(void);
 void mvo_set_num_threads(int n);
+void mvo_set_light_block_range(uint32_t lo, uint32_t hi);	/* mvo_march_light marches the 4x4x4 voxel blocks [lo, hi) only (x fastest); default all */
 void mvo_parallel_copy(void* dst, const void* src, size_t bytes);	/* first-touch spread of a freshly allocated array over the sockets' memory */
 
 #ifdef __cplusplus

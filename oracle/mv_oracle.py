@@ -56,6 +56,7 @@ def load():
         "mvo_march_view": (None, [_U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P]),
         "mvo_num_threads": (C.c_int, []), "mvo_set_num_threads": (None, [C.c_int]),
         "mvo_parallel_copy": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+        "mvo_set_light_block_range": (None, [_U32, _U32]),
         "mvo_unproject_z": (_F, [_F]), "mvo_cube_cast": (None, [_P, _P, _U32, _F, _P, _P, _P]),
         "mvo_cube_face_coords": (None, [_P, C.POINTER(_U32), _P]), "mvo_cube_texel_index": (C.c_uint64, [_U32, C.c_int32, C.c_int32, _U32]),
         "mvo_set_options": (None, [C.c_int, C.c_int]),

@@ -118,6 +118,7 @@ def test_two_rank_gloo_pipeline_matches_single_process(oracle, tmp_path):
     vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
     ref = oracle_pipeline(oracle, cfg, vols, 32)
     assert np.array_equal(got["lms"], ref["lightMaps"]), "per-shard relighting must produce the same light maps"
+    assert np.array_equal(got["lms"], ref["lightMaps"]), "the light march shared out by voxel blocks assembles the single-process light maps"
     assert np.array_equal(got["cm"], ref["cubeMaps"]) and np.array_equal(got["cd"], ref["cubeDepths"])
     img, _ = oracle.composite(cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"],
                               ref["info"], ref["vis"], ref["cubeMaps"], ref["cubeDepths"])
@@ -180,8 +181,38 @@ def _worker_dealt(rank, world, port, out_path):
         cfg = dict(scene.CONFIGS["T1"], W=96, H=88)
         V, N, L, W, H = cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"]
         vols = [rc.synth_volume(N, k) for k in range(V)]
-        ref = oracle_pipeline(o, cfg, vols, 32, eye=(24.0, 16.0, -52.0))   # light maps: every rank holds them all (the loop's all-reduce)
+        eye = (24.0, 16.0, -52.0)
+        ref = oracle_pipeline(o, cfg, vols, 32, frames=V - 1, eye=eye)   # every frame but the last: all ranks hold every light map
         info, vis, cube, lms = ref["info"], ref["vis"], ref["cube"], ref["lightMaps"]
+        # The LAST frame's light march, shared out like the loop's: every rank marches its 1 / world of the 4x4x4 voxel blocks of the relit
+        # map (every rank holds every volume), the shares are all-gathered as plain words, 64 per block, and every rank assembles the map.
+        _, _, _, cb_last, po_last = host_frame(cfg, V - 1, eye)
+        B = (L + 3) // 4
+        total = B * B * B
+        per = (total + world - 1) // world
+        lo, hi = min(rank * per, total), min((rank + 1) * per, total)
+        o.load().mvo_set_light_block_range(lo, hi)
+        mine_lm = np.zeros_like(lms)
+        relit, mine_lm, _ = o.march_light(V, N, L, 32, vols, ref["descs"], po_last, cb_last, ref["shadow"], None, vis, cfg["maxLight"], mine_lm)
+        o.load().mvo_set_light_block_range(0, 0xffffffff)
+
+        def block_voxels(b):
+            bx, by, bz = b % B, (b // B) % B, b // (B * B)
+            z, y, x = np.meshgrid(np.arange(bz * 4, bz * 4 + 4), np.arange(by * 4, by * 4 + 4), np.arange(bx * 4, bx * 4 + 4), indexing="ij")
+            ok = (z < L) & (y < L) & (x < L)
+            return z, y, x, ok
+
+        share = np.zeros((per, 64), np.uint32)
+        for b in range(lo, hi):
+            z, y, x, ok = block_voxels(b)
+            share[b - lo].reshape(4, 4, 4)[ok] = mine_lm[relit][z[ok], y[ok], x[ok]]
+        words = torch.empty(world * per * 64, dtype=torch.int32)
+        dist.all_gather_into_tensor(words, torch.from_numpy(share.view(np.int32).ravel().copy()))
+        words = words.numpy().view(np.uint32).reshape(world * per, 64)
+        for b in range(total):
+            z, y, x, ok = block_voxels(b)
+            lms[relit][z[ok], y[ok], x[ok]] = words[b].reshape(4, 4, 4)[ok]
+        ref = dict(ref, cb=cb_last, po=po_last)
         owner = D.deal_cube_volumes(info, vis, V, N, world)
         mine = [int(v) for v in cube if owner[int(v)] == rank]
         cm, cd, st = o.march_view(V, N, L, W, H, vols, lms, ref["depth"], ref["po"], ref["cb"], info, mine)
@@ -237,7 +268,7 @@ def _worker_dealt(rank, world, port, out_path):
         samples = torch.tensor([st["view_samples"], st["rays"]], dtype=torch.int64)
         dist.all_reduce(samples)
         if rank == 0:
-            np.savez(out_path, full=full, cm=cm, cd=cd, samples=samples.numpy(), owner=owner)
+            np.savez(out_path, full=full, cm=cm, cd=cd, samples=samples.numpy(), owner=owner, lms=lms)
     finally:
         dist.destroy_process_group()
 
@@ -256,6 +287,7 @@ def test_gloo_protocol_with_the_loops_work_deal(oracle, tmp_path, world):
     vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
     ref = oracle_pipeline(oracle, cfg, vols, 32, eye=(24.0, 16.0, -52.0))
     assert len(ref["cube"]) >= 2 and len(set(int(got["owner"][int(v)]) for v in ref["cube"])) >= 2, "the frame's volumes must be spread over ranks"
+    assert np.array_equal(got["lms"], ref["lightMaps"]), "the light march shared out by voxel blocks assembles the single-process light maps"
     assert np.array_equal(got["cm"], ref["cubeMaps"]) and np.array_equal(got["cd"], ref["cubeDepths"])
     img, _ = oracle.composite(cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"],
                               ref["info"], ref["vis"], ref["cubeMaps"], ref["cubeDepths"])
