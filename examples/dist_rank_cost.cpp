@@ -4,7 +4,7 @@
 // (scripts/exp_rank_cost.py is the same measurement through the Python mirror).  max over ranks = the frame time an ideal fabric would
 // give; its ratio to world 1 is the ceiling of the strong-scaling curve.
 // Build: g++ -O2 -std=c++17 examples/dist_rank_cost.cpp -Lmultivolumes_amd -lmultivolumes_amd -Wl,-rpath,$PWD/multivolumes_amd -o /tmp/dist_rank_cost
-// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3 (0)] [C3 | C5]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
 // Prints per rank: ms per frame, and in brackets the host's share (time spent inside DistFrame: constants + every HIP call of the frame).
 #include "../multivolumes_amd/csrc/MultiRayCaster.hpp"
 
@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 static int noGather(void*, const void*, void*, size_t, void*, int) { return 0; }
@@ -19,7 +20,8 @@ static int noReduce(void*, void*, size_t, void*, int) { return 0; }
 
 int main(int argc, char** argv)
 {
-	const uint32_t N = 256, L = 96, V = 16, W = 1024, H = 1024, M = 1024;
+	const bool c5 = argc > 5 && std::string(argv[5]) == "C5";	// BASELINE config C5: 64 volumes, 2048^2, 256 steps (default C3)
+	const uint32_t N = 256, L = 96, V = c5 ? 64 : 16, W = c5 ? 2048 : 1024, H = W, M = 1024;
 	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
 	const unsigned worlds = argc > 2 ? (unsigned)std::atoi(argv[2]) : 15u;
 	const int onlyRank = argc > 3 ? std::atoi(argv[3]) : -1;	// (one rank only: for a kernel trace)
@@ -27,7 +29,8 @@ int main(int argc, char** argv)
 	std::vector<std::vector<uint16_t>> vols(V, std::vector<uint16_t>((size_t)N * N * N * 4));
 	for (uint32_t k = 0; k < V; ++k) mvh_synth_volume(N, k, vols[k].data());
 
-	const float eye[3] = { 4.0f, 16.0f, -80.0f }, focus[3] = { 0, 0, 0 }, up[3] = { 0, 1, 0 }, light[3] = { 75, 75, -75 };
+	const float es = c5 ? 2.0f : 1.0f;	// the reference's camera, pulled back for the 8 x 8 grid (scene.py camera())
+	const float eye[3] = { 4.0f * es, 16.0f * es, -80.0f * es }, focus[3] = { 0, 0, 0 }, up[3] = { 0, 1, 0 }, light[3] = { 75, 75, -75 };
 	float view[16], proj[16], viewProj[16], shadowVP[16];
 	mvh_look_at_lh(eye, focus, up, view);
 	mvh_perspective_fov_lh(3.14159265f / 4, (float)W / H, 1.0f, 1000.0f, proj);
@@ -52,7 +55,7 @@ int main(int argc, char** argv)
 			if (!rc.Init(N, L, V, V, W, H, M, 0, nullptr, rank, world, MV_FLAG_PIPELINE_FRAMES, inFlight)) { std::fprintf(stderr, "Init failed (no gfx950 device?)\n"); return 2; }
 			for (uint32_t k = 0; k < V; ++k) if (!rc.LoadVolumeData(k, vols[k].data())) return 3;
 			if (!rc.SetRenderTargetsHost(depth.data(), shadow.data())) return 4;
-			rc.SetMaxSamples(128, 96);
+			rc.SetMaxSamples(c5 ? 256 : 128, 96);
 			rc.SetLight(light, lc, 3.0f * 3.14159265f);
 			rc.SetAmbient(ac, 2.0f * 3.14159265f);
 			if (mv_dist_init_callbacks(rc.Context(), noGather, noReduce, nullptr) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
