@@ -1708,7 +1708,7 @@ static int distCommonInitBody(mv_ctx* ctx)
 		// the light march of a frame is shared out by voxel blocks (mv_kernels.hip lightShare): 64 words per block, the same number of blocks per rank
 		DeviceState split = st;
 		split.flags |= mv::kFlagRotateAllLightMaps;
-		d->lightShareBytes = (size_t)mv::lightSharePerRank(split) * 64u * sizeof(uint32_t);
+		d->lightShareBytes = ((size_t)mv::lightSharePerRank(split) + 1u) * 64u * sizeof(uint32_t);	// its blocks + a trailer (what its cull decided: checked by the unpack)
 	}
 	int rc;
 	for (uint32_t c = 0; c < d->numChains; ++c)
@@ -1723,7 +1723,7 @@ static int distCommonInitBody(mv_ctx* ctx)
 		if ((rc = distAlloc(ctx, &d->rowRecv[c], d->maxBandBytes * world)) != MV_OK) return rc;
 	}
 	if (hipHostMalloc(reinterpret_cast<void**>(&d->reports), kMaxFrameSlots * 64, hipHostMallocCoherent) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned exchange reports");
-	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) d->reports[i * 8u] = ~0ull;
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) { d->reports[i * 8u] = ~0ull; d->reports[i * 8u + 1u] = 0ull; }
 	if (world > 1u) ctx->st.flags |= mv::kFlagInterleaveRows;	// screen rows dealt by tile row instead of in contiguous bands
 #ifndef MV_DIST_STATIC_OWNERS	// (A/B builds only: v % shard_count inside the loop too)
 	ctx->st.flags |= mv::kFlagBalanceOwners;	// the cube-map volumes of a frame are dealt to the ranks by estimated cost (replicated cull: the same deal everywhere)
@@ -1874,6 +1874,9 @@ static int distTailExchange(mv_ctx* ctx)
 			rep = *report;
 		}
 		MV_REQUIRE(ctx, (uint32_t)(rep >> 32) == st.frameTag, MV_ERR_HIP, "the cull's exchange report is missing");
+		// (the light exchange of this frame compared what every rank's cull decided: mv_kernels.hip lightUnpackKernel)
+		MV_REQUIRE(ctx, report[1] != (((unsigned long long)st.frameTag << 32) | 1ull), MV_ERR_INVALID_ARG,
+			"the ranks' culls of this frame disagree (different frame constants on different ranks?): its collectives would not match");
 		const size_t shardBytes = std::max<size_t>(16, ((size_t)(uint32_t)rep * 12u + 15u) & ~(size_t)15u);
 		MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
 		{ MV_SECTION(9); mv::launchExchangeCompact(X, st, true, d->sendBuf[chain], shardBytes); }

@@ -899,6 +899,16 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 	uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
 	volumeId = __builtin_amdgcn_readfirstlane(volumeId);
 	if (!(st.flags & kFlagRotateAllLightMaps) && !ownsVolume(st, volumeId)) return;
+	// Behind a rank's share of the all-gather: what its replicated cull decided for this frame.  Every rank's cull must have decided the
+	// same (same inputs, same kernel) -- the sizes of the frame's collectives follow from it -- so lightUnpackKernel compares the ranks'
+	// words and raises a flag the host reads before it sizes the frame's cube-face all-gather (a divergence, i.e. callers that passed
+	// different frame constants on different ranks, is then an error instead of a hang).
+	if (wordsOut && blockIdx.x == 0 && threadIdx.x < 4u)
+	{
+		const uint32_t totalB = ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2) * ((st.L + 3u) >> 2);
+		const uint32_t word = threadIdx.x == 0 ? st.frameTag : threadIdx.x == 1 ? st.counters[12] : threadIdx.x == 2 ? st.counters[0] : st.counters[1];
+		wordsOut[(size_t)lightShare(st, totalB).per * 64u + threadIdx.x] = word;
+	}
 
 	const u32x4* axisTables = nullptr;
 	if (LUT)
@@ -1426,11 +1436,25 @@ __global__ __launch_bounds__(256) void lightUnpackKernel(DeviceState st, const u
 	const uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
 	const uint32_t L = st.L, B = (L + 3u) >> 2, total = B * B * B;
 	const LightShare share = lightShare(st, total);
+	const size_t stride = ((size_t)share.per + 1u) * 64u;	// words per rank: `per` blocks + the trailer
+	if (blockIdx.x == 0)
+	{
+		// every rank's cull decided the same?  (see marchLightKernel)
+		bool differs = false;
+		for (uint32_t r = threadIdx.x; r < st.shardCount; r += blockDim.x)
+		{
+			const uint32_t* t = words + (size_t)r * stride + (size_t)share.per * 64u;
+			differs = differs || t[0] != st.frameTag || t[1] != st.counters[12] || t[2] != st.counters[0] || t[3] != st.counters[1];
+		}
+		if (differs && st.exchangeReport) st.exchangeReport[1] = ((unsigned long long)st.frameTag << 32) | 1ull;	// (pinned host memory; every writer stores the same word)
+	}
 	const uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
 	if (e >= total || (e >= share.lo && e < share.hi)) return;	// (its own share is in place already)
 	const uint32_t b = ordered ? st.lightOrder[e] : e;
+	const uint32_t r = e / share.per;
 	const uint32_t xx = (b % B) * 4u + (lane & 3u), yy = ((b / B) % B) * 4u + ((lane >> 2) & 3u), zz = (b / (B * B)) * 4u + (lane >> 4);
-	if (xx < L && yy < L && zz < L) storeLightTexel(reinterpret_cast<uint32_t*>(st.lightTable[volumeId]), L, xx, yy, zz, words[(size_t)e * 64u + lane]);
+	if (xx < L && yy < L && zz < L)
+		storeLightTexel(reinterpret_cast<uint32_t*>(st.lightTable[volumeId]), L, xx, yy, zz, words[(size_t)r * stride + (size_t)(e - r * share.per) * 64u + lane]);
 }
 
 #ifndef MV_LIGHT_ORDER

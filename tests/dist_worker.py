@@ -42,6 +42,7 @@ def main():
     out_path, frames, every = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     mode = sys.argv[4] if len(sys.argv) > 4 else "chains"           # "chains" (three view streams) or "single" (one view stream)
     static_depth = len(sys.argv) > 5 and sys.argv[5] == "1"          # no setter (= no drain of the frames in flight) inside the sequence
+    diverge = len(sys.argv) > 5 and sys.argv[5] == "3"               # rank 1 is handed another camera in frame 5: the loop must REPORT it, not hang
     after_setter = len(sys.argv) > 5 and sys.argv[5] == "2"          # a new host depth map every frame and NO flush: frame f - 1 is read back right after the setter of frame f
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rccl = os.environ.get("MV_TEST_RCCL") == "1"  # one GPU per rank and the library's own RCCL communicators (boxes with >= world GPUs)
@@ -64,13 +65,26 @@ def main():
             assert info["transport"] == "rccl" and info["ranks"] == world and info["communicators"] == (2 if mode == "single" else 3), info
         imgs, infos = [], []
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
-            if not static_depth or f == 0:
+            if (not static_depth and not diverge) or f == 0:
                 # (inside the loop the setter first enqueues the pending tail of frame f - 1 -- its exchange, composite and row gather --
                 # so that frame is composited against ITS depth map, not this one; a collective call, made by every rank)
                 c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
                 if after_setter and f > 0:
                     imgs.append(c.ReadBackComposite())
                     infos.append(c.ReadBackVolumeInfo())
+            if diverge:
+                if f == 5 and rank == 1:
+                    e = np.array([3.0, 9.0, -12.0], np.float32)  # inside the grid of volumes: another visible set, other shard sizes
+                    vp = rc.multiply(rc.look_at_lh(e, (0, 0, 0)), rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0))
+                try:
+                    c.DistFrame(vp, fr["shadowVP"], e)
+                    c.synchronize()  # (this test only: let the frame's light exchange, which carries the check, finish before the next call)
+                except Exception as ex:
+                    assert f == 6 and "disagree" in str(ex), (f, str(ex))
+                    print(f"rank {rank}: divergence reported at frame {f}: {ex}", flush=True)
+                    os._exit(0)  # nothing more can be exchanged; the ranks leave without a collective
+                assert f <= 5, "a frame after the divergent one went through"
+                continue
             c.DistFrame(vp, fr["shadowVP"], e)
             if after_setter and f != frames - 1:
                 continue

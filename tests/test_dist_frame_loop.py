@@ -111,6 +111,19 @@ def test_eight_ranks_at_c3_size_match_single_gpu(tmp_path, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["chains", "single"])
+def test_ranks_that_were_handed_different_frames_get_an_error_not_a_hang(tmp_path, mode):
+    """The sizes of a frame's collectives follow from the replicated cull; ranks whose callers passed different frame constants would
+    enter collectives that do not match.  Every rank's share of the frame's light exchange carries what its cull decided, the unpack
+    compares them, and the NEXT mv_dist_frame -- before it sizes that frame's cube-face all-gather -- fails on every rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path / "unused.npz"), "12", "1", mode, "3"]
+    r = run_group(cmd, 300, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("divergence reported at frame 6") == 2, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode", ["chains", "single"])
 def test_input_setters_inside_the_loop_leave_the_pending_frame_its_inputs(tmp_path, mode):
     """mv_dist_frame(k) defers frame k - 1's exchange, composite and row gather to the next call.  A caller that hands over a new host
     depth map before every frame (SetRenderTargets(depth_k); DistFrame(k)) must still get frame k - 1 composited against depth_{k-1}:
