@@ -16,6 +16,12 @@ for s in CSRayMarchV CSRayMarchL CSVolumeCull CSInitGridData CSR32FToRGBA16F VSC
     objs="$objs _ref/${s}_${mode}.o"
   done
 done
+# the work-graph library: two node functions in one module (cso2ll.py translate_lib)
+for mode in fp32 fp16; do
+  python3 dxil/cso2ll.py "$REF/Bin/LibRayMarch.cso" "dxil_LibRayMarch" $mode "_ref/LibRayMarch_${mode}.ll" "_ref/LibRayMarch.dxil.ll" > /dev/null
+  "$CLANG" -O1 -fPIC -mf16c -c "_ref/LibRayMarch_${mode}.ll" -o "_ref/LibRayMarch_${mode}.o" -Wno-override-module
+  objs="$objs _ref/LibRayMarch_${mode}.o"
+done
 # (no -lmv_oracle: the runtime answers every resource intrinsic itself, dxil/d3d_sampler.c)
 "$CLANG" -O2 -fPIC -ffp-contract=off -shared -o _ref/libmv_dxref.so dxil/dxil_rt.c dxil/d3d_sampler.c $objs -lm -lpthread
 echo "built oracle/_ref/libmv_dxref.so"

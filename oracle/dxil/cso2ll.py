@@ -139,27 +139,33 @@ def translate(ll, entry, mode="fp32"):
     # fetches the wanted lane's published value (waiting for it if that lane is behind).
     pub, lines = {}, s.splitlines()
     rd = re.compile(r"^(\s*)(%\S+) = call (float|i32) @dx\.op\.waveReadLaneAt\.(f32|i32)\(i32 117, (float|i32) (%[\w.]+), i32 ([^)]+)\)\s*$")
+    fn = 0  # values are numbered per function (a library holds several)
     for i, line in enumerate(lines):
+        if line.startswith("define "):
+            fn += 1
         m = rd.match(line)
         if not m:
             continue
         ind, res, ty, suf, _, val, lane = m.groups()
-        if val not in pub:
-            pub[val] = (len(pub), ty, suf)
-        lines[i] = f"{ind}{res} = call {ty} @rt_readlane_{suf}(i32 {pub[val][0]}, {ty} {val}, i32 {lane})"
+        if (fn, val) not in pub:
+            pub[(fn, val)] = (len(pub), ty, suf)
+        lines[i] = f"{ind}{res} = call {ty} @rt_readlane_{suf}(i32 {pub[(fn, val)][0]}, {ty} {val}, i32 {lane})"
     if pub:
         out2, pending = [], []
+        fn = 0
         for i, line in enumerate(lines):
             out2.append(line)
+            if line.startswith("define "):
+                fn += 1
             m = re.match(r"^\s*(%[\w.]+) = (\w+)", line)
-            if m and m.group(1) in pub:
-                pending.append(m.group(1))
+            if m and (fn, m.group(1)) in pub:
+                pending.append((fn, m.group(1)))
             # publish right behind the definition; behind the block's last phi when the definition is a phi
             nxt = lines[i + 1] if i + 1 < len(lines) else ""
             if pending and not re.match(r"^\s*%[\w.]+ = phi ", nxt):
                 for v in pending:
                     k, ty, suf = pub[v]
-                    out2.append(f"  call void @rt_publish_{suf}(i32 {k}, {ty} {v})")
+                    out2.append(f"  call void @rt_publish_{suf}(i32 {k}, {ty} {v[1]})")
                 pending = []
         lines = out2
         lines += ["", "declare void @rt_publish_f32(i32, float)", "declare void @rt_publish_i32(i32, i32)",
@@ -188,6 +194,62 @@ def translate(ll, entry, mode="fp32"):
     return ('target triple = "x86_64-unknown-linux-gnu"\n' + "\n".join(body_lines) + "\n\n" + "\n".join(uniq) + "\n")
 
 
+def translate_lib(ll, prefix, mode="fp32"):
+    """A lib_6_x module (the work-graph library Bin/LibRayMarch.cso): every defined function is a node; it becomes
+    @<prefix>_<node>_<mode>.  What a library has that a single shader has not, and how it is answered:
+      * resources are GLOBALS holding handles (`load %dx.types.Handle, ptr @"\01?g_txGrids@@..."[i]`): the mangled names become
+        @lib_<name>, defined by the runtime (dxil_rt.c) as descriptor slots the test binds by name (dxref_lib_bind);
+      * a cbuffer / structured buffer of a user type is loaded BY VALUE from a `_legacy` global and turned into a handle by
+        dx.op.createHandleForLib.<type>: the call becomes a load of the slot @lib_h_<name>, the by-value load stays as dead code;
+      * createHandleForLib / annotateHandle / annotateNodeHandle / annotateNodeRecordHandle pass their handle through;
+      * node records live in addrspace(6): plain pointers here; getNodeRecordPtr is the address of record i behind the handle;
+      * createNodeInputRecordHandle / createNodeOutputHandle / allocateNodeOutputRecords / outputComplete go to the runtime, which
+        plays the work-graph scheduler (dxref_node_begin / dxref_node_records)."""
+    s = ll
+    s = re.sub(r'@"\\01\?(g_\w+)@@[^"]*_legacy"', r"@lib_\1_legacy", s)
+    s = re.sub(r'@"\\01\?(g_\w+)@@[^"]*"', r"@lib_\1", s)
+    s = s.replace("@cbSampleRes", "@lib_cbSampleRes")
+    s = s.replace("ptr addrspace(6)", "ptr")
+    s = "\n".join(l for l in s.splitlines() if not l.startswith("@llvm.global_ctors"))
+    # user-typed resources: the by-value global becomes a dead zero, the handle comes from the runtime's slot
+    slots = {}
+    out = []
+    for line in s.splitlines():
+        m = re.match(r'^(@[\w.]+) = external global (%\S+|%"[^"]+")\s*$', line)
+        if m:
+            slots[m.group(2)] = "@lib_h_" + m.group(1)[1:].replace("_legacy", "").replace("lib_", "")
+            out.append(f"{m.group(1)} = internal global {m.group(2)} zeroinitializer")
+            continue
+        out.append(line)
+    s = "\n".join(out)
+    for ty, slot in slots.items():
+        s = re.sub(r'call %dx\.types\.Handle @"?dx\.op\.createHandleForLib\.[^"(]+"?\(i32 160, ' + re.escape(ty) + r' %\d+\)',
+                   f"load %dx.types.Handle, ptr {slot}", s)
+    s += "\n" + "\n".join(f"{slot} = external constant %dx.types.Handle" for slot in slots.values()) + "\n"
+    # pass-through and record-address intrinsics: definitions instead of declarations
+    defs = []
+
+    def passthrough(m):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        params = ", ".join(f"{a.strip()} %a{i}" for i, a in enumerate(args.split(",")))
+        defs.append(f"define internal {ret} @{name}({params}) alwaysinline {{\n  ret {ret} %a1\n}}")
+        return ""
+    s = re.sub(r"^declare (%dx\.types\.\w+) @(dx\.op\.(?:annotateHandle|annotateNodeHandle|annotateNodeRecordHandle|createHandleForLib\.dx\.types\.Handle))\((.*)\).*$",
+               passthrough, s, flags=re.M)
+
+    def record_ptr(m):
+        name, ty = m.group(1), m.group(2)
+        defs.append(f"define internal ptr @{name}(i32 %op, %dx.types.NodeRecordHandle %h, i32 %i) alwaysinline {{\n"
+                    f"  %p = extractvalue %dx.types.NodeRecordHandle %h, 0\n  %q = getelementptr %{ty}, ptr %p, i32 %i\n  ret ptr %q\n}}")
+        return ""
+    s = re.sub(r"^declare ptr @(dx\.op\.getNodeRecordPtr\.((?:struct\.)?[\w.]+))\(.*\).*$", record_ptr, s, flags=re.M)
+    s = re.sub(r'^declare %dx\.types\.Handle @"?dx\.op\.createHandleForLib\.hostlayout[^\n]*$', "", s, flags=re.M)
+    nodes = re.findall(r"^define void @(\w+)\(\)", s, flags=re.M)
+    for n in nodes:
+        s = re.sub(r"@" + n + r"\b", f"@{prefix}_{n}_{mode}", s)
+    return translate(s + "\n" + "\n".join(defs) + "\n", "main", mode), nodes
+
+
 def resources(ll):
     """The dx.resources metadata as text lines (for a human: which rangeId is which register range)."""
     return [l for l in ll.splitlines() if l.startswith("!") and ("ptr undef" in l or "dx.resources" in l)]
@@ -196,6 +258,11 @@ def resources(ll):
 if __name__ == "__main__":
     cso, entry, mode, out = sys.argv[1:5]
     text = disassemble(extract_bitcode(cso))
-    open(out, "w").write(translate(text, entry, mode))
+    if "@main()" in text:
+        open(out, "w").write(translate(text, entry, mode))
+    else:
+        ir, nodes = translate_lib(text, entry, mode)
+        open(out, "w").write(ir)
+        print("library nodes:", " ".join(nodes))
     if len(sys.argv) > 5:
         open(sys.argv[5], "w").write(text)

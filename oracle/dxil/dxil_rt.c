@@ -73,6 +73,7 @@ typedef struct dxr_wave
 	float val_f[64];
 	uint32_t out_u[64];
 	float out_f[64];
+	void* out_p[64];
 	uint32_t ballot[64][4];
 	uint8_t present[64];	/* lanes of the group being completed */
 	int kind[64], op[64];
@@ -83,7 +84,8 @@ typedef struct dxr_wave
 	uint8_t exited[64];
 } dxr_wave;
 
-enum { WK_READ = 1, WK_FIRST = 2, WK_BALLOT = 3, WK_ACTIVE = 4 };
+enum { WK_READ = 1, WK_FIRST = 2, WK_BALLOT = 3, WK_ACTIVE = 4, WK_COUNT = 5, WK_PREFIX = 6, WK_ALLOC = 7 };
+static void* node_alloc_records(uint32_t count);
 
 static void wave_try_complete(dxr_wave* w)
 {
@@ -129,6 +131,22 @@ static void wave_try_complete(dxr_wave* w)
 				}
 				for (uint32_t l = base; l < base + cl && l < w->size; ++l) if (w->present[l]) w->out_f[l] = acc;
 			}
+		}
+		else if (kind == WK_COUNT || kind == WK_PREFIX)
+		{
+			/* WaveActiveCountBits / WavePrefixCountBits over the lanes that are active at this site */
+			uint32_t n = 0;
+			for (uint32_t l = 0; l < w->size; ++l)
+				if (w->present[l]) { if (kind == WK_PREFIX) w->out_u[l] = n; n += w->val_u[l] ? 1u : 0u; }
+			if (kind == WK_COUNT) for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) w->out_u[l] = n;
+		}
+		else if (kind == WK_ALLOC)
+		{
+			/* GetGroupNodeOutputRecords: one allocation for the group (here one wave), every lane gets the same records */
+			uint32_t first = 0;
+			while (first < w->size && !w->present[first]) ++first;
+			void* recs = node_alloc_records(w->val_u[first]);
+			for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) w->out_p[l] = recs;
 		}
 		if (getenv("DXREF_TRACE")) { fprintf(stderr, "wave op kind %d op %d site %p lanes:", kind, op, s); for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) fprintf(stderr, " %u(v=%g,u=%u,want=%u->%g)", l, w->val_f[l], w->val_u[l], w->want[l], w->out_f[l]); fprintf(stderr, "\n"); }
 		for (uint32_t l = 0; l < w->size; ++l) if (w->present[l]) { w->site[l] = NULL; --w->blocked; }
@@ -575,6 +593,88 @@ float rt_waveActiveOp_f32(int32_t opc, float v, int32_t op, int32_t sign)
 	wave_meet(SITE(), WK_ACTIVE, op, 0u, v, 0u);
 	return t_ctx->wave->out_f[t_ctx->lane];
 }
+
+int32_t rt_waveAllOp(int32_t op, int32_t cond)
+{
+	if (op != 135) abort();	/* WaveAllBitCount */
+	if (!t_ctx->wave) return cond ? 1 : 0;
+	wave_meet(SITE(), WK_COUNT, 0, cond ? 1u : 0u, 0.0f, 0u);
+	return (int32_t)t_ctx->wave->out_u[t_ctx->lane];
+}
+int32_t rt_wavePrefixOp(int32_t op, int32_t cond)
+{
+	if (op != 136) abort();	/* WavePrefixBitCount */
+	if (!t_ctx->wave) return 0;
+	wave_meet(SITE(), WK_PREFIX, 0, cond ? 1u : 0u, 0.0f, 0u);
+	return (int32_t)t_ctx->wave->out_u[t_ctx->lane];
+}
+
+/* ---------------- work-graph library (lib_6_x: Bin/LibRayMarch.cso) ----------------
+ * Resources of a library are globals that hold handles (cso2ll.py translate_lib names them lib_<name>): descriptor slots here, bound
+ * by name.  The node intrinsics are answered by a minimal scheduler: the records a node allocates are appended to one list, which
+ * the test then feeds to the consumer node, one dispatch per record with the record's SV_DispatchGrid. */
+#define LIB_SLOTS 4096
+dxr_res* lib_g_smpLinear = &g_null_res; dxr_res* lib_g_smpPoint = &g_null_res; dxr_res* lib_g_txDepth = &g_null_res;
+dxr_res* lib_g_roVolumes = &g_null_res; dxr_res* lib_g_rwVisibleVolumes = &g_null_res; dxr_res* lib_g_rwVolumes = &g_null_res;
+dxr_res* lib_cbSampleRes = &g_null_res; dxr_res* lib_h_cbPerFrame = &g_null_res; dxr_res* lib_h_g_roPerObject = &g_null_res;
+dxr_res* lib_g_txLightMaps[LIB_SLOTS]; dxr_res* lib_g_txGrids[LIB_SLOTS]; dxr_res* lib_g_rwCubeMaps[LIB_SLOTS]; dxr_res* lib_g_rwCubeDepths[LIB_SLOTS];
+static const struct { const char* name; dxr_res** slot; uint32_t n; } g_lib_slots[] = {
+	{ "g_smpLinear", &lib_g_smpLinear, 1 }, { "g_smpPoint", &lib_g_smpPoint, 1 }, { "g_txDepth", &lib_g_txDepth, 1 },
+	{ "g_roVolumes", &lib_g_roVolumes, 1 }, { "g_rwVisibleVolumes", &lib_g_rwVisibleVolumes, 1 }, { "g_rwVolumes", &lib_g_rwVolumes, 1 },
+	{ "cbSampleRes", &lib_cbSampleRes, 1 }, { "cbPerFrame", &lib_h_cbPerFrame, 1 }, { "g_roPerObject", &lib_h_g_roPerObject, 1 },
+	{ "g_txLightMaps", lib_g_txLightMaps, LIB_SLOTS }, { "g_txGrids", lib_g_txGrids, LIB_SLOTS },
+	{ "g_rwCubeMaps", lib_g_rwCubeMaps, LIB_SLOTS }, { "g_rwCubeDepths", lib_g_rwCubeDepths, LIB_SLOTS } };
+/* every slot back to the null descriptor; the resources themselves are dxref_bind entries (dxref_reset forgets those) */
+void dxref_lib_reset(void)
+{
+	for (size_t i = 0; i < sizeof(g_lib_slots) / sizeof(g_lib_slots[0]); ++i)
+		for (uint32_t k = 0; k < g_lib_slots[i].n; ++k) g_lib_slots[i].slot[k] = &g_null_res;
+}
+/* slot `name`[index] = the resource bound LAST with dxref_bind */
+int dxref_lib_bind(const char* name, uint32_t index)
+{
+	if (!g_nbind) return -1;
+	for (size_t i = 0; i < sizeof(g_lib_slots) / sizeof(g_lib_slots[0]); ++i)
+		if (!strcmp(g_lib_slots[i].name, name))
+		{
+			if (index >= g_lib_slots[i].n) return -2;
+			g_lib_slots[i].slot[index] = &g_bind[g_nbind - 1].res;
+			return 0;
+		}
+	return -3;
+}
+uint32_t dxref_last_counter(void) { return g_nbind ? g_bind[g_nbind - 1].res.counter : 0; }
+
+#define NODE_MAX_RECORD_BYTES (1u << 22)
+static const void* g_node_in;
+static uint8_t* g_node_out;
+static uint32_t g_node_out_stride, g_node_out_count;
+/* before a node's dispatch: its input record, and the size of the records its output allocates */
+void dxref_node_begin(const void* input_record, uint32_t output_stride)
+{
+	g_node_in = input_record;
+	g_node_out_stride = output_stride;
+	if (!g_node_out) g_node_out = (uint8_t*)malloc(NODE_MAX_RECORD_BYTES);
+}
+void dxref_node_clear_output(void) { g_node_out_count = 0; }
+uint32_t dxref_node_records(const void** base) { *base = g_node_out; return g_node_out_count; }
+static void* node_alloc_records(uint32_t count)
+{
+	if (((size_t)g_node_out_count + count) * g_node_out_stride > NODE_MAX_RECORD_BYTES) abort();
+	void* p = g_node_out + (size_t)g_node_out_count * g_node_out_stride;
+	g_node_out_count += count;
+	return p;
+}
+void rt_createNodeInputRecordHandle(void** out, int32_t op, int32_t index) { (void)op; (void)index; *out = (void*)g_node_in; }
+void rt_createNodeOutputHandle(void** out, int32_t op, int32_t index) { (void)op; (void)index; *out = &g_node_out_stride; }
+void rt_allocateNodeOutputRecords(void** out, int32_t op, void* node, int32_t count, int32_t per_thread)
+{
+	(void)op; (void)node;
+	if (per_thread || !t_ctx->wave) abort();	/* the library only uses GetGroupNodeOutputRecords, from a one-wave group */
+	wave_meet(SITE(), WK_ALLOC, 0, (uint32_t)count, 0.0f, 0u);
+	*out = t_ctx->wave->out_p[t_ctx->lane];
+}
+void rt_outputComplete(int32_t op, void* records) { (void)op; (void)records; }
 
 /* ---------------- dispatch ---------------- */
 /* n invocations of a pixel (or vertex) shader, one after the other: inputs[i] = 8 signature elements x 4 components (raw bits),

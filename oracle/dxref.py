@@ -179,6 +179,77 @@ def cull(V, perObject, descs, cbPerFrame, maxRaySamples, volumeInfo=None, mode="
     return info, np.sort(vis[:nv]), np.sort(cube[:nc])
 
 
+def lib_ray_march(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, descs, cbPerFrame, maxRaySamples, volumeInfo=None,
+                  cubeMaps=None, cubeDepths=None, mode="fp32", fused_mad=False):
+    """Bin/LibRayMarch.cso, the work-graph statement of cull + view march (LibRayMarch.hlsl:39-134, 202-287), scheduled as
+    MultiRayCaster.cpp:1421-1428 dispatches it: the entry node VolumeCull over DIV_UP(V, 4) groups of 8 x 4 threads (one 32-lane
+    wave) with the record { V }; every RayMarchRecord it emits starts the RayMarch node over the record's SV_DispatchGrid of
+    8 x 8 x 6-thread groups.  Returns (volumeInfo [V,4] u16, visible volumes sorted, records [n,7] u32 sorted by volume,
+    cubeMaps, cubeDepths)."""
+    lib = load()
+    lib.dxref_reset()
+    lib.dxref_lib_reset()
+    lib.dxref_set_fused_mad(1 if fused_mad else 0)
+    chain = O.cube_chain_texels(N)
+    keep = []
+    slot = [0]
+
+    def bind(name, index, kind, fmt, arr, w=0, h=0, d=0, stride=0):
+        keep.append(arr)
+        _bind(SRV, 99, slot[0], kind, fmt, arr, w, h, d, stride)
+        slot[0] += 1
+        assert lib.dxref_lib_bind(name.encode(), index) == 0, name
+
+    vols = [np.ascontiguousarray(v).view(np.uint16) for v in volumes]
+    cm = np.zeros((V, chain, 4), np.uint16) if cubeMaps is None else np.ascontiguousarray(cubeMaps, np.uint16).copy()
+    cd = np.zeros((V, chain), np.float32) if cubeDepths is None else np.ascontiguousarray(cubeDepths, np.float32).copy()
+    lm = np.ascontiguousarray(lightMaps, np.uint32)
+    dm = np.ascontiguousarray(depthMap, np.float32)
+    po = np.ascontiguousarray(perObject).view(np.uint8).copy()
+    cb = np.ascontiguousarray(cbPerFrame).view(np.uint8).copy()
+    d = np.ascontiguousarray(descs, np.uint32)
+    info = np.zeros((V, 4), np.uint16) if volumeInfo is None else np.ascontiguousarray(volumeInfo, np.uint16).copy()
+    vis = np.zeros(max(V, 1), np.uint32)
+    cb1 = np.array([maxRaySamples, 0, 0, 0], np.uint32)
+    for v in range(V):
+        bind("g_txLightMaps", v, TEX3D, F_R11G11B10F, lm[v], L, L, L)
+    for i, g in enumerate(vols):
+        bind("g_txGrids", i, TEX3D, F_RGBA16F, g, N, N, N)
+    bind("g_txDepth", 0, TEX2D, F_R32F, dm, W, H, 1)
+    bind("g_roPerObject", 0, RAW, F_NONE, po, V, 0, 0, 224)
+    bind("g_roVolumes", 0, RAW, F_NONE, d, V, 0, 0, 4)
+    bind("g_rwVolumes", 0, TYPED_BUF, F_RGBA16U, info, V)
+    bind("cbPerFrame", 0, CBUF, F_NONE, cb, len(cb))
+    bind("cbSampleRes", 0, CBUF, F_NONE, cb1, 8)
+    bind("g_smpLinear", 0, SAMPLER_KIND, F_NONE, None)
+    bind("g_smpPoint", 0, SAMPLER_KIND, F_NONE, None)
+    for v in range(V):
+        for mip in range(5):
+            dim = N >> mip
+            if dim == 0:
+                continue
+            off = O.cube_mip_offset(N, mip)
+            bind("g_rwCubeMaps", 5 * v + mip, TEX2DARRAY, F_RGBA16F, cm[v][off:], dim, dim, 6)
+            bind("g_rwCubeDepths", 5 * v + mip, TEX2DARRAY, F_R32F, cd[v][off:], dim, dim, 6)
+    bind("g_rwVisibleVolumes", 0, RAW, F_NONE, vis, V, 0, 0, 4)   # bound last: dxref_last_counter reads its append counter
+    lib.dxref_node_begin.argtypes = [C.c_void_p, C.c_uint32]
+    lib.dxref_node_records.argtypes = [C.POINTER(C.c_void_p)]
+    lib.dxref_node_records.restype = C.c_uint32
+    lib.dxref_last_counter.restype = C.c_uint32
+    count = np.array([V], np.uint32)
+    lib.dxref_node_clear_output()
+    lib.dxref_node_begin(count.ctypes.data, 28)
+    _dispatch("LibRayMarch_VolumeCull", mode, ((V + 3) // 4, 1, 1), (8, 4, 1), wave=32, cluster=8)
+    base = C.c_void_p()
+    n = int(lib.dxref_node_records(C.byref(base)))
+    recs = np.ctypeslib.as_array(C.cast(base, C.POINTER(C.c_uint32)), shape=(max(n, 1), 7))[:n].copy()
+    nv = int(lib.dxref_last_counter())
+    for r in recs:
+        lib.dxref_node_begin(r.ctypes.data, 0)
+        _dispatch("LibRayMarch_RayMarch", mode, (int(r[0]), int(r[1]), 1), (8, 8, 6))
+    return info, np.sort(vis[:nv]), recs[np.argsort(recs[:, 2], kind="stable")], cm, cd
+
+
 TEXCUBE = 8
 
 

@@ -72,6 +72,40 @@ def test_view_march_equals_the_compiled_view_march(oracle, name, eye):
     assert d_f <= 1e-3
 
 
+@pytest.mark.parametrize("name,ncam", [("T1", 4), ("T2", 3), ("C1", 2)])
+def test_work_graph_library_equals_the_oracle(oracle, name, ncam):
+    """Bin/LibRayMarch.cso -- the reference's work-graph statement of cull + view march, both nodes run on the CPU and scheduled the
+    way MultiRayCaster.cpp:1421-1428 dispatches the graph (entry record { V }; one RayMarch dispatch per emitted record over its
+    SV_DispatchGrid).  The cull node must leave the same VolumeInfo and visible list as CSVolumeCull / the oracle's cull, its
+    RayMarchRecords must be exactly the cube-map volumes with the fields of their VolumeInfo and the grid DIV_UP(N >> mip, 8), and
+    the march node must produce the oracle's LibRayMarch mode (mvo_set_options(0, 1): no ComputeTargetHit clamp) bit for bit."""
+    cfg = dict(scene.CONFIGS[name])
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    moved = 0
+    for eye in cameras(ncam, 21):
+        ref = oracle_pipeline(oracle, cfg, vols, 32, frames=2, eye=eye)
+        oracle.load().mvo_set_options(0, 1)
+        try:
+            cm0, cd0, _ = oracle.march_view(V, N, L, cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], ref["info"], ref["cube"])
+        finally:
+            oracle.load().mvo_set_options(0, 0)
+        info, vis, recs, cm, cd = dxref.lib_ray_march(V, N, L, cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["descs"],
+                                                      ref["cb"], cfg["maxRay"])
+        assert np.array_equal(info, ref["info"]), eye
+        assert np.array_equal(vis, np.sort(ref["vis"])), eye
+        cube = np.sort(ref["cube"])
+        assert np.array_equal(recs[:, 2], cube), eye
+        for r in recs:
+            v = int(r[2])
+            assert [int(x) for x in r[3:7]] == [int(x) for x in ref["info"][v]], (eye, v)
+            assert int(r[0]) == int(r[1]) == ((N >> int(r[3])) + 7) // 8, (eye, v)
+        assert np.array_equal(cm, cm0), (eye, int((cm != cm0).sum()))
+        assert np.array_equal(cd, cd0), eye
+        moved += int((cm0 != ref["cubeMaps"]).sum())
+    print(f"{name}: {ncam} cameras; the LibRayMarch statement moves {moved} halves against CSRayMarchV's (the missing target clamp)")
+
+
 @pytest.mark.parametrize("use_sh", [False, True])
 def test_light_march_equals_the_compiled_light_march(oracle, use_sh):
     """CSRayMarchL.cso (shadow map and light probe compiled in, the probe switched by cbSampleRes): the relit volume's light map,
