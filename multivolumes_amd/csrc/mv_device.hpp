@@ -661,10 +661,31 @@ __device__ __forceinline__ float GetTMax(vec3 pos, vec3 rayOrigin, vec3 rayDir, 
 	return __builtin_fmaxf(__builtin_fmaxf(t.x, t.y), t.z);
 }
 
+// factorEv = min(1/256 / |dDensity|, 2) (:186).  The numerator is a power of two, so the IEEE quotient is the correctly rounded
+// reciprocal scaled exactly: v_rcp_f32 (1 ulp) + one fused Newton step gives it in 5 instructions instead of the compiler's 11 for
+// a general division.  scripts/micro/rcp_exact.cpp compares the two forms over all 2^32 inputs on the GPU (profiles/r03_step_rcp.txt):
+// identical for every |d| < 2^118, for +-0, +-inf and NaN (a density difference of half-float texels is at most 131008).
+// The max(e, -1) only acts when e is NaN (d = 0: r0 = inf; d = inf: r0 = 0) and makes r1 = r0 - r0: NaN -> factor 2, or 0.
+#ifndef MV_STEP_RCP
+#define MV_STEP_RCP 1
+#endif
+__device__ __forceinline__ float StepFactorEv(float dDensity)
+{
+#if MV_STEP_RCP
+	const float x = __builtin_fabsf(dDensity);
+	const float r0 = __builtin_amdgcn_rcpf(x);
+	const float e = __builtin_fmaxf(__builtin_fmaf(-x, r0, 1.0f), -1.0f);
+	const float r1 = __builtin_fmaf(e, r0, r0);
+	return __builtin_fminf(r1 * 0.00390625f, 2.0f);
+#else
+	return __builtin_fminf(1.0f / 256.0f / __builtin_fabsf(dDensity), 2.0f);
+#endif
+}
+
 // :182-192
 __device__ __forceinline__ float GetStep(float dDensity, float transm, float density, float step)
 {
-	const float factorEv = __builtin_fminf(1.0f / 256.0f / __builtin_fabsf(dDensity), 2.0f);
+	const float factorEv = StepFactorEv(dDensity);
 	const float factorUi = __builtin_fminf(1.0f - density, 1.0f);
 	const float factorTh = 1.0f - transm;
 	step *= __builtin_fmaxf(factorTh * 1.5f * factorEv * factorUi, 1.0f);	// the compiled order: ((factorTh * 1.5) * factorEv) * factorUi
@@ -675,7 +696,7 @@ __device__ __forceinline__ float GetStep(float dDensity, float transm, float den
 // was simplified to scatter.w (fast math), and the product is taken in the order ((scatter.w * 1.5) * factorEv) * factorUi.
 __device__ __forceinline__ float GetViewStep(float dDensity, float scatterW, float density, float step)
 {
-	const float factorEv = __builtin_fminf(1.0f / 256.0f / __builtin_fabsf(dDensity), 2.0f);
+	const float factorEv = StepFactorEv(dDensity);
 	const float factorUi = __builtin_fminf(1.0f - density, 1.0f);
 	return __builtin_fmaxf(scatterW * 1.5f * factorEv * factorUi, 1.0f) * step;
 }
