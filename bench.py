@@ -28,12 +28,17 @@ import time
 # more than three whole frames in flight need more than the HIP runtime's default of four hardware queues per process: must be in
 # the environment before the runtime starts (torch starts it), so before anything else (include/multivolumes.h, mv_config.frames_in_flight)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("OMP_PROC_BIND", "spread")  # the cpu_baseline leg: the oracle's threads stay where their pages are
+# (no OMP_PROC_BIND here: libgomp then pins the MAIN thread to one CPU when it loads, and every pthread created afterwards -- the group
+# workers of the reference leg of cpu_baseline, oracle/dxil/dxil_rt.c -- inherits that one-CPU mask: that leg ran at single-thread speed)
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (cpu_baseline leg only) how many CPUs the box really grants -- affinity and cgroup quota, read NOW: once an OpenMP runtime is loaded
+# with OMP_PROC_BIND set (torch's, the oracle's) the main thread is pinned to one CPU and the mask would say 1
+from oracle.mv_oracle import host_cpu_budget  # noqa: E402
+CPU_BUDGET = host_cpu_budget()
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
@@ -532,7 +537,9 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     # a bounded sample of the same frame's marchV: the whole frame on every thread, repeated until ~3 s have passed (the oracle marches
     # C3's 17 M samples in a fraction of a second on 128 threads), then one volume on ONE thread for the per-thread rate
     lib = o.load()
-    threads = lib.mvo_num_threads()
+    budget = CPU_BUDGET  # affinity and cgroup quota: the box shows 256 CPUs and grants 16; threads beyond the grant are throttled
+    threads = min(lib.mvo_num_threads(), budget) if "OMP_NUM_THREADS" not in os.environ else lib.mvo_num_threads()
+    lib.mvo_set_num_threads(threads)
     reps, dt, st = 0, 0.0, None
     t0 = time.perf_counter()
     while dt < 3.0 and reps < 64:
@@ -553,7 +560,7 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     lib.mvo_set_num_threads(threads)
     single = st1["view_samples"] / dt1 / 1e6
     rate = st["view_samples"] / dt / 1e6
-    port = {"value": rate, "unit": "Msamples/s", "cores": threads, "kind": "port",
+    port = {"value": rate, "unit": "Msamples/s", "cores": threads, "kind": "port", "host_cpus": os.cpu_count(), "cpu_budget": budget,
             "build": "oracle/mv_oracle.cpp, g++ -O3 -ffp-contract=off -fopenmp",
             "sample": f"marchV of {len(sel)} of the {len(cube)} cube-map volumes of the same frame ({st['view_samples']} samples) x {reps} repetitions, {dt * reps:.1f} s; "
                       f"single thread: one volume ({st1['view_samples']} samples, {dt1:.1f} s)",
@@ -565,7 +572,7 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
     try:
         from oracle import dxref
         if world == 1 and dxref.available():  # (N = 1 only: the multi-rank runs keep the oracle check of rank 0's cube maps and nothing else)
-            cores = os.cpu_count() or 1
+            cores = threads
             dxref.load().dxref_set_threads(cores)
             dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, fr["depth"], caster.perObject, caster.cbPerFrame, info, sel[:1])  # warm
             t0 = time.perf_counter()
@@ -586,7 +593,7 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
             dxref.load().dxref_set_threads(cores)
             single_ref = st1["view_samples"] / dtr1 / 1e6
             rate_ref = st["view_samples"] / dtr / 1e6
-            return {"value": rate_ref, "unit": "Msamples/s", "cores": min(cores, 256), "kind": "reference",
+            return {"value": rate_ref, "unit": "Msamples/s", "cores": min(cores, 256), "kind": "reference", "host_cpus": os.cpu_count(), "cpu_budget": budget,
                     "build": "oracle/_ref/libmv_dxref.so: the reference's shipped CSRayMarchV.cso (DXIL) translated to x86-64 by LLVM (clang -O1), "
                              "resource intrinsics answered by oracle/dxil/dxil_rt.c, thread groups spread over the host threads; inside a group the 64 lanes of a "
                              "wavefront run as threads that rendezvous on a mutex at every wave intrinsic (the emulation's cost, not the shader's)",

@@ -30,6 +30,46 @@ _lib = None
 _P, _U32, _F = C.c_void_p, C.c_uint32, C.c_float
 
 
+_budget = None
+
+
+def host_cpu_budget():
+    """(computed once, when this module is imported: an OpenMP runtime loaded later with OMP_PROC_BIND set pins the main thread to one
+    CPU, and the affinity mask would then say 1)
+    The CPUs this process can actually keep busy: the smaller of the affinity mask and the cgroup's CFS quota (a GPU box of this pool
+    shows 256 logical CPUs and grants 16: `cpu.max 1600000 100000`).  More threads than that are throttled, and the throughput of a
+    sustained run collapses (profiles/r03_cpu_scaling.txt) -- so this is the thread count of both CPU legs of bench.py's cpu_baseline
+    and the oracle's default."""
+    global _budget
+    if _budget is not None:
+        return _budget
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.999)))
+    _budget = max(1, n)
+    return _budget
+
+
+host_cpu_budget()
+
+
 def load():
     global _lib
     if _lib is not None:
@@ -69,6 +109,8 @@ def load():
         lib.mvo_composite.argtypes = [_U32, _U32, _U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P]
         lib.mvo_composite_over.restype = None
         lib.mvo_composite_over.argtypes = [_U32, _U32, _U32, _U32, _U32, _U32, _U32, _P, _P, _P, _P, _P, _P, _P, _U32, _P, _P, _P, _P, _P]
+    if "OMP_NUM_THREADS" not in os.environ:
+        lib.mvo_set_num_threads(host_cpu_budget())
     _lib = lib
     return lib
 
