@@ -1063,7 +1063,7 @@ static int marchLight(mv_ctx* ctx, uint32_t* wordsOut)
 	// every frame waited for: 0.349 -> 0.331 ms per frame at C3 with two output sets, 0.311 ms with three.)
 	hipStream_t L = ctx->lightOnViewStream ? streamB(ctx) : ctx->streamL;
 	if (distLightOnStreamA(ctx)) L = ctx->stream;
-	MV_HIP(ctx, evWait(ctx, L, ctx->evMainDone[(ctx->slot + 1u) % ctx->numSlots]));
+	MV_HIP(ctx, evWait(ctx, L, ctx->evMainDone[(ctx->slot + ctx->numSlots - ctx->st.lightBufs) % ctx->numSlots]));
 	MV_HIP(ctx, evWait(ctx, L, ctx->evStageA[ctx->slot]));	// this frame's upload + cull
 	EventPair ev = { nullptr, nullptr, 0 };
 	beginStage(ctx, 1, ev, L);
@@ -1972,7 +1972,7 @@ static int distLight(mv_ctx* ctx, uint32_t chain)
 		if (distLightOnStreamA(ctx)) E = ctx->stream;
 		if (!d->chains) MV_HIP(ctx, evWait(ctx, E, ctx->evLight[ctx->slot]));	// this rank's light march (chains: the same stream)
 		MV_HIP(ctx, evWait(ctx, E, ctx->evStageA[ctx->slot]));	// this frame's cull: the relit volume, its rotated buffer
-		MV_HIP(ctx, evWait(ctx, E, ctx->evMainDone[(ctx->slot + 1u) % ctx->numSlots]));	// frame k - 3, the last reader of the buffer the unpack overwrites
+		MV_HIP(ctx, evWait(ctx, E, ctx->evMainDone[(ctx->slot + ctx->numSlots - ctx->st.lightBufs) % ctx->numSlots]));	// frame k - 3, the last reader of the buffer the unpack overwrites
 		if ((rc = distAllGather(ctx, lightMine, lightAll, d->lightShareBytes, E, d->chains ? (int)chain : 1)) != MV_OK) return rc;
 		mv::launchLightUnpack(E, ctx->st, d->lightWords[chain]);
 		MV_HIP(ctx, hipGetLastError());
@@ -1995,6 +1995,22 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 	{ MV_SECTION(1); if ((rc = mv_cull(ctx)) != MV_OK) return rc; }
 #ifdef MV_HOST_PROFILE
 	++gSectionCalls;
+	if (getenv("MV_PROFILE_PHASE"))	// at the start of a call (after this frame's cull was enqueued): which earlier frames' stages has the GPU finished?
+	{
+		static uint64_t cullDone[6], tailDone[6], n;
+		for (uint32_t b = 1; b <= 5; ++b)
+		{
+			const uint32_t sl = (ctx->slot + ctx->numSlots * 4u - b) % ctx->numSlots;
+			if (b < ctx->numSlots && hipEventQuery(ctx->evStageA[sl]) == hipSuccess) ++cullDone[b];
+			if (b < ctx->numSlots && hipEventQuery(ctx->evMainDone[sl]) == hipSuccess) ++tailDone[b];
+		}
+		if (++n % 200 == 0)
+		{
+			fprintf(stderr, " [phase at call start, share of calls: cull done of frame k-1 %.2f k-2 %.2f k-3 %.2f; tail done of k-1 %.2f k-2 %.2f k-3 %.2f]",
+				cullDone[1] / 200.0, cullDone[2] / 200.0, cullDone[3] / 200.0, tailDone[1] / 200.0, tailDone[2] / 200.0, tailDone[3] / 200.0);
+			for (auto& x : cullDone) x = 0; for (auto& x : tailDone) x = 0;
+		}
+	}
 	if (getenv("MV_PROFILE_CULL_LATENCY"))	// how long after its enqueue the cull's report reaches pinned memory (spins: perturbs the loop)
 	{
 		const auto t0 = std::chrono::steady_clock::now();

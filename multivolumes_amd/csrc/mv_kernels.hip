@@ -25,6 +25,28 @@ __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 	return v;
 }
 
+// minimum over the wavefront, in every lane: a DPP reduction (row shifts, then the row broadcasts of gfx9), a dozen cycles per step
+// where a __shfl goes through the LDS crossbar
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dppMinStepU64(unsigned long long v)
+{
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)(uint32_t)v, CTRL, ROW_MASK, 0xf, false);
+	const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)(uint32_t)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+	const unsigned long long o = ((unsigned long long)hi << 32) | lo;	// (a lane without a source, or a masked row, sees the identity)
+	return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned long long waveMinU64(unsigned long long v)
+{
+	v = dppMinStepU64<0x111, 0xf>(v);	// row_shr:1
+	v = dppMinStepU64<0x112, 0xf>(v);	// row_shr:2
+	v = dppMinStepU64<0x114, 0xf>(v);	// row_shr:4
+	v = dppMinStepU64<0x118, 0xf>(v);	// row_shr:8 -> lane 15 of every row holds the row's minimum
+	v = dppMinStepU64<0x142, 0xa>(v);	// row_bcast:15 into rows 1 and 3
+	v = dppMinStepU64<0x143, 0xc>(v);	// row_bcast:31 into rows 2 and 3 -> lane 63 holds the wavefront's
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), 63);
+	return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ uint32_t waveExclusiveScanU32(uint32_t v, uint32_t lane, uint32_t& total)
 {
 	uint32_t incl = v;
@@ -464,30 +486,36 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		unsigned long long load = 0;
 		if (balance && st.V <= 64u)
 		{
-			// Up to 64 volumes (every scene of the reference): volume v's cost lives in lane v, rank r's load in lane r, and the deal is
-			// a scalar loop over v_readlane -- no cross-lane reduction, no LDS (the reductions of the general path below cost ~2 us per
-			// volume dealt, 20 us of a 12 us kernel at C3).
-			uint32_t myCost = lane < st.V ? sCost[lane] : 0u, myOwner = lane % shardCount;
-			uint32_t loadLo = 0, loadHi = 0;
-			for (uint32_t it = 0; it < nDeal; ++it)
+			// Up to 64 volumes (every scene of the reference): volume v's cost lives in lane v, rank r's load in lane r.  The greedy deal
+			// takes the volumes in the order (cost descending, v ascending) -- so every lane first finds its volume's POSITION in that order
+			// by counting the volumes in front of it (one v_readlane per volume, no branches), a ds_permute puts the costs in that order,
+			// and the loop that is sequential by nature only has left: the least loaded rank, by a DPP min-reduction of (load << 6 | rank).
+			// ~0.1 us per volume dealt.  (Round 2's version searched the maximum and the minimum with scalar loops over v_readlane in
+			// every step: 1.4 us per volume -- 14 of the cull's 30 us on a rank at C3, several times that at C5's 64 volumes.)
+			const uint32_t myCost = lane < st.V ? sCost[lane] : 0u;
+			uint32_t pos = 0;
+			for (uint32_t j0 = 0; j0 < st.V; j0 += 8u)
+#pragma unroll
+				for (uint32_t jj = 0; jj < 8u; ++jj)
+				{
+					const uint32_t j = j0 + jj;	// (lanes beyond V hold cost 0: they are in front of nobody with a cost)
+					const uint32_t cj = (uint32_t)__builtin_amdgcn_readlane((int)myCost, (int)j);
+					pos += (cj > myCost || (cj == myCost && j < lane)) ? 1u : 0u;
+				}
+			if (lane >= st.V) pos = lane;	// (a permutation of all 64 lanes)
+			const uint32_t sorted = (uint32_t)__builtin_amdgcn_ds_permute((int)(pos << 2), (int)myCost);	// lane k: the k-th volume's cost
+			unsigned long long load = 0;
+			uint32_t ownerAt = 0;	// lane k: the rank the k-th volume went to
+			for (uint32_t k = 0; k < nDeal; ++k)
 			{
-				uint32_t bestCost = 0, bestV = 0;
-				for (uint32_t v = 0; v < st.V; ++v)
-				{
-					const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)myCost, (int)v);
-					if (c > bestCost) { bestCost = c; bestV = v; }	// (ascending v: the first of equals stays)
-				}
-				unsigned long long minLoad = ~0ull;
-				uint32_t minRank = 0;
-				for (uint32_t r = 0; r < shardCount; ++r)
-				{
-					const unsigned long long l = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)loadHi, (int)r) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)loadLo, (int)r);
-					if (l < minLoad) { minLoad = l; minRank = r; }
-				}
-				if (lane == minRank) { const unsigned long long l = (((unsigned long long)loadHi << 32) | loadLo) + bestCost; loadLo = (uint32_t)l; loadHi = (uint32_t)(l >> 32); }
-				if (lane == bestV) { myCost = 0u; myOwner = minRank; }
+				const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)sorted, (int)k);
+				const unsigned long long key = waveMinU64(lane < shardCount ? (load << 6) | lane : ~0ull);	// ties: the lowest rank
+				const uint32_t minRank = (uint32_t)key & 63u;
+				if (lane == minRank) load += c;
+				if (lane == k) ownerAt = minRank;
 			}
-			if (lane < st.V) sInfo[lane] = (sInfo[lane] & 0xffffu) | (myOwner << 16);
+			const uint32_t myOwner = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(pos << 2), (int)ownerAt);
+			if (lane < st.V && myCost) sInfo[lane] = (sInfo[lane] & 0xffffu) | (myOwner << 16);	// (the others keep v % shardCount)
 			__syncthreads();
 		}
 		else
