@@ -23,6 +23,7 @@ int main(int argc, char** argv)
 	setenv("MV_DIST_NULL_TRANSPORT", "1", 1);	// the collectives below exchange nothing: no cross-rank check of the culls (mv_api.cpp)
 	const bool c5 = argc > 5 && std::string(argv[5]) == "C5";	// BASELINE config C5: 64 volumes, 2048^2, 256 steps (default C3)
 	const uint32_t N = 256, L = 96, V = c5 ? 64 : 16, W = c5 ? 2048 : 1024, H = W, M = 1024;
+	const bool withComposite = !std::getenv("RANK_COST_NO_COMPOSITE");	// (experiment: a frame without its composite + row gather)
 	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
 	const unsigned worlds = argc > 2 ? (unsigned)std::atoi(argv[2]) : 15u;
 	const int onlyRank = argc > 3 ? std::atoi(argv[3]) : -1;	// (one rank only: for a kernel trace)
@@ -61,12 +62,12 @@ int main(int argc, char** argv)
 			rc.SetAmbient(ac, 2.0f * 3.14159265f);
 			if (mv_dist_init_callbacks(rc.Context(), noGather, noReduce, nullptr) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
 			mv_dist_set_inplace_gather(rc.Context(), 1);	// like RCCL: no staging copies
-			for (int f = 0; f < std::min(200, frames); ++f) if (!rc.DistFrame(viewProj, shadowVP, eye)) { std::fprintf(stderr, "%s\n", rc.LastError()); return 6; }
+			for (int f = 0; f < std::min(200, frames); ++f) if (!rc.DistFrame(viewProj, shadowVP, eye, withComposite)) { std::fprintf(stderr, "%s\n", rc.LastError()); return 6; }
 			rc.DistFlush(); mv_synchronize(rc.Context());
 			double waited = 0.0;
 			mv_host_wait_ms(rc.Context(), &waited, 1);
 			const auto t0 = std::chrono::steady_clock::now();
-			for (int f = 0; f < frames; ++f) if (!rc.DistFrame(viewProj, shadowVP, eye)) return 6;
+			for (int f = 0; f < frames; ++f) if (!rc.DistFrame(viewProj, shadowVP, eye, withComposite)) return 6;
 			mv_host_wait_ms(rc.Context(), &waited, 1);
 			const double host = (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - waited) / frames;	// enqueueing, without the waits for a free frame slot
 			rc.DistFlush(); mv_synchronize(rc.Context());
