@@ -2,21 +2,17 @@
 //   min(1/256 / |d|, 2)   ==   min(RN-corrected rcp(|d|) * 2^-8, 2)
 // The numerator is a power of two, so the IEEE quotient is the correctly rounded reciprocal scaled exactly; v_rcp_f32 is within 1 ulp
 // and one fused Newton step r1 = fma(fma(-x, r0, 1), r0, r0) rounds it correctly -- this program proves (or refutes) that for every input.
-// build: hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -o rcp_exact.bin rcp_exact.cpp
-#include <hip/hip_runtime.h>
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -o rcp_exact.bin rcp_exact.cpp   (the library's flags)
+// tests/test_gpu_configs.py::test_step_factor_equals_the_ieee_quotient_for_every_input builds and runs it
+#define MV_STEP_RCP 1
+#include "../../multivolumes_amd/csrc/mv_device.hpp"
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
 
 __device__ __forceinline__ float viaDivision(float d) { return __builtin_fminf(1.0f / 256.0f / __builtin_fabsf(d), 2.0f); }
-__device__ __forceinline__ float viaRcp(float d)
-{
-	const float x = __builtin_fabsf(d);
-	const float r0 = __builtin_amdgcn_rcpf(x);
-	const float e = __builtin_fmaxf(__builtin_fmaf(-x, r0, 1.0f), -1.0f);	// NaN (x = 0 or inf) -> -1: r1 = r0 - r0
-	const float r1 = __builtin_fmaf(e, r0, r0);
-	return __builtin_fminf(r1 * 0.00390625f, 2.0f);
-}
+// the library's own function (mv_device.hpp, MV_STEP_RCP = 1: v_rcp_f32, one fused Newton step, max(e, -1) for the NaN cases, x 2^-8)
+__device__ __forceinline__ float viaRcp(float d) { return mv::StepFactorEv(d); }
 __global__ void check(unsigned long long* out)
 {
 	const uint32_t lane = blockIdx.x * blockDim.x + threadIdx.x;	// 2^20 threads, 2^12 patterns each

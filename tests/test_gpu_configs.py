@@ -532,3 +532,22 @@ def test_set_viewport_mid_sequence_equals_a_fresh_context(oracle):
                 assert np.array_equal(x, y)
         # the volumes themselves were never uploaded again
         assert np.array_equal(c.ReadBackVolume(3), vols[3].reshape(c.ReadBackVolume(3).shape))
+
+
+def test_step_factor_equals_the_ieee_quotient_for_every_input(tmp_path):
+    """GetStep's factorEv = min(1/256 / |d|, 2) (RayMarch.hlsli:186) is taken from v_rcp_f32 + one Newton step in the kernels
+    (mv_device.hpp StepFactorEv) instead of the compiler's IEEE division.  scripts/micro/rcp_exact.cpp includes that header and compares
+    the two over ALL 2^32 float bit patterns on the GPU; it fails if any input below 2^118 in magnitude, or any infinity / NaN, differs
+    (a density difference of half-float texels is at most 131008)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "rcp_exact.bin")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math", "-w", "-o", exe,
+                    os.path.join(root, "scripts", "micro", "rcp_exact.cpp")], check=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout.strip())
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "0 infinities / NaNs" in r.stdout
