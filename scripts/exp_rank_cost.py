@@ -3,6 +3,8 @@ GPU, mv_dist_frame with do-nothing collectives.  The images are wrong (nothing i
 (replicated cull + orders, its light marches, its share of the view march, pack / unpack, its rows of the composite, copy-forward)
 and their scheduling are the real ones.  max over ranks = the frame time an ideal fabric would give; the ratio to the one-GPU frame
 is the ceiling of the strong-scaling curve (run through gpurun: python scripts/exp_rank_cost.py [C3])."""
+import os
+os.environ["MV_DIST_NULL_TRANSPORT"] = "1"  # the collectives below exchange nothing: no cross-rank check of the culls (mv_api.cpp)
 import sys, os, time
 import torch; torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,7 @@
 """One rank of the multi-GPU loop with do-nothing collectives (see exp_rank_cost.py), for a kernel trace:
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_rank -- python3 scripts/exp_rank_trace.py 8 2 [single]; python3 scripts/timeline.py /tmp/prof_rank"""
+import os
+os.environ["MV_DIST_NULL_TRANSPORT"] = "1"  # the collectives below exchange nothing: no cross-rank check of the culls (mv_api.cpp)
 import sys, os
 import torch; torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -52,3 +52,21 @@ def oracle_pipeline(o, cfg, volumes, M, frames=None, sh=None, eye=None):
 
 def pack_r11g11b10f_const(o, r, g, b, L):
     return np.full((L, L, L), o.load().mvo_pack_r11g11b10f(r, g, b), np.uint32)
+
+
+def replicating_allgather(world):
+    """An all-gather callback for ONE rank alone on the GPU (no peers to exchange with): every slot of the receive buffer gets this rank's
+    own share, through hipMemcpyAsync on the collective's stream.  The loop's cross-rank check of the culls (the trailers of the light
+    exchange) then sees `world` equal trailers -- with a callback that copies nothing it would read whatever the buffer held."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.restype = C.c_int
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+
+    def allgather(send, recv, nbytes, stream, which):
+        for r in range(world):
+            dst = recv + r * nbytes
+            if dst != send and hip.hipMemcpyAsync(dst, send, nbytes, 3, stream) != 0:  # 3 = hipMemcpyDeviceToDevice
+                return 1
+        return 0
+    return allgather

@@ -201,6 +201,7 @@ def test_the_culls_deal_equals_its_host_restatement(V, world):
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
     from multivolumes_amd import distributed as D
+    from tests.helpers import replicating_allgather
     cfg = dict(scene.CONFIGS["T2"], V=V, W=256, H=168)
     N, L = cfg["N"], cfg["L"]
     vols = [rc.synth_volume(N, k % 5) for k in range(V)]
@@ -209,7 +210,7 @@ def test_the_culls_deal_equals_its_host_restatement(V, world):
         flags = _lib.MV_FLAG_PIPELINE_FRAMES
         with MultiRayCaster(N, L, V, 5, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world)) as c:
             fr = scene.setup_raycaster(c, cfg, vols[:5])
-            c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0)
+            c.DistInitCallbacks(replicating_allgather(world), lambda b, n, st, w: 0)  # (a rank alone: its own share in every slot)
             c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
             c.DistFlush()
             c.synchronize()
