@@ -20,7 +20,6 @@ static int noReduce(void*, void*, size_t, void*, int) { return 0; }
 
 int main(int argc, char** argv)
 {
-	setenv("MV_DIST_NULL_TRANSPORT", "1", 1);	// the collectives below exchange nothing: no cross-rank check of the culls (mv_api.cpp)
 	const bool c5 = argc > 5 && std::string(argv[5]) == "C5";	// BASELINE config C5: 64 volumes, 2048^2, 256 steps (default C3)
 	const uint32_t N = 256, L = 96, V = c5 ? 64 : 16, W = c5 ? 2048 : 1024, H = W, M = 1024;
 	const bool withComposite = !std::getenv("RANK_COST_NO_COMPOSITE");	// (experiment: a frame without its composite + row gather)
@@ -62,6 +61,7 @@ int main(int argc, char** argv)
 			rc.SetAmbient(ac, 2.0f * 3.14159265f);
 			if (mv_dist_init_callbacks(rc.Context(), noGather, noReduce, nullptr) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
 			mv_dist_set_inplace_gather(rc.Context(), 1);	// like RCCL: no staging copies
+			mv_dist_set_cull_crosscheck(rc.Context(), 0);	// the collectives here deliver nothing: the other ranks' culls are not there to compare
 			for (int f = 0; f < std::min(200, frames); ++f) if (!rc.DistFrame(viewProj, shadowVP, eye, withComposite)) { std::fprintf(stderr, "%s\n", rc.LastError()); return 6; }
 			rc.DistFlush(); mv_synchronize(rc.Context());
 			double waited = 0.0;

@@ -300,6 +300,11 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id /* MV_DIST_ID_BYTES, the same 
 typedef int (*mv_dist_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* stream, int which);
 typedef int (*mv_dist_allreduce_u32_fn)(void* user, void* buf, size_t count, void* stream, int which);
 int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user);
+/* Every frame the loop checks, through four words behind each rank's share of the light exchange, that all ranks' replicated culls
+ * decided the same (a caller that passed different frame constants on different ranks gets MV_ERR_INVALID_ARG instead of mismatched
+ * collectives).  On by default.  Off is for a rank driven ALONE with collectives that deliver nothing (examples/dist_rank_cost.cpp,
+ * scripts/exp_rank_cost.py: what one rank of N costs without a fabric) -- the other ranks' words are then not there to compare. */
+int mv_dist_set_cull_crosscheck(mv_ctx* ctx, int enabled);
 /* Caller-supplied collectives only: 1 = the all-gather may be called in place (send == recv + rank * bytes, NCCL's convention); the
  * row bands of the composite are then gathered straight into the frame buffer instead of through staging copies.  Default 0. */
 int mv_dist_set_inplace_gather(mv_ctx* ctx, int enabled);

@@ -115,6 +115,7 @@ ABI = {
     "mv_dist_selftest": (C.c_int, [_P]),
     "mv_dist_shutdown": (C.c_int, [_P]),
     "mv_dist_set_inplace_gather": (C.c_int, [_P, C.c_int]),
+    "mv_dist_set_cull_crosscheck": (C.c_int, [_P, C.c_int]),
     "mv_dist_frame": (C.c_int, [_P, _P, _P, C.c_int]),
     "mv_dist_flush": (C.c_int, [_P]),
     "mv_dist_exchanged_bytes": (C.c_int, [_P, C.POINTER(C.c_uint64), C.c_int]),

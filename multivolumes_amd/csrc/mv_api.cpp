@@ -107,6 +107,7 @@ struct DistState
 	// * single view stream (| MV_FLAG_SINGLE_VIEW_STREAM: two output sets): the view marches on the context's stream, the exchange and
 	//   composite of frame k - 1 beside frame k's march on stream X; comm [0] = cube faces + row bands, [1] = light maps.
 	bool chains = false;
+	bool cullCrosscheck = true;	// the loop compares the ranks' culls through the light exchange's trailers (mv_dist_set_cull_crosscheck)
 	bool inPlaceGather = false;	// the transport's all-gather accepts send == recv + rank * bytes (RCCL does; a caller says so with mv_dist_set_inplace_gather)
 	uint32_t numComm = 2;
 	uint32_t numChains = 1;			// chains: one per view stream of the context (3 by default), each with its communicator and buffers; else 1
@@ -1042,7 +1043,7 @@ int mv_cull(mv_ctx* ctx)
 }
 
 static int marchLight(mv_ctx* ctx, uint32_t* wordsOut);
-// EXPERIMENT (MV_DIST_LIGHT_ON_A=1): on a rank of the multi-GPU loop with whole-frame chains, the light share-out (march, all-gather,
+// EXPERIMENT (-DMV_DIAGNOSTICS builds, MV_DIST_LIGHT_ON_A=1; profiles/r03_light_on_stream_a.txt: slower): on a rank of the multi-GPU loop with whole-frame chains, the light share-out (march, all-gather,
 // unpack) goes on stream A behind the frame's cull instead of in front of the frame's view march on its chain
 static bool distLightOnStreamA(const mv_ctx* ctx);
 int mv_march_light(mv_ctx* ctx) { return ctx ? marchLight(ctx, nullptr) : MV_ERR_INVALID_ARG; }
@@ -1830,6 +1831,14 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
 	return distCommonInit(ctx);
 }
 
+int mv_dist_set_cull_crosscheck(mv_ctx* ctx, int enabled)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
+	ctx->dist->cullCrosscheck = enabled != 0;
+	return MV_OK;
+}
+
 int mv_dist_set_inplace_gather(mv_ctx* ctx, int enabled)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
@@ -1879,10 +1888,9 @@ static int distTailExchange(mv_ctx* ctx)
 		}
 		MV_REQUIRE(ctx, (uint32_t)(rep >> 32) == st.frameTag, MV_ERR_HIP, "the cull's exchange report is missing");
 		// (the light exchange of this frame compared what every rank's cull decided: mv_kernels.hip lightUnpackKernel)
-		// (MV_DIST_NULL_TRANSPORT=1: examples/dist_rank_cost.cpp measures a rank with callbacks that exchange nothing -- the other
-		// ranks' trailers are then not there to compare)
-		static const bool nullTransport = [] { const char* e = getenv("MV_DIST_NULL_TRANSPORT"); return e && e[0] == '1'; }();
-		MV_REQUIRE(ctx, nullTransport || report[1] != (((unsigned long long)st.frameTag << 32) | 1ull), MV_ERR_INVALID_ARG,
+		// (mv_dist_set_cull_crosscheck(ctx, 0): a rank measured alone, with callbacks that exchange nothing -- the other ranks'
+		// trailers are then not there to compare)
+		MV_REQUIRE(ctx, !d->cullCrosscheck || report[1] != (((unsigned long long)st.frameTag << 32) | 1ull), MV_ERR_INVALID_ARG,
 			"the ranks' culls of this frame disagree (different frame constants on different ranks?): its collectives would not match");
 		const size_t shardBytes = std::max<size_t>(16, ((size_t)(uint32_t)rep * 12u + 15u) & ~(size_t)15u);
 		MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
@@ -1951,8 +1959,13 @@ namespace { int distTail(mv_ctx* ctx)
 // every rank marches its own screen rows of every volume on the screen-space scheme.
 static bool distLightOnStreamA(const mv_ctx* ctx)
 {
+#ifdef MV_DIAGNOSTICS	// (the shipped library reads no environment variable)
 	static const bool on = [] { const char* e = getenv("MV_DIST_LIGHT_ON_A"); return e && e[0] == '1'; }();
 	return on && ctx->dist && ctx->dist->chains && ctx->st.shardCount > 1u;
+#else
+	(void)ctx;
+	return false;
+#endif
 }
 
 static int distLight(mv_ctx* ctx, uint32_t chain)

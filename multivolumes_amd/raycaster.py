@@ -469,6 +469,11 @@ class MultiRayCaster:
         """Caller-supplied collectives: the all-gather accepts send == recv + rank * bytes (NCCL's in-place convention)."""
         self._check(self._lib.mv_dist_set_inplace_gather(self._ctx, 1 if enabled else 0), "mv_dist_set_inplace_gather")
 
+    def DistSetCullCrosscheck(self, enabled=True):
+        """The loop's per-frame check that every rank's cull decided the same (on by default); off for a rank driven alone with
+        collectives that deliver nothing (scripts/exp_rank_cost.py)."""
+        self._check(self._lib.mv_dist_set_cull_crosscheck(self._ctx, 1 if enabled else 0), "mv_dist_set_cull_crosscheck")
+
     def DistShutdown(self):
         self._check(self._lib.mv_dist_shutdown(self._ctx), "mv_dist_shutdown")
         self._dist_cbs = None

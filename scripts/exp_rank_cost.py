@@ -3,8 +3,6 @@ GPU, mv_dist_frame with do-nothing collectives.  The images are wrong (nothing i
 (replicated cull + orders, its light marches, its share of the view march, pack / unpack, its rows of the composite, copy-forward)
 and their scheduling are the real ones.  max over ranks = the frame time an ideal fabric would give; the ratio to the one-GPU frame
 is the ceiling of the strong-scaling curve (run through gpurun: python scripts/exp_rank_cost.py [C3])."""
-import os
-os.environ["MV_DIST_NULL_TRANSPORT"] = "1"  # the collectives below exchange nothing: no cross-rank check of the culls (mv_api.cpp)
 import sys, os, time
 import torch; torch.cuda.init()
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,7 +23,7 @@ for mode, flags in (("chains (whole frames on three view streams)", _lib.MV_FLAG
         for rank in range(world):
             with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=1024, flags=flags, shard=(rank, world)) as c:
                 fr = scene.setup_raycaster(c, cfg, vols)
-                c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0); c.DistSetInPlaceGather(True)  # like RCCL: no staging copies
+                c.DistInitCallbacks(lambda s, r, n, st, w: 0, lambda b, n, st, w: 0); c.DistSetInPlaceGather(True); c.DistSetCullCrosscheck(False)  # like RCCL: no staging copies; nothing is delivered, so no cross-rank check
                 for _ in range(min(200, frames)): c.DistFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
                 c.DistFlush(); c.synchronize()
                 t0 = time.perf_counter()
