@@ -15,7 +15,7 @@ import numpy as np
 from . import mv_oracle as O
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_DIR, "_ref", "libmv_dxref.so")
+_PATH = os.environ.get("MV_DXREF_LIB") or os.path.join(_DIR, "_ref", "libmv_dxref.so")  # (MV_DXREF_LIB: scripts/sanitize_cpu.sh, the runtime built with ASan / UBSan)
 _lib = None
 
 SRV, UAV, CBV, SAMPLER = 0, 1, 2, 3

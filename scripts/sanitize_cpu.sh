@@ -31,3 +31,17 @@ export ASAN_OPTIONS="detect_leaks=0:alloc_dealloc_mismatch=0:halt_on_error=1:abo
 export UBSAN_OPTIONS="print_stacktrace=1"
 export MV_LIB_PATH="$OUT/libmultivolumes_amd.so" MV_ORACLE_LIB="$OUT/libmv_oracle.so"
 python -m pytest tests -q -m "not gpu" -p no:cacheprovider "$@"
+
+# Second pass: the runtime of the compiled-reference library (oracle/dxil: resource intrinsics, wave rendezvous, the work-graph scheduler,
+# the independent sampler).  It needs _Float16, which this image's gcc lacks on x86: built by ROCm's clang with ITS sanitizer runtime,
+# linked with the translated shaders' objects as `make -C oracle ref` left them, and run on its own (two ASan runtimes cannot share a
+# process): the oracle and the product library unsanitized here.
+if ls "$ROOT"/oracle/_ref/*_fp32.o > /dev/null 2>&1; then
+	CLANG=${CLANG:-/opt/rocm/lib/llvm/bin/clang}
+	"$CLANG" -O1 -fPIC -mf16c -ffp-contract=off -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -shared-libsan -shared \
+		-o "$OUT/libmv_dxref.so" "$ROOT/oracle/dxil/dxil_rt.c" "$ROOT/oracle/dxil/d3d_sampler.c" "$ROOT"/oracle/_ref/*_fp32.o "$ROOT"/oracle/_ref/*_fp16.o -lm -lpthread
+	unset MV_LIB_PATH MV_ORACLE_LIB
+	export LD_PRELOAD="$("$CLANG" -print-file-name=libclang_rt.asan-x86_64.so)"
+	export MV_DXREF_LIB="$OUT/libmv_dxref.so"
+	python -m pytest tests/test_oracle_vs_reference_dxil.py -q -p no:cacheprovider "$@"
+fi
