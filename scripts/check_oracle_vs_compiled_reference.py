@@ -34,6 +34,16 @@ for name in sys.argv[1:] or ["C2", "C3"]:
     rm, rd = dxref.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, i0, c0)
     print(f"{name}: view march, {st['view_samples']} samples, {st['rays']} rays: {int((rm != cm).sum())} of {int(sum(6 * (N >> int(i0[v, 0])) ** 2 * 4 for v in c0))} marched halves differ, "
           f"{int((rd != cd).sum())} cube depths differ  ({time.time() - t0:.0f} s)", flush=True)
+    # the reference's second statement of cull + view march, the work-graph library Bin/LibRayMarch.cso (both nodes, scheduled as the
+    # reference dispatches the graph), against the oracle's LibRayMarch mode (no ComputeTargetHit clamp)
+    o.load().mvo_set_options(0, 1)
+    cml, cdl, _ = o.march_view(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, i0, c0)
+    o.load().mvo_set_options(0, 0)
+    dxref.load().dxref_set_threads(o.host_cpu_budget())
+    il, vl, recs, rml, rdl = dxref.lib_ray_march(V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, descs, cb, cfg["maxRay"])
+    print(f"{name}: work-graph library: VolumeInfo / visible list identical: {np.array_equal(il, i0) and np.array_equal(vl, np.sort(v0))}; {len(recs)} RayMarchRecords == the cube-map volumes: "
+          f"{np.array_equal(recs[:, 2], np.sort(c0))}; {int((rml != cml).sum())} marched halves and {int((rdl != cdl).sum())} cube depths differ from the oracle's LibRayMarch mode "
+          f"(which differs from the CSRayMarchV statement in {int((cml != cm).sum())} halves)  ({time.time() - t0:.0f} s)", flush=True)
     W2, H2 = 256, 256   # the composite runs one Python-driven invocation per fragment: a quarter-size viewport
     cfg2 = dict(cfg, W=W2, H=H2)
     _, vp2, svp2, cb2, po2 = host_frame(cfg2, 0)
