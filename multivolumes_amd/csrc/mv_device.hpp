@@ -557,8 +557,33 @@ __device__ __forceinline__ LightFootprint fetchLightFootprint(const uint4* quads
 	return fetchLightFootprintAt((GlobalBytes)quads, 0u, L, uvw);
 }
 
+#ifndef MV_LIGHT_FMA_MIX
+#define MV_LIGHT_FMA_MIX 1	// the light footprint's x lerps on fp16 bits through v_fma_mix_f32 (0: convert every channel first, A/B)
+#endif
 __device__ __forceinline__ vec3 resolveLight(const LightFootprint& f)
 {
+#if MV_FMA_MIX && MV_LIGHT_FMA_MIX
+	// An 11- / 10-bit float is an fp16 without its low mantissa bits (same exponent field, unpack_r11g11b10f above): R and G of a texel go,
+	// as fp16 bit patterns, into the two halves of one register, B into the low half of another, and the four x lerps of a channel read
+	// them through v_fma_mix_f32 exactly as the colour footprint's do (lerpHalves: the same two FMAs as lerpf, the conversion riding on
+	// them) -- 24 conversions fewer per lit sample, the same bits.
+#define MV_RG(p) ((((p) << 4) & 0x7ff0u) | (((p) << 9) & 0x7ff00000u))
+#define MV_B(p) (((p) >> 17) & 0x7fe0u)
+	const uint32_t rg000 = MV_RG(f.q0.x), rg100 = MV_RG(f.q0.y), rg010 = MV_RG(f.q0.z), rg110 = MV_RG(f.q0.w);
+	const uint32_t rg001 = MV_RG(f.q1.x), rg101 = MV_RG(f.q1.y), rg011 = MV_RG(f.q1.z), rg111 = MV_RG(f.q1.w);
+	const uint32_t b000 = MV_B(f.q0.x), b100 = MV_B(f.q0.y), b010 = MV_B(f.q0.z), b110 = MV_B(f.q0.w);
+	const uint32_t b001 = MV_B(f.q1.x), b101 = MV_B(f.q1.y), b011 = MV_B(f.q1.z), b111 = MV_B(f.q1.w);
+#undef MV_RG
+#undef MV_B
+	vec3 o;
+	o.x = lerpf(lerpf(lerpHalves<0, 0>(rg000, rg100, f.cx), lerpHalves<0, 0>(rg010, rg110, f.cx), f.cy),
+		lerpf(lerpHalves<0, 0>(rg001, rg101, f.cx), lerpHalves<0, 0>(rg011, rg111, f.cx), f.cy), f.fz);
+	o.y = lerpf(lerpf(lerpHalves<1, 1>(rg000, rg100, f.cx), lerpHalves<1, 1>(rg010, rg110, f.cx), f.cy),
+		lerpf(lerpHalves<1, 1>(rg001, rg101, f.cx), lerpHalves<1, 1>(rg011, rg111, f.cx), f.cy), f.fz);
+	o.z = lerpf(lerpf(lerpHalves<0, 0>(b000, b100, f.cx), lerpHalves<0, 0>(b010, b110, f.cx), f.cy),
+		lerpf(lerpHalves<0, 0>(b001, b101, f.cx), lerpHalves<0, 0>(b011, b111, f.cx), f.cy), f.fz);
+	return o;
+#endif
 	const vec3 c000 = unpack_r11g11b10f(f.q0.x), c100 = unpack_r11g11b10f(f.q0.y), c010 = unpack_r11g11b10f(f.q0.z), c110 = unpack_r11g11b10f(f.q0.w);
 	const vec3 c001 = unpack_r11g11b10f(f.q1.x), c101 = unpack_r11g11b10f(f.q1.y), c011 = unpack_r11g11b10f(f.q1.z), c111 = unpack_r11g11b10f(f.q1.w);
 	vec3 r;
