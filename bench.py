@@ -37,8 +37,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # (cpu_baseline leg only) how many CPUs the box really grants -- affinity and cgroup quota, read NOW: once an OpenMP runtime is loaded
 # with OMP_PROC_BIND set (torch's, the oracle's) the main thread is pinned to one CPU and the mask would say 1
-from oracle.mv_oracle import host_cpu_budget  # noqa: E402
-CPU_BUDGET = host_cpu_budget()
+def _host_cpu_budget():
+    """min(CPUs of the affinity mask, cgroup CPU quota): a GPU box of this pool shows 256 logical CPUs and grants 16 (cpu.max)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q, per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = min(n, max(1, int(quota + 0.999)))
+    return max(1, n)
+
+
+CPU_BUDGET = _host_cpu_budget()
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
