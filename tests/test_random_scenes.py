@@ -1,6 +1,8 @@
 """Randomised parity sweep: the whole path (cull, V light marches, view march, composite) against the oracle on
 seeded random scenes -- ragged grid sizes, random eyes (outside, inside and between the volumes), sparse / dense / noisy
 volumes, SH on and off, with and without mesh depth.  Everything must match bit for bit, counters included."""
+import os
+
 import numpy as np
 import pytest
 
@@ -26,7 +28,7 @@ def random_volume(rng, N, kind):
     return v.view(np.uint16)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MV_RANDOM_SEEDS", "12"))))  # (a longer sweep: MV_RANDOM_SEEDS=300)
 def test_random_scene(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.choice([12, 17, 20, 24, 30, 36, 40]))
