@@ -192,7 +192,7 @@ def test_rccl_transport_on_one_rank():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("V,world", [(16, 4), (64, 8), (64, 3)])
+@pytest.mark.parametrize("V,world", [(16, 4), (64, 8), (64, 3), (4, 8), (1, 2), (9, 5), (33, 7)])  # (also fewer volumes than ranks)
 def test_the_culls_deal_equals_its_host_restatement(V, world):
     """What cullKernel's last workgroup decides inside the loop -- the owner of every cube-map volume (volumeFlags bits 16-31), the
     layout of the frame's cube-face exchange (exchangeOff) -- equals multivolumes_amd/distributed.py's numpy restatement of the rule
@@ -226,6 +226,6 @@ def test_the_culls_deal_equals_its_host_restatement(V, world):
         for v in (int(x) for x in cube):
             assert offs[v] == off[v], (rank, v)
         owners.append(owner)
-        assert len(cube) >= 2
+        assert len(cube) >= (2 if V >= 9 else 0)  # (the scene must give the deal something to do; the small cases are about fewer volumes than ranks)
     assert all(np.array_equal(owners[0], o) for o in owners), "every rank makes the same deal"
     assert len(set(int(owners[0][int(v)]) for v in cube)) >= min(world, len(cube)) - 1
