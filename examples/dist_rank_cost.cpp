@@ -4,7 +4,9 @@
 // (scripts/exp_rank_cost.py is the same measurement through the Python mirror).  max over ranks = the frame time an ideal fabric would
 // give; its ratio to world 1 is the ceiling of the strong-scaling curve.
 // Build: g++ -O2 -std=c++17 examples/dist_rank_cost.cpp -Lmultivolumes_amd -lmultivolumes_amd -Wl,-rpath,$PWD/multivolumes_amd -o /tmp/dist_rank_cost
-// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3 (0)] [C3 | C5]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3 (0)] [C3 | C5] [callbacks | peer | peer-nofold]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// "peer": the peer-store transport in loopback (MV_DIST_PEER_LOOPBACK): the rank's kernels store into all `world` copies -- every copy being
+// its own buffer -- and it raises the other ranks' flags itself: no pack / gather / unpack kernels, the flag kernels instead.
 // Prints per rank: ms per frame, and in brackets the host's share (time spent inside DistFrame: constants + every HIP call of the frame).
 #include "../multivolumes_amd/csrc/MultiRayCaster.hpp"
 
@@ -22,6 +24,8 @@ int main(int argc, char** argv)
 {
 	const bool c5 = argc > 5 && std::string(argv[5]) == "C5";	// BASELINE config C5: 64 volumes, 2048^2, 256 steps (default C3)
 	const uint32_t N = 256, L = 96, V = c5 ? 64 : 16, W = c5 ? 2048 : 1024, H = W, M = 1024;
+	const bool peer = argc > 6 && std::string(argv[6]).rfind("peer", 0) == 0;
+	const bool noFold = argc > 6 && std::string(argv[6]) == "peer-nofold";	// the flags as kernels of their own (what ranks that share a GPU run) instead of inside the marches and the composite
 	const bool withComposite = !std::getenv("RANK_COST_NO_COMPOSITE");	// (experiment: a frame without its composite + row gather)
 	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
 	const unsigned worlds = argc > 2 ? (unsigned)std::atoi(argv[2]) : 15u;
@@ -59,9 +63,16 @@ int main(int argc, char** argv)
 			rc.SetMaxSamples(c5 ? 256 : 128, 96);
 			rc.SetLight(light, lc, 3.0f * 3.14159265f);
 			rc.SetAmbient(ac, 2.0f * 3.14159265f);
-			if (mv_dist_init_callbacks(rc.Context(), noGather, noReduce, nullptr) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
-			mv_dist_set_inplace_gather(rc.Context(), 1);	// like RCCL: no staging copies
-			mv_dist_set_cull_crosscheck(rc.Context(), 0);	// the collectives here deliver nothing: the other ranks' culls are not there to compare
+			if (peer)
+			{
+				if (mv_dist_init_peer(rc.Context(), nullptr, MV_DIST_PEER_LOOPBACK | (noFold ? MV_DIST_PEER_NO_FOLD : 0u)) != MV_OK || mv_dist_selftest(rc.Context()) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
+			}
+			else
+			{
+				if (mv_dist_init_callbacks(rc.Context(), noGather, noReduce, nullptr) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
+				mv_dist_set_inplace_gather(rc.Context(), 1);	// like RCCL: no staging copies
+				mv_dist_set_cull_crosscheck(rc.Context(), 0);	// the collectives here deliver nothing: the other ranks' culls are not there to compare
+			}
 			for (int f = 0; f < std::min(200, frames); ++f) if (!rc.DistFrame(viewProj, shadowVP, eye, withComposite)) { std::fprintf(stderr, "%s\n", rc.LastError()); return 6; }
 			rc.DistFlush(); mv_synchronize(rc.Context());
 			double waited = 0.0;

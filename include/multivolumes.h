@@ -56,6 +56,7 @@ extern "C" {
 #define MV_ERR_OUT_OF_MEMORY (-4)
 #define MV_ERR_NOT_READY (-5)	/* an input the stage needs was never supplied */
 #define MV_ERR_RANGE (-6)
+#define MV_ERR_TIMEOUT (-7)		/* multi-GPU frame loop, peer-store transport: another rank did not reach a stage of a frame within the timeout */
 
 /* mv_config.flags */
 #define MV_FLAG_NONE 0u
@@ -118,7 +119,7 @@ typedef struct mv_stats
 
 const char* mv_error_string(int code);
 const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
-#define MV_ABI_VERSION 4u	/* 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms; 4: mv_config.frames_in_flight, MV_DIST_ID_BYTES 640 (up to five communicators), light march shared out over the ranks */
+#define MV_ABI_VERSION 5u	/* 5: peer-store transport (mv_dist_peer_export, mv_dist_init_peer, MV_ERR_TIMEOUT); 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms; 4: mv_config.frames_in_flight, MV_DIST_ID_BYTES 640 (up to five communicators), light march shared out over the ranks */
 uint32_t mv_abi_version(void);	/* == MV_ABI_VERSION of the header the library was built from */
 
 /* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,
@@ -300,6 +301,34 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id /* MV_DIST_ID_BYTES, the same 
 typedef int (*mv_dist_allgather_fn)(void* user, const void* send, void* recv, size_t bytes, void* stream, int which);
 typedef int (*mv_dist_allreduce_u32_fn)(void* user, void* buf, size_t count, void* stream, int which);
 int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user);
+/* ---- peer-store transport ("7 simultaneous direct peer writes" over xGMI) ----
+ * No collectives at all: every rank maps every rank's light maps, cube maps / depths and frame buffers (hipIpc handles between the
+ * processes of one node; plain pointers between contexts of one process) and the kernels that PRODUCE a frame's data store it into all
+ * of them -- the light march its share of the relit map, the view march its cube-face texels, the composite its screen rows.  A
+ * collective's ordering is replaced by one flag per (rank, stage, frame chain) in uncached device memory, raised behind the producing
+ * kernel and waited for in front of the consuming one (csrc/mv_peer.hip): a rank's frame is light share -> view march -> composite with
+ * no pack, all-gather or unpack between them.  Results equal the single-GPU frame bit for bit, like the other transports'.
+ *   1. every rank: mv_dist_peer_export(ctx, blob)           -- its handles (MV_DIST_PEER_BYTES);
+ *   2. the caller gathers the blobs of all ranks, rank order -- any bootstrap: torch.distributed, MPI, a file;
+ *   3. every rank: mv_dist_init_peer(ctx, all_blobs, 0)      -- maps the others; collective in effect (a barrier between 2 and the first frame is implied by the gather).
+ * Needs a context created with MV_FLAG_PIPELINE_FRAMES (whole-frame chains; not MV_FLAG_SINGLE_VIEW_STREAM), contexts of identical
+ * configuration and history (frames begun so far) on every rank, at most 64 ranks.  Every wait has a timeout (default 30 s,
+ * mv_dist_set_peer_timeout_ms): a rank that is left waiting returns MV_ERR_TIMEOUT from its next mv_dist_frame / mv_dist_flush /
+ * mv_synchronize instead of hanging.
+ * MV_DIST_PEER_LOOPBACK: a rank measured ALONE (examples/dist_rank_cost.cpp): every other rank is a set of stand-in buffers on the same GPU
+ * (about 1 GB each at C3) and the rank raises the other ranks' flags itself -- the kernels, their eight-fold stores and the schedule are a
+ * rank's real ones, the images are not. */
+#define MV_DIST_PEER_BYTES 2048
+#define MV_DIST_PEER_LOOPBACK 1u
+/* The flags are raised and waited for INSIDE the light march, the view march and the composite ("folded": a rank's chain is those three
+ * kernels and nothing else) when every rank owns its GPU -- the library decides from the ranks' PCI bus ids -- and by one-wavefront kernels
+ * of their own when ranks share a GPU (tests), where spinning consumers could crowd the producers they wait for out of the GPU.  These
+ * two force the choice (tests of the folded form on one GPU with two or three ranks; A/B timing): */
+#define MV_DIST_PEER_FOLD 2u
+#define MV_DIST_PEER_NO_FOLD 4u
+int mv_dist_peer_export(mv_ctx* ctx, void* out /* MV_DIST_PEER_BYTES */);
+int mv_dist_init_peer(mv_ctx* ctx, const void* all /* shard_count x MV_DIST_PEER_BYTES in rank order; NULL with MV_DIST_PEER_LOOPBACK */, uint32_t flags);
+int mv_dist_set_peer_timeout_ms(mv_ctx* ctx, uint32_t ms);
 /* Every frame the loop checks, through four words behind each rank's share of the light exchange, that all ranks' replicated culls
  * decided the same (a caller that passed different frame constants on different ranks gets MV_ERR_INVALID_ARG instead of mismatched
  * collectives).  On by default.  Off is for a rank driven ALONE with collectives that deliver nothing (examples/dist_rank_cost.cpp,
@@ -313,7 +342,7 @@ int mv_dist_selftest(mv_ctx* ctx);	/* one all-gather (plain and in place) and on
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite);
 int mv_dist_flush(mv_ctx* ctx);	/* enqueue the exchange + composite of the last frame begun (then mv_synchronize / readbacks see it) */
 int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset);	/* bytes this rank received through the collectives */
-/* transport: 0 none, 1 RCCL, 2 caller-supplied collectives; ranks: the size of the communicator as RCCL reports it (ncclCommCount), or
+/* transport: 0 none, 1 RCCL, 2 caller-supplied collectives, 3 peer stores; ranks: the size of the communicator as RCCL reports it (ncclCommCount), or
  * shard_count for caller-supplied collectives; communicators: how many the loop keeps busy (3 with whole-frame chains, else 2) */
 int mv_dist_info(mv_ctx* ctx, uint32_t* transport, uint32_t* ranks, uint32_t* communicators);
 

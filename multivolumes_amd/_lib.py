@@ -18,6 +18,7 @@ MV_ERR_NO_DEVICE = -3
 MV_ERR_OUT_OF_MEMORY = -4
 MV_ERR_NOT_READY = -5
 MV_ERR_RANGE = -6
+MV_ERR_TIMEOUT = -7
 
 MV_FLAG_FORCE_MIP0_ALL_FACES = 1
 MV_FLAG_PIPELINE_FRAMES = 2
@@ -30,7 +31,11 @@ MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5
 MV_BUF_VOLUME_FLAGS, MV_BUF_EXCHANGE_OFFSETS = 10, 11
 
 MV_DIST_ID_BYTES = 640
-MV_ABI_VERSION = 4  # include/multivolumes.h
+MV_DIST_PEER_BYTES = 2048
+MV_DIST_PEER_LOOPBACK = 1
+MV_DIST_PEER_FOLD = 2
+MV_DIST_PEER_NO_FOLD = 4
+MV_ABI_VERSION = 5  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 
@@ -112,6 +117,9 @@ ABI = {
     "mv_dist_unique_id": (C.c_int, [_P]),
     "mv_dist_init_rccl": (C.c_int, [_P, _P]),
     "mv_dist_init_callbacks": (C.c_int, [_P, _P, _P, _P]),
+    "mv_dist_peer_export": (C.c_int, [_P, _P]),
+    "mv_dist_init_peer": (C.c_int, [_P, _P, _U32]),
+    "mv_dist_set_peer_timeout_ms": (C.c_int, [_P, _U32]),
     "mv_dist_selftest": (C.c_int, [_P]),
     "mv_dist_shutdown": (C.c_int, [_P]),
     "mv_dist_set_inplace_gather": (C.c_int, [_P, C.c_int]),

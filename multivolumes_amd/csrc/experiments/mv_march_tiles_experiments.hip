@@ -31,6 +31,12 @@ constexpr uint32_t kTileWaves = MV_TILE_WAVES;
 typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
 typedef __attribute__((address_space(3))) void* LdsVoidPtr;
 
+#ifndef MV_TILE_PRIORITY
+#define MV_TILE_PRIORITY 0	// s_setprio by cost bin: measured (profiles/r03_view_march_tail.txt), no effect -- the long tiles wait for memory, not for issue slots
+#endif
+#ifndef MV_TILE_PRIORITY_BINS
+#define MV_TILE_PRIORITY_BINS 2	// bins 0 .. n - 1 at priority 3, the next n at 1, the rest at 0
+#endif
 
 static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 {
@@ -45,24 +51,17 @@ static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 // wavefronts per SIMD (N <= kLutMaxN).
 constexpr uint32_t kLutMaxN = 256;
 // IL: the rows of a sharded context are dealt by tile row (kFlagInterleaveRows) -- compile-time, see screenTileRowsT
-template <bool OVERFLOW, bool LUT, bool IL, bool PEER>
-__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis);
-
-// PEER: the peer-store transport's instantiation (stores into every rank's cube maps, folded flags); the others are untouched by it
-template <bool OVERFLOW, bool LUT, bool IL, bool PEER = false>
+// SPEC: the texels of the NEXT sample are requested before the current one is resolved (see "speculation" inside): for launches that
+// leave most of the GPU's wavefront slots empty, where a tile lasts as long as its longest ray's chain of dependent samples.
+// STAGE: the volume bricks a tile's 64 footprints of one step lie in are copied into LDS first (LDS-DMA) and the taps read from there
+// (see "staging" inside): the north star's "LDS-staged volume bricks", built to be measured.
+constexpr uint32_t kStageBricks = 32;	// bricks (512 B each) a wavefront stages per step: 16 KiB of LDS per wavefront
+template <bool OVERFLOW, bool LUT, bool IL, bool SPEC = false, bool STAGE = false>
 __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesKernel(DeviceState st, uint32_t firstSlot)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
-	// (peer-store transport, folded flags: wait for every rank's share of the light maps this frame reads; the last workgroup raises
-	// "this rank's cube faces have landed everywhere" -- mv_kernels.hpp peerFoldWait / peerFoldSignal; one scalar compare each otherwise)
-	if constexpr (PEER) peerFoldWait(st);
-	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis);
-	if constexpr (PEER) peerFoldSignal(st);
-}
-
-template <bool OVERFLOW, bool LUT, bool IL, bool PEER>
-__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis)
-{
+	__shared__ u32x4 sStage[STAGE ? kTileWaves * kStageBricks * 32u : 1];	// [wavefront][brick][32 x 16 bytes]
+	__shared__ uint32_t sBox[STAGE ? kTileWaves * 8u : 1];
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
@@ -85,6 +84,14 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	{
 	uint32_t costBin = 8u;
 	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(slot), &costBin));
+#if MV_TILE_PRIORITY
+	// The launch lasts as long as its longest rays: the tiles of the first cost bins (dispatched first) are on its critical path from
+	// the first microsecond, while the short tiles only have to fit in somewhere.  A wavefront of a long tile therefore raises its
+	// issue priority (s_setprio): on a SIMD shared by five wavefronts its instructions go first, the others fill the gaps.
+	if (costBin < (uint32_t)MV_TILE_PRIORITY_BINS) __builtin_amdgcn_s_setprio(3);
+	else if (costBin < 2u * (uint32_t)MV_TILE_PRIORITY_BINS) __builtin_amdgcn_s_setprio(1);
+	else __builtin_amdgcn_s_setprio(0);
+#endif
 
 	// find the work entry that owns this tile (wave-uniform)
 	uint32_t entry = 0;
@@ -142,7 +149,6 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 					clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
 				}
 				st.cubeDepths[outIndex] = clip.z;	// :105
-				if constexpr (PEER) storeToPeers(st, st.peerCubeDepths, outIndex, clip.z);	// (peer-store transport: every rank's copy)
 				tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
 				valid = true;
 				nRays = 1;
@@ -180,7 +186,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 		}
 	}
 
-	if (valid)
+	if (STAGE || valid)	// (STAGE: the whole wavefront takes part in the cooperative copies, lanes without a ray included)
 	{
 		{
 			const float stepScale = kMaxDist / (float)smpCount;
@@ -199,6 +205,236 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			uint32_t occIndex = 0xffffffffu;
 			uint64_t occWord = 0;
 #endif
+			if constexpr (STAGE)
+			{
+				// ---- staging (round 3; BASELINE north_star "LDS-staged volume bricks for coalesced HBM reads") ----
+				// Per step of the wavefront: (1) every lane that needs texels finds the bricks of its 2x2x2 footprint; the wavefront takes
+				// the bounding box of all of them in brick coordinates (LDS min / max atomics); (2) if the box holds at most kStageBricks
+				// bricks, the whole box goes into LDS with global_load_lds_dwordx4 -- two bricks per instruction, lane l's 16 bytes landing
+				// at base + 16 l, fully coalesced 512-byte reads, no VGPRs -- and every lane reads its eight taps from LDS (ds_read_b64);
+				// a larger box (a tile seen at a grazing angle, or rays far apart after adaptive steps) falls back to the direct gathers.
+				// The loop is the reference's, lane for lane; lanes run it in lockstep over i with a per-lane `alive` instead of
+				// break / continue, so that every lane reaches the cooperative copy.  Results are bit-identical.
+				// MEASURED (profiles/r03_lds_staging.txt): slower than the direct gathers -- see there and DESIGN.md section 4.
+				const uint32_t wave = threadIdx.x >> 6;
+				u32x4* stage = sStage + (size_t)wave * kStageBricks * 32u;
+				uint32_t* box = sBox + wave * 8u;
+				const uint32_t strideYb = brickPitchY(st.bricks), strideZb = brickPitchZ(st.bricks);
+				bool alive = valid;
+				for (uint32_t i = 0; i < smpCount && __ballot(alive); ++i)
+				{
+					vec3 uvw = v3(0.0f, 0.0f, 0.0f);
+					FootprintAddr fa;
+					bool fetch = false;
+					if (alive)
+					{
+						const vec3 pos = rayAt(rayOrigin, rayDir, t);
+						if (outsideBox(pos)) alive = false;	// :120
+						else
+						{
+							uvw = LocalToTex3DSpace(pos);
+							fa = footprintAddr(vol, uvw);
+							fetch = true;
+#if MV_OCCUPANCY
+							const uint32_t w = occupancyWord(fa.ix, fa.iy, fa.iz, regions);
+							if (w != occIndex) { occWord = occupancy[w]; occIndex = w; }
+							if (!((occWord >> occupancyBit(fa.ix, fa.iy, fa.iz)) & 1ull))
+							{
+								fetch = false;
+								++nSamples; ++nSkipped;
+								prevLit = false;
+								t += stepScale;
+								if (t > tMax) alive = false;	// :152
+							}
+#endif
+						}
+					}
+					// (1) bounding box of the footprints' bricks
+					const uint32_t N1 = vol.N - 1u;
+					// second taps: min(i + 1, N - 1) -- or the first tap again where the sampler's two taps coincide (a coordinate below the first
+					// texel centre: taps (0, 0); FootprintAddr marks that with a zero cell weight, and a zero weight makes the tap irrelevant)
+					const uint32_t x1 = fa.cx == 0.0f ? fa.ix : (fa.ix + 1u < N1 ? fa.ix + 1u : N1);
+					const uint32_t y1 = fa.cy == 0.0f ? fa.iy : (fa.iy + 1u < N1 ? fa.iy + 1u : N1);
+					const uint32_t z1 = fa.cz == 0.0f ? fa.iz : (fa.iz + 1u < N1 ? fa.iz + 1u : N1);
+					if (lane < 6u) box[lane] = lane < 3u ? 0xffffffffu : 0u;
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					if (fetch)
+					{
+						atomicMin(&box[0], fa.ix >> 2); atomicMin(&box[1], fa.iy >> 2); atomicMin(&box[2], fa.iz >> 2);
+						atomicMax(&box[3], x1 >> 2); atomicMax(&box[4], y1 >> 2); atomicMax(&box[5], z1 >> 2);
+					}
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					const uint32_t bx0 = __builtin_amdgcn_readfirstlane(box[0]), by0 = __builtin_amdgcn_readfirstlane(box[1]), bz0 = __builtin_amdgcn_readfirstlane(box[2]);
+					const uint32_t bx1 = __builtin_amdgcn_readfirstlane(box[3]), by1 = __builtin_amdgcn_readfirstlane(box[4]), bz1 = __builtin_amdgcn_readfirstlane(box[5]);
+					const bool any = bx0 != 0xffffffffu;
+					const uint32_t dx = any ? bx1 - bx0 + 1u : 0u, dy = any ? by1 - by0 + 1u : 0u, dz = any ? bz1 - bz0 + 1u : 0u, nb = dx * dy * dz;
+					const bool staged = any && nb <= kStageBricks;	// wave-uniform
+					ColourFootprint cf;
+					if (staged)
+					{
+						// (2) the box into LDS, two bricks per instruction
+						for (uint32_t j = 0; j < nb; j += 2u)
+						{
+							const uint32_t b = j + (lane >> 5);
+							if (b < nb)
+							{
+								const uint32_t bxi = b % dx, byi = (b / dx) % dy, bzi = b / (dx * dy);
+								const size_t brick = (size_t)(bz0 + bzi) * strideZb + (size_t)(by0 + byi) * strideYb + (bx0 + bxi);
+								__builtin_amdgcn_global_load_lds((GlobalVoidPtr)(vol.base + brick * 512u + (lane & 31u) * 16u), (LdsVoidPtr)(stage + (size_t)j * 32u), 16, 0, 0);
+							}
+						}
+						asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+						if (fetch)
+						{
+							// (volatile: nothing tells the compiler that the copies above wrote these addresses)
+							const volatile u32x2* ldsTexels = reinterpret_cast<const volatile u32x2*>(stage);
+							auto tap = [&](uint32_t x, uint32_t y, uint32_t z) -> uint2
+							{
+								const uint32_t b = (((z >> 2) - bz0) * dy + ((y >> 2) - by0)) * dx + ((x >> 2) - bx0);
+								const u32x2 v = ldsTexels[b * 64u + ((z & 3u) << 4) + ((y & 3u) << 2) + (x & 3u)];
+								return make_uint2(v.x, v.y);
+							};
+							cf.t000 = tap(fa.ix, fa.iy, fa.iz); cf.t100 = tap(x1, fa.iy, fa.iz);
+							cf.t010 = tap(fa.ix, y1, fa.iz); cf.t110 = tap(x1, y1, fa.iz);
+							cf.t001 = tap(fa.ix, fa.iy, z1); cf.t101 = tap(x1, fa.iy, z1);
+							cf.t011 = tap(fa.ix, y1, z1); cf.t111 = tap(x1, y1, z1);
+							cf.fx = fa.fx; cf.fy = fa.fy; cf.fz = fa.fz;
+						}
+					}
+					else if (fetch) cf = fetchColour(vol, fa);
+					if (fetch)
+					{
+						LightFootprint lf;
+						const bool early = MV_PREDICT_LIT && prevLit;
+						if (early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+						const float alpha = resolveAlphaFromTexels(cf);
+						++nSamples;
+						float newStep = stepScale;
+						const bool lit = alpha > kZeroThreshold;	// :128
+						prevLit = lit;
+						bool saturated = false;
+						if (lit)
+						{
+							if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
+							const vec3 light = resolveLight(lf);
+							vec3 color = resolveRGB(cf);
+							++nLit;
+							const float transm = 1.0f - scatter.w;
+							const float dDensity = alpha - prevDensity;
+							newStep = GetViewStep(dDensity, scatter.w, alpha, stepScale);
+							prevDensity = alpha;
+							const float a = transm * kAbsorption * alpha;
+							scatter.x += a * color.x * light.x;
+							scatter.y += a * color.y * light.y;
+							scatter.z += a * color.z * light.z;
+							scatter.w += a;
+							saturated = transm < kZeroThreshold;	// :146
+						}
+						if (saturated) alive = false;
+						else
+						{
+							t += newStep;
+							if (t > tMax) alive = false;	// :152
+						}
+					}
+				}
+			}
+			else
+			if constexpr (SPEC)
+			{
+				// ---- speculation (round 3) ----
+				// A ray is a chain of dependent samples: the next position needs this sample's step, which needs its alpha, which needs
+				// its texels.  While the accumulated alpha is small -- and through empty space always -- the step is exactly stepScale
+				// (GetStep, RayMarch.hlsli:182-192: max(1.5 scatter.w factorEv factorUi, 1) stepScale), so the footprint at t + stepScale is
+				// requested BEFORE this sample is resolved and is there when the loop arrives; a wrong guess (t advanced by a longer step)
+				// discards it and fetches at the real t.  `t + stepScale` is the very addition the loop performs, so a right guess is the
+				// same float: arithmetic, order and results are the reference's, only requests are issued earlier (and some in vain).
+				// It costs 40 registers (92 -> 132) and wasted requests.  MEASURED SLOWER in both regimes it was meant for -- a launch that fills
+				// the GPU (a wavefront per SIMD less) and a launch that leaves it nearly empty (a rank's share of a frame in the multi-GPU
+				// loop: 116 -> 158 us) -- so no launch selects it (MV_TILE_SPECULATE_BELOW = 0); kept as the experiment it was.
+				struct Prepared { ColourFootprint cf; vec3 uvw; float t; bool outside, skip; };
+				auto prepare = [&](float tt) -> Prepared
+				{
+					Prepared p;
+					p.t = tt;
+					const vec3 pos = rayAt(rayOrigin, rayDir, tt);
+					p.outside = outsideBox(pos);
+					p.skip = false;
+					p.uvw = LocalToTex3DSpace(pos);
+					if (p.outside) return p;
+					FootprintAddr fa;
+					uint32_t occSum = 0u;
+					if (LUT)
+					{
+						const u32x4 ex = sAxis[axisTableIndex(p.uvw.x, vol.N, fa.fx)];
+						const u32x4 ey = sAxis[(kLutMaxN + 1u) + axisTableIndex(p.uvw.y, vol.N, fa.fy)];
+						const u32x4 ez = sAxis[2u * (kLutMaxN + 1u) + axisTableIndex(p.uvw.z, vol.N, fa.fz)];
+						fa.x0 = ex.x; fa.x1 = ex.y;
+						fa.r00 = ey.x + ez.x; fa.r10 = ey.y + ez.x; fa.r01 = ey.x + ez.y; fa.r11 = ey.y + ez.y;
+						occSum = ex.z + ey.z + ez.z;
+					}
+					else fa = footprintAddr(vol, p.uvw);
+#if MV_OCCUPANCY
+					{
+						const uint32_t w = LUT ? occSum & 0xffffffu : occupancyWord(fa.ix, fa.iy, fa.iz, regions);
+						if (w != occIndex) { occWord = occupancy[w]; occIndex = w; }
+						p.skip = !((occWord >> (LUT ? occSum >> 24 : occupancyBit(fa.ix, fa.iy, fa.iz))) & 1ull);
+					}
+#endif
+					if (!p.skip) p.cf = fetchColour(vol, fa);
+					else { p.cf.fx = fa.fx; p.cf.fy = fa.fy; p.cf.fz = fa.fz; }
+					return p;
+				};
+				Prepared cur = prepare(t);
+				for (uint32_t i = 0; i < smpCount; ++i)
+				{
+					if (cur.outside) break;	// :120
+					const float tGuess = t + stepScale;
+					const bool last = i + 1u >= smpCount || tGuess > tMax;	// (nothing follows this sample if the step is stepScale: no request)
+					Prepared nxt;
+					if (!last) nxt = prepare(tGuess);
+					float newStep = stepScale;
+					if (cur.skip)
+					{
+						++nSamples;
+						++nSkipped;
+						prevLit = false;
+					}
+					else
+					{
+						LightFootprint lf;
+						const bool early = MV_PREDICT_LIT && prevLit;
+						if (early) lf = fetchLightFootprint(lightQuads, st.L, cur.uvw);
+						const float alpha = resolveAlphaFromTexels(cur.cf);
+						++nSamples;
+						const bool lit = alpha > kZeroThreshold;	// :128
+						prevLit = lit;
+						if (lit)
+						{
+							if (!early) lf = fetchLightFootprint(lightQuads, st.L, cur.uvw);
+							const vec3 light = resolveLight(lf);
+							vec3 color = resolveRGB(cur.cf);
+							++nLit;
+							const float transm = 1.0f - scatter.w;
+							const float dDensity = alpha - prevDensity;
+							newStep = GetViewStep(dDensity, scatter.w, alpha, stepScale);
+							prevDensity = alpha;
+							const float a = transm * kAbsorption * alpha;
+							scatter.x += a * color.x * light.x;
+							scatter.y += a * color.y * light.y;
+							scatter.z += a * color.z * light.z;
+							scatter.w += a;
+							if (transm < kZeroThreshold) break;	// :146
+						}
+					}
+					t += newStep;
+					if (t > tMax) break;	// :152
+					if (!last && t == tGuess) cur = nxt;
+					else if (i + 1u < smpCount) cur = prepare(t);
+				}
+			}
+			else
 			for (uint32_t i = 0; i < smpCount; ++i)
 			{
 				const vec3 pos = rayAt(rayOrigin, rayDir, t);
@@ -274,13 +510,13 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 
 			scatter.x *= kInvTwoPi; scatter.y *= kInvTwoPi; scatter.z *= kInvTwoPi;	// :155
 
-			if (!screenTile)
+			if (!valid) {}	// (STAGE: a lane without a ray went through the loop for the copies' sake)
+			else if (!screenTile)
 			{
 				uint2 o;
 				o.x = (uint32_t)float_to_half_bits(scatter.x) | ((uint32_t)float_to_half_bits(scatter.y) << 16);
 				o.y = (uint32_t)float_to_half_bits(scatter.z) | ((uint32_t)float_to_half_bits(scatter.w) << 16);
 				st.cubeMaps[outIndex] = o;	// :157
-				if constexpr (PEER) storeToPeers(st, st.peerCubeMaps, outIndex, o);
 			}
 			else
 			{
@@ -312,7 +548,22 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	}
 }
 
+uint32_t marchTilesResidentWaves(int device)
+{
+	int perCu = 0, cus = 0;
+	if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, marchTilesKernel<false, true, false>, 64 * kTileWaves, 0) != hipSuccess || perCu <= 0) perCu = 8;
+	if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) cus = 256;
+	return (uint32_t)perCu * (uint32_t)cus * kTileWaves;
+}
 
+#ifndef MV_TILE_STAGE
+#define MV_TILE_STAGE 0
+#endif
+#ifndef MV_TILE_SPECULATE_BELOW
+#define MV_TILE_SPECULATE_BELOW 0	// tiles per launch under which the next sample's texels are requested ahead (SPEC).  0 = never: measured (round 3,
+										// profiles/r03_speculation.txt) a rank's share of C3 on 8 ranks, 1.5 k tiles, 116 us -> 158 us with it -- a lone wavefront's
+										// iteration is its ~230 dependent VALU instructions, not the wait for its texels
+#endif
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
 {
 	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has
@@ -323,17 +574,21 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
 	blocks = ((blocks + 7) / 8) * 8;
 	const bool il = st.flags & kFlagInterleaveRows;
+	const bool spec = tiles < (uint64_t)MV_TILE_SPECULATE_BELOW;
 	const dim3 grid((uint32_t)blocks), block(64 * kTileWaves);
-	const bool lut = st.N <= kLutMaxN && MV_TILE_LUT != 0;
-	if (st.peerCount)	// (peer-store transport)
+#if MV_TILE_STAGE	// the LDS-staged variant instead of the direct gathers (an experiment: profiles/r03_lds_staging.txt)
+	if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true, false, true>), grid, block, 0, s, st, 0u);
+	else hipLaunchKernelGGL((marchTilesKernel<false, false, false, false, true>), grid, block, 0, s, st, 0u);
+	return blocks * kTileWaves < maxTiles ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
+#endif
+	if (st.N <= kLutMaxN && MV_TILE_LUT != 0)
 	{
-		if (lut) { if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true, true>), grid, block, 0, s, st, 0u); else hipLaunchKernelGGL((marchTilesKernel<false, true, false, true>), grid, block, 0, s, st, 0u); }
-		else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true, true>), grid, block, 0, s, st, 0u);
-		else hipLaunchKernelGGL((marchTilesKernel<false, false, false, true>), grid, block, 0, s, st, 0u);
-	}
-	else if (lut)
-	{
-		if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true>), grid, block, 0, s, st, 0u);
+		if (spec)
+		{
+			if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true, true>), grid, block, 0, s, st, 0u);
+			else hipLaunchKernelGGL((marchTilesKernel<false, true, false, true>), grid, block, 0, s, st, 0u);
+		}
+		else if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true>), grid, block, 0, s, st, 0u);
 		else hipLaunchKernelGGL((marchTilesKernel<false, true, false>), grid, block, 0, s, st, 0u);
 	}
 	else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true>), grid, block, 0, s, st, 0u);
@@ -343,13 +598,7 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot)
 {
-	const bool il = st.flags & kFlagInterleaveRows;
-	if (st.peerCount)
-	{
-		if (il) hipLaunchKernelGGL((marchTilesKernel<true, false, true, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
-		else hipLaunchKernelGGL((marchTilesKernel<true, false, false, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
-	}
-	else if (il) hipLaunchKernelGGL((marchTilesKernel<true, false, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
+	if (st.flags & kFlagInterleaveRows) hipLaunchKernelGGL((marchTilesKernel<true, false, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
 	else hipLaunchKernelGGL((marchTilesKernel<true, false, false>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
 }
 } // namespace mv

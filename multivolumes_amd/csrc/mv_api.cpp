@@ -4,450 +4,8 @@
 // D3D12 dispatches into an XUSG command list, this layer launches the gfx950 kernels of mv_kernels.hip on one HIP stream.
 // Kernel order on the stream = the reference's barrier graph (cull -> marchL -> marchV -> composite).
 // There is no CPU fallback: without a gfx950 device every entry point fails.
-#include "../../include/multivolumes.h"
-#include "mv_kernels.hpp"
-#include "mv_device.hpp"
-#include "mv_mesh.hpp"
-
-#include <algorithm>
-#include <chrono>
-
-#include <hip/hip_runtime.h>
-#include <string.h>
-#include <stdio.h>
-#include <string>
-#include <vector>
-#include <new>
-#include <dlfcn.h>
-#include <rccl/rccl.h>	// types and prototypes only: the library is opened with dlopen when mv_dist_init_rccl is called
-
-using mv::DeviceState;
-
-#ifdef MV_HOST_PROFILE	// (diagnostic builds: where the host's time inside mv_dist_frame goes; printed by mv_dist_shutdown / mv_destroy)
-static double gSection[12]; static uint64_t gSectionCalls;
-struct SectionTimer { int i; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); ~SectionTimer() { gSection[i] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } };
-#define MV_SECTION(i) SectionTimer section_##i{ i }
-#else
-#define MV_SECTION(i)
-#endif
-
-
-namespace
-{
-constexpr uint32_t kMaxScreenSlots = 32;	// screen-space-scheme volumes whose RayCast joins the view-march launch (16 B x W x H of layer each, per output set)
-// Frames in flight (MV_FLAG_PIPELINE_FRAMES; mv_config.frames_in_flight, default 3 like the reference's FrameCount, MultiRayCaster.h:52): C whole
-// frames on C view streams with C output sets.  What follows from C: light buffers per volume = max(3, C) (the light march of frame i
-// writes the buffer the relit volume held that many relights ago: frame i - lightBufs is the last that can still read it), frame slots
-// (constants + cull outputs; also the pinned upload slices) = light buffers + 1 (the cull of frame i + 1 runs while frame i - lightBufs + 1
-// is still marching).  With C = 3: 3 light buffers, 4 slots -- the numbers of rounds 1 and 2.
-constexpr uint32_t kMaxChains = 5;
-constexpr uint32_t kMaxFrameSlots = kMaxChains + 1;
-constexpr uint32_t kNumCounters = 8;	// read back; counters[8] (the cull's ticket) is device-only
-constexpr uint32_t kNumStats = 8;
-
-struct EventPair { hipEvent_t a, b; int stage; };
-}
-
-// Buffers that exist once per frame slot (constants + everything the cull writes): frame i+1's upload / cull / light march
-// (stream A) may then run while frame i's view march / composite (stream B) still read frame i's copies.
-struct FrameBufs
-{
-	void* dCb = nullptr;
-	void* dPerObject = nullptr;
-	uint8_t* cullBlock = nullptr;		// counters | VolumeInfo | visible | cube-map list | light table, contiguous
-	uint16_t* volumeInfo = nullptr;
-	uint32_t *visibleVolumes = nullptr, *cubeMapVolumes = nullptr, *counters = nullptr, *ownedVisible = nullptr;
-	uint32_t *workEntries = nullptr, *workTileStart = nullptr;
-	uint64_t* cubeOffset = nullptr;
-	uint32_t* volumeFlags = nullptr;
-	uint16_t* volumeRects = nullptr;
-	float4* lightDirs = nullptr;
-	uint32_t* screenSlot = nullptr;
-	uint32_t* exchangeOff = nullptr;
-	uint4** lightTable = nullptr;
-	uint32_t* tileCost = nullptr;
-	uint32_t* lightOrder = nullptr;	// dispatch order of the light march's voxel blocks (launchLightOrder), per slot
-	uint32_t *tileOrder = nullptr, *binCounts = nullptr;	// dispatch order of the view march (launchTileOrder), per slot
-	mv::VolumeConsts* volConsts = nullptr;
-	uint32_t* queueHeads = nullptr;
-};
-
-// Outputs of the view march / composite and their counters: one set, or kMaxOutSets-or-fewer rotating sets with
-// MV_FLAG_PIPELINE_FRAMES (frame i uses set i % numOutSets and view stream i % numOutSets), so that the view marches of
-// consecutive frames may overlap on the GPU.
-constexpr uint32_t kMaxOutSets = kMaxChains;
-struct OutBufs
-{
-	uint2* cubeMaps = nullptr;
-	float* cubeDepths = nullptr;
-	uint2* composite = nullptr;
-	float4* screenLayers = nullptr;
-	uint32_t* faceStamps = nullptr;
-	uint64_t *waveStats = nullptr, *compositeStats = nullptr;
-	uint32_t* compositeRetry = nullptr;
-	mv::RayRecord* rayRecords = nullptr;	// the view march's ray queue (mv_march.hip)
-	mv::TileInfo* tileInfo = nullptr;
-};
-
-// state of the in-library multi-GPU frame loop (mv_dist_*)
-constexpr uint32_t kDistChains = kMaxChains;	// (array sizes; the loop uses as many chains as the context has view streams)
-struct DistState
-{
-	int transport = 0;				// 1 = RCCL, 2 = caller-supplied collectives
-	void* rcclLib = nullptr;
-	decltype(&ncclCommInitRank) commInitRank = nullptr;
-	decltype(&ncclAllGather) allGather = nullptr;
-	decltype(&ncclAllReduce) allReduce = nullptr;
-	decltype(&ncclCommDestroy) commDestroy = nullptr;
-	decltype(&ncclGetErrorString) errorString = nullptr;
-	// Two ways to run the loop (chosen by how the context was created):
-	// * chains (MV_FLAG_PIPELINE_FRAMES alone: three view streams, three output sets): frame k's light march, light-map exchange, view
-	//   march, cube-face exchange, composite and row gather all go on view stream k % 3, with communicator / buffers k % 3 -- whole
-	//   frames overlap, which is what a rank needs once its share of a frame no longer fills the GPU;
-	// * single view stream (| MV_FLAG_SINGLE_VIEW_STREAM: two output sets): the view marches on the context's stream, the exchange and
-	//   composite of frame k - 1 beside frame k's march on stream X; comm [0] = cube faces + row bands, [1] = light maps.
-	bool chains = false;
-	bool cullCrosscheck = true;	// the loop compares the ranks' culls through the light exchange's trailers (mv_dist_set_cull_crosscheck)
-	bool inPlaceGather = false;	// the transport's all-gather accepts send == recv + rank * bytes (RCCL does; a caller says so with mv_dist_set_inplace_gather)
-	uint32_t numComm = 2;
-	uint32_t numChains = 1;			// chains: one per view stream of the context (3 by default), each with its communicator and buffers; else 1
-	ncclComm_t comm[kDistChains] = {};
-	mv_dist_allgather_fn cbAllGather = nullptr;
-	mv_dist_allreduce_u32_fn cbAllReduce = nullptr;
-	void* user = nullptr;
-	hipStream_t streamX = nullptr;	// (single view stream) exchange + composite of frame k - 1, beside frame k's view march
-	uint8_t *sendBuf[kDistChains] = {}, *recvBuf[kDistChains] = {};	// one shard / shard_count shards of marched cube faces ([0] only without chains)
-	size_t sendCap = 0;
-	uint32_t* lightWords[kDistChains] = {};	// the relit light map as every rank's share of its voxel blocks: shard_count x lightShareBytes (plain R11G11B10F words, 64 per block)
-	uint8_t* lightSend[kDistChains] = {};	// this rank's share when the transport cannot gather in place
-	size_t lightShareBytes = 0;
-	uint8_t *rowSend[kDistChains] = {}, *rowRecv[kDistChains] = {};	// staged row-band gather (unequal bands, or a transport without in-place all-gather)
-	size_t maxBandBytes = 0;
-	unsigned long long* reports = nullptr;	// pinned, one word per frame slot: {frame tag : texels of the largest exchange shard}, written by the cull
-	bool pending = false, pendingComposite = false;
-	DeviceState stPending;			// the device state of the frame whose exchange + composite are still to be enqueued
-	uint32_t slotPending = 0, chainPending = 0;
-	uint64_t bytes = 0;
-	std::vector<void*> allocs;		// device buffers of the loop (freed by distRelease: a shutdown followed by another init allocates afresh)
-};
-
-struct mv_ctx
-{
-	mv_config cfg;
-	hipStream_t stream = nullptr;		// stream B: view march, composite, exchange, producers, readbacks
-	hipStream_t streamA = nullptr;		// stream A: constant upload, cull (== stream unless MV_FLAG_PIPELINE_FRAMES); may run frames ahead
-	hipStream_t streamL = nullptr;		// stream L: light march (== stream unless MV_FLAG_PIPELINE_FRAMES)
-	hipStream_t streamB[kMaxOutSets] = {};	// view march + composite of frame i on streamB[i % numOutSets] ([0] == stream; the others == stream unless pipelined)
-	OutBufs ob[kMaxOutSets];
-	uint32_t numOutSets = 1, numViewStreams = 1;
-	uint32_t set = 0;
-	bool ownStream = false, ownStreamA = false, ownStreamL = false, ownStreamB1 = false;
-	bool lightOnViewStream = false;		// pipelined with several view streams: a frame's light march runs on that frame's view stream
-	DeviceState st;						// always holds the CURRENT frame slot's pointers (applyParity)
-	FrameBufs fb[kMaxFrameSlots];		// constants + cull outputs per slot (numSlots of them in use)
-	uint32_t numSlots = 4;				// light buffers per volume + 1
-	uint32_t slot = 0;					// frame counter mod numSlots
-	hipEvent_t evStageA[kMaxFrameSlots] = {}, evLight[kMaxFrameSlots] = {}, evMainDone[kMaxFrameSlots] = {}, evProducers = nullptr;
-	hipEvent_t evCopy[kMaxFrameSlots] = {};	// a frame's unmarched cube faces are up to date (copyForward)
-	bool copiedForward = false;			// this frame's copy-forward has been enqueued
-	bool marchedThisFrame = false;		// mv_march_view has run for the current frame (its RayCast layers are this frame's)
-	uint64_t lastCompleteFrame = 0;		// the last frame whose output set was completed (view march, or a composite-only frame's copy from every set)
-	bool producersDirty = false;
-
-	// owned device allocations
-	std::vector<uint2*> volumes;		// volumes[i] = volPool + i * volStride: ONE allocation (the march addresses it as base + 32-bit offset)
-	uint8_t* volPool = nullptr;
-	uint64_t* occPool = nullptr;
-	std::vector<uint4*> cells;
-	uint2** dVolumePtrs = nullptr;
-	uint4** dCellPtrs = nullptr;
-	std::vector<uint64_t*> occupancy;	// brick occupancy words per volume source
-	uint64_t** dOccPtrs = nullptr;
-	uint32_t* lightStaging = nullptr;	// L^3 plain R11G11B10F (readback / upload conversion)
-	bool orderTiles = true;				// false with MV_FLAG_LIST_ORDER
-	// mesh depth / shadow producer (mv_mesh_*)
-	float* meshPositions = nullptr;
-	uint32_t* meshIndices = nullptr;
-	uint32_t meshVerts = 0, meshTris = 0;
-	uint32_t* rasterBits = nullptr;		// max(W x H, M x M) depth bits
-	float* dMeshMatrix = nullptr;		// 16 floats
-	uint2* staging = nullptr;			// N^3 linear RGBA16F (upload / readback re-tiling)
-	size_t stagingBytes = 0;
-	float* ownDepth = nullptr;
-	uint16_t* ownShadow = nullptr;
-	uint32_t* dDescs = nullptr;
-	float* dSh = nullptr;
-	std::vector<void*> allocs;			// everything to hipFree
-
-	// pinned upload ring (the reference's upload-heap slices, MultiRayCaster.cpp:128-130, 461-467)
-	uint8_t* pinned = nullptr;			// numSlots slices: frame i's constants in slice i % numSlots, read by that frame's cull where they lie
-	size_t sliceBytes = 0;
-	uint64_t* pinnedStats = nullptr;
-	uint32_t* pinnedCounters = nullptr;
-	unsigned long long* pinnedTiles = nullptr;	// written by the cull kernel: {frame tag : tile count} of the most recent cull that has run (a hint, never waited for)
-	bool rayQueue = false;				// MV_FLAG_RAY_QUEUE: the two-stage ray-queue march (mv_march.hip) instead of one wavefront per tile
-	uint8_t* pinnedCull = nullptr;		// counters + VolumeInfo + both lists + light table, one readback
-	uint64_t frame = 0;					// frames begun (mv_update_frame)
-	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
-
-	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
-	bool leanEvents = false;			// inside mv_dist_frame on a chains context: event records that a later record of the same call supersedes are left out (the host enqueues a rank's frame in ~100 us: every call counts)
-	bool lightMarched = false, lightTableKept = false;	// this frame: mv_march_light ran / the frame keeps the previous frame's light table (see keepLightTable)
-	bool profiling = false;
-	std::vector<EventPair> pending;
-	std::vector<EventPair> freeEvents;
-	double msStage[4] = { 0, 0, 0, 0 };
-	uint64_t nStage[4] = { 0, 0, 0, 0 };
-	std::string lastError;
-	DistState* dist = nullptr;
-	// Cross-stream ordering goes through evRecord / evWait below, which leave out the waits that are redundant: an event recorded on the
-	// very stream that is asked to wait for it (stream order already says so), and a wait the stream has already made for the same
-	// record.  With whole frames on three view streams frame k - 3 sits on frame k's stream, so half of a frame's waits are of the
-	// first kind (a stream wait is ~1 us of host time on a pending event; a rank of the multi-GPU loop issued sixteen per frame).
-	struct EvTrack { hipEvent_t e = nullptr; hipStream_t on = nullptr; uint64_t seq = 0; uint64_t waited[8] = {}; };
-	EvTrack evTrack[24];
-	hipStream_t evStreams[8] = {};
-	uint64_t evSeq = 0;
-	double hostWaitMs = 0.0;			// time mv_update_frame spent waiting for the GPU to free a frame slot (mv_host_wait_ms)
-};
-
-namespace
-{
-int fail(mv_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
-{
-	if (ctx)
-	{
-		char buf[512];
-		if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s (%s)", what, hipGetErrorName(e), hipGetErrorString(e));
-		else snprintf(buf, sizeof(buf), "%s", what);
-		ctx->lastError = buf;
-	}
-	return code;
-}
-
-#define MV_HIP(ctx, call) do { const hipError_t e_ = (call); if (e_ != hipSuccess) return fail(ctx, e_ == hipErrorOutOfMemory ? MV_ERR_OUT_OF_MEMORY : MV_ERR_HIP, #call, e_); } while (0)
-#define MV_REQUIRE(ctx, cond, code, msg) do { if (!(cond)) return fail(ctx, code, msg); } while (0)
-
-template <typename T>
-int devAlloc(mv_ctx* ctx, T** out, size_t bytes, bool zero = true)
-{
-	void* p = nullptr;
-	MV_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
-	ctx->allocs.push_back(p);
-	if (zero) MV_HIP(ctx, hipMemsetAsync(p, 0, bytes ? bytes : 16, ctx->stream));
-	*out = reinterpret_cast<T*>(p);
-	return MV_OK;
-}
-
-// replace a buffer devAlloc made by one of another size (mv_set_viewport)
-template <typename T>
-int devRealloc(mv_ctx* ctx, T** p, size_t bytes, bool zero = true)
-{
-	void* fresh = nullptr;
-	MV_HIP(ctx, hipMalloc(&fresh, bytes ? bytes : 16));
-	if (zero) MV_HIP(ctx, hipMemsetAsync(fresh, 0, bytes ? bytes : 16, ctx->stream));
-	for (void*& a : ctx->allocs)
-		if (a == static_cast<void*>(*p)) { (void)hipFree(a); a = fresh; *p = reinterpret_cast<T*>(fresh); return MV_OK; }
-	ctx->allocs.push_back(fresh);
-	*p = reinterpret_cast<T*>(fresh);
-	return MV_OK;
-}
-
-// rows of the composite buffer: H, or the padded rank-major layout (kFlagInterleaveRows)
-static size_t compositeRows(const DeviceState& st)
-{
-	const uint32_t sc = st.shardCount ? st.shardCount : 1u;
-	const size_t dealt = (size_t)sc * mv::interleavedRowsPerRank(st.H, sc) * 8u;
-	return sc > 1u && dealt > st.H ? dealt : st.H;
-}
-
-// everything of DeviceState that follows from W x H (mv_create, mv_set_viewport)
-void viewportDerived(DeviceState& st)
-{
-	st.rowsPerRank = mv::interleavedRowsPerRank(st.H, st.shardCount);
-	// Rows this shard composites (multivolumes_amd/distributed.py::row_range states the same rule): whole 8-row tiles, split evenly.
-	{
-		const uint32_t tiles = (st.H + 7u) >> 3;
-		const uint32_t t0 = (uint32_t)(((uint64_t)tiles * st.shardIndex) / st.shardCount), t1 = (uint32_t)(((uint64_t)tiles * (st.shardIndex + 1u)) / st.shardCount);
-		st.bandRow0 = t0 * 8u < st.H ? t0 * 8u : st.H;
-		st.bandRow1 = t1 * 8u < st.H ? t1 * 8u : st.H;
-	}
-	// Screen-space-scheme volumes are marched inside the view-march launch (up to kMaxScreenSlots of them), by every shard for ITS rows
-	{
-		uint32_t cap = kMaxScreenSlots;
-#ifdef MV_DIAGNOSTICS
-		{ const char* e = getenv("MV_SCREEN_SLOTS"); if (e) cap = (uint32_t)atoi(e); }
-#endif
-		st.screenSlots = st.V < cap ? st.V : cap;
-	}
-	{
-		// tile rows this context can own: its contiguous band, or (multi-GPU frame loop) every shard_count-th tile row
-		const uint32_t bandTiles = (st.bandRow1 - st.bandRow0 + 7u) >> 3, dealt = mv::interleavedRowsPerRank(st.H, st.shardCount ? st.shardCount : 1u);
-		st.maxScreenTiles = st.screenSlots * ((st.W + 7u) >> 3) * (bandTiles > dealt ? bandTiles : dealt);
-	}
-	st.compositeSlots = ((st.W + 7u) >> 3) * ((st.H + 7u) >> 3);
-}
-
-void applyParity(mv_ctx* ctx)
-{
-	const FrameBufs& f = ctx->fb[ctx->slot];
-	const FrameBufs& q = ctx->fb[(ctx->slot + ctx->numSlots - 1u) % ctx->numSlots];	// the previous frame's
-	DeviceState& st = ctx->st;
-	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
-	st.exchangeReport = (ctx->dist && ctx->dist->reports) ? ctx->dist->reports + (size_t)ctx->slot * 8u : nullptr;
-	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
-	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
-	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.exchangeOff = f.exchangeOff; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
-	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
-	const OutBufs& o = ctx->ob[ctx->set];
-	st.cubeMaps = o.cubeMaps; st.cubeDepths = o.cubeDepths; st.composite = o.composite; st.screenLayers = o.screenLayers; st.faceStamps = o.faceStamps;
-	st.waveStats = o.waveStats; st.compositeStats = o.compositeStats; st.compositeRetry = o.compositeRetry; st.tileCost = f.tileCost;
-	st.rayRecords = o.rayRecords; st.tileInfo = o.tileInfo;
-	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
-	st.binCursor = ctx->orderTiles ? f.binCounts : nullptr;
-	st.orderCap = st.maxTiles + st.maxScreenTiles + 1u;
-}
-
-int syncAll(mv_ctx* ctx)
-{
-	if (ctx->streamA != ctx->stream)
-	{
-		const hipError_t e = hipStreamSynchronize(ctx->streamA);
-		if (e != hipSuccess) return (int)e;
-	}
-	if (ctx->streamL && ctx->streamL != ctx->stream)
-	{
-		const hipError_t e = hipStreamSynchronize(ctx->streamL);
-		if (e != hipSuccess) return (int)e;
-	}
-	for (uint32_t i = 1; i < kMaxOutSets; ++i)
-		if (ctx->streamB[i] && ctx->streamB[i] != ctx->stream)
-		{
-			const hipError_t e = hipStreamSynchronize(ctx->streamB[i]);
-			if (e != hipSuccess) return (int)e;
-		}
-	if (ctx->dist && ctx->dist->streamX)
-	{
-		const hipError_t e = hipStreamSynchronize(ctx->dist->streamX);
-		if (e != hipSuccess) return (int)e;
-	}
-	return (int)hipStreamSynchronize(ctx->stream);
-}
-
-mv_ctx::EvTrack* evFind(mv_ctx* ctx, hipEvent_t e)
-{
-	for (auto& t : ctx->evTrack) { if (t.e == e) return &t; if (!t.e) { t.e = e; return &t; } }
-	return nullptr;	// (more events than slots: untracked, every wait is issued)
-}
-int evStreamIndex(mv_ctx* ctx, hipStream_t s)
-{
-	for (int i = 0; i < 8; ++i) { if (ctx->evStreams[i] == s) return i; if (!ctx->evStreams[i]) { ctx->evStreams[i] = s; return i; } }
-	return -1;
-}
-void evForget(mv_ctx* ctx)	// streams were destroyed or created: nothing recorded so far may be relied on by address
-{
-	for (auto& t : ctx->evTrack) { t.on = nullptr; for (auto& w : t.waited) w = 0; }
-	for (auto& x : ctx->evStreams) x = nullptr;
-}
-hipError_t evRecord(mv_ctx* ctx, hipEvent_t e, hipStream_t s)
-{
-	const hipError_t r = hipEventRecord(e, s);
-	if (mv_ctx::EvTrack* t = evFind(ctx, e)) { t->on = r == hipSuccess ? s : nullptr; t->seq = ++ctx->evSeq; }
-	return r;
-}
-hipError_t evWait(mv_ctx* ctx, hipStream_t s, hipEvent_t e)
-{
-	mv_ctx::EvTrack* t = evFind(ctx, e);
-	const int si = evStreamIndex(ctx, s);
-	if (t && si >= 0)
-	{
-		if (t->seq == 0) return hipSuccess;				// never recorded: nothing to wait for
-		if (t->on == s) return hipSuccess;				// recorded on this stream: stream order
-		if (t->waited[si] == t->seq) return hipSuccess;	// this stream has already waited for this record
-		t->waited[si] = t->seq;
-	}
-	return hipStreamWaitEvent(s, e, 0);
-}
-
-// stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
-// (every one of these orders streams against each other: a failure must reach the caller, or a later stage reads unfinished data)
-hipError_t stageADone(mv_ctx* ctx, bool last = true) { return ctx->leanEvents && !last ? hipSuccess : evRecord(ctx, ctx->evStageA[ctx->slot], ctx->streamA); }
-hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->frame % ctx->numViewStreams]; }
-hipError_t stageBBegin(mv_ctx* ctx)
-{
-	const hipError_t e = evWait(ctx, streamB(ctx), ctx->evStageA[ctx->slot]);
-	if (e != hipSuccess) return e;
-	// this frame's light march, if one has been enqueued (and, when light marches run on their frames' view streams, those of the
-	// frames before it on the OTHER view streams: a view march reads every visible volume's light map)
-	const uint32_t others = ctx->lightOnViewStream ? ctx->numViewStreams - 1u : 0u;
-	for (uint32_t j = 0; j <= others; ++j)
-	{
-		const hipError_t e2 = evWait(ctx, streamB(ctx), ctx->evLight[(ctx->slot + ctx->numSlots - j) % ctx->numSlots]);
-		if (e2 != hipSuccess) return e2;
-	}
-	return hipSuccess;
-}
-// stage of stream B finished being enqueued: the next user of this slot's buffers (ctx->numSlots frames on) and the light march two frames on wait for it
-hipError_t stageBDone(mv_ctx* ctx) { return evRecord(ctx, ctx->evMainDone[ctx->slot], streamB(ctx)); }
-
-void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
-{
-	if (!ctx->profiling) return;
-	// timing events only (never used for ordering): a failure here loses one timing sample, nothing else
-	ev.a = ev.b = nullptr;
-	if (!ctx->freeEvents.empty()) { ev = ctx->freeEvents.back(); ctx->freeEvents.pop_back(); }
-	else if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { ev.a = ev.b = nullptr; return; }
-	ev.stage = stage;
-	if (hipEventRecord(ev.a, stream) != hipSuccess) { ctx->freeEvents.push_back(ev); ev.a = ev.b = nullptr; }
-}
-
-void endStage(mv_ctx* ctx, EventPair& ev, hipStream_t stream)
-{
-	if (!ctx->profiling || !ev.a) return;
-	if (hipEventRecord(ev.b, stream) != hipSuccess) { ctx->freeEvents.push_back(ev); return; }
-	ctx->pending.push_back(ev);
-}
-
-// Inside the multi-GPU frame loop the exchange, composite and row gather of the last frame begun are still to be enqueued (they go out
-// with the next mv_dist_frame).  Anything that is about to overwrite an input that tail reads -- depth / shadow map, SH, volumes, light
-// maps, VolumeDesc -- enqueues it first, then waits for every stream: the pending frame is composited against the inputs it was begun
-// with.  (The tail contains collectives: inside the loop these setters are collective calls, every rank makes them at the same point.)
-int distTail(mv_ctx* ctx);
-int drainForWrite(mv_ctx* ctx)
-{
-	if (ctx->dist && ctx->dist->pending)
-	{
-		const int rc = distTail(ctx);
-		if (rc != MV_OK) return rc;
-	}
-	const hipError_t e = (hipError_t)syncAll(ctx);
-	return e == hipSuccess ? MV_OK : fail(ctx, MV_ERR_HIP, "synchronising the frames in flight", e);
-}
-#define MV_DRAIN(ctx) do { const int rc_ = drainForWrite(ctx); if (rc_ != MV_OK) return rc_; } while (0)
-
-void foldEvents(mv_ctx* ctx)
-{
-	for (EventPair& ev : ctx->pending)
-	{
-		(void)hipEventSynchronize(ev.b);
-		float ms = 0.0f;
-		if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
-		{
-			ctx->msStage[ev.stage] += ms;
-			ctx->nStage[ev.stage] += 1;
-		}
-		ctx->freeEvents.push_back(ev);
-	}
-	ctx->pending.clear();
-}
-
-} // namespace
-
-// More than three whole frames in flight need more than the four hardware queues the HIP runtime gives a process by default (streams
-// that share a queue wait for each other: scripts/micro/hw_queues.cpp): when this library is loaded before the runtime has started --
-// a C++ host that links it, a Python process that imports it before touching the GPU -- it asks for eight, unless the caller has said
-// otherwise.  A process whose runtime is already up keeps what it has; mv_config.frames_in_flight > 3 then shares queues (slower, correct).
-__attribute__((constructor)) static void mvAskForHardwareQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+#include "mv_ctx.hpp"
+using namespace mvi;
 
 extern "C" {
 
@@ -461,6 +19,7 @@ const char* mv_error_string(int code)
 	case MV_ERR_NO_DEVICE: return "no usable gfx950 device (there is no CPU fallback)";
 	case MV_ERR_OUT_OF_MEMORY: return "out of device memory";
 	case MV_ERR_NOT_READY: return "a required input was never supplied";
+	case MV_ERR_TIMEOUT: return "another rank did not reach a stage of a frame within the timeout";
 	case MV_ERR_RANGE: return "index out of range";
 	default: return "unknown error";
 	}
@@ -730,21 +289,6 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	return MV_OK;
 }
 
-// Detach the multi-GPU frame loop: communicators, its stream, the pinned cull copies (device buffers stay in ctx->allocs until
-// mv_destroy; the RCCL library stays loaded).
-static void distRelease(mv_ctx* ctx)
-{
-	DistState* d = ctx->dist;
-	if (!d) return;
-	for (uint32_t i = 0; i < kDistChains; ++i) if (d->comm[i] && d->commDestroy) (void)d->commDestroy(d->comm[i]);
-	if (d->streamX) (void)hipStreamDestroy(d->streamX);
-	evForget(ctx);
-	if (d->reports) (void)hipHostFree(d->reports);
-	for (void* p : d->allocs) (void)hipFree(p);
-	delete d;
-	ctx->dist = nullptr;
-}
-
 void mv_destroy(mv_ctx* ctx)
 {
 	if (!ctx) return;
@@ -979,7 +523,7 @@ int mv_set_max_samples(mv_ctx* ctx, uint32_t maxRaySamples, uint32_t maxLightSam
 // frame's light march to fill it.  A caller may leave mv_march_light out of a frame (the reference then simply keeps its light
 // maps): the first stage of such a frame that reads light maps puts the previous frame's table back, so the frame -- and the
 // frames after it, which derive their table from this one -- read the maps that were last written.
-static int keepLightTable(mv_ctx* ctx)
+int mvi::keepLightTable(mv_ctx* ctx)
 {
 	if (ctx->lightMarched || ctx->lightTableKept) return MV_OK;
 	const FrameBufs& f = ctx->fb[ctx->slot];
@@ -1042,14 +586,12 @@ int mv_cull(mv_ctx* ctx)
 	return MV_OK;
 }
 
-static int marchLight(mv_ctx* ctx, uint32_t* wordsOut);
 // EXPERIMENT (-DMV_DIAGNOSTICS builds, MV_DIST_LIGHT_ON_A=1; profiles/r03_light_on_stream_a.txt: slower): on a rank of the multi-GPU loop with whole-frame chains, the light share-out (march, all-gather,
 // unpack) goes on stream A behind the frame's cull instead of in front of the frame's view march on its chain
-static bool distLightOnStreamA(const mv_ctx* ctx);
 int mv_march_light(mv_ctx* ctx) { return ctx ? marchLight(ctx, nullptr) : MV_ERR_INVALID_ARG; }
 
 // wordsOut: inside the multi-GPU frame loop, where this rank's share of the relit map goes for the all-gather
-static int marchLight(mv_ctx* ctx, uint32_t* wordsOut)
+int mvi::marchLight(mv_ctx* ctx, uint32_t* wordsOut)
 {
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
@@ -1080,7 +622,7 @@ static int marchLight(mv_ctx* ctx, uint32_t* wordsOut)
 // It reads the other set -- complete once the previous frame's view march (and, on a multi-GPU rank, its unpack) has finished --
 // and writes faces nobody else writes this frame, so it can run beside this frame's view march; the composite of this frame and
 // the view march of the NEXT frame (which writes the other set again) wait for it.
-static int copyForward(mv_ctx* ctx, hipStream_t s)
+int mvi::copyForward(mv_ctx* ctx, hipStream_t s)
 {
 	const OutBufs& other = ctx->ob[(ctx->set + ctx->numOutSets - 1u) % ctx->numOutSets];
 	mv::launchCopyForward(s, ctx->st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)ctx->frame, true);
@@ -1114,7 +656,7 @@ static int copyForwardFromAllSets(mv_ctx* ctx, bool marchFollows)
 #define MV_COPY_FORWARD 1	// (0: A/B timing only -- the two output sets then drift apart in the faces a frame does not march)
 #endif
 // First half of mv_march_view: bring the faces this frame does not march up to date in its output set (see copyForward above).
-static int viewCopyForward(mv_ctx* ctx)
+int mvi::viewCopyForward(mv_ctx* ctx)
 {
 	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
@@ -1147,7 +689,7 @@ static int viewCopyForward(mv_ctx* ctx)
 }
 
 // Second half: the march itself.
-static int viewMarch(mv_ctx* ctx)
+int mvi::viewMarch(mv_ctx* ctx)
 {
 	const uint32_t n = ctx->numOutSets;
 	ctx->marchedThisFrame = true;
@@ -1183,11 +725,21 @@ static int viewMarch(mv_ctx* ctx)
 				tiles = exact ? count : count + count / 4u + 256u;
 			}
 		}
-		const uint32_t beyond = mv::launchMarchTiles(streamB(ctx), ctx->st, tiles);
+		// (peer-store transport, folded flags: the main launch waits; the LAST launch raises -- the overflow launch if there is one)
+		DeviceState stMain = ctx->st;
+		const bool foldSignal = stMain.fold.nSignal != 0u;
+		if (!exact) stMain.fold.nSignal = 0u;
+		const uint32_t beyond = mv::launchMarchTiles(streamB(ctx), stMain, tiles);
 		// (an exact count is this frame's own: nothing can lie beyond the grid.  Otherwise the overflow launch follows on the same
 		// stream: on the high-priority stream A it would have to wait for this frame's light march and held up the next frame's cull --
 		// measured slower.  It is kept small, 64 workgroups, because its wavefronts must find slots on a GPU the other frame's march fills.)
-		if (!exact && beyond != 0xffffffffu) mv::launchMarchTilesOverflow(streamB(ctx), ctx->st, beyond);
+		if (!exact && beyond != 0xffffffffu)
+		{
+			DeviceState stOver = ctx->st;
+			stOver.fold.nWait = 0u;
+			mv::launchMarchTilesOverflow(streamB(ctx), stOver, beyond);
+		}
+		else if (!exact && foldSignal && ctx->dist) ctx->dist->foldSignalMissing = true;
 	}
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());
@@ -1469,7 +1021,7 @@ int mv_synchronize(mv_ctx* ctx)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	return MV_OK;
+	return distCheck(ctx);	// (peer-store transport: a wait for another rank that gave up)
 }
 
 void* mv_get_stream(mv_ctx* ctx) { return ctx ? reinterpret_cast<void*>(ctx->stream) : nullptr; }
@@ -1515,124 +1067,6 @@ int mv_get_buffer(mv_ctx* ctx, uint32_t which, uint32_t index, void** d_ptr, siz
 	}
 }
 
-// ---- mesh depth / shadow producer (ObjectRenderer.cpp:209-262) ----
-int mv_mesh_upload(mv_ctx* ctx, const float* positions, uint32_t numVerts, const uint32_t* indices, uint32_t numTris)
-{
-	if (!ctx || !positions || !indices || !numVerts || !numTris) return MV_ERR_INVALID_ARG;
-	for (size_t i = 0; i < (size_t)numTris * 3; ++i) MV_REQUIRE(ctx, indices[i] < numVerts, MV_ERR_RANGE, "mesh index out of range");
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	if (ctx->meshPositions) { (void)hipFree(ctx->meshPositions); ctx->meshPositions = nullptr; }
-	if (ctx->meshIndices) { (void)hipFree(ctx->meshIndices); ctx->meshIndices = nullptr; }
-	MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->meshPositions), (size_t)numVerts * 3 * sizeof(float)));
-	MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->meshIndices), (size_t)numTris * 3 * sizeof(uint32_t)));
-	if (!ctx->rasterBits)
-	{
-		const size_t n = std::max((size_t)ctx->st.W * ctx->st.H, (size_t)ctx->st.M * ctx->st.M);
-		MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->rasterBits), n * sizeof(uint32_t)));
-		MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->dMeshMatrix), 16 * sizeof(float)));
-	}
-	MV_HIP(ctx, hipMemcpy(ctx->meshPositions, positions, (size_t)numVerts * 3 * sizeof(float), hipMemcpyHostToDevice));
-	MV_HIP(ctx, hipMemcpy(ctx->meshIndices, indices, (size_t)numTris * 3 * sizeof(uint32_t), hipMemcpyHostToDevice));
-	ctx->meshVerts = numVerts; ctx->meshTris = numTris;
-	return MV_OK;
-}
-
-static int rasterInto(mv_ctx* ctx, const float matT[16], float bx, float by, uint32_t W, uint32_t H)
-{
-	MV_REQUIRE(ctx, ctx->meshTris > 0, MV_ERR_NOT_READY, "no mesh (mv_mesh_upload)");
-	MV_DRAIN(ctx);	// depth / shadow maps may still be read by frames in flight
-	MV_HIP(ctx, hipMemcpyAsync(ctx->dMeshMatrix, matT, 16 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-	mv::launchFillU32(ctx->stream, ctx->rasterBits, 0x3f800000u, (size_t)W * H);	// cleared to 1.0
-	mv::launchRasterDepthBits(ctx->stream, ctx->meshPositions, ctx->meshIndices, ctx->meshTris, ctx->dMeshMatrix, bx, by, W, H, ctx->rasterBits);
-	MV_HIP(ctx, hipGetLastError());
-	return MV_OK;
-}
-
-int mv_mesh_render_depth(mv_ctx* ctx, const float worldViewProjT[16], const float projBias[2])
-{
-	if (!ctx || !worldViewProjT) return MV_ERR_INVALID_ARG;
-	const int rc = rasterInto(ctx, worldViewProjT, projBias ? projBias[0] : 0.0f, projBias ? projBias[1] : 0.0f, ctx->st.W, ctx->st.H);
-	if (rc != MV_OK) return rc;
-	// the depth bits ARE the D32F values
-	MV_HIP(ctx, hipMemcpyAsync(ctx->ownDepth, ctx->rasterBits, (size_t)ctx->st.W * ctx->st.H * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	ctx->st.depthMap = ctx->ownDepth;
-	ctx->haveDepth = true;
-	return MV_OK;
-}
-
-int mv_mesh_render_shadow(mv_ctx* ctx, const float shadowWVPT[16])
-{
-	if (!ctx || !shadowWVPT) return MV_ERR_INVALID_ARG;
-	const int rc = rasterInto(ctx, shadowWVPT, 0.0f, 0.0f, ctx->st.M, ctx->st.M);
-	if (rc != MV_OK) return rc;
-	mv::launchDepthBitsToD16(ctx->stream, ctx->rasterBits, ctx->ownShadow, (size_t)ctx->st.M * ctx->st.M);
-	MV_HIP(ctx, hipGetLastError());
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	ctx->st.shadowMap = ctx->ownShadow;
-	ctx->haveShadow = true;
-	return MV_OK;
-}
-
-int mv_readback_depth_map(mv_ctx* ctx, float* dst)
-{
-	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	MV_HIP(ctx, hipMemcpy(dst, ctx->st.depthMap, (size_t)ctx->st.W * ctx->st.H * sizeof(float), hipMemcpyDeviceToHost));
-	return MV_OK;
-}
-
-int mv_readback_shadow_map(mv_ctx* ctx, uint16_t* dst)
-{
-	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	MV_HIP(ctx, hipMemcpy(dst, ctx->st.shadowMap, (size_t)ctx->st.M * ctx->st.M * sizeof(uint16_t), hipMemcpyDeviceToHost));
-	return MV_OK;
-}
-
-int mv_shard_rows(mv_ctx* ctx, uint32_t* row0, uint32_t* row1)
-{
-	if (!ctx || !row0 || !row1) return MV_ERR_INVALID_ARG;
-	*row0 = ctx->st.bandRow0; *row1 = ctx->st.bandRow1;
-	return MV_OK;
-}
-
-int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size_t* shard_bytes)
-{
-	if (!ctx || !slot_dim || !slot_bytes || !shard_bytes) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
-	MV_HIP(ctx, stageBBegin(ctx));
-	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedCounters, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	const uint32_t minMip = ctx->pinnedCounters[5] < MV_NUM_CUBE_MIP ? ctx->pinnedCounters[5] : 0u;
-	const uint32_t d = ctx->st.N >> minMip;
-	*slot_dim = d;
-	*slot_bytes = (size_t)6 * d * d * (sizeof(uint2) + sizeof(float));
-	const uint32_t sc = ctx->st.shardCount ? ctx->st.shardCount : 1u;
-	*shard_bytes = *slot_bytes * ((ctx->st.V + sc - 1u) / sc);
-	return MV_OK;
-}
-
-int mv_exchange_pack(mv_ctx* ctx, void* d_dst, uint32_t slot_dim)
-{
-	if (!ctx || !d_dst) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
-	MV_REQUIRE(ctx, slot_dim >= 1 && slot_dim <= ctx->st.N, MV_ERR_RANGE, "slot_dim out of range");
-	mv::launchExchangePack(streamB(ctx), ctx->st, slot_dim, d_dst);
-	MV_HIP(ctx, hipGetLastError());
-	return MV_OK;
-}
-
-int mv_exchange_unpack(mv_ctx* ctx, const void* d_src, uint32_t slot_dim)
-{
-	if (!ctx || !d_src) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->haveCull, MV_ERR_NOT_READY, "mv_cull has not been called");
-	MV_REQUIRE(ctx, slot_dim >= 1 && slot_dim <= ctx->st.N, MV_ERR_RANGE, "slot_dim out of range");
-	mv::launchExchangeUnpack(streamB(ctx), ctx->st, slot_dim, d_src);
-	MV_HIP(ctx, hipGetLastError());
-	return MV_OK;
-}
-
 int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info, uint32_t* visible, uint32_t* visibleCount,
 	uint32_t* cubeMapVolumes, uint32_t* cubeMapCount, uint32_t* minMip)
 {
@@ -1650,507 +1084,6 @@ int mv_readback_cull(mv_ctx* ctx, uint16_t* volume_info, uint32_t* visible, uint
 	memcpy(volume_info, p + 64, V * 8);
 	memcpy(visible, p + 64 + V * 8, V * 4);
 	memcpy(cubeMapVolumes, p + 64 + V * 12, V * 4);
-	return MV_OK;
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// multi-GPU frame loop inside the library (include/multivolumes.h "mv_dist_*")
-// ---------------------------------------------------------------------------------------------
-static int distAllGather(mv_ctx* ctx, const void* send, void* recv, size_t bytes, hipStream_t stream, int which)
-{
-	DistState* d = ctx->dist;
-	if (d->transport == 1)
-	{
-		const ncclResult_t r = d->allGather(send, recv, bytes, ncclUint8, d->comm[which], stream);
-		if (r != ncclSuccess) return fail(ctx, MV_ERR_HIP, d->errorString ? d->errorString(r) : "ncclAllGather failed");
-		return MV_OK;
-	}
-	if (d->cbAllGather(d->user, send, recv, bytes, reinterpret_cast<void*>(stream), which) != 0) return fail(ctx, MV_ERR_HIP, "the caller's all-gather failed");
-	return MV_OK;
-}
-
-static int distAllReduceU32(mv_ctx* ctx, uint32_t* buf, size_t count, hipStream_t stream, int which)
-{
-	DistState* d = ctx->dist;
-	if (d->transport == 1)
-	{
-		const ncclResult_t r = d->allReduce(buf, buf, count, ncclUint32, ncclSum, d->comm[which], stream);
-		if (r != ncclSuccess) return fail(ctx, MV_ERR_HIP, d->errorString ? d->errorString(r) : "ncclAllReduce failed");
-		return MV_OK;
-	}
-	if (d->cbAllReduce(d->user, buf, count, reinterpret_cast<void*>(stream), which) != 0) return fail(ctx, MV_ERR_HIP, "the caller's all-reduce failed");
-	return MV_OK;
-}
-
-// buffers, streams and events shared by both transports
-static int distAlloc(mv_ctx* ctx, uint8_t** out, size_t bytes, hipStream_t zeroOn = nullptr)
-{
-	void* p = nullptr;
-	MV_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
-	ctx->dist->allocs.push_back(p);
-	if (zeroOn) MV_HIP(ctx, hipMemsetAsync(p, 0, bytes ? bytes : 16, zeroOn));
-	*out = static_cast<uint8_t*>(p);
-	return MV_OK;
-}
-
-static int distCommonInitBody(mv_ctx* ctx)
-{
-	DistState* d = ctx->dist;
-	const DeviceState& st = ctx->st;
-	MV_REQUIRE(ctx, ctx->cfg.flags & MV_FLAG_PIPELINE_FRAMES, MV_ERR_INVALID_ARG,
-		"mv_dist_* needs a context created with MV_FLAG_PIPELINE_FRAMES (whole frames on three view streams), optionally | MV_FLAG_SINGLE_VIEW_STREAM (two output sets, cull and light march ahead)");
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	if (!d->chains) MV_HIP(ctx, hipStreamCreateWithFlags(&d->streamX, hipStreamNonBlocking));
-	evForget(ctx);
-	const uint32_t world = st.shardCount;
-	// One rank's shard of a frame's cube-face all-gather: the marched faces of the volumes the cull dealt to it.  The deal balances
-	// estimated march cost, not texels -- a rank may be handed every cheap (low SmpCount) volume of a frame -- so the buffers hold the
-	// worst case: every volume at mip 0 with six faces (C3: 75 MB per shard; 288 GB of HBM make that affordable).
-	d->sendCap = (size_t)st.V * 6u * st.N * st.N * 12u;
-	d->maxBandBytes = (size_t)mv::interleavedRowsPerRank(st.H, world) * 8u * st.W * sizeof(uint2);	// one rank's block of the rank-major composite image
-	{
-		// the light march of a frame is shared out by voxel blocks (mv_kernels.hip lightShare): 64 words per block, the same number of blocks per rank
-		DeviceState split = st;
-		split.flags |= mv::kFlagRotateAllLightMaps;
-		d->lightShareBytes = ((size_t)mv::lightSharePerRank(split) + 1u) * 64u * sizeof(uint32_t);	// its blocks + a trailer (what its cull decided: checked by the unpack)
-	}
-	int rc;
-	for (uint32_t c = 0; c < d->numChains; ++c)
-	{
-		if ((rc = distAlloc(ctx, &d->sendBuf[c], d->sendCap)) != MV_OK) return rc;
-		if ((rc = distAlloc(ctx, &d->recvBuf[c], d->sendCap * world)) != MV_OK) return rc;
-		uint8_t* w = nullptr;
-		if ((rc = distAlloc(ctx, &w, std::max<size_t>(d->lightShareBytes * world, 4096), ctx->stream)) != MV_OK) return rc;
-		d->lightWords[c] = reinterpret_cast<uint32_t*>(w);
-		if ((rc = distAlloc(ctx, &d->lightSend[c], std::max<size_t>(d->lightShareBytes, 4096), ctx->stream)) != MV_OK) return rc;
-		if ((rc = distAlloc(ctx, &d->rowSend[c], d->maxBandBytes, ctx->stream)) != MV_OK) return rc;
-		if ((rc = distAlloc(ctx, &d->rowRecv[c], d->maxBandBytes * world)) != MV_OK) return rc;
-	}
-	if (hipHostMalloc(reinterpret_cast<void**>(&d->reports), kMaxFrameSlots * 64, hipHostMallocCoherent) != hipSuccess) return fail(ctx, MV_ERR_OUT_OF_MEMORY, "pinned exchange reports");
-	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) { d->reports[i * 8u] = ~0ull; d->reports[i * 8u + 1u] = 0ull; }
-	if (world > 1u) ctx->st.flags |= mv::kFlagInterleaveRows;	// screen rows dealt by tile row instead of in contiguous bands
-#ifndef MV_DIST_STATIC_OWNERS	// (A/B builds only: v % shard_count inside the loop too)
-	ctx->st.flags |= mv::kFlagBalanceOwners;	// the cube-map volumes of a frame are dealt to the ranks by estimated cost (replicated cull: the same deal everywhere)
-#endif
-	ctx->st.flags |= mv::kFlagRotateAllLightMaps;	// every rank rotates the relit volume's light buffer: the exchange fills it on the non-owners
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	return MV_OK;
-}
-
-// (a failure leaves the context without a frame loop, never with half of one)
-static int distCommonInit(mv_ctx* ctx)
-{
-	const int rc = distCommonInitBody(ctx);
-	if (rc != MV_OK)
-	{
-		(void)syncAll(ctx);
-		distRelease(ctx);
-		ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows);
-	}
-	return rc;
-}
-
-static void* openRccl()
-{
-	void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-	return lib ? lib : dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-}
-
-int mv_dist_rccl_available(void)
-{
-	void* lib = openRccl();
-	if (!lib) return 0;
-	for (const char* name : { "ncclGetUniqueId", "ncclCommInitRank", "ncclAllGather", "ncclAllReduce", "ncclBroadcast", "ncclCommDestroy", "ncclCommCount", "ncclGroupStart", "ncclGroupEnd", "ncclSend", "ncclRecv" })
-		if (!dlsym(lib, name)) return 0;
-	return 1;
-}
-
-int mv_dist_unique_id(void* out)
-{
-	if (!out) return MV_ERR_INVALID_ARG;
-	void* lib = openRccl();
-	if (!lib) return MV_ERR_NOT_READY;
-	auto getId = reinterpret_cast<decltype(&ncclGetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
-	if (!getId) return MV_ERR_NOT_READY;
-	static_assert(kDistChains * sizeof(ncclUniqueId) == MV_DIST_ID_BYTES, "one RCCL unique id per communicator");
-	ncclUniqueId* ids = reinterpret_cast<ncclUniqueId*>(out);
-	for (uint32_t i = 0; i < kDistChains; ++i) if (getId(&ids[i]) != ncclSuccess) return MV_ERR_HIP;
-	return MV_OK;
-}
-
-int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
-{
-	if (!ctx || !id) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, !ctx->dist, MV_ERR_INVALID_ARG, "mv_dist_init_* was already called on this context");
-	MV_REQUIRE(ctx, ctx->st.shardCount >= 1, MV_ERR_INVALID_ARG, "shard_count");
-	DistState* d = new (std::nothrow) DistState();
-	if (!d) return MV_ERR_OUT_OF_MEMORY;
-	d->transport = 1; d->inPlaceGather = true;
-	d->chains = ctx->lightOnViewStream && ctx->numViewStreams >= 2u;
-	d->numChains = d->chains ? ctx->numViewStreams : 1u;
-	d->numComm = d->chains ? d->numChains : 2u;
-	d->rcclLib = openRccl();
-	if (d->rcclLib)
-	{
-		d->commInitRank = reinterpret_cast<decltype(d->commInitRank)>(dlsym(d->rcclLib, "ncclCommInitRank"));
-		d->allGather = reinterpret_cast<decltype(d->allGather)>(dlsym(d->rcclLib, "ncclAllGather"));
-		d->allReduce = reinterpret_cast<decltype(d->allReduce)>(dlsym(d->rcclLib, "ncclAllReduce"));
-		d->commDestroy = reinterpret_cast<decltype(d->commDestroy)>(dlsym(d->rcclLib, "ncclCommDestroy"));
-		d->errorString = reinterpret_cast<decltype(d->errorString)>(dlsym(d->rcclLib, "ncclGetErrorString"));
-	}
-	if (!d->rcclLib || !d->commInitRank || !d->allGather || !d->allReduce || !d->commDestroy) { delete d; return fail(ctx, MV_ERR_NOT_READY, "librccl.so could not be opened"); }
-	{ const hipError_t e = hipSetDevice(ctx->cfg.device); if (e != hipSuccess) { delete d; return fail(ctx, MV_ERR_HIP, "hipSetDevice", e); } }
-	const ncclUniqueId* ids = reinterpret_cast<const ncclUniqueId*>(id);
-	for (uint32_t i = 0; i < d->numComm; ++i)
-	{
-		const ncclResult_t r = d->commInitRank(&d->comm[i], (int)ctx->st.shardCount, ids[i], (int)ctx->st.shardIndex);
-		if (r != ncclSuccess)
-		{
-			const int rc = fail(ctx, MV_ERR_HIP, d->errorString ? d->errorString(r) : "ncclCommInitRank failed");
-			for (uint32_t j = 0; j < i; ++j) if (d->comm[j]) (void)d->commDestroy(d->comm[j]);
-			delete d;
-			return rc;
-		}
-	}
-	ctx->dist = d;
-	return distCommonInit(ctx);
-}
-
-int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_allreduce_u32_fn allreduce, void* user)
-{
-	if (!ctx || !allgather || !allreduce) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, !ctx->dist, MV_ERR_INVALID_ARG, "mv_dist_init_* was already called on this context");
-	DistState* d = new (std::nothrow) DistState();
-	if (!d) return MV_ERR_OUT_OF_MEMORY;
-	d->transport = 2; d->cbAllGather = allgather; d->cbAllReduce = allreduce; d->user = user;
-	d->chains = ctx->lightOnViewStream && ctx->numViewStreams >= 2u;
-	d->numChains = d->chains ? ctx->numViewStreams : 1u;
-	d->numComm = d->chains ? d->numChains : 2u;
-	ctx->dist = d;
-	return distCommonInit(ctx);
-}
-
-int mv_dist_set_cull_crosscheck(mv_ctx* ctx, int enabled)
-{
-	if (!ctx) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
-	ctx->dist->cullCrosscheck = enabled != 0;
-	return MV_OK;
-}
-
-int mv_dist_set_inplace_gather(mv_ctx* ctx, int enabled)
-{
-	if (!ctx) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
-	MV_REQUIRE(ctx, ctx->dist->transport == 2, MV_ERR_INVALID_ARG, "only for caller-supplied collectives (RCCL gathers in place already)");
-	ctx->dist->inPlaceGather = enabled != 0;
-	return MV_OK;
-}
-
-int mv_dist_shutdown(mv_ctx* ctx)
-{
-	if (!ctx) return MV_ERR_INVALID_ARG;
-	if (!ctx->dist) return MV_OK;
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	if (ctx->dist->streamX) MV_HIP(ctx, hipStreamSynchronize(ctx->dist->streamX));
-	distRelease(ctx);
-	ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows);
-	return MV_OK;
-}
-
-// Exchange and composite of the pending frame k - 1, enqueued while frame k is being begun: by then the host has k - 1's cull results
-// (they size the all-gather) without waiting.  Single view stream: both on stream X, beside frame k's view march.  Chains: on frame
-// k - 1's own view stream, behind its view march, with that chain's communicator and buffers.
-static hipStream_t distTailStream(mv_ctx* ctx, uint32_t chain) { return ctx->dist->chains ? ctx->streamB[chain] : ctx->dist->streamX; }
-
-static int distTailExchange(mv_ctx* ctx)
-{
-	DistState* d = ctx->dist;
-	if (!d->pending) return MV_OK;
-	const DeviceState& st = d->stPending;
-	const uint32_t slot = d->slotPending, world = st.shardCount;
-	const uint32_t chain = d->chains ? d->chainPending : 0u;
-
-	hipStream_t X = distTailStream(ctx, chain);
-	if (!d->chains) MV_HIP(ctx, evWait(ctx, X, ctx->evMainDone[slot]));	// the frame's view march (chains: the same stream)
-	if (world > 1)
-	{
-		// The frame's cull left {frame tag : texels of the largest shard of its deal} in pinned memory at least one mv_dist_frame ago: a
-		// plain read in steady state (the wait only happens if the host is that far ahead of the GPU).  It gives the size of the frame's
-		// all-gather, the same on every rank: the cull is replicated.
-		volatile unsigned long long* report = d->reports + (size_t)slot * 8u;
-		unsigned long long rep;
-		{
-			MV_SECTION(8);
-			if ((uint32_t)(*report >> 32) != st.frameTag) MV_HIP(ctx, hipEventSynchronize(ctx->evStageA[slot]));
-			rep = *report;
-		}
-		MV_REQUIRE(ctx, (uint32_t)(rep >> 32) == st.frameTag, MV_ERR_HIP, "the cull's exchange report is missing");
-		// (the light exchange of this frame compared what every rank's cull decided: mv_kernels.hip lightUnpackKernel)
-		// (mv_dist_set_cull_crosscheck(ctx, 0): a rank measured alone, with callbacks that exchange nothing -- the other ranks'
-		// trailers are then not there to compare)
-		MV_REQUIRE(ctx, !d->cullCrosscheck || report[1] != (((unsigned long long)st.frameTag << 32) | 1ull), MV_ERR_INVALID_ARG,
-			"the ranks' culls of this frame disagree (different frame constants on different ranks?): its collectives would not match");
-		const size_t shardBytes = std::max<size_t>(16, ((size_t)(uint32_t)rep * 12u + 15u) & ~(size_t)15u);
-		MV_REQUIRE(ctx, shardBytes <= d->sendCap, MV_ERR_RANGE, "exchange shard larger than its buffer");
-		{ MV_SECTION(9); mv::launchExchangeCompact(X, st, true, d->sendBuf[chain], shardBytes); }
-		MV_HIP(ctx, hipGetLastError());
-		int rc;
-		{ MV_SECTION(10); rc = distAllGather(ctx, d->sendBuf[chain], d->recvBuf[chain], shardBytes, X, (int)chain); }
-		if (rc != MV_OK) return rc;
-		{ MV_SECTION(11); mv::launchExchangeCompact(X, st, false, d->recvBuf[chain], shardBytes); }
-		MV_HIP(ctx, hipGetLastError());
-		d->bytes += shardBytes * world;
-	}
-	return MV_OK;
-}
-
-static int distTailComposite(mv_ctx* ctx)
-{
-	DistState* d = ctx->dist;
-	if (!d->pending) return MV_OK;
-	const DeviceState& st = d->stPending;
-	const uint32_t slot = d->slotPending, world = st.shardCount, rank = st.shardIndex;
-	const uint32_t chain = d->chains ? d->chainPending : 0u;
-	hipStream_t X = distTailStream(ctx, chain);
-	if (d->pendingComposite)
-	{
-		// chains: the copy-forward of this frame's unmarched faces ran on the stream of the frame before it
-		if (d->chains) MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[slot]));
-		mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
-		MV_HIP(ctx, hipGetLastError());
-		if (world > 1)
-		{
-			// The image is stored rank-major (kFlagInterleaveRows): every rank's tile rows are one contiguous block of the same size, so
-			// the frame buffer is the all-gather's output and this rank's block its input.
-			const size_t rowBytes = (size_t)st.W * sizeof(uint2);
-			const size_t block = d->maxBandBytes;
-			uint8_t* frame = reinterpret_cast<uint8_t*>(st.composite);
-			if (d->inPlaceGather)
-			{
-				const int rc = distAllGather(ctx, frame + (size_t)rank * block, frame, block, X, (int)chain);	// sendbuff == recvbuff + rank * count
-				if (rc != MV_OK) return rc;
-			}
-			else
-			{
-				MV_HIP(ctx, hipMemcpyAsync(d->rowSend[chain], frame + (size_t)rank * block, block, hipMemcpyDeviceToDevice, X));
-				const int rc = distAllGather(ctx, d->rowSend[chain], frame, block, X, (int)chain);
-				if (rc != MV_OK) return rc;
-			}
-			d->bytes += (size_t)st.H * rowBytes;
-		}
-	}
-	// everything that reads this frame's buffers has been enqueued: the next users of its slot / output set / light buffers wait for this
-	MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[slot], X));
-	d->pending = false;
-	return MV_OK;
-}
-
-namespace { int distTail(mv_ctx* ctx)
-{
-	const int rc = distTailExchange(ctx);
-	return rc != MV_OK ? rc : distTailComposite(ctx);
-} }
-
-// The light march of frame k, shared out over the ranks by voxel blocks (every rank holds every volume): this rank marches its
-// 1 / shard_count of the blocks, into its own copy of the relit volume's fresh light buffer and, as plain words, into its share of the
-// all-gather; the other ranks' shares are then unpacked into the local copy.  Every rank keeps every light map current, because
-// every rank marches its own screen rows of every volume on the screen-space scheme.
-static bool distLightOnStreamA(const mv_ctx* ctx)
-{
-#ifdef MV_DIAGNOSTICS	// (the shipped library reads no environment variable)
-	static const bool on = [] { const char* e = getenv("MV_DIST_LIGHT_ON_A"); return e && e[0] == '1'; }();
-	return on && ctx->dist && ctx->dist->chains && ctx->st.shardCount > 1u;
-#else
-	(void)ctx;
-	return false;
-#endif
-}
-
-static int distLight(mv_ctx* ctx, uint32_t chain)
-{
-	DistState* d = ctx->dist;
-	const uint32_t world = ctx->st.shardCount, rank = ctx->st.shardIndex;
-	uint8_t* lightAll = reinterpret_cast<uint8_t*>(d->lightWords[chain]);
-	uint8_t* lightMine = d->inPlaceGather ? lightAll + (size_t)rank * d->lightShareBytes : d->lightSend[chain];
-	int rc;
-	if ((rc = marchLight(ctx, world > 1u ? reinterpret_cast<uint32_t*>(lightMine) : nullptr)) != MV_OK) return rc;
-	if (world > 1u)
-	{
-		// The exchange goes in front of the view march that needs it, on that march's stream (chains: behind the light march, which is
-		// on that stream too).  Single view stream: not behind the light march on stream L, where it would hold up the NEXT frame's
-		// light march.
-		hipStream_t E = d->chains ? streamB(ctx) : ctx->stream;
-		if (distLightOnStreamA(ctx)) E = ctx->stream;
-		if (!d->chains) MV_HIP(ctx, evWait(ctx, E, ctx->evLight[ctx->slot]));	// this rank's light march (chains: the same stream)
-		MV_HIP(ctx, evWait(ctx, E, ctx->evStageA[ctx->slot]));	// this frame's cull: the relit volume, its rotated buffer
-		MV_HIP(ctx, evWait(ctx, E, ctx->evMainDone[(ctx->slot + ctx->numSlots - ctx->st.lightBufs) % ctx->numSlots]));	// frame k - 3, the last reader of the buffer the unpack overwrites
-		if ((rc = distAllGather(ctx, lightMine, lightAll, d->lightShareBytes, E, d->chains ? (int)chain : 1)) != MV_OK) return rc;
-		mv::launchLightUnpack(E, ctx->st, d->lightWords[chain]);
-		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], E));	// "this frame's light map is current on this rank": the next user of the slot waits for it
-		d->bytes += d->lightShareBytes * world;
-	}
-	return MV_OK;
-}
-
-int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite)
-{
-	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
-	DistState* d = ctx->dist;
-	int rc;
-	struct Lean { mv_ctx* c; ~Lean() { c->leanEvents = false; } } lean = { ctx };
-	ctx->leanEvents = d->chains;
-	// ---- frame k: constants + cull (stream A) ----
-	{ MV_SECTION(0); if ((rc = mv_update_frame(ctx, cbPerFrame, perObject)) != MV_OK) return rc; }
-	{ MV_SECTION(1); if ((rc = mv_cull(ctx)) != MV_OK) return rc; }
-#ifdef MV_HOST_PROFILE
-	++gSectionCalls;
-	if (getenv("MV_PROFILE_PHASE"))	// at the start of a call (after this frame's cull was enqueued): which earlier frames' stages has the GPU finished?
-	{
-		static uint64_t cullDone[6], tailDone[6], n;
-		for (uint32_t b = 1; b <= 5; ++b)
-		{
-			const uint32_t sl = (ctx->slot + ctx->numSlots * 4u - b) % ctx->numSlots;
-			if (b < ctx->numSlots && hipEventQuery(ctx->evStageA[sl]) == hipSuccess) ++cullDone[b];
-			if (b < ctx->numSlots && hipEventQuery(ctx->evMainDone[sl]) == hipSuccess) ++tailDone[b];
-		}
-		if (++n % 200 == 0)
-		{
-			fprintf(stderr, " [phase at call start, share of calls: cull done of frame k-1 %.2f k-2 %.2f k-3 %.2f; tail done of k-1 %.2f k-2 %.2f k-3 %.2f]",
-				cullDone[1] / 200.0, cullDone[2] / 200.0, cullDone[3] / 200.0, tailDone[1] / 200.0, tailDone[2] / 200.0, tailDone[3] / 200.0);
-			for (auto& x : cullDone) x = 0; for (auto& x : tailDone) x = 0;
-		}
-	}
-	if (getenv("MV_PROFILE_CULL_LATENCY"))	// how long after its enqueue the cull's report reaches pinned memory (spins: perturbs the loop)
-	{
-		const auto t0 = std::chrono::steady_clock::now();
-		while ((uint32_t)(*reinterpret_cast<const volatile unsigned long long*>(ctx->pinnedTiles) >> 32) != (uint32_t)ctx->frame) {}
-		const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-		static double sum = 0, worst = 0; static int n = 0;
-		sum += us; worst = us > worst ? us : worst;
-		if (++n % 200 == 0) { fprintf(stderr, " [cull latency after enqueue: avg %.1f us, max %.1f us]", sum / n, worst); sum = 0; worst = 0; n = 0; }
-	}
-#endif
-	const uint32_t chain = d->chains ? (uint32_t)(ctx->frame % d->numChains) : 0u;
-	if (d->chains)
-	{
-		// Whole frames on three view streams.  The ORDER OF THE CALLS is chosen for the two things the host reads from pinned memory
-		// without waiting: the size of frame k - 1's cube-face all-gather (its cull's report: the later the host asks, the surer it is
-		// there) and this frame's tile count (an exact grid for the view march, no overflow launch behind it).  So: this frame's light
-		// march and its exchange first (stream k % 3), then frame k - 1's tail (stream (k - 1) % 3), this frame's view march last.  The
-		// streams are independent, so the order costs the GPU nothing.
-		{ MV_SECTION(5); if ((rc = distLight(ctx, chain)) != MV_OK) return rc; }
-		// ---- frame k - 1's cube-face exchange, on ITS stream behind its view march; then k - 1's composite and row gather; then the
-		// copy-forward of the faces frame k does not march, which reads k - 1's set on that same stream, i.e. behind the unpack ----
-		{ MV_SECTION(2); if ((rc = distTailExchange(ctx)) != MV_OK) return rc; }
-		{ MV_SECTION(4); if ((rc = distTailComposite(ctx)) != MV_OK) return rc; }
-		// (the copy-forward behind the composite: the composite has already made this stream wait for frame k - 1's copy, which this
-		// one builds on, and nothing needs frame k's copy before frame k's own composite, a call from now)
-		{ MV_SECTION(3); if ((rc = viewCopyForward(ctx)) != MV_OK) return rc; }
-		{ MV_SECTION(6); if ((rc = viewMarch(ctx)) != MV_OK) return rc; }
-	}
-	else
-	{
-		if ((rc = distLight(ctx, chain)) != MV_OK) return rc;
-		if ((rc = mv_march_view(ctx)) != MV_OK) return rc;
-		// ---- frame k - 1: exchange + composite, on stream X beside this frame's march ----
-		if ((rc = distTail(ctx)) != MV_OK) return rc;
-		// ---- frame k's unmarched cube faces <- frame k - 1's set, now complete on this rank (stream X is in order); frame k + 1's march waits for it ----
-		MV_HIP(ctx, evWait(ctx, d->streamX, ctx->evStageA[ctx->slot]));
-		if ((rc = copyForward(ctx, d->streamX)) != MV_OK) return rc;
-	}
-	{ MV_SECTION(7); d->stPending = ctx->st; d->slotPending = ctx->slot; d->chainPending = chain; d->pendingComposite = with_composite != 0; d->pending = true; }
-	return MV_OK;
-}
-
-int mv_dist_flush(mv_ctx* ctx)
-{
-	if (!ctx) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
-	return distTail(ctx);
-}
-
-// One all-gather (separate buffers), one in-place all-gather and one all-reduce on each communicator, checked on the host: run once
-// after mv_dist_init_* so that a broken transport fails before any frame does.
-int mv_dist_selftest(mv_ctx* ctx)
-{
-	if (!ctx) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
-	DistState* d = ctx->dist;
-	const uint32_t world = ctx->st.shardCount, rank = ctx->st.shardIndex;
-	const size_t n = 4096;	// bytes per rank
-	MV_REQUIRE(ctx, d->sendCap >= n && d->maxBandBytes >= n, MV_ERR_RANGE, "self-test buffers");
-	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	std::vector<uint8_t> h(n * world), g(n * world);
-	for (int which = 0; which < (int)d->numComm; ++which)
-	{
-		// the stream the frame loop uses this communicator on, and the buffers it uses there
-		hipStream_t s = d->chains ? ctx->streamB[which] : which == 0 ? d->streamX : ctx->stream;
-		const uint32_t c = d->chains ? (uint32_t)which : 0u;
-		// all-gather, separate buffers
-		for (size_t i = 0; i < n; ++i) h[i] = (uint8_t)(rank * 31u + i * 7u + which);
-		MV_HIP(ctx, hipMemcpyAsync(d->sendBuf[c], h.data(), n, hipMemcpyHostToDevice, s));
-		int rc = distAllGather(ctx, d->sendBuf[c], d->recvBuf[c], n, s, which);
-		if (rc != MV_OK) return rc;
-		MV_HIP(ctx, hipMemcpyAsync(g.data(), d->recvBuf[c], n * world, hipMemcpyDeviceToHost, s));
-		MV_HIP(ctx, hipStreamSynchronize(s));
-		for (uint32_t r = 0; r < world; ++r)
-			for (size_t i = 0; i < n; ++i)
-				MV_REQUIRE(ctx, g[r * n + i] == (uint8_t)(r * 31u + i * 7u + which), MV_ERR_HIP, "all-gather self-test: wrong bytes");
-		// in place (the row-band gather of equal bands): sendbuff == recvbuff + rank * count
-		if (d->inPlaceGather)
-		{
-			MV_HIP(ctx, hipMemsetAsync(d->rowRecv[c], 0, n * world, s));
-			MV_HIP(ctx, hipMemcpyAsync(d->rowRecv[c] + (size_t)rank * n, h.data(), n, hipMemcpyHostToDevice, s));
-			rc = distAllGather(ctx, d->rowRecv[c] + (size_t)rank * n, d->rowRecv[c], n, s, which);
-			if (rc != MV_OK) return rc;
-			MV_HIP(ctx, hipMemcpyAsync(g.data(), d->rowRecv[c], n * world, hipMemcpyDeviceToHost, s));
-			MV_HIP(ctx, hipStreamSynchronize(s));
-			for (uint32_t r = 0; r < world; ++r)
-				for (size_t i = 0; i < n; ++i)
-					MV_REQUIRE(ctx, g[r * n + i] == (uint8_t)(r * 31u + i * 7u + which), MV_ERR_HIP, "in-place all-gather self-test: wrong bytes");
-		}
-		// all-reduce (integer sum; only one rank contributes non-zero words, like the light-map exchange)
-		std::vector<uint32_t> w(256, 0u);
-		if (rank == world - 1u) for (uint32_t i = 0; i < 256; ++i) w[i] = 0x9e3779b9u * (i + 1u) + which;
-		MV_HIP(ctx, hipMemcpyAsync(d->lightWords[c], w.data(), 1024, hipMemcpyHostToDevice, s));
-		rc = distAllReduceU32(ctx, d->lightWords[c], 256, s, which);
-		if (rc != MV_OK) return rc;
-		MV_HIP(ctx, hipMemcpyAsync(w.data(), d->lightWords[c], 1024, hipMemcpyDeviceToHost, s));
-		MV_HIP(ctx, hipStreamSynchronize(s));
-		for (uint32_t i = 0; i < 256; ++i) MV_REQUIRE(ctx, w[i] == 0x9e3779b9u * (i + 1u) + which, MV_ERR_HIP, "all-reduce self-test: wrong words");
-	}
-	return MV_OK;
-}
-
-int mv_dist_info(mv_ctx* ctx, uint32_t* transport, uint32_t* ranks, uint32_t* communicators)
-{
-	if (!ctx || !transport || !ranks || !communicators) return MV_ERR_INVALID_ARG;
-	*transport = 0; *ranks = 0; *communicators = 0;
-	const DistState* d = ctx->dist;
-	if (!d) return MV_OK;
-	*transport = (uint32_t)d->transport; *communicators = d->numComm;
-	*ranks = ctx->st.shardCount;
-	if (d->transport == 1)
-	{
-		// what RCCL itself says about the communicator (ncclCommCount), not what the context was told
-		auto commCount = reinterpret_cast<decltype(&ncclCommCount)>(dlsym(d->rcclLib, "ncclCommCount"));
-		int n = 0;
-		MV_REQUIRE(ctx, commCount && commCount(d->comm[0], &n) == ncclSuccess, MV_ERR_HIP, "ncclCommCount failed");
-		*ranks = (uint32_t)n;
-	}
-	return MV_OK;
-}
-
-int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset)
-{
-	if (!ctx || !bytes) return MV_ERR_INVALID_ARG;
-	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
-	*bytes = ctx->dist->bytes;
-	if (reset) ctx->dist->bytes = 0;
 	return MV_OK;
 }
 

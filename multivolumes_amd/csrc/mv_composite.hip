@@ -294,12 +294,14 @@ constexpr uint32_t kLayerNeedsMarch = 0xffff0000u;	// in .y: alpha = an fp16 NaN
 // MARCH = false: the launch over every 8x8 tile of the row range.  It leaves out the inline RayCast march (which alone costs the
 // kernel half of its wavefronts per SIMD): a tile in which some surviving layer needs that march is appended to `retry`
 // ({count, finished workgroups, tile ...}) and written by the MARCH = true launch behind it, which walks that list.
-template <bool MARCH>
+// PEER: the peer-store transport's instantiation (rows into every rank's frame buffer, folded flags); the others are untouched by it
+template <bool MARCH, bool PEER = false>
 __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background,
 	uint32_t* __restrict__ retry)
 {
 	const uint32_t lane = threadIdx.x;
 	const uint32_t tilesX = (st.W + 7u) >> 3;
+	if constexpr (PEER) peerFoldWait(st);	// (peer-store transport, folded flags: every rank's cube faces of this frame have landed in this rank's set)
 	const uint32_t nRetry = MARCH ? retry[0] : 0u;
 	for (uint32_t item = blockIdx.x; !MARCH || item < nRetry; item += gridDim.x)
 	{
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 			o.x = (uint32_t)float_to_half_bits(result.x) | ((uint32_t)float_to_half_bits(result.y) << 16);
 			o.y = (uint32_t)float_to_half_bits(result.z) | ((uint32_t)float_to_half_bits(result.w) << 16);
 			st.composite[(size_t)(storeY0 + (lane >> 3)) * st.W + px] = o;
+			if constexpr (PEER) storeToPeers(st, st.peerComposite, (size_t)(storeY0 + (lane >> 3)) * st.W + px, o);	// (peer-store transport: this rank's rows into every rank's frame buffer)
 		}
 	}
 
@@ -469,18 +472,28 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 		__threadfence();
 		if (atomicAdd(retry + 1, 1u) == gridDim.x - 1u) { retry[0] = 0u; retry[1] = 0u; }
 	}
+	if constexpr (PEER) peerFoldSignal(st);	// (the last workgroup: "this rank's rows have landed everywhere", "this rank is done with the frame")
 }
 
-void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background)
+uint32_t launchComposite(hipStream_t s, const DeviceState& stIn, uint32_t row0, uint32_t row1, const void* background)
 {
+	DeviceState st = stIn;
 	const bool interleaved = st.flags & kFlagInterleaveRows;	// (row0 / row1 unused: the rank's own tile rows)
 	const uint32_t tilesX = (st.W + 7u) >> 3, T = (st.H + 7u) >> 3;
 	const uint32_t tilesY = interleaved ? (st.shardIndex < T ? (T - st.shardIndex + st.shardCount - 1u) / st.shardCount : 0u) : (row1 - row0 + 7u) >> 3;
-	if (!tilesY) return;
-	hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	if (!tilesY) return 0u;
 	// The inline march can only be asked for by a screen-space volume without a slot, by rows outside this context's band (what the
 	// view march's screen tiles cover) or by a frame without a view march: when none of them can happen the second launch is left out.
-	if (st.screenSlots < st.V || (!interleaved && (row0 < st.bandRow0 || row1 > st.bandRow1)) || (st.flags & kFlagNoScreenLayers))
-		hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	const bool second = st.screenSlots < st.V || (!interleaved && (row0 < st.bandRow0 || row1 > st.bandRow1)) || (st.flags & kFlagNoScreenLayers);
+	// (peer-store transport, folded flags: the first launch waits, the last one raises)
+	const uint32_t nSignal = st.fold.nSignal;
+	if (second) st.fold.nSignal = 0u;
+	if (st.peerCount) hipLaunchKernelGGL((compositeKernel<false, true>), dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	else hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	if (!second) return 1u;
+	st.fold.nSignal = nSignal; st.fold.nWait = 0u;
+	if (st.peerCount) hipLaunchKernelGGL((compositeKernel<true, true>), dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	else hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	return 2u;
 }
 } // namespace mv

@@ -901,6 +901,7 @@ __host__ __device__ inline LightShare lightShare(const DeviceState& st, uint32_t
 
 // quad-replicated store of one light-map texel (see mv_device.hpp "light maps"): texel (x, y) is slot (sx, sy) of every cell (cx, cy)
 // with min(cx + sx, L-1) == x and min(cy + sy, L-1) == y
+template <bool PEER = false>
 __device__ __forceinline__ void storeLightTexel(uint32_t* quads, uint32_t L, uint32_t xx, uint32_t yy, uint32_t zz, uint32_t packed)
 {
 	const uint32_t cxs[3] = { xx, xx - 1u, xx }, sxs[3] = { 0u, 1u, 1u };
@@ -912,14 +913,33 @@ __device__ __forceinline__ void storeLightTexel(uint32_t* quads, uint32_t L, uin
 #pragma unroll
 		for (int a = 0; a < 3; ++a)
 			if (vx[a] && vy[b])
-				quads[((((size_t)zz * L + cys[b]) * L + cxs[a]) << 2) + sxs[a] + 2u * sxs[b]] = packed;
+			{
+				uint32_t* word = quads + (((((size_t)zz * L + cys[b]) * L + cxs[a]) << 2) + sxs[a] + 2u * sxs[b]);
+				if (PEER) peerStore(word, packed);	// another rank's copy (mv_kernels.hpp: written through at system scope)
+				else *word = packed;
+			}
 }
 
 // wordsOut: NULL, or where this context's share of the map goes as plain words, 64 per block in dispatch order from entry `lo` on
-template <bool LUT, bool ORDERED, int K>
+template <bool LUT, bool ORDERED, int K, bool PEER>
+__device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* __restrict__ wordsOut, u32x4* sAxis, unsigned long long (*sCand)[(1024u + 63u) / 64u]);
+
+// PEER: the peer-store transport's instantiation (stores into every rank's map, folded flags); the others are untouched by it
+template <bool LUT, bool ORDERED, int K, bool PEER = false>
 __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st, uint32_t* __restrict__ wordsOut)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLightLutMaxN + 1) : 1];
+	__shared__ unsigned long long sCand[kLightWaves][(1024u + 63u) / 64u];	// (MV_LIGHT_CANDIDATES: volumes beyond the first 64; MV_MAX_VOLUMES = 1024)
+	// (peer-store transport, folded flags: wait until every rank is done with the frames that read what this launch overwrites; the
+	// last workgroup raises "this rank's share has landed everywhere" -- mv_kernels.hpp peerFoldWait / peerFoldSignal)
+	if constexpr (PEER) peerFoldWait(st);
+	marchLightBody<LUT, ORDERED, K, PEER>(st, wordsOut, sAxis, sCand);
+	if constexpr (PEER) peerFoldSignal(st);
+}
+
+template <bool LUT, bool ORDERED, int K, bool PEER>
+__device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* __restrict__ wordsOut, u32x4* sAxis, unsigned long long (*sCand)[(1024u + 63u) / 64u])
+{
 	const PerObject* perObjects = reinterpret_cast<const PerObject*>(st.perObject);
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 
@@ -980,7 +1000,6 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 	// decides for the whole wavefront which volumes a light ray of the block can touch at all.  A clear bit means that every voxel's
 	// ComputeRayOrigin (RayMarch.hlsli:128-155) would return false: the loop below then `continue`s exactly as the reference does
 	// (which also skips that volume's AO ray, CSRayMarchL.hlsl:95).  Results are unchanged by construction; the per-voxel tests stay.
-	__shared__ unsigned long long sCand[kLightWaves][(1024u + 63u) / 64u];	// (volumes beyond the first 64: MV_MAX_VOLUMES = 1024)
 	unsigned long long cand0 = ~0ull;
 	if (MV_LIGHT_CANDIDATES)
 	{
@@ -1104,6 +1123,15 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 		const vec3 result = v3(shadow * lightColor.x + ambient.x, shadow * lightColor.y + ambient.y, shadow * lightColor.z + ambient.z);
 		packed = pack_r11g11b10f(result.x, result.y, result.z);
 		storeLightTexel(reinterpret_cast<uint32_t*>(st.lightTable[volumeId]), L, xx, yy, zz, packed);
+		if constexpr (PEER)
+		{
+			// peer-store transport: this rank's share goes straight into every rank's copy of the relit map (same layout everywhere:
+			// the map's offset inside lightBuffers), no words, no all-gather, no unpack
+			const size_t mapOff = reinterpret_cast<const uint8_t*>(st.lightTable[volumeId]) - reinterpret_cast<const uint8_t*>(st.lightBuffers);
+			for (uint32_t p = 0; p < st.peerCount; ++p)
+				if (p != st.shardIndex)
+					storeLightTexel<true>(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(st.peerLight[p]) + mapOff), L, xx, yy, zz, packed);
+		}
 	}
 	if (wordsOut) wordsOut[(size_t)(e - share.lo) * 64u + lane] = packed;
 
@@ -1499,20 +1527,27 @@ uint32_t lightSharePerRank(const DeviceState& st)
 	return lightShare(st, b * b * b).per;
 }
 
-template <int K>
-static void launchMarchLightK(hipStream_t s, const DeviceState& st, uint32_t* wordsOut, uint32_t count)
+template <int K, bool PEER>
+static void launchMarchLightKP(hipStream_t s, const DeviceState& st, uint32_t* wordsOut, uint32_t count)
 {
 	if (lightOrdered(st))
 	{
 		const uint32_t perXcd = (count + 7u) >> 3;
 		const uint32_t groups = 8u * ((perXcd + kLightWaves - 1u) / kLightWaves);
-		if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, true, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
-		else hipLaunchKernelGGL((marchLightKernel<false, true, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+		if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, true, K, PEER>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+		else hipLaunchKernelGGL((marchLightKernel<false, true, K, PEER>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
 		return;
 	}
 	const uint32_t groups = (count + kLightWaves - 1u) / kLightWaves;
-	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, false, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
-	else hipLaunchKernelGGL((marchLightKernel<false, false, K>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+	if (MV_LIGHT_LUT && st.N <= kLightLutMaxN) hipLaunchKernelGGL((marchLightKernel<true, false, K, PEER>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+	else hipLaunchKernelGGL((marchLightKernel<false, false, K, PEER>), dim3(groups), dim3(64 * kLightWaves), 0, s, st, wordsOut);
+}
+
+template <int K>
+static void launchMarchLightK(hipStream_t s, const DeviceState& st, uint32_t* wordsOut, uint32_t count)
+{
+	if (st.peerCount) launchMarchLightKP<K, true>(s, st, wordsOut, count);	// (peer-store transport)
+	else launchMarchLightKP<K, false>(s, st, wordsOut, count);
 }
 
 #ifndef MV_LIGHT_SPECULATE_BELOW

@@ -144,7 +144,136 @@ struct DeviceState
 	// ray queue of the view march (per output set: two frames may be between setup and march at the same time)
 	RayRecord* rayRecords;			// (maxTiles + maxScreenTiles) x 64, in dispatch order: slot s holds the rays of tile tileOrder[s]
 	TileInfo* tileInfo;				// maxTiles + maxScreenTiles
+	// Peer-store transport of the multi-GPU frame loop (mv_dist_init_peer; mv_peer.hip): every rank maps every rank's light maps, cube
+	// maps / depths and frame buffers (xGMI peer mappings: IPC handles between processes), and the kernels that PRODUCE them store
+	// into all of them -- no pack, no collective, no unpack.  peerCount = 0 outside that transport (the stores below cost one scalar
+	// compare); else shardCount, and entry [shardIndex] of every table is this context's own buffer.
+	uint32_t peerCount;
+	uint4* const* peerLight;		// [peerCount] every rank's lightBuffers (same layout everywhere: an address here + the offset of a map inside lightBuffers)
+	uint2* const* peerCubeMaps;		// [peerCount] every rank's cube maps of THIS frame's output set
+	float* const* peerCubeDepths;	// [peerCount]
+	uint2* const* peerComposite;	// [peerCount] every rank's frame buffer of this output set
+	// ...and the flags that order those stores, folded into the producing / consuming kernels themselves (mv_peer.hip explains the
+	// protocol and has the same two steps as a kernel of their own): a launch may WAIT, in every workgroup's prologue, until rows of this
+	// rank's flag block have reached a frame in every column, and RAISE, from the last workgroup to finish, its column of rows in every
+	// rank's block.  nWait = nSignal = 0: neither (every launch outside the folded peer-store loop).
+	struct PeerFold
+	{
+		unsigned long long* const* flagBlocks;	// [peerCount] every rank's flag block
+		unsigned long long* myFlags;
+		uint32_t* counter;						// workgroups of this launch that have finished (zero between launches)
+		unsigned long long* report;				// pinned: [2] = a wait that gave up
+		unsigned long long timeoutTicks;
+		uint32_t nWait, nSignal, loopback, frameTag;
+		uint32_t checkChain, checkCompare;		// checkChain: 0xffffffff, or the chain whose slot of cull words this launch raises with (a producer) or, checkCompare != 0, compares every rank's behind its wait (a consumer) -- mv_peer.hip
+		uint32_t waitRow[6], signalRow[2];
+		unsigned long long waitValue[6], signalValue[2];
+	} fold;
 };
+// Stores into a peer's memory: relaxed atomic stores at SYSTEM scope (global_store ... sc0 sc1: written through to the memory that owns
+// the address, nothing left dirty in this GPU's L2), so that the release in front of the flag that announces them (mv_peer.hip) has
+// nothing to write back.
+#ifdef MV_PEER_PLAIN_STORES	// (A/B timing only: what the stores would cost as plain ones -- NOT a valid build for a node: plain stores stay dirty in this GPU's L2)
+__device__ __forceinline__ void peerStore(uint32_t* p, uint32_t v) { *p = v; }
+__device__ __forceinline__ void peerStore(float* p, float v) { *p = v; }
+__device__ __forceinline__ void peerStore(uint2* p, uint2 v) { *p = v; }
+#else
+__device__ __forceinline__ void peerStore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void peerStore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void peerStore(uint2* p, uint2 v)
+{
+	__hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#endif
+// Every rank owns a block of flags that the OTHER ranks write and only it reads: row r, column p = "rank p has finished stage r.stage of
+// frame <value>", rows = stage x chain (frames k with k % chains == chain follow each other on one stream, so a row only ever grows).
+constexpr uint32_t kPeerMaxRanks = 64;		// ranks of one peer-store group (one node: 8); columns of a flag row
+constexpr uint32_t kPeerStages = 4;			// 0 light share landed, 1 cube faces landed, 2 rows landed, 3 frame done (its buffers may be overwritten)
+constexpr uint32_t kPeerMaxChains = 5;
+constexpr uint32_t kPeerRows = kPeerStages * kPeerMaxChains + 1u;	// + the self-test's row
+constexpr uint32_t kPeerCheckWords = 4;		// what a rank's cull decided for a frame (compared by the light stage's wait)
+constexpr size_t kPeerFlagWords = (size_t)kPeerRows * kPeerMaxRanks;	// uint64 each; behind them kPeerMaxChains x kPeerMaxRanks x kPeerCheckWords uint32
+constexpr size_t kPeerFlagBytes = kPeerFlagWords * 8u + (size_t)kPeerMaxChains * kPeerMaxRanks * kPeerCheckWords * 4u;
+
+// Prologue of a consumer (every thread of the workgroup calls it, before any early exit): the first wavefront polls, the workgroup waits for it.
+// No cache maintenance here, on purpose: thousands of workgroups each invalidating or writing back an L2 cost a launch three times its
+// length (measured, profiles/r04_peer_fold.txt).  The polls are system-scope loads (sc0 sc1: they bypass this GPU's caches); the data
+// they announce was written through, by kernels of other GPUs, into THIS GPU's memory, whose L2 the fabric keeps coherent with such
+// writes (the same property every collective library's "peer writes, local kernel reads" path rests on); the workgroup's own loads of
+// it are issued behind the barrier below, i.e. behind the poll that saw the flag, and this launch has not read those addresses before
+// (every buffer a frame's peers write was last read C frames ago: the output sets and light buffers rotate).
+__device__ __forceinline__ void peerFoldWait(const DeviceState& st)
+{
+	if (!st.fold.nWait) return;
+	if (threadIdx.x < 64u)
+	{
+		const uint32_t total = st.fold.nWait * st.peerCount;
+		const unsigned long long t0 = wall_clock64();
+		for (uint32_t i = threadIdx.x; i < total; i += 64u)
+		{
+			const uint32_t r = i / st.peerCount, p = i - r * st.peerCount;
+			const unsigned long long* flag = st.fold.myFlags + (size_t)st.fold.waitRow[r] * kPeerMaxRanks + p;
+			while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < st.fold.waitValue[r])
+			{
+				if (wall_clock64() - t0 > st.fold.timeoutTicks)
+				{
+					__hip_atomic_store(st.fold.report + 2, ((unsigned long long)st.fold.frameTag << 32) | ((unsigned long long)st.fold.waitRow[r] << 8) | p | 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					break;
+				}
+				__builtin_amdgcn_s_sleep(8);
+			}
+		}
+	}
+	__syncthreads();
+	if (st.fold.checkCompare && st.fold.checkChain != 0xffffffffu && blockIdx.x == 0u && threadIdx.x < 64u)
+	{
+		// every rank's cull must have decided the same for this frame (peerSyncKernel makes the same comparison)
+		const uint32_t* all = reinterpret_cast<const uint32_t*>(st.fold.myFlags + kPeerFlagWords) + (size_t)st.fold.checkChain * kPeerMaxRanks * kPeerCheckWords;
+		const uint32_t mine[4] = { st.fold.frameTag, st.counters[12], st.counters[0], st.counters[1] };
+		bool differs = false;
+		for (uint32_t p = threadIdx.x; p < st.peerCount; p += 64u)
+			for (uint32_t w = 0; w < kPeerCheckWords; ++w)
+				differs |= __hip_atomic_load(all + (size_t)p * kPeerCheckWords + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != mine[w];
+		if (differs) __hip_atomic_store(st.fold.report + 1, ((unsigned long long)st.fold.frameTag << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+// Epilogue of a producer (every thread of the workgroup calls it, after a body that RETURNS instead of exiting): the last workgroup of
+// the launch raises the flags, behind every workgroup's stores.  Again without cache maintenance: the stores into the other ranks'
+// memory are written through at system scope (peerStore), so "complete" is each wavefront's s_waitcnt vmcnt(0) -- the acknowledgement
+// of a write-through store comes from the memory that owns the address.  Every workgroup counts itself in AFTER that wait; the one
+// that counts last knows every store of the launch has been acknowledged, and only then issues the flag stores.
+__device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
+{
+	if (!st.fold.nSignal) return;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wavefront's stores, into every rank's memory, have been acknowledged
+	__syncthreads();
+	if (threadIdx.x != 0u) return;
+	const uint32_t finished = __hip_atomic_fetch_add(st.fold.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (finished != gridDim.x - 1u) return;
+	__hip_atomic_store(st.fold.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (the next launch that uses it is behind this one on its stream)
+	for (uint32_t p = 0; p < st.peerCount; ++p)
+	{
+		unsigned long long* block = st.fold.loopback ? st.fold.myFlags : st.fold.flagBlocks[p];	// loopback: a rank measured alone raises every column of its own block
+		const uint32_t column = st.fold.loopback ? p : st.shardIndex;
+		if (!st.fold.checkCompare && st.fold.checkChain != 0xffffffffu)
+		{
+			uint32_t* words = reinterpret_cast<uint32_t*>(block + kPeerFlagWords) + ((size_t)st.fold.checkChain * kPeerMaxRanks + column) * kPeerCheckWords;
+			peerStore(words + 0, st.fold.frameTag); peerStore(words + 1, st.counters[12]); peerStore(words + 2, st.counters[0]); peerStore(words + 3, st.counters[1]);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// the words are there before the flag that announces them
+		}
+		for (uint32_t i = 0; i < st.fold.nSignal; ++i)
+			__hip_atomic_store(block + (size_t)st.fold.signalRow[i] * kPeerMaxRanks + column, st.fold.signalValue[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+// the same element of every OTHER rank's buffer (the caller stores its own copy as before)
+template <typename T>
+__device__ __forceinline__ void storeToPeers(const DeviceState& st, T* const* table, size_t index, T v)
+{
+	for (uint32_t p = 0; p < st.peerCount; ++p)
+		if (p != st.shardIndex) peerStore(table[p] + index, v);
+}
 
 // Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
 // their position among this frame's screen tiles.  A key that names another tile after a mip / visibility change only
@@ -268,15 +397,34 @@ uint32_t lightSharePerRank(const DeviceState& st);	// voxel blocks per rank of t
 void launchLightUnpack(hipStream_t s, const DeviceState& st, const uint32_t* words);	// the all-gathered shares (64 words per block, lightSharePerRank blocks per rank) into the relit volume's light map
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// returns the first slot its grid does not cover (0xffffffff: none)
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
-uint32_t marchTilesResidentWaves(int device);
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
 uint32_t marchViewResidentWaves(int device, bool wideAddressing);	// wavefronts of the march kernel the device holds at once (occupancy query)
 void launchReduceStats(hipStream_t s, const DeviceState& st, int includeLight);
 uint32_t marchViewMaxTiles(uint32_t V, uint32_t N, uint32_t shardCount);
-void launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background = nullptr);	// background: W x H RGBA16F (device) or NULL
+uint32_t launchComposite(hipStream_t s, const DeviceState& st, uint32_t row0, uint32_t row1, const void* background = nullptr);	// background: W x H RGBA16F (device) or NULL; returns the kernels launched (0: this context owns no rows)
 void launchExchangePack(hipStream_t s, const DeviceState& st, uint32_t slotDim, void* dst);
 void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim, const void* src);
 void launchExchangeCompact(hipStream_t s, const DeviceState& st, bool pack, void* buf, size_t shardBytes);	// marched faces only (mv_dist_frame)
 void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag, bool marchFollows = true);
+
+// ---- peer-store transport (mv_peer.hip) ----
+struct PeerSync
+{
+	unsigned long long* const* peerFlags;	// [world] every rank's flag block (device table)
+	unsigned long long* myFlags;			// this rank's
+	uint32_t world, self, loopback;			// loopback: a rank measured alone -- it signals every column of its own block
+	uint32_t nSignal, signalRow[2];			// rows to raise to signalValue in every rank's block (after everything before this kernel on its stream)
+	unsigned long long signalValue[2];
+	uint32_t nWait, waitRow[8];				// rows of this rank's block that must reach waitValue in every column
+	unsigned long long waitValue[8];
+	uint32_t checkChain;					// 0xffffffff, or: signal with this rank's cull words of the frame, and compare every rank's after the wait
+	const uint32_t* counters;				// the frame's cull counters (device)
+	uint32_t frameTag;
+	unsigned long long timeoutTicks;		// wall_clock64 ticks (100 MHz) a wait may last
+	unsigned long long* report;				// pinned: [1] = {frameTag : 1} the ranks' culls disagree, [2] = {frameTag : row << 8 | column} a wait timed out
+};
+void launchPeerSync(hipStream_t s, const PeerSync& a);
+void launchPeerPattern(hipStream_t s, uint2* const* table, uint32_t world, uint32_t self, size_t wordsPerRank, uint32_t salt);	// self-test: a pattern into every rank's buffer at this rank's region
+void launchPeerVerify(hipStream_t s, const uint2* mine, uint32_t world, size_t wordsPerRank, uint32_t salt, uint32_t* mismatches);
 } // namespace mv

@@ -144,8 +144,47 @@ def stored_tile_row(t, H, world):
     return (t % world) * per_rank + t // world
 
 
-def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True):
+def init_peer_transport(caster, timeout_ms=None, fold=None):
+    """The peer-store transport (include/multivolumes.h): every rank exports IPC handles of its light maps, cube maps and frame buffers,
+    torch.distributed only gathers the blobs (any backend), every rank maps the others and the kernels store into all of them.
+    Every step is collective and unconditional; a vote after init + self-test decides for all ranks.  Returns True if it is attached."""
+    import sys
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    err = None
+    blob = bytes(_lib.MV_DIST_PEER_BYTES + 1)
+    try:
+        blob = caster.DistPeerExport() + b"\x01"
+    except Exception as e:  # (e.g. a context without whole-frame chains)
+        err = e
+    mine = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    gathered = torch.empty(world * len(blob), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(gathered, mine)
+    host = gathered.cpu().numpy().reshape(world, len(blob))
+    ok = 1 if (err is None and bool((host[:, -1] == 1).all())) else 0
+    if ok:
+        try:
+            caster.DistInitPeer(host[:, :-1].tobytes(), fold=fold)
+            if timeout_ms is not None:
+                caster.DistSetPeerTimeoutMs(timeout_ms)
+            caster.DistSelfTest()  # patterns through every mapping and every flag, verified on every rank, twice
+        except Exception as e:
+            err, ok = e, 0
+    vote = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+    if int(vote.item()) == 1:
+        return True
+    print(f"[rank {rank}] peer-store transport unavailable ({err if err is not None else 'another rank failed'})", file=sys.stderr)
+    caster.DistShutdown()
+    return False
+
+
+def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True, prefer_peer=False, peer_timeout_ms=None, peer_fold=None):
     """Attach the in-library multi-GPU frame loop (mv_dist_frame) to a sharded caster.
+
+    prefer_peer: try the peer-store transport first (whole-frame-chain contexts on one node; returns "peer").
 
     With the NCCL (= RCCL) backend the library opens RCCL itself and creates its own communicators (three: one per frame chain) from ids that rank 0 makes and
     torch.distributed only broadcasts: no Python and no torch call inside the frame loop.  Otherwise (gloo: CPU-side tests, or RCCL
@@ -155,6 +194,8 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()
+    if prefer_peer and init_peer_transport(caster, peer_timeout_ms, peer_fold):
+        return "peer"
     if prefer_rccl and backend == "nccl":
         # Every step below is unconditional and collective, whatever failed locally: a rank never leaves the others waiting in a
         # collective it skips.  (1) rank 0 makes the ids -- zeros and a flag if it cannot -- and ALWAYS broadcasts them;
@@ -190,9 +231,11 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True)
               "using torch.distributed callbacks", file=sys.stderr)
         caster.DistShutdown()
     # one group per communicator index the library uses (`which` = 0..2: include/multivolumes.h)
+    # (as many as the context has frames in flight -- mv_config.frames_in_flight up to 5 -- and never fewer than the two the single-view-stream schedule uses)
+    n_groups = max(3, int(getattr(caster, "framesInFlight", 3) or 3))
     groups = [group_main if group_main is not None else dist.new_group(list(range(world))),
-              group_light if group_light is not None else dist.new_group(list(range(world))),
-              dist.new_group(list(range(world)))]
+              group_light if group_light is not None else dist.new_group(list(range(world)))]
+    groups += [dist.new_group(list(range(world))) for _ in range(n_groups - 2)]
 
     def allgather(send, recv, nbytes, stream, which):
         try:

@@ -139,6 +139,7 @@ class MultiRayCaster:
         self.numVolumes, self.numVolumeSrcs = int(numVolumes), int(numVolumeSrcs)
         self.viewport = (int(viewport[0]), int(viewport[1]))
         self.shadowMapSize = int(shadowMapSize)
+        self.framesInFlight = int(framesInFlight) or 3
         cfg = mv_config(C.sizeof(mv_config), self.gridSize, self.lightGridSize, self.numVolumes, self.numVolumeSrcs,
                         self.viewport[0], self.viewport[1], self.shadowMapSize, int(device), int(flags),
                         C.c_void_p(stream) if stream else None, int(shard[0]), int(shard[1]), int(framesInFlight))
@@ -465,6 +466,26 @@ class MultiRayCaster:
                           _lib.DIST_ALLREDUCE_FN(lambda u, b, n, st, w: allreduce(b, n, st, w)))  # kept alive with the context
         self._check(self._lib.mv_dist_init_callbacks(self._ctx, self._dist_cbs[0], self._dist_cbs[1], None), "mv_dist_init_callbacks")
 
+    def DistPeerExport(self):
+        """This rank's handles for the peer-store transport (MV_DIST_PEER_BYTES): gather every rank's, rank order, hand them to DistInitPeer."""
+        buf = (C.c_uint8 * _lib.MV_DIST_PEER_BYTES)()
+        self._check(self._lib.mv_dist_peer_export(self._ctx, buf), "mv_dist_peer_export")
+        return bytes(buf)
+
+    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None):
+        """Attach the frame loop with the peer-store transport: every rank's kernels store into every rank's buffers (no collectives).
+        loopback: a rank measured alone (every peer is the context itself).  fold: True / False force the flags into / out of the
+        marches and the composite (None: the library decides -- folded when every rank owns its GPU)."""
+        flags = 0 if fold is None else (_lib.MV_DIST_PEER_FOLD if fold else _lib.MV_DIST_PEER_NO_FOLD)
+        if loopback:
+            self._check(self._lib.mv_dist_init_peer(self._ctx, None, _lib.MV_DIST_PEER_LOOPBACK | flags), "mv_dist_init_peer")
+            return
+        buf = (C.c_uint8 * len(all_blobs)).from_buffer_copy(all_blobs)
+        self._check(self._lib.mv_dist_init_peer(self._ctx, buf, flags), "mv_dist_init_peer")
+
+    def DistSetPeerTimeoutMs(self, ms):
+        self._check(self._lib.mv_dist_set_peer_timeout_ms(self._ctx, int(ms)), "mv_dist_set_peer_timeout_ms")
+
     def DistSetInPlaceGather(self, enabled=True):
         """Caller-supplied collectives: the all-gather accepts send == recv + rank * bytes (NCCL's in-place convention)."""
         self._check(self._lib.mv_dist_set_inplace_gather(self._ctx, 1 if enabled else 0), "mv_dist_set_inplace_gather")
@@ -491,10 +512,10 @@ class MultiRayCaster:
         self._check(self._lib.mv_dist_flush(self._ctx), "mv_dist_flush")
 
     def DistInfo(self):
-        """{"transport": "none" | "rccl" | "callbacks", "ranks": communicator size as RCCL reports it, "communicators": n}"""
+        """{"transport": "none" | "rccl" | "callbacks" | "peer", "ranks": communicator size as RCCL reports it, "communicators": n}"""
         t, r, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
         self._check(self._lib.mv_dist_info(self._ctx, C.byref(t), C.byref(r), C.byref(c)), "mv_dist_info")
-        return {"transport": ("none", "rccl", "callbacks")[t.value], "ranks": r.value, "communicators": c.value}
+        return {"transport": ("none", "rccl", "callbacks", "peer")[t.value], "ranks": r.value, "communicators": c.value}
 
     def DistExchangedBytes(self, reset=False):
         n = C.c_uint64()

@@ -1,5 +1,6 @@
 """Worker of tests/test_dist_frame_loop.py: one rank of a moving-camera sequence through the in-library multi-GPU frame loop
-(mv_dist_frame) with gloo collectives (ranks share cuda:0; RCCL refuses two ranks on one device).  Rank 0 saves the composites."""
+(mv_dist_frame) with gloo collectives (ranks share cuda:0; RCCL refuses two ranks on one device) -- or, MV_TEST_TRANSPORT=peer, with the
+peer-store transport (IPC mappings between the rank processes: works with every rank on one GPU).  Rank 0 saves the composites."""
 import os
 import sys
 
@@ -58,8 +59,13 @@ def main():
     flags = _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if mode == "single" else 0)
     with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world), device=device) as c:
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
-        kind = D.init_frame_loop(c)
-        assert kind == ("rccl" if rccl else "torch-callbacks"), kind
+        peer = os.environ.get("MV_TEST_TRANSPORT") == "peer"     # the peer-store transport: IPC mappings, works with every rank on one GPU
+        fold = {"1": True, "0": False}.get(os.environ.get("MV_TEST_PEER_FOLD"))  # (None: the library decides -- ranks sharing a GPU keep the flag kernels)
+        kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=120000, peer_fold=fold)
+        assert kind == ("peer" if peer else "rccl" if rccl else "torch-callbacks"), kind
+        if peer:
+            info = c.DistInfo()
+            assert info["transport"] == "peer" and info["ranks"] == world, info
         if rccl:
             info = c.DistInfo()
             assert info["transport"] == "rccl" and info["ranks"] == world and info["communicators"] == (2 if mode == "single" else 3), info
@@ -80,7 +86,9 @@ def main():
                     c.DistFrame(vp, fr["shadowVP"], e)
                     c.synchronize()  # (this test only: let the frame's light exchange, which carries the check, finish before the next call)
                 except Exception as ex:
-                    assert f == 6 and "disagree" in str(ex), (f, str(ex))
+                    # (collectives: the call after the divergent frame, before it sizes that frame's all-gather; peer stores: already the
+                    # divergent frame's own synchronize -- the light stage's wait has compared the ranks' cull words by then)
+                    assert f in ((5, 6) if peer else (6,)) and "disagree" in str(ex), (f, str(ex))
                     print(f"rank {rank}: divergence reported at frame {f}: {ex}", flush=True)
                     os._exit(0)  # nothing more can be exchanged; the ranks leave without a collective
                 assert f <= 5, "a frame after the divergent one went through"
