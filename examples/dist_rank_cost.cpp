@@ -25,7 +25,7 @@ int main(int argc, char** argv)
 	const bool c5 = argc > 5 && std::string(argv[5]) == "C5";	// BASELINE config C5: 64 volumes, 2048^2, 256 steps (default C3)
 	const uint32_t N = 256, L = 96, V = c5 ? 64 : 16, W = c5 ? 2048 : 1024, H = W, M = 1024;
 	const bool peer = argc > 6 && std::string(argv[6]).rfind("peer", 0) == 0;
-	const bool noFold = argc > 6 && std::string(argv[6]) == "peer-nofold";	// the flags as kernels of their own (what ranks that share a GPU run) instead of inside the marches and the composite
+	const bool noFold = argc > 6 && std::string(argv[6]) == "peer-nofold";
 	const bool withComposite = !std::getenv("RANK_COST_NO_COMPOSITE");	// (experiment: a frame without its composite + row gather)
 	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
 	const unsigned worlds = argc > 2 ? (unsigned)std::atoi(argv[2]) : 15u;

@@ -725,10 +725,10 @@ int mvi::viewMarch(mv_ctx* ctx)
 				tiles = exact ? count : count + count / 4u + 256u;
 			}
 		}
-		// (peer-store transport, folded flags: the main launch waits; the LAST launch raises -- the overflow launch if there is one)
+		// (peer-store transport: the main launch waits, the LAST launch raises "cube faces landed" -- the overflow launch if there is one)
+		const bool overflow = !exact && mv::marchTilesBeyond(ctx->st, tiles) != 0xffffffffu;
 		DeviceState stMain = ctx->st;
-		const bool foldSignal = stMain.fold.nSignal != 0u;
-		if (!exact) stMain.fold.nSignal = 0u;
+		if (overflow) stMain.fold.nSignal = 0u;
 		const uint32_t beyond = mv::launchMarchTiles(streamB(ctx), stMain, tiles);
 		// (an exact count is this frame's own: nothing can lie beyond the grid.  Otherwise the overflow launch follows on the same
 		// stream: on the high-priority stream A it would have to wait for this frame's light march and held up the next frame's cull --
@@ -739,7 +739,6 @@ int mvi::viewMarch(mv_ctx* ctx)
 			stOver.fold.nWait = 0u;
 			mv::launchMarchTilesOverflow(streamB(ctx), stOver, beyond);
 		}
-		else if (!exact && foldSignal && ctx->dist) ctx->dist->foldSignalMissing = true;
 	}
 	endStage(ctx, ev, streamB(ctx));
 	MV_HIP(ctx, hipGetLastError());

@@ -294,7 +294,7 @@ constexpr uint32_t kLayerNeedsMarch = 0xffff0000u;	// in .y: alpha = an fp16 NaN
 // MARCH = false: the launch over every 8x8 tile of the row range.  It leaves out the inline RayCast march (which alone costs the
 // kernel half of its wavefronts per SIMD): a tile in which some surviving layer needs that march is appended to `retry`
 // ({count, finished workgroups, tile ...}) and written by the MARCH = true launch behind it, which walks that list.
-// PEER: the peer-store transport's instantiation (rows into every rank's frame buffer, folded flags); the others are untouched by it
+// PEER: the peer-store transport's instantiation with a folded wait (mv_kernels.hpp peerFoldWait); the others are untouched by it
 template <bool MARCH, bool PEER = false>
 __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background,
 	uint32_t* __restrict__ retry)
@@ -451,7 +451,6 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 			o.x = (uint32_t)float_to_half_bits(result.x) | ((uint32_t)float_to_half_bits(result.y) << 16);
 			o.y = (uint32_t)float_to_half_bits(result.z) | ((uint32_t)float_to_half_bits(result.w) << 16);
 			st.composite[(size_t)(storeY0 + (lane >> 3)) * st.W + px] = o;
-			if constexpr (PEER) storeToPeers(st, st.peerComposite, (size_t)(storeY0 + (lane >> 3)) * st.W + px, o);	// (peer-store transport: this rank's rows into every rank's frame buffer)
 		}
 	}
 
@@ -472,7 +471,6 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 		__threadfence();
 		if (atomicAdd(retry + 1, 1u) == gridDim.x - 1u) { retry[0] = 0u; retry[1] = 0u; }
 	}
-	if constexpr (PEER) peerFoldSignal(st);	// (the last workgroup: "this rank's rows have landed everywhere", "this rank is done with the frame")
 }
 
 uint32_t launchComposite(hipStream_t s, const DeviceState& stIn, uint32_t row0, uint32_t row1, const void* background)
@@ -485,15 +483,11 @@ uint32_t launchComposite(hipStream_t s, const DeviceState& stIn, uint32_t row0, 
 	// The inline march can only be asked for by a screen-space volume without a slot, by rows outside this context's band (what the
 	// view march's screen tiles cover) or by a frame without a view march: when none of them can happen the second launch is left out.
 	const bool second = st.screenSlots < st.V || (!interleaved && (row0 < st.bandRow0 || row1 > st.bandRow1)) || (st.flags & kFlagNoScreenLayers);
-	// (peer-store transport, folded flags: the first launch waits, the last one raises)
-	const uint32_t nSignal = st.fold.nSignal;
-	if (second) st.fold.nSignal = 0u;
-	if (st.peerCount) hipLaunchKernelGGL((compositeKernel<false, true>), dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	// (peer-store transport, folded wait: the first launch waits)
+	if (st.fold.nWait) hipLaunchKernelGGL((compositeKernel<false, true>), dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 	else hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 	if (!second) return 1u;
-	st.fold.nSignal = nSignal; st.fold.nWait = 0u;
-	if (st.peerCount) hipLaunchKernelGGL((compositeKernel<true, true>), dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
-	else hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 	return 2u;
 }
 } // namespace mv

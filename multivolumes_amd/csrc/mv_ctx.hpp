@@ -142,9 +142,8 @@ struct DistState
 	uint64_t peerTimeoutTicks = 30ull * 100000000ull;	// 30 s of wall_clock64 (100 MHz)
 	uint32_t rowsStream[kDistChains] = {};		// per chain: the view stream its frames run on
 	uint64_t rowsWaitFrame[kDistChains] = {};	// per chain: the newest frame whose rows this rank has composited but not yet waited for from the others (0 = none): enqueued lazily, by whatever synchronises
-	bool peerFold = false;						// the flags are raised / waited for inside the producing / consuming kernels (mv_kernels.hpp peerFoldWait / peerFoldSignal) instead of by kernels of their own
-	bool foldSignalMissing = false;				// (set by viewMarch) the launch that was to raise the folded flag did not happen: the caller raises it with a kernel of its own
-	uint32_t* dPeerCounters = nullptr;			// finished-workgroup counters of the folded signals: [kind][chain]
+	bool peerFold = false;						// the waits are the consumers' own prologues (mv_kernels.hpp peerFoldWait) instead of one-wavefront kernels in front of them
+	uint32_t* dPeerCounters = nullptr;			// finished-workgroup counters of the push kernels: [kind][chain]
 	uint32_t* dPeerMismatch = nullptr;			// self-test counter
 	uint64_t peerSelfTests = 0;					// rounds of the self-test so far (its flag row counts in them; collective, so equal on every rank)
 };

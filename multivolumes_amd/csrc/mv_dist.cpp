@@ -160,6 +160,7 @@ static int distCommonInitBody(mv_ctx* ctx)
 	ctx->st.flags |= mv::kFlagBalanceOwners;	// the cube-map volumes of a frame are dealt to the ranks by estimated cost (replicated cull: the same deal everywhere)
 #endif
 	ctx->st.flags |= mv::kFlagRotateAllLightMaps;	// every rank rotates the relit volume's light buffer: the exchange fills it on the non-owners
+	if (d->transport == 3) ctx->st.flags |= mv::kFlagLightLayers;	// (peer stores: the light march shared out by layers of voxel blocks -- whole cells, contiguous, pushed as plain ranges)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
 }
@@ -172,7 +173,7 @@ static int distCommonInit(mv_ctx* ctx)
 	{
 		(void)syncAll(ctx);
 		distRelease(ctx);
-		ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows);
+		ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers);
 	}
 	return rc;
 }
@@ -281,7 +282,7 @@ int mv_dist_shutdown(mv_ctx* ctx)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	if (ctx->dist->streamX) MV_HIP(ctx, hipStreamSynchronize(ctx->dist->streamX));
 	distRelease(ctx);
-	ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows);
+	ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers);
 	return MV_OK;
 }
 
@@ -358,7 +359,7 @@ static void foldSignal(mv_ctx* ctx, DeviceState& st, int stage, uint64_t frame)
 	st.fold.signalRow[st.fold.nSignal] = (uint32_t)stage * mv::kPeerMaxChains + (uint32_t)(frame % ctx->dist->numChains);
 	st.fold.signalValue[st.fold.nSignal++] = frame;
 }
-static void foldClear(DeviceState& st) { st.fold.nWait = 0u; st.fold.nSignal = 0u; st.fold.checkChain = 0xffffffffu; st.fold.checkCompare = 0u; }
+static void foldClear(DeviceState& st) { st.fold.nWait = 0u; st.fold.nSignal = 0u; st.fold.checkChain = 0xffffffffu; st.fold.checkCompare = 0u; st.fold.stores = 0u; }
 
 // in front of a consumer on stream s: every rank's `stage` of frame `frame` has landed here
 static int peerWaitStage(mv_ctx* ctx, hipStream_t s, int stage, uint64_t frame, uint32_t frameTag, uint32_t slot)
@@ -392,70 +393,78 @@ static int peerCheckReports(mv_ctx* ctx)
 	return MV_OK;
 }
 
+// a wait of this rank's chain: as the consumer's own prologue (folded: the fields go into `st`, the next launch with them carries it) or
+// as a one-wavefront kernel in front of it
+struct PeerWaits { uint32_t n = 0; int stage[8]; uint64_t frame[8]; };
+static int peerWaitFor(mv_ctx* ctx, hipStream_t s, DeviceState& st, uint32_t kind, const PeerWaits& w, uint64_t frame, uint32_t frameTag, uint32_t slot, bool compareCulls)
+{
+	DistState* d = ctx->dist;
+	if (d->peerFold)
+	{
+		foldBase(ctx, st, kind, frame, frameTag, slot);
+		for (uint32_t i = 0; i < w.n && i < 6u; ++i) foldWait(ctx, st, w.stage[i], w.frame[i]);
+		if (compareCulls && d->cullCrosscheck) { st.fold.checkChain = (uint32_t)(frame % d->numChains); st.fold.checkCompare = 1u; }
+		return MV_OK;
+	}
+	if (!w.n) return MV_OK;
+	mv::PeerSync a = peerSyncBase(ctx, frameTag, slot);
+	for (uint32_t i = 0; i < w.n; ++i) { a.waitRow[a.nWait] = (uint32_t)w.stage[i] * mv::kPeerMaxChains + (uint32_t)(w.frame[i] % d->numChains); a.waitValue[a.nWait++] = w.frame[i]; }
+	if (compareCulls && d->cullCrosscheck) a.checkChain = (uint32_t)(frame % d->numChains);
+	mv::launchPeerSync(s, a);
+	MV_HIP(ctx, hipGetLastError());
+	return MV_OK;
+}
+// the fields of a push kernel's launch: which rows its last workgroup raises
+static DeviceState peerPushState(mv_ctx* ctx, const DeviceState& st, uint32_t kind, uint64_t frame, uint32_t frameTag, uint32_t slot)
+{
+	DeviceState sp = st;
+	foldBase(ctx, sp, kind, frame, frameTag, slot);
+	return sp;
+}
+
 // The light march of frame k with peer stores: wait until every rank is done with the frames that still read what this frame overwrites,
-// march this rank's share into EVERY rank's copy of the relit map, raise the flag, wait for the others' shares.
+// march this rank's layers of the relit map, push them into every rank's copy and raise the flag.
 static int peerLight(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
 	const uint64_t k = d->peerFrame;
 	const uint32_t C = d->numChains, lb = ctx->st.lightBufs;
 	hipStream_t S = streamB(ctx);
-	if (d->peerFold && ctx->st.shardCount > 1u)
-	{
-		// folded: the light march itself waits (the same rows as below) and its last workgroup raises "this rank's share has landed"
-		// with the cull words; the view marches that read the map wait for every rank's share themselves
-		foldBase(ctx, ctx->st, kFoldLight, k, ctx->st.frameTag, ctx->slot);
-		for (uint32_t i = 0; i < C; ++i) if (k > lb + i) foldWait(ctx, ctx->st, kStageDone, k - lb - i);
-		if (C < lb && k > C) foldWait(ctx, ctx->st, kStageDone, k - C);
-		foldSignal(ctx, ctx->st, kStageLight, k);
-		if (d->cullCrosscheck) ctx->st.fold.checkChain = (uint32_t)(k % C);
-		const int rc = mvi::marchLight(ctx, nullptr);
-		foldClear(ctx->st);
-		if (rc != MV_OK) return rc;
-		MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], S));	// (this rank's share: what stream order gives the frames behind it; the other ranks' shares are the flags')
-		d->bytes += (size_t)mv::lightSharePerRank(ctx->st) * 64u * sizeof(uint4) * (ctx->st.shardCount - 1u);
-		return MV_OK;
-	}
-	if (ctx->st.shardCount > 1u)
-	{
-		// Frame k's light march overwrites, on every rank, the light buffer frame k - lightBufs was the last to read; its view march,
-		// the output set frame k - C composited (and frame k - C + 1 copied forward from).  "Done" is raised per chain, a row per chain: all
-		// frames up to k - lightBufs are complete everywhere once the newest C of them are.
-		mv::PeerSync a = peerSyncBase(ctx, ctx->st.frameTag, ctx->slot);
-		for (uint32_t i = 0; i < C; ++i)
-			if (k > lb + i) { a.waitRow[a.nWait] = kStageDone * mv::kPeerMaxChains + (uint32_t)((k - lb - i) % C); a.waitValue[a.nWait++] = k - lb - i; }
-		if (C < lb && k > C) { a.waitRow[a.nWait] = kStageDone * mv::kPeerMaxChains + (uint32_t)(k % C); a.waitValue[a.nWait++] = k - C; }
-		if (a.nWait)
-		{
-			mv::launchPeerSync(S, a);
-			MV_HIP(ctx, hipGetLastError());
-		}
-	}
-	int rc;
-	if ((rc = mvi::marchLight(ctx, nullptr)) != MV_OK) return rc;	// (st.peerCount != 0: the kernel stores into every rank's map)
-	if (ctx->st.shardCount > 1u)
-	{
-		mv::PeerSync a = peerSyncBase(ctx, ctx->st.frameTag, ctx->slot);
-		a.nSignal = 1; a.signalRow[0] = kStageLight * mv::kPeerMaxChains + (uint32_t)(k % C); a.signalValue[0] = k;
-		a.nWait = 1; a.waitRow[0] = a.signalRow[0]; a.waitValue[0] = k;
-		if (d->cullCrosscheck) a.checkChain = (uint32_t)(k % C);
-		mv::launchPeerSync(S, a);
-		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], S));	// "this frame's light map is current on this rank": every share has landed
-		d->bytes += (size_t)mv::lightSharePerRank(ctx->st) * 64u * sizeof(uint4) * (ctx->st.shardCount - 1u);
-	}
+	if (ctx->st.shardCount <= 1u) return mvi::marchLight(ctx, nullptr);
+	// Frame k's light push overwrites, on every rank, the light buffer frame k - lightBufs was the last to read; its cube push, the
+	// output set frame k - C composited (and frame k - C + 1 copied forward from).  "Done" is raised per chain, a row per chain: all
+	// frames up to k - lightBufs are complete everywhere once the newest C of them are.
+	PeerWaits w;
+	for (uint32_t i = 0; i < C; ++i) if (k > lb + i) { w.stage[w.n] = kStageDone; w.frame[w.n++] = k - lb - i; }
+	if (C < lb && k > C) { w.stage[w.n] = kStageDone; w.frame[w.n++] = k - C; }
+	int rc = peerWaitFor(ctx, S, ctx->st, kFoldLight, w, k, ctx->st.frameTag, ctx->slot, false);
+	if (rc == MV_OK) rc = mvi::marchLight(ctx, nullptr);
+	foldClear(ctx->st);
+	if (rc != MV_OK) return rc;
+	DeviceState sp = peerPushState(ctx, ctx->st, kFoldLight, k, ctx->st.frameTag, ctx->slot);
+	foldSignal(ctx, sp, kStageLight, k);
+	if (d->cullCrosscheck) sp.fold.checkChain = (uint32_t)(k % C);	// (with what this rank's cull decided for the frame: compared by every rank's view march)
+	mv::launchPeerPushLight(S, sp);
+	MV_HIP(ctx, hipGetLastError());
+	MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], S));	// (this rank's layers are in place and on their way: what the frames behind it on the other streams order themselves by; the other ranks' layers are the flags')
+	d->bytes += (size_t)ctx->st.L * ctx->st.L * ctx->st.L * sizeof(uint4) / ctx->st.shardCount * (ctx->st.shardCount - 1u);
 	return MV_OK;
 }
 
-// behind this frame's view march: its faces have landed in every rank's output set
-static int peerSignalCube(mv_ctx* ctx)
+// in front of frame k's view march: every rank's layers of the light maps relit in this frame and in the C - 1 before it (the frames on
+// the other chains; earlier ones were waited for by this chain's previous march) have landed
+static int peerBeforeView(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
 	if (ctx->st.shardCount <= 1u) return MV_OK;
-	mv::PeerSync a = peerSyncBase(ctx, ctx->st.frameTag, ctx->slot);
-	a.nSignal = 1; a.signalRow[0] = kStageCube * mv::kPeerMaxChains + (uint32_t)(d->peerFrame % d->numChains); a.signalValue[0] = d->peerFrame;
-	mv::launchPeerSync(streamB(ctx), a);
-	MV_HIP(ctx, hipGetLastError());
+	PeerWaits w;
+	for (uint32_t j = 0; j < d->numChains; ++j) if (d->peerFrame > j) { w.stage[w.n] = kStageLight; w.frame[w.n++] = d->peerFrame - j; }
+	const int rc = peerWaitFor(ctx, streamB(ctx), ctx->st, kFoldView, w, d->peerFrame, ctx->st.frameTag, ctx->slot, true);
+	if (rc != MV_OK) return rc;
+	// ...and what the march's last workgroup raises, behind the texels it stored into every rank's cube maps
+	if (!d->peerFold) foldBase(ctx, ctx->st, kFoldView, d->peerFrame, ctx->st.frameTag, ctx->slot);	// (folded: peerWaitFor has filled the launch's fields in)
+	foldSignal(ctx, ctx->st, kStageCube, d->peerFrame);
+	ctx->st.fold.stores = 1u;	// (every launch of this march -- the overflow launch too, whichever of them waits or raises)
 	return MV_OK;
 }
 
@@ -598,7 +607,7 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 	MV_REQUIRE(ctx, all || loopback, MV_ERR_INVALID_ARG, "the ranks' export blobs");
 	DistState* d = ctx->dist;
 	const uint32_t world = ctx->st.shardCount, rank = ctx->st.shardIndex;
-	auto bail = [&](int rc) { mvi::distRelease(ctx); ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows); return rc; };
+	auto bail = [&](int rc) { mvi::distRelease(ctx); ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers); return rc; };
 	{ const hipError_t e = hipSetDevice(ctx->cfg.device); if (e != hipSuccess) return bail(fail(ctx, MV_ERR_HIP, "hipSetDevice", e)); }
 	void* mine[kPeerBuffers]; uint64_t mineBytes[kPeerBuffers];
 	peerBufferList(ctx, mine, mineBytes);
@@ -711,7 +720,7 @@ static int distTailExchange(mv_ctx* ctx)
 		if (world <= 1u) return MV_OK;
 		const unsigned long long rep = *reinterpret_cast<volatile unsigned long long*>(d->reports + (size_t)slot * 8u);
 		if ((uint32_t)(rep >> 32) == st.frameTag) d->bytes += (size_t)(uint32_t)rep * 12u * (world - 1u);
-		if (d->peerFold && d->pendingComposite) return MV_OK;	// (folded: the composite itself waits)
+		if (d->peerFold && d->pendingComposite && st.shardIndex < ((st.H + 7u) >> 3)) return MV_OK;	// (folded: the composite itself waits -- a rank with a row of the screen launches one)
 		return peerWaitStage(ctx, X, kStageCube, d->framePending, st.frameTag, slot);
 	}
 	if (world > 1)
@@ -754,21 +763,29 @@ static int distTailExchange(mv_ctx* ctx)
 // with frame j: its light buffers and output set may be overwritten".  (The copy-forward of frame j + 1 still reads frame j's set after
 // this -- on this very stream.  The set is next written by the other ranks' view marches of frame j + C, which they start behind this
 // rank's light share of frame j + C: a kernel of this same stream, behind that copy.)
-static int distTailSignal(mv_ctx* ctx, hipStream_t X, uint32_t localChain, uint64_t frame, uint32_t frameTag, uint32_t slot, bool composited, bool folded)
+static int distTailSignal(mv_ctx* ctx, hipStream_t X, uint32_t localChain, const DeviceState& st, uint64_t frame, uint32_t slot, bool composited)
 {
 	DistState* d = ctx->dist;
-	if (d->transport != 3) return MV_OK;
+	if (d->transport != 3 || st.shardCount <= 1u) return MV_OK;
 	const uint32_t c = (uint32_t)(frame % d->numChains);
-	if (folded) { d->rowsWaitFrame[c] = frame; d->rowsStream[c] = localChain; return MV_OK; }	// (the composite's last workgroup raises both)
-	mv::PeerSync a = peerSyncBase(ctx, frameTag, slot);
-	a.nSignal = 0;
-	if (composited) { a.signalRow[a.nSignal] = kStageRows * mv::kPeerMaxChains + c; a.signalValue[a.nSignal++] = frame; d->rowsWaitFrame[c] = frame; d->rowsStream[c] = localChain; }
-	a.signalRow[a.nSignal] = kStageDone * mv::kPeerMaxChains + c; a.signalValue[a.nSignal++] = frame;
-	mv::launchPeerSync(X, a);
+	if (composited)
+	{
+		// push this rank's rows into every rank's frame buffer; its last workgroup raises both flags
+		DeviceState sp = peerPushState(ctx, st, kFoldComposite, frame, st.frameTag, slot);
+		foldSignal(ctx, sp, kStageRows, frame);
+		foldSignal(ctx, sp, kStageDone, frame);
+		mv::launchPeerPushRows(X, sp);
+		d->rowsWaitFrame[c] = frame; d->rowsStream[c] = localChain;
+	}
+	else
+	{
+		mv::PeerSync a = peerSyncBase(ctx, st.frameTag, slot);
+		a.nSignal = 1; a.signalRow[0] = kStageDone * mv::kPeerMaxChains + c; a.signalValue[0] = frame;
+		mv::launchPeerSync(X, a);
+	}
 	MV_HIP(ctx, hipGetLastError());
 	return MV_OK;
 }
-
 static int distTailComposite(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
@@ -777,29 +794,20 @@ static int distTailComposite(mv_ctx* ctx)
 	const uint32_t slot = d->slotPending, world = st.shardCount, rank = st.shardIndex;
 	const uint32_t chain = d->chains ? d->chainPending : 0u;
 	hipStream_t X = distTailStream(ctx, chain);
-	bool tailFolded = false;
 	if (d->pendingComposite)
 	{
 		// chains: the copy-forward of this frame's unmarched faces ran on the stream of the frame before it
 		if (d->chains) MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[slot]));
-		bool folded = false;
 		if (d->transport == 3 && d->peerFold && world > 1u)
 		{
 			DeviceState stc = st;
-			foldBase(ctx, stc, kFoldComposite, d->framePending, st.frameTag, slot);
-			foldWait(ctx, stc, kStageCube, d->framePending);
-			foldSignal(ctx, stc, kStageRows, d->framePending);
-			foldSignal(ctx, stc, kStageDone, d->framePending);
-			folded = mv::launchComposite(X, stc, st.bandRow0, st.bandRow1) != 0u;
-			if (!folded)	// (a rank without a row of the screen: nothing was launched that could wait or raise)
-			{
-				const int rc = peerWaitStage(ctx, X, kStageCube, d->framePending, st.frameTag, slot);
-				if (rc != MV_OK) return rc;
-			}
+			PeerWaits w; w.n = 1; w.stage[0] = kStageCube; w.frame[0] = d->framePending;
+			const int rc = peerWaitFor(ctx, X, stc, kFoldComposite, w, d->framePending, st.frameTag, slot, false);
+			if (rc != MV_OK) return rc;
+			mv::launchComposite(X, stc, st.bandRow0, st.bandRow1);
 		}
 		else mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
 		MV_HIP(ctx, hipGetLastError());
-		tailFolded = folded;
 		if (d->transport == 3) d->bytes += (size_t)st.H * st.W * sizeof(uint2) / world * (world - 1u);	// (the composite stored its rows into every rank's frame buffer)
 		else if (world > 1)
 		{
@@ -822,7 +830,7 @@ static int distTailComposite(mv_ctx* ctx)
 			d->bytes += (size_t)st.H * rowBytes;
 		}
 	}
-	{ const int rc = distTailSignal(ctx, X, chain, d->framePending, st.frameTag, slot, d->pendingComposite, tailFolded); if (rc != MV_OK) return rc; }
+	{ const int rc = distTailSignal(ctx, X, chain, st, d->framePending, slot, d->pendingComposite); if (rc != MV_OK) return rc; }
 	// everything that reads this frame's buffers has been enqueued: the next users of its slot / output set / light buffers wait for this
 	MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[slot], X));
 	d->pending = false;
@@ -940,21 +948,10 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 		// (the copy-forward behind the composite: the composite has already made this stream wait for frame k - 1's copy, which this
 		// one builds on, and nothing needs frame k's copy before frame k's own composite, a call from now)
 		{ MV_SECTION(3); if ((rc = viewCopyForward(ctx)) != MV_OK) return rc; }
-		const bool foldView = d->transport == 3 && d->peerFold && ctx->st.shardCount > 1u;
-		if (foldView)
-		{
-			// folded: the march waits for every rank's share of the light maps relit in this frame and in the C - 1 before it (the frames
-			// on the other chains: earlier ones were waited for by this chain's previous march), its last workgroup raises "cube faces landed"
-			foldBase(ctx, ctx->st, kFoldView, d->peerFrame, ctx->st.frameTag, ctx->slot);
-			for (uint32_t j = 0; j < d->numChains; ++j) if (d->peerFrame > j) foldWait(ctx, ctx->st, kStageLight, d->peerFrame - j);
-			foldSignal(ctx, ctx->st, kStageCube, d->peerFrame);
-			if (d->cullCrosscheck) { ctx->st.fold.checkChain = (uint32_t)(d->peerFrame % d->numChains); ctx->st.fold.checkCompare = 1u; }
-			d->foldSignalMissing = false;
-		}
+		if (d->transport == 3 && (rc = peerBeforeView(ctx)) != MV_OK) return rc;	// (peer stores: every rank's light layers; folded into the march or a kernel in front of it)
 		{ MV_SECTION(6); rc = viewMarch(ctx); }
-		if (foldView) foldClear(ctx->st);
+		if (d->transport == 3) foldClear(ctx->st);
 		if (rc != MV_OK) return rc;
-		if (d->transport == 3 && (!foldView || d->foldSignalMissing) && (rc = peerSignalCube(ctx)) != MV_OK) return rc;	// (peer stores: this rank's faces have landed everywhere)
 	}
 	else
 	{

@@ -891,6 +891,16 @@ struct LightShare { uint32_t lo, hi, per; };
 __host__ __device__ inline LightShare lightShare(const DeviceState& st, uint32_t totalBlocks)
 {
 	LightShare r;
+	if ((st.flags & kFlagLightLayers) && st.shardCount > 1u)
+	{
+		// peer-store transport: whole layers of voxel blocks, layer l of the z axis to rank l % shardCount (entry e of a rank's share is
+		// block lightLayerBlock(e)); `per` is the largest share, the grid every rank launches
+		uint32_t B = 1u;
+		while (B * B * B < totalBlocks) ++B;
+		const uint32_t mine = lightLayersOfRank(B, st.shardIndex, st.shardCount);
+		r.per = ((B + st.shardCount - 1u) / st.shardCount) * B * B; r.lo = 0u; r.hi = mine * B * B;
+		return r;
+	}
 	const bool split = (st.flags & kFlagRotateAllLightMaps) && st.shardCount > 1u;
 	r.per = split ? (totalBlocks + st.shardCount - 1u) / st.shardCount : totalBlocks;
 	r.lo = split ? st.shardIndex * r.per : 0u;
@@ -901,7 +911,6 @@ __host__ __device__ inline LightShare lightShare(const DeviceState& st, uint32_t
 
 // quad-replicated store of one light-map texel (see mv_device.hpp "light maps"): texel (x, y) is slot (sx, sy) of every cell (cx, cy)
 // with min(cx + sx, L-1) == x and min(cy + sy, L-1) == y
-template <bool PEER = false>
 __device__ __forceinline__ void storeLightTexel(uint32_t* quads, uint32_t L, uint32_t xx, uint32_t yy, uint32_t zz, uint32_t packed)
 {
 	const uint32_t cxs[3] = { xx, xx - 1u, xx }, sxs[3] = { 0u, 1u, 1u };
@@ -913,28 +922,22 @@ __device__ __forceinline__ void storeLightTexel(uint32_t* quads, uint32_t L, uin
 #pragma unroll
 		for (int a = 0; a < 3; ++a)
 			if (vx[a] && vy[b])
-			{
-				uint32_t* word = quads + (((((size_t)zz * L + cys[b]) * L + cxs[a]) << 2) + sxs[a] + 2u * sxs[b]);
-				if (PEER) peerStore(word, packed);	// another rank's copy (mv_kernels.hpp: written through at system scope)
-				else *word = packed;
-			}
+				quads[((((size_t)zz * L + cys[b]) * L + cxs[a]) << 2) + sxs[a] + 2u * sxs[b]] = packed;
 }
 
 // wordsOut: NULL, or where this context's share of the map goes as plain words, 64 per block in dispatch order from entry `lo` on
 template <bool LUT, bool ORDERED, int K, bool PEER>
 __device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* __restrict__ wordsOut, u32x4* sAxis, unsigned long long (*sCand)[(1024u + 63u) / 64u]);
 
-// PEER: the peer-store transport's instantiation (stores into every rank's map, folded flags); the others are untouched by it
+// PEER: the peer-store transport's instantiation with a folded wait (mv_kernels.hpp peerFoldWait); the others are untouched by it
 template <bool LUT, bool ORDERED, int K, bool PEER = false>
 __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightKernel(DeviceState st, uint32_t* __restrict__ wordsOut)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLightLutMaxN + 1) : 1];
 	__shared__ unsigned long long sCand[kLightWaves][(1024u + 63u) / 64u];	// (MV_LIGHT_CANDIDATES: volumes beyond the first 64; MV_MAX_VOLUMES = 1024)
-	// (peer-store transport, folded flags: wait until every rank is done with the frames that read what this launch overwrites; the
-	// last workgroup raises "this rank's share has landed everywhere" -- mv_kernels.hpp peerFoldWait / peerFoldSignal)
+	// (peer-store transport, folded wait: until every rank is done with the frames that read what this launch -- and the push behind it -- overwrite)
 	if constexpr (PEER) peerFoldWait(st);
 	marchLightBody<LUT, ORDERED, K, PEER>(st, wordsOut, sAxis, sCand);
-	if constexpr (PEER) peerFoldSignal(st);
 }
 
 template <bool LUT, bool ORDERED, int K, bool PEER>
@@ -983,7 +986,12 @@ __device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* 
 		e = share.lo + k;
 	}
 	if (e >= share.hi) return;
-	const uint32_t b = ORDERED ? st.lightOrder[e] : e;
+	uint32_t b = ORDERED ? st.lightOrder[e] : e;	// (layers, ordered: the order holds this rank's blocks only, lightOrderRole)
+	if (!ORDERED && (st.flags & kFlagLightLayers) && st.shardCount > 1u)
+	{
+		const uint32_t perLayer = blocksPerAxis * blocksPerAxis, i = e / perLayer;	// the i-th layer of this rank
+		b = lightLayerOfRank(blocksPerAxis, st.shardIndex, st.shardCount, i) * perLayer + (e - i * perLayer);
+	}
 	const uint32_t bx = b % blocksPerAxis, by = (b / blocksPerAxis) % blocksPerAxis, bz = b / (blocksPerAxis * blocksPerAxis);
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t xx = bx * 4 + (lane & 3u), yy = by * 4 + ((lane >> 2) & 3u), zz = bz * 4 + (lane >> 4);
@@ -1123,15 +1131,6 @@ __device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* 
 		const vec3 result = v3(shadow * lightColor.x + ambient.x, shadow * lightColor.y + ambient.y, shadow * lightColor.z + ambient.z);
 		packed = pack_r11g11b10f(result.x, result.y, result.z);
 		storeLightTexel(reinterpret_cast<uint32_t*>(st.lightTable[volumeId]), L, xx, yy, zz, packed);
-		if constexpr (PEER)
-		{
-			// peer-store transport: this rank's share goes straight into every rank's copy of the relit map (same layout everywhere:
-			// the map's offset inside lightBuffers), no words, no all-gather, no unpack
-			const size_t mapOff = reinterpret_cast<const uint8_t*>(st.lightTable[volumeId]) - reinterpret_cast<const uint8_t*>(st.lightBuffers);
-			for (uint32_t p = 0; p < st.peerCount; ++p)
-				if (p != st.shardIndex)
-					storeLightTexel<true>(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(st.peerLight[p]) + mapOff), L, xx, yy, zz, packed);
-		}
 	}
 	if (wordsOut) wordsOut[(size_t)(e - share.lo) * 64u + lane] = packed;
 
@@ -1383,17 +1382,24 @@ __device__ __forceinline__ void lightOrderRole(const DeviceState& st, uint32_t* 
 	uint32_t* sWave = sMem + 4u * kLightOrderMaxB * kLightOrderMaxB;
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 	const uint32_t volumeId = relitVolume(st, cb->frameIdx, st.counters[0], st.visibleVolumes);
-	const uint32_t B = (st.L + 3u) >> 2, T = 2u * B, total = B * B * B, tubes = T * T;
+	const uint32_t B = (st.L + 3u) >> 2, T = 2u * B, tubes = T * T;
+	// (peer-store transport: the light march is shared out by layers of blocks -- layer l of the z axis to rank l % shardCount -- and the
+	// order holds THIS rank's blocks only, in tube order: the i-th block of the loops below is ownBlock(i))
+	const bool layers = (st.flags & kFlagLightLayers) && st.shardCount > 1u;
+	const uint32_t myLayers = layers ? lightLayersOfRank(B, st.shardIndex, st.shardCount) : B;
+	const uint32_t total = myLayers * B * B;
+	auto ownBlock = [&](uint32_t i) -> uint32_t { if (!layers) return i; const uint32_t l = i / (B * B); return lightLayerOfRank(B, st.shardIndex, st.shardCount, l) * B * B + (i - l * B * B); };
 	const float4 ld = st.lightDirs[volumeId];
 	float d[3] = { ld.x, ld.y, ld.z };
 	// The order depends on the direction only, and the slot's table still holds the order for the direction of four frames ago (kept
 	// behind the table): with volumes that share an orientation and a light that stands still it is the same one, frame after frame.
 	{
-		uint32_t* tag = st.lightOrder + total;
-		const bool same = tag[0] == __float_as_uint(d[0]) && tag[1] == __float_as_uint(d[1]) && tag[2] == __float_as_uint(d[2]) && tag[3] == total;
+		uint32_t* tag = st.lightOrder + B * B * B;	// (behind the largest order there can be)
+		const uint32_t what = total | (layers ? 0x80000000u : 0u);
+		const bool same = tag[0] == __float_as_uint(d[0]) && tag[1] == __float_as_uint(d[1]) && tag[2] == __float_as_uint(d[2]) && tag[3] == what;
 		__syncthreads();	// everybody has read the tag
 		if (same) return;
-		if (threadIdx.x == 0) { tag[0] = __float_as_uint(d[0]); tag[1] = __float_as_uint(d[1]); tag[2] = __float_as_uint(d[2]); tag[3] = total; }
+		if (threadIdx.x == 0) { tag[0] = __float_as_uint(d[0]); tag[1] = __float_as_uint(d[1]); tag[2] = __float_as_uint(d[2]); tag[3] = what; }
 	}
 	// dominant axis a; p, q the other two; slopes of the shear (0 for a direction that is not a finite, non-zero vector)
 	uint32_t a = 0;
@@ -1414,7 +1420,7 @@ __device__ __forceinline__ void lightOrderRole(const DeviceState& st, uint32_t* 
 	};
 	for (uint32_t i = threadIdx.x; i < tubes; i += kLightOrderThreads) sCursor[i] = 0u;
 	__syncthreads();
-	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) atomicAdd(&sCursor[tubeOf(b)], 1u);
+	for (uint32_t i = threadIdx.x; i < total; i += kLightOrderThreads) atomicAdd(&sCursor[tubeOf(ownBlock(i))], 1u);
 	__syncthreads();
 	// exclusive prefix over the tubes: every thread owns a run of consecutive counts
 	const uint32_t per = (tubes + kLightOrderThreads - 1u) / kLightOrderThreads;
@@ -1434,7 +1440,7 @@ __device__ __forceinline__ void lightOrderRole(const DeviceState& st, uint32_t* 
 		if (i < tubes) { const uint32_t c = sCursor[i]; sCursor[i] = base; base += c; }	// (a thread's own run: nobody else reads or writes it)
 	}
 	__syncthreads();
-	for (uint32_t b = threadIdx.x; b < total; b += kLightOrderThreads) st.lightOrder[atomicAdd(&sCursor[tubeOf(b)], 1u)] = b;
+	for (uint32_t i = threadIdx.x; i < total; i += kLightOrderThreads) { const uint32_t b = ownBlock(i); st.lightOrder[atomicAdd(&sCursor[tubeOf(b)], 1u)] = b; }
 	// Inside a tube the atomics above leave the blocks in arrival order.  The order must be the same on every rank of the multi-GPU loop
 	// (ranks march disjoint ranges of it) and in every frame slot, so every tube is put into a defined order: along the light's dominant
 	// axis, then by block index (a tube holds at most B blocks, one per step along that axis; an insertion sort in place).
@@ -1546,7 +1552,7 @@ static void launchMarchLightKP(hipStream_t s, const DeviceState& st, uint32_t* w
 template <int K>
 static void launchMarchLightK(hipStream_t s, const DeviceState& st, uint32_t* wordsOut, uint32_t count)
 {
-	if (st.peerCount) launchMarchLightKP<K, true>(s, st, wordsOut, count);	// (peer-store transport)
+	if (st.fold.nWait) launchMarchLightKP<K, true>(s, st, wordsOut, count);	// (peer-store transport, folded wait)
 	else launchMarchLightKP<K, false>(s, st, wordsOut, count);
 }
 

@@ -145,18 +145,18 @@ struct DeviceState
 	RayRecord* rayRecords;			// (maxTiles + maxScreenTiles) x 64, in dispatch order: slot s holds the rays of tile tileOrder[s]
 	TileInfo* tileInfo;				// maxTiles + maxScreenTiles
 	// Peer-store transport of the multi-GPU frame loop (mv_dist_init_peer; mv_peer.hip): every rank maps every rank's light maps, cube
-	// maps / depths and frame buffers (xGMI peer mappings: IPC handles between processes), and the kernels that PRODUCE them store
-	// into all of them -- no pack, no collective, no unpack.  peerCount = 0 outside that transport (the stores below cost one scalar
-	// compare); else shardCount, and entry [shardIndex] of every table is this context's own buffer.
+	// maps / depths and frame buffers (xGMI peer mappings: IPC handles between processes), and a push kernel behind each producer
+	// copies what it produced into all of them -- no pack, no collective, no unpack.  peerCount = 0 outside that transport; else
+	// shardCount, and entry [shardIndex] of every table is this context's own buffer.
 	uint32_t peerCount;
 	uint4* const* peerLight;		// [peerCount] every rank's lightBuffers (same layout everywhere: an address here + the offset of a map inside lightBuffers)
 	uint2* const* peerCubeMaps;		// [peerCount] every rank's cube maps of THIS frame's output set
 	float* const* peerCubeDepths;	// [peerCount]
 	uint2* const* peerComposite;	// [peerCount] every rank's frame buffer of this output set
-	// ...and the flags that order those stores, folded into the producing / consuming kernels themselves (mv_peer.hip explains the
-	// protocol and has the same two steps as a kernel of their own): a launch may WAIT, in every workgroup's prologue, until rows of this
-	// rank's flag block have reached a frame in every column, and RAISE, from the last workgroup to finish, its column of rows in every
-	// rank's block.  nWait = nSignal = 0: neither (every launch outside the folded peer-store loop).
+	// ...and the flags that order those stores (mv_peer.hip explains the protocol): a push kernel RAISES, from the last workgroup to
+	// finish, its column of rows in every rank's block; a consumer (light march, view march, composite) may WAIT, in every workgroup's
+	// prologue, until rows of this rank's flag block have reached a frame in every column ("folded" waits: ranks that own their GPU;
+	// ranks that share one wait in a one-wavefront kernel of its own, peerSyncKernel).  nWait = nSignal = 0: neither.
 	struct PeerFold
 	{
 		unsigned long long* const* flagBlocks;	// [peerCount] every rank's flag block
@@ -166,25 +166,26 @@ struct DeviceState
 		unsigned long long timeoutTicks;
 		uint32_t nWait, nSignal, loopback, frameTag;
 		uint32_t checkChain, checkCompare;		// checkChain: 0xffffffff, or the chain whose slot of cull words this launch raises with (a producer) or, checkCompare != 0, compares every rank's behind its wait (a consumer) -- mv_peer.hip
+		uint32_t stores, pad;					// (view march) this launch also stores its texels into the other ranks' cube maps
 		uint32_t waitRow[6], signalRow[2];
 		unsigned long long waitValue[6], signalValue[2];
 	} fold;
 };
-// Stores into a peer's memory: relaxed atomic stores at SYSTEM scope (global_store ... sc0 sc1: written through to the memory that owns
-// the address, nothing left dirty in this GPU's L2), so that the release in front of the flag that announces them (mv_peer.hip) has
-// nothing to write back.
-#ifdef MV_PEER_PLAIN_STORES	// (A/B timing only: what the stores would cost as plain ones -- NOT a valid build for a node: plain stores stay dirty in this GPU's L2)
-__device__ __forceinline__ void peerStore(uint32_t* p, uint32_t v) { *p = v; }
-__device__ __forceinline__ void peerStore(float* p, float v) { *p = v; }
-__device__ __forceinline__ void peerStore(uint2* p, uint2 v) { *p = v; }
-#else
+// Stores into a peer's memory: written through at SYSTEM scope (global_store ... sc0 sc1: the acknowledgement comes from the memory that
+// owns the address, nothing is left dirty in this GPU's L2), so that "complete" is the storing wavefront's s_waitcnt vmcnt(0) and no
+// cache has to be written back in front of the flag that announces them.  16 bytes per store wherever a range allows it: narrower
+// write-through stores are one fabric write each (dword ~6x, dwordx2 ~2.7x the time per byte of a dwordx4).
 __device__ __forceinline__ void peerStore(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void peerStore(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
-__device__ __forceinline__ void peerStore(uint2* p, uint2 v)
+__device__ __forceinline__ void peerStore8(uint2* p, uint2 v)
 {
 	__hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-#endif
+__device__ __forceinline__ void peerStore16(void* p, uint4 v)
+{
+	typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+	u32x4_t w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+	asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(w) : "memory");
+}
 // Every rank owns a block of flags that the OTHER ranks write and only it reads: row r, column p = "rank p has finished stage r.stage of
 // frame <value>", rows = stage x chain (frames k with k % chains == chain follow each other on one stream, so a row only ever grows).
 constexpr uint32_t kPeerMaxRanks = 64;		// ranks of one peer-store group (one node: 8); columns of a flag row
@@ -246,13 +247,21 @@ __device__ __forceinline__ void peerFoldWait(const DeviceState& st)
 __device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
 {
 	if (!st.fold.nSignal) return;
+	__shared__ uint32_t sLast;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wavefront's stores, into every rank's memory, have been acknowledged
 	__syncthreads();
-	if (threadIdx.x != 0u) return;
-	const uint32_t finished = __hip_atomic_fetch_add(st.fold.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	if (finished != gridDim.x - 1u) return;
-	__hip_atomic_store(st.fold.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (the next launch that uses it is behind this one on its stream)
-	for (uint32_t p = 0; p < st.peerCount; ++p)
+	if (threadIdx.x == 0u)
+	{
+		const uint32_t finished = __hip_atomic_fetch_add(st.fold.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const bool last = finished == gridDim.x * gridDim.y - 1u;
+		if (last) __hip_atomic_store(st.fold.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (the next launch that uses it is behind this one on its stream)
+		sLast = last ? 1u : 0u;
+	}
+	__syncthreads();
+	if (!sLast || threadIdx.x >= 64u) return;
+	// the last workgroup's first wavefront: lane p raises this rank's column in rank p's block (all ranks at once: a write-through
+	// store and its acknowledgement are a trip over the fabric each)
+	for (uint32_t p = threadIdx.x; p < st.peerCount; p += 64u)
 	{
 		unsigned long long* block = st.fold.loopback ? st.fold.myFlags : st.fold.flagBlocks[p];	// loopback: a rank measured alone raises every column of its own block
 		const uint32_t column = st.fold.loopback ? p : st.shardIndex;
@@ -267,14 +276,6 @@ __device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
 	}
 }
 
-// the same element of every OTHER rank's buffer (the caller stores its own copy as before)
-template <typename T>
-__device__ __forceinline__ void storeToPeers(const DeviceState& st, T* const* table, size_t index, T v)
-{
-	for (uint32_t p = 0; p < st.peerCount; ++p)
-		if (p != st.shardIndex) peerStore(table[p] + index, v);
-}
-
 // Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
 // their position among this frame's screen tiles.  A key that names another tile after a mip / visibility change only
 // misorders the dispatch.
@@ -286,6 +287,23 @@ __host__ __device__ inline uint32_t tileCostKeyCount(uint32_t V, uint32_t N, uin
 constexpr uint32_t kFlagInterleaveRows = 0x10000000u;	// DeviceState.flags (internal, mv_dist_frame contexts): this rank's screen rows are the 8-row tile rows t with t % shardCount == shardIndex (not the contiguous band), and the composite image is stored rank-major: tile row t at (t % shardCount) * ceil(T / shardCount) + t / shardCount
 constexpr uint32_t kFlagBalanceOwners = 0x20000000u;	// DeviceState.flags (internal, mv_dist_frame contexts): the cull deals the cube-map volumes of a frame to the ranks by estimated march cost instead of v % shardCount (volumeFlags bits 16-31 name the owner either way)
 constexpr uint32_t kFlagNoScreenLayers = 0x40000000u;	// DeviceState.flags (internal, per composite launch): this frame has had no view march, so the RayCast layers are not this frame's: the composite marches screen-space volumes itself
+constexpr uint32_t kFlagLightLayers = 0x08000000u;	// DeviceState.flags (internal, peer-store transport): the light march is shared out by LAYERS of voxel blocks (block layer l of the z axis to rank l % shardCount) instead of ranges of the dispatch order: a light-map cell holds texels of one z only, so a rank's layers are whole cells, contiguous in memory -- what it pushes to the other ranks is plain ranges
+// (kFlagLightLayers) which block layers of the z axis a rank marches: a slab of ceil(B / shardCount) adjacent ones (adjacent layers share
+// the texels their light rays read: measured against every shardCount-th layer, profiles/r04_peer_rank_cost.txt)
+#ifndef MV_LIGHT_LAYERS_INTERLEAVED
+#define MV_LIGHT_LAYERS_INTERLEAVED 0
+#endif
+__host__ __device__ inline uint32_t lightLayersOfRank(uint32_t B, uint32_t rank, uint32_t shardCount)
+{
+	if (MV_LIGHT_LAYERS_INTERLEAVED) return B > rank ? (B - rank + shardCount - 1u) / shardCount : 0u;
+	const uint32_t per = (B + shardCount - 1u) / shardCount, first = rank * per;
+	return first >= B ? 0u : (B - first < per ? B - first : per);
+}
+__host__ __device__ inline uint32_t lightLayerOfRank(uint32_t B, uint32_t rank, uint32_t shardCount, uint32_t i)	// its i-th layer
+{
+	if (MV_LIGHT_LAYERS_INTERLEAVED) return rank + i * shardCount;
+	return rank * ((B + shardCount - 1u) / shardCount) + i;
+}
 constexpr uint32_t kFlagRotateAllLightMaps = 0x80000000u;	// DeviceState.flags (internal): every rank rotates the relit volume's light buffer, not only its owner
 
 // The 8-row tile rows of a screen rectangle [y0, y1] (pixel rows, y1 already clipped to the viewport) that this context marches and
@@ -396,6 +414,7 @@ void launchMarchLight(hipStream_t s, const DeviceState& st, uint32_t* wordsOut =
 uint32_t lightSharePerRank(const DeviceState& st);	// voxel blocks per rank of the light march's share-out (all of them outside the multi-GPU frame loop)
 void launchLightUnpack(hipStream_t s, const DeviceState& st, const uint32_t* words);	// the all-gathered shares (64 words per block, lightSharePerRank blocks per rank) into the relit volume's light map
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// returns the first slot its grid does not cover (0xffffffff: none)
+uint32_t marchTilesBeyond(const DeviceState& st, uint32_t gridTiles);	// what launchMarchTiles would return for that estimate, without launching
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
@@ -425,6 +444,9 @@ struct PeerSync
 	unsigned long long* report;				// pinned: [1] = {frameTag : 1} the ranks' culls disagree, [2] = {frameTag : row << 8 | column} a wait timed out
 };
 void launchPeerSync(hipStream_t s, const PeerSync& a);
+// Behind a producer on its stream: copy what it produced into every other rank's buffers; the last workgroup raises st.fold's flags.
+void launchPeerPushLight(hipStream_t s, const DeviceState& st);	// this rank's layers of the relit volume's light map
+void launchPeerPushRows(hipStream_t s, const DeviceState& st);		// this rank's block of the rank-major frame buffer
 void launchPeerPattern(hipStream_t s, uint2* const* table, uint32_t world, uint32_t self, size_t wordsPerRank, uint32_t salt);	// self-test: a pattern into every rank's buffer at this rank's region
 void launchPeerVerify(hipStream_t s, const uint2* mine, uint32_t world, size_t wordsPerRank, uint32_t salt, uint32_t* mismatches);
 } // namespace mv

@@ -48,13 +48,13 @@ constexpr uint32_t kLutMaxN = 256;
 template <bool OVERFLOW, bool LUT, bool IL, bool PEER>
 __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis);
 
-// PEER: the peer-store transport's instantiation (stores into every rank's cube maps, folded flags); the others are untouched by it
+// PEER: the peer-store transport's instantiation: a folded wait in front (mv_kernels.hpp peerFoldWait), every marched texel also stored
+// into the other ranks' cube maps, the last workgroup raises "cube faces landed" (peerFoldSignal); the others are untouched by it
 template <bool OVERFLOW, bool LUT, bool IL, bool PEER = false>
 __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesKernel(DeviceState st, uint32_t firstSlot)
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
-	// (peer-store transport, folded flags: wait for every rank's share of the light maps this frame reads; the last workgroup raises
-	// "this rank's cube faces have landed everywhere" -- mv_kernels.hpp peerFoldWait / peerFoldSignal; one scalar compare each otherwise)
+	// (peer-store transport, folded wait: for every rank's share of the light maps this frame reads)
 	if constexpr (PEER) peerFoldWait(st);
 	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis);
 	if constexpr (PEER) peerFoldSignal(st);
@@ -113,6 +113,8 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	vec3 rayDir = v3(0.0f, 0.0f, 1.0f);
 	float tMax = 0.0f;
 	size_t outIndex = 0;
+	float peerDepth = 0.0f;	// (PEER) what this lane stored into the cube depth
+	uint2 peerColour; peerColour.x = peerColour.y = 0u;
 	if (!screenTile)
 	{
 		const uint32_t dims = st.N >> mipLevel;
@@ -142,7 +144,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 					clip = v3(cx, cy, samplePointR32F(st.depthMap, st.W, st.H, u, v));
 				}
 				st.cubeDepths[outIndex] = clip.z;	// :105
-				if constexpr (PEER) storeToPeers(st, st.peerCubeDepths, outIndex, clip.z);	// (peer-store transport: every rank's copy)
+				if constexpr (PEER) peerDepth = clip.z;
 				tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
 				valid = true;
 				nRays = 1;
@@ -280,7 +282,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				o.x = (uint32_t)float_to_half_bits(scatter.x) | ((uint32_t)float_to_half_bits(scatter.y) << 16);
 				o.y = (uint32_t)float_to_half_bits(scatter.z) | ((uint32_t)float_to_half_bits(scatter.w) << 16);
 				st.cubeMaps[outIndex] = o;	// :157
-				if constexpr (PEER) storeToPeers(st, st.peerCubeMaps, outIndex, o);
+				if constexpr (PEER) peerColour = o;
 			}
 			else
 			{
@@ -290,6 +292,36 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 		}
 	}
 
+	if constexpr (PEER)
+	{
+		// Peer-store transport: what this wavefront wrote into its own cube map and cube depth, into every other rank's -- the texels of
+		// rays that hit, as the reference writes them (CSRayMarch.hlsl:105, 157), 16 bytes per store where neighbouring lanes allow it: a
+		// tile row is 8 lanes = 8 texels in a row of the face, so an even lane takes its right neighbour's colour along (2 x 8 bytes) and
+		// every fourth lane its three neighbours' depths (4 x 4 bytes); narrower write-through stores are a fabric write each.
+		if (!screenTile && st.peerCount > 1u)	// (wave-uniform)
+		{
+			const bool have = valid;
+			const uint2 right = make_uint2(__shfl_down(peerColour.x, 1), __shfl_down(peerColour.y, 1));
+			const bool haveRight = __shfl_down(have ? 1 : 0, 1) != 0, haveLeft = __shfl_up(have ? 1 : 0, 1) != 0;
+			const bool even = !(lane & 1u);
+			const bool pair = even && have && haveRight && !(outIndex & 1u);	// (16-byte aligned: faces start at even texels whenever their edge is even)
+			const bool single = have && !pair && !(!even && haveLeft && !((outIndex - 1u) & 1u));	// (an odd lane whose left neighbour took it along stores nothing)
+			float d1 = __shfl_down(peerDepth, 1), d2 = __shfl_down(peerDepth, 2), d3 = __shfl_down(peerDepth, 3);
+			const unsigned long long hits = __ballot(have);
+			const bool quad = !(lane & 3u) && ((hits >> lane) & 0xfull) == 0xfull && !(outIndex & 3u);
+			const bool inQuad = ((hits >> (lane & ~3u)) & 0xfull) == 0xfull && !((outIndex - (lane & 3u)) & 3u);
+			for (uint32_t p = 0; p < st.peerCount; ++p)
+			{
+				if (p == st.shardIndex) continue;
+				uint2* colours = st.peerCubeMaps[p];
+				float* depths = st.peerCubeDepths[p];
+				if (pair) peerStore16(colours + outIndex, make_uint4(peerColour.x, peerColour.y, right.x, right.y));
+				else if (single) peerStore8(colours + outIndex, peerColour);
+				if (quad) peerStore16(depths + outIndex, make_uint4(__float_as_uint(peerDepth), __float_as_uint(d1), __float_as_uint(d2), __float_as_uint(d3)));
+				else if (have && !inQuad) peerStore(reinterpret_cast<uint32_t*>(depths + outIndex), __float_as_uint(peerDepth));
+			}
+		}
+	}
 	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays), totK = waveSumU32(nSkipped);
 	uint32_t maxS = nSamples;
 #pragma unroll
@@ -313,19 +345,29 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 }
 
 
+static uint64_t marchTilesBlocks(const DeviceState& st, uint32_t gridTiles)
+{
+	const uint64_t maxTiles = (uint64_t)st.maxTiles + st.maxScreenTiles;
+	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
+	const uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
+	return ((blocks + 7) / 8) * 8;
+}
+uint32_t marchTilesBeyond(const DeviceState& st, uint32_t gridTiles)
+{
+	const uint64_t covered = marchTilesBlocks(st, gridTiles) * kTileWaves;
+	return covered < (uint64_t)st.maxTiles + st.maxScreenTiles ? (uint32_t)covered : 0xffffffffu;
+}
+
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
 {
 	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has
 	// none).  The grid covers min(estimate, largest possible frame); returns the first dispatch slot beyond it (what the overflow
 	// launch has to cover), or 0xffffffff if the grid covers every frame there can be.
-	const uint64_t maxTiles = (uint64_t)st.maxTiles + st.maxScreenTiles;
-	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
-	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
-	blocks = ((blocks + 7) / 8) * 8;
+	const uint64_t blocks = marchTilesBlocks(st, gridTiles);
 	const bool il = st.flags & kFlagInterleaveRows;
 	const dim3 grid((uint32_t)blocks), block(64 * kTileWaves);
 	const bool lut = st.N <= kLutMaxN && MV_TILE_LUT != 0;
-	if (st.peerCount)	// (peer-store transport)
+	if (st.peerCount > 1u && st.fold.stores)	// (peer-store transport)
 	{
 		if (lut) { if (il) hipLaunchKernelGGL((marchTilesKernel<false, true, true, true>), grid, block, 0, s, st, 0u); else hipLaunchKernelGGL((marchTilesKernel<false, true, false, true>), grid, block, 0, s, st, 0u); }
 		else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true, true>), grid, block, 0, s, st, 0u);
@@ -338,13 +380,13 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	}
 	else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true>), grid, block, 0, s, st, 0u);
 	else hipLaunchKernelGGL((marchTilesKernel<false, false, false>), grid, block, 0, s, st, 0u);
-	return blocks * kTileWaves < maxTiles ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
+	return marchTilesBeyond(st, gridTiles);
 }
 
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot)
 {
 	const bool il = st.flags & kFlagInterleaveRows;
-	if (st.peerCount)
+	if (st.peerCount > 1u && st.fold.stores)
 	{
 		if (il) hipLaunchKernelGGL((marchTilesKernel<true, false, true, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);
 		else hipLaunchKernelGGL((marchTilesKernel<true, false, false, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);

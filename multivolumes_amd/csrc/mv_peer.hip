@@ -1,17 +1,21 @@
 // mv_peer.hip -- synchronisation of the peer-store transport (mv_dist_init_peer; SURVEY 8e "7 simultaneous direct peer writes").
 //
-// In this transport there are no collectives: the kernels that produce a frame's light-map share, cube faces and screen rows store
-// them straight into every rank's copy (mv_kernels.hpp storeToPeers), over xGMI peer mappings.  What is left of a collective is its
+// In this transport there are no collectives: behind the kernels that produce a frame's light-map share, cube faces and screen rows a
+// push kernel copies them straight into every rank's buffers, over xGMI peer mappings (below).  What is left of a collective is its
 // ordering, and that is one flag per (rank, stage, chain): a rank RAISES its column of a row in every rank's flag block when a stage
 // of a frame is complete on its side, and WAITS until every column of a row of its own block has reached the frame it needs.
-// Memory model: the flag blocks are uncached device memory (hipDeviceMallocUncached); a signal is a system-scope release store made
-// by a kernel that runs behind the producing kernel on the same stream (everything that kernel stored -- written through, see
-// peerStore -- is complete and visible before the flag is); a wait polls with system-scope acquire loads in a kernel of its own, and
-// the consumer is a LATER kernel on the same stream.  That is the pattern of a collective's kernels (flag written behind the data,
-// the consumer launched behind the kernel that saw the flag), with the data path left out.
+// Memory model: the flag blocks are uncached device memory (hipDeviceMallocUncached).  Data: every store into another rank's memory is
+// a write-through store at system scope (peerStore / peerStore16: acknowledged by the memory that owns the address); a push kernel's
+// wavefronts drain them (s_waitcnt vmcnt(0)) before they count themselves in, and the workgroup that counts last raises the flags --
+// so a flag is issued only after every store it announces has been acknowledged (mv_kernels.hpp peerFoldSignal).  A wait is either a
+// one-wavefront kernel of its own in front of the consumer (peerSyncKernel: ranks that share a GPU) or the consumer's own prologue
+// (peerFoldWait: ranks that own their GPU); either way the consumer's loads of the announced data are issued behind the poll that saw
+// the flag, by a dispatch that has not read those addresses before (the buffers rotate: what a frame's peers write was last read C
+// frames ago).  This is the pattern of a collective's kernels -- flag behind the data, reads behind the flag.
 // A wait never hangs: it gives up after timeoutTicks and leaves {frame : row, column} in pinned memory, which the host turns into
 // MV_ERR_TIMEOUT at its next call.
 #include "mv_kernels.hpp"
+#include "mv_device.hpp"
 
 namespace mv
 {
@@ -73,6 +77,77 @@ void launchPeerSync(hipStream_t s, const PeerSync& a)
 	hipLaunchKernelGGL(peerSyncKernel, dim3(1), dim3(64), 0, s, a);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Push kernels: behind the light march and the composite on their stream, copy what they produced into every OTHER rank's buffers -- the
+// same byte ranges at the same offsets, every rank's buffers having one layout -- with 16-byte write-through stores, and raise the
+// flags from the last workgroup (peerFoldSignal).  One kernel where a collective needs three (pack, all-gather, unpack).  (The view
+// march stores its texels into the other ranks' cube maps itself, mv_march_tiles.hip: its stores are 8- and 4-byte texels that pair up
+// into 16 bytes inside a wavefront and overlap the marching of the other tiles; the light march's and the composite's were measured
+// both ways, profiles/r04_peer_store_forms.txt.)
+// ---------------------------------------------------------------------------------------------
+// the range [off, off + bytes) of `src` (multiples of 4 bytes) into table[p] for every p != self; thread t of n
+template <typename T>
+__device__ __forceinline__ void peerPushRange(const DeviceState& st, T* const* table, const T* src, size_t off, size_t bytes, size_t t, size_t n)
+{
+	const uint8_t* s = reinterpret_cast<const uint8_t*>(src);
+	size_t head = (16u - ((reinterpret_cast<size_t>(s) + off) & 15u)) & 15u;	// (every rank's buffer has the same alignment: allocations of the same size from the same allocator, checked at init)
+	if (head > bytes) head = bytes;
+	const size_t body = (bytes - head) >> 4, tail = bytes - head - (body << 4);
+	// Four 16-byte units per thread and batch, ALL loads in front of the stores: vmcnt counts loads and stores in order, so a load
+	// behind a write-through store waits for that store's acknowledgement from the far memory -- one unit per iteration ran at the
+	// latency of seven such acknowledgements per 16 bytes (measured: 12 MB in 31 us).
+	for (size_t i = t; i < body; i += 4u * n)
+	{
+		uint4 v[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4u; ++j) if (i + j * n < body) v[j] = *reinterpret_cast<const uint4*>(s + off + head + ((i + j * n) << 4));
+#pragma unroll
+		for (uint32_t j = 0; j < 4u; ++j)
+			if (i + j * n < body)
+				for (uint32_t p = 0; p < st.peerCount; ++p)
+					if (p != st.shardIndex) peerStore16(reinterpret_cast<uint8_t*>(table[p]) + off + head + ((i + j * n) << 4), v[j]);
+	}
+	// (the few words in front of and behind the aligned body)
+	for (size_t i = t; i < (head + tail) >> 2; i += n)
+	{
+		const size_t o = off + (i < (head >> 2) ? (i << 2) : head + (body << 4) + ((i - (head >> 2)) << 2));
+		const uint32_t v = *reinterpret_cast<const uint32_t*>(s + o);
+		for (uint32_t p = 0; p < st.peerCount; ++p)
+			if (p != st.shardIndex) peerStore(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(table[p]) + o), v);
+	}
+}
+
+// this rank's layers of the relit volume's light map (kFlagLightLayers, lightLayersOfRank: a layer is 4 z slices of L x L whole cells, contiguous)
+__global__ __launch_bounds__(256) void peerPushLightKernel(DeviceState st)
+{
+	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
+	const uint32_t count = st.counters[0];
+	// CSRayMarchL.hlsl:29-33 (mv_kernels.hip relitVolume)
+	const uint32_t volumeId = count ? st.visibleVolumes[cb->frameIdx % count] : cb->frameIdx % st.V;
+	const size_t mapOff = reinterpret_cast<const uint8_t*>(st.lightTable[volumeId]) - reinterpret_cast<const uint8_t*>(st.lightBuffers);
+	const uint32_t B = (st.L + 3u) >> 2;
+	const size_t slice = (size_t)st.L * st.L * sizeof(uint4);
+	const uint32_t mine = lightLayersOfRank(B, st.shardIndex, st.shardCount);
+	for (uint32_t i = 0; i < mine; ++i)
+	{
+		const uint32_t layer = lightLayerOfRank(B, st.shardIndex, st.shardCount, i);
+		const uint32_t z0 = layer * 4u, z1 = z0 + 4u < st.L ? z0 + 4u : st.L;
+		peerPushRange(st, st.peerLight, st.lightBuffers, mapOff + (size_t)z0 * slice, (size_t)(z1 - z0) * slice, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+	}
+	peerFoldSignal(st);
+}
+
+// this rank's block of the rank-major frame buffer (kFlagInterleaveRows: rowsPerRank tile rows of 8 pixel rows)
+__global__ __launch_bounds__(256) void peerPushRowsKernel(DeviceState st)
+{
+	const size_t block = (size_t)st.rowsPerRank * 8u * st.W * sizeof(uint2);
+	peerPushRange(st, st.peerComposite, st.composite, (size_t)st.shardIndex * block, block, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+	peerFoldSignal(st);
+}
+
+void launchPeerPushLight(hipStream_t s, const DeviceState& st) { hipLaunchKernelGGL(peerPushLightKernel, dim3(128), dim3(256), 0, s, st); }
+void launchPeerPushRows(hipStream_t s, const DeviceState& st) { hipLaunchKernelGGL(peerPushRowsKernel, dim3(128), dim3(256), 0, s, st); }
+
 // ---- self-test of the mappings: rank r writes a pattern into words [r * wordsPerRank, (r + 1) * wordsPerRank) of every rank's buffer ----
 __device__ __forceinline__ uint2 peerPatternWord(uint32_t rank, size_t i, uint32_t salt)
 {
@@ -87,7 +162,7 @@ __global__ __launch_bounds__(256) void peerPatternKernel(uint2* const* table, ui
 		const uint2 v = peerPatternWord(self, i, salt);
 		for (uint32_t p = 0; p < world; ++p)
 			if (p == self) table[p][(size_t)self * wordsPerRank + i] = v;
-			else peerStore(table[p] + (size_t)self * wordsPerRank + i, v);
+			else { peerStore(&table[p][(size_t)self * wordsPerRank + i].x, v.x); peerStore(&table[p][(size_t)self * wordsPerRank + i].y, v.y); }
 	}
 }
 

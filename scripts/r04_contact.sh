@@ -1,14 +1,12 @@
-mkdir -p gpurun_out/r04e
+mkdir -p gpurun_out/r04j
 export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 1200 python -m pytest tests/test_dist_frame_loop.py -m gpu -q -k "peer and not eight and not side" 2>&1 | tail -3
+for t in peer callbacks; do
+  timeout 600 ./examples/dist_rank_cost.bin 400 8 -1 0 C3 $t 2>&1 | sed "s/^/$t: /"
+done
 cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-MV_OUT=$PWD/gpurun_out/r04e/plain.so ./multivolumes_amd/csrc/build.sh -DMV_PEER_PLAIN_STORES > /tmp/build_plain.log 2>&1 || tail -5 /tmp/build_plain.log
-cp multivolumes_amd/libmultivolumes_amd.so gpurun_out/r04e/product.so
-for v in product plain; do
-cp gpurun_out/r04e/$v.so multivolumes_amd/libmultivolumes_amd.so
-for t in peer peer-nofold; do
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r04e/trace_$t -- ./examples/dist_rank_cost.bin 400 8 2 0 C3 $t > gpurun_out/r04e/trace_$t.log 2>&1
-echo "== $v $t"; python3 scripts/timeline.py gpurun_out/r04e/trace_$t 2>&1 | head -22 | cut -c1-100
-rm -rf gpurun_out/r04e/trace_$t
+for t in peer; do
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r04j/trace_$t -- ./examples/dist_rank_cost.bin 400 8 2 0 C3 $t > gpurun_out/r04j/trace_$t.log 2>&1
+python3 scripts/timeline.py gpurun_out/r04j/trace_$t > gpurun_out/r04j/rank_timeline_$t.txt 2>&1; head -28 gpurun_out/r04j/rank_timeline_$t.txt | cut -c1-110
+rm -rf gpurun_out/r04j/trace_$t
 done
-done
-rm -f gpurun_out/r04e/*.so*

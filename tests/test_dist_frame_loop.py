@@ -69,7 +69,7 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     in flight (a depth-map setter does), so up to three frames -- collectives included -- really overlap between checkpoints.
     "peer": the chains schedule on the peer-store transport -- no collectives, every rank's kernels store into every rank's buffers
     through IPC mappings, flags instead of all-gathers (csrc/mv_peer.hip).  "peer-folded": the form ranks that own their GPU run -- the
-    flags raised and waited for inside the marches and the composite -- forced here on two and three ranks that share one."""
+    waits folded into the marches and the composite -- forced here on two and three ranks that share one."""
     frames = 26
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
