@@ -66,6 +66,28 @@ CPU_BUDGET = _host_cpu_budget()
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def roofline_fraction(alg_bytes, requested_bytes, traffic_bytes, launch_ms):
+    """roofline.achieved / frac of the dominant kernel: SURVEY 8(d)'s algorithmic bytes per launch over the launch's duration while that
+    is a fraction (<= 1: the headline config); otherwise the bytes the launch requested from the memory system (the algorithmic bytes
+    minus the samples whose brick-occupancy bit spared the fetch), and if cache hits make even that exceed the peak, the measured HBM
+    traffic."""
+    if not launch_ms or launch_ms <= 0:
+        return {"achieved": 0.0, "frac": None, "frac_basis": None}
+    gbs = lambda b: b / (launch_ms * 1e-3) / 1e9
+    alg = gbs(alg_bytes)
+    if alg <= HBM_PEAK_GBS:
+        return {"achieved": alg, "frac": alg / HBM_PEAK_GBS, "frac_basis": "algorithmic bytes (SURVEY 8d: 64 B / view sample + 32 B / lit sample + 16 B / ray)"}
+    out = {"frac_algorithmic_uncapped": alg / HBM_PEAK_GBS, "achieved_algorithmic_uncapped": alg}
+    req = gbs(requested_bytes)
+    if req <= HBM_PEAK_GBS:
+        out.update({"achieved": req, "frac": req / HBM_PEAK_GBS, "frac_basis": "requested bytes (algorithmic bytes without the fetch-free samples): the algorithmic figure exceeds the peak on this workload"})
+    elif traffic_bytes:
+        out.update({"achieved": gbs(traffic_bytes), "frac": gbs(traffic_bytes) / HBM_PEAK_GBS, "frac_basis": "measured HBM traffic (rocprofv3 PMC): algorithmic and requested bytes both exceed the peak (cache hits)"})
+    else:
+        out.update({"achieved": HBM_PEAK_GBS, "frac": 1.0, "frac_basis": "capped: algorithmic and requested bytes exceed the peak and no traffic measurement matches these sources"})
+    return out
+
+
 def march_source_hash():
     """Hash of the sources that decide the view march's memory traffic: profiles/traffic.json carries the hash it was measured
     at, and a stale measurement is not reported (scripts/make_profiles.sh regenerates it)."""
@@ -98,10 +120,12 @@ def parse():
     p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
     p.add_argument("--frames-in-flight", type=int, default=0, help="whole frames in flight = view streams = output sets (2..5; 0 = the library's default, 3)")
-    p.add_argument("--transport", default="auto", choices=["auto", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
-                   help="--gpus > 1: auto = the library's own RCCL communicators with whole frames on three view streams, and -- only if that "
-                        "fails or stops making progress -- the next of: RCCL with one view stream, torch.distributed's NCCL group through "
-                        "callbacks, gloo through host memory (the line says which one ran: config.transport, config.fallback_level)")
+    p.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
+                   help="--gpus > 1: auto = the peer-store transport (no collectives: every rank's kernels store into every rank's buffers over "
+                        "IPC mappings, flags instead of all-gathers), and -- only if that fails its self-test, fails or stops making progress -- "
+                        "the next of: the library's own RCCL communicators with one view stream (two communicators, one collective in flight "
+                        "per stream), RCCL with whole frames on three view streams, torch.distributed's NCCL group through callbacks, gloo through "
+                        "host memory (the line says which one ran: config.transport, config.fallback_level)")
     return p.parse_args()
 
 
@@ -116,7 +140,9 @@ def parse():
 # to exercise while it was written: if a rank dies or stops making progress, every supervisor kills its child (a fresh process each
 # time: nothing is exec'ed from a process that has touched the GPU) and all move to the next, more conservative transport together.
 # ---------------------------------------------------------------------------------------------------------------------
-LEVELS = ["rccl", "rccl-single-stream", "torch-nccl", "gloo"]
+# (the conservative RCCL schedule in front of the one that keeps three communicators busy on three streams of a device, until a box with
+# more than one GPU has run tests/test_rccl_multi_gpu.py)
+LEVELS = ["peer", "rccl-single-stream", "rccl", "torch-nccl", "gloo"]
 PHASE_TIMEOUT_S = {"start": 420.0, "setup": 420.0, "dist-init": 180.0, "warmup": 240.0, "timed": 240.0, "roofline": 240.0, "report": 600.0}
 
 
@@ -166,7 +192,9 @@ def supervise(args, world, rank):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo")
     share = os.environ.get("MV_BENCH_SHARE_GPU") == "1"
-    levels = ["gloo"] if share else LEVELS if args.transport == "auto" else [args.transport]
+    levels = (["peer", "gloo"] if args.transport == "auto" else [args.transport]) if share else LEVELS if args.transport == "auto" else [args.transport]
+    if args.dist_single_stream:
+        levels = [l for l in levels if l != "peer"] or levels  # (the peer-store transport runs whole-frame chains only)
     rc = 1
     for level, transport in enumerate(levels):
         port = [_free_port() if rank == 0 else 0]
@@ -231,7 +259,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    transport = os.environ.get("MV_BENCH_TRANSPORT", "rccl" if args.transport == "auto" else args.transport)
+    transport = os.environ.get("MV_BENCH_TRANSPORT", "peer" if args.transport == "auto" else args.transport)
     if transport == "rccl-single-stream":
         args.dist_single_stream = True
     if not torch.cuda.is_available():
@@ -244,7 +272,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu or transport == "gloo":
+        if share_gpu or transport in ("gloo", "peer"):  # (peer stores: torch.distributed only carries the IPC handles and the final sums -- no RCCL anywhere)
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -321,7 +349,12 @@ def main():
     from multivolumes_amd import distributed as D
     # N > 1: the per-frame protocol runs inside the library (mv_dist_frame); torch.distributed only distributes the RCCL ids
     phase("dist-init")
-    exchange = D.init_frame_loop(caster, prefer_rccl=transport in ("rccl", "rccl-single-stream")) if world > 1 else None
+    exchange = D.init_frame_loop(caster, prefer_rccl=transport in ("rccl", "rccl-single-stream"), prefer_peer=transport == "peer",
+                                 peer_timeout_ms=20000) if world > 1 else None
+    if world > 1 and transport == "peer" and exchange != "peer":
+        # (asked for by name or by the ladder: a rank that could not attach it leaves, and the supervisors move everybody to the next level)
+        print(f"bench.py: the peer-store transport could not be attached (got {exchange})", file=sys.stderr)
+        return 3
     phase("warmup")
     H, W = cfg["H"], cfg["W"]
     band = D.row_range(H, rank, world)
@@ -411,7 +444,21 @@ def main():
 
     # max time over ranks, sum of samples over ranks
     phase("report")
+    per_rank_ms, ranks_agree = None, None
     if world > 1:
+        # every rank's own time for the K frames (the line's ms_per_step is their maximum), and whether the ranks ended up with the same
+        # frame: with the peer-store transport and the all-gathers alike every rank holds the whole image
+        import zlib
+        mine = [None] * world
+        dist.all_gather_object(mine, (dt / args.steps * 1e3, zlib.crc32(caster.ReadBackComposite().tobytes()) if do_composite else 0))
+        per_rank_ms = [round(m[0], 5) for m in mine]
+        ranks_agree = len(set(m[1] for m in mine)) == 1
+        if not ranks_agree:
+            # a transport that delivered different images to different ranks is a failed transport: no line, and the supervisors move on
+            if rank == 0:
+                print(f"bench.py: the ranks do not hold the same frame after the run (transport {exchange}): {[hex(m[1]) for m in mine]}", file=sys.stderr)
+            caster.close()
+            return 4
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -486,23 +533,29 @@ def main():
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
-                "parallelism": f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, the frame's light march shared out by voxel blocks + all-gather of the shares; frame loop inside the library (mv_dist_frame), transport: {exchange}" if world > 1 else "single GPU",
+                "parallelism": (f"{world} ranks, peer stores (no collectives): cube-map volumes dealt per frame by estimated march cost, the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, rows pushed into every rank's frame buffer; the frame's light march shared out by layers of voxel blocks, pushed into every rank's light map; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
+                                else f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, the frame's light march shared out by voxel blocks + all-gather of the shares; frame loop inside the library (mv_dist_frame), transport: {exchange}") if world > 1 else "single GPU",
                 "frames_in_flight": ("up to 3 whole frames (light march, view march, composite) on 3 view streams; constants / cull 4 slots, march outputs 3 sets, light maps 3 buffers per volume" if world == 1
                                      else "upload + cull + light march ahead of the view march / exchange / composite stream" if args.dist_single_stream
                                      else "up to 3 whole frames (light-march share + all-gather, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
-                "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + ("+cube-face all-gather" if world > 1 else "") + ("+OIT composite" if do_composite else ""),
+                "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + (("+peer stores" if exchange == "peer" else "+cube-face all-gather") if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes_timed // max(1, K),
                 "transport": exchange, "fallback_level": int(os.environ.get("MV_BENCH_LEVEL", "0")),
+                "transport_ladder": LEVELS if world > 1 else None,
                 "rccl_ranks": caster.DistInfo()["ranks"] if world > 1 else None,
+                "ms_per_step_per_rank": per_rank_ms, "ranks_hold_the_same_frame": ranks_agree,
             },
             "kernel_ms": k_alone, "kernel_ms_in_flight": k_in_flight,
             "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,
             "light_msamples_per_s": tot_light / dt / 1e6,
             "roofline": {"bound": "hbm", "kernel": "marchViewKernel (mv_march.hip ray queue)" if args.ray_queue else "marchTilesKernel",
                          # SURVEY 8(d)'s figure: the a3 loop over cube-face texels -- 64 B per view sample + 32 B per lit sample + 16 B per ray, counted
-                         # for the launches of the timed region -- over the launch's HIP-event duration
-                         "achieved": alg_a3 / (ms_v * 1e-3) / 1e9 if ms_v > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (alg_a3 / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_v > 0 else None,
+                         # for the launches of the timed region -- over the launch's HIP-event duration.  A fraction of a roofline cannot exceed 1:
+                         # on workloads whose samples are mostly served without HBM (C3-stress: six faces at mip 0, 60 % of the samples fetch-free
+                         # or cache hits) the algorithmic figure does, and the line then prices the bytes the launch REQUESTED (frac_basis says
+                         # which; the algorithmic one stays beside it as frac_algorithmic_uncapped)
+                         **roofline_fraction(alg_a3, alg_bytes - 64 * st.get("fetch_free_samples", 0) / K, traffic, ms_v),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "traffic": traffic, "traffic_source": traffic_note,
                          # `achieved` / `frac` price ALGORITHMIC bytes (64 B per sample whether or not its texels were fetched or came from
                          # cache): they can exceed what HBM delivers.  What HBM really moved per launch is `traffic`:

@@ -1,3 +1,7 @@
+// experiments/mv_march_tiles_experiments.hip -- the tile march WITH its measured-and-rejected variants (LDS brick staging, speculation,
+// s_setprio by cost bin: profiles/r03_lds_staging.txt, r03_speculation.txt, r03_view_march_tail.txt).  Not part of the product: csrc/build.sh
+// compiles this file in place of mv_march_tiles.hip only when one of -DMV_TILE_STAGE / -DMV_TILE_SPECULATE_BELOW / -DMV_TILE_PRIORITY is
+// on its command line (scripts/check_switches.sh keeps them building and bit-identical).  No peer-store instantiation here.
 // mv_march_tiles.hip -- a3 (+ the fused screen-space RayCast) as one wavefront per 8x8 tile: the reference's thread-group tile
 // (Sh/CSRayMarch.hlsl:77), ray setup and sample loop in one kernel, wavefronts dispatched by the hardware in the cost-binned
 // tile order.  This is the form the context uses when a frame has only a few rays per lane of the GPU (C3: 0.66 M rays on
@@ -564,6 +568,15 @@ uint32_t marchTilesResidentWaves(int device)
 										// profiles/r03_speculation.txt) a rank's share of C3 on 8 ranks, 1.5 k tiles, 116 us -> 158 us with it -- a lone wavefront's
 										// iteration is its ~230 dependent VALU instructions, not the wait for its texels
 #endif
+uint32_t marchTilesBeyond(const DeviceState& st, uint32_t gridTiles)
+{
+	const uint64_t maxTiles = (uint64_t)st.maxTiles + st.maxScreenTiles;
+	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
+	uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
+	blocks = ((blocks + 7) / 8) * 8;
+	return blocks * kTileWaves < maxTiles ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
+}
+
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles)
 {
 	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has

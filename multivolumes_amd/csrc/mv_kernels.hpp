@@ -415,6 +415,8 @@ uint32_t lightSharePerRank(const DeviceState& st);	// voxel blocks per rank of t
 void launchLightUnpack(hipStream_t s, const DeviceState& st, const uint32_t* words);	// the all-gathered shares (64 words per block, lightSharePerRank blocks per rank) into the relit volume's light map
 uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTiles);	// returns the first slot its grid does not cover (0xffffffff: none)
 uint32_t marchTilesBeyond(const DeviceState& st, uint32_t gridTiles);	// what launchMarchTiles would return for that estimate, without launching
+bool marchTilesNarrow(const DeviceState& st, uint64_t tiles);	// a launch of that many tiles takes the latency-oriented form (mv_march_narrow.hip: eight lanes per ray, speculative requests)
+void launchMarchTilesNarrow(hipStream_t s, const DeviceState& st, uint32_t blocks);	// one workgroup per dispatch slot
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)

@@ -345,16 +345,27 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 }
 
 
-static uint64_t marchTilesBlocks(const DeviceState& st, uint32_t gridTiles)
+// the main launch's grid for the host's estimate of the frame's tile count, and the tiles it covers: one wavefront per tile, kTileWaves
+// per workgroup (-DMV_TILE_NARROW_BELOW builds: the narrow form's one workgroup per tile below that many tiles)
+static uint64_t marchTilesBlocks(const DeviceState& st, uint32_t gridTiles, bool* narrow, uint64_t* covered)
 {
 	const uint64_t maxTiles = (uint64_t)st.maxTiles + st.maxScreenTiles;
 	const uint64_t tiles = gridTiles < maxTiles ? (gridTiles ? gridTiles : 1u) : maxTiles;
-	const uint64_t blocks = (tiles + kTileWaves - 1) / kTileWaves;
-	return ((blocks + 7) / 8) * 8;
+#ifdef MV_TILE_NARROW_BELOW	// (an experiment: csrc/experiments/mv_march_narrow.hip, eight lanes per ray -- measured slower at every size)
+	*narrow = marchTilesNarrow(st, tiles);
+#else
+	*narrow = false;
+#endif
+	const uint64_t perBlock = *narrow ? 1u : kTileWaves;
+	uint64_t blocks = (tiles + perBlock - 1) / perBlock;
+	blocks = ((blocks + 7) / 8) * 8;
+	*covered = blocks * perBlock;
+	return blocks;
 }
 uint32_t marchTilesBeyond(const DeviceState& st, uint32_t gridTiles)
 {
-	const uint64_t covered = marchTilesBlocks(st, gridTiles) * kTileWaves;
+	bool narrow; uint64_t covered;
+	marchTilesBlocks(st, gridTiles, &narrow, &covered);
 	return covered < (uint64_t)st.maxTiles + st.maxScreenTiles ? (uint32_t)covered : 0xffffffffu;
 }
 
@@ -363,7 +374,11 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	// gridTiles: the host's estimate of this frame's tile count (the cull's latest report + a margin; anything large when it has
 	// none).  The grid covers min(estimate, largest possible frame); returns the first dispatch slot beyond it (what the overflow
 	// launch has to cover), or 0xffffffff if the grid covers every frame there can be.
-	const uint64_t blocks = marchTilesBlocks(st, gridTiles);
+	bool narrow; uint64_t covered;
+	const uint64_t blocks = marchTilesBlocks(st, gridTiles, &narrow, &covered);
+#ifdef MV_TILE_NARROW_BELOW
+	if (narrow) { launchMarchTilesNarrow(s, st, (uint32_t)blocks); return marchTilesBeyond(st, gridTiles); }
+#endif
 	const bool il = st.flags & kFlagInterleaveRows;
 	const dim3 grid((uint32_t)blocks), block(64 * kTileWaves);
 	const bool lut = st.N <= kLutMaxN && MV_TILE_LUT != 0;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on an MI355X box (run through gpurun from the repo root). Round tag in $1 (default r02).
-R=${1:-r02}
+R=${1:-r04}
 OUT=/root/repo/gpurun_out/profiles_$R
 rm -rf $OUT; mkdir -p $OUT
 cd /root/repo
@@ -8,6 +8,8 @@ HASH=$(python3 -c "import bench; print(bench.march_source_hash())")
 # 1. HBM traffic of every kernel: FETCH_SIZE / WRITE_SIZE in separate --pmc passes (no API tracing), C3 and C3-stress
 bash scripts/pmc.sh c3 "" FETCH_SIZE WRITE_SIZE > $OUT/pmc_c3.txt 2>&1
 bash scripts/pmc.sh c3s "--stress" FETCH_SIZE WRITE_SIZE > $OUT/pmc_c3_stress.txt 2>&1
+bash scripts/pmc.sh c2 "--config C2" FETCH_SIZE WRITE_SIZE > $OUT/pmc_c2.txt 2>&1
+bash scripts/pmc.sh c5 "--config C5" FETCH_SIZE WRITE_SIZE > $OUT/pmc_c5.txt 2>&1
 python3 - $OUT $R $HASH <<'PY'
 import json, re, sys
 out, R, H = sys.argv[1], sys.argv[2], sys.argv[3]
@@ -15,7 +17,7 @@ res = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE i
                "hbm_bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: on gfx950 FETCH_SIZE reports half the fetched bytes (MI355X_MICROARCH.md; calibrated on retileKernel: 134217728 B read -> 65564 KB)",
        "source_hash": H, "configs": {}}
 traffic = {"source_hash": H}
-for tag, name in (("c3", "C3"), ("c3_stress", "C3-stress")):
+for tag, name in (("c3", "C3"), ("c3_stress", "C3-stress"), ("c2", "C2"), ("c5", "C5")):
     k = {}
     for line in open(f"{out}/pmc_{tag}.txt"):
         m = re.match(r"(FETCH_SIZE|WRITE_SIZE)\s+(.+?)\s+n\s+\d+\s+mean\(last 8\)\s+(\S+)", line)

@@ -1,12 +1,9 @@
-mkdir -p gpurun_out/r04j
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-timeout 1200 python -m pytest tests/test_dist_frame_loop.py -m gpu -q -k "peer and not eight and not side" 2>&1 | tail -3
-for t in peer callbacks; do
-  timeout 600 ./examples/dist_rank_cost.bin 400 8 -1 0 C3 $t 2>&1 | sed "s/^/$t: /"
+mkdir -p gpurun_out/r04n
+for nb in 0 128 2048; do
+MV_OUT=$PWD/gpurun_out/r04n/nb$nb.so ./multivolumes_amd/csrc/build.sh -DMV_TILE_NARROW_BELOW=$nb > /tmp/b.log 2>&1 || tail -3 /tmp/b.log
+for cfgn in T1 T2 C1 C2; do
+MV_LIB_PATH=$PWD/gpurun_out/r04n/nb$nb.so python bench.py --config $cfgn --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('narrow below $nb', '$cfgn', 'frame ms', round(j['ms_per_step'],4), 'view march alone ms', round(j['roofline']['launch_ms'],4), 'rays', j['config']['rays_per_frame'])"
 done
-cd /tmp && export TMPDIR=/tmp && cd - > /dev/null
-for t in peer; do
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/r04j/trace_$t -- ./examples/dist_rank_cost.bin 400 8 2 0 C3 $t > gpurun_out/r04j/trace_$t.log 2>&1
-python3 scripts/timeline.py gpurun_out/r04j/trace_$t > gpurun_out/r04j/rank_timeline_$t.txt 2>&1; head -28 gpurun_out/r04j/rank_timeline_$t.txt | cut -c1-110
-rm -rf gpurun_out/r04j/trace_$t
 done
+rm -f gpurun_out/r04n/*.so*

@@ -46,6 +46,10 @@ def test_two_ranks_on_one_gpu(extra):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["exchange_bytes_per_frame"] > 0
+    # the first rung of the ladder: the peer-store transport (IPC mappings work between ranks that share a GPU) -- except for the
+    # single-view-stream schedule, which it does not run; every rank ends with the same frame, and the line says what every rank took
+    assert d["config"]["transport"] == ("torch-callbacks" if "--dist-single-stream" in extra else "peer"), d["config"]["transport"]
+    assert d["config"]["ranks_hold_the_same_frame"] is True and len(d["config"]["ms_per_step_per_rank"]) == 2
     assert d["cpu_baseline"]["gpu_vs_oracle_max_abs_err"] == 0.0
     # the same frame on one rank: the sharded run marches the same samples
     one = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + [e for e in extra if e != "--dist-single-stream"], 240)
@@ -65,7 +69,7 @@ def test_bench_starts_and_supervises_its_ranks():
     r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2"], 400, env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["transport"] == "torch-callbacks"
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["transport"] == "peer" and d["config"]["fallback_level"] == 0
     bad = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "T2", "--steps", "2", "--warmup", "1"], 120,
                     dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE" in bad.stderr and not [l for l in bad.stdout.splitlines() if l.startswith("{")]

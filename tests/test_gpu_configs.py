@@ -3,7 +3,8 @@ and the C4 shape (C3's 16 x 256^3 frame sharded over 4 contexts on one GPU, bit 
 plus the moving-depth-map schedule of frames in flight at C3 size.
 
 The oracle cannot march a whole C5 frame in seconds, so C5 is checked through size-independent properties (idempotence,
-counters against the cull, finite alpha in [0, 1]) and an oracle spot check of one volume and one composite row band.
+counters against the cull, finite alpha in [0, 1]) and oracle checks of five relit light maps (64 volumes x 256^3), of four volumes'
+view march fed the oracle's light maps, and of one composite row band.
 """
 import numpy as np
 import pytest
@@ -80,17 +81,37 @@ def test_c5_full_size_properties(oracle, flags):
         a = half_to_float(img1)
         assert np.all(np.isfinite(a)) and np.all((a[..., 3] >= 0) & (a[..., 3] <= 1.0)) and (a[..., 3] > 0).mean() > 0.2
 
-        # oracle spot checks, bit for bit: the largest cube-map volume's view march, then a band of the composite
-        # (the oracle composites from the GPU's own cube maps / light maps: it checks compositeKernel at 64 volumes, 2048^2)
+        # Oracle checks at the full size, bit for bit.
+        # (1) the light march (CSRayMarchL.hlsl:77-110: the loop over all 64 volumes, pool addresses beyond 4 GiB): the ORACLE relights five
+        # visible volumes -- frame f relights vis[f % count], and a relit map depends on the volumes' alpha only, not on other light
+        # maps -- among them the four the view march is checked on below; each equals the GPU's map of that volume.
         vols = [rc.synth_volume(N, k) for k in range(V)]
-        v = int(max(cube, key=lambda u: -int(info[u, 0])))
+        from tests.helpers import default_descs, host_frame
+        descs = default_descs(V, V, N)
+        _, vp0, svp0, _, _ = host_frame(cfg, 0)
+        _, shadow = scene.depth_and_shadow(cfg, vp0, svp0, M)
+        by_cost = sorted((int(u) for u in cube), key=lambda u: (int(info[u, 0]), -bin(int(info[u, 2]) & 0x3F).count("1")))
+        picked = [by_cost[0], by_cost[len(by_cost) // 3], by_cost[2 * len(by_cost) // 3], by_cost[-1]]  # near and far, mip 0 and beyond
+        extra = next(int(u) for u in vis if int(u) not in picked)
+        vis_list = [int(u) for u in vis]
+        lms_oracle = np.zeros((V, L, L, L), np.uint32)
+        for u in picked + [extra]:
+            f = vis_list.index(u)
+            _, _, _, cb_f, po_f = host_frame(cfg, f)
+            vid, lm_f, n_f = oracle.march_light(V, N, L, M, vols, descs, po_f, cb_f, shadow, None, vis, cfg["maxLight"])
+            assert vid == u and n_f > 0
+            assert np.array_equal(lm_f[u], c.ReadBackLightMap(u)), f"light map of volume {u} (relit in frame {f}) differs from the oracle's"
+            lms_oracle[u] = lm_f[u]
+        # (2) the view march of those four cube-map volumes, fed the ORACLE's light maps (not the GPU's own)
+        cm, cd, _ = oracle.march_view(V, N, L, W, H, vols, lms_oracle, fr["depth"], c.perObject, c.cbPerFrame, info, picked)
+        for v in picked:
+            mip = int(info[v, 0])
+            assert np.array_equal(oracle.cube_face_view(cm[v], N, mip), first[v][0]), v
+            assert np.array_equal(oracle.cube_face_view(cd[v], N, mip), first[v][1]), v
+        # (3) a band of the composite (the oracle composites from the GPU's cube maps and light maps: compositeKernel at 64 volumes, 2048^2)
         lms = np.zeros((V, L, L, L), np.uint32)
         for u in vis:
             lms[u] = c.ReadBackLightMap(int(u))
-        cm, cd, _ = oracle.march_view(V, N, L, W, H, vols, lms, fr["depth"], c.perObject, c.cbPerFrame, info, [v])
-        mip = int(info[v, 0])
-        assert np.array_equal(oracle.cube_face_view(cm[v], N, mip), first[v][0])
-        assert np.array_equal(oracle.cube_face_view(cd[v], N, mip), first[v][1])
         chain = oracle.cube_chain_texels(N)
         cms = np.zeros((V, chain, 4), np.uint16)
         cds = np.zeros((V, chain), np.float32)
