@@ -119,6 +119,8 @@ def parse():
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
     p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
+    p.add_argument("--rows-to-root", action="store_true", help="--gpus > 1, peer-store transport: the ranks push their screen rows to rank 0 only (SURVEY 8e: 'gather tiles to rank 0') "
+                   "instead of to every rank; the end-of-run check that every rank holds the same frame is then left out")
     p.add_argument("--frames-in-flight", type=int, default=0, help="whole frames in flight = view streams = output sets (2..5; 0 = the library's default, 3)")
     p.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
                    help="--gpus > 1: auto = the peer-store transport (no collectives: every rank's kernels store into every rank's buffers over "
@@ -297,6 +299,11 @@ def main():
             print("warning: --no-pipeline is ignored with --gpus > 1", file=sys.stderr)
         pipelined = True
         flags |= _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if args.dist_single_stream else 0)
+        if transport == "peer" and not args.dist_single_stream and args.frames_in_flight == 0:
+            # a rank's frame is a chain of short kernels: four whole frames in flight on the four hardware queues, every frame's upload
+            # and cull on its own view stream (profiles/r04_peer_rank_cost.txt)
+            flags |= _lib.MV_FLAG_CULL_ON_VIEW_STREAM
+            args.frames_in_flight = 4
     # a real (non-blocking) torch stream, made current so that the RCCL collectives of the multi-GPU path are ordered on it too:
     # torch's default is the legacy null stream, whose implicit synchronisation rules cost the pipelined frame ~20 %
     if os.environ.get("MV_BENCH_NULL_STREAM", "0") != "1":
@@ -350,7 +357,7 @@ def main():
     # N > 1: the per-frame protocol runs inside the library (mv_dist_frame); torch.distributed only distributes the RCCL ids
     phase("dist-init")
     exchange = D.init_frame_loop(caster, prefer_rccl=transport in ("rccl", "rccl-single-stream"), prefer_peer=transport == "peer",
-                                 peer_timeout_ms=20000) if world > 1 else None
+                                 peer_timeout_ms=20000, peer_rows_to_root=args.rows_to_root) if world > 1 else None
     if world > 1 and transport == "peer" and exchange != "peer":
         # (asked for by name or by the ladder: a rank that could not attach it leaves, and the supervisors move everybody to the next level)
         print(f"bench.py: the peer-store transport could not be attached (got {exchange})", file=sys.stderr)
@@ -452,7 +459,7 @@ def main():
         mine = [None] * world
         dist.all_gather_object(mine, (dt / args.steps * 1e3, zlib.crc32(caster.ReadBackComposite().tobytes()) if do_composite else 0))
         per_rank_ms = [round(m[0], 5) for m in mine]
-        ranks_agree = len(set(m[1] for m in mine)) == 1
+        ranks_agree = True if (args.rows_to_root and exchange == "peer") else len(set(m[1] for m in mine)) == 1
         if not ranks_agree:
             # a transport that delivered different images to different ranks is a failed transport: no line, and the supervisors move on
             if rank == 0:
@@ -543,7 +550,7 @@ def main():
                 "transport": exchange, "fallback_level": int(os.environ.get("MV_BENCH_LEVEL", "0")),
                 "transport_ladder": LEVELS if world > 1 else None,
                 "rccl_ranks": caster.DistInfo()["ranks"] if world > 1 else None,
-                "ms_per_step_per_rank": per_rank_ms, "ranks_hold_the_same_frame": ranks_agree,
+                "ms_per_step_per_rank": per_rank_ms, "ranks_hold_the_same_frame": None if (args.rows_to_root and exchange == "peer") else ranks_agree,
             },
             "kernel_ms": k_alone, "kernel_ms_in_flight": k_in_flight,
             "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,

@@ -79,6 +79,12 @@ extern "C" {
 										   a ray queue: ballot compaction) instead of one wavefront per 8x8 tile.  Same results bit for bit; it pays when
 										   a frame has many rays per lane of the GPU */
 
+#define MV_FLAG_CULL_ON_VIEW_STREAM 32u	/* with MV_FLAG_PIPELINE_FRAMES (not MV_FLAG_SINGLE_VIEW_STREAM): no stream of its own for the constant upload and the cull --
+											   frame i's go in front of it on view stream i mod C.  That frees one of the four hardware queues a HIP process has:
+											   FOUR whole frames in flight (frames_in_flight = 4) without streams sharing a queue -- what a rank of the multi-GPU
+											   loop wants, whose frame is a chain of short kernels (profiles/r04_peer_rank_cost.txt).  On one GPU, where the
+											   marches fill the device and the cull must run ahead of them, leave it off.  Results are identical. */
+
 typedef struct mv_ctx mv_ctx;
 
 typedef struct mv_config
@@ -236,7 +242,7 @@ void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */
 #define MV_BUF_COMPOSITE 5
 #define MV_BUF_DEPTH_MAP 6
 #define MV_BUF_SHADOW_MAP 7
-#define MV_BUF_TILE_COST 9		/* index = frame slot (0..3): the view march's tile cost table, uint32 per key: longest ray's samples + 1, 0 = never marched (diagnostics) */
+#define MV_BUF_TILE_COST 9		/* the view march's tile cost table (one for all frame slots; index < frame slots accepted), uint32 per key: longest ray's samples + 1, 0 = never marched (diagnostics) */
 #define MV_BUF_VOLUME_FLAGS 10	/* the cull's per-volume word of the current frame slot, uint32: bit 0 visible, bit 1 cube-map scheme, bits 2-4 mip, bits 5-10 marched faces, bits 16-31 the rank that marches the volume's cube map (sharded contexts; v % shard_count, or the cost deal inside mv_dist_frame) */
 #define MV_BUF_EXCHANGE_OFFSETS 11	/* uint32 per volume: texel offset of its marched faces inside its owner's shard of the frame's cube-face all-gather (sharded contexts) */
 #define MV_BUF_MARCH_TIMELINE 8	/* 8 x uint64 per march wavefront; only diagnostic builds (-DMV_TIMELINE) fill it (scripts/march_timeline.py) */
@@ -326,6 +332,10 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * two force the choice (tests of the folded form on one GPU with two or three ranks; A/B timing): */
 #define MV_DIST_PEER_FOLD 2u
 #define MV_DIST_PEER_NO_FOLD 4u
+/* The ranks push their screen rows to rank 0 only ("gather tiles to rank 0"): rank 0 holds the whole frame, the other ranks'
+ * frame buffers their own rows -- 1/7 of the row traffic (C5 on 8 ranks: 4 MB per rank and frame instead of 28).  Default: every rank
+ * gets every row, as with the all-gathers. */
+#define MV_DIST_PEER_ROWS_TO_ROOT 8u
 int mv_dist_peer_export(mv_ctx* ctx, void* out /* MV_DIST_PEER_BYTES */);
 int mv_dist_init_peer(mv_ctx* ctx, const void* all /* shard_count x MV_DIST_PEER_BYTES in rank order; NULL with MV_DIST_PEER_LOOPBACK */, uint32_t flags);
 int mv_dist_set_peer_timeout_ms(mv_ctx* ctx, uint32_t ms);

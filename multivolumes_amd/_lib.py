@@ -25,6 +25,7 @@ MV_FLAG_PIPELINE_FRAMES = 2
 MV_FLAG_SINGLE_VIEW_STREAM = 4
 MV_FLAG_LIST_ORDER = 8
 MV_FLAG_RAY_QUEUE = 16
+MV_FLAG_CULL_ON_VIEW_STREAM = 32
 
 MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
 MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7
@@ -35,6 +36,7 @@ MV_DIST_PEER_BYTES = 2048
 MV_DIST_PEER_LOOPBACK = 1
 MV_DIST_PEER_FOLD = 2
 MV_DIST_PEER_NO_FOLD = 4
+MV_DIST_PEER_ROWS_TO_ROOT = 8
 MV_ABI_VERSION = 5  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)

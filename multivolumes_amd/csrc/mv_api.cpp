@@ -76,8 +76,14 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		// thousands of view-march workgroups of the previous frame, or the overlap is lost
 		int prLow = 0, prHigh = 0;
 		(void)hipDeviceGetStreamPriorityRange(&prLow, &prHigh);
-		if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
-		ctx->ownStreamA = true;
+		// MV_FLAG_CULL_ON_VIEW_STREAM: no stream A -- every frame's upload and cull go in front of it on its own view stream (mv_update_frame),
+		// which leaves a hardware queue for a fourth chain
+		ctx->cullOnChain = (cfg->flags & MV_FLAG_CULL_ON_VIEW_STREAM) && !(cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM);
+		if (!ctx->cullOnChain)
+		{
+			if (hipStreamCreateWithPriority(&ctx->streamA, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
+			ctx->ownStreamA = true;
+		}
 		// One view stream (MV_FLAG_SINGLE_VIEW_STREAM, the multi-GPU loop): the light marches get a stream of their own and two
 		// output sets rotate.  Otherwise C output sets on C view streams (mv_config.frames_in_flight, default 3), each frame's light
 		// march on its view stream.  A HIP process has four hardware queues by default, and streams that share one wait for each
@@ -106,7 +112,11 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		}
 	}
 	ctx->st.lightBufs = ctx->numOutSets > 3u ? ctx->numOutSets : 3u;
-	ctx->numSlots = ctx->st.lightBufs + 1u;
+#ifndef MV_EXTRA_FRAME_SLOTS
+#define MV_EXTRA_FRAME_SLOTS 0	// (A/B: more slots of constants + cull outputs than light buffers + 1, so that upload and cull may run further ahead of the frames in flight)
+#endif
+	ctx->numSlots = ctx->st.lightBufs + 1u + MV_EXTRA_FRAME_SLOTS;
+	if (ctx->numSlots > kMaxFrameSlots) ctx->numSlots = kMaxFrameSlots;
 	for (uint32_t i = 0; i < ctx->numSlots; ++i)
 		if (hipEventCreateWithFlags(&ctx->evStageA[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evMainDone[i], hipEventDisableTiming) != hipSuccess
 			|| hipEventCreateWithFlags(&ctx->evLight[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
@@ -232,8 +242,16 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	{
 		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, 8u * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);	// a region per cost bin
 		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
-		// per-tile cost table, one per slot: the view march of frame i writes it, the tile order of frame i + 4 reads it
-		if ((rc = devAlloc(ctx, &ctx->fb[p].tileCost, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+	}
+	// Per-tile cost table: ONE for all frame slots -- every view march writes its tiles' costs into it, every tile order reads what is there,
+	// i.e. the costs of the newest frame whose march has got that far (one or two frames back in steady state).  A table per slot (rounds
+	// 1-3) made every order four frames old, which a moving camera paid for: the silhouettes it sorts by had moved on (bench.py --orbit).
+	// The order only decides which wavefront marches which tile, so costs of mixed age -- the march writes while the order reads -- cost
+	// nothing but, at worst, a tile's place in the launch.
+	{
+		uint32_t* costs = nullptr;
+		if ((rc = devAlloc(ctx, &costs, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return bail(rc);
+		for (uint32_t p = 0; p < ctx->numSlots; ++p) ctx->fb[p].tileCost = costs;
 	}
 	if ((rc = devAlloc(ctx, &st.lightStats, (size_t)st.lightBlocks * sizeof(uint64_t))) != MV_OK) return bail(rc);
 	// (MV_FORCE_TWO_SETS: validation only -- a one-stream context that alternates output sets like a pipelined one, see scripts/soak.py)
@@ -418,36 +436,58 @@ int mv_set_viewport(mv_ctx* ctx, uint32_t w, uint32_t h)
 	if (w == st.W && h == st.H) return MV_OK;
 	MV_DRAIN(ctx);
 	MV_REQUIRE(ctx, (uint64_t)st.screenSlots * w * h < (1ull << 31), MV_ERR_INVALID_ARG, "viewport too large for the RayCast layers' 31-bit element index");
+	// Everything that depends on W x H is allocated for the new size FIRST and swapped in only when every allocation has succeeded: a
+	// failure half way leaves the context exactly as it was (old dimensions, old buffers), not with new dimensions over old, smaller buffers.
+	DeviceState next = st;
+	next.W = w; next.H = h;
+	viewportDerived(next);
+	struct Swap { void** slot; void* fresh; bool tracked; };
+	std::vector<Swap> swaps;
+	auto want = [&](auto** slot, size_t bytes, bool zero, bool tracked = true) -> int
+	{
+		void* fresh = nullptr;
+		const hipError_t e = hipMalloc(&fresh, bytes ? bytes : 16);
+		if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? MV_ERR_OUT_OF_MEMORY : MV_ERR_HIP, "mv_set_viewport: allocating for the new size", e);
+		if (zero && hipMemsetAsync(fresh, 0, bytes ? bytes : 16, ctx->stream) != hipSuccess) { (void)hipFree(fresh); return fail(ctx, MV_ERR_HIP, "mv_set_viewport: clearing a new buffer"); }
+		swaps.push_back({ reinterpret_cast<void**>(slot), fresh, tracked });
+		return MV_OK;
+	};
+	int rc = want(&ctx->ownDepth, (size_t)w * h * sizeof(float), true);
+	for (uint32_t p = 0; p < ctx->numSlots && rc == MV_OK; ++p)
+		rc = want(&ctx->fb[p].tileOrder, 8u * ((size_t)next.maxTiles + next.maxScreenTiles + 1) * sizeof(uint32_t), true);
+	uint32_t* costs = ctx->fb[0].tileCost;	// (one table for all slots)
+	if (rc == MV_OK) rc = want(&costs, (size_t)mv::tileCostKeyCount(next.V, next.N, next.maxScreenTiles) * sizeof(uint32_t), true);
+	for (uint32_t p = 0; p < ctx->numOutSets && rc == MV_OK; ++p)
+	{
+		OutBufs& f = ctx->ob[p];
+		rc = want(&f.composite, (size_t)next.W * compositeRows(next) * sizeof(uint2), true);
+		if (rc == MV_OK) rc = want(&f.screenLayers, (size_t)next.screenSlots * next.W * next.H * sizeof(float4), true);
+		if (rc == MV_OK) rc = want(&f.compositeStats, (size_t)next.compositeSlots * sizeof(uint64_t), true);
+		if (rc == MV_OK) rc = want(&f.compositeRetry, ((size_t)next.compositeSlots + 2u) * sizeof(uint32_t), true);
+		if (rc == MV_OK && ctx->rayQueue) rc = want(&f.rayRecords, ((size_t)next.maxTiles + next.maxScreenTiles) * 64 * sizeof(mv::RayRecord), false);
+		if (rc == MV_OK && ctx->rayQueue) rc = want(&f.tileInfo, ((size_t)next.maxTiles + next.maxScreenTiles) * sizeof(mv::TileInfo), false);
+	}
+	if (rc == MV_OK && ctx->rasterBits) rc = want(&ctx->rasterBits, std::max((size_t)w * h, (size_t)next.M * next.M) * sizeof(uint32_t), false, false);
+	if (rc != MV_OK)
+	{
+		for (Swap& s : swaps) (void)hipFree(s.fresh);
+		return rc;
+	}
+	// commit: pointers, then dimensions
+	uint32_t* oldCosts = ctx->fb[0].tileCost;
+	for (Swap& s : swaps)
+	{
+		void* old = s.slot == reinterpret_cast<void**>(&costs) ? static_cast<void*>(oldCosts) : *s.slot;
+		if (s.tracked) { for (void*& t : ctx->allocs) if (t == old) t = s.fresh; }
+		(void)hipFree(old);
+		*s.slot = s.fresh;
+	}
+	for (uint32_t p = 0; p < ctx->numSlots; ++p) ctx->fb[p].tileCost = costs;
 	st.W = w; st.H = h;
 	ctx->cfg.viewport_w = w; ctx->cfg.viewport_h = h;
 	viewportDerived(st);
-	int rc;
-	if ((rc = devRealloc(ctx, &ctx->ownDepth, (size_t)w * h * sizeof(float))) != MV_OK) return rc;
 	st.depthMap = ctx->ownDepth;	// (a borrowed depth map was the old viewport's: the caller hands over the new one)
 	ctx->haveDepth = false;
-	for (uint32_t p = 0; p < ctx->numSlots; ++p)
-	{
-		if ((rc = devRealloc(ctx, &ctx->fb[p].tileOrder, 8u * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return rc;
-		if ((rc = devRealloc(ctx, &ctx->fb[p].tileCost, (size_t)mv::tileCostKeyCount(st.V, st.N, st.maxScreenTiles) * sizeof(uint32_t))) != MV_OK) return rc;
-	}
-	for (uint32_t p = 0; p < ctx->numOutSets; ++p)
-	{
-		OutBufs& f = ctx->ob[p];
-		if ((rc = devRealloc(ctx, &f.composite, (size_t)st.W * compositeRows(st) * sizeof(uint2))) != MV_OK) return rc;
-		if ((rc = devRealloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return rc;
-		if ((rc = devRealloc(ctx, &f.compositeStats, (size_t)st.compositeSlots * sizeof(uint64_t))) != MV_OK) return rc;
-		if ((rc = devRealloc(ctx, &f.compositeRetry, ((size_t)st.compositeSlots + 2u) * sizeof(uint32_t))) != MV_OK) return rc;
-		if (ctx->rayQueue)
-		{
-			if ((rc = devRealloc(ctx, &f.rayRecords, ((size_t)st.maxTiles + st.maxScreenTiles) * 64 * sizeof(mv::RayRecord), false)) != MV_OK) return rc;
-			if ((rc = devRealloc(ctx, &f.tileInfo, ((size_t)st.maxTiles + st.maxScreenTiles) * sizeof(mv::TileInfo), false)) != MV_OK) return rc;
-		}
-	}
-	if (ctx->rasterBits)
-	{
-		(void)hipFree(ctx->rasterBits); ctx->rasterBits = nullptr;
-		MV_HIP(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->rasterBits), std::max((size_t)w * h, (size_t)st.M * st.M) * sizeof(uint32_t)));
-	}
 	applyParity(ctx);
 	ctx->haveCull = false;	// the frame in progress (if any) was culled for the old viewport: mv_update_frame begins the next one
 	ctx->haveFrame = false;
@@ -540,6 +580,14 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	// a new frame: the next slot of constants / cull buffers (and the other parity's march outputs)
 	ctx->slot = (ctx->slot + 1u) % ctx->numSlots;
 	++ctx->frame;
+	const uint32_t prevSlot = (ctx->slot + ctx->numSlots - 1u) % ctx->numSlots;
+	if (ctx->cullOnChain)
+	{
+		// (MV_FLAG_CULL_ON_VIEW_STREAM) this frame's stage A runs on its own view stream; what stream A's order used to give must then
+		// be said: the cull reads the previous frame's light table, VolumeInfo and view hash (lightTablePrev, volumeInfoPrev, countersPrev)
+		ctx->streamA = ctx->streamB[ctx->frame % ctx->numViewStreams];
+		MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evStageA[prevSlot]));
+	}
 	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
 	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);

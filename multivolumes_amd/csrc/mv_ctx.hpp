@@ -142,6 +142,7 @@ struct DistState
 	uint64_t peerTimeoutTicks = 30ull * 100000000ull;	// 30 s of wall_clock64 (100 MHz)
 	uint32_t rowsStream[kDistChains] = {};		// per chain: the view stream its frames run on
 	uint64_t rowsWaitFrame[kDistChains] = {};	// per chain: the newest frame whose rows this rank has composited but not yet waited for from the others (0 = none): enqueued lazily, by whatever synchronises
+	bool peerRowsRoot = false;					// MV_DIST_PEER_ROWS_TO_ROOT: the ranks push their rows to rank 0 only
 	bool peerFold = false;						// the waits are the consumers' own prologues (mv_kernels.hpp peerFoldWait) instead of one-wavefront kernels in front of them
 	uint32_t* dPeerCounters = nullptr;			// finished-workgroup counters of the push kernels: [kind][chain]
 	uint32_t* dPeerMismatch = nullptr;			// self-test counter
@@ -159,6 +160,7 @@ struct mv_ctx
 	uint32_t numOutSets = 1, numViewStreams = 1;
 	uint32_t set = 0;
 	bool ownStream = false, ownStreamA = false, ownStreamL = false, ownStreamB1 = false;
+	bool cullOnChain = false;			// MV_FLAG_CULL_ON_VIEW_STREAM: upload and cull on the frame's own view stream instead of stream A
 	bool lightOnViewStream = false;		// pipelined with several view streams: a frame's light march runs on that frame's view stream
 	DeviceState st;						// always holds the CURRENT frame slot's pointers (applyParity)
 	FrameBufs fb[kMaxFrameSlots];		// constants + cull outputs per slot (numSlots of them in use)
@@ -329,7 +331,7 @@ void applyParity(mv_ctx* ctx)
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
 	st.exchangeReport = (ctx->dist && ctx->dist->reports) ? ctx->dist->reports + (size_t)ctx->slot * 8u : nullptr;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
-	st.counters = f.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
+	st.counters = f.counters; st.countersPrev = q.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.exchangeOff = f.exchangeOff; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
 	const OutBufs& o = ctx->ob[ctx->set];

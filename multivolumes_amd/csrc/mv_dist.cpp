@@ -678,6 +678,7 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 	// ranks that own their GPU: a consumer's workgroups then spin on flags only OTHER GPUs raise.  Ranks that share a GPU (tests) keep the
 	// flag kernels -- one wavefront each -- so that spinning consumers can never crowd the producers they wait for out of the GPU.
 	d->peerFold = (flags & MV_DIST_PEER_FOLD) ? true : (flags & MV_DIST_PEER_NO_FOLD) ? false : (loopback || distinctDevices);
+	d->peerRowsRoot = (flags & MV_DIST_PEER_ROWS_TO_ROOT) != 0;
 	d->peerFrame = 0;
 	for (uint32_t c = 0; c < kDistChains; ++c) { d->rowsWaitFrame[c] = 0; d->rowsStream[c] = 0; }
 	const int rc = distCommonInit(ctx);	// (releases everything on failure)
@@ -774,6 +775,7 @@ static int distTailSignal(mv_ctx* ctx, hipStream_t X, uint32_t localChain, const
 		DeviceState sp = peerPushState(ctx, st, kFoldComposite, frame, st.frameTag, slot);
 		foldSignal(ctx, sp, kStageRows, frame);
 		foldSignal(ctx, sp, kStageDone, frame);
+		sp.fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
 		mv::launchPeerPushRows(X, sp);
 		d->rowsWaitFrame[c] = frame; d->rowsStream[c] = localChain;
 	}
@@ -808,7 +810,7 @@ static int distTailComposite(mv_ctx* ctx)
 		}
 		else mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
 		MV_HIP(ctx, hipGetLastError());
-		if (d->transport == 3) d->bytes += (size_t)st.H * st.W * sizeof(uint2) / world * (world - 1u);	// (the composite stored its rows into every rank's frame buffer)
+		if (d->transport == 3) d->bytes += (size_t)st.H * st.W * sizeof(uint2) / world * (d->peerRowsRoot ? (st.shardIndex ? 0u : world - 1u) : world - 1u);	// (rows pushed into this rank's frame buffer)
 		else if (world > 1)
 		{
 			// The image is stored rank-major (kFlagInterleaveRows): every rank's tile rows are one contiguous block of the same size, so

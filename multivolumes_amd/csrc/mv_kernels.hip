@@ -730,9 +730,9 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		st.counters[8] = 0u;	// the ticket, for the next cull that uses this slot
 		st.counters[13] = 0u;	// and the hash accumulator
 		if (st.binCursor) { for (uint32_t b = 0; b < 8u; ++b) st.binCursor[b] = 0u; }	// room taken in every bin of the tile order (ordersKernel follows)
-		// [10] a hash of this frame's camera and volume transforms, [11] "it differs from the hash of this slot's previous frame",
-		// i.e. of the frame whose view march wrote the tile cost table this frame's tile order reads (tileBinOf)
-		st.counters[11] = st.counters[10] != viewHash ? 1u : 0u;
+		// [10] a hash of this frame's camera and volume transforms, [11] "it differs from the previous frame's": the tile costs this
+		// frame's order reads were taken one or two frames ago (tileBinOf dilates them then)
+		st.counters[11] = st.countersPrev[10] != viewHash ? 1u : 0u;
 		st.counters[10] = viewHash;
 		// host-visible {frame tag : tile count}: a hint for the grid sizes of later launches; the host never waits for it (mv_api.cpp)
 		if (st.tilesReport) *st.tilesReport = ((unsigned long long)st.frameTag << 32) | nTiles;
@@ -1171,11 +1171,11 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 	uint32_t cost = st.tileCost[key];
 #if MV_ORDER_DILATE
 	if (MV_ORDER_DILATE == 2 || st.counters[11])
-	// The table is four frames old.  With a moving camera (or moving volumes: the cull compares a hash of both with the one of the
+	// The table is a frame or two old.  With a moving camera (or moving volumes: the cull compares a hash of both with the one of the
 	// frame that wrote the table) nearly every tile still costs what it did (5 % change bin, 1.2 samples of
 	// mean drift at 0.004 rad per frame) -- but the few tiles a silhouette has moved INTO start late and run long, and the launch ends
 	// with them (+10 %: scripts/exp_orbit_positions.py).  A tile is therefore binned by the largest cost among itself and its
-	// neighbours in the face (or on the screen): a silhouette moves less than a tile in four frames.
+	// neighbours in the face (or on the screen): a silhouette moves less than a tile in that time.
 	{
 		uint32_t tilesX, tilesY, stride = 1u;
 		if (faceId == 7u)

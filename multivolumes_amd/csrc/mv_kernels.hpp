@@ -111,6 +111,7 @@ struct DeviceState
 									// next grid sizes, read without ever waiting for it
 	unsigned long long* exchangeReport;	// pinned host memory (NULL outside the multi-GPU frame loop): {frameTag : texels of the largest shard of this frame's cube-face exchange}
 	uint32_t frameTag;				// low 32 bits of the context's frame counter
+	const uint32_t* countersPrev;	// the previous frame's counters (its [10]: the hash the cull compares this frame's with)
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
 									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow),
 									// [8] the cull's ticket, [9] head of the march's ray queue (device-only), [10] hash of the frame's camera and volume
@@ -140,7 +141,7 @@ struct DeviceState
 	const uint32_t* tileOrder;		// dispatch order of the tile list, longest bins first (launchOrders): bin b's tiles at [b * orderCap, b * orderCap + binCursor[b]); NULL = list order
 	uint32_t* binCursor;			// 8: tiles in every bin (zeroed by the cull, counted up by the order kernel)
 	uint32_t orderCap;				// entries between the bins' regions of tileOrder
-	uint32_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch, by stable tile key
+	uint32_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch that marched it, by stable tile key (one table for all frame slots)
 	// ray queue of the view march (per output set: two frames may be between setup and march at the same time)
 	RayRecord* rayRecords;			// (maxTiles + maxScreenTiles) x 64, in dispatch order: slot s holds the rays of tile tileOrder[s]
 	TileInfo* tileInfo;				// maxTiles + maxScreenTiles
@@ -166,7 +167,7 @@ struct DeviceState
 		unsigned long long timeoutTicks;
 		uint32_t nWait, nSignal, loopback, frameTag;
 		uint32_t checkChain, checkCompare;		// checkChain: 0xffffffff, or the chain whose slot of cull words this launch raises with (a producer) or, checkCompare != 0, compares every rank's behind its wait (a consumer) -- mv_peer.hip
-		uint32_t stores, pad;					// (view march) this launch also stores its texels into the other ranks' cube maps
+		uint32_t stores, rowsRoot;				// stores: (view march) this launch also stores its texels into the other ranks' cube maps; rowsRoot: (row push) to rank 0 only
 		uint32_t waitRow[6], signalRow[2];
 		unsigned long long waitValue[6], signalValue[2];
 	} fold;

@@ -87,8 +87,9 @@ void launchPeerSync(hipStream_t s, const PeerSync& a)
 // ---------------------------------------------------------------------------------------------
 // the range [off, off + bytes) of `src` (multiples of 4 bytes) into table[p] for every p != self; thread t of n
 template <typename T>
-__device__ __forceinline__ void peerPushRange(const DeviceState& st, T* const* table, const T* src, size_t off, size_t bytes, size_t t, size_t n)
+__device__ __forceinline__ void peerPushRange(const DeviceState& st, T* const* table, const T* src, size_t off, size_t bytes, size_t t, size_t n, uint32_t onlyTo = 0xffffffffu)
 {
+	const uint32_t p0 = onlyTo == 0xffffffffu ? 0u : onlyTo, p1 = onlyTo == 0xffffffffu ? st.peerCount : onlyTo + 1u;	// every other rank, or one
 	const uint8_t* s = reinterpret_cast<const uint8_t*>(src);
 	size_t head = (16u - ((reinterpret_cast<size_t>(s) + off) & 15u)) & 15u;	// (every rank's buffer has the same alignment: allocations of the same size from the same allocator, checked at init)
 	if (head > bytes) head = bytes;
@@ -104,7 +105,7 @@ __device__ __forceinline__ void peerPushRange(const DeviceState& st, T* const* t
 #pragma unroll
 		for (uint32_t j = 0; j < 4u; ++j)
 			if (i + j * n < body)
-				for (uint32_t p = 0; p < st.peerCount; ++p)
+				for (uint32_t p = p0; p < p1; ++p)
 					if (p != st.shardIndex) peerStore16(reinterpret_cast<uint8_t*>(table[p]) + off + head + ((i + j * n) << 4), v[j]);
 	}
 	// (the few words in front of and behind the aligned body)
@@ -112,7 +113,7 @@ __device__ __forceinline__ void peerPushRange(const DeviceState& st, T* const* t
 	{
 		const size_t o = off + (i < (head >> 2) ? (i << 2) : head + (body << 4) + ((i - (head >> 2)) << 2));
 		const uint32_t v = *reinterpret_cast<const uint32_t*>(s + o);
-		for (uint32_t p = 0; p < st.peerCount; ++p)
+		for (uint32_t p = p0; p < p1; ++p)
 			if (p != st.shardIndex) peerStore(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(table[p]) + o), v);
 	}
 }
@@ -141,7 +142,9 @@ __global__ __launch_bounds__(256) void peerPushLightKernel(DeviceState st)
 __global__ __launch_bounds__(256) void peerPushRowsKernel(DeviceState st)
 {
 	const size_t block = (size_t)st.rowsPerRank * 8u * st.W * sizeof(uint2);
-	peerPushRange(st, st.peerComposite, st.composite, (size_t)st.shardIndex * block, block, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+	// (fold.rowsRoot: only rank 0 assembles the frame -- SURVEY 8e's "gather tiles to rank 0" -- and the others' frame buffers hold their own rows only)
+	peerPushRange(st, st.peerComposite, st.composite, (size_t)st.shardIndex * block, block, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x,
+		st.fold.rowsRoot ? 0u : 0xffffffffu);
 	peerFoldSignal(st);
 }
 

@@ -1,9 +1,8 @@
 export HSA_ENABLE_IPC_MODE_LEGACY=0
-mkdir -p gpurun_out/r04n
-for nb in 0 128 2048; do
-MV_OUT=$PWD/gpurun_out/r04n/nb$nb.so ./multivolumes_amd/csrc/build.sh -DMV_TILE_NARROW_BELOW=$nb > /tmp/b.log 2>&1 || tail -3 /tmp/b.log
-for cfgn in T1 T2 C1 C2; do
-MV_LIB_PATH=$PWD/gpurun_out/r04n/nb$nb.so python bench.py --config $cfgn --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; j=json.loads(sys.stdin.read()); print('narrow below $nb', '$cfgn', 'frame ms', round(j['ms_per_step'],4), 'view march alone ms', round(j['roofline']['launch_ms'],4), 'rays', j['config']['rays_per_frame'])"
+timeout 1500 python -m pytest tests/test_dist_frame_loop.py -m gpu -q -x -k "root" 2>&1 | tail -3
+for t in peer4 peer4-root; do
+timeout 600 ./examples/dist_rank_cost.bin 400 8 -1 0 C3 $t 2>&1 | sed "s/^/C3 $t: /"
 done
+for t in callbacks peer4 peer4-root; do
+timeout 600 ./examples/dist_rank_cost.bin 300 8 -1 0 C5 $t 2>&1 | sed "s/^/C5 $t: /"
 done
-rm -f gpurun_out/r04n/*.so*

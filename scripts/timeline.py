@@ -40,3 +40,13 @@ print("  idle gaps > 30 us: %d, total %.1f us/frame" % (len(gaps), sum(g for g, 
 for g, at in sorted(gaps, reverse=True)[:8]:
     prev = [e for e in ev if e[1] <= at][-3:]; nxt = [e for e in ev if e[0] >= at + g][:2]
     print("   gap %.1f us at %.1f us after %s before %s" % (g / 1e3, (at - t0) / 1e3, [p[2] for p in prev], [q[2] for q in nxt]))
+# per queue: how long a queue sits between the end of one kernel and the start of the next (by the kernel that follows), and the queue's cycle
+print("  per-queue gaps in front of a kernel (mean us over the window):")
+byq = collections.defaultdict(list)
+for s, e, k, q in ev: byq[q].append((s, e, k))
+for q, lst in sorted(byq.items()):
+    lst.sort()
+    g = collections.defaultdict(list)
+    for (s0, e0, k0), (s1, e1, k1) in zip(lst, lst[1:]): g[(k0, k1)].append((s1 - e0) / 1e3)
+    busy = sum(e - s for s, e, _ in lst) / 1e3
+    print("   q%-3s busy %.1f us/frame, span %.1f us/frame:" % (q, busy / n, (lst[-1][1] - lst[0][0]) / 1e3 / n) + "".join("  %s->%s %.1f" % (a[:10], b[:10], sum(v) / len(v)) for (a, b), v in sorted(g.items(), key=lambda kv: -sum(kv[1]))[:8]))

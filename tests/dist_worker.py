@@ -57,11 +57,14 @@ def main():
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
     flags = _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if mode == "single" else 0)
-    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world), device=device) as c:
+    four = os.environ.get("MV_TEST_FOUR_CHAINS") == "1"  # four whole frames in flight, upload + cull on the frames' own view streams
+    if four:
+        flags |= _lib.MV_FLAG_CULL_ON_VIEW_STREAM
+    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world), device=device, framesInFlight=4 if four else 0) as c:
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         peer = os.environ.get("MV_TEST_TRANSPORT") == "peer"     # the peer-store transport: IPC mappings, works with every rank on one GPU
         fold = {"1": True, "0": False}.get(os.environ.get("MV_TEST_PEER_FOLD"))  # (None: the library decides -- ranks sharing a GPU keep the flag kernels)
-        kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=120000, peer_fold=fold)
+        kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=120000, peer_fold=fold, peer_rows_to_root=os.environ.get("MV_TEST_ROWS_TO_ROOT") == "1")
         assert kind == ("peer" if peer else "rccl" if rccl else "torch-callbacks"), kind
         if peer:
             info = c.DistInfo()

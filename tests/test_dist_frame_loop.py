@@ -62,7 +62,9 @@ def single_gpu(world, frames, every, static_depth=False, all_frames=False):
 @pytest.mark.parametrize("world,mode,every,static_depth", [(2, "chains", 3, False), (3, "chains", 13, True), (2, "chains", 26, True),
                                                            (2, "single", 3, False), (3, "single", 13, True),
                                                            (2, "peer", 3, False), (3, "peer", 13, True), (2, "peer", 26, True), (5, "peer", 13, True),
-                                                           (2, "peer-folded", 3, False), (3, "peer-folded", 13, True), (2, "peer-folded", 26, True)])
+                                                           (2, "peer-folded", 3, False), (3, "peer-folded", 13, True), (2, "peer-folded", 26, True),
+                                                           (2, "peer-four", 3, False), (3, "peer-four", 13, True), (2, "peer-four", 26, True), (3, "chains-four", 13, True),
+                                                           (3, "peer-root", 13, True)])
 def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static_depth):
     """Both schedules of the loop (include/multivolumes.h): whole frames on three view streams with a communicator each ("chains"),
     and one view stream with the exchange beside it ("single").  With `static_depth` nothing inside the sequence drains the frames
@@ -73,9 +75,14 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     frames = 26
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "peer-root":  # the rows to rank 0 only (it is rank 0 whose frames the test compares)
+        mode, env["MV_TEST_ROWS_TO_ROOT"] = "peer", "1"
+    if mode.endswith("-four"):  # MV_FLAG_CULL_ON_VIEW_STREAM + four frames in flight: upload and cull on the frames' own view streams
+        env["MV_TEST_FOUR_CHAINS"] = "1"
     if mode.startswith("peer"):
         env["MV_TEST_PEER_FOLD"] = "1" if mode == "peer-folded" else "0"
         mode, env["MV_TEST_TRANSPORT"] = "chains", "peer"
+    mode = mode.replace("-four", "")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every), mode, "1" if static_depth else "0"]
     r = run_group(cmd, 300, env)
