@@ -359,7 +359,8 @@ static void foldSignal(mv_ctx* ctx, DeviceState& st, int stage, uint64_t frame)
 	st.fold.signalRow[st.fold.nSignal] = (uint32_t)stage * mv::kPeerMaxChains + (uint32_t)(frame % ctx->dist->numChains);
 	st.fold.signalValue[st.fold.nSignal++] = frame;
 }
-static void foldClear(DeviceState& st) { st.fold.nWait = 0u; st.fold.nSignal = 0u; st.fold.checkChain = 0xffffffffu; st.fold.checkCompare = 0u; st.fold.stores = 0u; }
+static void foldClear(DeviceState& st) { st.fold.nWait = 0u; st.fold.nSignal = 0u; st.fold.checkChain = 0xffffffffu; st.fold.checkCompare = 0u; st.fold.stores = 0u; st.fold.pushBlocks = 0u; }
+constexpr uint32_t kPeerLightPushBlocks = 224;	// workgroups (of the tile march's 128 threads) in front of a folded view march that push the light layers: 16 bytes x 4 per thread cover 1.8 MB
 
 // in front of a consumer on stream s: every rank's `stage` of frame `frame` has landed here
 static int peerWaitStage(mv_ctx* ctx, hipStream_t s, int stage, uint64_t frame, uint32_t frameTag, uint32_t slot)
@@ -441,6 +442,13 @@ static int peerLight(mv_ctx* ctx)
 	if (rc == MV_OK) rc = mvi::marchLight(ctx, nullptr);
 	foldClear(ctx->st);
 	if (rc != MV_OK) return rc;
+	if (d->peerFold)
+	{
+		// folded: the push is the leading workgroups of this frame's view march, the next kernel on this stream (peerBeforeView)
+		MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], S));	// (this rank's layers are in place: what its own frames on the other streams order themselves by)
+		d->bytes += (size_t)ctx->st.L * ctx->st.L * ctx->st.L * sizeof(uint4) / ctx->st.shardCount * (ctx->st.shardCount - 1u);
+		return MV_OK;
+	}
 	DeviceState sp = peerPushState(ctx, ctx->st, kFoldLight, k, ctx->st.frameTag, ctx->slot);
 	foldSignal(ctx, sp, kStageLight, k);
 	if (d->cullCrosscheck) sp.fold.checkChain = (uint32_t)(k % C);	// (with what this rank's cull decided for the frame: compared by every rank's view march)
@@ -465,6 +473,15 @@ static int peerBeforeView(mv_ctx* ctx)
 	if (!d->peerFold) foldBase(ctx, ctx->st, kFoldView, d->peerFrame, ctx->st.frameTag, ctx->slot);	// (folded: peerWaitFor has filled the launch's fields in)
 	foldSignal(ctx, ctx->st, kStageCube, d->peerFrame);
 	ctx->st.fold.stores = 1u;	// (every launch of this march -- the overflow launch too, whichever of them waits or raises)
+	if (d->peerFold)
+	{
+		// the leading workgroups of the main launch push this rank's light layers and raise "light layers landed" with the cull words
+		ctx->st.fold.pushBlocks = kPeerLightPushBlocks;
+		ctx->st.fold.pushRow = kStageLight * mv::kPeerMaxChains + (uint32_t)(d->peerFrame % d->numChains);
+		ctx->st.fold.pushValue = d->peerFrame;
+		ctx->st.fold.pushCounter = d->dPeerCounters + kFoldLight * mv::kPeerMaxChains + (uint32_t)(d->peerFrame % d->numChains);
+		ctx->st.fold.pushCheckChain = d->cullCrosscheck ? (uint32_t)(d->peerFrame % d->numChains) : 0xffffffffu;
+	}
 	return MV_OK;
 }
 

@@ -167,6 +167,11 @@ struct DeviceState
 		unsigned long long timeoutTicks;
 		uint32_t nWait, nSignal, loopback, frameTag;
 		uint32_t checkChain, checkCompare;		// checkChain: 0xffffffff, or the chain whose slot of cull words this launch raises with (a producer) or, checkCompare != 0, compares every rank's behind its wait (a consumer) -- mv_peer.hip
+		// (view march, folded) the leading pushBlocks workgroups of the launch do not march: they push this rank's light layers (peerPushLightRole)
+		// and the last of them raises pushRow to pushValue in every rank's block, with this rank's cull words (chain pushCheckChain)
+		uint32_t pushBlocks, pushRow, pushCheckChain, pad;
+		unsigned long long pushValue;
+		uint32_t* pushCounter;
 		uint32_t stores, rowsRoot;				// stores: (view march) this launch also stores its texels into the other ranks' cube maps; rowsRoot: (row push) to rank 0 only
 		uint32_t waitRow[6], signalRow[2];
 		unsigned long long waitValue[6], signalValue[2];
@@ -204,16 +209,19 @@ constexpr size_t kPeerFlagBytes = kPeerFlagWords * 8u + (size_t)kPeerMaxChains *
 // writes (the same property every collective library's "peer writes, local kernel reads" path rests on); the workgroup's own loads of
 // it are issued behind the barrier below, i.e. behind the poll that saw the flag, and this launch has not read those addresses before
 // (every buffer a frame's peers write was last read C frames ago: the output sets and light buffers rotate).
-__device__ __forceinline__ void peerFoldWait(const DeviceState& st)
+// (firstRow / endRow: the rows of fold.waitRow to wait for -- the view march waits for its newest row only in the workgroups that read
+// the light map that row announces)
+__device__ __forceinline__ void peerFoldWait(const DeviceState& st, uint32_t firstRow = 0u, uint32_t endRow = 0xffffffffu)
 {
-	if (!st.fold.nWait) return;
+	if (endRow > st.fold.nWait) endRow = st.fold.nWait;
+	if (firstRow >= endRow) return;
 	if (threadIdx.x < 64u)
 	{
-		const uint32_t total = st.fold.nWait * st.peerCount;
+		const uint32_t total = (endRow - firstRow) * st.peerCount;
 		const unsigned long long t0 = wall_clock64();
 		for (uint32_t i = threadIdx.x; i < total; i += 64u)
 		{
-			const uint32_t r = i / st.peerCount, p = i - r * st.peerCount;
+			const uint32_t r = firstRow + i / st.peerCount, p = i - (r - firstRow) * st.peerCount;
 			const unsigned long long* flag = st.fold.myFlags + (size_t)st.fold.waitRow[r] * kPeerMaxRanks + p;
 			while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < st.fold.waitValue[r])
 			{
@@ -227,7 +235,7 @@ __device__ __forceinline__ void peerFoldWait(const DeviceState& st)
 		}
 	}
 	__syncthreads();
-	if (st.fold.checkCompare && st.fold.checkChain != 0xffffffffu && blockIdx.x == 0u && threadIdx.x < 64u)
+	if (st.fold.checkCompare && st.fold.checkChain != 0xffffffffu && firstRow == 0u && blockIdx.x == 0u && threadIdx.x < 64u)	// (one workgroup compares, behind the wait for the row the words came with)
 	{
 		// every rank's cull must have decided the same for this frame (peerSyncKernel makes the same comparison)
 		const uint32_t* all = reinterpret_cast<const uint32_t*>(st.fold.myFlags + kPeerFlagWords) + (size_t)st.fold.checkChain * kPeerMaxRanks * kPeerCheckWords;
@@ -240,22 +248,56 @@ __device__ __forceinline__ void peerFoldWait(const DeviceState& st)
 	}
 }
 
+// The same wait by ONE wavefront for itself (all its lanes call it; no barrier): the view march's wavefronts whose tile reads the light map
+// relit in this frame wait for that frame's row -- and wavefront `compare` of the launch also compares the ranks' cull words behind it.
+__device__ __forceinline__ void peerFoldWaitWave(const DeviceState& st, uint32_t firstRow, uint32_t endRow, bool compare)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t total = (endRow - firstRow) * st.peerCount;
+	const unsigned long long t0 = wall_clock64();
+	for (uint32_t i = lane; i < total; i += 64u)
+	{
+		const uint32_t r = firstRow + i / st.peerCount, p = i - (r - firstRow) * st.peerCount;
+		const unsigned long long* flag = st.fold.myFlags + (size_t)st.fold.waitRow[r] * kPeerMaxRanks + p;
+		while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < st.fold.waitValue[r])
+		{
+			if (wall_clock64() - t0 > st.fold.timeoutTicks)
+			{
+				__hip_atomic_store(st.fold.report + 2, ((unsigned long long)st.fold.frameTag << 32) | ((unsigned long long)st.fold.waitRow[r] << 8) | p | 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				break;
+			}
+			__builtin_amdgcn_s_sleep(8);
+		}
+	}
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__builtin_amdgcn_wave_barrier();	// (the wavefront's loads of what the flags announce are issued behind every lane's poll)
+	if (compare && st.fold.checkCompare && st.fold.checkChain != 0xffffffffu)
+	{
+		const uint32_t* all = reinterpret_cast<const uint32_t*>(st.fold.myFlags + kPeerFlagWords) + (size_t)st.fold.checkChain * kPeerMaxRanks * kPeerCheckWords;
+		const uint32_t mine[4] = { st.fold.frameTag, st.counters[12], st.counters[0], st.counters[1] };
+		bool differs = false;
+		for (uint32_t p = lane; p < st.peerCount; p += 64u)
+			for (uint32_t w = 0; w < kPeerCheckWords; ++w)
+				differs |= __hip_atomic_load(all + (size_t)p * kPeerCheckWords + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != mine[w];
+		if (differs) __hip_atomic_store(st.fold.report + 1, ((unsigned long long)st.fold.frameTag << 32) | 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
 // Epilogue of a producer (every thread of the workgroup calls it, after a body that RETURNS instead of exiting): the last workgroup of
 // the launch raises the flags, behind every workgroup's stores.  Again without cache maintenance: the stores into the other ranks'
 // memory are written through at system scope (peerStore), so "complete" is each wavefront's s_waitcnt vmcnt(0) -- the acknowledgement
 // of a write-through store comes from the memory that owns the address.  Every workgroup counts itself in AFTER that wait; the one
 // that counts last knows every store of the launch has been acknowledged, and only then issues the flag stores.
-__device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
+__device__ __forceinline__ void peerRaise(const DeviceState& st, uint32_t* counter, uint32_t expected, uint32_t nSignal, const uint32_t* rows, const unsigned long long* values, uint32_t checkChain)
 {
-	if (!st.fold.nSignal) return;
 	__shared__ uint32_t sLast;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wavefront's stores, into every rank's memory, have been acknowledged
 	__syncthreads();
 	if (threadIdx.x == 0u)
 	{
-		const uint32_t finished = __hip_atomic_fetch_add(st.fold.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const bool last = finished == gridDim.x * gridDim.y - 1u;
-		if (last) __hip_atomic_store(st.fold.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (the next launch that uses it is behind this one on its stream)
+		const uint32_t finished = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const bool last = finished == expected - 1u;
+		if (last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);	// (the next launch that uses it is behind this one on its stream)
 		sLast = last ? 1u : 0u;
 	}
 	__syncthreads();
@@ -266,15 +308,20 @@ __device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
 	{
 		unsigned long long* block = st.fold.loopback ? st.fold.myFlags : st.fold.flagBlocks[p];	// loopback: a rank measured alone raises every column of its own block
 		const uint32_t column = st.fold.loopback ? p : st.shardIndex;
-		if (!st.fold.checkCompare && st.fold.checkChain != 0xffffffffu)
+		if (checkChain != 0xffffffffu)
 		{
-			uint32_t* words = reinterpret_cast<uint32_t*>(block + kPeerFlagWords) + ((size_t)st.fold.checkChain * kPeerMaxRanks + column) * kPeerCheckWords;
+			uint32_t* words = reinterpret_cast<uint32_t*>(block + kPeerFlagWords) + ((size_t)checkChain * kPeerMaxRanks + column) * kPeerCheckWords;
 			peerStore(words + 0, st.fold.frameTag); peerStore(words + 1, st.counters[12]); peerStore(words + 2, st.counters[0]); peerStore(words + 3, st.counters[1]);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// the words are there before the flag that announces them
 		}
-		for (uint32_t i = 0; i < st.fold.nSignal; ++i)
-			__hip_atomic_store(block + (size_t)st.fold.signalRow[i] * kPeerMaxRanks + column, st.fold.signalValue[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		for (uint32_t i = 0; i < nSignal; ++i)
+			__hip_atomic_store(block + (size_t)rows[i] * kPeerMaxRanks + column, values[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
+}
+__device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
+{
+	if (!st.fold.nSignal) return;
+	peerRaise(st, st.fold.counter, gridDim.x * gridDim.y, st.fold.nSignal, st.fold.signalRow, st.fold.signalValue, st.fold.checkCompare ? 0xffffffffu : st.fold.checkChain);
 }
 
 // Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
@@ -401,6 +448,61 @@ __host__ __device__ inline uint64_t cubeMipOffset(uint32_t N, uint32_t mip)
 	for (uint32_t m = 0; m < mip; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
 	return s;
 }
+// ---- push roles (mv_peer.hip explains the transport): copy what this rank produced into every OTHER rank's buffers ----
+// the range [off, off + bytes) of `src` (multiples of 4 bytes) into table[p] for every p != self; thread t of n
+template <typename T>
+__device__ __forceinline__ void peerPushRange(const DeviceState& st, T* const* table, const T* src, size_t off, size_t bytes, size_t t, size_t n, uint32_t onlyTo = 0xffffffffu)
+{
+	const uint32_t p0 = onlyTo == 0xffffffffu ? 0u : onlyTo, p1 = onlyTo == 0xffffffffu ? st.peerCount : onlyTo + 1u;	// every other rank, or one
+	const uint8_t* s = reinterpret_cast<const uint8_t*>(src);
+	size_t head = (16u - ((reinterpret_cast<size_t>(s) + off) & 15u)) & 15u;	// (every rank's buffer has the same alignment: allocations of the same size from the same allocator, checked at init)
+	if (head > bytes) head = bytes;
+	const size_t body = (bytes - head) >> 4, tail = bytes - head - (body << 4);
+	// Four 16-byte units per thread and batch, ALL loads in front of the stores: vmcnt counts loads and stores in order, so a load
+	// behind a write-through store waits for that store's acknowledgement from the far memory -- one unit per iteration ran at the
+	// latency of seven such acknowledgements per 16 bytes (measured: 12 MB in 31 us).
+	for (size_t i = t; i < body; i += 4u * n)
+	{
+		uint4 v[4];
+#pragma unroll
+		for (uint32_t j = 0; j < 4u; ++j) if (i + j * n < body) v[j] = *reinterpret_cast<const uint4*>(s + off + head + ((i + j * n) << 4));
+#pragma unroll
+		for (uint32_t j = 0; j < 4u; ++j)
+			if (i + j * n < body)
+				for (uint32_t p = p0; p < p1; ++p)
+					if (p != st.shardIndex) peerStore16(reinterpret_cast<uint8_t*>(table[p]) + off + head + ((i + j * n) << 4), v[j]);
+	}
+	// (the few words in front of and behind the aligned body)
+	for (size_t i = t; i < (head + tail) >> 2; i += n)
+	{
+		const size_t o = off + (i < (head >> 2) ? (i << 2) : head + (body << 4) + ((i - (head >> 2)) << 2));
+		const uint32_t v = *reinterpret_cast<const uint32_t*>(s + o);
+		for (uint32_t p = p0; p < p1; ++p)
+			if (p != st.shardIndex) peerStore(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(table[p]) + o), v);
+	}
+}
+
+// This rank's layers of the relit volume's light map (kFlagLightLayers, lightLayersOfRank: a layer is 4 z slices of L x L whole cells,
+// contiguous) into every other rank's copy of the map; thread t of n.
+__device__ __forceinline__ void peerPushLightRole(const DeviceState& st, size_t t, size_t n)
+{
+	const uint32_t* cbWords = reinterpret_cast<const uint32_t*>(st.cbPerFrame);
+	const uint32_t frameIdx = cbWords[52];	// CBPerFrame.FrameIdx (byte 208)
+	const uint32_t count = st.counters[0];
+	// CSRayMarchL.hlsl:29-33 (mv_kernels.hip relitVolume)
+	const uint32_t volumeId = count ? st.visibleVolumes[frameIdx % count] : frameIdx % st.V;
+	const size_t mapOff = reinterpret_cast<const uint8_t*>(st.lightTable[volumeId]) - reinterpret_cast<const uint8_t*>(st.lightBuffers);
+	const uint32_t B = (st.L + 3u) >> 2;
+	const size_t slice = (size_t)st.L * st.L * sizeof(uint4);
+	const uint32_t mine = lightLayersOfRank(B, st.shardIndex, st.shardCount);
+	for (uint32_t i = 0; i < mine; ++i)
+	{
+		const uint32_t layer = lightLayerOfRank(B, st.shardIndex, st.shardCount, i);
+		const uint32_t z0 = layer * 4u, z1 = z0 + 4u < st.L ? z0 + 4u : st.L;
+		peerPushRange(st, st.peerLight, st.lightBuffers, mapOff + (size_t)z0 * slice, (size_t)(z1 - z0) * slice, t, n);
+	}
+}
+
 void launchRetile(hipStream_t s, const uint2* linear, uint2* bricked, uint32_t N, uint32_t bricks);
 void launchUntile(hipStream_t s, const uint2* bricked, uint2* linear, uint32_t N, uint32_t bricks);
 void launchInitGridData(hipStream_t s, uint2* bricked, uint32_t N, uint32_t bricks);

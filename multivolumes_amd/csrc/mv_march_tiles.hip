@@ -55,7 +55,23 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 {
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
 	// (peer-store transport, folded wait: for every rank's share of the light maps this frame reads)
-	if constexpr (PEER) peerFoldWait(st);
+	if constexpr (PEER)
+	{
+		// (folded) the leading workgroups of the main launch push this rank's layers of the relit light map into every rank's copy, and the
+		// last of them raises "light layers landed" -- in front of the workgroups that march, which wait for every rank's (their own
+		// rank's too: these very workgroups, dispatched ahead of them)
+		if (!OVERFLOW && blockIdx.x < st.fold.pushBlocks)
+		{
+			peerPushLightRole(st, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)st.fold.pushBlocks * blockDim.x);
+			peerRaise(st, st.fold.pushCounter, st.fold.pushBlocks, 1u, &st.fold.pushRow, &st.fold.pushValue, st.fold.pushCheckChain);
+			peerFoldSignal(st);	// (counted among the launch's workgroups)
+			return;
+		}
+		// every rank's layers of the light maps relit in the frames BEFORE this one (rows 1 ..): long landed.  This frame's (row 0) is
+		// waited for inside the body, by the workgroups whose tile reads the volume relit in this frame -- the others march at once,
+		// beside the push above and the other ranks'
+		peerFoldWait(st, 1u);
+	}
 	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis);
 	if constexpr (PEER) peerFoldSignal(st);
 }
@@ -68,7 +84,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
 	if (LUT)
 	{
-		if (!OVERFLOW && blockIdx.x * kTileWaves >= nTiles) return;	// a surplus workgroup: nothing to march, no table to build
+		if (!OVERFLOW && ((PEER ? blockIdx.x - st.fold.pushBlocks : blockIdx.x) * kTileWaves >= nTiles)) return;	// a surplus workgroup: nothing to march, no table to build
 		const uint32_t P = st.N + 1u, regions = occupancyRegions(st.bricks);
 		const uint32_t strideY = brickPitchY(st.bricks) * 512u, strideZ = brickPitchZ(st.bricks) * 512u;
 		for (uint32_t k = threadIdx.x; k < 3u * P; k += 64u * kTileWaves)
@@ -81,7 +97,8 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	// The host sizes the main grid from the most recent tile count the cull has reported (plus a margin) without ever waiting for
 	// this frame's: wavefronts beyond the real count exit at once, and if the count grew past the grid the overflow launch that
 	// follows marches the rest.
-	for (uint32_t slot = firstSlot + blockIdx.x * kTileWaves + wave; slot < nTiles; slot += OVERFLOW ? gridDim.x * kTileWaves : 0xffffffffu - slot)
+	const uint32_t marchBlock = (PEER && !OVERFLOW) ? blockIdx.x - st.fold.pushBlocks : blockIdx.x;
+	for (uint32_t slot = firstSlot + marchBlock * kTileWaves + wave; slot < nTiles; slot += OVERFLOW ? gridDim.x * kTileWaves : 0xffffffffu - slot)
 	{
 	uint32_t costBin = 8u;
 	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(slot), &costBin));
@@ -105,6 +122,18 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	const PerObject& po = reinterpret_cast<const PerObject*>(st.perObject)[volumeId];
 	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
 	const bool screenTile = faceId == 7u;	// wave-uniform
+	if constexpr (PEER)
+	{
+		// (folded wait, row 0: every rank's layers of the light map relit in THIS frame -- needed by the tiles of that volume only; the
+		// launch's first marching wavefront waits for it whatever its tile, to compare the ranks' cull words that came with it)
+		if (!OVERFLOW && st.fold.nWait)
+		{
+			const uint32_t count = st.counters[0];
+			const uint32_t relit = count ? st.visibleVolumes[cb->frameIdx % count] : cb->frameIdx % st.V;	// CSRayMarchL.hlsl:29-33
+			const bool first = marchBlock == 0u && wave == 0u;
+			if (volumeId == relit || first) peerFoldWaitWave(st, 0u, 1u, first);	// (wave-uniform)
+		}
+	}
 
 	// ---- ray setup: a cube-face texel (CSRayMarch.hlsl:84-107) or a screen pixel of a RayCast volume (RayCast.hlsli:43-54)
 	uint32_t nSamples = 0, nLit = 0, nRays = 0, nSkipped = 0;
@@ -380,7 +409,8 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	if (narrow) { launchMarchTilesNarrow(s, st, (uint32_t)blocks); return marchTilesBeyond(st, gridTiles); }
 #endif
 	const bool il = st.flags & kFlagInterleaveRows;
-	const dim3 grid((uint32_t)blocks), block(64 * kTileWaves);
+	const bool peer = st.peerCount > 1u && st.fold.stores;
+	const dim3 grid((uint32_t)blocks + (peer ? st.fold.pushBlocks : 0u)), block(64 * kTileWaves);
 	const bool lut = st.N <= kLutMaxN && MV_TILE_LUT != 0;
 	if (st.peerCount > 1u && st.fold.stores)	// (peer-store transport)
 	{

@@ -85,56 +85,11 @@ void launchPeerSync(hipStream_t s, const PeerSync& a)
 // into 16 bytes inside a wavefront and overlap the marching of the other tiles; the light march's and the composite's were measured
 // both ways, profiles/r04_peer_store_forms.txt.)
 // ---------------------------------------------------------------------------------------------
-// the range [off, off + bytes) of `src` (multiples of 4 bytes) into table[p] for every p != self; thread t of n
-template <typename T>
-__device__ __forceinline__ void peerPushRange(const DeviceState& st, T* const* table, const T* src, size_t off, size_t bytes, size_t t, size_t n, uint32_t onlyTo = 0xffffffffu)
-{
-	const uint32_t p0 = onlyTo == 0xffffffffu ? 0u : onlyTo, p1 = onlyTo == 0xffffffffu ? st.peerCount : onlyTo + 1u;	// every other rank, or one
-	const uint8_t* s = reinterpret_cast<const uint8_t*>(src);
-	size_t head = (16u - ((reinterpret_cast<size_t>(s) + off) & 15u)) & 15u;	// (every rank's buffer has the same alignment: allocations of the same size from the same allocator, checked at init)
-	if (head > bytes) head = bytes;
-	const size_t body = (bytes - head) >> 4, tail = bytes - head - (body << 4);
-	// Four 16-byte units per thread and batch, ALL loads in front of the stores: vmcnt counts loads and stores in order, so a load
-	// behind a write-through store waits for that store's acknowledgement from the far memory -- one unit per iteration ran at the
-	// latency of seven such acknowledgements per 16 bytes (measured: 12 MB in 31 us).
-	for (size_t i = t; i < body; i += 4u * n)
-	{
-		uint4 v[4];
-#pragma unroll
-		for (uint32_t j = 0; j < 4u; ++j) if (i + j * n < body) v[j] = *reinterpret_cast<const uint4*>(s + off + head + ((i + j * n) << 4));
-#pragma unroll
-		for (uint32_t j = 0; j < 4u; ++j)
-			if (i + j * n < body)
-				for (uint32_t p = p0; p < p1; ++p)
-					if (p != st.shardIndex) peerStore16(reinterpret_cast<uint8_t*>(table[p]) + off + head + ((i + j * n) << 4), v[j]);
-	}
-	// (the few words in front of and behind the aligned body)
-	for (size_t i = t; i < (head + tail) >> 2; i += n)
-	{
-		const size_t o = off + (i < (head >> 2) ? (i << 2) : head + (body << 4) + ((i - (head >> 2)) << 2));
-		const uint32_t v = *reinterpret_cast<const uint32_t*>(s + o);
-		for (uint32_t p = p0; p < p1; ++p)
-			if (p != st.shardIndex) peerStore(reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(table[p]) + o), v);
-	}
-}
-
-// this rank's layers of the relit volume's light map (kFlagLightLayers, lightLayersOfRank: a layer is 4 z slices of L x L whole cells, contiguous)
+// this rank's layers of the relit volume's light map (mv_kernels.hpp peerPushLightRole), as a kernel of its own: ranks that share a GPU, whose
+// view marches wait in front of their launch -- ranks that own their GPU run the same role as the leading workgroups of the view march
 __global__ __launch_bounds__(256) void peerPushLightKernel(DeviceState st)
 {
-	const CBPerFrame* cb = reinterpret_cast<const CBPerFrame*>(st.cbPerFrame);
-	const uint32_t count = st.counters[0];
-	// CSRayMarchL.hlsl:29-33 (mv_kernels.hip relitVolume)
-	const uint32_t volumeId = count ? st.visibleVolumes[cb->frameIdx % count] : cb->frameIdx % st.V;
-	const size_t mapOff = reinterpret_cast<const uint8_t*>(st.lightTable[volumeId]) - reinterpret_cast<const uint8_t*>(st.lightBuffers);
-	const uint32_t B = (st.L + 3u) >> 2;
-	const size_t slice = (size_t)st.L * st.L * sizeof(uint4);
-	const uint32_t mine = lightLayersOfRank(B, st.shardIndex, st.shardCount);
-	for (uint32_t i = 0; i < mine; ++i)
-	{
-		const uint32_t layer = lightLayerOfRank(B, st.shardIndex, st.shardCount, i);
-		const uint32_t z0 = layer * 4u, z1 = z0 + 4u < st.L ? z0 + 4u : st.L;
-		peerPushRange(st, st.peerLight, st.lightBuffers, mapOff + (size_t)z0 * slice, (size_t)(z1 - z0) * slice, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
-	}
+	peerPushLightRole(st, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 	peerFoldSignal(st);
 }
 
