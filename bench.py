@@ -121,6 +121,8 @@ def parse():
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
     p.add_argument("--rows-to-root", action="store_true", help="--gpus > 1, peer-store transport: the ranks push their screen rows to rank 0 only (SURVEY 8e: 'gather tiles to rank 0') "
                    "instead of to every rank; the end-of-run check that every rank holds the same frame is then left out")
+    p.add_argument("--cull-on-view-stream", action="store_true", help="MV_FLAG_CULL_ON_VIEW_STREAM: every frame's upload and cull on its own view stream (no stream of their own); "
+                   "the default of the peer rung of --gpus > 1, an experiment on one GPU")
     p.add_argument("--frames-in-flight", type=int, default=0, help="whole frames in flight = view streams = output sets (2..5; 0 = the library's default, 3)")
     p.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
                    help="--gpus > 1: auto = the peer-store transport (no collectives: every rank's kernels store into every rank's buffers over "
@@ -292,6 +294,8 @@ def main():
     pipelined = not args.no_pipeline
     if pipelined:
         flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
+        if args.cull_on_view_stream:
+            flags |= _lib.MV_FLAG_CULL_ON_VIEW_STREAM
     if world > 1:
         # the in-library frame loop (mv_dist_frame): whole frames on three view streams, a communicator each; --dist-single-stream
         # selects its other schedule (one view stream, the exchange beside it)
@@ -570,7 +574,9 @@ def main():
                          "hbm_frac": (traffic / (ms_v * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and ms_v > 0) else None,
                          # the same launch also marches the screen-space RayCast tiles of the volumes on that scheme (RayCast.hlsli:43-108): with
                          # their samples priced the same way
-                         "frac_with_fused_raycast": achieved / HBM_PEAK_GBS,
+                         # (the same rule as `frac`: never above 1 -- C3-stress has no screen-space volume, its fused figure is the a3 one)
+                         "frac_with_fused_raycast": roofline_fraction(alg_bytes, alg_bytes - 64 * st.get("fetch_free_samples", 0) / K, traffic, ms_v)["frac"],
+                         "frac_with_fused_raycast_algorithmic_uncapped": achieved / HBM_PEAK_GBS,
                          # share of the launch's samples (cube-face + RayCast) whose brick occupancy bit proved alpha <= ZERO_THRESHOLD: counted and
                          # priced at 64 B like the others (the reference's loop reads them), but no texel was requested for them
                          "fetch_free_share": (st.get("fetch_free_samples", 0) / max(1, st["view_samples"] + fused)),

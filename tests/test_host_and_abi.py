@@ -136,3 +136,23 @@ def test_synthetic_inputs_are_deterministic_and_sane(oracle):
     assert abs(d[32, 32] - 1000.0 * (dist - 1.0) / (dist * 999.0)) < 5e-4
     s = rc.synth_sphere_shadow(64, scene.shadow_vp(dict(cfg, mesh=True)), (0, 0, 0), 8.0)
     assert s[0, 0] == 65535 and s[32, 32] < 65535
+
+
+def test_roofline_fraction_is_a_fraction_on_every_workload():
+    """bench.py's roofline line: SURVEY 8(d)'s algorithmic bytes while they are a fraction of the peak; on workloads
+    that are mostly served without HBM (C3-stress printed 1.40) the requested bytes, then the measured traffic, then a stated cap --
+    and the algorithmic figure stays beside it, uncapped."""
+    import bench
+    peak = bench.HBM_PEAK_GBS
+    ms = 0.25
+    at = lambda frac: frac * peak * 1e9 * ms * 1e-3   # bytes per launch that give that fraction
+    r = bench.roofline_fraction(at(0.727), at(0.57), at(0.64), ms)
+    assert abs(r["frac"] - 0.727) < 1e-9 and "algorithmic" in r["frac_basis"] and "frac_algorithmic_uncapped" not in r
+    r = bench.roofline_fraction(at(1.40), at(0.80), at(0.40), ms)
+    assert abs(r["frac"] - 0.80) < 1e-9 and abs(r["frac_algorithmic_uncapped"] - 1.40) < 1e-9 and "requested" in r["frac_basis"]
+    r = bench.roofline_fraction(at(1.40), at(1.10), at(0.40), ms)
+    assert abs(r["frac"] - 0.40) < 1e-9 and "traffic" in r["frac_basis"]
+    r = bench.roofline_fraction(at(1.40), at(1.10), None, ms)
+    assert r["frac"] == 1.0 and "capped" in r["frac_basis"]
+    assert bench.roofline_fraction(1.0, 1.0, None, 0.0)["frac"] is None
+    assert bench.LEVELS[0] == "peer" and bench.LEVELS.index("rccl-single-stream") < bench.LEVELS.index("rccl")
