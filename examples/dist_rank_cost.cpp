@@ -4,7 +4,7 @@
 // (scripts/exp_rank_cost.py is the same measurement through the Python mirror).  max over ranks = the frame time an ideal fabric would
 // give; its ratio to world 1 is the ceiling of the strong-scaling curve.
 // Build: g++ -O2 -std=c++17 examples/dist_rank_cost.cpp -Lmultivolumes_amd -lmultivolumes_amd -Wl,-rpath,$PWD/multivolumes_amd -o /tmp/dist_rank_cost
-// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3 (0)] [C3 | C5] [callbacks | peer | peer-nofold | peer4 | peer4-root]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3 (0)] [C3 | C5] [callbacks | peer | peer-nofold | peer4 | peer4-root | peer4x2 | peer4x4 | peer4x4-root]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
 // "peer": the peer-store transport in loopback (MV_DIST_PEER_LOOPBACK): the rank's kernels store into all `world` copies -- every copy being
 // its own buffer -- and it raises the other ranks' flags itself: no pack / gather / unpack kernels, the flag kernels instead.
 // Prints per rank: ms per frame, and in brackets the host's share (time spent inside DistFrame: constants + every HIP call of the frame).
@@ -27,7 +27,11 @@ int main(int argc, char** argv)
 	const bool peer = argc > 6 && std::string(argv[6]).rfind("peer", 0) == 0;
 	const bool noFold = argc > 6 && std::string(argv[6]) == "peer-nofold";
 	const bool root = argc > 6 && std::string(argv[6]) == "peer4-root";	// ... and the rows to rank 0 only (MV_DIST_PEER_ROWS_TO_ROOT)
-	const bool four = root || (argc > 6 && std::string(argv[6]) == "peer4");	// four whole frames in flight on the four hardware queues: MV_FLAG_CULL_ON_VIEW_STREAM (no stream of its own for upload + cull), frames_in_flight = 4
+	// "peer4x2", "peer4x3", "peer4x4" (+ "-root"): ... and B = 2, 3, 4 frames per launch (mv_config.frames_per_launch): 4 x B frames in flight
+	uint32_t perLaunch = 0;
+	bool rootB = false;
+	if (argc > 6 && std::string(argv[6]).rfind("peer4x", 0) == 0) { perLaunch = (uint32_t)std::atoi(argv[6] + 6); rootB = std::string(argv[6]).find("-root") != std::string::npos; }
+	const bool four = root || perLaunch || (argc > 6 && std::string(argv[6]) == "peer4");	// four whole frames in flight on the four hardware queues: MV_FLAG_CULL_ON_VIEW_STREAM (no stream of its own for upload + cull), frames_in_flight = 4
 	const bool withComposite = !std::getenv("RANK_COST_NO_COMPOSITE");	// (experiment: a frame without its composite + row gather)
 	const int frames = argc > 1 ? std::atoi(argv[1]) : 400;
 	const unsigned worlds = argc > 2 ? (unsigned)std::atoi(argv[2]) : 15u;
@@ -59,7 +63,7 @@ int main(int argc, char** argv)
 		{
 			if (onlyRank >= 0 && (uint32_t)onlyRank != rank) continue;
 			mvamd::MultiRayCaster rc;
-			if (!rc.Init(N, L, V, V, W, H, M, 0, nullptr, rank, world, MV_FLAG_PIPELINE_FRAMES | (four ? MV_FLAG_CULL_ON_VIEW_STREAM : 0u), four ? 4u : inFlight)) { std::fprintf(stderr, "Init failed (no gfx950 device?)\n"); return 2; }
+			if (!rc.Init(N, L, V, V, W, H, M, 0, nullptr, rank, world, MV_FLAG_PIPELINE_FRAMES | (four ? MV_FLAG_CULL_ON_VIEW_STREAM : 0u), four ? 4u : inFlight, perLaunch)) { std::fprintf(stderr, "Init failed (no gfx950 device?)\n"); return 2; }
 			for (uint32_t k = 0; k < V; ++k) if (!rc.LoadVolumeData(k, vols[k].data())) return 3;
 			if (!rc.SetRenderTargetsHost(depth.data(), shadow.data())) return 4;
 			rc.SetMaxSamples(c5 ? 256 : 128, 96);
@@ -67,7 +71,7 @@ int main(int argc, char** argv)
 			rc.SetAmbient(ac, 2.0f * 3.14159265f);
 			if (peer)
 			{
-				if (mv_dist_init_peer(rc.Context(), nullptr, MV_DIST_PEER_LOOPBACK | (noFold ? MV_DIST_PEER_NO_FOLD : 0u) | (root ? MV_DIST_PEER_ROWS_TO_ROOT : 0u)) != MV_OK || mv_dist_selftest(rc.Context()) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
+				if (mv_dist_init_peer(rc.Context(), nullptr, MV_DIST_PEER_LOOPBACK | (noFold ? MV_DIST_PEER_NO_FOLD : 0u) | ((root || rootB) ? MV_DIST_PEER_ROWS_TO_ROOT : 0u) | (std::getenv("RANK_COST_DEAL_VOLUMES") ? MV_DIST_PEER_DEAL_VOLUMES : 0u)) != MV_OK || mv_dist_selftest(rc.Context()) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
 			}
 			else
 			{
@@ -80,10 +84,10 @@ int main(int argc, char** argv)
 			double waited = 0.0;
 			mv_host_wait_ms(rc.Context(), &waited, 1);
 			const auto t0 = std::chrono::steady_clock::now();
-			for (int f = 0; f < frames; ++f) if (!rc.DistFrame(viewProj, shadowVP, eye, withComposite)) return 6;
+			for (int f = 0; f < frames; ++f) if (!rc.DistFrame(viewProj, shadowVP, eye, withComposite)) { std::fprintf(stderr, "frame %d: %s\n", f, rc.LastError()); return 6; }
 			mv_host_wait_ms(rc.Context(), &waited, 1);
 			const double host = (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() - waited) / frames;	// enqueueing, without the waits for a free frame slot
-			rc.DistFlush(); mv_synchronize(rc.Context());
+			if (!rc.DistFlush() || mv_synchronize(rc.Context()) != MV_OK) { std::fprintf(stderr, "flush: %s\n", rc.LastError()); return 7; }
 			const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / frames;
 			std::printf("%s%.4f (host %.4f)", rank ? ", " : "", ms, host);
 			std::fflush(stdout);

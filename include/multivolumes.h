@@ -104,8 +104,16 @@ typedef struct mv_config
 	uint32_t frames_in_flight;	/* with MV_FLAG_PIPELINE_FRAMES (and not MV_FLAG_SINGLE_VIEW_STREAM): whole frames in flight = view streams = output sets,
 								   2..5; 0 = 3, the reference's FrameCount (MultiRayCaster.h:52).  More than 3 need more than the four hardware
 								   queues a HIP process has by default: GPU_MAX_HW_QUEUES >= frames_in_flight + 1 in the environment before the HIP
-								   runtime initialises (the library sets GPU_MAX_HW_QUEUES=8 when it is loaded if the variable is unset).
+								   runtime initialises (the library sets no environment variable: the application does, as bench.py does).
 								   (ABI 4; a struct_size without this field is accepted and means 0.) */
+	uint32_t frames_per_launch;	/* B = 1..4 (0 = 1), with MV_FLAG_PIPELINE_FRAMES (not MV_FLAG_SINGLE_VIEW_STREAM): B consecutive frames share a view
+								   stream, so frames_in_flight x B (at most 16) frames are in flight, with as many output sets and light buffers per volume.
+								   What it is for: mv_dist_frame with the peer-store transport then launches the B frames of a group TOGETHER -- one
+								   light march, one view march, one composite, one row push for all of them (blockIdx.y = the frame) -- because a rank
+								   of eight holds an eighth of a frame: a wavefront per SIMD or less, every long kernel as long as its longest ray
+								   whatever else the GPU could do meanwhile, and four hardware queues are all the frames that can overlap.  The frames
+								   of a group reach the GPU when the group is full (or at mv_dist_flush / a setter): throughput for latency.
+								   Results are identical.  (ABI 5: the field occupies what was padding -- zero the struct before filling it in.) */
 } mv_config;
 
 /* counters accumulated since the last mv_reset_stats (all device-side, exact) */
@@ -324,7 +332,7 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * MV_DIST_PEER_LOOPBACK: a rank measured ALONE (examples/dist_rank_cost.cpp): every other rank is a set of stand-in buffers on the same GPU
  * (about 1 GB each at C3) and the rank raises the other ranks' flags itself -- the kernels, their eight-fold stores and the schedule are a
  * rank's real ones, the images are not. */
-#define MV_DIST_PEER_BYTES 2048
+#define MV_DIST_PEER_BYTES 8192
 #define MV_DIST_PEER_LOOPBACK 1u
 /* The flags are raised and waited for INSIDE the light march, the view march and the composite ("folded": a rank's chain is those three
  * kernels and nothing else) when every rank owns its GPU -- the library decides from the ranks' PCI bus ids -- and by one-wavefront kernels
@@ -336,6 +344,12 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * frame buffers their own rows -- 1/7 of the row traffic (C5 on 8 ranks: 4 MB per rank and frame instead of 28).  Default: every rank
  * gets every row, as with the all-gathers. */
 #define MV_DIST_PEER_ROWS_TO_ROOT 8u
+/* Who marches what.  Default: the view march of EVERY cube-map volume is shared out by tiles (rank r marches the 8x8 tiles t of each
+ * marched face with (t + volume) mod shard_count == r): a march that stores its texels into every rank's cube maps itself does not care who
+ * "owns" a volume, and eight ranks then carry an eighth of the tiles each.  With this flag whole volumes go to ranks, dealt by estimated
+ * cost as with the collectives (the north star's "volumes shard across the GPUs"): ten visible volumes on eight ranks leave two ranks with
+ * two volumes, which the frame then waits for (profiles/r04_frames_per_launch.txt).  Results are identical. */
+#define MV_DIST_PEER_DEAL_VOLUMES 16u
 int mv_dist_peer_export(mv_ctx* ctx, void* out /* MV_DIST_PEER_BYTES */);
 int mv_dist_init_peer(mv_ctx* ctx, const void* all /* shard_count x MV_DIST_PEER_BYTES in rank order; NULL with MV_DIST_PEER_LOOPBACK */, uint32_t flags);
 int mv_dist_set_peer_timeout_ms(mv_ctx* ctx, uint32_t ms);

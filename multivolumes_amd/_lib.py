@@ -32,11 +32,12 @@ MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5
 MV_BUF_VOLUME_FLAGS, MV_BUF_EXCHANGE_OFFSETS = 10, 11
 
 MV_DIST_ID_BYTES = 640
-MV_DIST_PEER_BYTES = 2048
+MV_DIST_PEER_BYTES = 8192
 MV_DIST_PEER_LOOPBACK = 1
 MV_DIST_PEER_FOLD = 2
 MV_DIST_PEER_NO_FOLD = 4
 MV_DIST_PEER_ROWS_TO_ROOT = 8
+MV_DIST_PEER_DEAL_VOLUMES = 16
 MV_ABI_VERSION = 5  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
@@ -52,7 +53,7 @@ class mv_config(C.Structure):
         ("num_volumes", C.c_uint32), ("num_volume_srcs", C.c_uint32),
         ("viewport_w", C.c_uint32), ("viewport_h", C.c_uint32), ("shadow_map_size", C.c_uint32),
         ("device", C.c_int32), ("flags", C.c_uint32), ("stream", C.c_void_p),
-        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("frames_in_flight", C.c_uint32),
+        ("shard_index", C.c_uint32), ("shard_count", C.c_uint32), ("frames_in_flight", C.c_uint32), ("frames_per_launch", C.c_uint32),
     ]
 
 

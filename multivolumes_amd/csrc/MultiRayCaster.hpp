@@ -29,7 +29,7 @@ public:
 	// Init (MultiRayCaster.cpp:79-166) + SetViewport (:226-241)
 	bool Init(uint32_t gridSize, uint32_t lightGridSize, uint32_t numVolumes, uint32_t numVolumeSrcs,
 		uint32_t width, uint32_t height, uint32_t shadowMapSize = 1024, int device = 0, void* hipStream = nullptr,
-		uint32_t shardIndex = 0, uint32_t shardCount = 1, uint32_t flags = 0, uint32_t framesInFlight = 0)
+		uint32_t shardIndex = 0, uint32_t shardCount = 1, uint32_t flags = 0, uint32_t framesInFlight = 0, uint32_t framesPerLaunch = 0)
 	{
 		mv_config cfg;
 		std::memset(&cfg, 0, sizeof(cfg));
@@ -37,7 +37,7 @@ public:
 		cfg.grid_size = gridSize; cfg.light_grid_size = lightGridSize;
 		cfg.num_volumes = numVolumes; cfg.num_volume_srcs = numVolumeSrcs;
 		cfg.viewport_w = width; cfg.viewport_h = height; cfg.shadow_map_size = shadowMapSize;
-		cfg.device = device; cfg.stream = hipStream; cfg.shard_index = shardIndex; cfg.shard_count = shardCount; cfg.flags = flags; cfg.frames_in_flight = framesInFlight;
+		cfg.device = device; cfg.stream = hipStream; cfg.shard_index = shardIndex; cfg.shard_count = shardCount; cfg.flags = flags; cfg.frames_in_flight = framesInFlight; cfg.frames_per_launch = framesPerLaunch;
 		if (mv_create(&cfg, &m_ctx) != MV_OK) return false;
 		m_numVolumes = numVolumes; m_width = width; m_height = height;
 		m_volumeWorlds.assign((size_t)numVolumes * 12, 0.0f);

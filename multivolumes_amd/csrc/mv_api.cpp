@@ -38,6 +38,9 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	*out = nullptr;
 	const uint32_t wantChains = cfg->struct_size == sizeof(mv_config) && cfg->frames_in_flight ? cfg->frames_in_flight : 3u;
 	if (wantChains < 2u || wantChains > kMaxChains) return MV_ERR_INVALID_ARG;
+	const uint32_t perLaunch = cfg->struct_size == sizeof(mv_config) && cfg->frames_per_launch ? cfg->frames_per_launch : 1u;
+	if (perLaunch > mv::kMaxBatch || wantChains * perLaunch > kMaxFramesInFlight) return MV_ERR_INVALID_ARG;
+	if (perLaunch > 1u && (!(cfg->flags & MV_FLAG_PIPELINE_FRAMES) || (cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM))) return MV_ERR_INVALID_ARG;	// groups of frames share a view stream: whole-frame chains only
 	if (cfg->grid_size < 2 || cfg->grid_size > 640 /* bricked alpha cells (16 B/texel) must stay < 4 GiB for 32-bit byte offsets */ || cfg->light_grid_size < 2 || cfg->light_grid_size > 640 /* 32-bit offsets into the 16 B/texel light quads */ || cfg->num_volumes < 1 || cfg->num_volumes > MV_MAX_VOLUMES /* the cull and the tile order keep per-volume tables in LDS (12 V and 48 V + 132 bytes of the 64 KiB a launch gets by default) */ ||
 		cfg->num_volume_srcs < 1 || cfg->num_volume_srcs > 16383 || cfg->viewport_w < 1 || cfg->viewport_h < 1 || cfg->shadow_map_size < 1)
 		return MV_ERR_INVALID_ARG;
@@ -98,14 +101,16 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		else
 		{
 			ctx->lightOnViewStream = true;
-			ctx->numOutSets = wantChains;
+			ctx->numOutSets = wantChains * perLaunch;
+			ctx->framesPerLaunch = perLaunch;
+			ctx->batchPos = perLaunch - 1u;	// (the first frame opens group 1)
 		}
 #ifdef MV_DIAGNOSTICS	// A/B measurements only (csrc/build.sh -DMV_DIAGNOSTICS); the shipped library reads no environment variable
 		{ const char* e = getenv("MV_OUT_SETS"); if (e) ctx->numOutSets = (uint32_t)atoi(e); if (ctx->numOutSets < 2u || ctx->numOutSets > kMaxOutSets) ctx->numOutSets = 2u; }
 #endif
 		if (!(cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM))
 		{
-			ctx->numViewStreams = ctx->numOutSets;
+			ctx->numViewStreams = ctx->numOutSets / ctx->framesPerLaunch;
 			for (uint32_t i = 1; i < ctx->numViewStreams; ++i)
 				if (hipStreamCreateWithFlags(&ctx->streamB[i], hipStreamNonBlocking) != hipSuccess) return bail(MV_ERR_HIP);
 			ctx->ownStreamB1 = true;
@@ -122,7 +127,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			|| hipEventCreateWithFlags(&ctx->evLight[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 	if (hipEventCreateWithFlags(&ctx->evProducers, hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 	for (uint32_t i = 0; i < ctx->numSlots; ++i)
-		if (hipEventCreateWithFlags(&ctx->evCopy[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
+		if (hipEventCreateWithFlags(&ctx->evCopy[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->evLanded[i], hipEventDisableTiming) != hipSuccess) return bail(MV_ERR_HIP);
 
 	DeviceState& st = ctx->st;
 	st.N = cfg->grid_size; st.bricks = (cfg->grid_size + 3u) >> 2; st.L = cfg->light_grid_size;
@@ -205,6 +210,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 				f.lightTable = reinterpret_cast<uint4**>(block + 64 + (size_t)st.V * 16);
 			}
 			if ((rc = devAlloc(ctx, &f.ownedVisible, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
+			if ((rc = devAlloc(ctx, &f.batchInfo, 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.screenSlot, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.exchangeOff, (size_t)st.V * sizeof(uint32_t))) != MV_OK) return bail(rc);
 			if ((rc = devAlloc(ctx, &f.workEntries, ((size_t)st.V * 6 + st.screenSlots) * sizeof(uint32_t))) != MV_OK) return bail(rc);
@@ -288,8 +294,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinned), ctx->sliceBytes * kMaxFrameSlots + 256, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
 	ctx->pinnedStats = reinterpret_cast<uint64_t*>(ctx->pinned + ctx->sliceBytes * kMaxFrameSlots);
 	ctx->pinnedCounters = reinterpret_cast<uint32_t*>(ctx->pinned + ctx->sliceBytes * kMaxFrameSlots + 128);
-	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedTiles), 64, hipHostMallocCoherent) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
-	*ctx->pinnedTiles = ~0ull;
+	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedTiles), (1u + kMaxFrameSlots) * sizeof(unsigned long long), hipHostMallocCoherent) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
+	for (uint32_t i = 0; i <= kMaxFrameSlots; ++i) ctx->pinnedTiles[i] = ~0ull;	// [0] the newest cull's report, [1 + slot] every frame slot's own
 	st.tilesReport = ctx->pinnedTiles;
 	ctx->rayQueue = (cfg->flags & MV_FLAG_RAY_QUEUE) != 0;
 	if (hipHostMalloc(reinterpret_cast<void**>(&ctx->pinnedCull), 64 + (size_t)st.V * 24, hipHostMallocDefault) != hipSuccess) return bail(MV_ERR_OUT_OF_MEMORY);
@@ -323,7 +329,7 @@ void mv_destroy(mv_ctx* ctx)
 	if (ctx->stream) (void)syncAll(ctx);
 	foldEvents(ctx);
 	distRelease(ctx);
-	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) if (ctx->evCopy[i]) (void)hipEventDestroy(ctx->evCopy[i]);
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) { if (ctx->evCopy[i]) (void)hipEventDestroy(ctx->evCopy[i]); if (ctx->evLanded[i]) (void)hipEventDestroy(ctx->evLanded[i]); }
 	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) { if (ctx->evStageA[i]) (void)hipEventDestroy(ctx->evStageA[i]); if (ctx->evMainDone[i]) (void)hipEventDestroy(ctx->evMainDone[i]); if (ctx->evLight[i]) (void)hipEventDestroy(ctx->evLight[i]); }
 	if (ctx->evProducers) (void)hipEventDestroy(ctx->evProducers);
 	if (ctx->ownStreamA && ctx->streamA) (void)hipStreamDestroy(ctx->streamA);
@@ -574,6 +580,9 @@ int mvi::keepLightTable(mv_ctx* ctx)
 	return MV_OK;
 }
 
+#ifndef MV_SLOT_SPIN_US
+#define MV_SLOT_SPIN_US 2000	// how long mv_update_frame polls for a free frame slot before it blocks (0: block at once)
+#endif
 int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 {
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
@@ -581,30 +590,56 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	ctx->slot = (ctx->slot + 1u) % ctx->numSlots;
 	++ctx->frame;
 	const uint32_t prevSlot = (ctx->slot + ctx->numSlots - 1u) % ctx->numSlots;
+	if (ctx->framesPerLaunch > 1u && !ctx->batchExplicit)
+	{
+		// (several frames per launch outside the multi-GPU loop: B consecutive frames share a view stream, nothing else changes)
+		ctx->batchPos = (ctx->batchPos + 1u) % ctx->framesPerLaunch;
+		if (ctx->batchPos == 0u) ++ctx->batchIndex;
+	}
+	ctx->prevChain = ctx->curChain;
+	ctx->curChain = chainOfFrame(ctx);
 	if (ctx->cullOnChain)
 	{
 		// (MV_FLAG_CULL_ON_VIEW_STREAM) this frame's stage A runs on its own view stream; what stream A's order used to give must then
 		// be said: the cull reads the previous frame's light table, VolumeInfo and view hash (lightTablePrev, volumeInfoPrev, countersPrev)
-		ctx->streamA = ctx->streamB[ctx->frame % ctx->numViewStreams];
-		MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evStageA[prevSlot]));
+		ctx->streamA = ctx->streamB[chainOfFrame(ctx)];
+		// (the multi-GPU loop with several frames per launch culls a group's frames together, later: the wait goes in front of that launch
+		// -- batchClose -- and the uploads need not wait for the culls of the group before)
+		if (!ctx->batchExplicit) MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evStageA[prevSlot]));
 	}
 	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
 	ctx->st.frameTag = (uint32_t)ctx->frame;
 	applyParity(ctx);
 	// the slot's previous user (ctx->numSlots frames ago) must be done with it; volume producers on stream B must have finished
+	{
+	MV_SECTION(8);
 	MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evMainDone[ctx->slot]));
 	MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evLight[ctx->slot]));
 	if (ctx->producersDirty) { MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evProducers)); ctx->producersDirty = false; }
+	}
 	// The constants go into this slot's pinned slice (the reference's upload-heap slices, MultiRayCaster.cpp:128-130, 461-467) and from
 	// there to the device in one copy on stream A.  The slice's previous user is the frame numSlots back: its copy must have run --
 	// in steady state it has, long ago (the slot's stage-A event covers it: no event of its own); a host that runs more than that many
 	// frames ahead of the GPU waits here, as the reference's does on its fence.
+	MV_SECTION(9);
 	if (hipEventQuery(ctx->evStageA[ctx->slot]) != hipSuccess)
 	{
+		// (polled for a while before the blocking wait: a host that is only just ahead of the GPU finds the event done within
+		// microseconds, while waking from hipEventSynchronize took ~100 us here -- time in which the queues of a rank of the multi-GPU loop ran dry)
 		const auto t0 = std::chrono::steady_clock::now();
-		MV_HIP(ctx, hipEventSynchronize(ctx->evStageA[ctx->slot]));
+		bool done = false;
+		while (!done && std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(MV_SLOT_SPIN_US)) { for (int i = 0; i < 64; ++i) __builtin_ia32_pause(); done = hipEventQuery(ctx->evStageA[ctx->slot]) == hipSuccess; }
+		if (!done) MV_HIP(ctx, hipEventSynchronize(ctx->evStageA[ctx->slot]));
 		ctx->hostWaitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+#ifdef MV_HOST_PROFILE
+		{
+			static double waitUs[4]; static uint64_t waits[4], calls;
+			waitUs[ctx->batchPos & 3u] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); ++waits[ctx->batchPos & 3u];
+			if (++calls % 100 == 0) { fprintf(stderr, " [slot waits by position in the group:"); for (int i = 0; i < 4; ++i) { fprintf(stderr, " %llu x %.0f us", (unsigned long long)waits[i], waits[i] ? waitUs[i] / waits[i] : 0.0); waitUs[i] = 0; waits[i] = 0; } fprintf(stderr, "]"); }
+		}
+#endif
 	}
+	MV_SECTION(10);
 	uint8_t* s = ctx->pinned + (size_t)ctx->slot * ctx->sliceBytes;
 	memcpy(s, cbPerFrame, MV_CB_PER_FRAME_BYTES);
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
@@ -724,7 +759,7 @@ int mvi::viewCopyForward(mv_ctx* ctx)
 		// completed the set it reads (a stream of its own would do, but HIP streams beyond four share hardware queues and wait for
 		// each other: measured).  It writes this frame's set, so the set's last reader (the composite of frame k - n) must be
 		// over, and it reads what the previous frame's copy wrote (a face nobody has marched for two frames travels set to set).
-		hipStream_t s = ctx->streamB[(ctx->frame + ctx->numViewStreams - 1u) % ctx->numViewStreams];
+		hipStream_t s = ctx->streamB[ctx->prevChain];
 		MV_HIP(ctx, evWait(ctx, s, ctx->evMainDone[(ctx->slot + ctx->numSlots - n) % ctx->numSlots]));
 		MV_HIP(ctx, evWait(ctx, s, ctx->evCopy[prevSlot]));
 		if (ctx->copiedForward) MV_HIP(ctx, evWait(ctx, s, ctx->evCopy[ctx->slot]));

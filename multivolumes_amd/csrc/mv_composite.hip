@@ -295,13 +295,31 @@ constexpr uint32_t kLayerNeedsMarch = 0xffff0000u;	// in .y: alpha = an fp16 NaN
 // kernel half of its wavefronts per SIMD): a tile in which some surviving layer needs that march is appended to `retry`
 // ({count, finished workgroups, tile ...}) and written by the MARCH = true launch behind it, which walks that list.
 // PEER: the peer-store transport's instantiation with a folded wait (mv_kernels.hpp peerFoldWait); the others are untouched by it
+template <bool MARCH>
+__device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background, uint32_t* __restrict__ retry);
+
 template <bool MARCH, bool PEER = false>
 __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background,
 	uint32_t* __restrict__ retry)
 {
+	if constexpr (PEER) peerFoldWait(st);	// (peer-store transport, folded flags: every rank's cube faces of this frame have landed in this rank's set)
+	compositeBody<MARCH>(st, row0, row1, background, retry);
+}
+
+// several frames in one launch (mv_kernels.hpp DeviceStateBatch; the multi-GPU loop's interleaved tile rows, no background): blockIdx.y is the frame
+template <bool MARCH>
+__global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compositeBatchKernel(DeviceStateBatch p)
+{
+	const DeviceState& st = p.s[blockIdx.y];
+	if (!MARCH) peerFoldWait(st);
+	compositeBody<MARCH>(st, st.bandRow0, st.bandRow1, nullptr, st.compositeRetry);
+}
+
+template <bool MARCH>
+__device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background, uint32_t* __restrict__ retry)
+{
 	const uint32_t lane = threadIdx.x;
 	const uint32_t tilesX = (st.W + 7u) >> 3;
-	if constexpr (PEER) peerFoldWait(st);	// (peer-store transport, folded flags: every rank's cube faces of this frame have landed in this rank's set)
 	const uint32_t nRetry = MARCH ? retry[0] : 0u;
 	for (uint32_t item = blockIdx.x; !MARCH || item < nRetry; item += gridDim.x)
 	{
@@ -488,6 +506,22 @@ uint32_t launchComposite(hipStream_t s, const DeviceState& stIn, uint32_t row0, 
 	else hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 	if (!second) return 1u;
 	hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	return 2u;
+}
+
+uint32_t launchCompositeBatch(hipStream_t s, const DeviceState* states, uint32_t n)
+{
+	DeviceStateBatch p;
+	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i] = states[i < n ? i : n - 1u];
+	const DeviceState& st = states[0];
+	const uint32_t tilesX = (st.W + 7u) >> 3, T = (st.H + 7u) >> 3;
+	const uint32_t tilesY = st.shardIndex < T ? (T - st.shardIndex + st.shardCount - 1u) / st.shardCount : 0u;
+	if (!tilesY) return 0u;
+	bool second = false;
+	for (uint32_t i = 0; i < n; ++i) second = second || states[i].screenSlots < states[i].V || (states[i].flags & kFlagNoScreenLayers);
+	hipLaunchKernelGGL(compositeBatchKernel<false>, dim3(tilesX * tilesY, n), dim3(64), MV_COMPOSITE_LDS, s, p);
+	if (!second) return 1u;
+	hipLaunchKernelGGL(compositeBatchKernel<true>, dim3(512, n), dim3(64), 0, s, p);
 	return 2u;
 }
 } // namespace mv

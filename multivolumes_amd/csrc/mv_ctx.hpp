@@ -37,8 +37,12 @@ constexpr uint32_t kMaxScreenSlots = 32;	// screen-space-scheme volumes whose Ra
 // writes the buffer the relit volume held that many relights ago: frame i - lightBufs is the last that can still read it), frame slots
 // (constants + cull outputs; also the pinned upload slices) = light buffers + 1 (the cull of frame i + 1 runs while frame i - lightBufs + 1
 // is still marching).  With C = 3: 3 light buffers, 4 slots -- the numbers of rounds 1 and 2.
+// Frames per launch (mv_config.frames_per_launch = B, 1..4; the multi-GPU loop with peer stores): B consecutive frames share a view stream and
+// go through each of its long kernels together (mv_kernels.hpp DeviceStateBatch), so C x B frames are in flight: C x B output sets, C x B
+// light buffers, C x B + 1 frame slots.
 constexpr uint32_t kMaxChains = 5;
-constexpr uint32_t kMaxFrameSlots = kMaxChains + 1;
+constexpr uint32_t kMaxFramesInFlight = 16;	// C x B
+constexpr uint32_t kMaxFrameSlots = kMaxFramesInFlight + 1;
 constexpr uint32_t kNumCounters = 8;	// read back; counters[8] (the cull's ticket) is device-only
 constexpr uint32_t kNumStats = 8;
 
@@ -58,6 +62,7 @@ struct FrameBufs
 	uint64_t* cubeOffset = nullptr;
 	uint32_t* volumeFlags = nullptr;
 	uint16_t* volumeRects = nullptr;
+	uint32_t* batchInfo = nullptr;		// 8 words: what the ranks of the multi-GPU loop compare of their culls, the volumes the frames of a launch relight (cullKernel's epilogue)
 	float4* lightDirs = nullptr;
 	uint32_t* screenSlot = nullptr;
 	uint32_t* exchangeOff = nullptr;
@@ -72,7 +77,7 @@ struct FrameBufs
 // Outputs of the view march / composite and their counters: one set, or kMaxOutSets-or-fewer rotating sets with
 // MV_FLAG_PIPELINE_FRAMES (frame i uses set i % numOutSets and view stream i % numOutSets), so that the view marches of
 // consecutive frames may overlap on the GPU.
-constexpr uint32_t kMaxOutSets = kMaxChains;
+constexpr uint32_t kMaxOutSets = kMaxFramesInFlight;
 struct OutBufs
 {
 	uint2* cubeMaps = nullptr;
@@ -142,10 +147,18 @@ struct DistState
 	uint64_t peerTimeoutTicks = 30ull * 100000000ull;	// 30 s of wall_clock64 (100 MHz)
 	uint32_t rowsStream[kDistChains] = {};		// per chain: the view stream its frames run on
 	uint64_t rowsWaitFrame[kDistChains] = {};	// per chain: the newest frame whose rows this rank has composited but not yet waited for from the others (0 = none): enqueued lazily, by whatever synchronises
+	bool peerDealVolumes = false;				// MV_DIST_PEER_DEAL_VOLUMES: whole cube-map volumes per rank (dealt by cost) instead of every volume's tiles shared out
 	bool peerRowsRoot = false;					// MV_DIST_PEER_ROWS_TO_ROOT: the ranks push their rows to rank 0 only
 	bool peerFold = false;						// the waits are the consumers' own prologues (mv_kernels.hpp peerFoldWait) instead of one-wavefront kernels in front of them
 	uint32_t* dPeerCounters = nullptr;			// finished-workgroup counters of the push kernels: [kind][chain]
 	uint32_t* dPeerMismatch = nullptr;			// self-test counter
+	// several frames per launch (mv_dist_batch: ctx->framesPerLaunch > 1): the frames of the group being collected (their upload, cull and orders
+	// are enqueued; light march and view march go out together when the group is full or flushed) and of the group before it (whose composite
+	// and row push are still to be enqueued)
+	struct BatchFrame { DeviceState st; uint32_t slot = 0, set = 0, prevChain = 0; uint64_t frame = 0; bool composite = false, culled = false; };
+	BatchFrame cur[4], pend[4];
+	uint32_t nCur = 0, nPend = 0;
+	uint64_t pendBatch = 0;					// the pending group's number (peerFrame counts groups in this mode)
 	uint64_t peerSelfTests = 0;					// rounds of the self-test so far (its flag row counts in them; collective, so equal on every rank)
 };
 
@@ -158,6 +171,11 @@ struct mv_ctx
 	hipStream_t streamB[kMaxOutSets] = {};	// view march + composite of frame i on streamB[i % numOutSets] ([0] == stream; the others == stream unless pipelined)
 	OutBufs ob[kMaxOutSets];
 	uint32_t numOutSets = 1, numViewStreams = 1;
+	uint32_t framesPerLaunch = 1;		// B (mv_config.frames_per_launch): frames (k - 1) / B share view stream ((k - 1) / B) % C; the multi-GPU loop launches them together
+	uint64_t batchIndex = 0;			// B > 1: which group of B frames the current frame belongs to (what picks its view stream)
+	bool batchExplicit = false;			// the multi-GPU loop counts the groups itself (a flush may close one early); otherwise mv_update_frame derives batchIndex from the frame number
+	uint32_t batchPos = 0;				// the current frame's position in its group
+	uint32_t curChain = 0, prevChain = 0;	// the view stream of the current frame and of the frame before it (mv_update_frame)
 	uint32_t set = 0;
 	bool ownStream = false, ownStreamA = false, ownStreamL = false, ownStreamB1 = false;
 	bool cullOnChain = false;			// MV_FLAG_CULL_ON_VIEW_STREAM: upload and cull on the frame's own view stream instead of stream A
@@ -168,6 +186,7 @@ struct mv_ctx
 	uint32_t slot = 0;					// frame counter mod numSlots
 	hipEvent_t evStageA[kMaxFrameSlots] = {}, evLight[kMaxFrameSlots] = {}, evMainDone[kMaxFrameSlots] = {}, evProducers = nullptr;
 	hipEvent_t evCopy[kMaxFrameSlots] = {};	// a frame's unmarched cube faces are up to date (copyForward)
+	hipEvent_t evLanded[kMaxFrameSlots] = {};	// (multi-GPU loop, several frames per launch) every rank's marched faces of the frame's group are in this rank's output sets
 	bool copiedForward = false;			// this frame's copy-forward has been enqueued
 	bool marchedThisFrame = false;		// mv_march_view has run for the current frame (its RayCast layers are this frame's)
 	uint64_t lastCompleteFrame = 0;		// the last frame whose output set was completed (view march, or a composite-only frame's copy from every set)
@@ -224,7 +243,7 @@ struct mv_ctx
 	// record.  With whole frames on three view streams frame k - 3 sits on frame k's stream, so half of a frame's waits are of the
 	// first kind (a stream wait is ~1 us of host time on a pending event; a rank of the multi-GPU loop issued sixteen per frame).
 	struct EvTrack { hipEvent_t e = nullptr; hipStream_t on = nullptr; uint64_t seq = 0; uint64_t waited[8] = {}; };
-	EvTrack evTrack[24];
+	EvTrack evTrack[5 * kMaxFrameSlots + 4];
 	hipStream_t evStreams[8] = {};
 	uint64_t evSeq = 0;
 	double hostWaitMs = 0.0;			// time mv_update_frame spent waiting for the GPU to free a frame slot (mv_host_wait_ms)
@@ -330,7 +349,9 @@ void applyParity(mv_ctx* ctx)
 	DeviceState& st = ctx->st;
 	st.cbPerFrame = f.dCb; st.perObject = f.dPerObject;
 	st.exchangeReport = (ctx->dist && ctx->dist->reports) ? ctx->dist->reports + (size_t)ctx->slot * 8u : nullptr;
+	st.tilesReportSlot = (ctx->pinnedTiles && ctx->framesPerLaunch > 1u) ? ctx->pinnedTiles + 1u + ctx->slot : nullptr;
 	st.volumeInfo = f.volumeInfo; st.visibleVolumes = f.visibleVolumes; st.cubeMapVolumes = f.cubeMapVolumes;
+	st.batchInfo = (ctx->dist && ctx->dist->peerReady) ? f.batchInfo : nullptr; st.batchInfoPrev = q.batchInfo; st.batchPos = ctx->batchPos; st.batchPad = 0u;
 	st.counters = f.counters; st.countersPrev = q.counters; st.ownedVisible = f.ownedVisible; st.workEntries = f.workEntries; st.workTileStart = f.workTileStart;
 	st.cubeOffset = f.cubeOffset; st.volumeFlags = f.volumeFlags; st.volumeRects = f.volumeRects; st.screenSlot = f.screenSlot; st.exchangeOff = f.exchangeOff; st.lightDirs = f.lightDirs; st.lightOrder = f.lightOrder;
 	st.lightTable = f.lightTable; st.lightTablePrev = q.lightTable; st.volumeInfoPrev = q.volumeInfo; st.volConsts = f.volConsts; st.queueHeads = f.queueHeads;
@@ -415,7 +436,9 @@ hipError_t evWait(mv_ctx* ctx, hipStream_t s, hipEvent_t e)
 // stage of stream A (cull, light march) finished being enqueued: stream B stages of this frame wait for it
 // (every one of these orders streams against each other: a failure must reach the caller, or a later stage reads unfinished data)
 hipError_t stageADone(mv_ctx* ctx, bool last = true) { return ctx->leanEvents && !last ? hipSuccess : evRecord(ctx, ctx->evStageA[ctx->slot], ctx->streamA); }
-hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[ctx->frame % ctx->numViewStreams]; }
+// the view stream of the current frame, and of the frame before it
+uint32_t chainOfFrame(const mv_ctx* ctx) { return (uint32_t)((ctx->framesPerLaunch > 1u ? ctx->batchIndex : ctx->frame) % ctx->numViewStreams); }
+hipStream_t streamB(mv_ctx* ctx) { return ctx->streamB[chainOfFrame(ctx)]; }
 hipError_t stageBBegin(mv_ctx* ctx)
 {
 	const hipError_t e = evWait(ctx, streamB(ctx), ctx->evStageA[ctx->slot]);
@@ -457,7 +480,7 @@ void endStage(mv_ctx* ctx, EventPair& ev, hipStream_t stream)
 // with.  (The tail contains collectives: inside the loop these setters are collective calls, every rank makes them at the same point.)
 int drainForWrite(mv_ctx* ctx)
 {
-	if (ctx->dist && ctx->dist->pending)
+	if (ctx->dist && (ctx->dist->pending || ctx->dist->nCur || ctx->dist->nPend))
 	{
 		const int rc = mvi::distTail(ctx);
 		if (rc != MV_OK) return rc;

@@ -160,6 +160,7 @@ static int distCommonInitBody(mv_ctx* ctx)
 	ctx->st.flags |= mv::kFlagBalanceOwners;	// the cube-map volumes of a frame are dealt to the ranks by estimated cost (replicated cull: the same deal everywhere)
 #endif
 	ctx->st.flags |= mv::kFlagRotateAllLightMaps;	// every rank rotates the relit volume's light buffer: the exchange fills it on the non-owners
+	if (d->transport == 3 && !d->peerDealVolumes) ctx->st.flags |= mv::kFlagDealTiles;	// (peer stores: the view march of every cube-map volume shared out by tiles; MV_DIST_PEER_DEAL_VOLUMES keeps whole volumes per rank)
 	if (d->transport == 3) ctx->st.flags |= mv::kFlagLightLayers;	// (peer stores: the light march shared out by layers of voxel blocks -- whole cells, contiguous, pushed as plain ranges)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	return MV_OK;
@@ -173,7 +174,7 @@ static int distCommonInit(mv_ctx* ctx)
 	{
 		(void)syncAll(ctx);
 		distRelease(ctx);
-		ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers);
+		ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers | mv::kFlagDealTiles);
 	}
 	return rc;
 }
@@ -211,6 +212,7 @@ int mv_dist_init_rccl(mv_ctx* ctx, const void* id)
 	if (!ctx || !id) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, !ctx->dist, MV_ERR_INVALID_ARG, "mv_dist_init_* was already called on this context");
 	MV_REQUIRE(ctx, ctx->st.shardCount >= 1, MV_ERR_INVALID_ARG, "shard_count");
+	MV_REQUIRE(ctx, ctx->framesPerLaunch == 1u, MV_ERR_INVALID_ARG, "mv_config.frames_per_launch > 1 is the peer-store transport's (mv_dist_init_peer): a collective per frame cannot be shared by the frames of a launch");
 	DistState* d = new (std::nothrow) DistState();
 	if (!d) return MV_ERR_OUT_OF_MEMORY;
 	d->transport = 1; d->inPlaceGather = true;
@@ -248,6 +250,7 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
 {
 	if (!ctx || !allgather || !allreduce) return MV_ERR_INVALID_ARG;
 	MV_REQUIRE(ctx, !ctx->dist, MV_ERR_INVALID_ARG, "mv_dist_init_* was already called on this context");
+	MV_REQUIRE(ctx, ctx->framesPerLaunch == 1u, MV_ERR_INVALID_ARG, "mv_config.frames_per_launch > 1 is the peer-store transport's (mv_dist_init_peer): a collective per frame cannot be shared by the frames of a launch");
 	DistState* d = new (std::nothrow) DistState();
 	if (!d) return MV_ERR_OUT_OF_MEMORY;
 	d->transport = 2; d->cbAllGather = allgather; d->cbAllReduce = allreduce; d->user = user;
@@ -282,7 +285,7 @@ int mv_dist_shutdown(mv_ctx* ctx)
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	if (ctx->dist->streamX) MV_HIP(ctx, hipStreamSynchronize(ctx->dist->streamX));
 	distRelease(ctx);
-	ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers);
+	ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers | mv::kFlagDealTiles);
 	return MV_OK;
 }
 
@@ -553,6 +556,7 @@ int mv_dist_peer_export(mv_ctx* ctx, void* out)
 		"the peer-store transport needs whole-frame chains: a context created with MV_FLAG_PIPELINE_FRAMES and without MV_FLAG_SINGLE_VIEW_STREAM");
 	MV_REQUIRE(ctx, ctx->st.shardCount <= mv::kPeerMaxRanks, MV_ERR_RANGE, "the peer-store transport serves at most 64 ranks (one node)");
 	MV_REQUIRE(ctx, !ctx->rayQueue, MV_ERR_INVALID_ARG, "the peer-store transport stores from the tile march: not with MV_FLAG_RAY_QUEUE");
+	MV_REQUIRE(ctx, ctx->framesPerLaunch == 1u || ctx->cullOnChain, MV_ERR_INVALID_ARG, "mv_config.frames_per_launch > 1 needs MV_FLAG_CULL_ON_VIEW_STREAM (a group's culls go in front of its marches on the group's view stream)");
 	DistState* d = new (std::nothrow) DistState();
 	if (!d) return MV_ERR_OUT_OF_MEMORY;
 	d->transport = 3;
@@ -624,7 +628,7 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 	MV_REQUIRE(ctx, all || loopback, MV_ERR_INVALID_ARG, "the ranks' export blobs");
 	DistState* d = ctx->dist;
 	const uint32_t world = ctx->st.shardCount, rank = ctx->st.shardIndex;
-	auto bail = [&](int rc) { mvi::distRelease(ctx); ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers); return rc; };
+	auto bail = [&](int rc) { mvi::distRelease(ctx); ctx->st.flags &= ~(mv::kFlagRotateAllLightMaps | mv::kFlagBalanceOwners | mv::kFlagInterleaveRows | mv::kFlagLightLayers | mv::kFlagDealTiles); return rc; };
 	{ const hipError_t e = hipSetDevice(ctx->cfg.device); if (e != hipSuccess) return bail(fail(ctx, MV_ERR_HIP, "hipSetDevice", e)); }
 	void* mine[kPeerBuffers]; uint64_t mineBytes[kPeerBuffers];
 	peerBufferList(ctx, mine, mineBytes);
@@ -695,7 +699,14 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 	// ranks that own their GPU: a consumer's workgroups then spin on flags only OTHER GPUs raise.  Ranks that share a GPU (tests) keep the
 	// flag kernels -- one wavefront each -- so that spinning consumers can never crowd the producers they wait for out of the GPU.
 	d->peerFold = (flags & MV_DIST_PEER_FOLD) ? true : (flags & MV_DIST_PEER_NO_FOLD) ? false : (loopback || distinctDevices);
+	if (ctx->framesPerLaunch > 1u)
+	{
+		// (several frames per launch exist in the folded form only: the launches that hold the frames carry their waits and flags)
+		if (flags & MV_DIST_PEER_NO_FOLD) return bail(fail(ctx, MV_ERR_INVALID_ARG, "MV_DIST_PEER_NO_FOLD with mv_config.frames_per_launch > 1"));
+		d->peerFold = true;
+	}
 	d->peerRowsRoot = (flags & MV_DIST_PEER_ROWS_TO_ROOT) != 0;
+	d->peerDealVolumes = (flags & MV_DIST_PEER_DEAL_VOLUMES) != 0;
 	d->peerFrame = 0;
 	for (uint32_t c = 0; c < kDistChains; ++c) { d->rowsWaitFrame[c] = 0; d->rowsStream[c] = 0; }
 	const int rc = distCommonInit(ctx);	// (releases everything on failure)
@@ -856,8 +867,291 @@ static int distTailComposite(mv_ctx* ctx)
 	return MV_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Several frames per launch (mv_config.frames_per_launch = B > 1; peer stores, folded flags, MV_FLAG_CULL_ON_VIEW_STREAM).
+// A GROUP of up to B consecutive frames shares a view stream (group J on stream J % C) and one column of flag values (J): what was
+// "frame k" to the flags is "group J" here.  Per mv_dist_frame call: the frame's upload, cull and orders go out at once (a cull needs the
+// cull before it, they cannot be merged); the FIRST call of a group also enqueues the tail of the group before it -- the copy-forwards
+// inside that group, ONE composite launch and ONE row push for all its frames -- and this frame's own copy-forward; the LAST call (or a
+// flush) enqueues ONE light march and ONE view march for the group's frames (mv_kernels.hpp DeviceStateBatch: blockIdx.y = the frame).
+// Ordering is the per-slot events' of the one-frame path (every frame records its own), plus stream order inside a group.
+// ---------------------------------------------------------------------------------------------
+static bool batchMode(const mv_ctx* ctx) { return ctx->dist && ctx->dist->transport == 3 && ctx->framesPerLaunch > 1u; }
+
+// wait, on stream s, for the newest record on every OTHER stream among these events (an older record on the same stream is implied)
+static int evWaitNewestPerStream(mv_ctx* ctx, hipStream_t s, hipEvent_t const* events, uint32_t n)
+{
+	hipStream_t seen[8]; uint64_t best[8]; hipEvent_t pick[8]; uint32_t m = 0;
+	for (uint32_t i = 0; i < n; ++i)
+	{
+		mv_ctx::EvTrack* t = evFind(ctx, events[i]);
+		if (!t || t->seq == 0 || t->on == s) continue;
+		uint32_t j = 0;
+		while (j < m && seen[j] != t->on) ++j;
+		if (j == m) { if (m == 8u) { MV_HIP(ctx, evWait(ctx, s, events[i])); continue; } seen[m] = t->on; best[m] = 0; pick[m] = nullptr; ++m; }
+		if (t->seq > best[j]) { best[j] = t->seq; pick[j] = events[i]; }
+	}
+	for (uint32_t j = 0; j < m; ++j) MV_HIP(ctx, evWait(ctx, s, pick[j]));
+	return MV_OK;
+}
+
+// composite + row push of the pending group, on its stream
+static int batchTail(mv_ctx* ctx)
+{
+	DistState* d = ctx->dist;
+	const uint32_t n = d->nPend;
+	if (!n) return MV_OK;
+	const uint64_t P = d->pendBatch;
+	const uint32_t C = d->numChains, chain = (uint32_t)(P % C);
+	hipStream_t X = ctx->streamB[chain];
+	const DistState::BatchFrame& last = d->pend[n - 1u];
+	const uint32_t world = last.st.shardCount;
+	const bool peers = world > 1u;
+	uint32_t nComposite = 0;
+	DeviceState sts[mv::kMaxBatch];
+	for (uint32_t i = 0; i < n; ++i) if (d->pend[i].composite) sts[nComposite++] = d->pend[i].st;
+	const uint32_t numSlots = ctx->numSlots, sets = ctx->numOutSets;
+	// The copy-forwards first -- the one chain that runs through ALL frames (frame i's unmarched faces <- frame i - 1's set, complete only
+	// once frame i - 1's own copy has run and every rank's marched faces of it have landed): they wait for the START of the group
+	// before this one's tail (its faces landed, its copies), not for its composite and row push, so the tails of consecutive groups
+	// overlap but for ~10 us per frame.
+	if (!d->pend[0].culled)	// (else: copied from every set when the frame was begun, distFrameBatch)
+	{
+		const DistState::BatchFrame& f0 = d->pend[0];
+		const uint32_t prevSlot = (f0.slot + numSlots - 1u) % numSlots;
+		MV_HIP(ctx, evWait(ctx, X, ctx->evMainDone[(f0.slot + numSlots - (sets % numSlots)) % numSlots]));	// the set's last reader
+		MV_HIP(ctx, evWait(ctx, X, ctx->evLanded[prevSlot]));
+		MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[prevSlot]));
+		const OutBufs& other = ctx->ob[(f0.set + sets - 1u) % sets];
+		mv::launchCopyForward(X, f0.st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)f0.frame, true);
+		MV_HIP(ctx, hipGetLastError());
+		MV_HIP(ctx, evRecord(ctx, ctx->evCopy[f0.slot], X));
+	}
+	// every rank's faces of the group's frames have landed in this rank's sets (a kernel of one wavefront: the copies below read them)
+	if (peers) { const int rc = peerWaitStage(ctx, X, kStageCube, P, last.st.frameTag, last.slot); if (rc != MV_OK) return rc; }
+	MV_HIP(ctx, evRecord(ctx, ctx->evLanded[last.slot], X));
+	const bool foldedWait = false;
+	for (uint32_t i = 1; i < n; ++i)
+	{
+		const OutBufs& other = ctx->ob[d->pend[i - 1u].set];
+		mv::launchCopyForward(X, d->pend[i].st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)d->pend[i].frame, true);
+		MV_HIP(ctx, hipGetLastError());
+		MV_HIP(ctx, evRecord(ctx, ctx->evCopy[d->pend[i].slot], X));
+	}
+	if (nComposite)
+	{
+		for (uint32_t i = 0; i < nComposite; ++i)
+		{
+			foldBase(ctx, sts[i], kFoldComposite, P, last.st.frameTag, last.slot);
+			if (foldedWait) foldWait(ctx, sts[i], kStageCube, P);
+		}
+		mv::launchCompositeBatch(X, sts, nComposite);
+		MV_HIP(ctx, hipGetLastError());
+		d->bytes += (size_t)nComposite * last.st.H * last.st.W * sizeof(uint2) / world * (d->peerRowsRoot ? (last.st.shardIndex ? 0u : world - 1u) : world - 1u);
+	}
+	if (peers)
+	{
+		if (nComposite)
+		{
+			// this rank's rows of every composited frame into every rank's frame buffers; the launch's last workgroup raises "rows landed" and "done"
+			for (uint32_t i = 0; i < nComposite; ++i)
+			{
+				foldBase(ctx, sts[i], kFoldComposite, P, last.st.frameTag, last.slot);
+				foldSignal(ctx, sts[i], kStageRows, P);
+				foldSignal(ctx, sts[i], kStageDone, P);
+				sts[i].fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
+			}
+			mv::launchPeerPushRowsBatch(X, sts, nComposite);
+			d->rowsWaitFrame[chain] = P; d->rowsStream[chain] = chain;
+		}
+		else
+		{
+			mv::PeerSync a = peerSyncBase(ctx, last.st.frameTag, last.slot);
+			a.nSignal = 1; a.signalRow[0] = kStageDone * mv::kPeerMaxChains + chain; a.signalValue[0] = P;
+			mv::launchPeerSync(X, a);
+		}
+		MV_HIP(ctx, hipGetLastError());
+	}
+	// everything that reads these frames' buffers has been enqueued: the next users of their slots / output sets / light buffers wait for this
+	for (uint32_t i = 0; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[d->pend[i].slot], X));
+	d->nPend = 0;
+	return MV_OK;
+}
+
+// light march + view march of the group being collected, on its stream
+static int batchClose(mv_ctx* ctx)
+{
+	DistState* d = ctx->dist;
+	const uint32_t n = d->nCur;
+	if (!n) return MV_OK;
+	const uint64_t J = d->peerFrame;
+	const uint32_t C = d->numChains, chain = (uint32_t)(J % C);
+	hipStream_t S = ctx->streamB[chain];
+	const DistState::BatchFrame& last = d->cur[n - 1u];
+	const bool peers = last.st.shardCount > 1u;
+	const uint32_t numSlots = ctx->numSlots, sets = ctx->numOutSets, lb = ctx->st.lightBufs;
+	DeviceState sts[mv::kMaxBatch];
+
+	// ---- culls and orders: one launch each (the workgroups of frame i + 1 wait for frame i's inside it: mv_kernels.hip cullBatchKernel) ----
+	{
+		MV_SECTION(1);
+		const uint32_t k0 = d->cur[0].culled ? 1u : 0u;
+		if (n > k0)
+		{
+			for (uint32_t i = k0; i < n; ++i) sts[i] = d->cur[i].st;
+			// (the cull of the frame before the group's first: the light table, VolumeInfo rows and view hash it left)
+			MV_HIP(ctx, evWait(ctx, S, ctx->evStageA[(d->cur[k0].slot + numSlots - 1u) % numSlots]));
+			mv::launchCullBatch(S, sts + k0, n - k0);
+			mv::launchOrdersBatch(S, sts + k0, n - k0);
+			MV_HIP(ctx, hipGetLastError());
+			for (uint32_t i = k0; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evStageA[d->cur[i].slot], S));
+		}
+		ctx->haveCull = true;
+	}
+	// ---- light marches: each frame relights its volume into that volume's freshly rotated buffer ----
+	{
+		MV_SECTION(5);
+		hipEvent_t ev[2 * mv::kMaxBatch]; uint32_t m = 0;
+		for (uint32_t i = 0; i < n; ++i) { ev[m++] = ctx->evMainDone[(d->cur[i].slot + numSlots - lb) % numSlots]; ev[m++] = ctx->evStageA[d->cur[i].slot]; }
+		{ const int rc = evWaitNewestPerStream(ctx, S, ev, m); if (rc != MV_OK) return rc; }
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			sts[i] = d->cur[i].st;
+			foldBase(ctx, sts[i], kFoldLight, J, last.st.frameTag, last.slot);
+		}
+		// Every rank is done with the groups whose frames still read what this group's light pushes and cube stores overwrite.  A
+		// one-wavefront kernel in front of the launch, not the launch's own prologue: a launch that holds B frames would put B times the
+		// workgroups on the GPU to spin -- enough, with the launches of the other streams doing the same, to keep the kernels they all
+		// wait for (this rank's own tails on the other streams among them) from ever getting a slot.
+		if (peers)
+		{
+			mv::PeerSync a = peerSyncBase(ctx, last.st.frameTag, last.slot);
+			for (uint32_t c = 0; c < C; ++c) if (J > (uint64_t)C + c) { a.waitRow[a.nWait] = kStageDone * mv::kPeerMaxChains + (uint32_t)((J - C - c) % C); a.waitValue[a.nWait++] = J - C - c; }
+			if (a.nWait) { mv::launchPeerSync(S, a); MV_HIP(ctx, hipGetLastError()); }
+		}
+		mv::launchMarchLightBatch(S, sts, n);
+		MV_HIP(ctx, hipGetLastError());
+		for (uint32_t i = 0; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evLight[d->cur[i].slot], S));
+		if (peers) d->bytes += (size_t)n * last.st.L * last.st.L * last.st.L * sizeof(uint4) / last.st.shardCount * (last.st.shardCount - 1u);
+	}
+	// ---- view marches ----
+	{
+		MV_SECTION(6);
+		hipEvent_t ev[3 * mv::kMaxBatch + kMaxFramesInFlight]; uint32_t m = 0;
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			const uint32_t slot = d->cur[i].slot;
+			ev[m++] = ctx->evCopy[(slot + numSlots - (sets - 1u)) % numSlots];		// the copy-forward that read this set as its source
+			ev[m++] = ctx->evMainDone[(slot + numSlots - (sets % numSlots)) % numSlots];	// the set's previous user
+		}
+		// this rank's light marches of the frames before these on the other streams (a view march reads every visible volume's light map)
+		for (uint32_t j = 0; j < sets && j < numSlots; ++j) ev[m++] = ctx->evLight[(last.slot + numSlots - j) % numSlots];
+		{ const int rc = evWaitNewestPerStream(ctx, S, ev, m); if (rc != MV_OK) return rc; }
+		uint32_t tiles[mv::kMaxBatch], beyond[mv::kMaxBatch];
+		bool overflow = false;
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			// the grid from this frame's own tile count if its cull has already reported it, else from the newest report there is, with a margin
+			tiles[i] = 0xffffffffu;
+			bool exact = false;
+			const unsigned long long own = *reinterpret_cast<const volatile unsigned long long*>(ctx->pinnedTiles + 1u + d->cur[i].slot);
+			const unsigned long long any = *reinterpret_cast<const volatile unsigned long long*>(ctx->pinnedTiles);
+			if (own != ~0ull && (uint32_t)(own >> 32) == d->cur[i].st.frameTag) { tiles[i] = (uint32_t)own; exact = true; }
+			else if (any != ~0ull) { const uint32_t count = (uint32_t)any; tiles[i] = count + count / 4u + 256u; }
+			if (!exact && mv::marchTilesBeyond(d->cur[i].st, tiles[i]) != 0xffffffffu) overflow = true;
+		}
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			sts[i] = d->cur[i].st;
+			foldBase(ctx, sts[i], kFoldView, J, last.st.frameTag, last.slot);
+			sts[i].fold.checkInfo = ctx->fb[last.slot].batchInfo;
+			if (peers)
+			{
+				foldWait(ctx, sts[i], kStageLight, J);	// (row 0 = this group's own: waited for by the tiles that read a map relit in it; the older groups': the kernel below)
+				if (d->cullCrosscheck) { sts[i].fold.checkChain = chain; sts[i].fold.checkCompare = 1u; }
+				foldSignal(ctx, sts[i], kStageCube, J);
+				sts[i].fold.stores = 1u;
+				sts[i].fold.pushBlocks = kPeerLightPushBlocks;
+				sts[i].fold.pushRow = kStageLight * mv::kPeerMaxChains + chain;
+				sts[i].fold.pushValue = J;
+				sts[i].fold.pushCounter = d->dPeerCounters + kFoldLight * mv::kPeerMaxChains + chain;
+				sts[i].fold.pushCheckChain = d->cullCrosscheck ? chain : 0xffffffffu;
+			}
+		}
+		// every rank's layers of the maps relit in the C - 1 groups before this one (on the other streams) have landed: again a kernel of
+		// one wavefront in front of the launch instead of a wait in every workgroup of it
+		if (peers && J > 1u)
+		{
+			mv::PeerSync a = peerSyncBase(ctx, last.st.frameTag, last.slot);
+			for (uint32_t c = 1; c < C; ++c) if (J > c) { a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + (uint32_t)((J - c) % C); a.waitValue[a.nWait++] = J - c; }
+			if (a.nWait) { mv::launchPeerSync(S, a); MV_HIP(ctx, hipGetLastError()); }
+		}
+		// (the main launch waits; the LAST launch raises "cube faces landed": the overflow launch if there is one)
+		DeviceState main[mv::kMaxBatch];
+		for (uint32_t i = 0; i < n; ++i) { main[i] = sts[i]; if (overflow) main[i].fold.nSignal = 0u; }
+		mv::launchMarchTilesBatch(S, main, n, tiles, beyond);
+		if (overflow)
+		{
+			for (uint32_t i = 0; i < n; ++i) { sts[i].fold.nWait = 0u; sts[i].fold.pushBlocks = 0u; }
+			mv::launchMarchTilesOverflowBatch(S, sts, n, beyond);
+		}
+		MV_HIP(ctx, hipGetLastError());
+	}
+	for (uint32_t i = 0; i < n; ++i) d->pend[i] = d->cur[i];
+	d->nPend = n; d->pendBatch = J; d->nCur = 0;
+	return MV_OK;
+}
+
+static int distFrameBatch(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite)
+{
+	DistState* d = ctx->dist;
+	MV_REQUIRE(ctx, d->peerReady, MV_ERR_NOT_READY, "mv_dist_init_peer has not been called (mv_dist_peer_export alone attaches nothing)");
+	int rc;
+	if ((rc = peerCheckReports(ctx)) != MV_OK) return rc;
+	const bool first = d->nCur == 0u;
+	if (first) ++d->peerFrame;	// (counts groups here)
+	ctx->batchExplicit = true; ctx->batchIndex = d->peerFrame; ctx->batchPos = d->nCur;
+	struct Lean { mv_ctx* c; ~Lean() { c->leanEvents = false; } } lean = { ctx };
+	ctx->leanEvents = true;
+#ifdef MV_HOST_PROFILE
+	++gSectionCalls;
+#endif
+	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
+	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
+	{ MV_SECTION(0); rc = mv_update_frame(ctx, cbPerFrame, perObject); }	// (the upload; the culls of the group go out together, batchClose)
+	ctx->batchExplicit = false;
+	if (rc != MV_OK) return rc;
+	bool culled = false;
+	if (first)
+	{
+		// the group before this one: its composite and row push
+		{ MV_SECTION(4); if ((rc = batchTail(ctx)) != MV_OK) return rc; }
+		if (ctx->lastCompleteFrame != 0u && ctx->lastCompleteFrame + 1u != ctx->frame)
+		{
+			// (the frame before this one left its output set untouched -- frames outside the loop in between: this frame's copy-forward
+			// takes the slow way, from every set, which needs its cull now)
+			MV_SECTION(3);
+			MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evStageA[(ctx->slot + ctx->numSlots - 1u) % ctx->numSlots]));
+			if ((rc = mv_cull(ctx)) != MV_OK) return rc;
+			if ((rc = viewCopyForward(ctx)) != MV_OK) return rc;
+			culled = true;
+		}
+	}
+	ctx->lastCompleteFrame = ctx->frame;	// (its copy-forward goes out with the group: batchClose for the first frame, the group's tail for the others)
+	DistState::BatchFrame& f = d->cur[d->nCur++];
+	f.st = ctx->st; f.slot = ctx->slot; f.set = ctx->set; f.frame = ctx->frame; f.composite = with_composite != 0; f.culled = culled; f.prevChain = ctx->prevChain;
+	ctx->marchedThisFrame = true; ctx->lightMarched = true;
+	if (d->nCur == ctx->framesPerLaunch) return batchClose(ctx);
+	return MV_OK;
+}
+
 int mvi::distTail(mv_ctx* ctx)
 {
+	if (batchMode(ctx))
+	{
+		const int rc = batchClose(ctx);
+		return rc != MV_OK ? rc : batchTail(ctx);
+	}
 	const int rc = distTailExchange(ctx);
 	return rc != MV_OK ? rc : distTailComposite(ctx);
 }
@@ -912,6 +1206,7 @@ int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, in
 	MV_REQUIRE(ctx, ctx->dist, MV_ERR_NOT_READY, "mv_dist_init_rccl / mv_dist_init_callbacks has not been called");
 	DistState* d = ctx->dist;
 	int rc;
+	if (batchMode(ctx)) return distFrameBatch(ctx, cbPerFrame, perObject, with_composite);
 	if (d->transport == 3)
 	{
 		MV_REQUIRE(ctx, d->peerReady, MV_ERR_NOT_READY, "mv_dist_init_peer has not been called (mv_dist_peer_export alone attaches nothing)");

@@ -254,7 +254,26 @@ __constant__ uint8_t kFaceEdges[6][4] = { {8,3,9,6},{10,2,11,7},{0,8,5,11},{1,10
 
 constexpr uint32_t kCullThreads = 64;
 
-__global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
+__device__ __forceinline__ void cullBody(const DeviceState& st);
+__global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st) { cullBody(st); }
+// The culls of several consecutive frames in one launch (mv_kernels.hpp DeviceStateBatch; the multi-GPU loop with several frames per
+// launch): blockIdx.y is the frame.  A frame's cull reads what the cull before it wrote -- the VolumeInfo rows of culled volumes, the
+// light-map table it rotates, the view hash, the launch's cull words -- so the workgroups of frame y wait for the last wavefront of frame
+// y - 1 to say it is through (batchInfo[3] = its frame tag).  A handful of workgroups, dispatched in that order: all resident.
+// What it saves: a rank's culls are a chain through ALL its frames (upload, cull, orders, ~50 us a frame) that nothing can overlap.
+__global__ __launch_bounds__(kCullThreads) void cullBatchKernel(DeviceStateBatch p)
+{
+	const DeviceState& st = p.s[blockIdx.y];
+	if (blockIdx.y)
+	{
+		const uint32_t want = st.frameTag - 1u;
+		if (threadIdx.x == 0) while (__hip_atomic_load(st.batchInfoPrev + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(2);
+		__syncthreads();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+	}
+	cullBody(st);
+}
+__device__ __forceinline__ void cullBody(const DeviceState& st)
 {
 	extern __shared__ uint32_t sInfo[];	// per volume: bit0 visible, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask; then V x 2 words of screen rectangle
 	uint32_t* sRect = sInfo + st.V;
@@ -463,7 +482,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	const uint32_t shardCount = st.shardCount ? st.shardCount : 1u;
 	if (shardCount > 1u)
 	{
-		const bool balance = (st.flags & kFlagBalanceOwners) && shardCount <= 64u;
+		const bool balance = (st.flags & kFlagBalanceOwners) && shardCount <= 64u && !(st.flags & kFlagDealTiles);	// (tiles dealt: every rank marches its tiles of every volume, nothing to balance)
 		uint32_t nDeal = 0;
 		for (uint32_t v = lane; v < st.V; v += 64)
 		{
@@ -585,7 +604,8 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		const uint32_t info = v < st.V ? sInfo[v] : 0u;
 		const bool vis = info & 1u, cube = info & 2u;
 		const bool owned = (v % shardCount) == st.shardIndex;	// (the light march's and the whole-cube exchange's notion: fixed)
-		const bool marches = shardCount > 1u ? (info >> 16) == st.shardIndex : true;	// this frame's view march of a cube-map volume
+		const bool dealTiles = (st.flags & kFlagDealTiles) && shardCount > 1u;
+		const bool marches = (shardCount > 1u && !dealTiles) ? (info >> 16) == st.shardIndex : true;	// this frame's view march of a cube-map volume
 		const uint32_t mip = (info >> 2) & 7u, mask = (info >> 5) & 0x3fu;
 		const uint64_t bVis = __ballot(vis), bCube = __ballot(cube), bOwn = __ballot(vis && owned);
 		if (vis)
@@ -599,8 +619,9 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		nVis += __popcll(bVis); nCube += __popcll(bCube); nOwned += __popcll(bOwn);
 
 		const uint32_t dims = st.N >> mip;
-		const uint32_t tilesPerFace = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
-		const uint32_t myFaces = (cube && marches) ? (uint32_t)__popc(mask) : 0u;
+		const uint32_t tilesOfFace = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
+		const uint32_t tilesPerFace = dealTiles ? dealtTilesOfFace(tilesOfFace, st.shardIndex, shardCount, v) : tilesOfFace;	// (this rank's)
+		const uint32_t myFaces = (cube && marches && tilesPerFace) ? (uint32_t)__popc(mask) : 0u;
 		uint32_t totFaces, totTiles;
 		const uint32_t eBase = nEntries + waveExclusiveScanU32(myFaces, lane, totFaces);
 		const uint32_t tBase = nTiles + waveExclusiveScanU32(myFaces * tilesPerFace, lane, totTiles);
@@ -618,6 +639,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(minMip, o); minMip = m < minMip ? m : minMip; }
 
 	// This frame's light-map table = last frame's, with the volume this shard is about to relight switched to its next buffer.
+	uint32_t relitOfFrame = 0xffffffffu;	// (the volume CSRayMarchL relights this frame, whoever owns it)
 	{
 		uint32_t relit;
 		if (nVis)
@@ -639,6 +661,7 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		else relit = relitVolume(st, cb->frameIdx, 0u, nullptr);
 		// another shard's: nothing rotates here -- unless the context keeps every light map current through mv_dist_frame's exchange,
 		// which fills the fresh buffer on the ranks that do not own the volume
+		relitOfFrame = relit;
 		if (!ownsVolume(st, relit) && !(st.flags & kFlagRotateAllLightMaps)) relit = 0xffffffffu;
 		const size_t L3 = (size_t)st.L * st.L * st.L;
 		for (uint32_t v = lane; v < st.V; v += 64)
@@ -736,6 +759,26 @@ __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st)
 		st.counters[10] = viewHash;
 		// host-visible {frame tag : tile count}: a hint for the grid sizes of later launches; the host never waits for it (mv_api.cpp)
 		if (st.tilesReport) *st.tilesReport = ((unsigned long long)st.frameTag << 32) | nTiles;
+		if (st.tilesReportSlot) *st.tilesReportSlot = ((unsigned long long)st.frameTag << 32) | nTiles;
+		// What the ranks of the multi-GPU loop compare of their culls ([0..2]: hash, visible, cube-map volumes) and which volumes the
+		// frames of this launch relight ([4 + position]) -- carried from frame to frame of a launch that holds several (batchPos > 0:
+		// the previous frame's words are folded in, position-weighted), so that the launch's LAST frame holds the words for all of them
+		// and the march needs no other frame's state (mv_kernels.hpp DeviceStateBatch).
+		if (st.batchInfo)
+		{
+			const uint32_t pos = st.batchPos, h = st.counters[12];
+			const bool carry = pos != 0u && st.batchInfoPrev;
+			st.batchInfo[0] = (carry ? st.batchInfoPrev[0] : 0u) + (pos ? (h << (7u * pos)) | (h >> (32u - 7u * pos)) : h);
+			st.batchInfo[1] = (carry ? st.batchInfoPrev[1] : 0u) + nVis * (2u * pos + 1u);
+			st.batchInfo[2] = (carry ? st.batchInfoPrev[2] : 0u) + nCube * (2u * pos + 1u);
+			for (uint32_t j = 0; j < kMaxBatch; ++j) st.batchInfo[4u + j] = j == pos ? relitOfFrame : (carry && j < pos ? st.batchInfoPrev[4u + j] : 0xffffffffu);
+		}
+	}
+	// "this frame's cull is through" -- for the next frame's workgroups when they sit in the same launch (cullBatchKernel)
+	if (st.batchInfo)
+	{
+		__threadfence();
+		if (lane == 0) __hip_atomic_store(st.batchInfo + 3, st.frameTag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 	}
 }
 
@@ -938,6 +981,18 @@ __global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLig
 	// (peer-store transport, folded wait: until every rank is done with the frames that read what this launch -- and the push behind it -- overwrite)
 	if constexpr (PEER) peerFoldWait(st);
 	marchLightBody<LUT, ORDERED, K, PEER>(st, wordsOut, sAxis, sCand);
+}
+
+// several frames in one launch (mv_kernels.hpp DeviceStateBatch; peer-store transport, folded wait): blockIdx.y is the frame -- each
+// relights its own volume into its own freshly rotated buffer
+template <bool LUT, bool ORDERED, int K>
+__global__ __launch_bounds__(64 * kLightWaves, MV_LIGHT_MIN_WAVES) void marchLightBatchKernel(DeviceStateBatch p)
+{
+	__shared__ u32x4 sAxis[LUT ? 3 * (kLightLutMaxN + 1) : 1];
+	__shared__ unsigned long long sCand[kLightWaves][(1024u + 63u) / 64u];
+	const DeviceState& st = p.s[blockIdx.y];
+	peerFoldWait(st);
+	marchLightBody<LUT, ORDERED, K, true>(st, nullptr, sAxis, sCand);
 }
 
 template <bool LUT, bool ORDERED, int K, bool PEER>
@@ -1165,7 +1220,7 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 		if (sStart[mid] <= tile) lo = mid; else hi = mid;
 	}
 	const uint32_t we = sEntry[lo];
-	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16, localTile = tile - sStart[lo];
+	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16, localTile = faceId == 7u ? tile - sStart[lo] : cubeLocalTile(st, volumeId, tile - sStart[lo]);
 	const uint32_t key = tileCostKey(st, volumeId, faceId, localTile, tile, nCubeTiles);
 	const uint32_t width = st.maxRaySamples >= kOrderBins ? st.maxRaySamples / kOrderBins : 1u;
 	uint32_t cost = st.tileCost[key];
@@ -1362,6 +1417,12 @@ void launchCull(hipStream_t s, const DeviceState& st)
 {
 	hipLaunchKernelGGL(cullKernel, dim3((st.V + 7u) / 8u), dim3(kCullThreads), st.V * 4 * sizeof(uint32_t), s, st);
 }
+void launchCullBatch(hipStream_t s, const DeviceState* states, uint32_t n)
+{
+	DeviceStateBatch p;
+	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i] = states[i < n ? i : n - 1u];
+	hipLaunchKernelGGL(cullBatchKernel, dim3((states[0].V + 7u) / 8u, n), dim3(kCullThreads), states[0].V * 4 * sizeof(uint32_t), s, p);
+}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1480,6 +1541,26 @@ __global__ __launch_bounds__(kLightOrderThreads) void ordersKernel(DeviceState s
 	else lightOrderRole(st, sOrders);
 }
 
+__global__ __launch_bounds__(kLightOrderThreads) void ordersBatchKernel(DeviceStateBatch p, uint32_t tileGroups)	// blockIdx.y = the frame
+{
+	extern __shared__ uint32_t sOrders[];
+	const DeviceState& st = p.s[blockIdx.y];
+	if (blockIdx.x < tileGroups) tileOrderRole(st, sOrders, blockIdx.x * (kLightOrderThreads / 64u) + (threadIdx.x >> 6), tileGroups * (kLightOrderThreads / 64u));
+	else lightOrderRole(st, sOrders);
+}
+void launchOrdersBatch(hipStream_t s, const DeviceState* states, uint32_t n)
+{
+	const DeviceState& st = states[0];
+	const bool tiles = st.tileOrder != nullptr;
+	const bool light = st.lightOrder && ((st.L + 3u) >> 2) <= kLightOrderMaxB;
+	if (!tiles && !light) return;
+	DeviceStateBatch p;
+	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i] = states[i < n ? i : n - 1u];
+	const size_t tileLds = (2 * ((size_t)st.V * 6 + st.screenSlots) + 1) * sizeof(uint32_t), lightLds = (size_t)kLightOrderLdsWords * sizeof(uint32_t);
+	const uint32_t tileGroups = tiles ? kOrderGroups : 0u;
+	hipLaunchKernelGGL(ordersBatchKernel, dim3(tileGroups + (light ? 1u : 0u), n), dim3(kLightOrderThreads), tileLds > lightLds ? tileLds : lightLds, s, p, tileGroups);
+}
+
 void launchOrders(hipStream_t s, const DeviceState& st)
 {
 	const bool tiles = st.tileOrder != nullptr;
@@ -1566,6 +1647,28 @@ void launchMarchLight(hipStream_t s, const DeviceState& st, uint32_t* wordsOut)
 	const uint32_t count = lightShare(st, total).per;	// (the same grid on every rank; the last rank's share may be shorter)
 	if (MV_LIGHT_SPECULATE && count < MV_LIGHT_SPECULATE_BELOW) launchMarchLightK<4>(s, st, wordsOut, count);
 	else launchMarchLightK<MV_LIGHT_SPECULATE ? 1 : 0>(s, st, wordsOut, count);
+}
+
+void launchMarchLightBatch(hipStream_t s, const DeviceState* states, uint32_t n)
+{
+	DeviceStateBatch p;
+	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i] = states[i < n ? i : n - 1u];
+	const DeviceState& st = states[0];
+	const uint32_t b = (st.L + 3u) >> 2, total = b * b * b;
+	const uint32_t count = lightShare(st, total).per;
+	constexpr int K = MV_LIGHT_SPECULATE ? 1 : 0;
+	const bool lut = MV_LIGHT_LUT && st.N <= kLightLutMaxN;
+	if (lightOrdered(st))
+	{
+		const uint32_t perXcd = (count + 7u) >> 3;
+		const dim3 grid(8u * ((perXcd + kLightWaves - 1u) / kLightWaves), n);
+		if (lut) hipLaunchKernelGGL((marchLightBatchKernel<true, true, K>), grid, dim3(64 * kLightWaves), 0, s, p);
+		else hipLaunchKernelGGL((marchLightBatchKernel<false, true, K>), grid, dim3(64 * kLightWaves), 0, s, p);
+		return;
+	}
+	const dim3 grid((count + kLightWaves - 1u) / kLightWaves, n);
+	if (lut) hipLaunchKernelGGL((marchLightBatchKernel<true, false, K>), grid, dim3(64 * kLightWaves), 0, s, p);
+	else hipLaunchKernelGGL((marchLightBatchKernel<false, false, K>), grid, dim3(64 * kLightWaves), 0, s, p);
 }
 
 void launchLightUnpack(hipStream_t s, const DeviceState& st, const uint32_t* words)

@@ -109,9 +109,13 @@ struct DeviceState
 	uint32_t* cubeMapVolumes;		// V
 	unsigned long long* tilesReport;	// pinned host memory (may be NULL): the cull stores {frameTag : tile count} here -- a HINT for the host's
 									// next grid sizes, read without ever waiting for it
+	unsigned long long* tilesReportSlot;	// the same word once more, in this frame slot's own place (several frames per launch: every frame's count, not just the newest)
 	unsigned long long* exchangeReport;	// pinned host memory (NULL outside the multi-GPU frame loop): {frameTag : texels of the largest shard of this frame's cube-face exchange}
 	uint32_t frameTag;				// low 32 bits of the context's frame counter
 	const uint32_t* countersPrev;	// the previous frame's counters (its [10]: the hash the cull compares this frame's with)
+	uint32_t* batchInfo;			// 8 words per frame slot (NULL outside the multi-GPU loop's peer stores): what the ranks compare of their culls, the volumes
+	const uint32_t* batchInfoPrev;	//   relit by the frames of a launch so far (cullKernel's epilogue); the previous frame's
+	uint32_t batchPos, batchPad;	// position of this frame among the frames of its launch (mv_config.frames_per_launch; 0 when there is one)
 	uint32_t* counters;				// [0] visible count, [1] cube-map count, [2] work entries, [3] total tiles,
 									// [4] owned visible count, [5] min selected mip over visible volumes, [6] cube tiles (screen tiles follow),
 									// [8] the cull's ticket, [9] head of the march's ray queue (device-only), [10] hash of the frame's camera and volume
@@ -172,11 +176,19 @@ struct DeviceState
 		uint32_t pushBlocks, pushRow, pushCheckChain, pad;
 		unsigned long long pushValue;
 		uint32_t* pushCounter;
+		const uint32_t* checkInfo;				// NULL, or the batchInfo of the launch's last frame: the cull words of all its frames (several frames per launch)
 		uint32_t stores, rowsRoot;				// stores: (view march) this launch also stores its texels into the other ranks' cube maps; rowsRoot: (row push) to rank 0 only
 		uint32_t waitRow[6], signalRow[2];
 		unsigned long long waitValue[6], signalValue[2];
 	} fold;
 };
+// Several frames in ONE launch (mv_config.frames_per_launch, the multi-GPU frame loop with peer stores): blockIdx.y picks the frame.  A
+// rank of eight has an eighth of a frame's tiles, voxel blocks and rows -- a wavefront per SIMD or less, so that every long kernel of its
+// chain lasts as long as its longest ray whatever else the GPU could do meanwhile, and four hardware queues are all the frames that can
+// overlap.  B frames per launch put B wavefronts where one was: the chain gets little longer and carries B frames.
+// The states travel by value in the kernel argument segment (784 bytes each: four fit under its 4 KB).
+constexpr uint32_t kMaxBatch = 4;
+struct DeviceStateBatch { DeviceState s[kMaxBatch]; };
 // Stores into a peer's memory: written through at SYSTEM scope (global_store ... sc0 sc1: the acknowledgement comes from the memory that
 // owns the address, nothing is left dirty in this GPU's L2), so that "complete" is the storing wavefront's s_waitcnt vmcnt(0) and no
 // cache has to be written back in front of the flag that announces them.  16 bytes per store wherever a range allows it: narrower
@@ -250,6 +262,17 @@ __device__ __forceinline__ void peerFoldWait(const DeviceState& st, uint32_t fir
 
 // The same wait by ONE wavefront for itself (all its lanes call it; no barrier): the view march's wavefronts whose tile reads the light map
 // relit in this frame wait for that frame's row -- and wavefront `compare` of the launch also compares the ranks' cull words behind it.
+// What a rank's cull decided for the frame(s) of a launch, as the four words the ranks compare: the frame tag and the cull's words of
+// the launch's last frame (checkInfo: cullKernel folds the earlier frames' in; one frame per launch: hash, visible, cube-map volumes).
+// (Nothing here walks the other frames' states: they are a by-value kernel argument, which the compiler reads straight from the argument
+// segment only while every access has one dynamic index at most -- otherwise each workgroup first copies 3 KB into scratch.)
+__device__ __forceinline__ void peerCheckWordsOf(const DeviceState& st, uint32_t w[4])
+{
+	const uint32_t* info = st.fold.checkInfo;
+	w[0] = st.fold.frameTag;
+	if (info) { w[1] = info[0]; w[2] = info[1]; w[3] = info[2]; }
+	else { w[1] = st.counters[12]; w[2] = st.counters[0]; w[3] = st.counters[1]; }
+}
 __device__ __forceinline__ void peerFoldWaitWave(const DeviceState& st, uint32_t firstRow, uint32_t endRow, bool compare)
 {
 	const uint32_t lane = threadIdx.x & 63u;
@@ -274,7 +297,8 @@ __device__ __forceinline__ void peerFoldWaitWave(const DeviceState& st, uint32_t
 	if (compare && st.fold.checkCompare && st.fold.checkChain != 0xffffffffu)
 	{
 		const uint32_t* all = reinterpret_cast<const uint32_t*>(st.fold.myFlags + kPeerFlagWords) + (size_t)st.fold.checkChain * kPeerMaxRanks * kPeerCheckWords;
-		const uint32_t mine[4] = { st.fold.frameTag, st.counters[12], st.counters[0], st.counters[1] };
+		uint32_t mine[4];
+		peerCheckWordsOf(st, mine);
 		bool differs = false;
 		for (uint32_t p = lane; p < st.peerCount; p += 64u)
 			for (uint32_t w = 0; w < kPeerCheckWords; ++w)
@@ -311,19 +335,37 @@ __device__ __forceinline__ void peerRaise(const DeviceState& st, uint32_t* count
 		if (checkChain != 0xffffffffu)
 		{
 			uint32_t* words = reinterpret_cast<uint32_t*>(block + kPeerFlagWords) + ((size_t)checkChain * kPeerMaxRanks + column) * kPeerCheckWords;
-			peerStore(words + 0, st.fold.frameTag); peerStore(words + 1, st.counters[12]); peerStore(words + 2, st.counters[0]); peerStore(words + 3, st.counters[1]);
+			uint32_t mine[4];
+			peerCheckWordsOf(st, mine);
+			peerStore(words + 0, mine[0]); peerStore(words + 1, mine[1]); peerStore(words + 2, mine[2]); peerStore(words + 3, mine[3]);
 			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// the words are there before the flag that announces them
 		}
 		for (uint32_t i = 0; i < nSignal; ++i)
 			__hip_atomic_store(block + (size_t)rows[i] * kPeerMaxRanks + column, values[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 }
+// (several frames per launch: the frames share the counter, the rows and the values -- the last workgroup of the WHOLE launch raises)
 __device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
 {
 	if (!st.fold.nSignal) return;
 	peerRaise(st, st.fold.counter, gridDim.x * gridDim.y, st.fold.nSignal, st.fold.signalRow, st.fold.signalValue, st.fold.checkCompare ? 0xffffffffu : st.fold.checkChain);
 }
 
+constexpr uint32_t kFlagDealTiles = 0x04000000u;	// DeviceState.flags (internal, peer-store transport): the view march of EVERY cube-map volume is shared out by tiles -- rank r marches the tiles t of
+													// each marched face with (t + volume) % shardCount == r -- instead of whole volumes dealt by estimated cost: ten visible volumes on eight ranks leave two ranks
+													// with two volumes each (profiles/r04_frames_per_launch.txt); a march that stores its texels into every rank's cube maps itself does not care who owns what
+// kFlagDealTiles: the k-th tile this rank marches of a face of volume v, and how many of a face's T tiles are its
+__host__ __device__ inline uint32_t dealtTileFirst(uint32_t shardIndex, uint32_t shardCount, uint32_t v) { return (shardIndex + shardCount - v % shardCount) % shardCount; }
+__host__ __device__ inline uint32_t dealtTilesOfFace(uint32_t T, uint32_t shardIndex, uint32_t shardCount, uint32_t v)
+{
+	const uint32_t first = dealtTileFirst(shardIndex, shardCount, v);
+	return first < T ? (T - first + shardCount - 1u) / shardCount : 0u;
+}
+__device__ __forceinline__ uint32_t cubeLocalTile(const DeviceState& st, uint32_t volumeId, uint32_t k)
+{
+	if (!(st.flags & kFlagDealTiles) || st.shardCount <= 1u) return k;
+	return dealtTileFirst(st.shardIndex, st.shardCount, volumeId) + k * st.shardCount;
+}
 // Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
 // their position among this frame's screen tiles.  A key that names another tile after a mip / visibility change only
 // misorders the dispatch.
@@ -521,6 +563,16 @@ uint32_t marchTilesBeyond(const DeviceState& st, uint32_t gridTiles);	// what la
 bool marchTilesNarrow(const DeviceState& st, uint64_t tiles);	// a launch of that many tiles takes the latency-oriented form (mv_march_narrow.hip: eight lanes per ray, speculative requests)
 void launchMarchTilesNarrow(hipStream_t s, const DeviceState& st, uint32_t blocks);	// one workgroup per dispatch slot
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot);	// one wavefront per tile (mv_march_tiles.hip)
+// Several frames per launch (DeviceStateBatch; peer-store transport, folded flags: every state carries its launch's fold fields, the frames
+// of a launch share counters, rows and values).  gridTiles[i]: the host's estimate of frame i's tile count; beyond[i]: the first dispatch slot
+// of frame i the grid does not cover (0xffffffff: none) -- launchMarchTilesOverflowBatch marches those.
+void launchCullBatch(hipStream_t s, const DeviceState* states, uint32_t n);	// consecutive frames: frame i + 1's workgroups wait for frame i's inside the launch
+void launchOrdersBatch(hipStream_t s, const DeviceState* states, uint32_t n);
+void launchMarchLightBatch(hipStream_t s, const DeviceState* states, uint32_t n);
+void launchMarchTilesBatch(hipStream_t s, const DeviceState* states, uint32_t n, const uint32_t* gridTiles, uint32_t* beyond);
+void launchMarchTilesOverflowBatch(hipStream_t s, const DeviceState* states, uint32_t n, const uint32_t* firstSlot);
+uint32_t launchCompositeBatch(hipStream_t s, const DeviceState* states, uint32_t n);	// every state's own tile rows (kFlagInterleaveRows); returns the kernels launched
+void launchPeerPushRowsBatch(hipStream_t s, const DeviceState* states, uint32_t n);
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
 uint32_t marchViewResidentWaves(int device, bool wideAddressing);	// wavefronts of the march kernel the device holds at once (occupancy query)

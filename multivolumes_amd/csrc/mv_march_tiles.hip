@@ -45,8 +45,9 @@ static __device__ __forceinline__ uint32_t waveSumU32(uint32_t v)
 // wavefronts per SIMD (N <= kLutMaxN).
 constexpr uint32_t kLutMaxN = 256;
 // IL: the rows of a sharded context are dealt by tile row (kFlagInterleaveRows) -- compile-time, see screenTileRowsT
+// (marchBlock: this workgroup's index among the workgroups that march)
 template <bool OVERFLOW, bool LUT, bool IL, bool PEER>
-__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis);
+__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis, uint32_t marchBlock);
 
 // PEER: the peer-store transport's instantiation: a folded wait in front (mv_kernels.hpp peerFoldWait), every marched texel also stored
 // into the other ranks' cube maps, the last workgroup raises "cube faces landed" (peerFoldSignal); the others are untouched by it
@@ -72,19 +73,55 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 		// beside the push above and the other ranks'
 		peerFoldWait(st, 1u);
 	}
-	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis);
+	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis, (PEER && !OVERFLOW) ? blockIdx.x - st.fold.pushBlocks : blockIdx.x);
 	if constexpr (PEER) peerFoldSignal(st);
 }
 
+// Several frames in one launch (mv_kernels.hpp DeviceStateBatch).  Always the peer-store transport's folded form: pushBlocks
+// workgroups per frame push that frame's light layers, and ONE counter over all of them decides who raises "light layers landed" (to
+// the launch's value: its group's) -- likewise "cube faces landed" behind the marches.
+// The main launch's grid is one-dimensional, in the order workgroups are dispatched: first EVERY frame's push workgroups, then the
+// marching workgroups, the frames interleaved -- a marching wavefront that waits for the light layers (the tiles that read a map relit in
+// this launch) then waits for workgroups dispatched before it, whatever fills the GPU.  (The overflow launch: 64 workgroups per frame,
+// blockIdx.y = the frame, firstSlots = its first dispatch slot per frame; 0xffffffff: the main grid covered that frame.)
+template <bool OVERFLOW, bool LUT, bool IL>
+__global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesBatchKernel(DeviceStateBatch p, uint32_t n, uint4 firstSlots)
+{
+	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
+	if (OVERFLOW)
+	{
+		const DeviceState& st = p.s[blockIdx.y];
+		const uint32_t first = blockIdx.y == 0u ? firstSlots.x : blockIdx.y == 1u ? firstSlots.y : blockIdx.y == 2u ? firstSlots.z : firstSlots.w;
+		if (first != 0xffffffffu) marchTilesBody<true, LUT, IL, true>(st, first, sAxis, blockIdx.x);
+		peerFoldSignal(st);
+		return;
+	}
+	const uint32_t pushBlocks = p.s[0].fold.pushBlocks, pushAll = pushBlocks * n;
+	if (blockIdx.x < pushAll)
+	{
+		const uint32_t frame = blockIdx.x / pushBlocks, block = blockIdx.x - frame * pushBlocks;
+		const DeviceState& st = p.s[frame];
+		peerPushLightRole(st, (size_t)block * blockDim.x + threadIdx.x, (size_t)pushBlocks * blockDim.x);
+		peerRaise(st, st.fold.pushCounter, pushAll, 1u, &st.fold.pushRow, &st.fold.pushValue, st.fold.pushCheckChain);
+		peerFoldSignal(st);	// (counted among the launch's workgroups)
+		return;
+	}
+	const uint32_t m = blockIdx.x - pushAll, marchBlock = m / n;
+	const DeviceState& st = p.s[m - marchBlock * n];
+	peerFoldWait(st, 1u);
+	marchTilesBody<false, LUT, IL, true>(st, 0u, sAxis, marchBlock);
+	peerFoldSignal(st);
+}
+
 template <bool OVERFLOW, bool LUT, bool IL, bool PEER>
-__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis)
+__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis, uint32_t marchBlock)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
 	const uint32_t nEntries = st.counters[2], nTiles = st.counters[3];
 	if (LUT)
 	{
-		if (!OVERFLOW && ((PEER ? blockIdx.x - st.fold.pushBlocks : blockIdx.x) * kTileWaves >= nTiles)) return;	// a surplus workgroup: nothing to march, no table to build
+		if (!OVERFLOW && marchBlock * kTileWaves >= nTiles) return;	// a surplus workgroup: nothing to march, no table to build
 		const uint32_t P = st.N + 1u, regions = occupancyRegions(st.bricks);
 		const uint32_t strideY = brickPitchY(st.bricks) * 512u, strideZ = brickPitchZ(st.bricks) * 512u;
 		for (uint32_t k = threadIdx.x; k < 3u * P; k += 64u * kTileWaves)
@@ -97,7 +134,6 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	// The host sizes the main grid from the most recent tile count the cull has reported (plus a margin) without ever waiting for
 	// this frame's: wavefronts beyond the real count exit at once, and if the count grew past the grid the overflow launch that
 	// follows marches the rest.
-	const uint32_t marchBlock = (PEER && !OVERFLOW) ? blockIdx.x - st.fold.pushBlocks : blockIdx.x;
 	for (uint32_t slot = firstSlot + marchBlock * kTileWaves + wave; slot < nTiles; slot += OVERFLOW ? gridDim.x * kTileWaves : 0xffffffffu - slot)
 	{
 	uint32_t costBin = 8u;
@@ -115,7 +151,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	entry = __builtin_amdgcn_readfirstlane(entry);
 	const uint32_t we = st.workEntries[entry];
 	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16;
-	const uint32_t localTile = tile - st.workTileStart[entry];
+	const uint32_t localTile = faceId == 7u ? tile - st.workTileStart[entry] : cubeLocalTile(st, volumeId, tile - st.workTileStart[entry]);	// (kFlagDealTiles: this rank's k-th tile of the face)
 
 	const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId];	// CSRayMarch.hlsl:81
 	const uint32_t mipLevel = vi.x, smpCount = vi.y, volTexId = vi.w;
@@ -131,7 +167,10 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			const uint32_t count = st.counters[0];
 			const uint32_t relit = count ? st.visibleVolumes[cb->frameIdx % count] : cb->frameIdx % st.V;	// CSRayMarchL.hlsl:29-33
 			const bool first = marchBlock == 0u && wave == 0u;
-			if (volumeId == relit || first) peerFoldWaitWave(st, 0u, 1u, first);	// (wave-uniform)
+			bool fresh = volumeId == relit;
+			// (several frames per launch: the maps relit in the EARLIER frames of this launch arrive with the same row; the cull listed them)
+			for (uint32_t j = 0; j < st.batchPos; ++j) fresh = fresh || volumeId == st.batchInfo[4u + j];
+			if (fresh || first) peerFoldWaitWave(st, 0u, 1u, first);	// (wave-uniform)
 		}
 	}
 
@@ -426,6 +465,39 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	else if (il) hipLaunchKernelGGL((marchTilesKernel<false, false, true>), grid, block, 0, s, st, 0u);
 	else hipLaunchKernelGGL((marchTilesKernel<false, false, false>), grid, block, 0, s, st, 0u);
 	return marchTilesBeyond(st, gridTiles);
+}
+
+void launchMarchTilesBatch(hipStream_t s, const DeviceState* states, uint32_t n, const uint32_t* gridTiles, uint32_t* beyond)
+{
+	DeviceStateBatch p;
+	uint64_t blocks = 0;
+	for (uint32_t i = 0; i < kMaxBatch; ++i)
+	{
+		p.s[i] = states[i < n ? i : n - 1u];
+		if (i >= n) continue;
+		bool narrow; uint64_t covered;
+		const uint64_t b = marchTilesBlocks(states[i], gridTiles[i], &narrow, &covered);
+		blocks = b > blocks ? b : blocks;
+	}
+	const uint64_t most = (uint64_t)states[0].maxTiles + states[0].maxScreenTiles;
+	for (uint32_t i = 0; i < n; ++i) beyond[i] = blocks * kTileWaves < most ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
+	const bool il = states[0].flags & kFlagInterleaveRows;
+	const bool lut = states[0].N <= kLutMaxN && MV_TILE_LUT != 0;
+	const dim3 grid(((uint32_t)blocks + states[0].fold.pushBlocks) * n), block(64 * kTileWaves);
+	const uint4 none = make_uint4(0u, 0u, 0u, 0u);
+	if (lut) { if (il) hipLaunchKernelGGL((marchTilesBatchKernel<false, true, true>), grid, block, 0, s, p, n, none); else hipLaunchKernelGGL((marchTilesBatchKernel<false, true, false>), grid, block, 0, s, p, n, none); }
+	else if (il) hipLaunchKernelGGL((marchTilesBatchKernel<false, false, true>), grid, block, 0, s, p, n, none);
+	else hipLaunchKernelGGL((marchTilesBatchKernel<false, false, false>), grid, block, 0, s, p, n, none);
+}
+
+void launchMarchTilesOverflowBatch(hipStream_t s, const DeviceState* states, uint32_t n, const uint32_t* firstSlot)
+{
+	DeviceStateBatch p;
+	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i] = states[i < n ? i : n - 1u];
+	const uint4 first = make_uint4(firstSlot[0], n > 1u ? firstSlot[1] : 0xffffffffu, n > 2u ? firstSlot[2] : 0xffffffffu, n > 3u ? firstSlot[3] : 0xffffffffu);
+	const bool il = states[0].flags & kFlagInterleaveRows;
+	if (il) hipLaunchKernelGGL((marchTilesBatchKernel<true, false, true>), dim3(64, n), dim3(64 * kTileWaves), 0, s, p, n, first);
+	else hipLaunchKernelGGL((marchTilesBatchKernel<true, false, false>), dim3(64, n), dim3(64 * kTileWaves), 0, s, p, n, first);
 }
 
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot)

@@ -131,7 +131,7 @@ class MultiRayCaster:
     FrameCount = 3  # MultiRayCaster.h:52
 
     def __init__(self, gridSize, lightGridSize, numVolumes, numVolumeSrcs, viewport, shadowMapSize=1024,
-                 device=0, stream=None, flags=0, shard=(0, 1), framesInFlight=0):
+                 device=0, stream=None, flags=0, shard=(0, 1), framesInFlight=0, framesPerLaunch=0):
         """MultiRayCaster::Init (MultiRayCaster.cpp:79-166) + SetViewport (:226-241)."""
         self._lib = _lib.load()
         self._ctx = C.c_void_p()
@@ -140,9 +140,10 @@ class MultiRayCaster:
         self.viewport = (int(viewport[0]), int(viewport[1]))
         self.shadowMapSize = int(shadowMapSize)
         self.framesInFlight = int(framesInFlight) or 3
+        self.framesPerLaunch = int(framesPerLaunch) or 1  # mv_config.frames_per_launch: B frames of the multi-GPU loop (peer stores) per kernel launch
         cfg = mv_config(C.sizeof(mv_config), self.gridSize, self.lightGridSize, self.numVolumes, self.numVolumeSrcs,
                         self.viewport[0], self.viewport[1], self.shadowMapSize, int(device), int(flags),
-                        C.c_void_p(stream) if stream else None, int(shard[0]), int(shard[1]), int(framesInFlight))
+                        C.c_void_p(stream) if stream else None, int(shard[0]), int(shard[1]), int(framesInFlight), int(framesPerLaunch))
         rc = self._lib.mv_create(C.byref(cfg), C.byref(self._ctx))
         if rc != 0:
             self._ctx = C.c_void_p()
@@ -472,13 +473,15 @@ class MultiRayCaster:
         self._check(self._lib.mv_dist_peer_export(self._ctx, buf), "mv_dist_peer_export")
         return bytes(buf)
 
-    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False):
+    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False, deal_volumes=False):
         """Attach the frame loop with the peer-store transport: every rank's kernels store into every rank's buffers (no collectives).
         loopback: a rank measured alone (every peer is the context itself).  fold: True / False force the flags into / out of the
         marches and the composite (None: the library decides -- folded when every rank owns its GPU)."""
         flags = 0 if fold is None else (_lib.MV_DIST_PEER_FOLD if fold else _lib.MV_DIST_PEER_NO_FOLD)
         if rows_to_root:  # only rank 0 assembles the whole frame
             flags |= _lib.MV_DIST_PEER_ROWS_TO_ROOT
+        if deal_volumes:  # whole cube-map volumes per rank, dealt by cost (default: every volume's tiles shared out over the ranks)
+            flags |= _lib.MV_DIST_PEER_DEAL_VOLUMES
         if loopback:
             self._check(self._lib.mv_dist_init_peer(self._ctx, None, _lib.MV_DIST_PEER_LOOPBACK | flags), "mv_dist_init_peer")
             return

@@ -6,12 +6,12 @@ f = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("void ", "").split("(")[0].split("<")[0].replace("mv::", ""), r.get("Queue_Id", "?")) for r in rows)
 # keep the steady state: from the (skip)th marchViewKernel on
-mv = [i for i, e in enumerate(ev) if e[2].startswith("marchTilesKernel")]
+mv = [i for i, e in enumerate(ev) if e[2].startswith("marchTiles")]
 lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.34
 hi = float(sys.argv[3]) if len(sys.argv) > 3 else 0.99
 ev = ev[mv[int(lo * len(mv))]:mv[min(len(mv) - 2, int(hi * len(mv)))]]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
-n = sum(1 for e in ev if e[2].startswith("cullKernel"))  # one cull per frame (the view march may have an overflow launch behind it)
+n = sum(1 for e in ev if e[2].startswith("cullKernel")) or sum(1 for e in ev if e[2].startswith("__amd_rocclr_copyBuffer"))  # one cull per frame (the view march may have an overflow launch behind it); several frames per launch: one upload per frame
 print("frames %d  span %.3f ms  -> %.4f ms/frame" % (n, (t1 - t0) / 1e6, (t1 - t0) / 1e6 / n))
 dur = collections.defaultdict(list)
 for s, e, k, q in ev: dur[(k, q)].append(e - s)
@@ -50,3 +50,12 @@ for q, lst in sorted(byq.items()):
     for (s0, e0, k0), (s1, e1, k1) in zip(lst, lst[1:]): g[(k0, k1)].append((s1 - e0) / 1e3)
     busy = sum(e - s for s, e, _ in lst) / 1e3
     print("   q%-3s busy %.1f us/frame, span %.1f us/frame:" % (q, busy / n, (lst[-1][1] - lst[0][0]) / 1e3 / n) + "".join("  %s->%s %.1f" % (a[:10], b[:10], sum(v) / len(v)) for (a, b), v in sorted(g.items(), key=lambda kv: -sum(kv[1]))[:8]))
+# the steady-state schedule as lanes: every kernel of 2.5 ms from the middle of the window, one column per queue
+if len(sys.argv) > 4 or True:
+    base = ev[len(ev) // 2][0]
+    qs = sorted(byq)
+    print("  lanes (start us, duration us; one column per queue):")
+    for s, e, k, q in ev[len(ev) // 2:]:
+        if s - base > 2500e3: break
+        col = qs.index(q)
+        print("   %8.1f  " % ((s - base) / 1e3) + " " * (34 * col) + "%-22s %6.1f" % (k[:22], (e - s) / 1e3))

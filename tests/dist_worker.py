@@ -60,11 +60,14 @@ def main():
     four = os.environ.get("MV_TEST_FOUR_CHAINS") == "1"  # four whole frames in flight, upload + cull on the frames' own view streams
     if four:
         flags |= _lib.MV_FLAG_CULL_ON_VIEW_STREAM
-    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world), device=device, framesInFlight=4 if four else 0) as c:
+    per_launch = int(os.environ.get("MV_TEST_FRAMES_PER_LAUNCH", "0"))  # B > 1: groups of B frames go through every long kernel together (needs the four-chain flags, folded peer stores)
+    with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, shard=(rank, world), device=device, framesInFlight=4 if four else 0,
+                        framesPerLaunch=per_launch) as c:
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         peer = os.environ.get("MV_TEST_TRANSPORT") == "peer"     # the peer-store transport: IPC mappings, works with every rank on one GPU
         fold = {"1": True, "0": False}.get(os.environ.get("MV_TEST_PEER_FOLD"))  # (None: the library decides -- ranks sharing a GPU keep the flag kernels)
-        kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=120000, peer_fold=fold, peer_rows_to_root=os.environ.get("MV_TEST_ROWS_TO_ROOT") == "1")
+        kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=120000, peer_fold=fold, peer_rows_to_root=os.environ.get("MV_TEST_ROWS_TO_ROOT") == "1",
+                                 peer_deal_volumes=os.environ.get("MV_TEST_DEAL_VOLUMES") == "1")
         assert kind == ("peer" if peer else "rccl" if rccl else "torch-callbacks"), kind
         if peer:
             info = c.DistInfo()
@@ -91,10 +94,12 @@ def main():
                 except Exception as ex:
                     # (collectives: the call after the divergent frame, before it sizes that frame's all-gather; peer stores: already the
                     # divergent frame's own synchronize -- the light stage's wait has compared the ranks' cull words by then)
-                    assert f in ((5, 6) if peer else (6,)) and "disagree" in str(ex), (f, str(ex))
+                    # (several frames per launch: the group that holds frame 5 is compared as a whole, when it goes out)
+                    late = tuple(range(5, 6 + 2 * per_launch)) if per_launch > 1 else ()
+                    assert f in (late or ((5, 6) if peer else (6,))) and "disagree" in str(ex), (f, str(ex))
                     print(f"rank {rank}: divergence reported at frame {f}: {ex}", flush=True)
                     os._exit(0)  # nothing more can be exchanged; the ranks leave without a collective
-                assert f <= 5, "a frame after the divergent one went through"
+                assert f <= 5 + 2 * max(per_launch, 1) - 2, "a frame after the divergent one went through"
                 continue
             c.DistFrame(vp, fr["shadowVP"], e)
             if after_setter and f != frames - 1:

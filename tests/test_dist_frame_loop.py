@@ -30,7 +30,10 @@ def run_group(cmd, timeout, env=None):
         out, err = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
         os.killpg(p.pid, signal.SIGKILL)
-        out, err = p.communicate()
+        try:
+            out, err = p.communicate(timeout=60)
+        except subprocess.TimeoutExpired:  # (ranks stuck in a GPU kernel can take long to die: do not wait for their pipes)
+            out, err = "", "(the killed ranks have not closed their pipes)"
         raise AssertionError(f"timed out after {timeout} s; stderr tail:\n{err[-3000:]}\nstdout tail:\n{out[-1000:]}")
     return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
@@ -64,19 +67,28 @@ def single_gpu(world, frames, every, static_depth=False, all_frames=False):
                                                            (2, "peer", 3, False), (3, "peer", 13, True), (2, "peer", 26, True), (5, "peer", 13, True),
                                                            (2, "peer-folded", 3, False), (3, "peer-folded", 13, True), (2, "peer-folded", 26, True),
                                                            (2, "peer-four", 3, False), (3, "peer-four", 13, True), (2, "peer-four", 26, True), (3, "chains-four", 13, True),
-                                                           (3, "peer-root", 13, True)])
+                                                           (3, "peer-root", 13, True), (3, "peer-volumes", 13, True), (2, "peer-volumes", 3, False),
+                                                           (2, "peer-x2", 3, False), (3, "peer-x2", 13, True), (2, "peer-x2", 26, True), (2, "peer-x3", 13, True), (3, "peer-x4", 7, True),
+                                                           (5, "peer-x4", 13, True)])
 def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static_depth):
     """Both schedules of the loop (include/multivolumes.h): whole frames on three view streams with a communicator each ("chains"),
     and one view stream with the exchange beside it ("single").  With `static_depth` nothing inside the sequence drains the frames
     in flight (a depth-map setter does), so up to three frames -- collectives included -- really overlap between checkpoints.
     "peer": the chains schedule on the peer-store transport -- no collectives, every rank's kernels store into every rank's buffers
     through IPC mappings, flags instead of all-gathers (csrc/mv_peer.hip).  "peer-folded": the form ranks that own their GPU run -- the
-    waits folded into the marches and the composite -- forced here on two and three ranks that share one."""
+    waits folded into the marches and the composite -- forced here on two and three ranks that share one.  "peer-xB": B frames per
+    launch (mv_config.frames_per_launch): a group of B frames goes through one light march, one view march, one composite and one row
+    push (blockIdx.y = the frame); checkpoints that do not fall on a group's end close groups early."""
     frames = 26
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if mode == "peer-root":  # the rows to rank 0 only (it is rank 0 whose frames the test compares)
         mode, env["MV_TEST_ROWS_TO_ROOT"] = "peer", "1"
+    if mode == "peer-volumes":  # whole cube-map volumes per rank (MV_DIST_PEER_DEAL_VOLUMES) instead of every volume's tiles shared out
+        mode, env["MV_TEST_DEAL_VOLUMES"] = "peer", "1"
+    if "-x" in mode:  # mv_config.frames_per_launch = 2, 3, 4: groups of frames through every long kernel together (four chains, folded flags); a checkpoint or a setter closes a group early
+        env["MV_TEST_FRAMES_PER_LAUNCH"] = mode[-1]
+        mode, env["MV_TEST_FOUR_CHAINS"] = "peer-folded", "1"
     if mode.endswith("-four"):  # MV_FLAG_CULL_ON_VIEW_STREAM + four frames in flight: upload and cull on the frames' own view streams
         env["MV_TEST_FOUR_CHAINS"] = "1"
     if mode.startswith("peer"):
@@ -127,12 +139,39 @@ def test_eight_ranks_at_c3_size_match_single_gpu(tmp_path, mode, monkeypatch):
     assert int(d["nbytes"]) // frames > 8 * 1024 * 1024
 
 
-@pytest.mark.parametrize("mode", ["chains", "single", "peer"])
+def test_one_rank_at_c3_size_four_frames_per_launch(tmp_path, monkeypatch):
+    """mv_config.frames_per_launch = 4 at the full C3 frame: the launches that hold four frames each (light march, view march, composite:
+    blockIdx.y = the frame), sixteen frames in flight, on ONE rank through mv_dist_frame -- bit for bit the frames of the plain single-GPU
+    path.  (Ranks of this form that SHARE a GPU only work while their launches leave it mostly empty -- the small configs above: the
+    tiles that read a map relit in their launch spin until the other ranks' layers land, and two ranks' worth of a full C3 frame fills
+    the GPU with them.  On a GPU of its own a rank of eight has a quarter of the GPU's workgroup slots in such a launch.)"""
+    monkeypatch.setenv("MV_TEST_CONFIG", "C3")
+    world, frames, every = 1, 14, 7
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_CONFIG="C3", OMP_NUM_THREADS="4", MV_TEST_TRANSPORT="peer",
+               MV_TEST_FRAMES_PER_LAUNCH="4", MV_TEST_FOUR_CHAINS="1", MV_TEST_PEER_FOLD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every), "chains", "1"]
+    r = run_group(cmd, 600, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = np.load(out)
+    imgs, infos, counts, lms = single_gpu(world, frames, every, True)
+    assert np.array_equal(d["infos"], infos)
+    for i in range(len(imgs)):
+        assert np.array_equal(d["imgs"][i], imgs[i]), f"composite of checkpoint {i} differs ({(d['imgs'][i] != imgs[i]).sum()} halfs)"
+    assert np.array_equal(d["lms"], lms)
+    assert np.array_equal(d["counts"], counts) and counts[0] > 10_000_000 * frames
+
+
+@pytest.mark.parametrize("mode", ["chains", "single", "peer", "peer-x2"])
 def test_ranks_that_were_handed_different_frames_get_an_error_not_a_hang(tmp_path, mode):
     """The sizes of a frame's collectives follow from the replicated cull; ranks whose callers passed different frame constants would
     enter collectives that do not match.  Every rank's share of the frame's light exchange carries what its cull decided, the unpack
     compares them, and the NEXT mv_dist_frame -- before it sizes that frame's cube-face all-gather -- fails on every rank."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "peer-x2":  # (two frames per launch: the group that holds the divergent frame is compared as a whole)
+        env.update(MV_TEST_FRAMES_PER_LAUNCH="2", MV_TEST_FOUR_CHAINS="1", MV_TEST_PEER_FOLD="1")
+        mode = "peer"
     if mode == "peer":  # (the light stage's wait compares the ranks' cull words there)
         mode, env["MV_TEST_TRANSPORT"] = "chains", "peer"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -142,7 +181,7 @@ def test_ranks_that_were_handed_different_frames_get_an_error_not_a_hang(tmp_pat
     assert r.stdout.count("divergence reported at frame") == 2, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("mode", ["chains", "single", "peer"])
+@pytest.mark.parametrize("mode", ["chains", "single", "peer", "peer-x3"])
 def test_input_setters_inside_the_loop_leave_the_pending_frame_its_inputs(tmp_path, mode):
     """mv_dist_frame(k) defers frame k - 1's exchange, composite and row gather to the next call.  A caller that hands over a new host
     depth map before every frame (SetRenderTargets(depth_k); DistFrame(k)) must still get frame k - 1 composited against depth_{k-1}:
@@ -151,6 +190,9 @@ def test_input_setters_inside_the_loop_leave_the_pending_frame_its_inputs(tmp_pa
     frames, world = 12, 2
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode == "peer-x3":  # (three frames per launch: the setter closes the group it interrupts -- here every group holds one frame)
+        env.update(MV_TEST_FRAMES_PER_LAUNCH="3", MV_TEST_FOUR_CHAINS="1", MV_TEST_PEER_FOLD="1")
+        mode = "peer"
     if mode == "peer":
         mode, env["MV_TEST_TRANSPORT"] = "chains", "peer"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
