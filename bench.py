@@ -124,6 +124,8 @@ def parse():
     p.add_argument("--cull-on-view-stream", action="store_true", help="MV_FLAG_CULL_ON_VIEW_STREAM: every frame's upload and cull on its own view stream (no stream of their own); "
                    "the default of the peer rung of --gpus > 1, an experiment on one GPU")
     p.add_argument("--frames-in-flight", type=int, default=0, help="whole frames in flight = view streams = output sets (2..5; 0 = the library's default, 3)")
+    p.add_argument("--frames-per-launch", type=int, default=0, help="--gpus N > 1, peer stores: B = 1..4 consecutive frames go through every long kernel of a rank's chain together "
+                   "(mv_config.frames_per_launch; 0 = 4 on the peer-store rung, 1 elsewhere): a rank of eight holds an eighth of a frame, which leaves its GPU to latency")
     p.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
                    help="--gpus > 1: auto = the peer-store transport (no collectives: every rank's kernels store into every rank's buffers over "
                         "IPC mappings, flags instead of all-gathers), and -- only if that fails its self-test, fails or stops making progress -- "
@@ -308,13 +310,19 @@ def main():
             # and cull on its own view stream (profiles/r04_peer_rank_cost.txt)
             flags |= _lib.MV_FLAG_CULL_ON_VIEW_STREAM
             args.frames_in_flight = 4
+            if args.frames_per_launch == 0 and not share_gpu:  # (ranks that share a GPU -- tests -- fill it with each other's waiting workgroups at full size: only when asked)
+                # ... and four frames per launch on each: sixteen frames in flight per rank (profiles/r04_frames_per_launch.txt:
+                # a rank of eight 0.095 -> 0.060 ms per C3 frame, of four 0.129 -> 0.099, of two 0.201 -> 0.175)
+                args.frames_per_launch = 4
+    if not (world > 1 and transport == "peer" and (flags & _lib.MV_FLAG_CULL_ON_VIEW_STREAM)):
+        args.frames_per_launch = 0  # (groups of frames per launch are the peer-store loop's)
     # a real (non-blocking) torch stream, made current so that the RCCL collectives of the multi-GPU path are ordered on it too:
     # torch's default is the legacy null stream, whose implicit synchronisation rules cost the pipelined frame ~20 %
     if os.environ.get("MV_BENCH_NULL_STREAM", "0") != "1":
         torch.cuda.set_stream(torch.cuda.Stream(device=local_rank))
     stream = torch.cuda.current_stream().cuda_stream
     caster = MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=M, device=local_rank,
-                            stream=stream, flags=flags, shard=(rank, world), framesInFlight=args.frames_in_flight)
+                            stream=stream, flags=flags, shard=(rank, world), framesInFlight=args.frames_in_flight, framesPerLaunch=args.frames_per_launch)
 
     # ---- synthetic inputs, resident in HBM before the timed region ----
     t0 = time.time()
@@ -406,6 +414,8 @@ def main():
     skip_light[0] = args.no_light
     for _ in range(args.warmup):
         frame()
+    if world > 1:
+        caster.DistFlush()  # (several frames per launch: the last group of warm-up frames goes out now, not inside the timed region)
     caster.synchronize()
     caster.ResetStats()
     caster.SetProfiling(True)
@@ -544,7 +554,8 @@ def main():
                 "view_samples_per_frame": tot_view // K, "lane_utilisation": (st["view_samples"] / st["reserved0"]) if st.get("reserved0") else None, "lit_samples_per_frame": tot_lit // K, "rays_per_frame": tot_rays // K,
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
-                "parallelism": (f"{world} ranks, peer stores (no collectives): cube-map volumes dealt per frame by estimated march cost, the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, rows pushed into every rank's frame buffer; the frame's light march shared out by layers of voxel blocks, pushed into every rank's light map; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
+                "frames_per_launch": (args.frames_per_launch or 1) if world > 1 else None,
+                "parallelism": (f"{world} ranks, peer stores (no collectives): every cube-map volume's 8x8 tiles dealt over the ranks, the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, rows pushed into every rank's frame buffer; the frame's light march shared out by layers of voxel blocks, pushed into every rank's light map; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
                                 else f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, the frame's light march shared out by voxel blocks + all-gather of the shares; frame loop inside the library (mv_dist_frame), transport: {exchange}") if world > 1 else "single GPU",
                 "frames_in_flight": ("up to 3 whole frames (light march, view march, composite) on 3 view streams; constants / cull 4 slots, march outputs 3 sets, light maps 3 buffers per volume" if world == 1
                                      else "upload + cull + light march ahead of the view march / exchange / composite stream" if args.dist_single_stream

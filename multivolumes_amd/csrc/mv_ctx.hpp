@@ -498,8 +498,9 @@ void foldEvents(mv_ctx* ctx)
 		float ms = 0.0f;
 		if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess)
 		{
-			ctx->msStage[ev.stage] += ms;
-			ctx->nStage[ev.stage] += 1;
+			// (several frames per launch: bits 8.. of the stage hold the frames the launch carried -- the averages stay per frame)
+			ctx->msStage[ev.stage & 0xff] += ms;
+			ctx->nStage[ev.stage & 0xff] += (ev.stage >> 8) > 0 ? (uint64_t)(ev.stage >> 8) : 1u;
 		}
 		ctx->freeEvents.push_back(ev);
 	}

@@ -945,7 +945,10 @@ static int batchTail(mv_ctx* ctx)
 			foldBase(ctx, sts[i], kFoldComposite, P, last.st.frameTag, last.slot);
 			if (foldedWait) foldWait(ctx, sts[i], kStageCube, P);
 		}
+		EventPair evt = { nullptr, nullptr, 0 };
+		beginStage(ctx, 3 | (int)(nComposite << 8), evt, X);
 		mv::launchCompositeBatch(X, sts, nComposite);
+		endStage(ctx, evt, X);
 		MV_HIP(ctx, hipGetLastError());
 		d->bytes += (size_t)nComposite * last.st.H * last.st.W * sizeof(uint2) / world * (d->peerRowsRoot ? (last.st.shardIndex ? 0u : world - 1u) : world - 1u);
 	}
@@ -1001,7 +1004,10 @@ static int batchClose(mv_ctx* ctx)
 			for (uint32_t i = k0; i < n; ++i) sts[i] = d->cur[i].st;
 			// (the cull of the frame before the group's first: the light table, VolumeInfo rows and view hash it left)
 			MV_HIP(ctx, evWait(ctx, S, ctx->evStageA[(d->cur[k0].slot + numSlots - 1u) % numSlots]));
+			EventPair evt = { nullptr, nullptr, 0 };
+			beginStage(ctx, 0 | (int)((n - k0) << 8), evt, S);
 			mv::launchCullBatch(S, sts + k0, n - k0);
+			endStage(ctx, evt, S);
 			mv::launchOrdersBatch(S, sts + k0, n - k0);
 			MV_HIP(ctx, hipGetLastError());
 			for (uint32_t i = k0; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evStageA[d->cur[i].slot], S));
@@ -1029,7 +1035,10 @@ static int batchClose(mv_ctx* ctx)
 			for (uint32_t c = 0; c < C; ++c) if (J > (uint64_t)C + c) { a.waitRow[a.nWait] = kStageDone * mv::kPeerMaxChains + (uint32_t)((J - C - c) % C); a.waitValue[a.nWait++] = J - C - c; }
 			if (a.nWait) { mv::launchPeerSync(S, a); MV_HIP(ctx, hipGetLastError()); }
 		}
+		EventPair evt = { nullptr, nullptr, 0 };
+		beginStage(ctx, 1 | (int)(n << 8), evt, S);
 		mv::launchMarchLightBatch(S, sts, n);
+		endStage(ctx, evt, S);
 		MV_HIP(ctx, hipGetLastError());
 		for (uint32_t i = 0; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evLight[d->cur[i].slot], S));
 		if (peers) d->bytes += (size_t)n * last.st.L * last.st.L * last.st.L * sizeof(uint4) / last.st.shardCount * (last.st.shardCount - 1u);
@@ -1089,12 +1098,15 @@ static int batchClose(mv_ctx* ctx)
 		// (the main launch waits; the LAST launch raises "cube faces landed": the overflow launch if there is one)
 		DeviceState main[mv::kMaxBatch];
 		for (uint32_t i = 0; i < n; ++i) { main[i] = sts[i]; if (overflow) main[i].fold.nSignal = 0u; }
+		EventPair evt = { nullptr, nullptr, 0 };
+		beginStage(ctx, 2 | (int)(n << 8), evt, S);
 		mv::launchMarchTilesBatch(S, main, n, tiles, beyond);
 		if (overflow)
 		{
 			for (uint32_t i = 0; i < n; ++i) { sts[i].fold.nWait = 0u; sts[i].fold.pushBlocks = 0u; }
 			mv::launchMarchTilesOverflowBatch(S, sts, n, beyond);
 		}
+		endStage(ctx, evt, S);
 		MV_HIP(ctx, hipGetLastError());
 	}
 	for (uint32_t i = 0; i < n; ++i) d->pend[i] = d->cur[i];

@@ -36,7 +36,7 @@ def run_group(cmd, timeout, env=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--orbit"], ["--orbit", "--dist-single-stream"]])
+@pytest.mark.parametrize("extra", [[], ["--orbit"], ["--orbit", "--dist-single-stream"], ["--orbit", "--frames-per-launch", "4"]])
 def test_two_ranks_on_one_gpu(extra):
     env = dict(os.environ, MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -52,7 +52,7 @@ def test_two_ranks_on_one_gpu(extra):
     assert d["config"]["ranks_hold_the_same_frame"] is True and len(d["config"]["ms_per_step_per_rank"]) == 2
     assert d["cpu_baseline"]["gpu_vs_oracle_max_abs_err"] == 0.0
     # the same frame on one rank: the sharded run marches the same samples
-    one = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + [e for e in extra if e != "--dist-single-stream"], 240)
+    one = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + [e for e in extra if e in ("--orbit",)], 240)
     assert one.returncode == 0, one.stderr[-2000:]
     s = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     for k in ("view_samples_per_frame", "lit_samples_per_frame", "rays_per_frame", "light_samples_per_frame"):
