@@ -195,7 +195,15 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		for (uint32_t p = 0; p < ctx->numSlots; ++p)
 		{
 			FrameBufs& f = ctx->fb[p];
-			if ((rc = devAlloc(ctx, &f.dCb, 256 + (size_t)st.V * MV_PER_OBJECT_BYTES)) != MV_OK) return bail(rc);	// one upload: CBPerFrame, then PerObject[V]
+			// one upload: CBPerFrame, then PerObject[V] -- the slots' copies side by side in ONE allocation, like their pinned slices (the
+			// multi-GPU loop with several frames per launch uploads a group's constants with one copy: mv_dist.cpp batchClose)
+			if (p == 0)
+			{
+				uint8_t* all = nullptr;
+				if ((rc = devAlloc(ctx, &all, (256 + (size_t)st.V * MV_PER_OBJECT_BYTES) * ctx->numSlots)) != MV_OK) return bail(rc);
+				ctx->dCbAll = all;
+			}
+			f.dCb = ctx->dCbAll + (256 + (size_t)st.V * MV_PER_OBJECT_BYTES) * p;
 			f.dPerObject = static_cast<uint8_t*>(f.dCb) + 256;
 			// what mv_readback_cull brings back sits in ONE block, in the order of its pinned copy: counters (64 B), VolumeInfo[V],
 			// visible[V], cube-map list[V], light table[V]
@@ -643,7 +651,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	uint8_t* s = ctx->pinned + (size_t)ctx->slot * ctx->sliceBytes;
 	memcpy(s, cbPerFrame, MV_CB_PER_FRAME_BYTES);
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
-	MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));
+	if (!ctx->deferUpload) MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));	// (deferred: the multi-GPU loop uploads a group's slices together)
 	MV_HIP(ctx, stageADone(ctx, false));	// (a frame that never culls still marks its copy; inside the multi-GPU loop the cull's record follows at once)
 	ctx->haveFrame = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs

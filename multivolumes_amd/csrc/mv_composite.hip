@@ -153,6 +153,62 @@ __global__ __launch_bounds__(256) void copyForwardKernel(DeviceState st, const u
 	if (threadIdx.x == 0) st.faceStamps[idx] = theirs;
 }
 
+// The copy-forwards of the frames of one launch group (mv_kernels.hpp DeviceStateBatch; the multi-GPU loop with several frames per
+// launch), one after the other inside ONE kernel: a (volume, mip, face) is a workgroup's own through all of them -- frame i's copy reads
+// what frame i - 1's wrote -- so the chain needs no launch boundary.  Frame `first`'s source is the set of the frame before the group
+// (prev*); then, peers: every rank's marched faces of the group's frames must have landed in this rank's sets before frame i + 1 copies
+// from frame i's (the folded wait of the launch: mv_kernels.hpp peerFoldWait; one wavefront per workgroup polls).
+__global__ __launch_bounds__(256) void copyForwardBatchKernel(DeviceStateBatch p, uint32_t first, uint32_t n, const uint2* __restrict__ prevMaps, const float* __restrict__ prevDepths,
+	const uint32_t* __restrict__ prevStamps, uint4 tags)
+{
+	const uint32_t f = blockIdx.x % 6u, mip = (blockIdx.x / 6u) % kNumCubeMip, v = blockIdx.x / (6u * kNumCubeMip);
+	const uint32_t idx = (v * kNumCubeMip + mip) * 6u + f;
+	const uint2* srcMaps = prevMaps; const float* srcDepths = prevDepths; const uint32_t* srcStamps = prevStamps;
+#pragma unroll
+	for (uint32_t i = 0; i < kMaxBatch; ++i)
+	{
+		if (i >= n) break;
+		const DeviceState& st = p.s[i];
+		if (i == 1u) peerFoldWait(p.s[0]);	// (from here on the sources are sets of this group)
+		if (i >= first)
+		{
+			const uint32_t tag = i == 0u ? tags.x : i == 1u ? tags.y : i == 2u ? tags.z : tags.w;
+			const uint32_t info = st.volumeFlags[v];
+			if ((info & 3u) == 3u && ((info >> 2) & 7u) == mip && (((info >> 5) & 0x3fu) & (1u << f)))
+			{
+				if (threadIdx.x == 0) st.faceStamps[idx] = tag;	// marched this frame
+			}
+			else
+			{
+				const uint32_t mine = st.faceStamps[idx], theirs = srcStamps[idx];
+				if ((int32_t)(theirs - mine) > 0)
+				{
+					const uint32_t d = st.N >> mip;
+					const size_t base = (size_t)v * cubeChainTexels(st.N) + cubeMipOffset(st.N, mip) + (size_t)f * d * d;
+					for (uint32_t k = threadIdx.x; k < d * d; k += blockDim.x)
+					{
+						st.cubeMaps[base + k] = srcMaps[base + k];
+						st.cubeDepths[base + k] = srcDepths[base + k];
+					}
+					__syncthreads();
+					if (threadIdx.x == 0) st.faceStamps[idx] = theirs;
+				}
+			}
+			__threadfence_block();
+			__syncthreads();	// (what this workgroup wrote is what it reads as the next frame's source)
+		}
+		srcMaps = st.cubeMaps; srcDepths = st.cubeDepths; srcStamps = st.faceStamps;
+	}
+}
+
+void launchCopyForwardBatch(hipStream_t s, const DeviceState* states, uint32_t first, uint32_t n, const uint2* prevMaps, const float* prevDepths, const uint32_t* prevStamps, const uint32_t* tags)
+{
+	DeviceStateBatch p;
+	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i] = states[i < n ? i : n - 1u];
+	const uint4 t = make_uint4(tags[0], n > 1u ? tags[1] : 0u, n > 2u ? tags[2] : 0u, n > 3u ? tags[3] : 0u);
+	hipLaunchKernelGGL(copyForwardBatchKernel, dim3(states[0].V * kNumCubeMip * 6u), dim3(256), 0, s, p, first, n, prevMaps, prevDepths, prevStamps, t);
+}
+
 void launchCopyForward(hipStream_t s, const DeviceState& st, const uint2* otherMaps, const float* otherDepths, const uint32_t* otherStamps, uint32_t tag, bool marchFollows)
 {
 	hipLaunchKernelGGL(copyForwardKernel, dim3(st.V * kNumCubeMip * 6u), dim3(256), 0, s, st, otherMaps, otherDepths, otherStamps, tag, marchFollows ? 1 : 0);

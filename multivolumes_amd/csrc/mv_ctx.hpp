@@ -218,6 +218,8 @@ struct mv_ctx
 	std::vector<void*> allocs;			// everything to hipFree
 
 	// pinned upload ring (the reference's upload-heap slices, MultiRayCaster.cpp:128-130, 461-467)
+	uint8_t* dCbAll = nullptr;			// the slots' device copies of the constants, sliceBytes apart (fb[slot].dCb points into it)
+	bool deferUpload = false;			// mv_update_frame fills the pinned slice only: the caller copies it (several frames per launch: one copy per group)
 	uint8_t* pinned = nullptr;			// numSlots slices: frame i's constants in slice i % numSlots, read by that frame's cull where they lie
 	size_t sliceBytes = 0;
 	uint64_t* pinnedStats = nullptr;

@@ -876,6 +876,9 @@ static int distTailComposite(mv_ctx* ctx)
 // flush) enqueues ONE light march and ONE view march for the group's frames (mv_kernels.hpp DeviceStateBatch: blockIdx.y = the frame).
 // Ordering is the per-slot events' of the one-frame path (every frame records its own), plus stream order inside a group.
 // ---------------------------------------------------------------------------------------------
+#ifndef MV_BATCH_ONE_WAIT
+#define MV_BATCH_ONE_WAIT 0	// 1: one wait kernel per group (in front of the light march: the done rows AND the older groups' light rows) instead of two -- measured slower (profiles/r04_frames_per_launch.txt)
+#endif
 static bool batchMode(const mv_ctx* ctx) { return ctx->dist && ctx->dist->transport == 3 && ctx->framesPerLaunch > 1u; }
 
 // wait, on stream s, for the newest record on every OTHER stream among these events (an older record on the same stream is implied)
@@ -915,29 +918,35 @@ static int batchTail(mv_ctx* ctx)
 	// once frame i - 1's own copy has run and every rank's marched faces of it have landed): they wait for the START of the group
 	// before this one's tail (its faces landed, its copies), not for its composite and row push, so the tails of consecutive groups
 	// overlap but for ~10 us per frame.
-	if (!d->pend[0].culled)	// (else: copied from every set when the frame was begun, distFrameBatch)
 	{
 		const DistState::BatchFrame& f0 = d->pend[0];
+		const uint32_t first = f0.culled ? 1u : 0u;	// (a first frame begun the slow way has copied from every set already: distFrameBatch)
 		const uint32_t prevSlot = (f0.slot + numSlots - 1u) % numSlots;
-		MV_HIP(ctx, evWait(ctx, X, ctx->evMainDone[(f0.slot + numSlots - (sets % numSlots)) % numSlots]));	// the set's last reader
-		MV_HIP(ctx, evWait(ctx, X, ctx->evLanded[prevSlot]));
-		MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[prevSlot]));
-		const OutBufs& other = ctx->ob[(f0.set + sets - 1u) % sets];
-		mv::launchCopyForward(X, f0.st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)f0.frame, true);
-		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, evRecord(ctx, ctx->evCopy[f0.slot], X));
+		if (!first)
+		{
+			MV_HIP(ctx, evWait(ctx, X, ctx->evMainDone[(f0.slot + numSlots - (sets % numSlots)) % numSlots]));	// the first frame's set: its last reader
+			MV_HIP(ctx, evWait(ctx, X, ctx->evLanded[prevSlot]));
+			MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[prevSlot]));
+		}
+		// ONE kernel for the group's copies, one after the other inside it; in front of the first copy FROM a set of this group it waits
+		// until every rank's marched faces of the group have landed (folded: one wavefront per workgroup polls)
+		DeviceState cf[mv::kMaxBatch];
+		uint32_t tags[mv::kMaxBatch];
+		for (uint32_t i = 0; i < n; ++i) { cf[i] = d->pend[i].st; tags[i] = (uint32_t)d->pend[i].frame; }
+		foldBase(ctx, cf[0], kFoldComposite, P, last.st.frameTag, last.slot);
+		if (peers && n > 1u) foldWait(ctx, cf[0], kStageCube, P);
+		if (n > first)
+		{
+			const OutBufs& other = ctx->ob[(f0.set + sets - 1u) % sets];
+			mv::launchCopyForwardBatch(X, cf, first, n, other.cubeMaps, other.cubeDepths, other.faceStamps, tags);
+			MV_HIP(ctx, hipGetLastError());
+			for (uint32_t i = first; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evCopy[d->pend[i].slot], X));
+		}
 	}
-	// every rank's faces of the group's frames have landed in this rank's sets (a kernel of one wavefront: the copies below read them)
-	if (peers) { const int rc = peerWaitStage(ctx, X, kStageCube, P, last.st.frameTag, last.slot); if (rc != MV_OK) return rc; }
+	// (a group of one frame: nothing above waited for the other ranks' faces -- a kernel of one wavefront does)
+	if (peers && n == 1u) { const int rc = peerWaitStage(ctx, X, kStageCube, P, last.st.frameTag, last.slot); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, evRecord(ctx, ctx->evLanded[last.slot], X));
 	const bool foldedWait = false;
-	for (uint32_t i = 1; i < n; ++i)
-	{
-		const OutBufs& other = ctx->ob[d->pend[i - 1u].set];
-		mv::launchCopyForward(X, d->pend[i].st, other.cubeMaps, other.cubeDepths, other.faceStamps, (uint32_t)d->pend[i].frame, true);
-		MV_HIP(ctx, hipGetLastError());
-		MV_HIP(ctx, evRecord(ctx, ctx->evCopy[d->pend[i].slot], X));
-	}
 	if (nComposite)
 	{
 		for (uint32_t i = 0; i < nComposite; ++i)
@@ -1002,6 +1011,14 @@ static int batchClose(mv_ctx* ctx)
 		if (n > k0)
 		{
 			for (uint32_t i = k0; i < n; ++i) sts[i] = d->cur[i].st;
+			// the frames' constants: consecutive slots are consecutive slices, pinned and on the device -- one copy, two where the slots wrap around
+			for (uint32_t i = k0; i < n; )
+			{
+				uint32_t run = 1;
+				while (i + run < n && d->cur[i + run].slot == d->cur[i].slot + run) ++run;
+				MV_HIP(ctx, hipMemcpyAsync(ctx->fb[d->cur[i].slot].dCb, ctx->pinned + (size_t)d->cur[i].slot * ctx->sliceBytes, (size_t)run * ctx->sliceBytes, hipMemcpyHostToDevice, S));
+				i += run;
+			}
 			// (the cull of the frame before the group's first: the light table, VolumeInfo rows and view hash it left)
 			MV_HIP(ctx, evWait(ctx, S, ctx->evStageA[(d->cur[k0].slot + numSlots - 1u) % numSlots]));
 			EventPair evt = { nullptr, nullptr, 0 };
@@ -1033,6 +1050,16 @@ static int batchClose(mv_ctx* ctx)
 		{
 			mv::PeerSync a = peerSyncBase(ctx, last.st.frameTag, last.slot);
 			for (uint32_t c = 0; c < C; ++c) if (J > (uint64_t)C + c) { a.waitRow[a.nWait] = kStageDone * mv::kPeerMaxChains + (uint32_t)((J - C - c) % C); a.waitValue[a.nWait++] = J - C - c; }
+			// ... and, for the view march behind the light march: every rank's layers of the maps relit in the C - 1 groups before this one (on
+			// the other streams) have landed -- their view marches started well before this group's culls did
+#if MV_BATCH_ONE_WAIT
+			for (uint32_t c = 1; c < C; ++c)
+				if (J > c)
+				{
+					if (a.nWait == 8u) { mv::launchPeerSync(S, a); a.nWait = 0; }	// (five chains: nine rows, a second kernel)
+					a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + (uint32_t)((J - c) % C); a.waitValue[a.nWait++] = J - c;
+				}
+#endif
 			if (a.nWait) { mv::launchPeerSync(S, a); MV_HIP(ctx, hipGetLastError()); }
 		}
 		EventPair evt = { nullptr, nullptr, 0 };
@@ -1087,6 +1114,7 @@ static int batchClose(mv_ctx* ctx)
 				sts[i].fold.pushCheckChain = d->cullCrosscheck ? chain : 0xffffffffu;
 			}
 		}
+#if !MV_BATCH_ONE_WAIT
 		// every rank's layers of the maps relit in the C - 1 groups before this one (on the other streams) have landed: again a kernel of
 		// one wavefront in front of the launch instead of a wait in every workgroup of it
 		if (peers && J > 1u)
@@ -1095,6 +1123,7 @@ static int batchClose(mv_ctx* ctx)
 			for (uint32_t c = 1; c < C; ++c) if (J > c) { a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + (uint32_t)((J - c) % C); a.waitValue[a.nWait++] = J - c; }
 			if (a.nWait) { mv::launchPeerSync(S, a); MV_HIP(ctx, hipGetLastError()); }
 		}
+#endif
 		// (the main launch waits; the LAST launch raises "cube faces landed": the overflow launch if there is one)
 		DeviceState main[mv::kMaxBatch];
 		for (uint32_t i = 0; i < n; ++i) { main[i] = sts[i]; if (overflow) main[i].fold.nSignal = 0u; }
@@ -1130,8 +1159,9 @@ static int distFrameBatch(mv_ctx* ctx, const void* cbPerFrame, const void* perOb
 #endif
 	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
 	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
-	{ MV_SECTION(0); rc = mv_update_frame(ctx, cbPerFrame, perObject); }	// (the upload; the culls of the group go out together, batchClose)
-	ctx->batchExplicit = false;
+	ctx->deferUpload = true;
+	{ MV_SECTION(0); rc = mv_update_frame(ctx, cbPerFrame, perObject); }	// (the constants into their pinned slice; upload and cull of the group's frames go out together, batchClose)
+	ctx->batchExplicit = false; ctx->deferUpload = false;
 	if (rc != MV_OK) return rc;
 	bool culled = false;
 	if (first)
@@ -1144,6 +1174,7 @@ static int distFrameBatch(mv_ctx* ctx, const void* cbPerFrame, const void* perOb
 			// takes the slow way, from every set, which needs its cull now)
 			MV_SECTION(3);
 			MV_HIP(ctx, evWait(ctx, ctx->streamA, ctx->evStageA[(ctx->slot + ctx->numSlots - 1u) % ctx->numSlots]));
+			MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, ctx->pinned + (size_t)ctx->slot * ctx->sliceBytes, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));
 			if ((rc = mv_cull(ctx)) != MV_OK) return rc;
 			if ((rc = viewCopyForward(ctx)) != MV_OK) return rc;
 			culled = true;

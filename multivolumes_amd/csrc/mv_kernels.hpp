@@ -573,6 +573,7 @@ void launchMarchTilesBatch(hipStream_t s, const DeviceState* states, uint32_t n,
 void launchMarchTilesOverflowBatch(hipStream_t s, const DeviceState* states, uint32_t n, const uint32_t* firstSlot);
 uint32_t launchCompositeBatch(hipStream_t s, const DeviceState* states, uint32_t n);	// every state's own tile rows (kFlagInterleaveRows); returns the kernels launched
 void launchPeerPushRowsBatch(hipStream_t s, const DeviceState* states, uint32_t n);
+void launchCopyForwardBatch(hipStream_t s, const DeviceState* states, uint32_t first, uint32_t n, const uint2* prevMaps, const float* prevDepths, const uint32_t* prevStamps, const uint32_t* tags);	// frames first .. n - 1, one after the other in one kernel; states[0].fold: the wait before a set of the group is read
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
 uint32_t marchViewResidentWaves(int device, bool wideAddressing);	// wavefronts of the march kernel the device holds at once (occupancy query)
