@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 	entry = __builtin_amdgcn_readfirstlane(entry);
 	const uint32_t we = st.workEntries[entry];
 	const uint32_t volumeId = we & 0xffffu, faceId = we >> 16;
-	const uint32_t localTile = tile - st.workTileStart[entry];
+	const uint32_t localTile = faceId == 7u ? tile - st.workTileStart[entry] : cubeLocalTile(st, volumeId, tile - st.workTileStart[entry]);
 
 	const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId];	// CSRayMarch.hlsl:81
 	const uint32_t mipLevel = vi.x, smpCount = vi.y, volTexId = vi.w;
@@ -609,6 +609,9 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 	return blocks * kTileWaves < maxTiles ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
 }
 
+// (several frames per launch -- mv_config.frames_per_launch in the multi-GPU loop -- exist for the product kernel only: these builds are A/B builds of the single-GPU march)
+void launchMarchTilesBatch(hipStream_t, const DeviceState*, uint32_t, const uint32_t*, uint32_t*) { fprintf(stderr, "multivolumes_amd: this build of the tile march (csrc/experiments) has no launches of several frames\n"); abort(); }
+void launchMarchTilesOverflowBatch(hipStream_t, const DeviceState*, uint32_t, const uint32_t*) { abort(); }
 void launchMarchTilesOverflow(hipStream_t s, const DeviceState& st, uint32_t firstSlot)
 {
 	if (st.flags & kFlagInterleaveRows) hipLaunchKernelGGL((marchTilesKernel<true, false, true>), dim3(64), dim3(64 * kTileWaves), 0, s, st, firstSlot);

@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * kSetupWaves) void raySetupKernel(DeviceState s
 		entry = __builtin_amdgcn_readfirstlane(entry);
 		const uint32_t we = st.workEntries[entry];
 		const uint32_t volumeId = we & 0xffffu, faceId = we >> 16;
-		const uint32_t localTile = tile - st.workTileStart[entry];
+		const uint32_t localTile = faceId == 7u ? tile - st.workTileStart[entry] : cubeLocalTile(st, volumeId, tile - st.workTileStart[entry]);
 
 		const ushort4 vi = reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId];	// CSRayMarch.hlsl:81
 		const uint32_t mipLevel = vi.x;

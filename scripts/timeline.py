@@ -11,7 +11,8 @@ lo = float(sys.argv[2]) if len(sys.argv) > 2 else 0.34
 hi = float(sys.argv[3]) if len(sys.argv) > 3 else 0.99
 ev = ev[mv[int(lo * len(mv))]:mv[min(len(mv) - 2, int(hi * len(mv)))]]
 t0, t1 = ev[0][0], max(e[1] for e in ev)
-n = sum(1 for e in ev if e[2].startswith("cullKernel")) or sum(1 for e in ev if e[2].startswith("__amd_rocclr_copyBuffer"))  # one cull per frame (the view march may have an overflow launch behind it); several frames per launch: one upload per frame
+import os
+n = sum(1 for e in ev if e[2].startswith("cullKernel")) or int(os.environ.get("TIMELINE_FRAMES_PER_LAUNCH", "4")) * sum(1 for e in ev if e[2].startswith("cullBatchKernel"))  # one cull per frame (the view march may have an overflow launch behind it); several frames per launch: TIMELINE_FRAMES_PER_LAUNCH (4) frames per cull launch
 print("frames %d  span %.3f ms  -> %.4f ms/frame" % (n, (t1 - t0) / 1e6, (t1 - t0) / 1e6 / n))
 dur = collections.defaultdict(list)
 for s, e, k, q in ev: dur[(k, q)].append(e - s)
