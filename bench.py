@@ -124,6 +124,7 @@ def parse():
     p.add_argument("--cull-on-view-stream", action="store_true", help="MV_FLAG_CULL_ON_VIEW_STREAM: every frame's upload and cull on its own view stream (no stream of their own); "
                    "the default of the peer rung of --gpus > 1, an experiment on one GPU")
     p.add_argument("--frames-in-flight", type=int, default=0, help="whole frames in flight = view streams = output sets (2..5; 0 = the library's default, 3)")
+    p.add_argument("--cull-on-stream-a", action="store_true", help="one GPU: three chains and a stream of its own for upload + cull (the library's default) instead of four chains with the culls on them")
     p.add_argument("--frames-per-launch", type=int, default=0, help="--gpus N > 1, peer stores: B = 1..4 consecutive frames go through every long kernel of a rank's chain together "
                    "(mv_config.frames_per_launch; 0 = 4 on the peer-store rung, 1 elsewhere): a rank of eight holds an eighth of a frame, which leaves its GPU to latency")
     p.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
@@ -296,6 +297,11 @@ def main():
     pipelined = not args.no_pipeline
     if pipelined:
         flags |= _lib.MV_FLAG_PIPELINE_FRAMES  # frames in flight, like the reference's upload ring (MultiRayCaster.h:52)
+        if world == 1 and args.frames_in_flight == 0 and not args.cull_on_stream_a and not args.ray_queue:
+            # four whole frames on the four hardware queues, every frame's upload and cull on its own view stream: 0.3124-0.3144 ms per C3
+            # frame against 0.3158-0.3185 with three chains + a stream for the culls (scripts/r04_one_gpu_chains_ab.sh, three alternations)
+            args.cull_on_view_stream = True
+            args.frames_in_flight = 4
         if args.cull_on_view_stream:
             flags |= _lib.MV_FLAG_CULL_ON_VIEW_STREAM
     if world > 1:
@@ -557,7 +563,8 @@ def main():
                 "frames_per_launch": (args.frames_per_launch or 1) if world > 1 else None,
                 "parallelism": (f"{world} ranks, peer stores (no collectives): every cube-map volume's 8x8 tiles dealt over the ranks, the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, rows pushed into every rank's frame buffer; the frame's light march shared out by layers of voxel blocks, pushed into every rank's light map; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
                                 else f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, the frame's light march shared out by voxel blocks + all-gather of the shares; frame loop inside the library (mv_dist_frame), transport: {exchange}") if world > 1 else "single GPU",
-                "frames_in_flight": ("up to 3 whole frames (light march, view march, composite) on 3 view streams; constants / cull 4 slots, march outputs 3 sets, light maps 3 buffers per volume" if world == 1
+                "frames_in_flight": ((f"up to {args.frames_in_flight or 3} whole frames (" + ("upload, cull, " if args.cull_on_view_stream else "") + f"light march, view march, composite) on {args.frames_in_flight or 3} view streams"
+                                      + ("" if args.cull_on_view_stream else "; upload + cull on a stream of their own")) if world == 1
                                      else "upload + cull + light march ahead of the view march / exchange / composite stream" if args.dist_single_stream
                                      else "up to 3 whole frames (light-march share + all-gather, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + (("+peer stores" if exchange == "peer" else "+cube-face all-gather") if world > 1 else "") + ("+OIT composite" if do_composite else ""),
