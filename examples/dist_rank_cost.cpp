@@ -4,7 +4,7 @@
 // (scripts/exp_rank_cost.py is the same measurement through the Python mirror).  max over ranks = the frame time an ideal fabric would
 // give; its ratio to world 1 is the ceiling of the strong-scaling curve.
 // Build: g++ -O2 -std=c++17 examples/dist_rank_cost.cpp -Lmultivolumes_amd -lmultivolumes_amd -Wl,-rpath,$PWD/multivolumes_amd -o /tmp/dist_rank_cost
-// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3 (0)] [C3 | C5] [callbacks | peer | peer-nofold | peer4 | peer4-root | peer4x2 | peer4x4 | peer4x4-root]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
+// Usage: /tmp/dist_rank_cost [frames = 400] [worlds = 1,2,4,8 as a bit mask: 15] [one rank only, -1 = all] [frames in flight = 3 (0)] [C3 | C5 | C2] [callbacks | peer | peer-nofold | peer4 | peer4-root | peer4x2 | peer4x4 | peer4x4-root]      (config C3: 16 x 256^3, 1024^2, 128 steps / 96 light steps)
 // "peer": the peer-store transport in loopback (MV_DIST_PEER_LOOPBACK): the rank's kernels store into all `world` copies -- every copy being
 // its own buffer -- and it raises the other ranks' flags itself: no pack / gather / unpack kernels, the flag kernels instead.
 // Prints per rank: ms per frame, and in brackets the host's share (time spent inside DistFrame: constants + every HIP call of the frame).
@@ -23,7 +23,8 @@ static int noReduce(void*, void*, size_t, void*, int) { return 0; }
 int main(int argc, char** argv)
 {
 	const bool c5 = argc > 5 && std::string(argv[5]) == "C5";	// BASELINE config C5: 64 volumes, 2048^2, 256 steps (default C3)
-	const uint32_t N = 256, L = 96, V = c5 ? 64 : 16, W = c5 ? 2048 : 1024, H = W, M = 1024;
+	const bool c2 = argc > 5 && std::string(argv[5]) == "C2";	// BASELINE config C2: 4 volumes of 128^3, 512^2, 64 steps (a frame that cannot fill the GPU even on one rank)
+	const uint32_t N = c2 ? 128 : 256, L = 96, V = c5 ? 64 : c2 ? 4 : 16, W = c5 ? 2048 : c2 ? 512 : 1024, H = W, M = 1024;
 	const bool peer = argc > 6 && std::string(argv[6]).rfind("peer", 0) == 0;
 	const bool noFold = argc > 6 && std::string(argv[6]) == "peer-nofold";
 	const bool root = argc > 6 && std::string(argv[6]) == "peer4-root";	// ... and the rows to rank 0 only (MV_DIST_PEER_ROWS_TO_ROOT)
@@ -66,7 +67,7 @@ int main(int argc, char** argv)
 			if (!rc.Init(N, L, V, V, W, H, M, 0, nullptr, rank, world, MV_FLAG_PIPELINE_FRAMES | (four ? MV_FLAG_CULL_ON_VIEW_STREAM : 0u), four ? 4u : inFlight, perLaunch)) { std::fprintf(stderr, "Init failed (no gfx950 device?)\n"); return 2; }
 			for (uint32_t k = 0; k < V; ++k) if (!rc.LoadVolumeData(k, vols[k].data())) return 3;
 			if (!rc.SetRenderTargetsHost(depth.data(), shadow.data())) return 4;
-			rc.SetMaxSamples(c5 ? 256 : 128, 96);
+			rc.SetMaxSamples(c5 ? 256 : c2 ? 64 : 128, 96);
 			rc.SetLight(light, lc, 3.0f * 3.14159265f);
 			rc.SetAmbient(ac, 2.0f * 3.14159265f);
 			if (peer)

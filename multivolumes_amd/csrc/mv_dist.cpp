@@ -946,13 +946,11 @@ static int batchTail(mv_ctx* ctx)
 	// (a group of one frame: nothing above waited for the other ranks' faces -- a kernel of one wavefront does)
 	if (peers && n == 1u) { const int rc = peerWaitStage(ctx, X, kStageCube, P, last.st.frameTag, last.slot); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, evRecord(ctx, ctx->evLanded[last.slot], X));
-	const bool foldedWait = false;
 	if (nComposite)
 	{
 		for (uint32_t i = 0; i < nComposite; ++i)
 		{
 			foldBase(ctx, sts[i], kFoldComposite, P, last.st.frameTag, last.slot);
-			if (foldedWait) foldWait(ctx, sts[i], kStageCube, P);
 		}
 		EventPair evt = { nullptr, nullptr, 0 };
 		beginStage(ctx, 3 | (int)(nComposite << 8), evt, X);
