@@ -127,7 +127,7 @@ def parse():
     p.add_argument("--cull-on-stream-a", action="store_true", help="one GPU: three chains and a stream of its own for upload + cull (the library's default) instead of four chains with the culls on them")
     p.add_argument("--frames-per-launch", type=int, default=0, help="--gpus N > 1, peer stores: B = 1..4 consecutive frames go through every long kernel of a rank's chain together "
                    "(mv_config.frames_per_launch; 0 = 4 on the peer-store rung, 1 elsewhere): a rank of eight holds an eighth of a frame, which leaves its GPU to latency")
-    p.add_argument("--transport", default="auto", choices=["auto", "peer", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
+    p.add_argument("--transport", default="auto", choices=["auto", "peer", "peer-one-frame-per-launch", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
                    help="--gpus > 1: auto = the peer-store transport (no collectives: every rank's kernels store into every rank's buffers over "
                         "IPC mappings, flags instead of all-gathers), and -- only if that fails its self-test, fails or stops making progress -- "
                         "the next of: the library's own RCCL communicators with one view stream (two communicators, one collective in flight "
@@ -149,7 +149,7 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------------
 # (the conservative RCCL schedule in front of the one that keeps three communicators busy on three streams of a device, until a box with
 # more than one GPU has run tests/test_rccl_multi_gpu.py)
-LEVELS = ["peer", "rccl-single-stream", "rccl", "torch-nccl", "gloo"]
+LEVELS = ["peer", "peer-one-frame-per-launch", "rccl-single-stream", "rccl", "torch-nccl", "gloo"]  # ("peer": four frames per launch; its second rung: the same transport, a frame per launch)
 PHASE_TIMEOUT_S = {"start": 420.0, "setup": 420.0, "dist-init": 180.0, "warmup": 240.0, "timed": 240.0, "roofline": 240.0, "report": 600.0}
 
 
@@ -201,7 +201,7 @@ def supervise(args, world, rank):
     share = os.environ.get("MV_BENCH_SHARE_GPU") == "1"
     levels = (["peer", "gloo"] if args.transport == "auto" else [args.transport]) if share else LEVELS if args.transport == "auto" else [args.transport]
     if args.dist_single_stream:
-        levels = [l for l in levels if l != "peer"] or levels  # (the peer-store transport runs whole-frame chains only)
+        levels = [l for l in levels if not l.startswith("peer")] or levels  # (the peer-store transport runs whole-frame chains only)
     rc = 1
     for level, transport in enumerate(levels):
         port = [_free_port() if rank == 0 else 0]
@@ -267,6 +267,10 @@ def main():
     import torch.distributed as dist
 
     transport = os.environ.get("MV_BENCH_TRANSPORT", "peer" if args.transport == "auto" else args.transport)
+    if transport == "peer-one-frame-per-launch":  # (the ladder's second rung: what round 4 measured first -- no launch holds more than one frame)
+        transport = "peer"
+        if args.frames_per_launch == 0:
+            args.frames_per_launch = 1
     if transport == "rccl-single-stream":
         args.dist_single_stream = True
     if not torch.cuda.is_available():
