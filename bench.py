@@ -570,6 +570,7 @@ def main():
                 "frames_in_flight": ((f"up to {args.frames_in_flight or 3} whole frames (" + ("upload, cull, " if args.cull_on_view_stream else "") + f"light march, view march, composite) on {args.frames_in_flight or 3} view streams"
                                       + ("" if args.cull_on_view_stream else "; upload + cull on a stream of their own")) if world == 1
                                      else "upload + cull + light march ahead of the view march / exchange / composite stream" if args.dist_single_stream
+                                     else (f"{args.frames_in_flight} chains (view streams) x {args.frames_per_launch or 1} frames per launch: upload, cull, light-march layers, view march (stores its texels and the light layers into every rank's buffers), composite, row push per group of frames") if exchange == "peer"
                                      else "up to 3 whole frames (light-march share + all-gather, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + (("+peer stores" if exchange == "peer" else "+cube-face all-gather") if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes_timed // max(1, K),
