@@ -381,18 +381,20 @@ def test_c3_with_the_reference_scenes_mesh(oracle):
         assert g["view_samples"] == st["view_samples"] and g["lit_samples"] == st["lit_samples"] and g["rays"] == st["rays"]
 
 
-@pytest.mark.parametrize("extra,in_flight", [(0, 0), (_lib.MV_FLAG_CULL_ON_VIEW_STREAM, 4)], ids=["three_chains", "four_chains_cull_on_view_stream"])
-def test_orbit_with_frames_in_flight_reads_like_one_output_set(extra, in_flight):
+@pytest.mark.parametrize("extra,in_flight,per_launch", [(0, 0, 0), (_lib.MV_FLAG_CULL_ON_VIEW_STREAM, 4, 0), (_lib.MV_FLAG_CULL_ON_VIEW_STREAM, 4, 3)],
+                         ids=["three_chains", "four_chains_cull_on_view_stream", "four_chains_three_frames_per_stream"])
+def test_orbit_with_frames_in_flight_reads_like_one_output_set(extra, in_flight, per_launch):
     """The reference never clears its cube maps: a face a frame does not march keeps older data, and a CubeCast gather across a cube
     edge can read it.  With frames in flight three output sets rotate; the copy-forward of unmarched faces must make every one
     of them read exactly like the single set of a one-stream context.  An orbit that keeps changing face masks, mips and schemes, composites
     compared every few frames (scripts/soak.py runs the same for 40 000 frames).  Also with four output sets on four view streams and
-    every frame's upload and cull on its own view stream (MV_FLAG_CULL_ON_VIEW_STREAM)."""
+    every frame's upload and cull on its own view stream (MV_FLAG_CULL_ON_VIEW_STREAM) -- and with mv_config.frames_per_launch = 3 outside
+    the multi-GPU loop: three consecutive frames share a view stream, twelve output sets and light buffers rotate, nothing else changes."""
     cfg = dict(scene.CONFIGS["T2"], W=320, H=200)
     V, N = cfg["V"], cfg["N"]
     vols = [rc.synth_volume(N, k) for k in range(V)]
     proj = rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0)
-    cs = [make_caster(cfg, 64), MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=_lib.MV_FLAG_PIPELINE_FRAMES | extra, framesInFlight=in_flight)]
+    cs = [make_caster(cfg, 64), MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=_lib.MV_FLAG_PIPELINE_FRAMES | extra, framesInFlight=in_flight, framesPerLaunch=per_launch)]
     try:
         frs = [scene.setup_raycaster(c, cfg, vols, use_sh=True) for c in cs]
         differing = 0
