@@ -1048,9 +1048,8 @@ static int batchClose(mv_ctx* ctx)
 		{
 			mv::PeerSync a = peerSyncBase(ctx, last.st.frameTag, last.slot);
 			for (uint32_t c = 0; c < C; ++c) if (J > (uint64_t)C + c) { a.waitRow[a.nWait] = kStageDone * mv::kPeerMaxChains + (uint32_t)((J - C - c) % C); a.waitValue[a.nWait++] = J - C - c; }
-			// ... and, for the view march behind the light march: every rank's layers of the maps relit in the C - 1 groups before this one (on
-			// the other streams) have landed -- their view marches started well before this group's culls did
-#if MV_BATCH_ONE_WAIT
+#if MV_BATCH_ONE_WAIT	// (rejected: the light march then waits for the view march of the group before to start)
+			// ... and, for the view march behind the light march: every rank's layers of the maps relit in the C - 1 groups before this one
 			for (uint32_t c = 1; c < C; ++c)
 				if (J > c)
 				{
@@ -1145,18 +1144,18 @@ static int distFrameBatch(mv_ctx* ctx, const void* cbPerFrame, const void* perOb
 {
 	DistState* d = ctx->dist;
 	MV_REQUIRE(ctx, d->peerReady, MV_ERR_NOT_READY, "mv_dist_init_peer has not been called (mv_dist_peer_export alone attaches nothing)");
+	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
+	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
 	int rc;
 	if ((rc = peerCheckReports(ctx)) != MV_OK) return rc;
 	const bool first = d->nCur == 0u;
 	if (first) ++d->peerFrame;	// (counts groups here)
-	ctx->batchExplicit = true; ctx->batchIndex = d->peerFrame; ctx->batchPos = d->nCur;
 	struct Lean { mv_ctx* c; ~Lean() { c->leanEvents = false; } } lean = { ctx };
 	ctx->leanEvents = true;
 #ifdef MV_HOST_PROFILE
 	++gSectionCalls;
 #endif
-	MV_REQUIRE(ctx, ctx->haveDepth, MV_ERR_NOT_READY, "no depth map (mv_set_depth_map)");
-	MV_REQUIRE(ctx, ctx->haveShadow, MV_ERR_NOT_READY, "no shadow map (mv_set_shadow_map)");
+	ctx->batchExplicit = true; ctx->batchIndex = d->peerFrame; ctx->batchPos = d->nCur;
 	ctx->deferUpload = true;
 	{ MV_SECTION(0); rc = mv_update_frame(ctx, cbPerFrame, perObject); }	// (the constants into their pinned slice; upload and cull of the group's frames go out together, batchClose)
 	ctx->batchExplicit = false; ctx->deferUpload = false;
