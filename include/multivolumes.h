@@ -112,7 +112,7 @@ typedef struct mv_config
 								   light march, one view march, one composite, one row push for all of them (blockIdx.y = the frame) -- because a rank
 								   of eight holds an eighth of a frame: a wavefront per SIMD or less, every long kernel as long as its longest ray
 								   whatever else the GPU could do meanwhile, and four hardware queues are all the frames that can overlap.  The frames
-								   of a group reach the GPU when the group is full (or at mv_dist_flush / a setter): throughput for latency.
+								   of a group reach the GPU when the group is full (or at mv_dist_flush / a setter; mv_synchronize alone does not send them, mv_dist_shutdown drops them): throughput for latency.
 								   Results are identical.  (ABI 5: the field occupies what was padding -- zero the struct before filling it in.) */
 } mv_config;
 
