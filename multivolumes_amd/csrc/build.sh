@@ -26,12 +26,13 @@ $HIPCC $FLAGS -c mv_composite.hip -o $OBJ/mv_composite.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_mesh.hip -o $OBJ/mv_mesh.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_api.cpp -o $OBJ/mv_api.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_dist.cpp -o $OBJ/mv_dist.o "$@" & pids+=($!)
+$HIPCC $FLAGS -c mv_dist_peer.cpp -o $OBJ/mv_dist_peer.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_mesh_api.cpp -o $OBJ/mv_mesh_api.o "$@" & pids+=($!)
 g++ -O3 -ffp-contract=off -std=c++17 -fPIC -Wall -c mv_host.cpp -o $OBJ/mv_host.o & pids+=($!)
 rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=1; done
 if [ $rc -ne 0 ]; then echo "build.sh: a compile job failed" >&2; rm -rf "$OBJ"; exit 1; fi
-$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT.tmp" $OBJ/mv_kernels.o $OBJ/mv_march.o $OBJ/mv_march_tiles.o $NARROW $OBJ/mv_peer.o $OBJ/mv_composite.o $OBJ/mv_mesh.o $OBJ/mv_api.o $OBJ/mv_dist.o $OBJ/mv_mesh_api.o $OBJ/mv_host.o -lpthread
+$HIPCC -shared -fPIC --offload-arch=gfx950 -o "$OUT.tmp" $OBJ/mv_kernels.o $OBJ/mv_march.o $OBJ/mv_march_tiles.o $NARROW $OBJ/mv_peer.o $OBJ/mv_composite.o $OBJ/mv_mesh.o $OBJ/mv_api.o $OBJ/mv_dist.o $OBJ/mv_dist_peer.o $OBJ/mv_mesh_api.o $OBJ/mv_host.o -lpthread
 mv -f "$OUT.tmp" "$OUT"
 # content hash of the sources this library was built from (multivolumes_amd/_lib.py::_source_hash computes the same):
 # the loader rebuilds when the tree no longer matches it
