@@ -75,7 +75,10 @@ void foldSignal(mv_ctx* ctx, DeviceState& st, int stage, uint64_t frame)
 	st.fold.signalValue[st.fold.nSignal++] = frame;
 }
 void foldClear(DeviceState& st) { st.fold.nWait = 0u; st.fold.nSignal = 0u; st.fold.checkChain = 0xffffffffu; st.fold.checkCompare = 0u; st.fold.stores = 0u; st.fold.pushBlocks = 0u; }
-constexpr uint32_t kPeerLightPushBlocks = 224;	// workgroups (of the tile march's 128 threads) in front of a folded view march that push the light layers: 16 bytes x 4 per thread cover 1.8 MB
+#ifndef MV_PEER_LIGHT_PUSH_BLOCKS
+#define MV_PEER_LIGHT_PUSH_BLOCKS 224
+#endif
+constexpr uint32_t kPeerLightPushBlocks = MV_PEER_LIGHT_PUSH_BLOCKS;	// workgroups (of the tile march's 128 threads) in front of a folded view march that push the light layers: 16 bytes x 4 per thread cover 1.8 MB
 
 // in front of a consumer on stream s: every rank's `stage` of frame `frame` has landed here
 int peerWaitStage(mv_ctx* ctx, hipStream_t s, int stage, uint64_t frame, uint32_t frameTag, uint32_t slot)
