@@ -16,7 +16,13 @@ V, N = cfg["V"], cfg["N"]
 vols = [rc.synth_volume(N, k) for k in range(V)]
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
 check = int(sys.argv[2]) if len(sys.argv) > 2 else frames // 8
-cs = [MultiRayCaster(N, cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=f) for f in (0, _lib.MV_FLAG_PIPELINE_FRAMES)]
+# MV_SOAK_FOUR_CHAINS=1: the pipelined context as bench.py creates it on one GPU since round 4 (four chains, every frame's upload and cull on its own view stream);
+# MV_SOAK_FRAMES_PER_LAUNCH=B: ... and B consecutive frames per view stream (mv_config.frames_per_launch outside the multi-GPU loop)
+four = os.environ.get("MV_SOAK_FOUR_CHAINS") == "1"
+per_launch = int(os.environ.get("MV_SOAK_FRAMES_PER_LAUNCH", "0"))
+cs = [MultiRayCaster(N, cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64),
+      MultiRayCaster(N, cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=_lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_CULL_ON_VIEW_STREAM if four else 0),
+                     framesInFlight=4 if four else 0, framesPerLaunch=per_launch)]
 frs = [scene.setup_raycaster(c, cfg, vols, use_sh=True) for c in cs]
 proj = rc.perspective_fov_lh(scene.FOV_ANGLE_Y, cfg["W"] / cfg["H"], 1.0, 1000.0)
 t0 = time.time()
