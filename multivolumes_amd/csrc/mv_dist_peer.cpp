@@ -449,6 +449,7 @@ int mv_dist_set_peer_timeout_ms(mv_ctx* ctx, uint32_t ms)
 // the other inside it), one composite launch, one row push.  Ordering is the per-slot events' of the one-frame path (every frame
 // records its own), stream order inside a group, and the flags between ranks.
 // ---------------------------------------------------------------------------------------------
+static_assert(sizeof(mv::DeviceStateBatch) + 64 <= 4096, "the frames' states of a launch travel by value: a kernel's argument segment holds 4 KB");
 #ifndef MV_BATCH_ONE_WAIT
 #define MV_BATCH_ONE_WAIT 0	// 1: one wait kernel per group (in front of the light march: the done rows AND the older groups' light rows) instead of two -- measured slower (profiles/r04_frames_per_launch.txt)
 #endif
