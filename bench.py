@@ -565,7 +565,7 @@ def main():
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
                 "frames_per_launch": (args.frames_per_launch or 1) if world > 1 else None,
-                "parallelism": (f"{world} ranks, peer stores (no collectives): every cube-map volume's 8x8 tiles dealt over the ranks, the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, rows pushed into every rank's frame buffer; the frame's light march shared out by layers of voxel blocks, pushed into every rank's light map; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
+                "parallelism": (f"{world} ranks, peer stores (no collectives): " + ("every cube-map volume's 8x8 tiles dealt over the ranks" if (args.frames_per_launch or 1) > 1 else "cube-map volumes dealt per frame by estimated march cost") + ", the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, rows pushed into every rank's frame buffer; the frame's light march shared out by layers of voxel blocks, pushed into every rank's light map; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
                                 else f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, the frame's light march shared out by voxel blocks + all-gather of the shares; frame loop inside the library (mv_dist_frame), transport: {exchange}") if world > 1 else "single GPU",
                 "frames_in_flight": ((f"up to {args.frames_in_flight or 3} whole frames (" + ("upload, cull, " if args.cull_on_view_stream else "") + f"light march, view march, composite) on {args.frames_in_flight or 3} view streams"
                                       + ("" if args.cull_on_view_stream else "; upload + cull on a stream of their own")) if world == 1

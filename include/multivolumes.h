@@ -344,12 +344,16 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * frame buffers their own rows -- 1/7 of the row traffic (C5 on 8 ranks: 4 MB per rank and frame instead of 28).  Default: every rank
  * gets every row, as with the all-gathers. */
 #define MV_DIST_PEER_ROWS_TO_ROOT 8u
-/* Who marches what.  Default: the view march of EVERY cube-map volume is shared out by tiles (rank r marches the 8x8 tiles t of each
- * marched face with (t + volume) mod shard_count == r): a march that stores its texels into every rank's cube maps itself does not care who
- * "owns" a volume, and eight ranks then carry an eighth of the tiles each.  With this flag whole volumes go to ranks, dealt by estimated
- * cost as with the collectives (the north star's "volumes shard across the GPUs"): ten visible volumes on eight ranks leave two ranks with
- * two volumes, which the frame then waits for (profiles/r04_frames_per_launch.txt).  Results are identical. */
+/* Who marches what.  With several frames per launch (mv_config.frames_per_launch > 1) the view march of EVERY cube-map volume is
+ * shared out by tiles (rank r marches the 8x8 tiles t of each marched face with (t + volume) mod shard_count == r): a march that stores
+ * its texels into every rank's cube maps itself does not care who "owns" a volume, and eight ranks then carry an eighth of the tiles each
+ * -- ten visible volumes dealt to eight ranks leave two ranks with two volumes, which a launch of four frames then waits for (0.080 against
+ * 0.060 ms per C3 frame).  With one frame per launch whole volumes go to ranks, dealt by estimated cost as with the collectives (the north
+ * star's "volumes shard across the GPUs"): there the frame is a chain of latencies, and a rank that touches one or two volumes runs it
+ * faster (0.095 against 0.103 ms) than one that touches a slice of all of them.  These two flags force either deal
+ * (profiles/r04_frames_per_launch.txt).  Results are identical. */
 #define MV_DIST_PEER_DEAL_VOLUMES 16u
+#define MV_DIST_PEER_DEAL_TILES 32u
 int mv_dist_peer_export(mv_ctx* ctx, void* out /* MV_DIST_PEER_BYTES */);
 int mv_dist_init_peer(mv_ctx* ctx, const void* all /* shard_count x MV_DIST_PEER_BYTES in rank order; NULL with MV_DIST_PEER_LOOPBACK */, uint32_t flags);
 int mv_dist_set_peer_timeout_ms(mv_ctx* ctx, uint32_t ms);

@@ -147,7 +147,7 @@ struct DistState
 	uint64_t peerTimeoutTicks = 30ull * 100000000ull;	// 30 s of wall_clock64 (100 MHz)
 	uint32_t rowsStream[kDistChains] = {};		// per chain: the view stream its frames run on
 	uint64_t rowsWaitFrame[kDistChains] = {};	// per chain: the newest frame whose rows this rank has composited but not yet waited for from the others (0 = none): enqueued lazily, by whatever synchronises
-	bool peerDealVolumes = false;				// MV_DIST_PEER_DEAL_VOLUMES: whole cube-map volumes per rank (dealt by cost) instead of every volume's tiles shared out
+	bool peerDealVolumes = false;				// whole cube-map volumes per rank (dealt by cost: the default with one frame per launch) instead of every volume's tiles shared out
 	bool peerRowsRoot = false;					// MV_DIST_PEER_ROWS_TO_ROOT: the ranks push their rows to rank 0 only
 	bool peerFold = false;						// the waits are the consumers' own prologues (mv_kernels.hpp peerFoldWait) instead of one-wavefront kernels in front of them
 	uint32_t* dPeerCounters = nullptr;			// finished-workgroup counters of the push kernels: [kind][chain]

@@ -420,7 +420,7 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 		d->peerFold = true;
 	}
 	d->peerRowsRoot = (flags & MV_DIST_PEER_ROWS_TO_ROOT) != 0;
-	d->peerDealVolumes = (flags & MV_DIST_PEER_DEAL_VOLUMES) != 0;
+	d->peerDealVolumes = (flags & MV_DIST_PEER_DEAL_VOLUMES) ? true : (flags & MV_DIST_PEER_DEAL_TILES) ? false : ctx->framesPerLaunch == 1u;	// (see the header: tiles pay with several frames per launch)
 	d->peerFrame = 0;
 	for (uint32_t c = 0; c < kDistChains; ++c) { d->rowsWaitFrame[c] = 0; d->rowsStream[c] = 0; }
 	const int rc = distCommonInit(ctx);	// (releases everything on failure)

@@ -144,7 +144,7 @@ def stored_tile_row(t, H, world):
     return (t % world) * per_rank + t // world
 
 
-def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, deal_volumes=False):
+def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, deal_volumes=None):
     """The peer-store transport (include/multivolumes.h): every rank exports IPC handles of its light maps, cube maps and frame buffers,
     torch.distributed only gathers the blobs (any backend), every rank maps the others and the kernels store into all of them.
     Every step is collective and unconditional; a vote after init + self-test decides for all ranks.  Returns True if it is attached."""
@@ -181,7 +181,7 @@ def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, 
     return False
 
 
-def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True, prefer_peer=False, peer_timeout_ms=None, peer_fold=None, peer_rows_to_root=False, peer_deal_volumes=False):
+def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True, prefer_peer=False, peer_timeout_ms=None, peer_fold=None, peer_rows_to_root=False, peer_deal_volumes=None):
     """Attach the in-library multi-GPU frame loop (mv_dist_frame) to a sharded caster.
 
     prefer_peer: try the peer-store transport first (whole-frame-chain contexts on one node; returns "peer").

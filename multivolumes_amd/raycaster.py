@@ -473,15 +473,15 @@ class MultiRayCaster:
         self._check(self._lib.mv_dist_peer_export(self._ctx, buf), "mv_dist_peer_export")
         return bytes(buf)
 
-    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False, deal_volumes=False):
+    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False, deal_volumes=None):
         """Attach the frame loop with the peer-store transport: every rank's kernels store into every rank's buffers (no collectives).
         loopback: a rank measured alone (every peer is the context itself).  fold: True / False force the flags into / out of the
         marches and the composite (None: the library decides -- folded when every rank owns its GPU)."""
         flags = 0 if fold is None else (_lib.MV_DIST_PEER_FOLD if fold else _lib.MV_DIST_PEER_NO_FOLD)
         if rows_to_root:  # only rank 0 assembles the whole frame
             flags |= _lib.MV_DIST_PEER_ROWS_TO_ROOT
-        if deal_volumes:  # whole cube-map volumes per rank, dealt by cost (default: every volume's tiles shared out over the ranks)
-            flags |= _lib.MV_DIST_PEER_DEAL_VOLUMES
+        if deal_volumes is not None:  # whole cube-map volumes per rank, dealt by cost / every volume's tiles shared out (None: the library's choice -- volumes with one frame per launch, tiles with several)
+            flags |= _lib.MV_DIST_PEER_DEAL_VOLUMES if deal_volumes else _lib.MV_DIST_PEER_DEAL_TILES
         if loopback:
             self._check(self._lib.mv_dist_init_peer(self._ctx, None, _lib.MV_DIST_PEER_LOOPBACK | flags), "mv_dist_init_peer")
             return

@@ -67,7 +67,7 @@ def single_gpu(world, frames, every, static_depth=False, all_frames=False):
                                                            (2, "peer", 3, False), (3, "peer", 13, True), (2, "peer", 26, True), (5, "peer", 13, True),
                                                            (2, "peer-folded", 3, False), (3, "peer-folded", 13, True), (2, "peer-folded", 26, True),
                                                            (2, "peer-four", 3, False), (3, "peer-four", 13, True), (2, "peer-four", 26, True), (3, "chains-four", 13, True),
-                                                           (3, "peer-root", 13, True), (3, "peer-volumes", 13, True), (2, "peer-volumes", 3, False),
+                                                           (3, "peer-root", 13, True), (3, "peer-tiles", 13, True), (2, "peer-tiles", 3, False), (3, "peer-x2-volumes", 13, True),
                                                            (2, "peer-x2", 3, False), (3, "peer-x2", 13, True), (2, "peer-x2", 26, True), (2, "peer-x3", 13, True), (3, "peer-x4", 7, True),
                                                            (5, "peer-x4", 13, True)])
 def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static_depth):
@@ -84,8 +84,10 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if mode == "peer-root":  # the rows to rank 0 only (it is rank 0 whose frames the test compares)
         mode, env["MV_TEST_ROWS_TO_ROOT"] = "peer", "1"
-    if mode == "peer-volumes":  # whole cube-map volumes per rank (MV_DIST_PEER_DEAL_VOLUMES) instead of every volume's tiles shared out
-        mode, env["MV_TEST_DEAL_VOLUMES"] = "peer", "1"
+    if mode == "peer-tiles":  # one frame per launch with every cube-map volume's tiles shared out (MV_DIST_PEER_DEAL_TILES; the default there: whole volumes per rank)
+        mode, env["MV_TEST_DEAL_VOLUMES"] = "peer", "0"
+    if mode.endswith("-volumes"):  # several frames per launch with whole volumes per rank (MV_DIST_PEER_DEAL_VOLUMES; the default there: tiles)
+        mode, env["MV_TEST_DEAL_VOLUMES"] = mode[:-len("-volumes")], "1"
     if "-x" in mode:  # mv_config.frames_per_launch = 2, 3, 4: groups of frames through every long kernel together (four chains, folded flags); a checkpoint or a setter closes a group early
         env["MV_TEST_FRAMES_PER_LAUNCH"] = mode[-1]
         mode, env["MV_TEST_FOUR_CHAINS"] = "peer-folded", "1"
