@@ -156,3 +156,5 @@ def test_roofline_fraction_is_a_fraction_on_every_workload():
     assert r["frac"] == 1.0 and "capped" in r["frac_basis"]
     assert bench.roofline_fraction(1.0, 1.0, None, 0.0)["frac"] is None
     assert bench.LEVELS[0] == "peer" and bench.LEVELS.index("rccl-single-stream") < bench.LEVELS.index("rccl")
+    # (the peer-store transport twice: four frames per launch first, then -- should that form fail on a fabric it has never met -- a frame per launch)
+    assert bench.LEVELS[1] == "peer-one-frame-per-launch"
