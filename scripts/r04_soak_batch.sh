@@ -8,3 +8,5 @@ MV_TEST_FRAMES_PER_LAUNCH=3 timeout 900 python scripts/soak_dist.py 5 400 50 cha
 MV_TEST_FRAMES_PER_LAUNCH=2 MV_TEST_DEAL_VOLUMES=1 timeout 900 python scripts/soak_dist.py 3 400 11 chains
 MV_TEST_FRAMES_PER_LAUNCH=4 MV_TEST_W=250 MV_TEST_H=173 timeout 900 python scripts/soak_dist.py 4 300 13 chains
 } 2>&1 | grep -v "^W\|warn" | tee $out/soak.txt
+# ... and at the full C3 frame on one rank (sixteen output sets of full size rotating): MV_TEST_CONFIG=C3
+MV_TEST_CONFIG=C3 MV_TEST_FRAMES_PER_LAUNCH=4 OMP_NUM_THREADS=4 timeout 1200 python scripts/soak_dist.py 1 400 37 chains 2>&1 | grep -v "^W\|warn" | tee -a gpurun_out/r04_batch/soak.txt
