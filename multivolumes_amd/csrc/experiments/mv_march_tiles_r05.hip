@@ -1,3 +1,9 @@
+// experiments/mv_march_tiles_r05.hip -- the product kernel (csrc/mv_march_tiles.hip) with the round-5 experiments' switches, built INSTEAD of
+// it by csrc/build.sh when one of them is on its command line (measured, rejected: profiles/r05_instruction_cuts.txt):
+//   -DMV_EMPTY_REGIONS=1       advance through all-empty 16^3 regions with the bare `t += stepScale` (emptyRegionEnd below)
+//   -DMV_EMULATE_LIGHT_PAIRS   TIMING ONLY: the load and instruction stream of light cells kept as fp16 pairs (32-byte cells); images are garbage
+//   -DMV_TILE_LDS_PAD=bytes    extra LDS per workgroup: the march at fewer wavefronts per SIMD
+//   -DMV_DIAG_ITER             wave-iteration census into the timeline buffer (scripts/exp_wave_iterations.py)
 // mv_march_tiles.hip -- a3 (+ the fused screen-space RayCast) as one wavefront per 8x8 tile: the reference's thread-group tile
 // (Sh/CSRayMarch.hlsl:77), ray setup and sample loop in one kernel, wavefronts dispatched by the hardware in the cost-binned
 // tile order.  This is the form the context uses when a frame has only a few rays per lane of the GPU (C3: 0.66 M rays on
@@ -5,6 +11,7 @@
 // its record traffic and refills ("tiles or ray queue").  Same arithmetic, same results, bit for bit.
 #include "mv_device.hpp"
 #include "mv_kernels.hpp"
+// (built with -I csrc)
 
 namespace mv
 {
@@ -23,9 +30,83 @@ constexpr uint32_t kTileWaves = MV_TILE_WAVES;
 #ifndef MV_TILE_LUT
 #define MV_TILE_LUT 1	// per-axis address tables in LDS (N <= 256); 0 = compute every tap's offsets (A/B timing)
 #endif
+#ifndef MV_EMPTY_REGIONS
+#define MV_EMPTY_REGIONS 0	// (measured: profiles/r05_instruction_cuts.txt) advance through 16^3 regions without an occupied brick with the bare `t += stepScale` (mv_device.hpp emptyRegionEnd)
+#endif
 #ifndef MV_TILE_MIN_WAVES
 #define MV_TILE_MIN_WAVES 3	// occupancy bound given to the register allocator / scheduler. Measured at C3: 3 -> 0.360 ms, 5 -> 0.395, 6 -> 0.414,
 							// 7 -> 0.46, 8 -> 0.60 (spills); all of 1..5 allocate about 90 VGPRs, the looser bound schedules loads earlier
+#endif
+
+
+// ---- round-5 experiments' device functions (not in the product headers) ----
+// A 64-bit occupancy word that is ZERO says more than one sample's bit: every sample whose first taps lie in that 16^3-texel region is
+// fetch-free, so until the ray leaves the region CSRayMarch.hlsl:117-153 does nothing but `t += stepScale` and its two exit tests.
+// emptyRegionEnd returns a ray parameter below which the ray's samples provably (a) have their first taps in the region of the sample at
+// `t` and (b) lie inside the box (the loop's `any(abs(pos) > 1)` test cannot fire): the march advances through them with the bare
+// addition -- the same additions, the same counters -- instead of an address computation and an occupancy lookup per sample.
+// In region units r = (u N - 0.5) / 16 per axis the region of the sample is [floor(r), floor(r) + 1), the box [-0.5, N - 0.5] / 16 (taps
+// clamp: a coordinate below the first or beyond the last texel centre still belongs to the edge region); the exit distance along each
+// axis, shortened by kEmptyMargin = 1/64 texel, over the ray's speed along it -- v_rcp_f32 is enough, the margin is a thousand times the
+// rounding of everything here and of the loop's own `o + d t` (a few 1e-5 texels at N = 256).  Conservative is all it has to be: a
+// sample left out takes the ordinary path, finds the same zero word and counts the same.
+constexpr float kEmptyMargin = 1.0f / 1024.0f;	// in regions of 16 texels
+__device__ __forceinline__ float emptyRegionEnd(vec3 uvw, vec3 d, float t, uint32_t N)
+{
+	const float n = (float)N, speed = n * (0.5f / 16.0f);	// regions per unit of t and unit direction component (pos = o + d t, u = pos / 2 + 1/2)
+	const float boxLo = -0.5f / 16.0f, boxHi = (n - 0.5f) * 0.0625f;
+	float tEnd = kFltMax;
+#pragma unroll
+	for (int a = 0; a < 3; ++a)
+	{
+		const float da = comp(d, a);
+		const float r = (comp(uvw, a) * n - 0.5f) * 0.0625f;
+		const float rl = __builtin_floorf(r);
+		const float up = __builtin_fminf(rl + 1.0f, boxHi) - r, down = r - __builtin_fmaxf(rl, boxLo);
+		const float dist = (da >= 0.0f ? up : down) - kEmptyMargin;
+		tEnd = __builtin_fminf(tEnd, dist * __builtin_amdgcn_rcpf(__builtin_fabsf(da) * speed));	// (da = 0: +inf, or NaN when dist = 0 -- ignored by fmin)
+	}
+	return t + tEnd;
+}
+
+
+// TIMING EXPERIMENT ONLY: the instruction and load stream the view march would have with light cells kept as fp16
+// pairs -- 32 bytes per cell {RG(x,y), RG(x+1,y), RG(x,y+1), RG(x+1,y+1) | B ...}, four 16-byte loads per footprint, no 11/10-bit decode.
+// The buffers hold no such cells (the light march still writes 16-byte ones into a buffer allocated twice the size: mv_api.cpp under the
+// same flag): the light values, hence the images, of such a build are garbage; the march's control flow (alpha only) and its counters are not.
+struct LightPairFootprint { u32x4 q0, q1, b0, b1; float cx, cy, fz; };
+__device__ __forceinline__ LightPairFootprint fetchLightPairs(const uint4* quads, uint32_t L, vec3 uvw, float fL, float fLp1)
+{
+	const GlobalBytes pool = (GlobalBytes)quads;
+	const Taps tx = linearTaps(uvw.x, L, 0, fL, fLp1), ty = linearTaps(uvw.y, L, 0, fL, fLp1), tz = linearTaps(uvw.z, L, 0, fL, fLp1);
+	const uint32_t row = (__umul24((uint32_t)ty.i0, L) + (uint32_t)tx.i0) << 4;
+	const uint32_t slice = (L * L) << 4;
+	const uint32_t a0 = (__umul24((uint32_t)tz.i0, slice) + row) << 1, a1 = (__umul24((uint32_t)tz.i1, slice) + row) << 1;
+	LightPairFootprint f;
+	f.q0 = *(GlobalUint4)(pool + a0); f.b0 = *(GlobalUint4)(pool + a0 + 16u);
+	f.q1 = *(GlobalUint4)(pool + a1); f.b1 = *(GlobalUint4)(pool + a1 + 16u);
+	f.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; f.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; f.fz = tz.f;
+	return f;
+}
+__device__ __forceinline__ vec3 resolveLightPairs(const LightPairFootprint& f)
+{
+	vec3 o;
+	o.x = lerpf(lerpf(lerpHalves<0, 0>(f.q0.x, f.q0.y, f.cx), lerpHalves<0, 0>(f.q0.z, f.q0.w, f.cx), f.cy),
+		lerpf(lerpHalves<0, 0>(f.q1.x, f.q1.y, f.cx), lerpHalves<0, 0>(f.q1.z, f.q1.w, f.cx), f.cy), f.fz);
+	o.y = lerpf(lerpf(lerpHalves<1, 1>(f.q0.x, f.q0.y, f.cx), lerpHalves<1, 1>(f.q0.z, f.q0.w, f.cx), f.cy),
+		lerpf(lerpHalves<1, 1>(f.q1.x, f.q1.y, f.cx), lerpHalves<1, 1>(f.q1.z, f.q1.w, f.cx), f.cy), f.fz);
+	o.z = lerpf(lerpf(lerpHalves<0, 0>(f.b0.x, f.b0.y, f.cx), lerpHalves<0, 0>(f.b0.z, f.b0.w, f.cx), f.cy),
+		lerpf(lerpHalves<0, 0>(f.b1.x, f.b1.y, f.cx), lerpHalves<0, 0>(f.b1.z, f.b1.w, f.cx), f.cy), f.fz);
+	return o;
+}
+#ifdef MV_EMULATE_LIGHT_PAIRS
+#define MV_LIGHT_FOOTPRINT LightPairFootprint
+#define MV_FETCH_LIGHT fetchLightPairs
+#define MV_RESOLVE_LIGHT resolveLightPairs
+#else
+#define MV_LIGHT_FOOTPRINT LightFootprint
+#define MV_FETCH_LIGHT fetchLightFootprint
+#define MV_RESOLVE_LIGHT resolveLight
 #endif
 
 typedef const __attribute__((address_space(1))) void* GlobalVoidPtr;
@@ -54,7 +135,11 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 template <bool OVERFLOW, bool LUT, bool IL, bool PEER = false>
 __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTilesKernel(DeviceState st, uint32_t firstSlot)
 {
+#ifdef MV_TILE_LDS_PAD	// (experiment: extra LDS per workgroup, to measure the march at FEWER wavefronts per SIMD -- what a wavefront more would be worth)
+	__shared__ u32x4 sAxis[(LUT ? 3 * (kLutMaxN + 1) : 1) + MV_TILE_LDS_PAD / 16];
+#else
 	__shared__ u32x4 sAxis[LUT ? 3 * (kLutMaxN + 1) : 1];
+#endif
 	// (peer-store transport, folded wait: for every rank's share of the light maps this frame reads)
 	if constexpr (PEER)
 	{
@@ -298,6 +383,9 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			const float fN = st.fN, fNm1 = st.fNm1, fL = st.fL, fLp1 = st.fLp1;
 			const VolumeView vol = makeVolumeView(uniformPtr(st.volumes[volTexId]), uniformPtr(st.alphaCells[volTexId]), st.N, st.bricks);
 			const uint4* lightQuads = uniformPtr(st.lightTable[volumeId]);
+#ifdef MV_EMULATE_LIGHT_PAIRS
+			lightQuads = st.lightBuffers + 2 * (lightQuads - st.lightBuffers);	// (timing experiment: the map's cells 32 bytes apart in a buffer twice the size)
+#endif
 
 			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
 			float t = 0.0f;
@@ -305,14 +393,33 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			// The loop at :117-153.  One aligned 16-byte alpha-cell load decides the alpha test (:128); only lit samples
 			// fetch the eight RGBA16F texels and the two light-map quads (issued together: one round trip).
 			bool prevLit = false;
+#ifdef MV_DIAG_ITER
+			uint32_t dAllSkip = 0, dAllZero = 0, dLanes = 0;
+#endif
 #if MV_OCCUPANCY
 			const GlobalBytes occupancy = (GlobalBytes)uniformPtr(st.occupancy[volTexId]);	// (scalar base + 32-bit offset: N <= 640 keeps the words below 2^20)
 			const uint32_t regions = occupancyRegions(st.bricks);
 			uint32_t occIndex = 0xffffffffu;
 			uint64_t occWord = 0;
 #endif
+#if MV_OCCUPANCY && MV_EMPTY_REGIONS
+			float tEmptyEnd = 0.0f;	// below it the ray is inside a 16^3 region without an occupied brick, and inside the box (emptyRegionEnd)
+#endif
 			for (uint32_t i = 0; i < smpCount; ++i)
 			{
+#if MV_OCCUPANCY && MV_EMPTY_REGIONS
+				// Through an all-empty region: what :117-153 does for a sample whose alpha cannot pass :128 -- count it, advance, test :152 --
+				// without the address arithmetic that would only find the same zero word again (the box test :120 cannot fire before tEmptyEnd)
+				if (t < tEmptyEnd)
+				{
+					++nSamples;
+					nLitSkipped += 0x10000u;
+					prevLit = false;
+					t += stepScale;
+					if (t > tMax) break;	// :152
+					continue;
+				}
+#endif
 				const vec3 pos = rayAt(rayOrigin, rayDir, t);
 				if (outsideBox(pos)) break;	// :120
 				const vec3 uvw = LocalToTex3DSpace(pos);
@@ -337,8 +444,19 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				{
 					const uint32_t w = LUT ? occSum & 0xffffffu : occupancyWord(fa.ix, fa.iy, fa.iz, regions);
 					if (w != occIndex) { occWord = *(GlobalUint64)(occupancy + (w << 3)); occIndex = w; }
+#ifdef MV_DIAG_ITER	// (diagnostic build, scripts/exp_wave_iterations.py: how many wave-iterations have no lane that fetches, and how many of those only zero words)
+					{
+						const bool dSkip = !((occWord >> (LUT ? occSum >> 24 : occupancyBit(fa.ix, fa.iy, fa.iz))) & 1ull);
+						const unsigned long long act = __ballot(1), sk = __ballot(dSkip), zr = __ballot(dSkip && !occWord);
+						dAllSkip += sk == act ? 1u : 0u; dAllZero += zr == act ? 1u : 0u;
+						dLanes += sk == act ? (uint32_t)__popcll(act) : 0u;
+					}
+#endif
 					if (!((occWord >> (LUT ? occSum >> 24 : occupancyBit(fa.ix, fa.iy, fa.iz))) & 1ull))
 					{
+#if MV_EMPTY_REGIONS
+						if (!occWord) tEmptyEnd = emptyRegionEnd(uvw, rayDir, t, vol.N);
+#endif
 						++nSamples;
 						nLitSkipped += 0x10000u;
 						prevLit = false;
@@ -350,9 +468,9 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 #endif
 				// latency-oriented form: the eight RGBA texels are fetched unconditionally and alpha comes from them
 				ColourFootprint cf = fetchColour(vol, fa);
-				LightFootprint lf;
+				MV_LIGHT_FOOTPRINT lf;
 				const bool early = MV_PREDICT_LIT && prevLit;
-				if (early) lf = fetchLightFootprint(lightQuads, st.L, uvw, fL, fLp1);
+				if (early) lf = MV_FETCH_LIGHT(lightQuads, st.L, uvw, fL, fLp1);
 				const float alpha = resolveAlphaFromTexels(cf);
 				++nSamples;
 				float newStep = stepScale;
@@ -360,8 +478,8 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				prevLit = lit;
 				if (lit)
 				{
-					if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw, fL, fLp1);
-					const vec3 light = resolveLight(lf);
+					if (!early) lf = MV_FETCH_LIGHT(lightQuads, st.L, uvw, fL, fLp1);
+					const vec3 light = MV_RESOLVE_LIGHT(lf);
 					vec3 color = resolveRGB(cf);
 					++nLitSkipped;
 
@@ -385,6 +503,19 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			}
 
 			scatter.x *= kInvTwoPi; scatter.y *= kInvTwoPi; scatter.z *= kInvTwoPi;	// :155
+#ifdef MV_DIAG_ITER
+			if (!screenTile)
+			{
+				// every lane saw the same ballots while it lived: the longest-lived lane holds the tile's counts
+				unsigned long long key = ((unsigned long long)nSamples << 32) | lane, best = key;
+				for (int o = 32; o > 0; o >>= 1) { const unsigned long long m = __shfl_xor(best, o); best = m > best ? m : best; }
+				if (key == best)
+				{
+					unsigned long long* tl = reinterpret_cast<unsigned long long*>(st.timeline) + (size_t)(slot % st.marchWaves) * 8u;
+					atomicAdd(tl + 0, (unsigned long long)nSamples); atomicAdd(tl + 1, (unsigned long long)dAllSkip); atomicAdd(tl + 2, (unsigned long long)dAllZero); atomicAdd(tl + 3, (unsigned long long)dLanes);
+				}
+			}
+#endif
 
 			const size_t outIndex = outIndexOf();
 			if (!screenTile)

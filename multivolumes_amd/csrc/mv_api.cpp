@@ -131,6 +131,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 
 	DeviceState& st = ctx->st;
 	st.N = cfg->grid_size; st.bricks = (cfg->grid_size + 3u) >> 2; st.L = cfg->light_grid_size;
+	st.fN = (float)st.N; st.fNm1 = (float)st.N - 1.0f; st.fL = (float)st.L; st.fLp1 = (float)st.L + 1.0f;
 	st.V = cfg->num_volumes; st.S = cfg->num_volume_srcs; st.W = cfg->viewport_w; st.H = cfg->viewport_h; st.M = cfg->shadow_map_size;
 	st.flags = cfg->flags; st.shardIndex = cfg->shard_count > 1 ? cfg->shard_index : 0u; st.shardCount = cfg->shard_count > 1 ? cfg->shard_count : 1u;
 	st.shardMagic = st.shardCount > 1u ? (uint32_t)(((1ull << 32) + st.shardCount - 1u) / st.shardCount) : 0xffffffffu;
@@ -176,7 +177,11 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	if ((rc = devAlloc(ctx, &ctx->staging, ctx->stagingBytes, false)) != MV_OK) return bail(rc);
 
 	// lightMaps[V], cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-126), all zero-initialised
+	#ifdef MV_EMULATE_LIGHT_PAIRS	// (timing experiment only, csrc/experiments/mv_march_tiles_r05.hip: room for 32-byte light cells; the images of such a build are garbage)
+	if ((rc = devAlloc(ctx, &st.lightBuffers, 2u * (size_t)st.V * st.lightBufs * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
+#else
 	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * st.lightBufs * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
+#endif
 	if ((rc = devAlloc(ctx, &ctx->lightStaging, L3 * sizeof(uint32_t), false)) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownDepth, (size_t)st.W * st.H * sizeof(float))) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownShadow, (size_t)st.M * st.M * sizeof(uint16_t))) != MV_OK) return bail(rc);

@@ -46,6 +46,18 @@ __device__ __forceinline__ float signf(float x) { return x > 0.0f ? 1.0f : (x < 
 __device__ __forceinline__ vec3 rayAt(vec3 o, vec3 d, float t) { return v3(t * d.x + o.x, t * d.y + o.y, t * d.z + o.z); }	// compiled as a multiplication and an addition (the build has -ffp-contract=off)
 __device__ __forceinline__ bool outsideBox(vec3 p) { return __builtin_fabsf(p.x) > 1.0f || __builtin_fabsf(p.y) > 1.0f || __builtin_fabsf(p.z) > 1.0f; }
 
+// A pointer every lane of the wavefront holds alike, moved to scalar registers: the compiler cannot prove that what a wave-uniform index
+// loaded is itself uniform, and keeps such a pointer in two vector registers through a loop.  (Uniform FLOATS the kernel would convert from
+// scalar integers -- (float)N and the like -- come as kernel arguments instead, DeviceState.fN ..: __builtin_amdgcn_readfirstlane is
+// folded away where the compiler can see the value is uniform, and the converted float then stays in a vector register all the same.)
+template <typename T>
+__device__ __forceinline__ T* uniformPtr(T* p)
+{
+	const uint64_t v = reinterpret_cast<uint64_t>(p);
+	const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+	return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 __device__ __forceinline__ uint32_t f2u_sat(float x)	// D3D ftou
 {
 	if (!(x > 0.0f)) return 0u;
@@ -159,20 +171,22 @@ __device__ __forceinline__ uint32_t pack_r11g11b10f(float r, float g, float b)	/
 // ---- sampler addressing: LINEAR + CLAMP on one axis ----
 struct Taps { int i0, i1; float f; };
 
-__device__ __forceinline__ Taps linearTaps(float coord01, uint32_t size, int off)
+// (fSize = (float)size, fSizeP1 = (float)size + 1: callers inside a loop hand them over from scalar registers: DeviceState.fN ..)
+__device__ __forceinline__ Taps linearTaps(float coord01, uint32_t size, int off, float fSize, float fSizeP1)
 {
-	const float c = coord01 * (float)size - 0.5f;
+	const float c = coord01 * fSize - 0.5f;
 	const float fl = __builtin_floorf(c);
 	Taps t;
 	t.f = c - fl;
 	// Clamp in float first (NaN -> -2) so the int conversion is always in range; after the integer clamp to
 	// [0, size-1] this equals a saturating floor-to-int for every finite coordinate (|off| <= 1).
-	const float flc = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), (float)size + 1.0f);
+	const float flc = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), fSizeP1);
 	const int i = (int)flc + off;
 	t.i0 = clampi(i, 0, (int)size - 1);
 	t.i1 = clampi(i + 1, 0, (int)size - 1);
 	return t;
 }
+__device__ __forceinline__ Taps linearTaps(float coord01, uint32_t size, int off) { return linearTaps(coord01, size, off, (float)size, (float)size + 1.0f); }
 
 // ---- volume texel storage -------------------------------------------------------------------
 // Volumes live in HBM as 4x4x4-texel bricks of RGBA16F (64 texels x 8 B = 512 B = four 128-B lines), bricks in
@@ -313,14 +327,16 @@ __device__ __forceinline__ u32x4 axisTableEntry(uint32_t axis, uint32_t j, uint3
 }
 
 // index of a coordinate's table entry and its filter weight (LINEAR sampler: c = u * size - 0.5)
-__device__ __forceinline__ uint32_t axisTableIndex(float coord01, uint32_t size, float& frac)
+// (fSize = (float)size, fSizeM1 = (float)size - 1)
+__device__ __forceinline__ uint32_t axisTableIndex(float coord01, float fSize, float fSizeM1, float& frac)
 {
-	const float c = coord01 * (float)size - 0.5f;
+	const float c = coord01 * fSize - 0.5f;
 	const float fl = __builtin_floorf(c);
 	frac = c - fl;
 	// float clamp first (NaN -> -1), so that the conversion is in range: floor + 1 in [0, size]
-	return (uint32_t)((int)__builtin_fminf(__builtin_fmaxf(fl, -1.0f), (float)size - 1.0f) + 1);
+	return (uint32_t)((int)__builtin_fminf(__builtin_fmaxf(fl, -1.0f), fSizeM1) + 1);
 }
+__device__ __forceinline__ uint32_t axisTableIndex(float coord01, uint32_t size, float& frac) { return axisTableIndex(coord01, (float)size, (float)size - 1.0f, frac); }
 
 // ---- brick occupancy ---------------------------------------------------------------------------
 // One bit per 4x4x4 brick: set when ANY texel of the brick or of its +1 halo (the texels a trilinear footprint whose first
@@ -539,9 +555,9 @@ __device__ __forceinline__ float resolveAlphaFromTexels(const ColourFootprint& f
 struct LightFootprint { u32x4 q0, q1; float cx, cy, fz; };
 
 // `pool` + `mapOff`: the light map starts mapOff bytes into a (wave-uniform) pool; mapOff may differ from lane to lane
-__device__ __forceinline__ LightFootprint fetchLightFootprintAt(GlobalBytes pool, uint32_t mapOff, uint32_t L, vec3 uvw)
+__device__ __forceinline__ LightFootprint fetchLightFootprintAt(GlobalBytes pool, uint32_t mapOff, uint32_t L, vec3 uvw, float fL, float fLp1)
 {
-	const Taps tx = linearTaps(uvw.x, L, 0), ty = linearTaps(uvw.y, L, 0), tz = linearTaps(uvw.z, L, 0);
+	const Taps tx = linearTaps(uvw.x, L, 0, fL, fLp1), ty = linearTaps(uvw.y, L, 0, fL, fLp1), tz = linearTaps(uvw.z, L, 0, fL, fLp1);
 	// 32-bit byte offsets and 24-bit multiplies: L <= 640 (mv_create), so L^2 * 16 < 2^24 and L^3 * 16 < 2^32
 	const uint32_t row = ((__umul24((uint32_t)ty.i0, L) + (uint32_t)tx.i0) << 4) + mapOff;
 	const uint32_t slice = (L * L) << 4;
@@ -552,9 +568,17 @@ __device__ __forceinline__ LightFootprint fetchLightFootprintAt(GlobalBytes pool
 	return f;
 }
 
+__device__ __forceinline__ LightFootprint fetchLightFootprintAt(GlobalBytes pool, uint32_t mapOff, uint32_t L, vec3 uvw)
+{
+	return fetchLightFootprintAt(pool, mapOff, L, uvw, (float)L, (float)L + 1.0f);
+}
 __device__ __forceinline__ LightFootprint fetchLightFootprint(const uint4* quads, uint32_t L, vec3 uvw)
 {
 	return fetchLightFootprintAt((GlobalBytes)quads, 0u, L, uvw);
+}
+__device__ __forceinline__ LightFootprint fetchLightFootprint(const uint4* quads, uint32_t L, vec3 uvw, float fL, float fLp1)
+{
+	return fetchLightFootprintAt((GlobalBytes)quads, 0u, L, uvw, fL, fLp1);
 }
 
 #ifndef MV_LIGHT_FMA_MIX

@@ -70,6 +70,8 @@ struct DeviceState
 	uint32_t maxRaySamples, maxLightSamples;
 	uint32_t hasLightProbe;
 	uint32_t lightBufs;				// light-map buffers per volume (see above)
+	float fN, fNm1, fL, fLp1;		// (float)N, N - 1, (float)L, L + 1: the samplers' constants, as kernel arguments so that they sit in scalar registers
+									// (a float the kernel converts from a scalar integer lives in a vector register through its loops)
 
 	// per-frame constants (device copies of the reference's upload-heap slices)
 	const void* cbPerFrame;			// CBPerFrame, 212 B
