@@ -1,4 +1,5 @@
-// experiments/mv_march_tiles_r05.hip -- the product kernel (csrc/mv_march_tiles.hip) with the round-5 experiments' switches, built INSTEAD of
+// experiments/mv_march_tiles_r05.hip -- the REGISTER-DIET form of the tile march (79 VGPRs = six wavefronts per SIMD: measured, not shipped) with
+// the round-5 experiments' switches, built INSTEAD of
 // it by csrc/build.sh when one of them is on its command line (measured, rejected: profiles/r05_instruction_cuts.txt):
 //   -DMV_EMPTY_REGIONS=1       advance through all-empty 16^3 regions with the bare `t += stepScale` (emptyRegionEnd below)
 //   -DMV_EMULATE_LIGHT_PAIRS   TIMING ONLY: the load and instruction stream of light cells kept as fp16 pairs (32-byte cells); images are garbage

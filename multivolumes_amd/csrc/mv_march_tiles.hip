@@ -175,38 +175,19 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	}
 
 	// ---- ray setup: a cube-face texel (CSRayMarch.hlsl:84-107) or a screen pixel of a RayCast volume (RayCast.hlsli:43-54)
-	// (register diet: the loop runs at the wavefronts per SIMD its registers allow -- 80 for six.  What the loop does not need is not carried
-	// through it: the output index is derived again at the stores, lit and fetch-free samples count in the two halves of one register
-	// (SmpCount is 16 bits: VolumeInfo), a ray is counted by `valid`)
-	uint32_t nSamples = 0, nLitSkipped = 0;
+	uint32_t nSamples = 0, nLit = 0, nRays = 0, nSkipped = 0;
 	bool valid = false;
 	vec3 rayOrigin = mul43(v3(cb->eyePos[0], cb->eyePos[1], cb->eyePos[2]), po.worldI);	// :89
 	vec3 rayDir = v3(0.0f, 0.0f, 1.0f);
 	float tMax = 0.0f;
+	size_t outIndex = 0;
+	float peerDepth = 0.0f;	// (PEER) what this lane stored into the cube depth
 	uint2 peerColour; peerColour.x = peerColour.y = 0u;
-	// where this lane's result goes: a texel of cubeMaps / cubeDepths, or of screenLayers
-	auto outIndexOf = [&]() -> size_t
-	{
-		if (!screenTile)
-		{
-			const uint32_t dims = st.N >> mipLevel;
-			const uint32_t tilesX = (dims + 7u) >> 3;
-			const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
-			return (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
-		}
-		const ushort4 rect = reinterpret_cast<const ushort4*>(st.volumeRects)[volumeId];
-		const uint32_t x1 = rect.z < st.W - 1u ? rect.z : st.W - 1u;
-		const ScreenTileRows rows = screenTileRowsT<IL>(st, rect.y, rect.w < st.H - 1u ? rect.w : st.H - 1u);
-		const uint32_t tx0 = rect.x >> 3, tw = (x1 >> 3) - tx0 + 1u;
-		const uint32_t px = (tx0 + localTile % tw) * 8u + (lane & 7u), py = (rows.first + (localTile / tw) * rows.step) * 8u + (lane >> 3);
-		return ((size_t)st.screenSlot[volumeId] * st.H + py) * st.W + px;
-	};
 	if (!screenTile)
 	{
 		const uint32_t dims = st.N >> mipLevel;
 		const uint32_t tilesX = (dims + 7u) >> 3;
 		const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
-		float peerDepth = 0.0f;	// (PEER) what this lane stored into the cube depth
 		if (px < dims && py < dims)
 		{
 			const vec3 target = GetLocalPos((float)px, (float)py, faceId, (float)dims);
@@ -214,7 +195,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			if (ComputeRayOrigin(rayOrigin, rayDir))	// :96
 			{
 				tMax = ComputeTargetHit(rayOrigin, target, rayDir);
-				const size_t outIndex = (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
+				outIndex = (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
 
 				// GetClipPos (:59-71)
 				vec3 clip;
@@ -234,27 +215,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				if constexpr (PEER) peerDepth = clip.z;
 				tMax = __builtin_fminf(GetTMax(clip, rayOrigin, rayDir, po.wvpI), tMax);	// :106
 				valid = true;
-			}
-		}
-		if constexpr (PEER)
-		{
-			// Peer-store transport: the cube depth this wavefront wrote (CSRayMarch.hlsl:105), into every other rank's cube depths -- here, in
-			// front of the march, which does not touch it: 16 bytes per store where four neighbouring lanes of a tile row hit (4 x 4 bytes),
-			// single words otherwise (narrower write-through stores are a fabric write each)
-			if (st.peerCount > 1u)	// (wave-uniform)
-			{
-				const size_t outIndex = outIndexOf();
-				const float d1 = __shfl_down(peerDepth, 1), d2 = __shfl_down(peerDepth, 2), d3 = __shfl_down(peerDepth, 3);
-				const unsigned long long hits = __ballot(valid);
-				const bool quad = !(lane & 3u) && ((hits >> lane) & 0xfull) == 0xfull && !(outIndex & 3u);
-				const bool inQuad = ((hits >> (lane & ~3u)) & 0xfull) == 0xfull && !((outIndex - (lane & 3u)) & 3u);
-				for (uint32_t p = 0; p < st.peerCount; ++p)
-				{
-					if (p == st.shardIndex) continue;
-					float* depths = st.peerCubeDepths[p];
-					if (quad) peerStore16(depths + outIndex, make_uint4(__float_as_uint(peerDepth), __float_as_uint(d1), __float_as_uint(d2), __float_as_uint(d3)));
-					else if (valid && !inQuad) peerStore(reinterpret_cast<uint32_t*>(depths + outIndex), __float_as_uint(peerDepth));
-				}
+				nRays = 1;
 			}
 		}
 	}
@@ -273,7 +234,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			nx = nx * 2.0f - 1.0f; ny = ny * 2.0f - 1.0f; ny = -ny;
 			vec3 lpt;
 			float z;
-			const size_t outIndex = ((size_t)st.screenSlot[volumeId] * st.H + py) * st.W + px;
+			outIndex = ((size_t)st.screenSlot[volumeId] * st.H + py) * st.W + px;
 			if (findExitFragment(po, rayOrigin, pixelRayWorld(cb, nx, ny), lpt, z))
 			{
 				rayDir = normalize3(lpt - rayOrigin);	// PSCube.hlsl:33, 50: normalize(input.LPt - localSpaceEyePt)
@@ -292,12 +253,9 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	if (valid)
 	{
 		{
-			// (what the whole wavefront shares goes to scalar registers by hand -- pointers a wave-uniform index loaded; float constants come as
-			// kernel arguments: the compiler kept fourteen such values in vector registers through the loop, which runs at the wavefronts its registers allow)
-			const float stepScale = st.volConsts[volumeId].stepScale;	// g_maxDist / SmpCount (:109), divided by the cull: a scalar load
-			const float fN = st.fN, fNm1 = st.fNm1, fL = st.fL, fLp1 = st.fLp1;
-			const VolumeView vol = makeVolumeView(uniformPtr(st.volumes[volTexId]), uniformPtr(st.alphaCells[volTexId]), st.N, st.bricks);
-			const uint4* lightQuads = uniformPtr(st.lightTable[volumeId]);
+			const float stepScale = kMaxDist / (float)smpCount;
+			const VolumeView vol = makeVolumeView(st.volumes[volTexId], st.alphaCells[volTexId], st.N, st.bricks);
+			const uint4* lightQuads = st.lightTable[volumeId];
 
 			vec4 scatter; scatter.x = scatter.y = scatter.z = scatter.w = 0.0f;
 			float t = 0.0f;
@@ -306,7 +264,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			// fetch the eight RGBA16F texels and the two light-map quads (issued together: one round trip).
 			bool prevLit = false;
 #if MV_OCCUPANCY
-			const GlobalBytes occupancy = (GlobalBytes)uniformPtr(st.occupancy[volTexId]);	// (scalar base + 32-bit offset: N <= 640 keeps the words below 2^20)
+			const uint64_t* occupancy = st.occupancy[volTexId];
 			const uint32_t regions = occupancyRegions(st.bricks);
 			uint32_t occIndex = 0xffffffffu;
 			uint64_t occWord = 0;
@@ -321,9 +279,9 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				uint32_t occSum = 0u;
 				if (LUT)
 				{
-					const u32x4 ex = sAxis[axisTableIndex(uvw.x, fN, fNm1, fa.fx)];
-					const u32x4 ey = sAxis[(kLutMaxN + 1u) + axisTableIndex(uvw.y, fN, fNm1, fa.fy)];
-					const u32x4 ez = sAxis[2u * (kLutMaxN + 1u) + axisTableIndex(uvw.z, fN, fNm1, fa.fz)];
+					const u32x4 ex = sAxis[axisTableIndex(uvw.x, vol.N, fa.fx)];
+					const u32x4 ey = sAxis[(kLutMaxN + 1u) + axisTableIndex(uvw.y, vol.N, fa.fy)];
+					const u32x4 ez = sAxis[2u * (kLutMaxN + 1u) + axisTableIndex(uvw.z, vol.N, fa.fz)];
 					fa.x0 = ex.x; fa.x1 = ex.y;
 					fa.r00 = ey.x + ez.x; fa.r10 = ey.y + ez.x; fa.r01 = ey.x + ez.y; fa.r11 = ey.y + ez.y;
 					occSum = ex.z + ey.z + ez.z;
@@ -336,11 +294,11 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				// ray enters another one; requesting the next region's word ahead of time was measured slower (0.289 ms).
 				{
 					const uint32_t w = LUT ? occSum & 0xffffffu : occupancyWord(fa.ix, fa.iy, fa.iz, regions);
-					if (w != occIndex) { occWord = *(GlobalUint64)(occupancy + (w << 3)); occIndex = w; }
+					if (w != occIndex) { occWord = occupancy[w]; occIndex = w; }
 					if (!((occWord >> (LUT ? occSum >> 24 : occupancyBit(fa.ix, fa.iy, fa.iz))) & 1ull))
 					{
 						++nSamples;
-						nLitSkipped += 0x10000u;
+						++nSkipped;
 						prevLit = false;
 						t += stepScale;
 						if (t > tMax) break;	// :152
@@ -352,7 +310,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				ColourFootprint cf = fetchColour(vol, fa);
 				LightFootprint lf;
 				const bool early = MV_PREDICT_LIT && prevLit;
-				if (early) lf = fetchLightFootprint(lightQuads, st.L, uvw, fL, fLp1);
+				if (early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
 				const float alpha = resolveAlphaFromTexels(cf);
 				++nSamples;
 				float newStep = stepScale;
@@ -360,10 +318,10 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 				prevLit = lit;
 				if (lit)
 				{
-					if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw, fL, fLp1);
+					if (!early) lf = fetchLightFootprint(lightQuads, st.L, uvw);
 					const vec3 light = resolveLight(lf);
 					vec3 color = resolveRGB(cf);
-					++nLitSkipped;
+					++nLit;
 
 					const float transm = 1.0f - scatter.w;
 					const float dDensity = alpha - prevDensity;
@@ -386,7 +344,6 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 
 			scatter.x *= kInvTwoPi; scatter.y *= kInvTwoPi; scatter.z *= kInvTwoPi;	// :155
 
-			const size_t outIndex = outIndexOf();
 			if (!screenTile)
 			{
 				uint2 o;
@@ -405,28 +362,35 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 
 	if constexpr (PEER)
 	{
-		// Peer-store transport: the texel this wavefront wrote into its own cube map (CSRayMarch.hlsl:157), into every other rank's, 16 bytes
-		// per store where neighbouring lanes allow it: a tile row is 8 lanes = 8 texels in a row of the face, so an even lane takes its right
-		// neighbour's colour along (2 x 8 bytes); narrower write-through stores are a fabric write each.  (The depths went out in front of the march.)
+		// Peer-store transport: what this wavefront wrote into its own cube map and cube depth, into every other rank's -- the texels of
+		// rays that hit, as the reference writes them (CSRayMarch.hlsl:105, 157), 16 bytes per store where neighbouring lanes allow it: a
+		// tile row is 8 lanes = 8 texels in a row of the face, so an even lane takes its right neighbour's colour along (2 x 8 bytes) and
+		// every fourth lane its three neighbours' depths (4 x 4 bytes); narrower write-through stores are a fabric write each.
 		if (!screenTile && st.peerCount > 1u)	// (wave-uniform)
 		{
-			const size_t outIndex = outIndexOf();
 			const bool have = valid;
 			const uint2 right = make_uint2(__shfl_down(peerColour.x, 1), __shfl_down(peerColour.y, 1));
 			const bool haveRight = __shfl_down(have ? 1 : 0, 1) != 0, haveLeft = __shfl_up(have ? 1 : 0, 1) != 0;
 			const bool even = !(lane & 1u);
 			const bool pair = even && have && haveRight && !(outIndex & 1u);	// (16-byte aligned: faces start at even texels whenever their edge is even)
 			const bool single = have && !pair && !(!even && haveLeft && !((outIndex - 1u) & 1u));	// (an odd lane whose left neighbour took it along stores nothing)
+			float d1 = __shfl_down(peerDepth, 1), d2 = __shfl_down(peerDepth, 2), d3 = __shfl_down(peerDepth, 3);
+			const unsigned long long hits = __ballot(have);
+			const bool quad = !(lane & 3u) && ((hits >> lane) & 0xfull) == 0xfull && !(outIndex & 3u);
+			const bool inQuad = ((hits >> (lane & ~3u)) & 0xfull) == 0xfull && !((outIndex - (lane & 3u)) & 3u);
 			for (uint32_t p = 0; p < st.peerCount; ++p)
 			{
 				if (p == st.shardIndex) continue;
 				uint2* colours = st.peerCubeMaps[p];
+				float* depths = st.peerCubeDepths[p];
 				if (pair) peerStore16(colours + outIndex, make_uint4(peerColour.x, peerColour.y, right.x, right.y));
 				else if (single) peerStore8(colours + outIndex, peerColour);
+				if (quad) peerStore16(depths + outIndex, make_uint4(__float_as_uint(peerDepth), __float_as_uint(d1), __float_as_uint(d2), __float_as_uint(d3)));
+				else if (have && !inQuad) peerStore(reinterpret_cast<uint32_t*>(depths + outIndex), __float_as_uint(peerDepth));
 			}
 		}
 	}
-	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLitSkipped & 0xffffu), totR = (uint32_t)__popcll(__ballot(valid && !screenTile)), totK = waveSumU32(nLitSkipped >> 16);
+	const uint32_t totS = waveSumU32(nSamples), totL = waveSumU32(nLit), totR = waveSumU32(nRays), totK = waveSumU32(nSkipped);
 	uint32_t maxS = nSamples;
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
