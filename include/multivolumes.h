@@ -354,9 +354,20 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * (profiles/r04_frames_per_launch.txt).  Results are identical. */
 #define MV_DIST_PEER_DEAL_VOLUMES 16u
 #define MV_DIST_PEER_DEAL_TILES 32u
+/* A folded wait ends with a system-scope ACQUIRE by the wavefront that polled (`buffer_inv sc0 sc1`: invalidate, no write-back) in front of
+ * the workgroup's plain loads of what the flags announce -- the default.  MV_DIST_PEER_NO_ACQUIRE leaves it out (round 4's form: it rested
+ * on the rotation of the buffers alone), for A/B timing. */
+#define MV_DIST_PEER_NO_ACQUIRE 64u
 int mv_dist_peer_export(mv_ctx* ctx, void* out /* MV_DIST_PEER_BYTES */);
 int mv_dist_init_peer(mv_ctx* ctx, const void* all /* shard_count x MV_DIST_PEER_BYTES in rank order; NULL with MV_DIST_PEER_LOOPBACK */, uint32_t flags);
 int mv_dist_set_peer_timeout_ms(mv_ctx* ctx, uint32_t ms);
+/* The in-kernel coherence test by itself (collective: every rank calls it, after mv_dist_init_peer): ONE launch per rank reads every
+ * rank's region of a buffer, waits INSIDE the kernel until every rank has, overwrites its region of every rank's buffer, waits inside the
+ * kernel for everybody's stores, ends that wait with an acquire (acquire != 0) or not, and reads again with plain loads.
+ * stale_words: words of the second read that still showed the old pattern (0 = what the folded waits need); first_read_bad: words of
+ * the first read that did not show the old pattern (0 unless the mappings themselves are broken).  mv_dist_selftest runs it, with the
+ * context's acquire setting, whenever the waits are folded, and fails on a stale word. */
+int mv_dist_peer_coherence(mv_ctx* ctx, uint32_t acquire, uint32_t* stale_words, uint32_t* first_read_bad);
 /* Every frame the loop checks, through four words behind each rank's share of the light exchange, that all ranks' replicated culls
  * decided the same (a caller that passed different frame constants on different ranks gets MV_ERR_INVALID_ARG instead of mismatched
  * collectives).  On by default.  Off is for a rank driven ALONE with collectives that deliver nothing (examples/dist_rank_cost.cpp,

@@ -39,6 +39,7 @@ MV_DIST_PEER_NO_FOLD = 4
 MV_DIST_PEER_ROWS_TO_ROOT = 8
 MV_DIST_PEER_DEAL_VOLUMES = 16
 MV_DIST_PEER_DEAL_TILES = 32
+MV_DIST_PEER_NO_ACQUIRE = 64
 MV_ABI_VERSION = 5  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
@@ -124,6 +125,7 @@ ABI = {
     "mv_dist_peer_export": (C.c_int, [_P, _P]),
     "mv_dist_init_peer": (C.c_int, [_P, _P, _U32]),
     "mv_dist_set_peer_timeout_ms": (C.c_int, [_P, _U32]),
+    "mv_dist_peer_coherence": (C.c_int, [_P, _U32, C.POINTER(_U32), C.POINTER(_U32)]),
     "mv_dist_selftest": (C.c_int, [_P]),
     "mv_dist_shutdown": (C.c_int, [_P]),
     "mv_dist_set_inplace_gather": (C.c_int, [_P, C.c_int]),

@@ -150,6 +150,8 @@ struct DistState
 	bool peerDealVolumes = false;				// whole cube-map volumes per rank (dealt by cost: the default with one frame per launch) instead of every volume's tiles shared out
 	bool peerRowsRoot = false;					// MV_DIST_PEER_ROWS_TO_ROOT: the ranks push their rows to rank 0 only
 	bool peerFold = false;						// the waits are the consumers' own prologues (mv_kernels.hpp peerFoldWait) instead of one-wavefront kernels in front of them
+	bool peerAcquire = true;					// a folded wait ends with a system-scope acquire by the wavefront that polled (mv_kernels.hpp peerFoldAcquire); false: MV_DIST_PEER_NO_ACQUIRE, round 4's form
+	uint32_t peerStaleWords = 0, peerFirstReadBad = 0;	// what the last in-kernel coherence test saw (mv_dist_peer_coherence)
 	uint32_t* dPeerCounters = nullptr;			// finished-workgroup counters of the push kernels: [kind][chain]
 	uint32_t* dPeerMismatch = nullptr;			// self-test counter
 	// several frames per launch (mv_dist_batch: ctx->framesPerLaunch > 1): the frames of the group being collected (their upload, cull and orders

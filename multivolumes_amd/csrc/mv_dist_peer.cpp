@@ -63,6 +63,7 @@ void foldBase(mv_ctx* ctx, DeviceState& st, uint32_t kind, uint64_t frame, uint3
 	st.fold.report = d->reports + (size_t)slot * 8u;
 	st.fold.timeoutTicks = d->peerTimeoutTicks;
 	st.fold.loopback = d->peerLoopback ? 1u : 0u; st.fold.frameTag = frameTag; st.fold.checkChain = 0xffffffffu;
+	st.fold.acquire = d->peerAcquire ? 1u : 0u;
 }
 void foldWait(mv_ctx* ctx, DeviceState& st, int stage, uint64_t frame)
 {
@@ -183,7 +184,21 @@ int peerBeforeView(mv_ctx* ctx)
 	DistState* d = ctx->dist;
 	if (ctx->st.shardCount <= 1u) return MV_OK;
 	PeerWaits w;
-	for (uint32_t j = 0; j < d->numChains; ++j) if (d->peerFrame > j) { w.stage[w.n] = kStageLight; w.frame[w.n++] = d->peerFrame - j; }
+	if (d->peerFold)
+	{
+		// Folded: only THIS frame's row is waited for inside the march (by the wavefronts whose tile reads the map relit in this frame; its own
+		// rank's column is raised by the push workgroups of this very launch, dispatched in front of them).  The rows of the C - 1 frames before
+		// it -- on the other streams -- are waited for by a kernel of one wavefront in front of the launch, as batchClose does: their columns
+		// include THIS rank's, raised by the push workgroups of launches on other streams, which a march whose every workgroup spins in its
+		// prologue could keep from ever being dispatched (round 4's form) -- and every spinning workgroup would end its wait with
+		// an invalidate of its CU's L1 (profiles/r05_peer_acquire.txt).
+		mv::PeerSync a = peerSyncBase(ctx, ctx->st.frameTag, ctx->slot);
+		for (uint32_t j = 1; j < d->numChains; ++j) if (d->peerFrame > j) { a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + (uint32_t)((d->peerFrame - j) % d->numChains); a.waitValue[a.nWait++] = d->peerFrame - j; }
+		if (a.nWait) { mv::launchPeerSync(streamB(ctx), a); MV_HIP(ctx, hipGetLastError()); }
+		w.stage[w.n] = kStageLight; w.frame[w.n++] = d->peerFrame;
+	}
+	else
+		for (uint32_t j = 0; j < d->numChains; ++j) if (d->peerFrame > j) { w.stage[w.n] = kStageLight; w.frame[w.n++] = d->peerFrame - j; }
 	const int rc = peerWaitFor(ctx, streamB(ctx), ctx->st, kFoldView, w, d->peerFrame, ctx->st.frameTag, ctx->slot, true);
 	if (rc != MV_OK) return rc;
 	// ...and what the march's last workgroup raises, behind the texels it stored into every rank's cube maps
@@ -224,6 +239,8 @@ int mvi::distBeforeSync(mv_ctx* ctx)
 	return MV_OK;
 }
 
+int peerCoherenceTest(mv_ctx* ctx, bool acquire, uint32_t* stale, uint32_t* firstReadBad);
+
 // Self-test of the mappings and of the flags, twice with different patterns (a stale cached line would show the first pattern in the
 // second round): every rank writes its pattern into its region of every rank's frame buffer (output set 0), raises a flag, waits for
 // everybody's, verifies all regions of its own buffer, and only then -- a second flag -- lets anybody overwrite them.
@@ -257,10 +274,88 @@ int peerSelfTest(mv_ctx* ctx)
 	MV_HIP(ctx, hipStreamSynchronize(s));
 	{ const int rc = peerCheckReports(ctx); if (rc != MV_OK) return rc; }
 	MV_REQUIRE(ctx, bad == 0, MV_ERR_HIP, "peer-store self-test: a rank's pattern did not arrive (or arrived stale) in this rank's buffer");
+	// ... and what the FOLDED waits rest on: other ranks' stores seen by plain loads behind a wait INSIDE a running kernel, of lines that
+	// kernel has read before (the self-test above only crosses kernel boundaries)
+	if (d->peerFold)
+	{
+		uint32_t stale = 0, first = 0;
+		const int rc = peerCoherenceTest(ctx, d->peerAcquire, &stale, &first);
+		if (rc != MV_OK) return rc;
+		MV_REQUIRE(ctx, first == 0, MV_ERR_HIP, "peer-store self-test: the in-kernel test's first read did not find the pattern the kernel-boundary test had verified");
+		if (stale)
+		{
+			char msg[256];
+			snprintf(msg, sizeof(msg), "peer-store self-test: %u words were STALE behind a wait inside a running kernel (folded waits%s): use MV_DIST_PEER_NO_FOLD (waits as kernels of their own)",
+				stale, d->peerAcquire ? ", acquire on" : ", MV_DIST_PEER_NO_ACQUIRE");
+			return fail(ctx, MV_ERR_HIP, msg);
+		}
+	}
+	return MV_OK;
+}
+
+// The in-kernel coherence test (mv_peer.hip peerCoherenceKernel; collective: every rank calls it): behind the pattern rounds above, whose
+// second pattern the frame buffers of output set 0 still hold.  acquire: end the in-kernel wait as the folded waits do.
+int peerCoherenceTest(mv_ctx* ctx, bool acquire, uint32_t* stale, uint32_t* firstReadBad)
+{
+	DistState* d = ctx->dist;
+	const uint32_t world = ctx->st.shardCount, rank = ctx->st.shardIndex;
+	*stale = 0; *firstReadBad = 0;
+	if (d->peerLoopback || world <= 1u) return MV_OK;	// (a rank alone has nobody to be incoherent with)
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	hipStream_t s = ctx->streamB[0];
+	const size_t words = std::min<size_t>(65536, (size_t)ctx->st.W * compositeRows(ctx->st) / world);
+	const uint32_t row = 4u * mv::kPeerMaxChains;
+	// (everybody is past whatever it did to its buffer before -- the clearing at the end of the test in front of this one)
+	{
+		const unsigned long long b0 = 2ull * (d->peerSelfTests++);
+		mv::PeerSync a = peerSyncBase(ctx, 0u, 0u);
+		a.nSignal = 1; a.signalRow[0] = row; a.signalValue[0] = b0 + 1u; a.nWait = 1; a.waitRow[0] = row; a.waitValue[0] = b0 + 1u;
+		mv::launchPeerSync(s, a);
+	}
+	// the old pattern, through the kernel-boundary path the rounds of peerSelfTest have verified
+	{
+		const unsigned long long base = 2ull * (d->peerSelfTests++);
+		mv::launchPeerPattern(s, d->dPeerComposite[0], world, rank, words, 31u);
+		mv::PeerSync a = peerSyncBase(ctx, 0u, 0u);
+		a.nSignal = 1; a.signalRow[0] = row; a.signalValue[0] = base + 1u; a.nWait = 1; a.waitRow[0] = row; a.waitValue[0] = base + 1u;
+		mv::launchPeerSync(s, a);
+	}
+	MV_HIP(ctx, hipMemsetAsync(d->dPeerMismatch, 0, 64, s));
+	mv::PeerCoherence c;
+	memset(&c, 0, sizeof(c));
+	const unsigned long long base = 2ull * (d->peerSelfTests++);
+	c.table = d->dPeerComposite[0]; c.mine = ctx->ob[0].composite; c.peerFlags = d->dPeerFlags; c.myFlags = d->peerFlags;
+	c.world = world; c.self = rank; c.row = row; c.acquire = acquire ? 1u : 0u; c.wordsPerRank = words; c.saltOld = 31u; c.saltNew = 32u;
+	c.valueRead = base + 1u; c.valueWritten = base + 2u;
+	c.counters = d->dPeerMismatch + 4; c.mismatches = d->dPeerMismatch;
+	c.timeoutTicks = d->peerTimeoutTicks; c.report = d->reports;
+	mv::launchPeerCoherence(s, c);
+	MV_HIP(ctx, hipGetLastError());
+	uint32_t out[2] = { 0, 0 };
+	MV_HIP(ctx, hipMemcpyAsync(out, d->dPeerMismatch, 8, hipMemcpyDeviceToHost, s));
+	// nobody may overwrite the regions before everybody has verified them: one more round of the flag
+	{
+		const unsigned long long b2 = 2ull * (d->peerSelfTests++);
+		mv::PeerSync a = peerSyncBase(ctx, 0u, 0u);
+		a.nSignal = 1; a.signalRow[0] = row; a.signalValue[0] = b2 + 1u; a.nWait = 1; a.waitRow[0] = row; a.waitValue[0] = b2 + 1u;
+		mv::launchPeerSync(s, a);
+	}
+	MV_HIP(ctx, hipMemsetAsync(ctx->ob[0].composite, 0, (size_t)ctx->st.W * compositeRows(ctx->st) * sizeof(uint2), s));
+	MV_HIP(ctx, hipStreamSynchronize(s));
+	{ const int rc = peerCheckReports(ctx); if (rc != MV_OK) return rc; }
+	*stale = out[0]; *firstReadBad = out[1];
+	d->peerStaleWords = out[0]; d->peerFirstReadBad = out[1];
 	return MV_OK;
 }
 
 extern "C" {
+
+int mv_dist_peer_coherence(mv_ctx* ctx, uint32_t acquire, uint32_t* stale_words, uint32_t* first_read_bad)
+{
+	if (!ctx || !stale_words || !first_read_bad) return MV_ERR_INVALID_ARG;
+	MV_REQUIRE(ctx, ctx->dist && ctx->dist->transport == 3 && ctx->dist->peerReady, MV_ERR_NOT_READY, "mv_dist_init_peer has not been called");
+	return peerCoherenceTest(ctx, acquire != 0u, stale_words, first_read_bad);
+}
 
 int mv_dist_peer_export(mv_ctx* ctx, void* out)
 {
@@ -410,7 +505,8 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 	}
 	d->peerLoopback = loopback;
 	// Folded flags (raised / waited for inside the marches and the composite: three kernels of a rank's chain instead of eight) are for
-	// ranks that own their GPU: a consumer's workgroups then spin on flags only OTHER GPUs raise.  Ranks that share a GPU (tests) keep the
+	// ranks that own their GPU: a consumer's workgroups then spin on flags only OTHER GPUs raise -- or, the view march's own row, workgroups
+	// of the same launch dispatched in front of them (peerBeforeView).  Ranks that share a GPU (tests) keep the
 	// flag kernels -- one wavefront each -- so that spinning consumers can never crowd the producers they wait for out of the GPU.
 	d->peerFold = (flags & MV_DIST_PEER_FOLD) ? true : (flags & MV_DIST_PEER_NO_FOLD) ? false : (loopback || distinctDevices);
 	if (ctx->framesPerLaunch > 1u)
@@ -419,6 +515,7 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 		if (flags & MV_DIST_PEER_NO_FOLD) return bail(fail(ctx, MV_ERR_INVALID_ARG, "MV_DIST_PEER_NO_FOLD with mv_config.frames_per_launch > 1"));
 		d->peerFold = true;
 	}
+	d->peerAcquire = !(flags & MV_DIST_PEER_NO_ACQUIRE);
 	d->peerRowsRoot = (flags & MV_DIST_PEER_ROWS_TO_ROOT) != 0;
 	d->peerDealVolumes = (flags & MV_DIST_PEER_DEAL_VOLUMES) ? true : (flags & MV_DIST_PEER_DEAL_TILES) ? false : ctx->framesPerLaunch == 1u;	// (see the header: tiles pay with several frames per launch)
 	d->peerFrame = 0;

@@ -175,7 +175,8 @@ struct DeviceState
 		uint32_t checkChain, checkCompare;		// checkChain: 0xffffffff, or the chain whose slot of cull words this launch raises with (a producer) or, checkCompare != 0, compares every rank's behind its wait (a consumer) -- mv_peer.hip
 		// (view march, folded) the leading pushBlocks workgroups of the launch do not march: they push this rank's light layers (peerPushLightRole)
 		// and the last of them raises pushRow to pushValue in every rank's block, with this rank's cull words (chain pushCheckChain)
-		uint32_t pushBlocks, pushRow, pushCheckChain, pad;
+		uint32_t pushBlocks, pushRow, pushCheckChain;
+		uint32_t acquire;						// a wait that saw its flags ends with a system-scope acquire (buffer_inv sc0 sc1) by the polling wavefront: peerFoldAcquire
 		unsigned long long pushValue;
 		uint32_t* pushCounter;
 		const uint32_t* checkInfo;				// NULL, or the batchInfo of the launch's last frame: the cull words of all its frames (several frames per launch)
@@ -217,12 +218,18 @@ constexpr size_t kPeerFlagWords = (size_t)kPeerRows * kPeerMaxRanks;	// uint64 e
 constexpr size_t kPeerFlagBytes = kPeerFlagWords * 8u + (size_t)kPeerMaxChains * kPeerMaxRanks * kPeerCheckWords * 4u;
 
 // Prologue of a consumer (every thread of the workgroup calls it, before any early exit): the first wavefront polls, the workgroup waits for it.
-// No cache maintenance here, on purpose: thousands of workgroups each invalidating or writing back an L2 cost a launch three times its
-// length (measured, profiles/r04_peer_fold.txt).  The polls are system-scope loads (sc0 sc1: they bypass this GPU's caches); the data
-// they announce was written through, by kernels of other GPUs, into THIS GPU's memory, whose L2 the fabric keeps coherent with such
-// writes (the same property every collective library's "peer writes, local kernel reads" path rests on); the workgroup's own loads of
-// it are issued behind the barrier below, i.e. behind the poll that saw the flag, and this launch has not read those addresses before
-// (every buffer a frame's peers write was last read C frames ago: the output sets and light buffers rotate).
+// The polls are relaxed system-scope loads (sc0 sc1: they bypass this GPU's caches).  What they announce was written through, by kernels of
+// other GPUs, into THIS GPU's memory; the wavefront that saw the flags then makes the ACQUIRE the memory model asks for between another
+// agent's release and this agent's plain loads -- peerFoldAcquire: `buffer_inv sc0 sc1`, invalidate only, no write-back -- and the
+// workgroup's own loads of the data are issued behind the barrier below, i.e. behind that invalidate.  (Round 4 had no invalidate here and
+// rested on "this launch has not read those addresses before, the buffers rotate"; that still holds and is why the invalidate finds
+// little to drop -- but a stale line would have corrupted a frame silently, and the only evidence against one was a GPU with itself.
+// What was measured three times a launch's length in round 4 were per-workgroup WRITE-BACKS (buffer_wbl2); the invalidate alone costs
+// the launch of a rank profiles/r05_peer_acquire.txt's figure.  fold.acquire = 0, MV_DIST_PEER_NO_ACQUIRE, is round 4's form, for A/B.)
+__device__ __forceinline__ void peerFoldAcquire(const DeviceState& st)
+{
+	if (st.fold.acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");	// system scope: s_waitcnt vmcnt(0); buffer_inv sc0 sc1
+}
 // (firstRow / endRow: the rows of fold.waitRow to wait for -- the view march waits for its newest row only in the workgroups that read
 // the light map that row announces)
 __device__ __forceinline__ void peerFoldWait(const DeviceState& st, uint32_t firstRow = 0u, uint32_t endRow = 0xffffffffu)
@@ -247,6 +254,8 @@ __device__ __forceinline__ void peerFoldWait(const DeviceState& st, uint32_t fir
 				__builtin_amdgcn_s_sleep(8);
 			}
 		}
+		peerFoldAcquire(st);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// (the invalidate completes asynchronously: the barrier below must not open before it has)
 	}
 	__syncthreads();
 	if (st.fold.checkCompare && st.fold.checkChain != 0xffffffffu && firstRow == 0u && blockIdx.x == 0u && threadIdx.x < 64u)	// (one workgroup compares, behind the wait for the row the words came with)
@@ -296,6 +305,8 @@ __device__ __forceinline__ void peerFoldWaitWave(const DeviceState& st, uint32_t
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	__builtin_amdgcn_wave_barrier();	// (the wavefront's loads of what the flags announce are issued behind every lane's poll)
+	peerFoldAcquire(st);
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	if (compare && st.fold.checkCompare && st.fold.checkChain != 0xffffffffu)
 	{
 		const uint32_t* all = reinterpret_cast<const uint32_t*>(st.fold.myFlags + kPeerFlagWords) + (size_t)st.fold.checkChain * kPeerMaxRanks * kPeerCheckWords;
@@ -609,4 +620,24 @@ void launchPeerPushLight(hipStream_t s, const DeviceState& st);	// this rank's l
 void launchPeerPushRows(hipStream_t s, const DeviceState& st);		// this rank's block of the rank-major frame buffer
 void launchPeerPattern(hipStream_t s, uint2* const* table, uint32_t world, uint32_t self, size_t wordsPerRank, uint32_t salt);	// self-test: a pattern into every rank's buffer at this rank's region
 void launchPeerVerify(hipStream_t s, const uint2* mine, uint32_t world, size_t wordsPerRank, uint32_t salt, uint32_t* mismatches);
+// The self-test of what the folded waits rest on, in ONE launch per rank (mv_peer.hip peerCoherenceKernel): read every rank's region of
+// this rank's buffer (the lines are in this GPU's caches now), tell everybody, wait INSIDE the kernel until everybody has read, overwrite
+// this rank's region of every rank's buffer with a new pattern, raise, wait inside the kernel for everybody's, acquire as the folded
+// waits do, read again with plain loads: a word of the old pattern is a stale line.
+struct PeerCoherence
+{
+	uint2* const* table;					// [world] every rank's buffer
+	uint2* mine;
+	unsigned long long* const* peerFlags;	// [world]
+	unsigned long long* myFlags;
+	uint32_t world, self, row, acquire;
+	size_t wordsPerRank;
+	uint32_t saltOld, saltNew;
+	unsigned long long valueRead, valueWritten;	// the flag row's values: "this rank has read", "this rank has written"
+	uint32_t* counters;						// 2, zero
+	uint32_t* mismatches;					// [0] += words of the second read that are not the new pattern, [1] += words of the FIRST read that are not the old one
+	unsigned long long timeoutTicks;
+	unsigned long long* report;
+};
+void launchPeerCoherence(hipStream_t s, const PeerCoherence& a);
 } // namespace mv

@@ -152,6 +152,77 @@ __global__ __launch_bounds__(256) void peerVerifyKernel(const uint2* mine, uint3
 	if (bad) atomicAdd(mismatches, bad);
 }
 
+// ---- in-kernel coherence self-test (mv_kernels.hpp PeerCoherence) ----
+// What a folded wait does -- poll inside the kernel, acquire, read with plain loads -- under the worst case for it: every line it then reads
+// was read by this very launch before the other ranks overwrote it.  64 workgroups, all resident; a thread reads the same words both times.
+__device__ __forceinline__ void coherenceRaise(const PeerCoherence& a, uint32_t* counter, unsigned long long value)
+{
+	__shared__ uint32_t sLast;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (threadIdx.x == 0u) sLast = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u ? 1u : 0u;
+	__syncthreads();
+	if (sLast && threadIdx.x < 64u)
+		for (uint32_t p = threadIdx.x; p < a.world; p += 64u)
+			__hip_atomic_store(a.peerFlags[p] + (size_t)a.row * kPeerMaxRanks + a.self, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void coherenceWait(const PeerCoherence& a, unsigned long long value, bool acquire)
+{
+	if (threadIdx.x < 64u)
+	{
+		const unsigned long long t0 = wall_clock64();
+		for (uint32_t p = threadIdx.x; p < a.world; p += 64u)
+		{
+			const unsigned long long* flag = a.myFlags + (size_t)a.row * kPeerMaxRanks + p;
+			while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < value)
+			{
+				if (wall_clock64() - t0 > a.timeoutTicks)
+				{
+					__hip_atomic_store(a.report + 2, ((unsigned long long)a.row << 8) | p | 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					break;
+				}
+				__builtin_amdgcn_s_sleep(8);
+			}
+		}
+		if (acquire) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	__syncthreads();
+}
+__global__ __launch_bounds__(256) void peerCoherenceKernel(PeerCoherence a)
+{
+	const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)gridDim.x * blockDim.x, total = a.wordsPerRank * a.world;
+	// 1. the first read: the old pattern, into this CU's L1 and this XCD's L2
+	uint32_t badOld = 0;
+	for (size_t i = t; i < total; i += n)
+	{
+		const uint2 v = a.mine[i], e = peerPatternWord((uint32_t)(i / a.wordsPerRank), i % a.wordsPerRank, a.saltOld);
+		badOld += v.x != e.x || v.y != e.y;
+	}
+	if (badOld) atomicAdd(a.mismatches + 1, badOld);
+	coherenceRaise(a, a.counters + 0, a.valueRead);
+	coherenceWait(a, a.valueRead, false);	// everybody has read: nobody's first read can see the new pattern
+	// 2. this rank's region of every rank's buffer: the new pattern (its own copy with plain stores, the others' written through)
+	for (size_t i = t; i < a.wordsPerRank; i += n)
+	{
+		const uint2 v = peerPatternWord(a.self, i, a.saltNew);
+		for (uint32_t p = 0; p < a.world; ++p)
+			if (p == a.self) a.table[p][(size_t)a.self * a.wordsPerRank + i] = v;
+			else peerStore8(&a.table[p][(size_t)a.self * a.wordsPerRank + i], v);
+	}
+	coherenceRaise(a, a.counters + 1, a.valueWritten);
+	// 3. the folded wait, and the second read
+	coherenceWait(a, a.valueWritten, a.acquire != 0u);
+	uint32_t bad = 0;
+	for (size_t i = t; i < total; i += n)
+	{
+		const uint2 v = a.mine[i], e = peerPatternWord((uint32_t)(i / a.wordsPerRank), i % a.wordsPerRank, a.saltNew);
+		bad += v.x != e.x || v.y != e.y;
+	}
+	if (bad) atomicAdd(a.mismatches + 0, bad);
+}
+void launchPeerCoherence(hipStream_t s, const PeerCoherence& a) { hipLaunchKernelGGL(peerCoherenceKernel, dim3(64), dim3(256), 0, s, a); }
+
 void launchPeerPattern(hipStream_t s, uint2* const* table, uint32_t world, uint32_t self, size_t wordsPerRank, uint32_t salt)
 {
 	hipLaunchKernelGGL(peerPatternKernel, dim3(64), dim3(256), 0, s, table, world, self, wordsPerRank, salt);

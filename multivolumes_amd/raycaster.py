@@ -473,7 +473,7 @@ class MultiRayCaster:
         self._check(self._lib.mv_dist_peer_export(self._ctx, buf), "mv_dist_peer_export")
         return bytes(buf)
 
-    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False, deal_volumes=None):
+    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False, deal_volumes=None, acquire=True):
         """Attach the frame loop with the peer-store transport: every rank's kernels store into every rank's buffers (no collectives).
         loopback: a rank measured alone (every peer is the context itself).  fold: True / False force the flags into / out of the
         marches and the composite (None: the library decides -- folded when every rank owns its GPU)."""
@@ -482,11 +482,20 @@ class MultiRayCaster:
             flags |= _lib.MV_DIST_PEER_ROWS_TO_ROOT
         if deal_volumes is not None:  # whole cube-map volumes per rank, dealt by cost / every volume's tiles shared out (None: the library's choice -- volumes with one frame per launch, tiles with several)
             flags |= _lib.MV_DIST_PEER_DEAL_VOLUMES if deal_volumes else _lib.MV_DIST_PEER_DEAL_TILES
+        if not acquire:  # round 4's folded waits: no invalidate behind the poll (A/B timing)
+            flags |= _lib.MV_DIST_PEER_NO_ACQUIRE
         if loopback:
             self._check(self._lib.mv_dist_init_peer(self._ctx, None, _lib.MV_DIST_PEER_LOOPBACK | flags), "mv_dist_init_peer")
             return
         buf = (C.c_uint8 * len(all_blobs)).from_buffer_copy(all_blobs)
         self._check(self._lib.mv_dist_init_peer(self._ctx, buf, flags), "mv_dist_init_peer")
+
+    def DistPeerCoherence(self, acquire=True):
+        """The in-kernel coherence test of the peer-store transport (collective: every rank calls it): (stale words behind a wait inside a
+        running kernel, words the first read got wrong).  (0, 0) is what the folded waits need."""
+        stale, first = C.c_uint32(0), C.c_uint32(0)
+        self._check(self._lib.mv_dist_peer_coherence(self._ctx, 1 if acquire else 0, C.byref(stale), C.byref(first)), "mv_dist_peer_coherence")
+        return int(stale.value), int(first.value)
 
     def DistSetPeerTimeoutMs(self, ms):
         self._check(self._lib.mv_dist_set_peer_timeout_ms(self._ctx, int(ms)), "mv_dist_set_peer_timeout_ms")

@@ -47,7 +47,10 @@ def main():
     after_setter = len(sys.argv) > 5 and sys.argv[5] == "2"          # a new host depth map every frame and NO flush: frame f - 1 is read back right after the setter of frame f
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rccl = os.environ.get("MV_TEST_RCCL") == "1"  # one GPU per rank and the library's own RCCL communicators (boxes with >= world GPUs)
-    device = int(os.environ.get("LOCAL_RANK", "0")) if rccl else 0
+    # MV_TEST_SEPARATE_GPUS=1: one GPU per rank for the peer-store transport too (boxes with >= world GPUs: the stores then cross the fabric,
+    # and the folded waits meet caches that are not the writer's)
+    separate = rccl or (os.environ.get("MV_TEST_SEPARATE_GPUS") == "1" and torch.cuda.device_count() >= world)
+    device = int(os.environ.get("LOCAL_RANK", "0")) if separate else 0
     torch.cuda.set_device(device)
     if rccl:
         dist.init_process_group("nccl", device_id=torch.device("cuda", device))
@@ -72,6 +75,13 @@ def main():
         if peer:
             info = c.DistInfo()
             assert info["transport"] == "peer" and info["ranks"] == world, info
+            if os.environ.get("MV_TEST_COHERENCE") == "1":
+                # the in-kernel coherence test by itself, with and without the acquire behind the wait (collective); rank 0 reports
+                with_acq, without = c.DistPeerCoherence(True), c.DistPeerCoherence(False)
+                res = torch.tensor([with_acq[0], with_acq[1], without[0], without[1]], dtype=torch.int64)
+                dist.all_reduce(res)
+                if rank == 0:
+                    print("COHERENCE acquire stale %d first_bad %d | no acquire stale %d first_bad %d" % tuple(res.tolist()), flush=True)
         if rccl:
             info = c.DistInfo()
             assert info["transport"] == "rccl" and info["ranks"] == world and info["communicators"] == (2 if mode == "single" else 3), info

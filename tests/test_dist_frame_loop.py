@@ -113,6 +113,26 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     assert int(d["nbytes"]) > 0
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_in_kernel_coherence_selftest(tmp_path, world):
+    """The self-test of what the folded waits rest on (mv_dist_peer_coherence; run by mv_dist_selftest whenever the waits are folded): ONE
+    launch per rank reads every rank's region, waits inside the kernel, every rank overwrites its region everywhere, the launch waits
+    inside the kernel again, acquires as the folded waits do and reads once more with plain loads.  The ranks share cuda:0 here, but their
+    workgroups sit on eight XCDs with an L2 each, and on 256 CUs with an L1 each that no store of another CU ever refreshes: a wait without
+    the acquire DOES see stale words on this one GPU (reported, not asserted: how many depends on what stayed resident) -- with it, none."""
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_TRANSPORT="peer", MV_TEST_PEER_FOLD="1", MV_TEST_COHERENCE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, "4", "4", "chains", "1"]
+    r = run_group(cmd, 300, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("COHERENCE")]
+    assert line, r.stdout[-2000:]
+    print(line[0])
+    assert " acquire stale 0 first_bad 0 " in line[0] + " ", line[0]
+    assert " first_bad 0" in line[0].split("|")[1], line[0]
+
+
 @pytest.mark.parametrize("mode", ["chains", "single", "peer"])
 def test_eight_ranks_at_c3_size_match_single_gpu(tmp_path, mode, monkeypatch):
     """BASELINE.json configs[3] (C4) at its real shape: the full C3 frame -- 16 x 256^3, 1024^2, 128 steps/ray, mesh depth -- through

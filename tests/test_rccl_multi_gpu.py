@@ -51,8 +51,54 @@ def test_bench_starts_its_own_ranks_over_rccl():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == world and d["value"] > 0
-    assert d["config"]["rccl_ranks"] == world
-    assert d["config"]["transport"] in ("rccl", "torch-callbacks"), d["config"]
-    if d["config"]["fallback_level"] == 0:
-        assert d["config"]["transport"] == "rccl"
+    # whichever rung of the ladder ran (bench.py LEVELS: the peer-store transport first), the line says so; RCCL's own rank count only
+    # exists on the rungs that open RCCL
+    cfg = d["config"]
+    assert cfg["transport"] in ("peer", "rccl", "torch-callbacks"), cfg
+    assert cfg["transport_ladder"][cfg["fallback_level"]].startswith({"peer": "peer", "rccl": "rccl", "torch-callbacks": ("torch-nccl", "gloo")}[cfg["transport"]]), cfg
+    if cfg["transport"] == "rccl":
+        assert cfg["rccl_ranks"] == world
+    if cfg["transport"] == "peer":
+        assert cfg["ranks_hold_the_same_frame"] in (True, None) and cfg["outbound_bytes_per_frame"] > 0
     assert d["cpu_baseline"]["gpu_vs_oracle_max_abs_err"] == 0.0
+
+
+def test_bench_over_rccl_when_asked():
+    """--transport rccl: the library's own communicators, whatever the ladder would have picked first."""
+    world = min(_gpus(), 8)
+    if world < 2:
+        pytest.skip("one GPU: RCCL with world size > 1 needs a GPU per rank")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--config", "T2", "--steps", "20", "--warmup", "5", "--transport", "rccl"], 900, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["config"]["transport"] == "rccl" and d["config"]["rccl_ranks"] == world
+
+
+@pytest.mark.parametrize("variant", ["peer", "peer-fold", "peer-x4"])
+def test_frame_loop_over_peer_stores_on_separate_gpus(tmp_path, variant):
+    """The peer-store transport with one GPU per rank: the stores cross the fabric, the flags are polled by another device than the one that
+    raised them, and the folded waits (the library's choice when every rank owns its GPU) read other GPUs' write-through stores.  Bit for bit
+    against the single-GPU frames; the in-kernel coherence test's verdict is part of the output."""
+    world = min(_gpus(), 8)
+    if world < 2:
+        pytest.skip("one GPU: ranks on separate devices need a GPU per rank (tests/test_dist_frame_loop.py runs the transport with the ranks sharing cuda:0)")
+    frames, every = 26, 13
+    out = str(tmp_path / "dist.npz")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_TRANSPORT="peer", MV_TEST_SEPARATE_GPUS="1", MV_TEST_COHERENCE="1", GPU_MAX_HW_QUEUES="8")
+    if variant != "peer":
+        env.update(MV_TEST_FOUR_CHAINS="1", MV_TEST_PEER_FOLD="1")
+    if variant == "peer-x4":
+        env["MV_TEST_FRAMES_PER_LAUNCH"] = "4"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every), "chains", "1"]
+    r = run_group(cmd, 900, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("COHERENCE")]
+    assert line and " acquire stale 0 first_bad 0 " in line[0] + " ", line
+    d = np.load(out)
+    imgs, infos, counts, lms = single_gpu(world, frames, every, True)
+    assert np.array_equal(d["infos"], infos)
+    for i in range(len(imgs)):
+        assert np.array_equal(d["imgs"][i], imgs[i]), f"composite of checkpoint {i} differs ({(d['imgs'][i] != imgs[i]).sum()} halfs)"
+    assert np.array_equal(d["lms"], lms) and np.array_equal(d["counts"], counts)
