@@ -119,15 +119,19 @@ def parse():
     p.add_argument("--profile-every", type=int, default=8, help="HIP-event pairs around the kernel launches of every n-th timed frame (each pair costs the pipelined frame ~0.5 %%)")
     p.add_argument("--roofline-frames", type=int, default=64, help="frames of the one-at-a-time pass that measures roofline.launch_ms")
     p.add_argument("--cpu-volumes", type=int, default=0, help="volumes the CPU baseline marches (0 = auto-bounded)")
-    p.add_argument("--rows-to-root", action="store_true", help="--gpus > 1, peer-store transport: the ranks push their screen rows to rank 0 only (SURVEY 8e: 'gather tiles to rank 0') "
-                   "instead of to every rank; the end-of-run check that every rank holds the same frame is then left out")
+    p.add_argument("--rows-to-root", action="store_true", help="(the default since round 5; kept for old command lines)")
+    p.add_argument("--rows-to-all", action="store_true", help="--gpus > 1, peer-store transport: every rank gets every rank's screen rows (as with the all-gathers) instead of rank 0 only "
+                   "(SURVEY 8e: 'gather tiles to rank 0' -- a seventh of the row traffic; the default)")
+    p.add_argument("--peer-no-acquire", action="store_true", help="DIAGNOSTIC: the folded waits of the peer-store transport without their acquire (round 4's form; MV_DIST_PEER_NO_ACQUIRE)")
+    p.add_argument("--finegrained", action="store_true", help="MV_FLAG_FINEGRAINED_PEER_BUFFERS: the buffers other ranks store into allocated fine-grained (what it costs on one GPU: profiles/r05_finegrained.txt)")
+    p.add_argument("--steady-frames", type=int, default=400, help="frames of the steady-state pass behind the timed region (its own barrier-to-barrier time: `steady_state_ms_per_step`); 0 = none")
     p.add_argument("--cull-on-view-stream", action="store_true", help="MV_FLAG_CULL_ON_VIEW_STREAM: every frame's upload and cull on its own view stream (no stream of their own); "
                    "the default of the peer rung of --gpus > 1, an experiment on one GPU")
     p.add_argument("--frames-in-flight", type=int, default=0, help="whole frames in flight = view streams = output sets (2..5; 0 = the library's default, 3)")
     p.add_argument("--cull-on-stream-a", action="store_true", help="one GPU: three chains and a stream of its own for upload + cull (the library's default) instead of four chains with the culls on them")
     p.add_argument("--frames-per-launch", type=int, default=0, help="--gpus N > 1, peer stores: B = 1..4 consecutive frames go through every long kernel of a rank's chain together "
                    "(mv_config.frames_per_launch; 0 = 4 on the peer-store rung, 1 elsewhere): a rank of eight holds an eighth of a frame, which leaves its GPU to latency")
-    p.add_argument("--transport", default="auto", choices=["auto", "peer", "peer-one-frame-per-launch", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
+    p.add_argument("--transport", default="auto", choices=["auto", "peer", "peer-one-frame-per-launch", "peer-no-fold", "rccl", "rccl-single-stream", "torch-nccl", "gloo"],
                    help="--gpus > 1: auto = the peer-store transport (no collectives: every rank's kernels store into every rank's buffers over "
                         "IPC mappings, flags instead of all-gathers), and -- only if that fails its self-test, fails or stops making progress -- "
                         "the next of: the library's own RCCL communicators with one view stream (two communicators, one collective in flight "
@@ -149,7 +153,10 @@ def parse():
 # ---------------------------------------------------------------------------------------------------------------------
 # (the conservative RCCL schedule in front of the one that keeps three communicators busy on three streams of a device, until a box with
 # more than one GPU has run tests/test_rccl_multi_gpu.py)
-LEVELS = ["peer", "peer-one-frame-per-launch", "rccl-single-stream", "rccl", "torch-nccl", "gloo"]  # ("peer": four frames per launch; its second rung: the same transport, a frame per launch)
+# "peer": four frames per launch, waits folded into the kernels; then the same transport with a frame per launch; then with every wait a
+# kernel of its own in front of its consumer ("peer-no-fold": a kernel boundary between another GPU's stores and this GPU's loads of them --
+# the rung for a node on which the in-kernel coherence self-test of the folded waits fails); then the collectives
+LEVELS = ["peer", "peer-one-frame-per-launch", "peer-no-fold", "rccl-single-stream", "rccl", "torch-nccl", "gloo"]
 PHASE_TIMEOUT_S = {"start": 420.0, "setup": 420.0, "dist-init": 180.0, "warmup": 240.0, "timed": 240.0, "roofline": 240.0, "report": 600.0}
 
 
@@ -267,10 +274,15 @@ def main():
     import torch.distributed as dist
 
     transport = os.environ.get("MV_BENCH_TRANSPORT", "peer" if args.transport == "auto" else args.transport)
+    peer_fold = None  # (the library decides: folded when every rank owns its GPU)
     if transport == "peer-one-frame-per-launch":  # (the ladder's second rung: what round 4 measured first -- no launch holds more than one frame)
         transport = "peer"
         if args.frames_per_launch == 0:
             args.frames_per_launch = 1
+    if transport == "peer-no-fold":  # (third rung: every wait a one-wavefront kernel in front of its consumer; several frames per launch exist folded only)
+        transport, peer_fold = "peer", False
+        args.frames_per_launch = 1
+    rows_to_root = not args.rows_to_all
     if transport == "rccl-single-stream":
         args.dist_single_stream = True
     if not torch.cuda.is_available():
@@ -296,6 +308,8 @@ def main():
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
     M = 1024
     flags = _lib.MV_FLAG_FORCE_MIP0_ALL_FACES if args.stress else 0
+    if args.finegrained:
+        flags |= _lib.MV_FLAG_FINEGRAINED_PEER_BUFFERS
     if args.ray_queue:
         flags |= _lib.MV_FLAG_RAY_QUEUE
     pipelined = not args.no_pipeline
@@ -379,7 +393,7 @@ def main():
     # N > 1: the per-frame protocol runs inside the library (mv_dist_frame); torch.distributed only distributes the RCCL ids
     phase("dist-init")
     exchange = D.init_frame_loop(caster, prefer_rccl=transport in ("rccl", "rccl-single-stream"), prefer_peer=transport == "peer",
-                                 peer_timeout_ms=20000, peer_rows_to_root=args.rows_to_root) if world > 1 else None
+                                 peer_timeout_ms=20000, peer_rows_to_root=rows_to_root, peer_fold=peer_fold, peer_acquire=not args.peer_no_acquire) if world > 1 else None
     if world > 1 and transport == "peer" and exchange != "peer":
         # (asked for by name or by the ladder: a rank that could not attach it leaves, and the supervisors move everybody to the next level)
         print(f"bench.py: the peer-store transport could not be attached (got {exchange})", file=sys.stderr)
@@ -439,6 +453,7 @@ def main():
         caster.DistFlush()
         caster.synchronize()
         caster.DistExchangedBytes(reset=True)  # exchange bytes of the timed frames only
+    caster.SetLatencySampling(max(1, args.profile_every))  # (a host function behind the last kernel of every n-th frame)
     barrier()
     phase("timed")
     t0 = time.perf_counter()
@@ -458,6 +473,21 @@ def main():
     xbytes_timed = caster.DistExchangedBytes() if world > 1 else 0
     caster.SetProfiling(False)
     st = caster.GetStats()
+    latency = caster.GetLatency(reset=True)
+    caster.SetLatencySampling(0)
+
+    # steady state: the same loop for --steady-frames more frames with its own barriers.  The driver's 20 timed frames are little more than one
+    # depth of the pipeline when sixteen frames are in flight (four chains x four frames per launch): mostly fill and drain.
+    dt_steady = None
+    if args.steady_frames > 0:
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steady_frames):
+            frame()
+        if world > 1:
+            caster.DistFlush()
+        barrier()
+        dt_steady = time.perf_counter() - t1
 
     # roofline pass: the same frames, one at a time, so that a launch's HIP-event duration is the kernel's own time
     phase("roofline")
@@ -481,23 +511,45 @@ def main():
         # frame: with the peer-store transport and the all-gathers alike every rank holds the whole image
         import zlib
         mine = [None] * world
-        dist.all_gather_object(mine, (dt / args.steps * 1e3, zlib.crc32(caster.ReadBackComposite().tobytes()) if do_composite else 0))
+        to_root = rows_to_root and exchange == "peer"
+        # what EVERY rank holds whoever produced it: every light map and the marched faces of every cube map (and, unless the rows go to
+        # rank 0 only, the frame itself) -- a transport that left any rank with other bytes is a failed transport
+        info_ = caster.ReadBackVolumeInfo()
+        vis_, cube_ = caster.ReadBackVisibleLists()
+        crc = 0
+        for v in range(V):
+            crc = zlib.crc32(caster.ReadBackLightMap(v).tobytes(), crc)
+        for v in sorted(int(x) for x in cube_):
+            crc = zlib.crc32(caster.ReadBackCubeMap(v, int(info_[v, 0])).tobytes(), crc)
+            crc = zlib.crc32(caster.ReadBackCubeDepth(v, int(info_[v, 0])).tobytes(), crc)
+        if do_composite and not to_root:
+            crc = zlib.crc32(caster.ReadBackComposite().tobytes(), crc)
+        # bytes this rank sends per frame (peer stores): its marched texels (8 B colour + 4 B depth) and its layers of the relit light map to
+        # every other rank, its screen rows to every other rank or to rank 0
+        pinfo = caster.DistPeerInfo()
+        rows_mine = len(D.tile_rows_of_rank(H, rank, world)) * 8 * W * 8 if hasattr(D, "tile_rows_of_rank") else (band[1] - band[0]) * W * 8
+        out_bytes = ((st["rays"] / max(1, args.steps)) * 12 + (L ** 3 // world) * pinfo["light_push_bytes_per_texel"]) * (world - 1) \
+            + rows_mine * ((0 if rank == 0 else 1) if to_root else (world - 1)) if exchange == "peer" else None
+        dist.all_gather_object(mine, (dt / args.steps * 1e3, crc, out_bytes, (dt_steady / args.steady_frames * 1e3) if dt_steady else None, latency))
         per_rank_ms = [round(m[0], 5) for m in mine]
-        ranks_agree = True if (args.rows_to_root and exchange == "peer") else len(set(m[1] for m in mine)) == 1
+        ranks_agree = len(set(m[1] for m in mine)) == 1
         if not ranks_agree:
             # a transport that delivered different images to different ranks is a failed transport: no line, and the supervisors move on
             if rank == 0:
                 print(f"bench.py: the ranks do not hold the same frame after the run (transport {exchange}): {[hex(m[1]) for m in mine]}", file=sys.stderr)
             caster.close()
             return 4
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, dt_steady or 0.0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, dt_steady = float(t[0].item()), (float(t[1].item()) or None)
+        out_per_rank = [m[2] for m in mine]
+        latency = {"mean_ms": max(m[4]["mean_ms"] for m in mine), "max_ms": max(m[4]["max_ms"] for m in mine), "samples": min(m[4]["samples"] for m in mine)}
         cnt = torch.tensor([st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"], st["fetch_free_samples"]], dtype=torch.int64, device="cuda")
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         tot_view, tot_lit, tot_rays, tot_light, tot_free = [int(x) for x in cnt.tolist()]
     else:
         tot_view, tot_lit, tot_rays, tot_light, tot_free = st["view_samples"], st["lit_samples"], st["rays"], st["light_samples"], st["fetch_free_samples"]
+        out_per_rank = None
 
     if rank == 0:
         K = args.steps
@@ -552,6 +604,12 @@ def main():
             "metric": "volume_samples_per_sec", "value": tot_view / dt / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
             "frames_per_s": K / dt, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            # depth: whole frames the host may run ahead of the GPU (chains x frames per launch), and what a frame pays for it -- host clock at
+            # the hand-over of its constants to host clock behind its last kernel, sampled inside the timed region (max over ranks)
+            "frames_in_flight_total": (2 if (world > 1 and args.dist_single_stream) else (args.frames_in_flight or 3) * (args.frames_per_launch or 1)) if pipelined else 1,
+            "latency_ms": latency["mean_ms"] if latency["samples"] else None, "latency_ms_max": latency["max_ms"] if latency["samples"] else None, "latency_samples": latency["samples"],
+            # the same loop over --steady-frames more frames, its own barriers (max over ranks): what the K timed frames would say if K were large
+            "steady_state_ms_per_step": (dt_steady / args.steady_frames * 1e3) if dt_steady else None, "steady_state_frames": args.steady_frames if dt_steady else 0,
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"{args.config}{'-stress' if args.stress else ''}: {V}x{N}^3 RGBA16F volumes, {cfg['W']}x{cfg['H']} viewport, "
@@ -574,10 +632,17 @@ def main():
                                      else "up to 3 whole frames (light-march share + all-gather, view march, cube-face all-gather, composite, row all-gather) on 3 view streams with a communicator each") if pipelined else 1,
                 "step": "UpdateFrame+cull+marchL(1 volume)+marchV" + (("+peer stores" if exchange == "peer" else "+cube-face all-gather") if world > 1 else "") + ("+OIT composite" if do_composite else ""),
                 "exchange_bytes_per_frame": xbytes_timed // max(1, K),
+                # peer stores: what a rank SENDS per frame (the largest rank's; every rank's beside it) and the rate that is at this run's frame time --
+                # against 7 links x 76.8 GB/s one way per GPU (DESIGN.md 5.5 has the budget)
+                "outbound_bytes_per_frame": int(max(out_per_rank)) if out_per_rank and out_per_rank[0] is not None else None,
+                "outbound_bytes_per_frame_per_rank": [int(x) for x in out_per_rank] if out_per_rank and out_per_rank[0] is not None else None,
+                "outbound_gb_per_s_at_this_frame_time": (max(out_per_rank) / (dt / K) / 1e9) if out_per_rank and out_per_rank[0] is not None else None,
+                "peer": caster.DistPeerInfo() if (world > 1 and exchange == "peer") else None,
                 "transport": exchange, "fallback_level": int(os.environ.get("MV_BENCH_LEVEL", "0")),
                 "transport_ladder": LEVELS if world > 1 else None,
                 "rccl_ranks": caster.DistInfo()["ranks"] if world > 1 else None,
-                "ms_per_step_per_rank": per_rank_ms, "ranks_hold_the_same_frame": None if (args.rows_to_root and exchange == "peer") else ranks_agree,
+                "ms_per_step_per_rank": per_rank_ms, "ranks_hold_the_same_frame": ranks_agree,
+                "ranks_compared": ("every light map, the marched faces of every cube map" + ("" if (rows_to_root and exchange == "peer") else ", the composite")) if world > 1 else None,
             },
             "kernel_ms": k_alone, "kernel_ms_in_flight": k_in_flight,
             "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,
@@ -659,11 +724,15 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
         reps += 1
         dt = time.perf_counter() - t0
     dt /= reps
+    def marched(a, v):
+        # the faces this frame marched (VolumeInfo.MaskBits): the others keep what an earlier frame left there -- the reference never clears
+        # its cube maps -- which a moving camera makes differ from the oracle's zero-initialised buffer
+        return a[[f for f in range(6) if (int(info[v, 2]) >> f) & 1]]
     worst = 0.0
     for v in sel:
         mip = int(info[v, 0])
-        exp = o.cube_face_view(cm[v], N, mip).view(np.float16).astype(np.float32)
-        got = caster.ReadBackCubeMap(v, mip).view(np.float16).astype(np.float32)
+        exp = marched(o.cube_face_view(cm[v], N, mip), v).view(np.float16).astype(np.float32)
+        got = marched(caster.ReadBackCubeMap(v, mip), v).view(np.float16).astype(np.float32)
         worst = max(worst, float(np.max(np.abs(exp - got))))
     lib.mvo_set_num_threads(1)
     t1 = time.perf_counter()
@@ -698,8 +767,8 @@ def cpu_baseline(args, cfg, caster, fr, info, cube, vols_host):
             worst_ref = 0.0
             for v in sel:  # the GPU's cube maps against the reference's own, no oracle in between
                 mip = int(info[v, 0])
-                exp = o.cube_face_view(rm[v], N, mip).view(np.float16).astype(np.float32)
-                got = caster.ReadBackCubeMap(v, mip).view(np.float16).astype(np.float32)
+                exp = marched(o.cube_face_view(rm[v], N, mip), v).view(np.float16).astype(np.float32)
+                got = marched(caster.ReadBackCubeMap(v, mip), v).view(np.float16).astype(np.float32)
                 worst_ref = max(worst_ref, float(np.max(np.abs(exp - got))))
             # one group-worker thread (the lanes of a wavefront still run as threads that meet at every wave intrinsic: the emulation's cost)
             dxref.load().dxref_set_threads(1)

@@ -85,6 +85,14 @@ extern "C" {
 											   loop wants, whose frame is a chain of short kernels (profiles/r04_peer_rank_cost.txt).  On one GPU it is worth 1 %
 											   (C3: 0.313 against 0.317 ms per frame, bench.py's default there).  Results are identical. */
 
+#define MV_FLAG_FINEGRAINED_PEER_BUFFERS 64u	/* the buffers other ranks store into (peer-store transport: light maps, cube maps / depths, frame buffers) are allocated
+											   FINE-GRAINED (hipExtMallocWithFlags hipDeviceMallocFinegrained): memory the hardware keeps coherent between agents
+											   inside running kernels, which is what the HSA memory model asks of memory another GPU writes while a kernel here
+											   polls for it.  Plain (coarse-grained) allocations are the default: the folded waits make the acquire themselves and
+											   the transport's self-test checks it (mv_dist_peer_coherence); this flag is the belt beside those braces, for a
+											   node where that self-test fails.  What it costs on ONE GPU: profiles/r05_finegrained.txt.  mv_create fails with
+											   MV_ERR_OUT_OF_MEMORY where the runtime refuses such allocations. */
+
 typedef struct mv_ctx mv_ctx;
 
 typedef struct mv_config
@@ -238,6 +246,12 @@ int mv_synchronize(mv_ctx* ctx);
 /* Time (ms) mv_update_frame has spent waiting for the GPU to free a frame slot (four frames of constants are in flight at most, as the
  * reference waits on its fence with FrameCount = 3, MultiVolumes.cpp MoveToNextFrame): 0 while the host is the slower side. */
 int mv_host_wait_ms(mv_ctx* ctx, double* ms, int reset);
+/* Frame latency, sampled: every n-th frame (0 = off, the default) the library notes the host's clock when the frame's constants are handed
+ * over (mv_update_frame / mv_dist_frame) and again -- a host function behind the frame's last kernel on its stream -- when the GPU is done
+ * with it.  With frames in flight (and several frames per launch) that is the latency a frame pays for the throughput: depth x period.
+ * mv_get_latency drains the frames in flight first. */
+int mv_set_latency_sampling(mv_ctx* ctx, uint32_t every_n_frames);
+int mv_get_latency(mv_ctx* ctx, double* mean_ms, double* max_ms, uint64_t* samples, int reset);
 
 /* Raw handles for callers that keep data resident (torch / RCCL plumbing): */
 void* mv_get_stream(mv_ctx* ctx);			/* the hipStream_t */
@@ -380,7 +394,11 @@ int mv_dist_shutdown(mv_ctx* ctx);	/* detach the frame loop (drains it first); m
 int mv_dist_selftest(mv_ctx* ctx);	/* one all-gather (plain and in place) and one all-reduce per communicator, verified: call once after init on every rank */
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite);
 int mv_dist_flush(mv_ctx* ctx);	/* enqueue the exchange + composite of the last frame begun (then mv_synchronize / readbacks see it) */
-int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset);	/* bytes this rank received through the collectives */
+int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset);
+/* peer-store transport: out[8] = { waits folded, folded waits acquire, rows to rank 0 only, whole volumes per rank, bytes pushed per texel of a
+ * rank's share of the relit light map, kind of memory the flag block lives in (2 uncached, 1 fine-grained, 0 plain), stale words and
+ * wrong first reads of the last in-kernel coherence test }; all zero on the other transports */
+int mv_dist_peer_info(mv_ctx* ctx, uint32_t* out);	/* bytes this rank received through the collectives */
 /* transport: 0 none, 1 RCCL, 2 caller-supplied collectives, 3 peer stores; ranks: the size of the communicator as RCCL reports it (ncclCommCount), or
  * shard_count for caller-supplied collectives; communicators: how many the loop keeps busy (3 with whole-frame chains, else 2) */
 int mv_dist_info(mv_ctx* ctx, uint32_t* transport, uint32_t* ranks, uint32_t* communicators);

@@ -26,6 +26,7 @@ MV_FLAG_SINGLE_VIEW_STREAM = 4
 MV_FLAG_LIST_ORDER = 8
 MV_FLAG_RAY_QUEUE = 16
 MV_FLAG_CULL_ON_VIEW_STREAM = 32
+MV_FLAG_FINEGRAINED_PEER_BUFFERS = 64
 
 MV_BUF_VOLUME, MV_BUF_LIGHT_MAP, MV_BUF_CUBE_MAP, MV_BUF_CUBE_DEPTH = 0, 1, 2, 3
 MV_BUF_VOLUME_INFO, MV_BUF_COMPOSITE, MV_BUF_DEPTH_MAP, MV_BUF_SHADOW_MAP = 4, 5, 6, 7
@@ -136,6 +137,9 @@ ABI = {
     "mv_dist_rccl_available": (C.c_int, []),
     "mv_dist_info": (C.c_int, [_P, C.POINTER(_U32), C.POINTER(_U32), C.POINTER(_U32)]),
     "mv_host_wait_ms": (C.c_int, [_P, C.POINTER(C.c_double), C.c_int]),
+    "mv_set_latency_sampling": (C.c_int, [_P, _U32]),
+    "mv_get_latency": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    "mv_dist_peer_info": (C.c_int, [_P, C.POINTER(_U32)]),
     "mv_set_viewport": (C.c_int, [_P, _U32, _U32]),
     "mv_mesh_upload": (C.c_int, [_P, _P, _U32, _P, _U32]),
     "mv_mesh_render_depth": (C.c_int, [_P, _P, _P]),

@@ -180,7 +180,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	#ifdef MV_EMULATE_LIGHT_PAIRS	// (timing experiment only, csrc/experiments/mv_march_tiles_r05.hip: room for 32-byte light cells; the images of such a build are garbage)
 	if ((rc = devAlloc(ctx, &st.lightBuffers, 2u * (size_t)st.V * st.lightBufs * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
 #else
-	if ((rc = devAlloc(ctx, &st.lightBuffers, (size_t)st.V * st.lightBufs * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
+	if ((rc = devAllocShared(ctx, &st.lightBuffers, (size_t)st.V * st.lightBufs * L3 * sizeof(uint4))) != MV_OK) return bail(rc);
 #endif
 	if ((rc = devAlloc(ctx, &ctx->lightStaging, L3 * sizeof(uint32_t), false)) != MV_OK) return bail(rc);
 	if ((rc = devAlloc(ctx, &ctx->ownDepth, (size_t)st.W * st.H * sizeof(float))) != MV_OK) return bail(rc);
@@ -281,10 +281,10 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	{
 		OutBufs& f = ctx->ob[p];
 		// cubeMaps[V] (5 mips), cubeDepths[V] (MultiRayCaster.cpp:107-121), zero-initialised
-		if ((rc = devAlloc(ctx, &f.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
-		if ((rc = devAlloc(ctx, &f.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
+		if ((rc = devAllocShared(ctx, &f.cubeMaps, (size_t)st.V * chain * sizeof(uint2))) != MV_OK) return bail(rc);
+		if ((rc = devAllocShared(ctx, &f.cubeDepths, (size_t)st.V * chain * sizeof(float))) != MV_OK) return bail(rc);
 		// (sharded: room for the rank-major layout of the multi-GPU frame loop, shard_count blocks of ceil(tile rows / shard_count) tile rows)
-		if ((rc = devAlloc(ctx, &f.composite, (size_t)st.W * compositeRows(st) * sizeof(uint2))) != MV_OK) return bail(rc);
+		if ((rc = devAllocShared(ctx, &f.composite, (size_t)st.W * compositeRows(st) * sizeof(uint2))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.screenLayers, (size_t)st.screenSlots * st.W * st.H * sizeof(float4))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.faceStamps, (size_t)st.V * MV_NUM_CUBE_MIP * 6 * sizeof(uint32_t))) != MV_OK) return bail(rc);
 		if ((rc = devAlloc(ctx, &f.waveStats, (size_t)st.marchWaves * 8 * sizeof(uint64_t))) != MV_OK) return bail(rc);
@@ -622,6 +622,14 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	}
 	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
 	ctx->st.frameTag = (uint32_t)ctx->frame;
+	if (ctx->latEvery)
+	{
+		// (latency sampling: the slot's previous sample is over -- its frame was numSlots frames ago -- or never finished being taken)
+		latencyHarvest(ctx, ctx->slot);
+		mv_ctx::LatencySample& l = ctx->lat[ctx->slot];
+		l.armed = ctx->frame % ctx->latEvery == 0u;
+		if (l.armed) { l.doneNs.store(0, std::memory_order_relaxed); l.startNs.store(hostNowNs(), std::memory_order_relaxed); }
+	}
 	applyParity(ctx);
 	// the slot's previous user (ctx->numSlots frames ago) must be done with it; volume producers on stream B must have finished
 	{
@@ -1101,6 +1109,25 @@ int mv_set_profiling(mv_ctx* ctx, int on)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	ctx->profiling = on != 0;
+	return MV_OK;
+}
+
+int mv_set_latency_sampling(mv_ctx* ctx, uint32_t every_n_frames)
+{
+	if (!ctx) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) { latencyHarvest(ctx, i); ctx->lat[i].armed = false; }
+	ctx->latEvery = every_n_frames;
+	return MV_OK;
+}
+
+int mv_get_latency(mv_ctx* ctx, double* mean_ms, double* max_ms, uint64_t* samples, int reset)
+{
+	if (!ctx || !mean_ms || !max_ms || !samples) return MV_ERR_INVALID_ARG;
+	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// (the frames in flight finish; the host functions behind them have run)
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) latencyHarvest(ctx, i);
+	*samples = ctx->latCount; *mean_ms = ctx->latCount ? ctx->latSumMs / (double)ctx->latCount : 0.0; *max_ms = ctx->latMaxMs;
+	if (reset) { ctx->latSumMs = 0.0; ctx->latMaxMs = 0.0; ctx->latCount = 0; }
 	return MV_OK;
 }
 

@@ -14,6 +14,8 @@
 #include <stdio.h>
 #include <string>
 #include <vector>
+#include <atomic>
+#include <chrono>
 #include <new>
 #include <dlfcn.h>
 #include <rccl/rccl.h>	// types and prototypes only: the library is opened with dlopen when mv_dist_init_rccl is called
@@ -233,6 +235,13 @@ struct mv_ctx
 	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
 
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
+	// Frame latency, sampled (mv_set_latency_sampling): the host's clock when a frame's constants are handed over (mv_update_frame /
+	// mv_dist_frame) and when the last kernel of that frame has finished -- a host function behind the record of the frame's "done" event.
+	struct LatencySample { std::atomic<long long> startNs{0}, doneNs{0}; bool armed = false; };
+	LatencySample lat[kMaxFrameSlots];
+	uint32_t latEvery = 0;
+	double latSumMs = 0.0, latMaxMs = 0.0;
+	uint64_t latCount = 0;
 	bool leanEvents = false;			// inside mv_dist_frame on a chains context: event records that a later record of the same call supersedes are left out (the host enqueues a rank's frame in ~100 us: every call counts)
 	bool lightMarched = false, lightTableKept = false;	// this frame: mv_march_light ran / the frame keeps the previous frame's light table (see keepLightTable)
 	bool profiling = false;
@@ -293,6 +302,19 @@ int devAlloc(mv_ctx* ctx, T** out, size_t bytes, bool zero = true)
 	MV_HIP(ctx, hipMalloc(&p, bytes ? bytes : 16));
 	ctx->allocs.push_back(p);
 	if (zero) MV_HIP(ctx, hipMemsetAsync(p, 0, bytes ? bytes : 16, ctx->stream));
+	*out = reinterpret_cast<T*>(p);
+	return MV_OK;
+}
+
+// a buffer OTHER ranks may store into (peer-store transport): fine-grained memory under MV_FLAG_FINEGRAINED_PEER_BUFFERS, plain otherwise
+template <typename T>
+int devAllocShared(mv_ctx* ctx, T** out, size_t bytes)
+{
+	if (!(ctx->cfg.flags & MV_FLAG_FINEGRAINED_PEER_BUFFERS)) return devAlloc(ctx, out, bytes);
+	void* p = nullptr;
+	if (hipExtMallocWithFlags(&p, bytes ? bytes : 16, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return fail(ctx, MV_ERR_OUT_OF_MEMORY, "hipExtMallocWithFlags(hipDeviceMallocFinegrained): MV_FLAG_FINEGRAINED_PEER_BUFFERS on a runtime that refuses it"); }
+	ctx->allocs.push_back(p);
+	MV_HIP(ctx, hipMemsetAsync(p, 0, bytes ? bytes : 16, ctx->stream));
 	*out = reinterpret_cast<T*>(p);
 	return MV_OK;
 }
@@ -458,7 +480,28 @@ hipError_t stageBBegin(mv_ctx* ctx)
 	return hipSuccess;
 }
 // stage of stream B finished being enqueued: the next user of this slot's buffers (ctx->numSlots frames on) and the light march two frames on wait for it
-hipError_t stageBDone(mv_ctx* ctx) { return evRecord(ctx, ctx->evMainDone[ctx->slot], streamB(ctx)); }
+// (latency sampling) behind a record of slot's "done" event on stream s: the host's clock at that point of the stream
+inline long long hostNowNs() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline void latencyDoneFn(void* p) { static_cast<mv_ctx::LatencySample*>(p)->doneNs.store(hostNowNs(), std::memory_order_release); }
+inline void latencyHarvest(mv_ctx* ctx, uint32_t slot)
+{
+	mv_ctx::LatencySample& l = ctx->lat[slot];
+	const long long done = l.doneNs.load(std::memory_order_acquire);
+	if (!l.armed || !done) return;
+	const double ms = (double)(done - l.startNs.load(std::memory_order_relaxed)) * 1e-6;
+	ctx->latSumMs += ms; ctx->latMaxMs = ms > ctx->latMaxMs ? ms : ctx->latMaxMs; ++ctx->latCount;
+	l.armed = false; l.doneNs.store(0, std::memory_order_relaxed);
+}
+inline hipError_t latencyMark(mv_ctx* ctx, uint32_t slot, hipStream_t s)
+{
+	if (!ctx->latEvery || !ctx->lat[slot].armed) return hipSuccess;
+	return hipLaunchHostFunc(s, latencyDoneFn, &ctx->lat[slot]);	// (a frame may be marked twice -- behind its march and behind its composite: the later clock stands)
+}
+hipError_t stageBDone(mv_ctx* ctx)
+{
+	const hipError_t e = evRecord(ctx, ctx->evMainDone[ctx->slot], streamB(ctx));
+	return e != hipSuccess ? e : latencyMark(ctx, ctx->slot, streamB(ctx));
+}
 
 void beginStage(mv_ctx* ctx, int stage, EventPair& ev, hipStream_t stream)
 {

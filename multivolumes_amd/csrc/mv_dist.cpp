@@ -429,6 +429,7 @@ static int distTailComposite(mv_ctx* ctx)
 	{ const int rc = distTailSignal(ctx, X, chain, st, d->framePending, slot, d->pendingComposite); if (rc != MV_OK) return rc; }
 	// everything that reads this frame's buffers has been enqueued: the next users of its slot / output set / light buffers wait for this
 	MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[slot], X));
+	MV_HIP(ctx, latencyMark(ctx, slot, X));
 	d->pending = false;
 	return MV_OK;
 }
@@ -647,6 +648,18 @@ int mv_dist_info(mv_ctx* ctx, uint32_t* transport, uint32_t* ranks, uint32_t* co
 		MV_REQUIRE(ctx, commCount && commCount(d->comm[0], &n) == ncclSuccess, MV_ERR_HIP, "ncclCommCount failed");
 		*ranks = (uint32_t)n;
 	}
+	return MV_OK;
+}
+
+int mv_dist_peer_info(mv_ctx* ctx, uint32_t* out)
+{
+	if (!ctx || !out) return MV_ERR_INVALID_ARG;
+	for (uint32_t i = 0; i < 8u; ++i) out[i] = 0u;
+	const DistState* d = ctx->dist;
+	if (!d || d->transport != 3) return MV_OK;
+	out[0] = d->peerFold ? 1u : 0u; out[1] = d->peerAcquire ? 1u : 0u; out[2] = d->peerRowsRoot ? 1u : 0u; out[3] = d->peerDealVolumes ? 1u : 0u;
+	out[4] = (uint32_t)sizeof(uint4);	// bytes a rank pushes per texel of its share of the relit light map
+	out[5] = (uint32_t)d->peerFlagsKind; out[6] = d->peerStaleWords; out[7] = d->peerFirstReadBad;
 	return MV_OK;
 }
 

@@ -654,7 +654,7 @@ int batchTail(mv_ctx* ctx)
 		MV_HIP(ctx, hipGetLastError());
 	}
 	// everything that reads these frames' buffers has been enqueued: the next users of their slots / output sets / light buffers wait for this
-	for (uint32_t i = 0; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[d->pend[i].slot], X));
+	for (uint32_t i = 0; i < n; ++i) { MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[d->pend[i].slot], X)); MV_HIP(ctx, latencyMark(ctx, d->pend[i].slot, X)); }
 	d->nPend = 0;
 	return MV_OK;
 }

@@ -531,6 +531,22 @@ class MultiRayCaster:
         self._check(self._lib.mv_dist_info(self._ctx, C.byref(t), C.byref(r), C.byref(c)), "mv_dist_info")
         return {"transport": ("none", "rccl", "callbacks", "peer")[t.value], "ranks": r.value, "communicators": c.value}
 
+    def DistPeerInfo(self):
+        """The peer-store transport's settings and its last coherence verdict (all zero / False on the other transports)."""
+        out = (C.c_uint32 * 8)()
+        self._check(self._lib.mv_dist_peer_info(self._ctx, out), "mv_dist_peer_info")
+        return {"folded": bool(out[0]), "acquire": bool(out[1]), "rows_to_root": bool(out[2]), "deal_volumes": bool(out[3]), "light_push_bytes_per_texel": int(out[4]),
+                "flags_memory": ("plain", "fine-grained", "uncached")[min(int(out[5]), 2)], "stale_words": int(out[6]), "first_read_bad": int(out[7])}
+
+    def SetLatencySampling(self, every_n_frames):
+        """Every n-th frame: host clock at the hand-over of its constants -> host clock behind its last kernel (0 = off)."""
+        self._check(self._lib.mv_set_latency_sampling(self._ctx, int(every_n_frames)), "mv_set_latency_sampling")
+
+    def GetLatency(self, reset=False):
+        mean, mx, n = C.c_double(), C.c_double(), C.c_uint64()
+        self._check(self._lib.mv_get_latency(self._ctx, C.byref(mean), C.byref(mx), C.byref(n), 1 if reset else 0), "mv_get_latency")
+        return {"mean_ms": mean.value, "max_ms": mx.value, "samples": int(n.value)}
+
     def DistExchangedBytes(self, reset=False):
         n = C.c_uint64()
         self._check(self._lib.mv_dist_exchanged_bytes(self._ctx, C.byref(n), 1 if reset else 0), "mv_dist_exchanged_bytes")

@@ -40,7 +40,7 @@ def run_group(cmd, timeout, env=None):
 def test_two_ranks_on_one_gpu(extra):
     env = dict(os.environ, MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2"] + extra
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24"] + extra
     r = run_group(cmd, 240, env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -51,8 +51,18 @@ def test_two_ranks_on_one_gpu(extra):
     assert d["config"]["transport"] == ("torch-callbacks" if "--dist-single-stream" in extra else "peer"), d["config"]["transport"]
     assert d["config"]["ranks_hold_the_same_frame"] is True and len(d["config"]["ms_per_step_per_rank"]) == 2
     assert d["cpu_baseline"]["gpu_vs_oracle_max_abs_err"] == 0.0
+    # depth and what it costs a frame; the steady-state figure beside the K timed frames
+    per_launch = 4 if "--frames-per-launch" in extra else 1
+    assert d["frames_in_flight_total"] == (2 if "--dist-single-stream" in extra else (4 * per_launch if d["config"]["transport"] == "peer" else 3)), d["frames_in_flight_total"]
+    assert d["latency_samples"] > 0 and d["latency_ms"] >= d["ms_per_step"] * 0.5 and d["latency_ms_max"] >= d["latency_ms"]
+    assert d["steady_state_ms_per_step"] > 0 and d["steady_state_frames"] == 24
+    if d["config"]["transport"] == "peer":
+        c = d["config"]
+        assert c["peer"]["rows_to_root"] and c["peer"]["acquire"] and c["peer"]["stale_words"] == 0
+        assert len(c["outbound_bytes_per_frame_per_rank"]) == 2 and c["outbound_bytes_per_frame"] == max(c["outbound_bytes_per_frame_per_rank"]) > 0
+        assert c["outbound_gb_per_s_at_this_frame_time"] > 0 and "light map" in c["ranks_compared"]
     # the same frame on one rank: the sharded run marches the same samples
-    one = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"] + [e for e in extra if e in ("--orbit",)], 240)
+    one = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "T2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--steady-frames", "0"] + [e for e in extra if e in ("--orbit",)], 240)
     assert one.returncode == 0, one.stderr[-2000:]
     s = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     for k in ("view_samples_per_frame", "lit_samples_per_frame", "rays_per_frame", "light_samples_per_frame"):
@@ -66,7 +76,7 @@ def test_bench_starts_and_supervises_its_ranks():
     ranks share cuda:0 over gloo, MV_BENCH_SHARE_GPU=1).  And a WORLD_SIZE that contradicts --gpus is an error, not a warning."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2"], 400, env)
+    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24"], 400, env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["transport"] == "peer" and d["config"]["fallback_level"] == 0
@@ -89,6 +99,7 @@ def test_one_rank_bench_line_carries_both_cpu_baselines():
         assert cb["kind"] == "reference" and cb["reference_equals_oracle"] and cb["gpu_vs_reference_max_abs_err"] == 0.0
     else:
         assert cb["kind"] == "port"
+    assert d["frames_in_flight_total"] == 4 and d["latency_samples"] > 0 and d["latency_ms"] > d["ms_per_step"] and d["steady_state_ms_per_step"] > 0
     r = d["roofline"]
     assert 0 < r["frac"] <= r["frac_with_fused_raycast"] and 0 <= r["fetch_free_share"] < 1 and d["n_gpus"] == 1
     assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9, "frac is achieved / peak: SURVEY 8(d)'s algorithmic bytes of the a3 loop over the launch time"
