@@ -123,6 +123,7 @@ def parse():
     p.add_argument("--rows-to-all", action="store_true", help="--gpus > 1, peer-store transport: every rank gets every rank's screen rows (as with the all-gathers) instead of rank 0 only "
                    "(SURVEY 8e: 'gather tiles to rank 0' -- a seventh of the row traffic; the default)")
     p.add_argument("--peer-no-acquire", action="store_true", help="DIAGNOSTIC: the folded waits of the peer-store transport without their acquire (round 4's form; MV_DIST_PEER_NO_ACQUIRE)")
+    p.add_argument("--peer-push-cells", action="store_true", help="DIAGNOSTIC: the peer-store transport pushes whole light cells (16 B per texel, round 4) instead of plain texels that the receivers rebuild (MV_DIST_PEER_PUSH_CELLS)")
     p.add_argument("--finegrained", action="store_true", help="MV_FLAG_FINEGRAINED_PEER_BUFFERS: the buffers other ranks store into allocated fine-grained (what it costs on one GPU: profiles/r05_finegrained.txt)")
     p.add_argument("--steady-frames", type=int, default=400, help="frames of the steady-state pass behind the timed region (its own barrier-to-barrier time: `steady_state_ms_per_step`); 0 = none")
     p.add_argument("--cull-on-view-stream", action="store_true", help="MV_FLAG_CULL_ON_VIEW_STREAM: every frame's upload and cull on its own view stream (no stream of their own); "
@@ -393,7 +394,7 @@ def main():
     # N > 1: the per-frame protocol runs inside the library (mv_dist_frame); torch.distributed only distributes the RCCL ids
     phase("dist-init")
     exchange = D.init_frame_loop(caster, prefer_rccl=transport in ("rccl", "rccl-single-stream"), prefer_peer=transport == "peer",
-                                 peer_timeout_ms=20000, peer_rows_to_root=rows_to_root, peer_fold=peer_fold, peer_acquire=not args.peer_no_acquire) if world > 1 else None
+                                 peer_timeout_ms=20000, peer_rows_to_root=rows_to_root, peer_fold=peer_fold, peer_acquire=not args.peer_no_acquire, peer_push_cells=args.peer_push_cells) if world > 1 else None
     if world > 1 and transport == "peer" and exchange != "peer":
         # (asked for by name or by the ladder: a rank that could not attach it leaves, and the supervisors move everybody to the next level)
         print(f"bench.py: the peer-store transport could not be attached (got {exchange})", file=sys.stderr)

@@ -72,7 +72,7 @@ int main(int argc, char** argv)
 			rc.SetAmbient(ac, 2.0f * 3.14159265f);
 			if (peer)
 			{
-				if (mv_dist_init_peer(rc.Context(), nullptr, MV_DIST_PEER_LOOPBACK | (noFold ? MV_DIST_PEER_NO_FOLD : 0u) | ((root || rootB) ? MV_DIST_PEER_ROWS_TO_ROOT : 0u) | (std::getenv("RANK_COST_DEAL_VOLUMES") ? MV_DIST_PEER_DEAL_VOLUMES : 0u) | (std::getenv("RANK_COST_DEAL_TILES") ? MV_DIST_PEER_DEAL_TILES : 0u) | (std::getenv("RANK_COST_NO_ACQUIRE") ? MV_DIST_PEER_NO_ACQUIRE : 0u)) != MV_OK || mv_dist_selftest(rc.Context()) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
+				if (mv_dist_init_peer(rc.Context(), nullptr, MV_DIST_PEER_LOOPBACK | (noFold ? MV_DIST_PEER_NO_FOLD : 0u) | ((root || rootB) ? MV_DIST_PEER_ROWS_TO_ROOT : 0u) | (std::getenv("RANK_COST_DEAL_VOLUMES") ? MV_DIST_PEER_DEAL_VOLUMES : 0u) | (std::getenv("RANK_COST_DEAL_TILES") ? MV_DIST_PEER_DEAL_TILES : 0u) | (std::getenv("RANK_COST_NO_ACQUIRE") ? MV_DIST_PEER_NO_ACQUIRE : 0u) | (std::getenv("RANK_COST_PUSH_CELLS") ? MV_DIST_PEER_PUSH_CELLS : 0u)) != MV_OK || mv_dist_selftest(rc.Context()) != MV_OK) { std::fprintf(stderr, "%s\n", rc.LastError()); return 5; }
 			}
 			else
 			{

@@ -372,6 +372,11 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * the workgroup's plain loads of what the flags announce -- the default.  MV_DIST_PEER_NO_ACQUIRE leaves it out (round 4's form: it rested
  * on the rotation of the buffers alone), for A/B timing. */
 #define MV_DIST_PEER_NO_ACQUIRE 64u
+/* A frame's relit light map travels as PLAIN R11G11B10F texels (4 bytes; the device keeps light maps as quad-replicated cells of 16) into a
+ * staging map per frame slot on every rank, and every rank rebuilds the cells of the other ranks' layers itself -- workgroups of the view-march
+ * launch between the ones that push and the ones that march (waits as kernels: a kernel of its own): a rank of eight sends 3.1 MB of light per
+ * C3 frame instead of 12.4.  The default.  MV_DIST_PEER_PUSH_CELLS pushes whole cells (round 4), for A/B timing. */
+#define MV_DIST_PEER_PUSH_CELLS 128u
 int mv_dist_peer_export(mv_ctx* ctx, void* out /* MV_DIST_PEER_BYTES */);
 int mv_dist_init_peer(mv_ctx* ctx, const void* all /* shard_count x MV_DIST_PEER_BYTES in rank order; NULL with MV_DIST_PEER_LOOPBACK */, uint32_t flags);
 int mv_dist_set_peer_timeout_ms(mv_ctx* ctx, uint32_t ms);

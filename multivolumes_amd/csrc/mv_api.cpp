@@ -622,14 +622,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	}
 	ctx->set = (uint32_t)(ctx->frame % ctx->numOutSets);
 	ctx->st.frameTag = (uint32_t)ctx->frame;
-	if (ctx->latEvery)
-	{
-		// (latency sampling: the slot's previous sample is over -- its frame was numSlots frames ago -- or never finished being taken)
-		latencyHarvest(ctx, ctx->slot);
-		mv_ctx::LatencySample& l = ctx->lat[ctx->slot];
-		l.armed = ctx->frame % ctx->latEvery == 0u;
-		if (l.armed) { l.doneNs.store(0, std::memory_order_relaxed); l.startNs.store(hostNowNs(), std::memory_order_relaxed); }
-	}
+	latencyBegin(ctx, ctx->slot, ctx->frame);
 	applyParity(ctx);
 	// the slot's previous user (ctx->numSlots frames ago) must be done with it; volume producers on stream B must have finished
 	{
@@ -1116,7 +1109,9 @@ int mv_set_latency_sampling(mv_ctx* ctx, uint32_t every_n_frames)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) { latencyHarvest(ctx, i); ctx->lat[i].armed = false; }
+	latencyHarvest(ctx);
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) ctx->latOfSlot[i] = -1;
+	for (uint32_t i = 0; i < mv_ctx::kLatencyPool; ++i) ctx->lat[i].busy = false;
 	ctx->latEvery = every_n_frames;
 	return MV_OK;
 }
@@ -1125,7 +1120,7 @@ int mv_get_latency(mv_ctx* ctx, double* mean_ms, double* max_ms, uint64_t* sampl
 {
 	if (!ctx || !mean_ms || !max_ms || !samples) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// (the frames in flight finish; the host functions behind them have run)
-	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) latencyHarvest(ctx, i);
+	latencyHarvest(ctx);
 	*samples = ctx->latCount; *mean_ms = ctx->latCount ? ctx->latSumMs / (double)ctx->latCount : 0.0; *max_ms = ctx->latMaxMs;
 	if (reset) { ctx->latSumMs = 0.0; ctx->latMaxMs = 0.0; ctx->latCount = 0; }
 	return MV_OK;

@@ -142,6 +142,10 @@ struct DistState
 	std::vector<void*> peerMapped;				// IPC mappings of the other ranks' buffers (closed by distRelease)
 	unsigned long long** dPeerFlags = nullptr;	// device tables, [world] each: every rank's flag block ...
 	uint4** dPeerLight = nullptr;				// ... light buffers ...
+	uint32_t* lightPlain = nullptr;				// (plain light push) this rank's staging maps: numSlots x L^3 plain R11G11B10F texels, the slot of frame k at (k's frame slot) x L^3
+	uint32_t** dPeerLightPlain = nullptr;		// ... every rank's
+	uint32_t peerRebuildBlocks = 32;			// (plain light push) workgroups of a view-march launch that rebuild the other ranks' cells (mv_dist_init_peer: 256 for ranks that own their GPU, 32 for ranks that share one)
+	bool peerPlainLight = true;					// a frame's relit map travels as plain texels and the receivers rebuild the cells (false: MV_DIST_PEER_PUSH_CELLS, round 4's whole cells)
 	uint2** dPeerCube[kMaxOutSets] = {};		// ... and, per output set, cube maps, cube depths, frame buffer
 	float** dPeerDepth[kMaxOutSets] = {};
 	uint2** dPeerComposite[kMaxOutSets] = {};
@@ -237,8 +241,10 @@ struct mv_ctx
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
 	// Frame latency, sampled (mv_set_latency_sampling): the host's clock when a frame's constants are handed over (mv_update_frame /
 	// mv_dist_frame) and when the last kernel of that frame has finished -- a host function behind the record of the frame's "done" event.
-	struct LatencySample { std::atomic<long long> startNs{0}, doneNs{0}; bool armed = false; };
-	LatencySample lat[kMaxFrameSlots];
+	struct LatencySample { std::atomic<long long> startNs{0}, doneNs{0}; bool busy = false; };
+	static constexpr uint32_t kLatencyPool = 64;	// samples in flight (a frame slot is reused by the HOST before the GPU is done with the frame it held: samples live apart from slots)
+	LatencySample lat[kLatencyPool];
+	int latOfSlot[kMaxFrameSlots];					// the sample of the frame a slot holds, or -1
 	uint32_t latEvery = 0;
 	double latSumMs = 0.0, latMaxMs = 0.0;
 	uint64_t latCount = 0;
@@ -390,8 +396,10 @@ void applyParity(mv_ctx* ctx)
 		const DistState* d = ctx->dist;
 		st.peerCount = st.shardCount; st.peerLight = d->dPeerLight;
 		st.peerCubeMaps = d->dPeerCube[ctx->set]; st.peerCubeDepths = d->dPeerDepth[ctx->set]; st.peerComposite = d->dPeerComposite[ctx->set];
+		st.lightPlainOff = (uint64_t)ctx->slot * st.L * st.L * st.L;
+		st.lightPlain = (d->peerPlainLight && d->lightPlain) ? d->lightPlain + st.lightPlainOff : nullptr; st.peerLightPlain = d->dPeerLightPlain;
 	}
-	else { st.peerCount = 0u; st.peerLight = nullptr; st.peerCubeMaps = nullptr; st.peerCubeDepths = nullptr; st.peerComposite = nullptr; }
+	else { st.peerCount = 0u; st.peerLight = nullptr; st.peerCubeMaps = nullptr; st.peerCubeDepths = nullptr; st.peerComposite = nullptr; st.lightPlain = nullptr; st.peerLightPlain = nullptr; st.lightPlainOff = 0; }
 	st.tileOrder = ctx->orderTiles ? f.tileOrder : nullptr;
 	st.binCursor = ctx->orderTiles ? f.binCounts : nullptr;
 	st.orderCap = st.maxTiles + st.maxScreenTiles + 1u;
@@ -483,19 +491,36 @@ hipError_t stageBBegin(mv_ctx* ctx)
 // (latency sampling) behind a record of slot's "done" event on stream s: the host's clock at that point of the stream
 inline long long hostNowNs() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline void latencyDoneFn(void* p) { static_cast<mv_ctx::LatencySample*>(p)->doneNs.store(hostNowNs(), std::memory_order_release); }
-inline void latencyHarvest(mv_ctx* ctx, uint32_t slot)
+inline void latencyHarvest(mv_ctx* ctx)
 {
-	mv_ctx::LatencySample& l = ctx->lat[slot];
-	const long long done = l.doneNs.load(std::memory_order_acquire);
-	if (!l.armed || !done) return;
-	const double ms = (double)(done - l.startNs.load(std::memory_order_relaxed)) * 1e-6;
-	ctx->latSumMs += ms; ctx->latMaxMs = ms > ctx->latMaxMs ? ms : ctx->latMaxMs; ++ctx->latCount;
-	l.armed = false; l.doneNs.store(0, std::memory_order_relaxed);
+	for (uint32_t i = 0; i < mv_ctx::kLatencyPool; ++i)
+	{
+		mv_ctx::LatencySample& l = ctx->lat[i];
+		const long long done = l.doneNs.load(std::memory_order_acquire);
+		if (!l.busy || !done) continue;
+		const double ms = (double)(done - l.startNs.load(std::memory_order_relaxed)) * 1e-6;
+		ctx->latSumMs += ms; ctx->latMaxMs = ms > ctx->latMaxMs ? ms : ctx->latMaxMs; ++ctx->latCount;
+		l.busy = false; l.doneNs.store(0, std::memory_order_relaxed);
+	}
+}
+// a new frame in `slot`: every latEvery-th one is sampled, if a sample is free
+inline void latencyBegin(mv_ctx* ctx, uint32_t slot, uint64_t frame)
+{
+	ctx->latOfSlot[slot] = -1;
+	if (!ctx->latEvery || frame % ctx->latEvery != 0u) return;
+	latencyHarvest(ctx);
+	for (uint32_t i = 0; i < mv_ctx::kLatencyPool; ++i)
+		if (!ctx->lat[i].busy)
+		{
+			ctx->lat[i].busy = true; ctx->lat[i].doneNs.store(0, std::memory_order_relaxed); ctx->lat[i].startNs.store(hostNowNs(), std::memory_order_relaxed);
+			ctx->latOfSlot[slot] = (int)i;
+			return;
+		}
 }
 inline hipError_t latencyMark(mv_ctx* ctx, uint32_t slot, hipStream_t s)
 {
-	if (!ctx->latEvery || !ctx->lat[slot].armed) return hipSuccess;
-	return hipLaunchHostFunc(s, latencyDoneFn, &ctx->lat[slot]);	// (a frame may be marked twice -- behind its march and behind its composite: the later clock stands)
+	if (!ctx->latEvery || ctx->latOfSlot[slot] < 0) return hipSuccess;
+	return hipLaunchHostFunc(s, latencyDoneFn, &ctx->lat[ctx->latOfSlot[slot]]);	// (a frame may be marked twice -- behind its march and behind its composite: the later clock stands)
 }
 hipError_t stageBDone(mv_ctx* ctx)
 {

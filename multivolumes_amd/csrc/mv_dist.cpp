@@ -22,7 +22,7 @@ void mvi::distRelease(mv_ctx* ctx)
 	// the current frame's device state named buffers of the loop (the pinned exchange report, the peer tables): a stage called on it
 	// now would write freed memory -- the next mv_update_frame starts clean
 	ctx->st.exchangeReport = nullptr;
-	ctx->st.peerCount = 0u; ctx->st.peerLight = nullptr; ctx->st.peerCubeMaps = nullptr; ctx->st.peerCubeDepths = nullptr; ctx->st.peerComposite = nullptr;
+	ctx->st.peerCount = 0u; ctx->st.peerLight = nullptr; ctx->st.peerCubeMaps = nullptr; ctx->st.peerCubeDepths = nullptr; ctx->st.peerComposite = nullptr; ctx->st.lightPlain = nullptr; ctx->st.peerLightPlain = nullptr;
 	ctx->haveCull = false; ctx->haveFrame = false;
 }
 
@@ -658,7 +658,7 @@ int mv_dist_peer_info(mv_ctx* ctx, uint32_t* out)
 	const DistState* d = ctx->dist;
 	if (!d || d->transport != 3) return MV_OK;
 	out[0] = d->peerFold ? 1u : 0u; out[1] = d->peerAcquire ? 1u : 0u; out[2] = d->peerRowsRoot ? 1u : 0u; out[3] = d->peerDealVolumes ? 1u : 0u;
-	out[4] = (uint32_t)sizeof(uint4);	// bytes a rank pushes per texel of its share of the relit light map
+	out[4] = (d->peerPlainLight && d->lightPlain) ? (uint32_t)sizeof(uint32_t) : (uint32_t)sizeof(uint4);	// bytes a rank pushes per texel of its share of the relit light map
 	out[5] = (uint32_t)d->peerFlagsKind; out[6] = d->peerStaleWords; out[7] = d->peerFirstReadBad;
 	return MV_OK;
 }

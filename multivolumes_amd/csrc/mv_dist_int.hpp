@@ -12,8 +12,8 @@ MV_INTERNAL int distCommonInit(mv_ctx* ctx);	// what every transport's init ends
 
 // ---- mv_dist_peer.cpp ----
 // stages a rank raises a flag for (rows of the flag block = stage x chain) and the launches that carry folded waits / signals
-enum { kStageLight = 0, kStageCube = 1, kStageRows = 2, kStageDone = 3 };
-enum { kFoldLight = 0, kFoldView = 1, kFoldComposite = 2 };
+enum { kStageLight = 0, kStageCube = 1, kStageRows = 2, kStageDone = 3, kStageRebuilt = 4 /* local: this rank has rebuilt the light cells of the other ranks' layers from their texels */ };
+enum { kFoldLight = 0, kFoldView = 1, kFoldComposite = 2, kFoldRebuild = 3 };
 struct PeerWaits { uint32_t n = 0; int stage[8]; uint64_t frame[8]; };
 MV_INTERNAL mv::PeerSync peerSyncBase(mv_ctx* ctx, uint32_t frameTag, uint32_t slot);
 MV_INTERNAL void foldBase(mv_ctx* ctx, DeviceState& st, uint32_t kind, uint64_t frame, uint32_t frameTag, uint32_t slot);

@@ -10,7 +10,7 @@ using namespace mvi;
 // ---------------------------------------------------------------------------------------------
 
 // what a rank tells the others about itself (MV_DIST_PEER_BYTES)
-constexpr uint32_t kPeerBuffers = 2u + 3u * kMaxOutSets;	// flag block, light buffers, then per output set: cube maps, cube depths, frame buffer
+constexpr uint32_t kPeerBuffers = 3u + 3u * kMaxOutSets;	// flag block, light buffers, then per output set: cube maps, cube depths, frame buffer; last: the staging maps of the plain light push
 struct PeerBlob
 {
 	uint32_t magic, version, rank, world;
@@ -38,6 +38,7 @@ static void peerBufferList(mv_ctx* ctx, void** ptr, uint64_t* bytes)
 		ptr[3 + 3 * s] = ctx->ob[s].cubeDepths; bytes[3 + 3 * s] = (uint64_t)st.V * chain * sizeof(float);
 		ptr[4 + 3 * s] = ctx->ob[s].composite; bytes[4 + 3 * s] = (uint64_t)st.W * compositeRows(st) * sizeof(uint2);
 	}
+	ptr[kPeerBuffers - 1u] = ctx->dist->lightPlain; bytes[kPeerBuffers - 1u] = ctx->dist->lightPlain ? (uint64_t)ctx->numSlots * L3 * sizeof(uint32_t) : 0u;
 }
 
 mv::PeerSync peerSyncBase(mv_ctx* ctx, uint32_t frameTag, uint32_t slot)
@@ -75,9 +76,12 @@ void foldSignal(mv_ctx* ctx, DeviceState& st, int stage, uint64_t frame)
 	st.fold.signalRow[st.fold.nSignal] = (uint32_t)stage * mv::kPeerMaxChains + (uint32_t)(frame % ctx->dist->numChains);
 	st.fold.signalValue[st.fold.nSignal++] = frame;
 }
-void foldClear(DeviceState& st) { st.fold.nWait = 0u; st.fold.nSignal = 0u; st.fold.checkChain = 0xffffffffu; st.fold.checkCompare = 0u; st.fold.stores = 0u; st.fold.pushBlocks = 0u; }
+void foldClear(DeviceState& st) { st.fold.nWait = 0u; st.fold.nSignal = 0u; st.fold.checkChain = 0xffffffffu; st.fold.checkCompare = 0u; st.fold.stores = 0u; st.fold.pushBlocks = 0u; st.fold.rebuildBlocks = 0u; st.fold.waitLocal = 0u; }
 #ifndef MV_PEER_LIGHT_PUSH_BLOCKS
 #define MV_PEER_LIGHT_PUSH_BLOCKS 224
+#endif
+#ifndef MV_PEER_REBUILD_BLOCKS
+#define MV_PEER_REBUILD_BLOCKS 128
 #endif
 constexpr uint32_t kPeerLightPushBlocks = MV_PEER_LIGHT_PUSH_BLOCKS;	// workgroups (of the tile march's 128 threads) in front of a folded view march that push the light layers: 16 bytes x 4 per thread cover 1.8 MB
 
@@ -164,7 +168,7 @@ int peerLight(mv_ctx* ctx)
 	{
 		// folded: the push is the leading workgroups of this frame's view march, the next kernel on this stream (peerBeforeView)
 		MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], S));	// (this rank's layers are in place: what its own frames on the other streams order themselves by)
-		d->bytes += (size_t)ctx->st.L * ctx->st.L * ctx->st.L * sizeof(uint4) / ctx->st.shardCount * (ctx->st.shardCount - 1u);
+		d->bytes += (size_t)ctx->st.L * ctx->st.L * ctx->st.L * (ctx->st.lightPlain ? sizeof(uint32_t) : sizeof(uint4)) / ctx->st.shardCount * (ctx->st.shardCount - 1u);
 		return MV_OK;
 	}
 	DeviceState sp = peerPushState(ctx, ctx->st, kFoldLight, k, ctx->st.frameTag, ctx->slot);
@@ -173,7 +177,7 @@ int peerLight(mv_ctx* ctx)
 	mv::launchPeerPushLight(S, sp);
 	MV_HIP(ctx, hipGetLastError());
 	MV_HIP(ctx, evRecord(ctx, ctx->evLight[ctx->slot], S));	// (this rank's layers are in place and on their way: what the frames behind it on the other streams order themselves by; the other ranks' layers are the flags')
-	d->bytes += (size_t)ctx->st.L * ctx->st.L * ctx->st.L * sizeof(uint4) / ctx->st.shardCount * (ctx->st.shardCount - 1u);
+	d->bytes += (size_t)ctx->st.L * ctx->st.L * ctx->st.L * (ctx->st.lightPlain ? sizeof(uint32_t) : sizeof(uint4)) / ctx->st.shardCount * (ctx->st.shardCount - 1u);
 	return MV_OK;
 }
 
@@ -183,6 +187,8 @@ int peerBeforeView(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
 	if (ctx->st.shardCount <= 1u) return MV_OK;
+	const bool plain = ctx->st.lightPlain != nullptr;
+	const uint32_t C = d->numChains, chain = (uint32_t)(d->peerFrame % C);
 	PeerWaits w;
 	if (d->peerFold)
 	{
@@ -191,16 +197,43 @@ int peerBeforeView(mv_ctx* ctx)
 		// it -- on the other streams -- are waited for by a kernel of one wavefront in front of the launch, as batchClose does: their columns
 		// include THIS rank's, raised by the push workgroups of launches on other streams, which a march whose every workgroup spins in its
 		// prologue could keep from ever being dispatched (round 4's form) -- and every spinning workgroup would end its wait with
-		// an invalidate of its CU's L1 (profiles/r05_peer_acquire.txt).
+		// an invalidate of its CU's L1 (profiles/r05_peer_acquire.txt).  (Plain light push: what the older frames' readers need is this rank's
+		// REBUILT cells -- the local row its rebuild workgroups raise, which implies that the texels had landed.)
 		mv::PeerSync a = peerSyncBase(ctx, ctx->st.frameTag, ctx->slot);
-		for (uint32_t j = 1; j < d->numChains; ++j) if (d->peerFrame > j) { a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + (uint32_t)((d->peerFrame - j) % d->numChains); a.waitValue[a.nWait++] = d->peerFrame - j; }
+		const uint32_t stage = plain ? kStageRebuilt : kStageLight;
+		for (uint32_t j = 1; j < C; ++j) if (d->peerFrame > j) { a.waitRow[a.nWait] = stage * mv::kPeerMaxChains + (uint32_t)((d->peerFrame - j) % C); a.waitValue[a.nWait++] = d->peerFrame - j; }
+		a.waitLocal = plain ? 1u : 0u;
 		if (a.nWait) { mv::launchPeerSync(streamB(ctx), a); MV_HIP(ctx, hipGetLastError()); }
 		w.stage[w.n] = kStageLight; w.frame[w.n++] = d->peerFrame;
+		if (plain) { w.stage[w.n] = kStageRebuilt; w.frame[w.n++] = d->peerFrame; }
 	}
 	else
-		for (uint32_t j = 0; j < d->numChains; ++j) if (d->peerFrame > j) { w.stage[w.n] = kStageLight; w.frame[w.n++] = d->peerFrame - j; }
-	const int rc = peerWaitFor(ctx, streamB(ctx), ctx->st, kFoldView, w, d->peerFrame, ctx->st.frameTag, ctx->slot, true);
+	{
+		// waits as kernels: every rank's layers (texels) of this frame's map, then -- plain light push -- this rank's rebuild of them as a kernel
+		// of its own, which raises the local row; the maps relit in the C - 1 frames before are waited for by their (local) rebuilt rows
+		if (plain)
+		{
+			mv::PeerSync a = peerSyncBase(ctx, ctx->st.frameTag, ctx->slot);
+			a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + chain; a.waitValue[a.nWait++] = d->peerFrame;
+			if (d->cullCrosscheck) a.checkChain = chain;
+			mv::launchPeerSync(streamB(ctx), a);
+			DeviceState sr = ctx->st;
+			foldBase(ctx, sr, kFoldRebuild, d->peerFrame, ctx->st.frameTag, ctx->slot);
+			sr.fold.rebuildRow = kStageRebuilt * mv::kPeerMaxChains + chain; sr.fold.rebuildValue = d->peerFrame;
+			sr.fold.rebuildCounter = d->dPeerCounters + kFoldRebuild * mv::kPeerMaxChains + chain;
+			mv::launchPeerRebuildLight(streamB(ctx), sr);
+			MV_HIP(ctx, hipGetLastError());
+			mv::PeerSync b = peerSyncBase(ctx, ctx->st.frameTag, ctx->slot);
+			for (uint32_t j = 1; j < C; ++j) if (d->peerFrame > j) { b.waitRow[b.nWait] = kStageRebuilt * mv::kPeerMaxChains + (uint32_t)((d->peerFrame - j) % C); b.waitValue[b.nWait++] = d->peerFrame - j; }
+			b.waitLocal = 1u;
+			if (b.nWait) { mv::launchPeerSync(streamB(ctx), b); MV_HIP(ctx, hipGetLastError()); }
+		}
+		else
+			for (uint32_t j = 0; j < C; ++j) if (d->peerFrame > j) { w.stage[w.n] = kStageLight; w.frame[w.n++] = d->peerFrame - j; }
+	}
+	const int rc = peerWaitFor(ctx, streamB(ctx), ctx->st, kFoldView, w, d->peerFrame, ctx->st.frameTag, ctx->slot, !(plain && !d->peerFold));
 	if (rc != MV_OK) return rc;
+	if (d->peerFold && plain) ctx->st.fold.waitLocal = 2u;	// (row 1 of the march's waits is this rank's own)
 	// ...and what the march's last workgroup raises, behind the texels it stored into every rank's cube maps
 	if (!d->peerFold) foldBase(ctx, ctx->st, kFoldView, d->peerFrame, ctx->st.frameTag, ctx->slot);	// (folded: peerWaitFor has filled the launch's fields in)
 	foldSignal(ctx, ctx->st, kStageCube, d->peerFrame);
@@ -213,6 +246,12 @@ int peerBeforeView(mv_ctx* ctx)
 		ctx->st.fold.pushValue = d->peerFrame;
 		ctx->st.fold.pushCounter = d->dPeerCounters + kFoldLight * mv::kPeerMaxChains + (uint32_t)(d->peerFrame % d->numChains);
 		ctx->st.fold.pushCheckChain = d->cullCrosscheck ? (uint32_t)(d->peerFrame % d->numChains) : 0xffffffffu;
+		if (plain)
+		{
+			ctx->st.fold.rebuildBlocks = d->peerRebuildBlocks;
+			ctx->st.fold.rebuildRow = kStageRebuilt * mv::kPeerMaxChains + chain; ctx->st.fold.rebuildValue = d->peerFrame;
+			ctx->st.fold.rebuildCounter = d->dPeerCounters + kFoldRebuild * mv::kPeerMaxChains + chain;
+		}
 	}
 	return MV_OK;
 }
@@ -254,7 +293,7 @@ int peerSelfTest(mv_ctx* ctx)
 	const size_t words = std::min<size_t>(65536, (size_t)ctx->st.W * compositeRows(ctx->st) / world);
 	MV_REQUIRE(ctx, words >= 1, MV_ERR_RANGE, "self-test region");
 	MV_HIP(ctx, hipMemsetAsync(d->dPeerMismatch, 0, 4, s));
-	const uint32_t row = 4u * mv::kPeerMaxChains;	// the self-test's own row
+	const uint32_t row = mv::kPeerStages * mv::kPeerMaxChains;	// the self-test's own row
 	for (uint32_t round = 0; round < 2u; ++round)
 	{
 		const unsigned long long base = 2ull * (d->peerSelfTests++);
@@ -304,7 +343,7 @@ int peerCoherenceTest(mv_ctx* ctx, bool acquire, uint32_t* stale, uint32_t* firs
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	hipStream_t s = ctx->streamB[0];
 	const size_t words = std::min<size_t>(65536, (size_t)ctx->st.W * compositeRows(ctx->st) / world);
-	const uint32_t row = 4u * mv::kPeerMaxChains;
+	const uint32_t row = mv::kPeerStages * mv::kPeerMaxChains;
 	// (everybody is past whatever it did to its buffer before -- the clearing at the end of the test in front of this one)
 	{
 		const unsigned long long b0 = 2ull * (d->peerSelfTests++);
@@ -390,6 +429,14 @@ int mv_dist_peer_export(mv_ctx* ctx, void* out)
 	}
 	d->peerFlags = static_cast<unsigned long long*>(flags);
 	if (hipMemset(flags, 0, mv::kPeerFlagBytes) != hipSuccess) return bail(fail(ctx, MV_ERR_HIP, "clearing the peer-store flag block"));
+	{
+		// the staging maps of the plain light push: one per frame slot (a slot is reused numSlots frames later: further apart than the light
+		// buffers, whose "done" flags already hold a rank back from writing into what another still reads)
+		uint8_t* raw = nullptr;
+		const int rc = distAlloc(ctx, &raw, (size_t)ctx->numSlots * ctx->st.L * ctx->st.L * ctx->st.L * sizeof(uint32_t), ctx->stream);
+		if (rc != MV_OK) return bail(rc);
+		d->lightPlain = reinterpret_cast<uint32_t*>(raw);
+	}
 	PeerBlob b;
 	memset(&b, 0, sizeof(b));
 	b.magic = kPeerMagic; b.version = MV_ABI_VERSION; b.rank = ctx->st.shardIndex; b.world = ctx->st.shardCount;
@@ -498,9 +545,10 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 			d->dPeerDepth[s] = reinterpret_cast<float**>(dev + (size_t)(3 + 3 * s) * world);
 			d->dPeerComposite[s] = reinterpret_cast<uint2**>(dev + (size_t)(4 + 3 * s) * world);
 		}
+		d->dPeerLightPlain = reinterpret_cast<uint32_t**>(dev + (size_t)(kPeerBuffers - 1u) * world);
 		if ((rc = distAlloc(ctx, &raw, 64, ctx->stream)) != MV_OK) return bail(rc);
 		d->dPeerMismatch = reinterpret_cast<uint32_t*>(raw);
-		if ((rc = distAlloc(ctx, &raw, 3u * mv::kPeerMaxChains * sizeof(uint32_t), ctx->stream)) != MV_OK) return bail(rc);
+		if ((rc = distAlloc(ctx, &raw, 4u * mv::kPeerMaxChains * sizeof(uint32_t), ctx->stream)) != MV_OK) return bail(rc);
 		d->dPeerCounters = reinterpret_cast<uint32_t*>(raw);
 	}
 	d->peerLoopback = loopback;
@@ -516,6 +564,10 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 		d->peerFold = true;
 	}
 	d->peerAcquire = !(flags & MV_DIST_PEER_NO_ACQUIRE);
+	d->peerPlainLight = !(flags & MV_DIST_PEER_PUSH_CELLS);
+	// (plain light push) the rebuild workgroups of a launch spin until every rank's texels have landed: many on a GPU of their own (0.77 M
+	// cells at L = 96: twelve iterations of four per thread; 64: 0.0685, 128: 0.0658, 256: 0.0664 ms per frame of a rank of eight), few where ranks SHARE a GPU (tests), which must leave room for the workgroups they wait for
+	d->peerRebuildBlocks = (loopback || distinctDevices) ? MV_PEER_REBUILD_BLOCKS : 32u;
 	d->peerRowsRoot = (flags & MV_DIST_PEER_ROWS_TO_ROOT) != 0;
 	d->peerDealVolumes = (flags & MV_DIST_PEER_DEAL_VOLUMES) ? true : (flags & MV_DIST_PEER_DEAL_TILES) ? false : ctx->framesPerLaunch == 1u;	// (see the header: tiles pay with several frames per launch)
 	d->peerFrame = 0;
@@ -736,7 +788,7 @@ int batchClose(mv_ctx* ctx)
 		endStage(ctx, evt, S);
 		MV_HIP(ctx, hipGetLastError());
 		for (uint32_t i = 0; i < n; ++i) MV_HIP(ctx, evRecord(ctx, ctx->evLight[d->cur[i].slot], S));
-		if (peers) d->bytes += (size_t)n * last.st.L * last.st.L * last.st.L * sizeof(uint4) / last.st.shardCount * (last.st.shardCount - 1u);
+		if (peers) d->bytes += (size_t)n * last.st.L * last.st.L * last.st.L * (last.st.lightPlain ? sizeof(uint32_t) : sizeof(uint4)) / last.st.shardCount * (last.st.shardCount - 1u);
 	}
 	// ---- view marches ----
 	{
@@ -771,7 +823,14 @@ int batchClose(mv_ctx* ctx)
 			sts[i].fold.checkInfo = ctx->fb[last.slot].batchInfo;
 			if (peers)
 			{
-				foldWait(ctx, sts[i], kStageLight, J);	// (row 0 = this group's own: waited for by the tiles that read a map relit in it; the older groups': the kernel below)
+				foldWait(ctx, sts[i], kStageLight, J);	// (row 0 = this group's own: waited for by the tiles that read a map relit in it -- plain light push: by the rebuild workgroups, and the tiles wait for THEIR row, 1; the older groups': the kernel below)
+				if (sts[i].lightPlain)
+				{
+					foldWait(ctx, sts[i], kStageRebuilt, J); sts[i].fold.waitLocal = 2u;
+					sts[i].fold.rebuildBlocks = d->peerRebuildBlocks;
+					sts[i].fold.rebuildRow = kStageRebuilt * mv::kPeerMaxChains + chain; sts[i].fold.rebuildValue = J;
+					sts[i].fold.rebuildCounter = d->dPeerCounters + kFoldRebuild * mv::kPeerMaxChains + chain;
+				}
 				if (d->cullCrosscheck) { sts[i].fold.checkChain = chain; sts[i].fold.checkCompare = 1u; }
 				foldSignal(ctx, sts[i], kStageCube, J);
 				sts[i].fold.stores = 1u;
@@ -788,7 +847,9 @@ int batchClose(mv_ctx* ctx)
 		if (peers && J > 1u)
 		{
 			mv::PeerSync a = peerSyncBase(ctx, last.st.frameTag, last.slot);
-			for (uint32_t c = 1; c < C; ++c) if (J > c) { a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + (uint32_t)((J - c) % C); a.waitValue[a.nWait++] = J - c; }
+			const bool plain = last.st.lightPlain != nullptr;	// (then: this rank's rebuilt cells of those maps -- local rows)
+			for (uint32_t c = 1; c < C; ++c) if (J > c) { a.waitRow[a.nWait] = (plain ? kStageRebuilt : kStageLight) * mv::kPeerMaxChains + (uint32_t)((J - c) % C); a.waitValue[a.nWait++] = J - c; }
+			a.waitLocal = plain ? 1u : 0u;
 			if (a.nWait) { mv::launchPeerSync(S, a); MV_HIP(ctx, hipGetLastError()); }
 		}
 #endif
@@ -800,7 +861,7 @@ int batchClose(mv_ctx* ctx)
 		mv::launchMarchTilesBatch(S, main, n, tiles, beyond);
 		if (overflow)
 		{
-			for (uint32_t i = 0; i < n; ++i) { sts[i].fold.nWait = 0u; sts[i].fold.pushBlocks = 0u; }
+			for (uint32_t i = 0; i < n; ++i) { sts[i].fold.nWait = 0u; sts[i].fold.pushBlocks = 0u; sts[i].fold.rebuildBlocks = 0u; }
 			mv::launchMarchTilesOverflowBatch(S, sts, n, beyond);
 		}
 		endStage(ctx, evt, S);

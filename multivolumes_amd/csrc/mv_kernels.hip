@@ -1186,6 +1186,7 @@ __device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* 
 		const vec3 result = v3(shadow * lightColor.x + ambient.x, shadow * lightColor.y + ambient.y, shadow * lightColor.z + ambient.z);
 		packed = pack_r11g11b10f(result.x, result.y, result.z);
 		storeLightTexel(reinterpret_cast<uint32_t*>(st.lightTable[volumeId]), L, xx, yy, zz, packed);
+		if (st.lightPlain) st.lightPlain[((size_t)zz * L + yy) * L + xx] = packed;	// (peer stores, plain light push: what the push workgroups send)
 	}
 	if (wordsOut) wordsOut[(size_t)(e - share.lo) * 64u + lane] = packed;
 

@@ -160,6 +160,12 @@ struct DeviceState
 	uint2* const* peerCubeMaps;		// [peerCount] every rank's cube maps of THIS frame's output set
 	float* const* peerCubeDepths;	// [peerCount]
 	uint2* const* peerComposite;	// [peerCount] every rank's frame buffer of this output set
+	// (plain light push, the default) a frame's relit map travels as PLAIN R11G11B10F texels -- 4 bytes each instead of the 16 of a
+	// quad-replicated cell: a rank's share 0.44 MB instead of 1.77 MB per peer at L = 96 -- into a staging map per frame slot on every rank,
+	// and the receiver rebuilds the cells of the other ranks' layers itself (peerRebuildLightRole).  NULL: whole cells are pushed (round 4).
+	uint32_t* lightPlain;			// this rank's staging map of this frame's slot: L^3 words, [z][y][x]
+	uint32_t* const* peerLightPlain;	// [peerCount] every rank's staging maps (all slots); this slot's starts lightPlainOff words in
+	uint64_t lightPlainOff;
 	// ...and the flags that order those stores (mv_peer.hip explains the protocol): a push kernel RAISES, from the last workgroup to
 	// finish, its column of rows in every rank's block; a consumer (light march, view march, composite) may WAIT, in every workgroup's
 	// prologue, until rows of this rank's flag block have reached a frame in every column ("folded" waits: ranks that own their GPU;
@@ -181,6 +187,12 @@ struct DeviceState
 		uint32_t* pushCounter;
 		const uint32_t* checkInfo;				// NULL, or the batchInfo of the launch's last frame: the cull words of all its frames (several frames per launch)
 		uint32_t stores, rowsRoot;				// stores: (view march) this launch also stores its texels into the other ranks' cube maps; rowsRoot: (row push) to rank 0 only
+		// (plain light push) behind the push workgroups, rebuildBlocks workgroups wait for every rank's texels of this frame (waitRow[0]),
+		// rebuild the cells of the other ranks' layers and the last of them raises rebuildRow to rebuildValue in THIS rank's block, column
+		// shardIndex: a local row (bit in waitLocal: only that column is waited for) -- what the tiles that read the relit map wait for
+		uint32_t rebuildBlocks, rebuildRow, waitLocal, rebuildPad;
+		unsigned long long rebuildValue;
+		uint32_t* rebuildCounter;
 		uint32_t waitRow[6], signalRow[2];
 		unsigned long long waitValue[6], signalValue[2];
 	} fold;
@@ -210,7 +222,7 @@ __device__ __forceinline__ void peerStore16(void* p, uint4 v)
 // Every rank owns a block of flags that the OTHER ranks write and only it reads: row r, column p = "rank p has finished stage r.stage of
 // frame <value>", rows = stage x chain (frames k with k % chains == chain follow each other on one stream, so a row only ever grows).
 constexpr uint32_t kPeerMaxRanks = 64;		// ranks of one peer-store group (one node: 8); columns of a flag row
-constexpr uint32_t kPeerStages = 4;			// 0 light share landed, 1 cube faces landed, 2 rows landed, 3 frame done (its buffers may be overwritten)
+constexpr uint32_t kPeerStages = 5;			// 0 light share landed, 1 cube faces landed, 2 rows landed, 3 frame done (its buffers may be overwritten), 4 (local) light cells rebuilt from the landed texels
 constexpr uint32_t kPeerMaxChains = 5;
 constexpr uint32_t kPeerRows = kPeerStages * kPeerMaxChains + 1u;	// + the self-test's row
 constexpr uint32_t kPeerCheckWords = 4;		// what a rank's cull decided for a frame (compared by the light stage's wait)
@@ -243,6 +255,7 @@ __device__ __forceinline__ void peerFoldWait(const DeviceState& st, uint32_t fir
 		for (uint32_t i = threadIdx.x; i < total; i += 64u)
 		{
 			const uint32_t r = firstRow + i / st.peerCount, p = i - (r - firstRow) * st.peerCount;
+			if (((st.fold.waitLocal >> r) & 1u) && p != st.shardIndex) continue;	// (a local row: this rank's own column is the only one ever raised)
 			const unsigned long long* flag = st.fold.myFlags + (size_t)st.fold.waitRow[r] * kPeerMaxRanks + p;
 			while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < st.fold.waitValue[r])
 			{
@@ -292,6 +305,7 @@ __device__ __forceinline__ void peerFoldWaitWave(const DeviceState& st, uint32_t
 	for (uint32_t i = lane; i < total; i += 64u)
 	{
 		const uint32_t r = firstRow + i / st.peerCount, p = i - (r - firstRow) * st.peerCount;
+		if (((st.fold.waitLocal >> r) & 1u) && p != st.shardIndex) continue;
 		const unsigned long long* flag = st.fold.myFlags + (size_t)st.fold.waitRow[r] * kPeerMaxRanks + p;
 		while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < st.fold.waitValue[r])
 		{
@@ -325,7 +339,8 @@ __device__ __forceinline__ void peerFoldWaitWave(const DeviceState& st, uint32_t
 // memory are written through at system scope (peerStore), so "complete" is each wavefront's s_waitcnt vmcnt(0) -- the acknowledgement
 // of a write-through store comes from the memory that owns the address.  Every workgroup counts itself in AFTER that wait; the one
 // that counts last knows every store of the launch has been acknowledged, and only then issues the flag stores.
-__device__ __forceinline__ void peerRaise(const DeviceState& st, uint32_t* counter, uint32_t expected, uint32_t nSignal, const uint32_t* rows, const unsigned long long* values, uint32_t checkChain)
+// (localOnly: the rows are raised in THIS rank's block alone, column shardIndex -- what kernels of this rank wait for, e.g. "light cells rebuilt")
+__device__ __forceinline__ void peerRaise(const DeviceState& st, uint32_t* counter, uint32_t expected, uint32_t nSignal, const uint32_t* rows, const unsigned long long* values, uint32_t checkChain, bool localOnly = false)
 {
 	__shared__ uint32_t sLast;
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");	// this wavefront's stores, into every rank's memory, have been acknowledged
@@ -339,6 +354,13 @@ __device__ __forceinline__ void peerRaise(const DeviceState& st, uint32_t* count
 	}
 	__syncthreads();
 	if (!sLast || threadIdx.x >= 64u) return;
+	if (localOnly)
+	{
+		if (threadIdx.x == 0u)
+			for (uint32_t i = 0; i < nSignal; ++i)
+				__hip_atomic_store(st.fold.myFlags + (size_t)rows[i] * kPeerMaxRanks + st.shardIndex, values[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		return;
+	}
 	// the last workgroup's first wavefront: lane p raises this rank's column in rank p's block (all ranks at once: a write-through
 	// store and its acknowledgement are a trip over the fabric each)
 	for (uint32_t p = threadIdx.x; p < st.peerCount; p += 64u)
@@ -554,7 +576,60 @@ __device__ __forceinline__ void peerPushLightRole(const DeviceState& st, size_t 
 	{
 		const uint32_t layer = lightLayerOfRank(B, st.shardIndex, st.shardCount, i);
 		const uint32_t z0 = layer * 4u, z1 = z0 + 4u < st.L ? z0 + 4u : st.L;
-		peerPushRange(st, st.peerLight, st.lightBuffers, mapOff + (size_t)z0 * slice, (size_t)(z1 - z0) * slice, t, n);
+		if (st.lightPlain)
+		{
+			// plain texels (the light march left them in this rank's staging map beside the cells it wrote): a quarter of the bytes
+			const size_t plane = (size_t)st.L * st.L * sizeof(uint32_t);
+			peerPushRange(st, st.peerLightPlain, st.lightPlain - st.lightPlainOff, st.lightPlainOff * sizeof(uint32_t) + (size_t)z0 * plane, (size_t)(z1 - z0) * plane, t, n);
+		}
+		else peerPushRange(st, st.peerLight, st.lightBuffers, mapOff + (size_t)z0 * slice, (size_t)(z1 - z0) * slice, t, n);
+	}
+}
+
+// (plain light push) the cells of the OTHER ranks' layers of the relit map, rebuilt from the texels those ranks pushed into this rank's
+// staging map: cell (x, y, z) = {t(x, y), t(x + 1, y), t(x, y + 1), t(x + 1, y + 1)} of slice z, +1 clamped -- a cell holds texels of one
+// z only, so a rank's layers rebuild from that rank's texels alone.  Written through (sc0 sc1), like everything another CU's plain loads read
+// behind a flag inside the same launch: plain stores + one agent-scope release per workgroup were measured slower, and slower the more
+// workgroups there are -- every buffer_wbl2 walks its XCD's whole L2 (profiles/r05_plain_light_push.txt).  Thread t of n.
+__device__ __forceinline__ void peerRebuildLightRole(const DeviceState& st, size_t t, size_t n)
+{
+	const uint32_t* cbWords = reinterpret_cast<const uint32_t*>(st.cbPerFrame);
+	const uint32_t frameIdx = cbWords[52];
+	const uint32_t count = st.counters[0];
+	const uint32_t volumeId = count ? st.visibleVolumes[frameIdx % count] : frameIdx % st.V;	// CSRayMarchL.hlsl:29-33
+	uint4* cells = st.lightTable[volumeId];
+	const uint32_t L = st.L, B = (L + 3u) >> 2;
+	const uint32_t per = (B + st.shardCount - 1u) / st.shardCount;
+	const size_t plane = (size_t)L * L;
+	// (slabs: this rank's layers are [first, first + mine); everything else belongs to the others)
+	const uint32_t mine = lightLayersOfRank(B, st.shardIndex, st.shardCount), first = MV_LIGHT_LAYERS_INTERLEAVED ? 0u : st.shardIndex * per;
+	const uint32_t z0m = first * 4u, z1m = (first + mine) * 4u < L ? (first + mine) * 4u : L;
+	const size_t before = (size_t)(MV_LIGHT_LAYERS_INTERLEAVED ? 0u : z0m) * plane, total = (size_t)L * plane - (MV_LIGHT_LAYERS_INTERLEAVED ? 0u : (size_t)(z1m - z0m) * plane);
+	// Consecutive lanes take consecutive cells (every load and the 16-byte store of a wavefront are contiguous), four cells per thread and
+	// iteration with all sixteen loads in front of the four stores: vmcnt counts loads and stores in order, so a thread's next loads queue
+	// behind its stores -- one cell per iteration with write-through stores ran at a store acknowledgement per cell, 95 cells per thread
+	// (profiles/r05_plain_light_push.txt)
+	// (32-bit indices: L <= 640 keeps L^3 below 2^28, and a 64-bit division per cell cost more than the cell)
+	const uint32_t total32 = (uint32_t)total, before32 = (uint32_t)before, skip32 = (z1m - z0m) * (uint32_t)plane, plane32 = (uint32_t)plane, n32 = (uint32_t)n;
+	for (uint32_t k = (uint32_t)t; k < total32; k += 4u * n32)
+	{
+		uint4 c[4];
+		uint32_t at[4];
+#pragma unroll
+		for (uint32_t u = 0; u < 4u; ++u)
+		{
+			const uint32_t kk = k + u * n32;
+			const uint32_t i = MV_LIGHT_LAYERS_INTERLEAVED ? kk : (kk < before32 ? kk : kk + skip32);	// skip this rank's own slab
+			at[u] = kk < total32 ? i : 0xffffffffu;
+			if (kk >= total32) continue;
+			const uint32_t z = i / plane32, r = i - z * plane32, y = r / L, x = r - y * L;
+			if (MV_LIGHT_LAYERS_INTERLEAVED && ((z >> 2) % st.shardCount) == st.shardIndex) { at[u] = 0xffffffffu; continue; }
+			const uint32_t x1 = x + 1u < L ? x + 1u : L - 1u, y1 = y + 1u < L ? y + 1u : L - 1u;
+			const uint32_t* s = st.lightPlain + (size_t)z * plane;
+			c[u] = make_uint4(s[y * L + x], s[y * L + x1], s[y1 * L + x], s[y1 * L + x1]);
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < 4u; ++u) if (at[u] != 0xffffffffu) peerStore16(cells + at[u], c[u]);
 	}
 }
 
@@ -607,6 +682,7 @@ struct PeerSync
 	uint32_t nSignal, signalRow[2];			// rows to raise to signalValue in every rank's block (after everything before this kernel on its stream)
 	unsigned long long signalValue[2];
 	uint32_t nWait, waitRow[8];				// rows of this rank's block that must reach waitValue in every column
+	uint32_t waitLocal;						// != 0: the rows are local ones (only this rank's own column is ever raised: "light cells rebuilt")
 	unsigned long long waitValue[8];
 	uint32_t checkChain;					// 0xffffffff, or: signal with this rank's cull words of the frame, and compare every rank's after the wait
 	const uint32_t* counters;				// the frame's cull counters (device)
@@ -617,6 +693,7 @@ struct PeerSync
 void launchPeerSync(hipStream_t s, const PeerSync& a);
 // Behind a producer on its stream: copy what it produced into every other rank's buffers; the last workgroup raises st.fold's flags.
 void launchPeerPushLight(hipStream_t s, const DeviceState& st);	// this rank's layers of the relit volume's light map
+void launchPeerRebuildLight(hipStream_t s, const DeviceState& st);	// (plain light push, waits as kernels) the other ranks' layers: cells from the landed texels; raises fold.rebuildRow locally
 void launchPeerPushRows(hipStream_t s, const DeviceState& st);		// this rank's block of the rank-major frame buffer
 void launchPeerPattern(hipStream_t s, uint2* const* table, uint32_t world, uint32_t self, size_t wordsPerRank, uint32_t salt);	// self-test: a pattern into every rank's buffer at this rank's region
 void launchPeerVerify(hipStream_t s, const uint2* mine, uint32_t world, size_t wordsPerRank, uint32_t salt, uint32_t* mismatches);

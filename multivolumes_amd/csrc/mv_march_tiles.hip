@@ -68,12 +68,21 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 			peerFoldSignal(st);	// (counted among the launch's workgroups)
 			return;
 		}
-		// every rank's layers of the light maps relit in the frames BEFORE this one (rows 1 ..): long landed.  This frame's (row 0) is
-		// waited for inside the body, by the workgroups whose tile reads the volume relit in this frame -- the others march at once,
-		// beside the push above and the other ranks'
-		peerFoldWait(st, 1u);
+		// (plain light push) the next rebuildBlocks workgroups wait for every rank's texels of the map relit in this frame, rebuild the
+		// cells of the other ranks' layers from them and raise "cells rebuilt" locally
+		if (!OVERFLOW && blockIdx.x < st.fold.pushBlocks + st.fold.rebuildBlocks)
+		{
+			peerFoldWait(st, 0u, 1u);
+			peerRebuildLightRole(st, (size_t)(blockIdx.x - st.fold.pushBlocks) * blockDim.x + threadIdx.x, (size_t)st.fold.rebuildBlocks * blockDim.x);
+			peerRaise(st, st.fold.rebuildCounter, st.fold.rebuildBlocks, 1u, &st.fold.rebuildRow, &st.fold.rebuildValue, 0xffffffffu, true);
+			peerFoldSignal(st);
+			return;
+		}
+		// (the light maps relit in the frames BEFORE this one: waited for by a kernel in front of this launch.  This frame's is waited for
+		// inside the body, by the wavefronts whose tile reads the volume relit in this frame -- the others march at once, beside the push
+		// above and the other ranks')
 	}
-	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis, (PEER && !OVERFLOW) ? blockIdx.x - st.fold.pushBlocks : blockIdx.x);
+	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis, (PEER && !OVERFLOW) ? blockIdx.x - st.fold.pushBlocks - st.fold.rebuildBlocks : blockIdx.x);
 	if constexpr (PEER) peerFoldSignal(st);
 }
 
@@ -106,9 +115,21 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 		peerFoldSignal(st);	// (counted among the launch's workgroups)
 		return;
 	}
-	const uint32_t m = blockIdx.x - pushAll, marchBlock = m / n;
+	const uint32_t rebuildBlocks = p.s[0].fold.rebuildBlocks, rebuildAll = rebuildBlocks * n;
+	if (blockIdx.x < pushAll + rebuildAll)
+	{
+		// (plain light push) every frame's rebuild workgroups, behind ALL push workgroups in dispatch order; one counter over all of them
+		// decides who raises "cells rebuilt" (to the launch's value: its group's)
+		const uint32_t r = blockIdx.x - pushAll, frame = r / rebuildBlocks, block = r - frame * rebuildBlocks;
+		const DeviceState& st = p.s[frame];
+		peerFoldWait(st, 0u, 1u);
+		peerRebuildLightRole(st, (size_t)block * blockDim.x + threadIdx.x, (size_t)rebuildBlocks * blockDim.x);
+		peerRaise(st, st.fold.rebuildCounter, rebuildAll, 1u, &st.fold.rebuildRow, &st.fold.rebuildValue, 0xffffffffu, true);
+		peerFoldSignal(st);
+		return;
+	}
+	const uint32_t m = blockIdx.x - pushAll - rebuildAll, marchBlock = m / n;
 	const DeviceState& st = p.s[m - marchBlock * n];
-	peerFoldWait(st, 1u);
 	marchTilesBody<false, LUT, IL, true>(st, 0u, sAxis, marchBlock);
 	peerFoldSignal(st);
 }
@@ -170,7 +191,11 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 			bool fresh = volumeId == relit;
 			// (several frames per launch: the maps relit in the EARLIER frames of this launch arrive with the same row; the cull listed them)
 			for (uint32_t j = 0; j < st.batchPos; ++j) fresh = fresh || volumeId == st.batchInfo[4u + j];
-			if (fresh || first) peerFoldWaitWave(st, 0u, 1u, first);	// (wave-uniform)
+			// (plain light push: the tiles wait for the cells this rank's rebuild workgroups make of the texels -- row 1, local -- and the
+			// launch's first marching wavefront for the ranks' texels too, row 0, whose cull words it compares)
+			const uint32_t tileRow = st.fold.rebuildBlocks ? 1u : 0u;
+			if (first) peerFoldWaitWave(st, 0u, tileRow + 1u, true);
+			else if (fresh) peerFoldWaitWave(st, tileRow, tileRow + 1u, false);	// (wave-uniform)
 		}
 	}
 
@@ -449,7 +474,7 @@ uint32_t launchMarchTiles(hipStream_t s, const DeviceState& st, uint32_t gridTil
 #endif
 	const bool il = st.flags & kFlagInterleaveRows;
 	const bool peer = st.peerCount > 1u && st.fold.stores;
-	const dim3 grid((uint32_t)blocks + (peer ? st.fold.pushBlocks : 0u)), block(64 * kTileWaves);
+	const dim3 grid((uint32_t)blocks + (peer ? st.fold.pushBlocks + st.fold.rebuildBlocks : 0u)), block(64 * kTileWaves);
 	const bool lut = st.N <= kLutMaxN && MV_TILE_LUT != 0;
 	if (st.peerCount > 1u && st.fold.stores)	// (peer-store transport)
 	{
@@ -483,7 +508,7 @@ void launchMarchTilesBatch(hipStream_t s, const DeviceState* states, uint32_t n,
 	for (uint32_t i = 0; i < n; ++i) beyond[i] = blocks * kTileWaves < most ? (uint32_t)(blocks * kTileWaves) : 0xffffffffu;
 	const bool il = states[0].flags & kFlagInterleaveRows;
 	const bool lut = states[0].N <= kLutMaxN && MV_TILE_LUT != 0;
-	const dim3 grid(((uint32_t)blocks + states[0].fold.pushBlocks) * n), block(64 * kTileWaves);
+	const dim3 grid(((uint32_t)blocks + states[0].fold.pushBlocks + states[0].fold.rebuildBlocks) * n), block(64 * kTileWaves);
 	const uint4 none = make_uint4(0u, 0u, 0u, 0u);
 	if (lut) { if (il) hipLaunchKernelGGL((marchTilesBatchKernel<false, true, true>), grid, block, 0, s, p, n, none); else hipLaunchKernelGGL((marchTilesBatchKernel<false, true, false>), grid, block, 0, s, p, n, none); }
 	else if (il) hipLaunchKernelGGL((marchTilesBatchKernel<false, false, true>), grid, block, 0, s, p, n, none);

@@ -46,6 +46,7 @@ __global__ __launch_bounds__(64) void peerSyncKernel(PeerSync a)
 		for (uint32_t i = 0; i < a.nWait; ++i)
 			for (uint32_t p = lane; p < a.world; p += 64u)
 			{
+				if (a.waitLocal && p != a.self) continue;
 				const unsigned long long* flag = a.myFlags + (size_t)a.waitRow[i] * kPeerMaxRanks + p;
 				while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.waitValue[i])
 				{
@@ -92,6 +93,14 @@ __global__ __launch_bounds__(256) void peerPushLightKernel(DeviceState st)
 	peerPushLightRole(st, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 	peerFoldSignal(st);
 }
+
+// (plain light push, waits as kernels: behind the wait for every rank's texels on this stream) the other ranks' layers of the relit map
+__global__ __launch_bounds__(256) void peerRebuildLightKernel(DeviceState st)
+{
+	peerRebuildLightRole(st, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
+	peerRaise(st, st.fold.rebuildCounter, gridDim.x, 1u, &st.fold.rebuildRow, &st.fold.rebuildValue, 0xffffffffu, true);
+}
+void launchPeerRebuildLight(hipStream_t s, const DeviceState& st) { hipLaunchKernelGGL(peerRebuildLightKernel, dim3(128), dim3(256), 0, s, st); }
 
 // this rank's block of the rank-major frame buffer (kFlagInterleaveRows: rowsPerRank tile rows of 8 pixel rows)
 __device__ __forceinline__ void peerPushRowsRole(const DeviceState& st)

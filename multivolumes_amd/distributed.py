@@ -144,7 +144,7 @@ def stored_tile_row(t, H, world):
     return (t % world) * per_rank + t // world
 
 
-def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, deal_volumes=None, acquire=True):
+def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, deal_volumes=None, acquire=True, push_cells=False):
     """The peer-store transport (include/multivolumes.h): every rank exports IPC handles of its light maps, cube maps and frame buffers,
     torch.distributed only gathers the blobs (any backend), every rank maps the others and the kernels store into all of them.
     Every step is collective and unconditional; a vote after init + self-test decides for all ranks.  Returns True if it is attached."""
@@ -166,7 +166,7 @@ def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, 
     ok = 1 if (err is None and bool((host[:, -1] == 1).all())) else 0
     if ok:
         try:
-            caster.DistInitPeer(host[:, :-1].tobytes(), fold=fold, rows_to_root=rows_to_root, deal_volumes=deal_volumes, acquire=acquire)
+            caster.DistInitPeer(host[:, :-1].tobytes(), fold=fold, rows_to_root=rows_to_root, deal_volumes=deal_volumes, acquire=acquire, push_cells=push_cells)
             if timeout_ms is not None:
                 caster.DistSetPeerTimeoutMs(timeout_ms)
             caster.DistSelfTest()  # patterns through every mapping and every flag, verified on every rank, twice
@@ -181,7 +181,7 @@ def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, 
     return False
 
 
-def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True, prefer_peer=False, peer_timeout_ms=None, peer_fold=None, peer_rows_to_root=False, peer_deal_volumes=None, peer_acquire=True):
+def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True, prefer_peer=False, peer_timeout_ms=None, peer_fold=None, peer_rows_to_root=False, peer_deal_volumes=None, peer_acquire=True, peer_push_cells=False):
     """Attach the in-library multi-GPU frame loop (mv_dist_frame) to a sharded caster.
 
     prefer_peer: try the peer-store transport first (whole-frame-chain contexts on one node; returns "peer").
@@ -194,7 +194,7 @@ def init_frame_loop(caster, group_main=None, group_light=None, prefer_rccl=True,
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()
-    if prefer_peer and init_peer_transport(caster, peer_timeout_ms, peer_fold, peer_rows_to_root, peer_deal_volumes, peer_acquire):
+    if prefer_peer and init_peer_transport(caster, peer_timeout_ms, peer_fold, peer_rows_to_root, peer_deal_volumes, peer_acquire, peer_push_cells):
         return "peer"
     if prefer_rccl and backend == "nccl":
         # Every step below is unconditional and collective, whatever failed locally: a rank never leaves the others waiting in a

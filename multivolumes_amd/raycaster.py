@@ -473,7 +473,7 @@ class MultiRayCaster:
         self._check(self._lib.mv_dist_peer_export(self._ctx, buf), "mv_dist_peer_export")
         return bytes(buf)
 
-    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False, deal_volumes=None, acquire=True):
+    def DistInitPeer(self, all_blobs=None, loopback=False, fold=None, rows_to_root=False, deal_volumes=None, acquire=True, push_cells=False):
         """Attach the frame loop with the peer-store transport: every rank's kernels store into every rank's buffers (no collectives).
         loopback: a rank measured alone (every peer is the context itself).  fold: True / False force the flags into / out of the
         marches and the composite (None: the library decides -- folded when every rank owns its GPU)."""
@@ -484,6 +484,8 @@ class MultiRayCaster:
             flags |= _lib.MV_DIST_PEER_DEAL_VOLUMES if deal_volumes else _lib.MV_DIST_PEER_DEAL_TILES
         if not acquire:  # round 4's folded waits: no invalidate behind the poll (A/B timing)
             flags |= _lib.MV_DIST_PEER_NO_ACQUIRE
+        if push_cells:  # round 4's light push: whole quad-replicated cells instead of plain texels rebuilt by the receiver (A/B timing)
+            flags |= _lib.MV_DIST_PEER_PUSH_CELLS
         if loopback:
             self._check(self._lib.mv_dist_init_peer(self._ctx, None, _lib.MV_DIST_PEER_LOOPBACK | flags), "mv_dist_init_peer")
             return

@@ -70,7 +70,8 @@ def main():
         peer = os.environ.get("MV_TEST_TRANSPORT") == "peer"     # the peer-store transport: IPC mappings, works with every rank on one GPU
         fold = {"1": True, "0": False}.get(os.environ.get("MV_TEST_PEER_FOLD"))  # (None: the library decides -- ranks sharing a GPU keep the flag kernels)
         kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=120000, peer_fold=fold, peer_rows_to_root=os.environ.get("MV_TEST_ROWS_TO_ROOT") == "1",
-                                 peer_deal_volumes={"1": True, "0": False}.get(os.environ.get("MV_TEST_DEAL_VOLUMES")))  # (None: the library's choice)
+                                 peer_deal_volumes={"1": True, "0": False}.get(os.environ.get("MV_TEST_DEAL_VOLUMES")),  # (None: the library's choice)
+                                 peer_push_cells=os.environ.get("MV_TEST_PUSH_CELLS") == "1")  # (round 4's light push: whole cells; the default is plain texels rebuilt by the receiver)
         assert kind == ("peer" if peer else "rccl" if rccl else "torch-callbacks"), kind
         if peer:
             info = c.DistInfo()
