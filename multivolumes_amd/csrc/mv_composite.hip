@@ -351,15 +351,20 @@ constexpr uint32_t kLayerNeedsMarch = 0xffff0000u;	// in .y: alpha = an fp16 NaN
 // kernel half of its wavefronts per SIMD): a tile in which some surviving layer needs that march is appended to `retry`
 // ({count, finished workgroups, tile ...}) and written by the MARCH = true launch behind it, which walks that list.
 // PEER: the peer-store transport's instantiation with a folded wait (mv_kernels.hpp peerFoldWait); the others are untouched by it
-template <bool MARCH>
+template <bool MARCH, bool PEER>
 __device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background, uint32_t* __restrict__ retry);
 
+// PEER (the peer-store transport's instantiation; the others are untouched by it): a folded wait in front (every rank's cube faces of this
+// frame have landed in this rank's set), every pixel the launch writes also stored into the other ranks' frame buffers -- rank 0's only with
+// fold.rowsRoot -- and the last workgroup raises "rows landed" and "frame done" behind them: no kernel of its own for the row push (round
+// 4's peerPushRowsKernel: 15 us alone, 60-190 us beside the marches of the other streams)
 template <bool MARCH, bool PEER = false>
 __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background,
 	uint32_t* __restrict__ retry)
 {
-	if constexpr (PEER) peerFoldWait(st);	// (peer-store transport, folded flags: every rank's cube faces of this frame have landed in this rank's set)
-	compositeBody<MARCH>(st, row0, row1, background, retry);
+	if constexpr (PEER) if (!MARCH) peerFoldWait(st);
+	compositeBody<MARCH, PEER>(st, row0, row1, background, retry);
+	if constexpr (PEER) peerFoldSignal(st);
 }
 
 // several frames in one launch (mv_kernels.hpp DeviceStateBatch; the multi-GPU loop's interleaved tile rows, no background): blockIdx.y is the frame
@@ -368,10 +373,11 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 {
 	const DeviceState& st = p.s[blockIdx.y];
 	if (!MARCH) peerFoldWait(st);
-	compositeBody<MARCH>(st, st.bandRow0, st.bandRow1, nullptr, st.compositeRetry);
+	compositeBody<MARCH, true>(st, st.bandRow0, st.bandRow1, nullptr, st.compositeRetry);
+	peerFoldSignal(st);
 }
 
-template <bool MARCH>
+template <bool MARCH, bool PEER>
 __device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background, uint32_t* __restrict__ retry)
 {
 	const uint32_t lane = threadIdx.x;
@@ -389,6 +395,8 @@ __device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t ro
 	const uint32_t px = tileX0 + (lane & 7u), py = tileY0 + (lane >> 3);
 	uint32_t nSamples = 0, nLit = 0;
 	bool deferred = false;
+	uint2 outPixel; outPixel.x = outPixel.y = 0u;	// (PEER) what this lane wrote into the frame buffer, if it did
+	bool wrote = false;
 
 	if (px < st.W && py < row1)
 	{
@@ -525,6 +533,30 @@ __device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t ro
 			o.x = (uint32_t)float_to_half_bits(result.x) | ((uint32_t)float_to_half_bits(result.y) << 16);
 			o.y = (uint32_t)float_to_half_bits(result.z) | ((uint32_t)float_to_half_bits(result.w) << 16);
 			st.composite[(size_t)(storeY0 + (lane >> 3)) * st.W + px] = o;
+			if constexpr (PEER) { outPixel = o; wrote = true; }
+		}
+	}
+	if constexpr (PEER)
+	{
+		// Peer-store transport: the pixels this wavefront wrote, into the other ranks' frame buffers (rank 0's only: fold.rowsRoot) at the same
+		// place of the rank-major image -- 16 bytes per store where an even lane and its right neighbour both wrote (a tile row is 8 lanes = 8
+		// pixels of a screen row: 2 x 8 bytes); narrower write-through stores are a fabric write each
+		if (st.fold.stores && st.peerCount > 1u)	// (wave-uniform)
+		{
+			const size_t index = (size_t)(storeY0 + (lane >> 3)) * st.W + px;
+			const uint2 right = make_uint2(__shfl_down(outPixel.x, 1), __shfl_down(outPixel.y, 1));
+			const bool wroteRight = __shfl_down(wrote ? 1 : 0, 1) != 0, wroteLeft = __shfl_up(wrote ? 1 : 0, 1) != 0;
+			const bool even = !(lane & 1u);
+			const bool pair = even && wrote && wroteRight && !(index & 1u);
+			const bool single = wrote && !pair && !(!even && wroteLeft && !((index - 1u) & 1u));	// (an odd lane whose left neighbour took it along stores nothing)
+			const uint32_t p0 = st.fold.rowsRoot ? 0u : 0u, p1 = st.fold.rowsRoot ? 1u : st.peerCount;
+			for (uint32_t p = p0; p < p1; ++p)
+			{
+				if (p == st.shardIndex) continue;
+				uint2* dst = st.peerComposite[p];
+				if (pair) peerStore16(dst + index, make_uint4(outPixel.x, outPixel.y, right.x, right.y));
+				else if (single) peerStore8(dst + index, outPixel);
+			}
 		}
 	}
 
@@ -557,9 +589,18 @@ uint32_t launchComposite(hipStream_t s, const DeviceState& stIn, uint32_t row0, 
 	// The inline march can only be asked for by a screen-space volume without a slot, by rows outside this context's band (what the
 	// view march's screen tiles cover) or by a frame without a view march: when none of them can happen the second launch is left out.
 	const bool second = st.screenSlots < st.V || (!interleaved && (row0 < st.bandRow0 || row1 > st.bandRow1)) || (st.flags & kFlagNoScreenLayers);
-	// (peer-store transport, folded wait: the first launch waits)
-	if (st.fold.nWait) hipLaunchKernelGGL((compositeKernel<false, true>), dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
-	else hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+	// (peer-store transport: the first launch waits -- folded -- and both store their pixels to the other ranks; the LAST launch raises the flags)
+	if (st.fold.nWait || st.fold.nSignal || st.fold.stores)
+	{
+		DeviceState first = st;
+		if (second) first.fold.nSignal = 0u;
+		hipLaunchKernelGGL((compositeKernel<false, true>), dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, first, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+		if (!second) return 1u;
+		st.fold.nWait = 0u;
+		hipLaunchKernelGGL((compositeKernel<true, true>), dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+		return 2u;
+	}
+	hipLaunchKernelGGL(compositeKernel<false>, dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 	if (!second) return 1u;
 	hipLaunchKernelGGL(compositeKernel<true>, dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 	return 2u;
@@ -575,8 +616,12 @@ uint32_t launchCompositeBatch(hipStream_t s, const DeviceState* states, uint32_t
 	if (!tilesY) return 0u;
 	bool second = false;
 	for (uint32_t i = 0; i < n; ++i) second = second || states[i].screenSlots < states[i].V || (states[i].flags & kFlagNoScreenLayers);
-	hipLaunchKernelGGL(compositeBatchKernel<false>, dim3(tilesX * tilesY, n), dim3(64), MV_COMPOSITE_LDS, s, p);
+	// (the first launch waits, both store their pixels to the other ranks, the LAST launch raises "rows landed" and "done")
+	DeviceStateBatch first = p;
+	if (second) for (uint32_t i = 0; i < kMaxBatch; ++i) first.s[i].fold.nSignal = 0u;
+	hipLaunchKernelGGL(compositeBatchKernel<false>, dim3(tilesX * tilesY, n), dim3(64), MV_COMPOSITE_LDS, s, first);
 	if (!second) return 1u;
+	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i].fold.nWait = 0u;
 	hipLaunchKernelGGL(compositeBatchKernel<true>, dim3(512, n), dim3(64), 0, s, p);
 	return 2u;
 }

@@ -358,25 +358,29 @@ static int distTailExchange(mv_ctx* ctx)
 // with frame j: its light buffers and output set may be overwritten".  (The copy-forward of frame j + 1 still reads frame j's set after
 // this -- on this very stream.  The set is next written by the other ranks' view marches of frame j + C, which they start behind this
 // rank's light share of frame j + C: a kernel of this same stream, behind that copy.)
-static int distTailSignal(mv_ctx* ctx, hipStream_t X, uint32_t localChain, const DeviceState& st, uint64_t frame, uint32_t slot, bool composited)
+#ifndef MV_COMPOSITE_RAISES
+#define MV_COMPOSITE_RAISES 0	// 1: the composite's last workgroup raises "rows landed" and "done" itself (every wavefront then drains its write-through stores and counts in: measured slower than a kernel of one wavefront behind the launch, profiles/r05_rank_chain.txt)
+#endif
+static int distTailSignal(mv_ctx* ctx, hipStream_t X, uint32_t localChain, const DeviceState& st, uint64_t frame, uint32_t slot, bool composited, bool wanted)
 {
 	DistState* d = ctx->dist;
 	if (d->transport != 3 || st.shardCount <= 1u) return MV_OK;
 	const uint32_t c = (uint32_t)(frame % d->numChains);
-	if (composited)
+	if (composited && MV_COMPOSITE_RAISES)
 	{
-		// push this rank's rows into every rank's frame buffer; its last workgroup raises both flags
-		DeviceState sp = peerPushState(ctx, st, kFoldComposite, frame, st.frameTag, slot);
-		foldSignal(ctx, sp, kStageRows, frame);
-		foldSignal(ctx, sp, kStageDone, frame);
-		sp.fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
-		mv::launchPeerPushRows(X, sp);
+		// (the composite has stored this rank's rows into the other ranks' frame buffers itself, and its last workgroup has raised both flags)
 		d->rowsWaitFrame[c] = frame; d->rowsStream[c] = localChain;
 	}
 	else
 	{
 		mv::PeerSync a = peerSyncBase(ctx, st.frameTag, slot);
 		a.nSignal = 1; a.signalRow[0] = kStageDone * mv::kPeerMaxChains + c; a.signalValue[0] = frame;
+		if (wanted || composited)
+		{
+			// (the composite has stored this rank's rows into the other ranks' frame buffers itself -- or: a composite was asked for and this rank has no row of the screen: its -- empty -- share of the rows has landed all the same)
+			a.nSignal = 2; a.signalRow[1] = kStageRows * mv::kPeerMaxChains + c; a.signalValue[1] = frame;
+			d->rowsWaitFrame[c] = frame; d->rowsStream[c] = localChain;
+		}
 		mv::launchPeerSync(X, a);
 	}
 	MV_HIP(ctx, hipGetLastError());
@@ -390,19 +394,32 @@ static int distTailComposite(mv_ctx* ctx)
 	const uint32_t slot = d->slotPending, world = st.shardCount, rank = st.shardIndex;
 	const uint32_t chain = d->chains ? d->chainPending : 0u;
 	hipStream_t X = distTailStream(ctx, chain);
+	bool compositeLaunched = false;	// (a rank without a row of the screen launches none: the flags are raised by a kernel of one wavefront then)
 	if (d->pendingComposite)
 	{
 		// chains: the copy-forward of this frame's unmarched faces ran on the stream of the frame before it
 		if (d->chains) MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[slot]));
-		if (d->transport == 3 && d->peerFold && world > 1u)
+		uint32_t launched = 0;
+		if (d->transport == 3 && world > 1u)
 		{
+			// peer stores: the composite waits for every rank's cube faces itself (folded; else a kernel in front of it has), stores every
+			// pixel it writes into the other ranks' frame buffers (rank 0's only: MV_DIST_PEER_ROWS_TO_ROOT) and its last workgroup raises
+			// "rows landed" and "frame done"
 			DeviceState stc = st;
-			PeerWaits w; w.n = 1; w.stage[0] = kStageCube; w.frame[0] = d->framePending;
+			PeerWaits w;
+			if (d->peerFold) { w.n = 1; w.stage[0] = kStageCube; w.frame[0] = d->framePending; }
 			const int rc = peerWaitFor(ctx, X, stc, kFoldComposite, w, d->framePending, st.frameTag, slot, false);
 			if (rc != MV_OK) return rc;
-			mv::launchComposite(X, stc, st.bandRow0, st.bandRow1);
+			if (!d->peerFold) foldBase(ctx, stc, kFoldComposite, d->framePending, st.frameTag, slot);
+#if MV_COMPOSITE_RAISES
+			foldSignal(ctx, stc, kStageRows, d->framePending);
+			foldSignal(ctx, stc, kStageDone, d->framePending);
+#endif
+			stc.fold.stores = 1u; stc.fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
+			launched = mv::launchComposite(X, stc, st.bandRow0, st.bandRow1);
 		}
-		else mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
+		else launched = mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
+		compositeLaunched = launched != 0u;
 		MV_HIP(ctx, hipGetLastError());
 		if (d->transport == 3) d->bytes += (size_t)st.H * st.W * sizeof(uint2) / world * (d->peerRowsRoot ? (st.shardIndex ? 0u : world - 1u) : world - 1u);	// (rows pushed into this rank's frame buffer)
 		else if (world > 1)
@@ -426,7 +443,7 @@ static int distTailComposite(mv_ctx* ctx)
 			d->bytes += (size_t)st.H * rowBytes;
 		}
 	}
-	{ const int rc = distTailSignal(ctx, X, chain, st, d->framePending, slot, d->pendingComposite); if (rc != MV_OK) return rc; }
+	{ const int rc = distTailSignal(ctx, X, chain, st, d->framePending, slot, d->pendingComposite && compositeLaunched, d->pendingComposite); if (rc != MV_OK) return rc; }
 	// everything that reads this frame's buffers has been enqueued: the next users of its slot / output set / light buffers wait for this
 	MV_HIP(ctx, evRecord(ctx, ctx->evMainDone[slot], X));
 	MV_HIP(ctx, latencyMark(ctx, slot, X));

@@ -2,6 +2,9 @@
 // no collectives; csrc/mv_peer.hip) and its form with several frames per launch (mv_config.frames_per_launch).  The loop itself, the
 // collective transports and the exchange building blocks: mv_dist.cpp.
 #include "mv_dist_int.hpp"
+#ifndef MV_COMPOSITE_RAISES
+#define MV_COMPOSITE_RAISES 0	// (see mv_dist.cpp)
+#endif
 #include <unistd.h>
 using namespace mvi;
 
@@ -669,38 +672,41 @@ int batchTail(mv_ctx* ctx)
 	// (a group of one frame: nothing above waited for the other ranks' faces -- a kernel of one wavefront does)
 	if (peers && n == 1u) { const int rc = peerWaitStage(ctx, X, kStageCube, P, last.st.frameTag, last.slot); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, evRecord(ctx, ctx->evLanded[last.slot], X));
+	uint32_t compositeLaunches = 0;
 	if (nComposite)
 	{
+		// The composite of the group's frames: it stores every pixel it writes into the other ranks' frame buffers itself (rank 0's only:
+		// MV_DIST_PEER_ROWS_TO_ROOT) and the last workgroup of its last launch raises "rows landed" and "done" -- round 4 had a push kernel
+		// behind it for that (15 us alone, 60-190 us beside the other streams' marches: profiles/r05_rank_chain.txt)
 		for (uint32_t i = 0; i < nComposite; ++i)
 		{
 			foldBase(ctx, sts[i], kFoldComposite, P, last.st.frameTag, last.slot);
+			if (peers)
+			{
+#if MV_COMPOSITE_RAISES
+				foldSignal(ctx, sts[i], kStageRows, P);
+				foldSignal(ctx, sts[i], kStageDone, P);
+#endif
+				sts[i].fold.stores = 1u; sts[i].fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
+			}
 		}
 		EventPair evt = { nullptr, nullptr, 0 };
 		beginStage(ctx, 3 | (int)(nComposite << 8), evt, X);
-		mv::launchCompositeBatch(X, sts, nComposite);
+		compositeLaunches = mv::launchCompositeBatch(X, sts, nComposite);
 		endStage(ctx, evt, X);
 		MV_HIP(ctx, hipGetLastError());
 		d->bytes += (size_t)nComposite * last.st.H * last.st.W * sizeof(uint2) / world * (d->peerRowsRoot ? (last.st.shardIndex ? 0u : world - 1u) : world - 1u);
 	}
 	if (peers)
 	{
-		if (nComposite)
-		{
-			// this rank's rows of every composited frame into every rank's frame buffers; the launch's last workgroup raises "rows landed" and "done"
-			for (uint32_t i = 0; i < nComposite; ++i)
-			{
-				foldBase(ctx, sts[i], kFoldComposite, P, last.st.frameTag, last.slot);
-				foldSignal(ctx, sts[i], kStageRows, P);
-				foldSignal(ctx, sts[i], kStageDone, P);
-				sts[i].fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
-			}
-			mv::launchPeerPushRowsBatch(X, sts, nComposite);
-			d->rowsWaitFrame[chain] = P; d->rowsStream[chain] = chain;
-		}
+		if (compositeLaunches && MV_COMPOSITE_RAISES) { d->rowsWaitFrame[chain] = P; d->rowsStream[chain] = chain; }
 		else
 		{
+			// (the flags behind the composite's launches: a kernel boundary is what says that every store of theirs has been acknowledged)
+			// (no composite in this group, or this rank has no row of the screen: "done" by a kernel of one wavefront)
 			mv::PeerSync a = peerSyncBase(ctx, last.st.frameTag, last.slot);
 			a.nSignal = 1; a.signalRow[0] = kStageDone * mv::kPeerMaxChains + chain; a.signalValue[0] = P;
+			if (nComposite) { a.nSignal = 2; a.signalRow[1] = kStageRows * mv::kPeerMaxChains + chain; a.signalValue[1] = P; d->rowsWaitFrame[chain] = P; d->rowsStream[chain] = chain; }
 			mv::launchPeerSync(X, a);
 		}
 		MV_HIP(ctx, hipGetLastError());

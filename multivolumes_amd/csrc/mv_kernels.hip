@@ -254,26 +254,29 @@ __constant__ uint8_t kFaceEdges[6][4] = { {8,3,9,6},{10,2,11,7},{0,8,5,11},{1,10
 
 constexpr uint32_t kCullThreads = 64;
 
-__device__ __forceinline__ void cullBody(const DeviceState& st);
+// (chained: this frame's cull sits in one launch with the cull of the frame before it -- cullBatchKernel -- and reads what that one leaves)
+__device__ __forceinline__ void cullBody(const DeviceState& st, bool chained = false);
 __global__ __launch_bounds__(kCullThreads) void cullKernel(DeviceState st) { cullBody(st); }
 // The culls of several consecutive frames in one launch (mv_kernels.hpp DeviceStateBatch; the multi-GPU loop with several frames per
 // launch): blockIdx.y is the frame.  A frame's cull reads what the cull before it wrote -- the VolumeInfo rows of culled volumes, the
-// light-map table it rotates, the view hash, the launch's cull words -- so the workgroups of frame y wait for the last wavefront of frame
-// y - 1 to say it is through (batchInfo[3] = its frame tag).  A handful of workgroups, dispatched in that order: all resident.
-// What it saves: a rank's culls are a chain through ALL its frames (upload, cull, orders, ~50 us a frame) that nothing can overlap.
+// light-map table it rotates, the view hash, the launch's cull words -- but only its LAST wavefront does, and only in the second half of
+// its epilogue: the per-volume work of all frames (projection, masks, LOD), their compaction, the deal and the work lists run side by
+// side, and the last wavefront of frame y waits for the last wavefront of frame y - 1 to say it is through (batchInfo[3] = its frame tag)
+// right in front of the first thing it needs of it (round 4 made every workgroup of frame y wait at its start: the culls of a group were
+// a chain of four whole culls, 108 us; profiles/r05_rank_chain.txt).  A handful of workgroups, dispatched in that order: all resident.
 __global__ __launch_bounds__(kCullThreads) void cullBatchKernel(DeviceStateBatch p)
 {
-	const DeviceState& st = p.s[blockIdx.y];
-	if (blockIdx.y)
-	{
-		const uint32_t want = st.frameTag - 1u;
-		if (threadIdx.x == 0) while (__hip_atomic_load(st.batchInfoPrev + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(2);
-		__syncthreads();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-	}
-	cullBody(st);
+	cullBody(p.s[blockIdx.y], blockIdx.y != 0u);
 }
-__device__ __forceinline__ void cullBody(const DeviceState& st)
+// (the wait of a chained cull's last wavefront; all its lanes call it)
+__device__ __forceinline__ void cullWaitForPreviousFrame(const DeviceState& st)
+{
+	const uint32_t want = st.frameTag - 1u;
+	if ((threadIdx.x & 63u) == 0u) while (__hip_atomic_load(st.batchInfoPrev + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) __builtin_amdgcn_s_sleep(2);
+	__syncthreads();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 {
 	extern __shared__ uint32_t sInfo[];	// per volume: bit0 visible, bit1 cube-map scheme, bits 2-4 mip, bits 5-10 face mask; then V x 2 words of screen rectangle
 	uint32_t* sRect = sInfo + st.V;
@@ -451,7 +454,8 @@ __device__ __forceinline__ void cullBody(const DeviceState& st)
 				reinterpret_cast<ushort4*>(st.volumeInfo)[volumeId] = out;
 				info = 1u | (useCubeMap ? 2u : 0u) | (mipLevel << 2) | ((faceMask & 0x3fu) << 5);
 			}
-			else reinterpret_cast<ushort4*>(st.volumeInfo)[volumeId] = reinterpret_cast<const ushort4*>(st.volumeInfoPrev)[volumeId];	// CSVolumeCull.hlsl:38 returns without writing
+			else if (!chained) reinterpret_cast<ushort4*>(st.volumeInfo)[volumeId] = reinterpret_cast<const ushort4*>(st.volumeInfoPrev)[volumeId];	// CSVolumeCull.hlsl:38 returns without writing
+			// (chained: the row the frame before leaves there is not final yet -- the last wavefront copies it, below, behind its wait)
 			st.volumeFlags[volumeId] = info;
 		}
 	}
@@ -638,6 +642,15 @@ __device__ __forceinline__ void cullBody(const DeviceState& st)
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(minMip, o); minMip = m < minMip ? m : minMip; }
 
+	if (chained)
+	{
+		// From here on the epilogue reads what the cull of the frame before left: its light table, its view hash, its cull words -- and the
+		// VolumeInfo rows of the volumes THIS frame culls, which keep what they held (CSVolumeCull.hlsl:38 returns without writing)
+		cullWaitForPreviousFrame(st);
+		for (uint32_t v = lane; v < st.V; v += 64)
+			if (!(sInfo[v] & 1u)) reinterpret_cast<ushort4*>(st.volumeInfo)[v] = reinterpret_cast<const ushort4*>(st.volumeInfoPrev)[v];
+		__threadfence();	// (other lanes of this wavefront read these rows below: VolumeConsts)
+	}
 	// This frame's light-map table = last frame's, with the volume this shard is about to relight switched to its next buffer.
 	uint32_t relitOfFrame = 0xffffffffu;	// (the volume CSRayMarchL relights this frame, whoever owns it)
 	{
