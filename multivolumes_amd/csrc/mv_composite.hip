@@ -355,16 +355,17 @@ template <bool MARCH, bool PEER>
 __device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background, uint32_t* __restrict__ retry);
 
 // PEER (the peer-store transport's instantiation; the others are untouched by it): a folded wait in front (every rank's cube faces of this
-// frame have landed in this rank's set), every pixel the launch writes also stored into the other ranks' frame buffers -- rank 0's only with
-// fold.rowsRoot -- and the last workgroup raises "rows landed" and "frame done" behind them: no kernel of its own for the row push (round
-// 4's peerPushRowsKernel: 15 us alone, 60-190 us beside the marches of the other streams)
+// frame have landed in this rank's set) and every pixel the launch writes also stored into the other ranks' frame buffers -- rank 0's only
+// with fold.rowsRoot: no kernel of its own for the row push (round 4's peerPushRowsKernel: 15 us alone, 60-190 us beside the marches of
+// the other streams).  The flags that announce the rows are raised by a kernel of one wavefront BEHIND the composite's launches: a
+// wavefront's s_endpgm waits for its stores, so the kernel boundary says they are acknowledged -- raising them from the composite's last
+// workgroup (every wavefront drains, counts in) was measured slower (profiles/r05_rank_chain.txt)
 template <bool MARCH, bool PEER = false>
 __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compositeKernel(DeviceState st, uint32_t row0, uint32_t row1, const uint2* __restrict__ background,
 	uint32_t* __restrict__ retry)
 {
 	if constexpr (PEER) if (!MARCH) peerFoldWait(st);
 	compositeBody<MARCH, PEER>(st, row0, row1, background, retry);
-	if constexpr (PEER) peerFoldSignal(st);
 }
 
 // several frames in one launch (mv_kernels.hpp DeviceStateBatch; the multi-GPU loop's interleaved tile rows, no background): blockIdx.y is the frame
@@ -374,7 +375,6 @@ __global__ __launch_bounds__(64, MARCH ? 4 : MV_COMPOSITE_MIN_WAVES) void compos
 	const DeviceState& st = p.s[blockIdx.y];
 	if (!MARCH) peerFoldWait(st);
 	compositeBody<MARCH, true>(st, st.bandRow0, st.bandRow1, nullptr, st.compositeRetry);
-	peerFoldSignal(st);
 }
 
 template <bool MARCH, bool PEER>
@@ -589,12 +589,10 @@ uint32_t launchComposite(hipStream_t s, const DeviceState& stIn, uint32_t row0, 
 	// The inline march can only be asked for by a screen-space volume without a slot, by rows outside this context's band (what the
 	// view march's screen tiles cover) or by a frame without a view march: when none of them can happen the second launch is left out.
 	const bool second = st.screenSlots < st.V || (!interleaved && (row0 < st.bandRow0 || row1 > st.bandRow1)) || (st.flags & kFlagNoScreenLayers);
-	// (peer-store transport: the first launch waits -- folded -- and both store their pixels to the other ranks; the LAST launch raises the flags)
-	if (st.fold.nWait || st.fold.nSignal || st.fold.stores)
+	// (peer-store transport: the first launch waits -- folded -- and both store their pixels to the other ranks)
+	if (st.fold.nWait || st.fold.stores)
 	{
-		DeviceState first = st;
-		if (second) first.fold.nSignal = 0u;
-		hipLaunchKernelGGL((compositeKernel<false, true>), dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, first, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
+		hipLaunchKernelGGL((compositeKernel<false, true>), dim3(tilesX * tilesY), dim3(64), MV_COMPOSITE_LDS, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
 		if (!second) return 1u;
 		st.fold.nWait = 0u;
 		hipLaunchKernelGGL((compositeKernel<true, true>), dim3(512), dim3(64), 0, s, st, row0, row1, reinterpret_cast<const uint2*>(background), st.compositeRetry);
@@ -616,10 +614,8 @@ uint32_t launchCompositeBatch(hipStream_t s, const DeviceState* states, uint32_t
 	if (!tilesY) return 0u;
 	bool second = false;
 	for (uint32_t i = 0; i < n; ++i) second = second || states[i].screenSlots < states[i].V || (states[i].flags & kFlagNoScreenLayers);
-	// (the first launch waits, both store their pixels to the other ranks, the LAST launch raises "rows landed" and "done")
-	DeviceStateBatch first = p;
-	if (second) for (uint32_t i = 0; i < kMaxBatch; ++i) first.s[i].fold.nSignal = 0u;
-	hipLaunchKernelGGL(compositeBatchKernel<false>, dim3(tilesX * tilesY, n), dim3(64), MV_COMPOSITE_LDS, s, first);
+	// (the first launch waits, both store their pixels to the other ranks)
+	hipLaunchKernelGGL(compositeBatchKernel<false>, dim3(tilesX * tilesY, n), dim3(64), MV_COMPOSITE_LDS, s, p);
 	if (!second) return 1u;
 	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i].fold.nWait = 0u;
 	hipLaunchKernelGGL(compositeBatchKernel<true>, dim3(512, n), dim3(64), 0, s, p);

@@ -358,21 +358,14 @@ static int distTailExchange(mv_ctx* ctx)
 // with frame j: its light buffers and output set may be overwritten".  (The copy-forward of frame j + 1 still reads frame j's set after
 // this -- on this very stream.  The set is next written by the other ranks' view marches of frame j + C, which they start behind this
 // rank's light share of frame j + C: a kernel of this same stream, behind that copy.)
-#ifndef MV_COMPOSITE_RAISES
-#define MV_COMPOSITE_RAISES 0	// 1: the composite's last workgroup raises "rows landed" and "done" itself (every wavefront then drains its write-through stores and counts in: measured slower than a kernel of one wavefront behind the launch, profiles/r05_rank_chain.txt)
-#endif
 static int distTailSignal(mv_ctx* ctx, hipStream_t X, uint32_t localChain, const DeviceState& st, uint64_t frame, uint32_t slot, bool composited, bool wanted)
 {
 	DistState* d = ctx->dist;
 	if (d->transport != 3 || st.shardCount <= 1u) return MV_OK;
 	const uint32_t c = (uint32_t)(frame % d->numChains);
-	if (composited && MV_COMPOSITE_RAISES)
 	{
-		// (the composite has stored this rank's rows into the other ranks' frame buffers itself, and its last workgroup has raised both flags)
-		d->rowsWaitFrame[c] = frame; d->rowsStream[c] = localChain;
-	}
-	else
-	{
+		// "done", and -- behind a composite, whose launches have stored this rank's rows into the other ranks' frame buffers themselves -- "rows
+		// landed": a kernel of one wavefront; the kernel boundary in front of it is what says that those stores have been acknowledged
 		mv::PeerSync a = peerSyncBase(ctx, st.frameTag, slot);
 		a.nSignal = 1; a.signalRow[0] = kStageDone * mv::kPeerMaxChains + c; a.signalValue[0] = frame;
 		if (wanted || composited)
@@ -402,19 +395,14 @@ static int distTailComposite(mv_ctx* ctx)
 		uint32_t launched = 0;
 		if (d->transport == 3 && world > 1u)
 		{
-			// peer stores: the composite waits for every rank's cube faces itself (folded; else a kernel in front of it has), stores every
-			// pixel it writes into the other ranks' frame buffers (rank 0's only: MV_DIST_PEER_ROWS_TO_ROOT) and its last workgroup raises
-			// "rows landed" and "frame done"
+			// peer stores: the composite waits for every rank's cube faces itself (folded; else a kernel in front of it has) and stores every
+			// pixel it writes into the other ranks' frame buffers (rank 0's only: MV_DIST_PEER_ROWS_TO_ROOT); distTailSignal raises the flags
 			DeviceState stc = st;
 			PeerWaits w;
 			if (d->peerFold) { w.n = 1; w.stage[0] = kStageCube; w.frame[0] = d->framePending; }
 			const int rc = peerWaitFor(ctx, X, stc, kFoldComposite, w, d->framePending, st.frameTag, slot, false);
 			if (rc != MV_OK) return rc;
 			if (!d->peerFold) foldBase(ctx, stc, kFoldComposite, d->framePending, st.frameTag, slot);
-#if MV_COMPOSITE_RAISES
-			foldSignal(ctx, stc, kStageRows, d->framePending);
-			foldSignal(ctx, stc, kStageDone, d->framePending);
-#endif
 			stc.fold.stores = 1u; stc.fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
 			launched = mv::launchComposite(X, stc, st.bandRow0, st.bandRow1);
 		}

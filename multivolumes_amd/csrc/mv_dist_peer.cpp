@@ -2,9 +2,6 @@
 // no collectives; csrc/mv_peer.hip) and its form with several frames per launch (mv_config.frames_per_launch).  The loop itself, the
 // collective transports and the exchange building blocks: mv_dist.cpp.
 #include "mv_dist_int.hpp"
-#ifndef MV_COMPOSITE_RAISES
-#define MV_COMPOSITE_RAISES 0	// (see mv_dist.cpp)
-#endif
 #include <unistd.h>
 using namespace mvi;
 
@@ -676,17 +673,13 @@ int batchTail(mv_ctx* ctx)
 	if (nComposite)
 	{
 		// The composite of the group's frames: it stores every pixel it writes into the other ranks' frame buffers itself (rank 0's only:
-		// MV_DIST_PEER_ROWS_TO_ROOT) and the last workgroup of its last launch raises "rows landed" and "done" -- round 4 had a push kernel
-		// behind it for that (15 us alone, 60-190 us beside the other streams' marches: profiles/r05_rank_chain.txt)
+		// MV_DIST_PEER_ROWS_TO_ROOT) -- round 4 had a push kernel behind it for that (15 us alone, 60-190 us beside the other streams'
+		// marches: profiles/r05_rank_chain.txt); the flags follow from a kernel of one wavefront
 		for (uint32_t i = 0; i < nComposite; ++i)
 		{
 			foldBase(ctx, sts[i], kFoldComposite, P, last.st.frameTag, last.slot);
 			if (peers)
 			{
-#if MV_COMPOSITE_RAISES
-				foldSignal(ctx, sts[i], kStageRows, P);
-				foldSignal(ctx, sts[i], kStageDone, P);
-#endif
 				sts[i].fold.stores = 1u; sts[i].fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
 			}
 		}
@@ -699,8 +692,6 @@ int batchTail(mv_ctx* ctx)
 	}
 	if (peers)
 	{
-		if (compositeLaunches && MV_COMPOSITE_RAISES) { d->rowsWaitFrame[chain] = P; d->rowsStream[chain] = chain; }
-		else
 		{
 			// (the flags behind the composite's launches: a kernel boundary is what says that every store of theirs has been acknowledged)
 			// (no composite in this group, or this rank has no row of the screen: "done" by a kernel of one wavefront)

@@ -660,7 +660,6 @@ void launchMarchLightBatch(hipStream_t s, const DeviceState* states, uint32_t n)
 void launchMarchTilesBatch(hipStream_t s, const DeviceState* states, uint32_t n, const uint32_t* gridTiles, uint32_t* beyond);
 void launchMarchTilesOverflowBatch(hipStream_t s, const DeviceState* states, uint32_t n, const uint32_t* firstSlot);
 uint32_t launchCompositeBatch(hipStream_t s, const DeviceState* states, uint32_t n);	// every state's own tile rows (kFlagInterleaveRows); returns the kernels launched
-void launchPeerPushRowsBatch(hipStream_t s, const DeviceState* states, uint32_t n);
 void launchCopyForwardBatch(hipStream_t s, const DeviceState* states, uint32_t first, uint32_t n, const uint2* prevMaps, const float* prevDepths, const uint32_t* prevStamps, const uint32_t* tags);	// frames first .. n - 1, one after the other in one kernel; states[0].fold: the wait before a set of the group is read
 void launchRaySetup(hipStream_t s, const DeviceState& st);
 void launchMarchView(hipStream_t s, const DeviceState& st);	// st.marchWaves wavefronts (see marchViewWaves)
@@ -694,7 +693,6 @@ void launchPeerSync(hipStream_t s, const PeerSync& a);
 // Behind a producer on its stream: copy what it produced into every other rank's buffers; the last workgroup raises st.fold's flags.
 void launchPeerPushLight(hipStream_t s, const DeviceState& st);	// this rank's layers of the relit volume's light map
 void launchPeerRebuildLight(hipStream_t s, const DeviceState& st);	// (plain light push, waits as kernels) the other ranks' layers: cells from the landed texels; raises fold.rebuildRow locally
-void launchPeerPushRows(hipStream_t s, const DeviceState& st);		// this rank's block of the rank-major frame buffer
 void launchPeerPattern(hipStream_t s, uint2* const* table, uint32_t world, uint32_t self, size_t wordsPerRank, uint32_t salt);	// self-test: a pattern into every rank's buffer at this rank's region
 void launchPeerVerify(hipStream_t s, const uint2* mine, uint32_t world, size_t wordsPerRank, uint32_t salt, uint32_t* mismatches);
 // The self-test of what the folded waits rest on, in ONE launch per rank (mv_peer.hip peerCoherenceKernel): read every rank's region of

@@ -102,35 +102,7 @@ __global__ __launch_bounds__(256) void peerRebuildLightKernel(DeviceState st)
 }
 void launchPeerRebuildLight(hipStream_t s, const DeviceState& st) { hipLaunchKernelGGL(peerRebuildLightKernel, dim3(128), dim3(256), 0, s, st); }
 
-// this rank's block of the rank-major frame buffer (kFlagInterleaveRows: rowsPerRank tile rows of 8 pixel rows)
-__device__ __forceinline__ void peerPushRowsRole(const DeviceState& st)
-{
-	const size_t block = (size_t)st.rowsPerRank * 8u * st.W * sizeof(uint2);
-	// (fold.rowsRoot: only rank 0 assembles the frame -- SURVEY 8e's "gather tiles to rank 0" -- and the others' frame buffers hold their own rows only)
-	peerPushRange(st, st.peerComposite, st.composite, (size_t)st.shardIndex * block, block, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x,
-		st.fold.rowsRoot ? 0u : 0xffffffffu);
-}
-__global__ __launch_bounds__(256) void peerPushRowsKernel(DeviceState st)
-{
-	peerPushRowsRole(st);
-	peerFoldSignal(st);
-}
-
-// several frames in one launch (DeviceStateBatch): blockIdx.y is the frame; the last workgroup of the whole launch raises the rows
-__global__ __launch_bounds__(256) void peerPushRowsBatchKernel(DeviceStateBatch p, uint32_t n)
-{
-	const DeviceState& st = p.s[blockIdx.y];
-	peerPushRowsRole(st);
-	peerFoldSignal(st);
-}
-void launchPeerPushRowsBatch(hipStream_t s, const DeviceState* states, uint32_t n)
-{
-	DeviceStateBatch p;
-	for (uint32_t i = 0; i < kMaxBatch; ++i) p.s[i] = states[i < n ? i : n - 1u];
-	hipLaunchKernelGGL(peerPushRowsBatchKernel, dim3(128, n), dim3(256), 0, s, p, n);
-}
 void launchPeerPushLight(hipStream_t s, const DeviceState& st) { hipLaunchKernelGGL(peerPushLightKernel, dim3(128), dim3(256), 0, s, st); }
-void launchPeerPushRows(hipStream_t s, const DeviceState& st) { hipLaunchKernelGGL(peerPushRowsKernel, dim3(128), dim3(256), 0, s, st); }
 
 // ---- self-test of the mappings: rank r writes a pattern into words [r * wordsPerRank, (r + 1) * wordsPerRank) of every rank's buffer ----
 __device__ __forceinline__ uint2 peerPatternWord(uint32_t rank, size_t i, uint32_t salt)
