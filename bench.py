@@ -84,7 +84,8 @@ def roofline_fraction(alg_bytes, requested_bytes, traffic_bytes, launch_ms):
     elif traffic_bytes:
         out.update({"achieved": gbs(traffic_bytes), "frac": gbs(traffic_bytes) / HBM_PEAK_GBS, "frac_basis": "measured HBM traffic (rocprofv3 PMC): algorithmic and requested bytes both exceed the peak (cache hits)"})
     else:
-        out.update({"achieved": HBM_PEAK_GBS, "frac": 1.0, "frac_basis": "capped: algorithmic and requested bytes exceed the peak and no traffic measurement matches these sources"})
+        # nothing measured that is a fraction of the roofline: say so instead of inventing one
+        out.update({"achieved": None, "frac": None, "frac_basis": "none: algorithmic and requested bytes exceed the peak and no traffic measurement matches these sources (scripts/make_profiles.sh)"})
     return out
 
 

@@ -91,7 +91,9 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		// output sets rotate.  Otherwise C output sets on C view streams (mv_config.frames_in_flight, default 3), each frame's light
 		// march on its view stream.  A HIP process has four hardware queues by default, and streams that share one wait for each
 		// other: with three chains that is four streams; more chains need GPU_MAX_HW_QUEUES >= C + 1 in the environment before the HIP
-		// runtime starts (this library sets it to 8 when it is loaded, if the variable is not set -- see the constructor below).
+		// runtime starts -- the CALLER's job (bench.py does it): the library sets no environment variable.  A context that asks for more streams
+		// than the process has hardware queues still works, its frames share queues and wait for each other (profiles/r03_frames_in_flight.txt);
+		// mv_last_error says so after mv_create.
 		if (cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM)
 		{
 			if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
@@ -322,6 +324,19 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	}
 
 	if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(MV_ERR_HIP);
+	{
+		// (a warning, not an error: more streams than hardware queues work, and wait for each other)
+		const uint32_t streams = ctx->numViewStreams + (ctx->cullOnChain ? 0u : 1u) + (ctx->ownStreamL ? 1u : 0u);
+		const char* q = getenv("GPU_MAX_HW_QUEUES");
+		const uint32_t queues = q ? (uint32_t)atoi(q) : 4u;
+		if ((cfg->flags & MV_FLAG_PIPELINE_FRAMES) && streams > queues)
+		{
+			char buf[256];
+			snprintf(buf, sizeof(buf), "warning: this context keeps %u streams busy and the process has %u hardware queues (GPU_MAX_HW_QUEUES%s): streams that share a queue wait for each other",
+				streams, queues, q ? "" : " is not set: the runtime's default of 4");
+			ctx->lastError = buf;
+		}
+	}
 	*out = ctx;
 	return MV_OK;
 }

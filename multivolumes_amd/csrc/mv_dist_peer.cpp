@@ -15,6 +15,7 @@ struct PeerBlob
 {
 	uint32_t magic, version, rank, world;
 	uint64_t pid, frame;
+	uint64_t nonce;								// a random number of the exporting PROCESS (pids repeat across pid namespaces: containers)
 	uint32_t device, numOutSets, lightBufs, flagsKind;
 	uint32_t N, L, V, S, W, H, cfgFlags, pad;
 	char gpu[32];								// PCI bus id of the rank's GPU (ranks that share one keep the flag kernels: see mv_dist_init_peer)
@@ -25,6 +26,17 @@ struct PeerBlob
 static_assert(sizeof(PeerBlob) <= MV_DIST_PEER_BYTES, "MV_DIST_PEER_BYTES");
 constexpr uint32_t kPeerMagic = 0x7265704du;	// "Mper"
 
+static uint64_t processNonce()
+{
+	static const uint64_t n = [] {
+		uint64_t v = 0;
+		FILE* f = fopen("/dev/urandom", "rb");
+		if (f) { if (fread(&v, sizeof(v), 1, f) != 1) v = 0; fclose(f); }
+		if (!v) v = ((uint64_t)getpid() << 32) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ reinterpret_cast<uint64_t>(&v);
+		return v;
+	}();
+	return n;
+}
 static void peerBufferList(mv_ctx* ctx, void** ptr, uint64_t* bytes)
 {
 	const DeviceState& st = ctx->st;
@@ -440,7 +452,7 @@ int mv_dist_peer_export(mv_ctx* ctx, void* out)
 	PeerBlob b;
 	memset(&b, 0, sizeof(b));
 	b.magic = kPeerMagic; b.version = MV_ABI_VERSION; b.rank = ctx->st.shardIndex; b.world = ctx->st.shardCount;
-	b.pid = (uint64_t)getpid(); b.frame = ctx->frame; b.device = (uint32_t)ctx->cfg.device; b.numOutSets = ctx->numOutSets; b.lightBufs = ctx->st.lightBufs; b.flagsKind = (uint32_t)d->peerFlagsKind;
+	b.pid = (uint64_t)getpid(); b.nonce = processNonce(); b.frame = ctx->frame; b.device = (uint32_t)ctx->cfg.device; b.numOutSets = ctx->numOutSets; b.lightBufs = ctx->st.lightBufs; b.flagsKind = (uint32_t)d->peerFlagsKind;
 	b.N = ctx->st.N; b.L = ctx->st.L; b.V = ctx->st.V; b.S = ctx->st.S; b.W = ctx->st.W; b.H = ctx->st.H; b.cfgFlags = ctx->cfg.flags;
 	if (hipDeviceGetPCIBusId(b.gpu, (int)sizeof(b.gpu), ctx->cfg.device) != hipSuccess) snprintf(b.gpu, sizeof(b.gpu), "device %d of pid %llu", ctx->cfg.device, (unsigned long long)b.pid);
 	void* ptr[kPeerBuffers];
@@ -521,7 +533,9 @@ int mv_dist_init_peer(mv_ctx* ctx, const void* all, uint32_t flags)
 		{
 			if (!mine[i]) continue;
 			if (b.bytes[i] != mineBytes[i]) return bail(fail(ctx, MV_ERR_INVALID_ARG, "a peer's buffer has another size"));
-			if (b.pid == (uint64_t)getpid()) { table[(size_t)i * world + r] = reinterpret_cast<void*>(b.pointer[i]); continue; }	// a context of this process
+			// (every rank's buffers are addressed with this rank's offsets, and the pushes store 16 bytes at a time: the same alignment everywhere)
+			if ((b.pointer[i] & 15u) != (reinterpret_cast<uint64_t>(mine[i]) & 15u)) return bail(fail(ctx, MV_ERR_INVALID_ARG, "a peer's buffer is aligned differently from this rank's"));
+			if (b.pid == (uint64_t)getpid() && b.nonce == processNonce()) { table[(size_t)i * world + r] = reinterpret_cast<void*>(b.pointer[i]); continue; }	// a context of this very process (pid AND nonce: pids repeat across containers)
 			void* p = nullptr;
 			const hipError_t e = hipIpcOpenMemHandle(&p, b.handle[i], hipIpcMemLazyEnablePeerAccess);
 			if (e != hipSuccess) return bail(fail(ctx, MV_ERR_HIP, "hipIpcOpenMemHandle (is the peer on this node, HSA_ENABLE_IPC_MODE_LEGACY=0 set?)", e));
