@@ -140,7 +140,7 @@ def test_synthetic_inputs_are_deterministic_and_sane(oracle):
 
 def test_roofline_fraction_is_a_fraction_on_every_workload():
     """bench.py's roofline line: SURVEY 8(d)'s algorithmic bytes while they are a fraction of the peak; on workloads
-    that are mostly served without HBM (C3-stress printed 1.40) the requested bytes, then the measured traffic, then a stated cap --
+    that are mostly served without HBM (C3-stress printed 1.40) the requested bytes, then the measured traffic, then NO fraction (not an invented one) --
     and the algorithmic figure stays beside it, uncapped."""
     import bench
     peak = bench.HBM_PEAK_GBS
@@ -153,7 +153,7 @@ def test_roofline_fraction_is_a_fraction_on_every_workload():
     r = bench.roofline_fraction(at(1.40), at(1.10), at(0.40), ms)
     assert abs(r["frac"] - 0.40) < 1e-9 and "traffic" in r["frac_basis"]
     r = bench.roofline_fraction(at(1.40), at(1.10), None, ms)
-    assert r["frac"] == 1.0 and "capped" in r["frac_basis"]
+    assert r["frac"] is None and r["achieved"] is None and "none" in r["frac_basis"], "no measurement: no fraction (ADVICE r04: never an invented 1.0)"
     assert bench.roofline_fraction(1.0, 1.0, None, 0.0)["frac"] is None
     assert bench.LEVELS[0] == "peer" and bench.LEVELS.index("rccl-single-stream") < bench.LEVELS.index("rccl")
     # (the peer-store transport twice: four frames per launch first, then -- should that form fail on a fabric it has never met -- a frame per launch)
