@@ -126,6 +126,7 @@ def parse():
     p.add_argument("--peer-no-acquire", action="store_true", help="DIAGNOSTIC: the folded waits of the peer-store transport without their acquire (round 4's form; MV_DIST_PEER_NO_ACQUIRE)")
     p.add_argument("--peer-push-cells", action="store_true", help="DIAGNOSTIC: the peer-store transport pushes whole light cells (16 B per texel, round 4) instead of plain texels that the receivers rebuild (MV_DIST_PEER_PUSH_CELLS)")
     p.add_argument("--finegrained", action="store_true", help="MV_FLAG_FINEGRAINED_PEER_BUFFERS: the buffers other ranks store into allocated fine-grained (what it costs on one GPU: profiles/r05_finegrained.txt)")
+    p.add_argument("--latency-frames", type=int, default=128, help="frames of the latency pass behind the timed region (every 8th sampled); 0 = none")
     p.add_argument("--steady-frames", type=int, default=400, help="frames of the steady-state pass behind the timed region (its own barrier-to-barrier time: `steady_state_ms_per_step`); 0 = none")
     p.add_argument("--cull-on-view-stream", action="store_true", help="MV_FLAG_CULL_ON_VIEW_STREAM: every frame's upload and cull on its own view stream (no stream of their own); "
                    "the default of the peer rung of --gpus > 1, an experiment on one GPU")
@@ -455,7 +456,6 @@ def main():
         caster.DistFlush()
         caster.synchronize()
         caster.DistExchangedBytes(reset=True)  # exchange bytes of the timed frames only
-    caster.SetLatencySampling(max(1, args.profile_every))  # (a host function behind the last kernel of every n-th frame)
     barrier()
     phase("timed")
     t0 = time.perf_counter()
@@ -475,8 +475,6 @@ def main():
     xbytes_timed = caster.DistExchangedBytes() if world > 1 else 0
     caster.SetProfiling(False)
     st = caster.GetStats()
-    latency = caster.GetLatency(reset=True)
-    caster.SetLatencySampling(0)
 
     # steady state: the same loop for --steady-frames more frames with its own barriers.  The driver's 20 timed frames are little more than one
     # depth of the pipeline when sixteen frames are in flight (four chains x four frames per launch): mostly fill and drain.
@@ -490,6 +488,19 @@ def main():
             caster.DistFlush()
         barrier()
         dt_steady = time.perf_counter() - t1
+    # latency: a pass of its own (a host function behind the last kernel of every 8th frame holds that frame's stream until it has run: inside
+    # the timed region that cost the 20-frame figure 4 %), the same loop, frames in flight as in the timed region
+    latency = {"mean_ms": 0.0, "max_ms": 0.0, "samples": 0}
+    if args.latency_frames > 0:
+        caster.SetLatencySampling(8)
+        barrier()
+        for i in range(args.latency_frames):
+            frame()
+        if world > 1:
+            caster.DistFlush()
+        barrier()
+        latency = caster.GetLatency(reset=True)
+        caster.SetLatencySampling(0)
 
     # roofline pass: the same frames, one at a time, so that a launch's HIP-event duration is the kernel's own time
     phase("roofline")
@@ -607,7 +618,7 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": dt / K * 1e3,
             "frames_per_s": K / dt, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             # depth: whole frames the host may run ahead of the GPU (chains x frames per launch), and what a frame pays for it -- host clock at
-            # the hand-over of its constants to host clock behind its last kernel, sampled inside the timed region (max over ranks)
+            # the hand-over of its constants to host clock behind its last kernel, every 8th frame of a pass of --latency-frames frames behind the timed region (max over ranks)
             "frames_in_flight_total": (2 if (world > 1 and args.dist_single_stream) else (args.frames_in_flight or 3) * (args.frames_per_launch or 1)) if pipelined else 1,
             "latency_ms": latency["mean_ms"] if latency["samples"] else None, "latency_ms_max": latency["max_ms"] if latency["samples"] else None, "latency_samples": latency["samples"],
             # the same loop over --steady-frames more frames, its own barriers (max over ranks): what the K timed frames would say if K were large

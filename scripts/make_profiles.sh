@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on an MI355X box (run through gpurun from the repo root). Round tag in $1 (default r02).
-R=${1:-r04}
+R=${1:-r05}
 OUT=/root/repo/gpurun_out/profiles_$R
 rm -rf $OUT; mkdir -p $OUT
 cd /root/repo
@@ -37,7 +37,7 @@ cd /tmp && export TMPDIR=/tmp
 for mode in "" "--no-pipeline"; do
   tag=${mode:+_no_pipeline}
   rm -rf /tmp/prof$tag
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof$tag -- python3 /root/repo/bench.py --no-cpu-baseline $mode > $OUT/${R}_C3_bench${tag}_under_rocprofv3.json 2> $OUT/rocprof$tag.log
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof$tag -- python3 /root/repo/bench.py --no-cpu-baseline --steady-frames 0 --latency-frames 0 $mode > $OUT/${R}_C3_bench${tag}_under_rocprofv3.json 2> $OUT/rocprof$tag.log
   cp /tmp/prof$tag/*/*kernel_stats.csv $OUT/${R}_C3_kernel_stats$tag.csv
 done
 cd /root/repo
@@ -56,5 +56,6 @@ python3 bench.py --ray-queue --config C5 --steps 200 --warmup 40 --no-cpu-baseli
 for f in $OUT/*bench*.json; do tail -1 $f > $f.tmp 2>/dev/null && mv $f.tmp $f; done
 bash scripts/exp_stage_cost.sh > $OUT/${R}_stage_cost.txt 2>&1
 bash scripts/prof_timeline.sh > $OUT/${R}_timeline_pipelined.txt 2>&1
+bash scripts/prof_timeline.sh --config C2 > $OUT/${R}_C2_timeline_pipelined.txt 2>&1
 grep -h "march" $OUT/${R}_C3_kernel_stats*.csv | cut -d, -f1-4
 for f in $OUT/*bench*.json; do python3 -c "import sys,json; d=json.loads(open('$f').read()); r=d['roofline']; print('$f'.split('/')[-1], round(d['ms_per_step'],4), round(d['value']), 'frac', round(r['frac'],3), 'with fused RayCast', round(r['frac_with_fused_raycast'],3), 'hbm_frac', r['hbm_frac'] and round(r['hbm_frac'],3), 'launch', round(r['launch_ms'],4), 'in flight', round(r['launch_ms_in_flight'],4))"; done

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for c in "$@"; do
   out=/root/repo/gpurun_out/pmc_${tag}_${c}
   rm -rf $out; mkdir -p $out
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -- python3 /root/repo/bench.py --no-cpu-baseline --no-pipeline --steps 12 --warmup 4 --roofline-frames 0 $args > $out.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out -- python3 /root/repo/bench.py --no-cpu-baseline --no-pipeline --steps 12 --warmup 4 --roofline-frames 0 --steady-frames 0 --latency-frames 0 $args > $out.log 2>&1
   python3 - "$out" "$c" <<'PY'
 import csv, glob, sys, collections
 d, c = sys.argv[1], sys.argv[2]

@@ -40,7 +40,7 @@ def run_group(cmd, timeout, env=None):
 def test_two_ranks_on_one_gpu(extra):
     env = dict(os.environ, MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24"] + extra
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24", "--latency-frames", "24"] + extra
     r = run_group(cmd, 240, env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
@@ -76,7 +76,7 @@ def test_bench_starts_and_supervises_its_ranks():
     ranks share cuda:0 over gloo, MV_BENCH_SHARE_GPU=1).  And a WORLD_SIZE that contradicts --gpus is an error, not a warning."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env.update(MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24"], 400, env)
+    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24", "--latency-frames", "24"], 400, env)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["transport"] == "peer" and d["config"]["fallback_level"] == 0
