@@ -144,6 +144,27 @@ def stored_tile_row(t, H, world):
     return (t % world) * per_rank + t // world
 
 
+def light_layers_of_rank(L, rank, world):
+    """Peer-store transport (csrc/mv_kernels.hpp lightLayersOfRank): the z slices [z0, z1) of the relit light map a rank marches and pushes -- a
+    slab of ceil(B / world) adjacent layers of 4 slices (B = ceil(L / 4) layers of voxel blocks), empty for ranks beyond the last layer."""
+    B = (L + 3) // 4
+    per = (B + world - 1) // world
+    first = rank * per
+    if first >= B:
+        return 0, 0
+    return first * 4, min((first + min(per, B - first)) * 4, L)
+
+
+def light_cells_from_texels(plain):
+    """The device layout of a light map from its plain R11G11B10F texels [z][y][x] (csrc/mv_kernels.hpp peerRebuildLightRole; mv_device.hpp
+    "light maps"): cell (x, y, z) = {t(x, y), t(x + 1, y), t(x, y + 1), t(x + 1, y + 1)} of slice z, +1 clamped -- texels of one z only, which is
+    why a rank's layers travel as plain texels (a quarter of the bytes) and every receiver rebuilds their cells from them alone."""
+    import numpy as np
+    ny, nx = plain.shape[1], plain.shape[2]   # (any number of z slices: a rank's slab rebuilds alone)
+    y1, x1 = np.minimum(np.arange(ny) + 1, ny - 1), np.minimum(np.arange(nx) + 1, nx - 1)
+    return np.stack([plain, plain[:, :, x1], plain[:, y1, :], plain[:, y1][:, :, x1]], axis=-1)
+
+
 def init_peer_transport(caster, timeout_ms=None, fold=None, rows_to_root=False, deal_volumes=None, acquire=True, push_cells=False):
     """The peer-store transport (include/multivolumes.h): every rank exports IPC handles of its light maps, cube maps and frame buffers,
     torch.distributed only gathers the blobs (any backend), every rank maps the others and the kernels store into all of them.

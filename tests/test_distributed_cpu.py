@@ -35,6 +35,29 @@ def test_partition_and_layout_pure():
     assert bands[0][0] == 0 and bands[-1][1] == 100 and all(bands[i][1] == bands[i + 1][0] for i in range(2))
 
 
+def test_light_layers_and_cell_rebuild_pure():
+    """The peer-store transport's light push, restated in numpy: the ranks' z slabs tile the map exactly once, and the cells every receiver
+    rebuilds from the slabs' PLAIN texels (a cell holds texels of one z only) are the cells of the whole map."""
+    rng = np.random.default_rng(5)
+    for L, world in ((96, 8), (48, 3), (16, 5), (10, 8), (7, 2)):
+        covered = np.zeros(L, np.int32)
+        for r in range(world):
+            z0, z1 = D.light_layers_of_rank(L, r, world)
+            assert 0 <= z0 <= z1 <= L and z0 % 4 == 0
+            covered[z0:z1] += 1
+        assert (covered == 1).all(), (L, world)
+        plain = rng.integers(0, 2 ** 32, size=(L, L, L), dtype=np.uint64).astype(np.uint32)
+        whole = D.light_cells_from_texels(plain)
+        assert whole.shape == (L, L, L, 4) and np.array_equal(whole[..., 0], plain)
+        assert np.array_equal(whole[3, 2, L - 1], [plain[3, 2, L - 1]] * 2 + [plain[3, 3, L - 1]] * 2), "x + 1 clamps"
+        rebuilt = np.zeros_like(whole)
+        for r in range(world):  # what rank r pushes is all a receiver needs for rank r's layers
+            z0, z1 = D.light_layers_of_rank(L, r, world)
+            if z1 > z0:
+                rebuilt[z0:z1] = D.light_cells_from_texels(plain[z0:z1])
+        assert np.array_equal(rebuilt, whole)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
