@@ -261,8 +261,8 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 	ctx->orderTiles = !(cfg->flags & MV_FLAG_LIST_ORDER);
 	for (uint32_t p = 0; p < ctx->numSlots; ++p)
 	{
-		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, 8u * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);	// a region per cost bin
-		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, 8 * sizeof(uint32_t))) != MV_OK) return bail(rc);
+		if ((rc = devAlloc(ctx, &ctx->fb[p].tileOrder, mv::kOrderBins * ((size_t)st.maxTiles + st.maxScreenTiles + 1) * sizeof(uint32_t))) != MV_OK) return bail(rc);	// a region per cost bin
+		if ((rc = devAlloc(ctx, &ctx->fb[p].binCounts, mv::kOrderBins * sizeof(uint32_t))) != MV_OK) return bail(rc);
 	}
 	// Per-tile cost table: ONE for all frame slots -- every view march writes its tiles' costs into it, every tile order reads what is there,
 	// i.e. the costs of the newest frame whose march has got that far (one or two frames back in steady state).  A table per slot (rounds
@@ -488,7 +488,7 @@ int mv_set_viewport(mv_ctx* ctx, uint32_t w, uint32_t h)
 	};
 	int rc = want(&ctx->ownDepth, (size_t)w * h * sizeof(float), true);
 	for (uint32_t p = 0; p < ctx->numSlots && rc == MV_OK; ++p)
-		rc = want(&ctx->fb[p].tileOrder, 8u * ((size_t)next.maxTiles + next.maxScreenTiles + 1) * sizeof(uint32_t), true);
+		rc = want(&ctx->fb[p].tileOrder, mv::kOrderBins * ((size_t)next.maxTiles + next.maxScreenTiles + 1) * sizeof(uint32_t), true);
 	uint32_t* costs = ctx->fb[0].tileCost;	// (one table for all slots)
 	if (rc == MV_OK) rc = want(&costs, (size_t)mv::tileCostKeyCount(next.V, next.N, next.maxScreenTiles) * sizeof(uint32_t), true);
 	for (uint32_t p = 0; p < ctx->numOutSets && rc == MV_OK; ++p)

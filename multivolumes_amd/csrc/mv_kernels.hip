@@ -765,7 +765,7 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 		st.counters[7] = nTiles < 2u ? 1u : stride;
 		st.counters[8] = 0u;	// the ticket, for the next cull that uses this slot
 		st.counters[13] = 0u;	// and the hash accumulator
-		if (st.binCursor) { for (uint32_t b = 0; b < 8u; ++b) st.binCursor[b] = 0u; }	// room taken in every bin of the tile order (ordersKernel follows)
+		if (st.binCursor) { for (uint32_t b = 0; b < kOrderBins; ++b) st.binCursor[b] = 0u; }	// room taken in every bin of the tile order (ordersKernel follows)
 		// [10] a hash of this frame's camera and volume transforms, [11] "it differs from the previous frame's": the tile costs this
 		// frame's order reads were taken one or two frames ago (tileBinOf dilates them then)
 		st.counters[11] = st.countersPrev[10] != viewHash ? 1u : 0u;
@@ -1211,7 +1211,7 @@ __device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* 
 #ifndef MV_ORDER_DILATE
 #define MV_ORDER_DILATE 1	// bin a tile by the largest cost in its 3x3 neighbourhood when the camera or a volume has moved since the costs were taken (0: never, 2: always; A/B timing)
 #endif
-constexpr uint32_t kOrderBins = 8, kOrderWaves = 256;
+constexpr uint32_t kOrderWaves = 256;	// (kOrderBins: mv_kernels.hpp)
 
 // ---------------------------------------------------------------------------------------------
 // Dispatch order of the view march: tiles binned by the length of their longest ray in the last launch that used this
@@ -1272,6 +1272,13 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 	}
 #endif
 	if (cost == 0u) return 0u;	// never marched (a face or a screen tile that has just come into view): with the longest, where a wrong guess costs nothing
+#if MV_TILE_BALANCE
+	{
+		// time costs: bin 0 from 2.56 us per step of the longest possible ray upwards, four bins to the octave below
+		const float l = 4.0f * __log2f((float)st.maxRaySamples * 256.0f / (float)cost);
+		return l <= 0.0f ? 0u : l >= (float)(kOrderBins - 1u) ? kOrderBins - 1u : (uint32_t)l;
+	}
+#endif
 	const uint32_t b = (cost - 1u) / width;
 	return kOrderBins - 1u - (b < kOrderBins - 1u ? b : kOrderBins - 1u);
 }
@@ -1301,13 +1308,13 @@ __device__ __forceinline__ void tileOrderRole(const DeviceState& st, uint32_t* s
 	uint32_t count[kOrderBins];
 #pragma unroll
 	for (uint32_t b = 0; b < kOrderBins; ++b) count[b] = 0;
-	uint32_t cached = 0;	// bins of this lane's tile in batches 0..7, four bits each (8 = no tile)
+	uint64_t cached = 0;	// bins of this lane's tile in batches 0..7, five bits each (kOrderBins = no tile)
 	uint32_t batch = 0;
 	for (uint32_t first = begin; first < end; first += 64u, ++batch)
 	{
 		const uint32_t tile = first + lane;
 		const uint32_t bin = tile < end ? tileBinOf(st, sStart, sEntry, nEntries, nCubeTiles, tile) : kOrderBins;
-		if (batch < 8u) cached |= bin << (4u * batch);
+		if (batch < 8u) cached |= (uint64_t)bin << (5u * batch);
 #pragma unroll
 		for (uint32_t b = 0; b < kOrderBins; ++b) count[b] += (uint32_t)__popcll(__ballot(bin == b));
 	}
@@ -1325,7 +1332,7 @@ __device__ __forceinline__ void tileOrderRole(const DeviceState& st, uint32_t* s
 	for (uint32_t first = begin; first < end; first += 64u, ++batch)
 	{
 		const uint32_t tile = first + lane;
-		const uint32_t bin = batch < 8u ? (cached >> (4u * batch)) & 0xfu : tile < end ? tileBinOf(st, sStart, sEntry, nEntries, nCubeTiles, tile) : kOrderBins;
+		const uint32_t bin = batch < 8u ? (uint32_t)(cached >> (5u * batch)) & 0x1fu : tile < end ? tileBinOf(st, sStart, sEntry, nEntries, nCubeTiles, tile) : kOrderBins;
 #pragma unroll
 		for (uint32_t b = 0; b < kOrderBins; ++b)
 		{

@@ -145,7 +145,7 @@ struct DeviceState
 	uint32_t* compositeRetry;		// 2 + compositeSlots: {count, finished workgroups, tiles the composite's second launch has to march inline}
 	uint32_t maxTiles, lightBlocks, compositeSlots, maxScreenTiles, marchWaves;
 	const uint32_t* tileOrder;		// dispatch order of the tile list, longest bins first (launchOrders): bin b's tiles at [b * orderCap, b * orderCap + binCursor[b]); NULL = list order
-	uint32_t* binCursor;			// 8: tiles in every bin (zeroed by the cull, counted up by the order kernel)
+	uint32_t* binCursor;			// kOrderBins: tiles in every bin (zeroed by the cull, counted up by the order kernel)
 	uint32_t orderCap;				// entries between the bins' regions of tileOrder
 	uint32_t* tileCost;				// V x 6 x ceil(N/8)^2 + maxScreenTiles + 1: samples of a tile's longest ray in the last launch that marched it, by stable tile key (one table for all frame slots)
 	// ray queue of the view march (per output set: two frames may be between setup and march at the same time)
@@ -494,16 +494,34 @@ __device__ inline uint32_t tileCostKey(const DeviceState& st, uint32_t volumeId,
 	return (st.flags & kFlagInterleaveRows) ? tileCostKeyT<true>(st, volumeId, faceId, localTile, tile, nCubeTiles) : tileCostKeyT<false>(st, volumeId, faceId, localTile, tile, nCubeTiles);
 }
 
-// dispatch slot -> tile (wave-uniform: scalar loads and compares).  The eight cursors are the bin totals once the order kernel has run.
-// `bin` (optional): the cost bin of the slot, 0 = the longest rays (or tiles never marched before) .. 7 = the shortest; 8 in list order.
+// MV_TILE_BALANCE (experiment, profiles/r05_tile_timeline.txt): the tiles' cost is the TIME their wavefront took last time (10 ns ticks), binned
+// four to the octave in sixteen bins, and the slots of every other group of 256 workgroups are dealt backwards: a launch that has the GPU to
+// itself puts workgroups w, w + 256, w + 512 .. on the same CU (measured: period 512 slots at two wavefronts per workgroup), so dealing the
+// sorted tiles there and back gives every CU the same sum of costs -- the launch ends when its slowest CU does.
+#ifndef MV_TILE_BALANCE
+#define MV_TILE_BALANCE 0
+#endif
+constexpr uint32_t kOrderBins = MV_TILE_BALANCE ? 16u : 8u;
+
+// dispatch slot -> tile (wave-uniform: scalar loads and compares).  The cursors are the bin totals once the order kernel has run.
+// `bin` (optional): the cost bin of the slot, 0 = the longest rays (or tiles never marched before) .. kOrderBins - 1 = the shortest; kOrderBins in list order.
 __device__ __forceinline__ uint32_t orderedTile(const DeviceState& st, uint32_t slot, uint32_t* bin = nullptr)
 {
-	if (bin) *bin = 8u;
+	if (bin) *bin = kOrderBins;
 	if (!st.tileOrder) return slot;
+#if MV_TILE_BALANCE
+	{
+		uint32_t total = 0;
+#pragma unroll
+		for (uint32_t b = 0; b < kOrderBins; ++b) total += st.binCursor[b];
+		const uint32_t w = slot >> 1, k = w >> 8;	// (whole groups of 512 slots only: a permutation of the slots there are)
+		if ((k & 1u) && ((k + 1u) << 9) <= total) slot = (((k << 8) | (255u - (w & 255u))) << 1) | (slot & 1u);
+	}
+#endif
 	uint32_t base = 0, at = slot;	// (a slot beyond the total -- never dispatched -- maps to itself)
 	bool found = false;
 #pragma unroll
-	for (uint32_t b = 0; b < 8u; ++b)
+	for (uint32_t b = 0; b < kOrderBins; ++b)
 	{
 		const uint32_t n = st.binCursor[b];
 		if (!found && slot < base + n) { at = b * st.orderCap + (slot - base); found = true; if (bin) *bin = b; }

@@ -157,8 +157,21 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	// follows marches the rest.
 	for (uint32_t slot = firstSlot + marchBlock * kTileWaves + wave; slot < nTiles; slot += OVERFLOW ? gridDim.x * kTileWaves : 0xffffffffu - slot)
 	{
-	uint32_t costBin = 8u;
-	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(slot), &costBin));
+#ifdef MV_TILE_TIMELINE	// (diagnostic build, scripts/tile_timeline.py: per-wavefront stamps of the tiles dispatched first)
+	const unsigned long long tlStart = wall_clock64();
+	unsigned long long tlLoop = 0;
+#endif
+#ifdef MV_TILE_ROTATE	// (with it: the first 4096 dispatch slots take each other's tiles, rotated by the frame -- the same tile on eight different CUs over eight frames)
+	const uint32_t orderSlot = slot < 4096u && nTiles >= 4096u ? (slot + (st.frameTag & 7u) * 74u) & 4095u : slot;
+#else
+	const uint32_t orderSlot = slot;
+#endif
+#if MV_TILE_BALANCE
+	static_assert(kTileWaves == 2u, "orderedTile's dealing assumes two wavefronts per workgroup");
+	const unsigned long long tileStart = wall_clock64();
+#endif
+	uint32_t costBin = kOrderBins;
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(orderSlot), &costBin));
 
 	// find the work entry that owns this tile (wave-uniform)
 	uint32_t entry = 0;
@@ -275,6 +288,9 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 		}
 	}
 
+#ifdef MV_TILE_TIMELINE
+	tlLoop = wall_clock64();
+#endif
 	if (valid)
 	{
 		{
@@ -420,9 +436,22 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) { const uint32_t m = __shfl_xor(maxS, o); maxS = m > maxS ? m : maxS; }
 	const uint32_t nCubeTiles = st.counters[6];
+#ifdef MV_TILE_TIMELINE
+	if (lane == 0 && slot < st.marchWaves)
+	{
+		unsigned long long* tl = reinterpret_cast<unsigned long long*>(st.timeline) + (size_t)slot * 8u;
+		uint32_t xcc, hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_HW_ID)" : "=s"(xcc), "=s"(hw));
+		tl[0] = tlStart; tl[1] = tlLoop; tl[2] = wall_clock64(); tl[3] = maxS | (costBin << 16) | (faceId << 20) | (volumeId << 24);
+		tl[4] = hw | ((unsigned long long)(xcc & 0xfu) << 32); tl[5] = tile; tl[6] = totL | ((unsigned long long)totS << 32); tl[7] = totK;
+	}
+#endif
 	if (lane == 0)
 	{
+#if MV_TILE_BALANCE
+		{ const unsigned long long took = wall_clock64() - tileStart; st.tileCost[tileCostKeyT<IL>(st, volumeId, faceId, localTile, tile, nCubeTiles)] = took < 1ull ? 1u : took > 0xffffffull ? 0xffffffu : (uint32_t)took; }
+#else
 		st.tileCost[tileCostKeyT<IL>(st, volumeId, faceId, localTile, tile, nCubeTiles)] = maxS + 1u;	// (0 = never marched)
+#endif
 		// counters: a slot of the wave-stats table shared by the tiles that map to it (no-return atomics, once per tile)
 		unsigned long long* s = reinterpret_cast<unsigned long long*>(st.waveStats) + (size_t)(slot % st.marchWaves) * 8u;
 		if (!screenTile)

@@ -183,13 +183,14 @@ __global__ __launch_bounds__(256) void peerCoherenceKernel(PeerCoherence a)
 	if (badOld) atomicAdd(a.mismatches + 1, badOld);
 	coherenceRaise(a, a.counters + 0, a.valueRead);
 	coherenceWait(a, a.valueRead, false);	// everybody has read: nobody's first read can see the new pattern
-	// 2. this rank's region of every rank's buffer: the new pattern (its own copy with plain stores, the others' written through)
+	// 2. this rank's region of every rank's buffer: the new pattern, written through -- its own copy too, as the frame loop's kernels write
+	// what a later role of the SAME launch reads (the rebuilt light cells): a plain store would stay dirty in the writer's XCD, and the
+	// word's reader below is a workgroup of another XCD whenever wordsPerRank is not a multiple of 8 workgroups' words (odd viewports)
 	for (size_t i = t; i < a.wordsPerRank; i += n)
 	{
 		const uint2 v = peerPatternWord(a.self, i, a.saltNew);
 		for (uint32_t p = 0; p < a.world; ++p)
-			if (p == a.self) a.table[p][(size_t)a.self * a.wordsPerRank + i] = v;
-			else peerStore8(&a.table[p][(size_t)a.self * a.wordsPerRank + i], v);
+			peerStore8(&a.table[p][(size_t)a.self * a.wordsPerRank + i], v);
 	}
 	coherenceRaise(a, a.counters + 1, a.valueWritten);
 	// 3. the folded wait, and the second read

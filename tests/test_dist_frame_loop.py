@@ -113,15 +113,19 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     assert int(d["nbytes"]) > 0
 
 
-@pytest.mark.parametrize("world", [2, 5])
-def test_in_kernel_coherence_selftest(tmp_path, world):
+@pytest.mark.parametrize("world,viewport", [(2, None), (5, None), (4, (250, 173))])
+def test_in_kernel_coherence_selftest(tmp_path, world, viewport):
     """The self-test of what the folded waits rest on (mv_dist_peer_coherence; run by mv_dist_selftest whenever the waits are folded): ONE
     launch per rank reads every rank's region, waits inside the kernel, every rank overwrites its region everywhere, the launch waits
     inside the kernel again, acquires as the folded waits do and reads once more with plain loads.  The ranks share cuda:0 here, but their
     workgroups sit on eight XCDs with an L2 each, and on 256 CUs with an L1 each that no store of another CU ever refreshes: a wait without
-    the acquire DOES see stale words on this one GPU (reported, not asserted: how many depends on what stayed resident) -- with it, none."""
+    the acquire DOES see stale words on this one GPU (reported, not asserted: how many depends on what stayed resident) -- with it, none.
+    The odd viewport puts the ranks' regions on odd workgroup boundaries: a word's writer and its reader are workgroups of different XCDs on
+    the writing rank too (round 5's soak: the test's own plain-stored copy read stale there and refused a sound transport)."""
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_TRANSPORT="peer", MV_TEST_PEER_FOLD="1", MV_TEST_COHERENCE="1")
+    if viewport:
+        env.update(MV_TEST_W=str(viewport[0]), MV_TEST_H=str(viewport[1]), MV_TEST_FOUR_CHAINS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, "4", "4", "chains", "1"]
     r = run_group(cmd, 300, env)
