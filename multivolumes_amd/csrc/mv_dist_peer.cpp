@@ -683,7 +683,6 @@ int batchTail(mv_ctx* ctx)
 	// (a group of one frame: nothing above waited for the other ranks' faces -- a kernel of one wavefront does)
 	if (peers && n == 1u) { const int rc = peerWaitStage(ctx, X, kStageCube, P, last.st.frameTag, last.slot); if (rc != MV_OK) return rc; }
 	MV_HIP(ctx, evRecord(ctx, ctx->evLanded[last.slot], X));
-	uint32_t compositeLaunches = 0;
 	if (nComposite)
 	{
 		// The composite of the group's frames: it stores every pixel it writes into the other ranks' frame buffers itself (rank 0's only:
@@ -699,7 +698,7 @@ int batchTail(mv_ctx* ctx)
 		}
 		EventPair evt = { nullptr, nullptr, 0 };
 		beginStage(ctx, 3 | (int)(nComposite << 8), evt, X);
-		compositeLaunches = mv::launchCompositeBatch(X, sts, nComposite);
+		mv::launchCompositeBatch(X, sts, nComposite);
 		endStage(ctx, evt, X);
 		MV_HIP(ctx, hipGetLastError());
 		d->bytes += (size_t)nComposite * last.st.H * last.st.W * sizeof(uint2) / world * (d->peerRowsRoot ? (last.st.shardIndex ? 0u : world - 1u) : world - 1u);

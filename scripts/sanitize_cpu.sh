@@ -15,16 +15,18 @@ cd "$ROOT/multivolumes_amd/csrc"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
 pids=()
-for f in mv_kernels mv_march mv_march_tiles mv_composite mv_mesh; do
-	$HIPCC $FLAGS -c $f.hip -o "$OUT/$f.o" & pids+=($!)
+for f in mv_kernels mv_march mv_march_tiles mv_peer mv_composite mv_mesh; do
+	$HIPCC $FLAGS -I. -c $f.hip -o "$OUT/$f.o" & pids+=($!)
 done
-$HIPCC $FLAGS -c mv_api.cpp -o "$OUT/mv_api.o" & pids+=($!)	# includes device headers: not a g++ translation unit (without a GPU it only ever rejects arguments)
+for f in mv_api mv_dist mv_dist_peer mv_mesh_api; do	# (they include device headers: not g++ translation units; without a GPU they only ever reject arguments)
+	$HIPCC $FLAGS -c $f.cpp -o "$OUT/$f.o" & pids+=($!)
+done
 g++ -O1 -std=c++17 -fPIC -Wall $SAN -c mv_host.cpp -o "$OUT/mv_host.o" & pids+=($!)
 rc=0
 for p in "${pids[@]}"; do wait "$p" || rc=1; done
 [ $rc -eq 0 ] || { echo "sanitize_cpu.sh: a compile job failed" >&2; exit 1; }
-g++ -shared -fPIC $SAN -o "$OUT/libmultivolumes_amd.so" "$OUT"/mv_kernels.o "$OUT"/mv_march.o "$OUT"/mv_march_tiles.o "$OUT"/mv_composite.o "$OUT"/mv_mesh.o \
-	"$OUT/mv_api.o" "$OUT/mv_host.o" -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread -ldl
+g++ -shared -fPIC $SAN -o "$OUT/libmultivolumes_amd.so" "$OUT"/mv_kernels.o "$OUT"/mv_march.o "$OUT"/mv_march_tiles.o "$OUT"/mv_peer.o "$OUT"/mv_composite.o "$OUT"/mv_mesh.o \
+	"$OUT/mv_api.o" "$OUT/mv_dist.o" "$OUT/mv_dist_peer.o" "$OUT/mv_mesh_api.o" "$OUT/mv_host.o" -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib -lpthread -ldl
 cd "$ROOT"
 export LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 export ASAN_OPTIONS="detect_leaks=0:alloc_dealloc_mismatch=0:halt_on_error=1:abort_on_error=0"
