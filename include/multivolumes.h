@@ -359,7 +359,8 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * gets every row, as with the all-gathers. */
 #define MV_DIST_PEER_ROWS_TO_ROOT 8u
 /* Who marches what.  With several frames per launch (mv_config.frames_per_launch > 1) the view march of EVERY cube-map volume is
- * shared out by tiles (rank r marches the 8x8 tiles t of each marched face with (t + volume) mod shard_count == r): a march that stores
+ * shared out by tiles (rank r marches the groups g of 8x8 tiles of each marched face with (g + volume) mod shard_count == r; a group is
+ * two whole rows of tiles where the face has that many per rank, else one tile): a march that stores
  * its texels into every rank's cube maps itself does not care who "owns" a volume, and eight ranks then carry an eighth of the tiles each
  * -- ten visible volumes dealt to eight ranks leave two ranks with two volumes, which a launch of four frames then waits for (0.080 against
  * 0.060 ms per C3 frame).  With one frame per launch whole volumes go to ranks, dealt by estimated cost as with the collectives (the north

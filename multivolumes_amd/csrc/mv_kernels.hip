@@ -624,7 +624,7 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 
 		const uint32_t dims = st.N >> mip;
 		const uint32_t tilesOfFace = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
-		const uint32_t tilesPerFace = dealTiles ? dealtTilesOfFace(tilesOfFace, st.shardIndex, shardCount, v) : tilesOfFace;	// (this rank's)
+		const uint32_t tilesPerFace = dealTiles ? dealtTilesOfFace(tilesOfFace, (dims + 7u) >> 3, st.shardIndex, shardCount, v) : tilesOfFace;	// (this rank's)
 		const uint32_t myFaces = (cube && marches && tilesPerFace) ? (uint32_t)__popc(mask) : 0u;
 		uint32_t totFaces, totTiles;
 		const uint32_t eBase = nEntries + waveExclusiveScanU32(myFaces, lane, totFaces);

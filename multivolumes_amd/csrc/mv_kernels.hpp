@@ -386,20 +386,42 @@ __device__ __forceinline__ void peerFoldSignal(const DeviceState& st)
 	peerRaise(st, st.fold.counter, gridDim.x * gridDim.y, st.fold.nSignal, st.fold.signalRow, st.fold.signalValue, st.fold.checkCompare ? 0xffffffffu : st.fold.checkChain);
 }
 
-constexpr uint32_t kFlagDealTiles = 0x04000000u;	// DeviceState.flags (internal, peer-store transport): the view march of EVERY cube-map volume is shared out by tiles -- rank r marches the tiles t of
-													// each marched face with (t + volume) % shardCount == r -- instead of whole volumes dealt by estimated cost: ten visible volumes on eight ranks leave two ranks
+constexpr uint32_t kFlagDealTiles = 0x04000000u;	// DeviceState.flags (internal, peer-store transport): the view march of EVERY cube-map volume is shared out by tiles -- rank r marches the groups g of
+													// tiles of each marched face with (g + volume) % shardCount == r (dealtGroup below) -- instead of whole volumes dealt by estimated cost: ten visible volumes on eight ranks leave two ranks
 													// with two volumes each (profiles/r04_frames_per_launch.txt); a march that stores its texels into every rank's cube maps itself does not care who owns what
-// kFlagDealTiles: the k-th tile this rank marches of a face of volume v, and how many of a face's T tiles are its
-__host__ __device__ inline uint32_t dealtTileFirst(uint32_t shardIndex, uint32_t shardCount, uint32_t v) { return (shardIndex + shardCount - v % shardCount) % shardCount; }
-__host__ __device__ inline uint32_t dealtTilesOfFace(uint32_t T, uint32_t shardIndex, uint32_t shardCount, uint32_t v)
+// kFlagDealTiles: the k-th tile this rank marches of a face of volume v, and how many of a face's T tiles are its.  The unit of the deal is a
+// GROUP of G consecutive tiles of the face, group g to rank (g + v) % shardCount: MV_DEAL_ROWS = n whole rows of tiles where the face has at
+// least n rows per rank -- a rank's wavefronts then march neighbouring tiles, whose rays share cache lines -- and single tiles (G = 1, round
+// 4's deal: every shardCount-th tile) on smaller faces.  A rank of eight at C3 (faces of 16 x 16 tiles): n = 0 0.0662 ms, 1 0.0654, 2 0.0643
+// (= a contiguous eighth of the face) per frame, profiles/r05_rank_chain.txt.
+#ifndef MV_DEAL_ROWS
+#define MV_DEAL_ROWS 2
+#endif
+__host__ __device__ inline uint32_t dealtGroup(uint32_t tilesX, uint32_t shardCount)
 {
+	return (MV_DEAL_ROWS && tilesX >= shardCount * MV_DEAL_ROWS) ? tilesX * MV_DEAL_ROWS : 1u;
+}
+__host__ __device__ inline uint32_t dealtTileFirst(uint32_t shardIndex, uint32_t shardCount, uint32_t v) { return (shardIndex + shardCount - v % shardCount) % shardCount; }	// (the rank's first group)
+__host__ __device__ inline uint32_t dealtTilesOfFace(uint32_t T, uint32_t tilesX, uint32_t shardIndex, uint32_t shardCount, uint32_t v)
+{
+	const uint32_t G = dealtGroup(tilesX, shardCount), groups = (T + G - 1u) / G;
 	const uint32_t first = dealtTileFirst(shardIndex, shardCount, v);
-	return first < T ? (T - first + shardCount - 1u) / shardCount : 0u;
+	if (first >= groups) return 0u;
+	const uint32_t mine = (groups - first + shardCount - 1u) / shardCount;
+	const bool ownsLast = (groups - 1u - first) % shardCount == 0u;
+	return mine * G - (ownsLast ? groups * G - T : 0u);
 }
 __device__ __forceinline__ uint32_t cubeLocalTile(const DeviceState& st, uint32_t volumeId, uint32_t k)
 {
 	if (!(st.flags & kFlagDealTiles) || st.shardCount <= 1u) return k;
-	return dealtTileFirst(st.shardIndex, st.shardCount, volumeId) + k * st.shardCount;
+	const uint32_t first = dealtTileFirst(st.shardIndex, st.shardCount, volumeId);
+#if MV_DEAL_ROWS
+	const uint32_t dims = st.N >> reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId].x;
+	const uint32_t G = dealtGroup((dims + 7u) >> 3, st.shardCount);
+	return (first + (k / G) * st.shardCount) * G + k % G;
+#else
+	return first + k * st.shardCount;
+#endif
 }
 // Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
 // their position among this frame's screen tiles.  A key that names another tile after a mip / visibility change only
