@@ -771,8 +771,9 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 		st.counters[11] = st.countersPrev[10] != viewHash ? 1u : 0u;
 		st.counters[10] = viewHash;
 		// host-visible {frame tag : tile count}: a hint for the grid sizes of later launches; the host never waits for it (mv_api.cpp)
-		if (st.tilesReport) *st.tilesReport = ((unsigned long long)st.frameTag << 32) | nTiles;
-		if (st.tilesReportSlot) *st.tilesReportSlot = ((unsigned long long)st.frameTag << 32) | nTiles;
+		// (system-scope stores: written through to the host at once, whatever release the runtime gives this kernel's end)
+		if (st.tilesReport) __hip_atomic_store(st.tilesReport, ((unsigned long long)st.frameTag << 32) | nTiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		if (st.tilesReportSlot) __hip_atomic_store(st.tilesReportSlot, ((unsigned long long)st.frameTag << 32) | nTiles, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		// What the ranks of the multi-GPU loop compare of their culls ([0..2]: hash, visible, cube-map volumes) and which volumes the
 		// frames of this launch relight ([4 + position]) -- carried from frame to frame of a launch that holds several (batchPos > 0:
 		// the previous frame's words are folded in, position-weighted), so that the launch's LAST frame holds the words for all of them
