@@ -390,16 +390,19 @@ constexpr uint32_t kFlagDealTiles = 0x04000000u;	// DeviceState.flags (internal,
 													// tiles of each marched face with (g + volume) % shardCount == r (dealtGroup below) -- instead of whole volumes dealt by estimated cost: ten visible volumes on eight ranks leave two ranks
 													// with two volumes each (profiles/r04_frames_per_launch.txt); a march that stores its texels into every rank's cube maps itself does not care who owns what
 // kFlagDealTiles: the k-th tile this rank marches of a face of volume v, and how many of a face's T tiles are its.  The unit of the deal is a
-// GROUP of G consecutive tiles of the face, group g to rank (g + v) % shardCount: MV_DEAL_ROWS = n whole rows of tiles where the face has at
-// least n rows per rank -- a rank's wavefronts then march neighbouring tiles, whose rays share cache lines -- and single tiles (G = 1, round
-// 4's deal: every shardCount-th tile) on smaller faces.  A rank of eight at C3 (faces of 16 x 16 tiles): n = 0 0.0662 ms, 1 0.0654, 2 0.0643
-// (= a contiguous eighth of the face) per frame, profiles/r05_rank_chain.txt.
+// GROUP of G consecutive tiles of the face, group g to rank (g + v) % shardCount: n <= MV_DEAL_ROWS whole rows of tiles, the largest n that
+// leaves every rank the same number of groups -- a rank's wavefronts then march neighbouring tiles, whose rays share cache lines -- and
+// single tiles (G = 1, round 4's deal: every shardCount-th tile) on faces that no such n divides.  A rank of eight at C3 (faces of 16 x 16
+// tiles; n = 2 is a contiguous eighth): single tiles 0.0662 ms per frame, n = 1 0.0654, n = 2 0.0643; a rank of four: n = 2 0.0978, n = 4 (a
+// contiguous quarter) 0.0988 -- two bands balance better than one; profiles/r05_rank_chain.txt.
 #ifndef MV_DEAL_ROWS
 #define MV_DEAL_ROWS 2
 #endif
 __host__ __device__ inline uint32_t dealtGroup(uint32_t tilesX, uint32_t shardCount)
 {
-	return (MV_DEAL_ROWS && tilesX >= shardCount * MV_DEAL_ROWS) ? tilesX * MV_DEAL_ROWS : 1u;
+	for (uint32_t n = MV_DEAL_ROWS; n >= 1u; --n)
+		if (tilesX % n == 0u && (tilesX / n) % shardCount == 0u) return tilesX * n;
+	return 1u;
 }
 __host__ __device__ inline uint32_t dealtTileFirst(uint32_t shardIndex, uint32_t shardCount, uint32_t v) { return (shardIndex + shardCount - v % shardCount) % shardCount; }	// (the rank's first group)
 __host__ __device__ inline uint32_t dealtTilesOfFace(uint32_t T, uint32_t tilesX, uint32_t shardIndex, uint32_t shardCount, uint32_t v)
