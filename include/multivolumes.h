@@ -360,7 +360,7 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
 #define MV_DIST_PEER_ROWS_TO_ROOT 8u
 /* Who marches what.  With several frames per launch (mv_config.frames_per_launch > 1) the view march of EVERY cube-map volume is
  * shared out by tiles (rank r marches the groups g of 8x8 tiles of each marched face with (g + volume) mod shard_count == r; a group is
- * two whole rows of tiles where the face has that many per rank, else one tile): a march that stores
+ * two whole rows of tiles, or one, where that gives every rank equally many groups of the face, else one tile: mv_dealt_tiles): a march that stores
  * its texels into every rank's cube maps itself does not care who "owns" a volume, and eight ranks then carry an eighth of the tiles each
  * -- ten visible volumes dealt to eight ranks leave two ranks with two volumes, which a launch of four frames then waits for (0.080 against
  * 0.060 ms per C3 frame).  With one frame per launch whole volumes go to ranks, dealt by estimated cost as with the collectives (the north
@@ -369,6 +369,9 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
  * (profiles/r04_frames_per_launch.txt).  Results are identical. */
 #define MV_DIST_PEER_DEAL_VOLUMES 16u
 #define MV_DIST_PEER_DEAL_TILES 32u
+/* The deal's rule as a function (tests, tools): the tiles of a cube face of tiles_x x tiles_x tiles of volume `volume` that rank shard_index of
+ * shard_count marches, in its marching order, into tiles[0 .. capacity); returns how many there are.  Over the ranks: a partition of the face. */
+uint32_t mv_dealt_tiles(uint32_t tiles_x, uint32_t shard_index, uint32_t shard_count, uint32_t volume, uint32_t* tiles, uint32_t capacity);
 /* A folded wait ends with a system-scope ACQUIRE by the wavefront that polled (`buffer_inv sc0 sc1`: invalidate, no write-back) in front of
  * the workgroup's plain loads of what the flags announce -- the default.  MV_DIST_PEER_NO_ACQUIRE leaves it out (round 4's form: it rested
  * on the rotation of the buffers alone), for A/B timing. */

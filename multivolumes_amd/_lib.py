@@ -128,6 +128,7 @@ ABI = {
     "mv_dist_init_peer": (C.c_int, [_P, _P, _U32]),
     "mv_dist_set_peer_timeout_ms": (C.c_int, [_P, _U32]),
     "mv_dist_peer_coherence": (C.c_int, [_P, _U32, C.POINTER(_U32), C.POINTER(_U32)]),
+    "mv_dealt_tiles": (_U32, [_U32, _U32, _U32, _U32, C.POINTER(_U32), _U32]),
     "mv_dist_selftest": (C.c_int, [_P]),
     "mv_dist_shutdown": (C.c_int, [_P]),
     "mv_dist_set_inplace_gather": (C.c_int, [_P, C.c_int]),

@@ -401,6 +401,14 @@ int peerCoherenceTest(mv_ctx* ctx, bool acquire, uint32_t* stale, uint32_t* firs
 
 extern "C" {
 
+uint32_t mv_dealt_tiles(uint32_t tiles_x, uint32_t shard_index, uint32_t shard_count, uint32_t volume, uint32_t* tiles, uint32_t capacity)
+{
+	if (!tiles_x || !shard_count || shard_index >= shard_count) return 0u;
+	const uint32_t n = mv::dealtTilesOfFace(tiles_x * tiles_x, tiles_x, shard_index, shard_count, volume);
+	for (uint32_t k = 0; k < n && k < capacity && tiles; ++k) tiles[k] = mv::dealtTile(k, tiles_x, shard_index, shard_count, volume);
+	return n;
+}
+
 int mv_dist_peer_coherence(mv_ctx* ctx, uint32_t acquire, uint32_t* stale_words, uint32_t* first_read_bad)
 {
 	if (!ctx || !stale_words || !first_read_bad) return MV_ERR_INVALID_ARG;

@@ -414,17 +414,16 @@ __host__ __device__ inline uint32_t dealtTilesOfFace(uint32_t T, uint32_t tilesX
 	const bool ownsLast = (groups - 1u - first) % shardCount == 0u;
 	return mine * G - (ownsLast ? groups * G - T : 0u);
 }
+__host__ __device__ inline uint32_t dealtTile(uint32_t k, uint32_t tilesX, uint32_t shardIndex, uint32_t shardCount, uint32_t v)	// the rank's k-th tile of a face
+{
+	const uint32_t G = dealtGroup(tilesX, shardCount);
+	return (dealtTileFirst(shardIndex, shardCount, v) + (k / G) * shardCount) * G + k % G;
+}
 __device__ __forceinline__ uint32_t cubeLocalTile(const DeviceState& st, uint32_t volumeId, uint32_t k)
 {
 	if (!(st.flags & kFlagDealTiles) || st.shardCount <= 1u) return k;
-	const uint32_t first = dealtTileFirst(st.shardIndex, st.shardCount, volumeId);
-#if MV_DEAL_ROWS
 	const uint32_t dims = st.N >> reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId].x;
-	const uint32_t G = dealtGroup((dims + 7u) >> 3, st.shardCount);
-	return (first + (k / G) * st.shardCount) * G + k % G;
-#else
-	return first + k * st.shardCount;
-#endif
+	return dealtTile(k, (dims + 7u) >> 3, st.shardIndex, st.shardCount, volumeId);
 }
 // Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
 // their position among this frame's screen tiles.  A key that names another tile after a mip / visibility change only

@@ -316,3 +316,36 @@ def test_gloo_protocol_with_the_loops_work_deal(oracle, tmp_path, world):
                               ref["info"], ref["vis"], ref["cubeMaps"], ref["cubeDepths"])
     assert np.array_equal(got["full"], img)
     assert int(got["samples"][0]) == ref["stats"]["view_samples"] and int(got["samples"][1]) == ref["stats"]["rays"]
+
+
+def test_tile_deal_is_a_partition_of_every_face():
+    """Peer-store transport, several frames per launch: the tiles of a marched cube face are dealt over the ranks in groups of whole tile rows
+    (csrc/mv_kernels.hpp dealtGroup / dealtTile; include/multivolumes.h mv_dealt_tiles).  Whatever the face size, the world size and the volume:
+    every tile belongs to exactly one rank, a rank's k-th tiles are distinct, the counts the cull sizes its work list with are the lists'
+    lengths, and power-of-two worlds get equal shares of faces their size divides.  (Pure host arithmetic: runs without a GPU.)"""
+    import ctypes as C
+    from multivolumes_amd import _lib
+    lib = _lib.load()
+    buf = (C.c_uint32 * 4096)()
+    for tiles_x in (1, 2, 3, 4, 5, 6, 7, 8, 12, 16, 20, 32, 40):
+        T = tiles_x * tiles_x
+        for world in range(1, 9):
+            for v in (0, 1, 2, 5, 7, 8, 13, 63):
+                seen = []
+                counts = []
+                for rank in range(world):
+                    n = lib.mv_dealt_tiles(tiles_x, rank, world, v, buf, 4096)
+                    assert n == lib.mv_dealt_tiles(tiles_x, rank, world, v, None, 0), "the count does not depend on the buffer"
+                    mine = list(buf[:n])
+                    assert len(set(mine)) == n and all(t < T for t in mine), (tiles_x, world, v, rank)
+                    assert mine == sorted(mine), "a rank marches its tiles in face order"
+                    seen += mine
+                    counts.append(n)
+                assert sorted(seen) == list(range(T)), (tiles_x, world, v)
+                if world in (1, 2, 4, 8) and tiles_x % (2 * world) == 0:
+                    assert len(set(counts)) == 1, (tiles_x, world, v, counts)   # two-row groups, equally many per rank
+                    # ... and they are whole rows: a rank's tiles come in runs of 2 * tiles_x
+                    n = lib.mv_dealt_tiles(tiles_x, 0, world, v, buf, 4096)
+                    runs = [buf[i] for i in range(0, n, 2 * tiles_x)]
+                    assert all(r % (2 * tiles_x) == 0 for r in runs), (tiles_x, world, v)
+    assert lib.mv_dealt_tiles(0, 0, 1, 0, buf, 16) == 0 and lib.mv_dealt_tiles(4, 3, 3, 0, buf, 16) == 0   # (nonsense in: nothing out)
