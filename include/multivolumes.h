@@ -141,7 +141,7 @@ typedef struct mv_stats
 
 const char* mv_error_string(int code);
 const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
-#define MV_ABI_VERSION 5u	/* (mv_config MUST be zeroed before it is filled in: frames_per_launch, ABI 5, took the place of padding, and a caller of ABI 4 that left garbage there gets MV_ERR_INVALID_ARG or B times the output sets) 5: peer-store transport (mv_dist_peer_export, mv_dist_init_peer, MV_ERR_TIMEOUT, MV_DIST_PEER_BYTES 8192), mv_config.frames_per_launch, MV_FLAG_CULL_ON_VIEW_STREAM; 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms; 4: mv_config.frames_in_flight, MV_DIST_ID_BYTES 640 (up to five communicators), light march shared out over the ranks */
+#define MV_ABI_VERSION 6u	/* (mv_config MUST be zeroed before it is filled in: frames_per_launch, ABI 5, took the place of padding, and a caller of ABI 4 that left garbage there gets MV_ERR_INVALID_ARG or B times the output sets) 6: the peer-store export blob carries a per-process nonce and a staging map per rank (blobs of ABI 5 are refused), MV_FLAG_FINEGRAINED_PEER_BUFFERS, MV_DIST_PEER_NO_ACQUIRE / _PUSH_CELLS, mv_dist_peer_coherence, mv_dist_peer_info, mv_set_latency_sampling / mv_get_latency, mv_dealt_tiles; 5: peer-store transport (mv_dist_peer_export, mv_dist_init_peer, MV_ERR_TIMEOUT, MV_DIST_PEER_BYTES 8192), mv_config.frames_per_launch, MV_FLAG_CULL_ON_VIEW_STREAM; 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms; 4: mv_config.frames_in_flight, MV_DIST_ID_BYTES 640 (up to five communicators), light march shared out over the ranks */
 uint32_t mv_abi_version(void);	/* == MV_ABI_VERSION of the header the library was built from */
 
 /* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,

@@ -42,7 +42,7 @@ MV_DIST_PEER_DEAL_VOLUMES = 16
 MV_DIST_PEER_DEAL_TILES = 32
 MV_DIST_PEER_NO_ACQUIRE = 64
 MV_DIST_PEER_PUSH_CELLS = 128
-MV_ABI_VERSION = 5  # include/multivolumes.h
+MV_ABI_VERSION = 6  # include/multivolumes.h
 DIST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 DIST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int)
 

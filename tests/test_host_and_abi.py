@@ -27,7 +27,7 @@ def test_abi_exports_every_declared_symbol(mvlib):
         assert hasattr(mvlib, name), f"{name} is declared in include/ but not exported"
         assert name in _lib.ABI, f"{name} has no ctypes signature in multivolumes_amd/_lib.py"
     hdr = open(os.path.join(ROOT, "include", "multivolumes.h")).read()
-    assert mvlib.mv_abi_version() == int(re.search(r"#define MV_ABI_VERSION (\d+)u", hdr).group(1)) == 5
+    assert mvlib.mv_abi_version() == int(re.search(r"#define MV_ABI_VERSION (\d+)u", hdr).group(1)) == 6
     assert C.sizeof(_lib.mv_config) == 64 and C.sizeof(_lib.mv_stats) == 128
     assert mvlib.mv_error_string(_lib.MV_ERR_NO_DEVICE).decode().startswith("no usable gfx950")
 
