@@ -535,21 +535,39 @@ def main():
         for v in sorted(int(x) for x in cube_):
             crc = zlib.crc32(caster.ReadBackCubeMap(v, int(info_[v, 0])).tobytes(), crc)
             crc = zlib.crc32(caster.ReadBackCubeDepth(v, int(info_[v, 0])).tobytes(), crc)
-        if do_composite and not to_root:
-            crc = zlib.crc32(caster.ReadBackComposite().tobytes(), crc)
+        # the frame: with the rows pushed to every rank, every rank's whole image; with the rows to rank 0 only (the default), rank r's OWN tile
+        # rows as rank r composited them against the same rows of rank 0's assembled image -- the bytes the composite's peer stores carried
+        # (that image, the only complete one, was compared with nothing)
+        row_crcs = None
+        if do_composite:
+            img_ = caster.ReadBackComposite()
+            if not to_root:
+                crc = zlib.crc32(img_.tobytes(), crc)
+            else:
+                def rows_crc(r_):
+                    c_ = 0
+                    for t_ in D.tile_rows_of_rank(H, r_, world):
+                        c_ = zlib.crc32(img_[8 * t_:min(8 * t_ + 8, H)].tobytes(), c_)
+                    return c_
+                row_crcs = [rows_crc(r_) for r_ in range(world)] if rank == 0 else rows_crc(rank)
         # bytes this rank sends per frame (peer stores): its marched texels (8 B colour + 4 B depth) and its layers of the relit light map to
         # every other rank, its screen rows to every other rank or to rank 0
         pinfo = caster.DistPeerInfo()
         rows_mine = len(D.tile_rows_of_rank(H, rank, world)) * 8 * W * 8 if hasattr(D, "tile_rows_of_rank") else (band[1] - band[0]) * W * 8
         out_bytes = ((st["rays"] / max(1, args.steps)) * 12 + (L ** 3 // world) * pinfo["light_push_bytes_per_texel"]) * (world - 1) \
             + rows_mine * ((0 if rank == 0 else 1) if to_root else (world - 1)) if exchange == "peer" else None
-        dist.all_gather_object(mine, (dt / args.steps * 1e3, crc, out_bytes, (dt_steady / args.steady_frames * 1e3) if dt_steady else None, latency))
+        dist.all_gather_object(mine, (dt / args.steps * 1e3, crc, out_bytes, (dt_steady / args.steady_frames * 1e3) if dt_steady else None, latency, row_crcs))
         per_rank_ms = [round(m[0], 5) for m in mine]
         ranks_agree = len(set(m[1] for m in mine)) == 1
-        if not ranks_agree:
+        rows_agree = True
+        if to_root and do_composite:  # rank 0's assembled image holds every rank's rows as that rank wrote them
+            rows_agree = all(mine[0][5][r_] == (mine[r_][5] if r_ else mine[0][5][0]) for r_ in range(world))
+        if not ranks_agree or not rows_agree:
             # a transport that delivered different images to different ranks is a failed transport: no line, and the supervisors move on
             if rank == 0:
-                print(f"bench.py: the ranks do not hold the same frame after the run (transport {exchange}): {[hex(m[1]) for m in mine]}", file=sys.stderr)
+                what = "the ranks do not hold the same light maps / cube faces" if not ranks_agree else "rank 0's assembled frame does not hold the rows the ranks composited"
+                print(f"bench.py: {what} after the run (transport {exchange}): {[hex(m[1]) for m in mine]}"
+                      + ("" if rows_agree else f"; rows at rank 0 {[hex(x) for x in mine[0][5]]}, at their ranks {[hex(m[5]) if i else '-' for i, m in enumerate(mine)]}"), file=sys.stderr)
             caster.close()
             return 4
         t = torch.tensor([dt, dt_steady or 0.0], dtype=torch.float64, device="cuda")
@@ -636,7 +654,7 @@ def main():
                 "light_samples_per_frame": tot_light // K,
                 "fetch_free_samples_per_frame": tot_free // K,
                 "frames_per_launch": (args.frames_per_launch or 1) if world > 1 else None,
-                "parallelism": (f"{world} ranks, peer stores (no collectives): " + ("every cube-map volume's 8x8 tiles dealt over the ranks" if (args.frames_per_launch or 1) > 1 else "cube-map volumes dealt per frame by estimated march cost") + ", the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, rows pushed into every rank's frame buffer; the frame's light march shared out by layers of voxel blocks, pushed into every rank's light map; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
+                "parallelism": (f"{world} ranks, peer stores (no collectives): " + ("every cube-map volume's 8x8 tiles dealt over the ranks" if (args.frames_per_launch or 1) > 1 else "cube-map volumes dealt per frame by estimated march cost") + ", the view march stores its texels into every rank's cube maps; screen-space RayCast and composite dealt by 8-row tile row, " + ("rows stored by the composite into rank 0's frame buffer" if rows_to_root else "rows stored by the composite into every rank's frame buffer") + "; the frame's light march shared out by layers of voxel blocks, " + ("whole cells pushed into every rank's light map" if args.peer_push_cells else "plain texels pushed into every rank's staging map and the cells rebuilt by the receivers") + "; flags in uncached device memory order them; frame loop inside the library (mv_dist_frame)" if exchange == "peer"
                                 else f"{world} ranks: cube-map volumes dealt per frame by estimated march cost + all-gather of the marched cube faces, screen-space RayCast and composite dealt by 8-row tile row + in-place all-gather of the rows, the frame's light march shared out by voxel blocks + all-gather of the shares; frame loop inside the library (mv_dist_frame), transport: {exchange}") if world > 1 else "single GPU",
                 "frames_in_flight": ((f"up to {args.frames_in_flight or 3} whole frames (" + ("upload, cull, " if args.cull_on_view_stream else "") + f"light march, view march, composite) on {args.frames_in_flight or 3} view streams"
                                       + ("" if args.cull_on_view_stream else "; upload + cull on a stream of their own")) if world == 1
@@ -655,7 +673,7 @@ def main():
                 "transport_ladder": LEVELS if world > 1 else None,
                 "rccl_ranks": caster.DistInfo()["ranks"] if world > 1 else None,
                 "ms_per_step_per_rank": per_rank_ms, "ranks_hold_the_same_frame": ranks_agree,
-                "ranks_compared": ("every light map, the marched faces of every cube map" + ("" if (rows_to_root and exchange == "peer") else ", the composite")) if world > 1 else None,
+                "ranks_compared": ("every light map, the marched faces of every cube map" + (", every rank's own rows of the composite against rank 0's assembled frame" if (rows_to_root and exchange == "peer") else ", the composite")) if world > 1 else None,
             },
             "kernel_ms": k_alone, "kernel_ms_in_flight": k_in_flight,
             "composite_msamples_per_s": st["composite_samples"] / dt / 1e6,

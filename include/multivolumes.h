@@ -141,7 +141,10 @@ typedef struct mv_stats
 
 const char* mv_error_string(int code);
 const char* mv_last_error(const mv_ctx* ctx);	/* text of the last failure on this context ("" if none) */
-#define MV_ABI_VERSION 6u	/* (mv_config MUST be zeroed before it is filled in: frames_per_launch, ABI 5, took the place of padding, and a caller of ABI 4 that left garbage there gets MV_ERR_INVALID_ARG or B times the output sets) 6: the peer-store export blob carries a per-process nonce and a staging map per rank (blobs of ABI 5 are refused), MV_FLAG_FINEGRAINED_PEER_BUFFERS, MV_DIST_PEER_NO_ACQUIRE / _PUSH_CELLS, mv_dist_peer_coherence, mv_dist_peer_info, mv_set_latency_sampling / mv_get_latency, mv_dealt_tiles; 5: peer-store transport (mv_dist_peer_export, mv_dist_init_peer, MV_ERR_TIMEOUT, MV_DIST_PEER_BYTES 8192), mv_config.frames_per_launch, MV_FLAG_CULL_ON_VIEW_STREAM; 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms; 4: mv_config.frames_in_flight, MV_DIST_ID_BYTES 640 (up to five communicators), light march shared out over the ranks */
+const char* mv_get_warning(const mv_ctx* ctx);	/* what mv_create found worth saying although it succeeded ("" if nothing): today, a context that keeps more streams busy than
+												   the process has hardware queues -- GPU_MAX_HW_QUEUES >= frames_in_flight + 1 must be in the environment BEFORE the HIP runtime
+												   starts (the library sets no environment variable; bench.py sets 8); without it the frames share queues and wait for each other */
+#define MV_ABI_VERSION 6u	/* (mv_config MUST be zeroed before it is filled in: frames_per_launch, ABI 5, took the place of padding, and a caller of ABI 4 that left garbage there gets MV_ERR_INVALID_ARG or B times the output sets) 6: the peer-store export blob carries a per-process nonce and a staging map per rank (blobs of ABI 5 are refused), MV_FLAG_FINEGRAINED_PEER_BUFFERS, MV_DIST_PEER_NO_ACQUIRE / _PUSH_CELLS, mv_dist_peer_coherence, mv_dist_peer_info, mv_set_latency_sampling / mv_get_latency, mv_dealt_tiles, mv_light_rebuild_range, mv_get_warning (round 6, additive: the queue warning of mv_create no longer sits in mv_last_error); 5: peer-store transport (mv_dist_peer_export, mv_dist_init_peer, MV_ERR_TIMEOUT, MV_DIST_PEER_BYTES 8192), mv_config.frames_per_launch, MV_FLAG_CULL_ON_VIEW_STREAM; 2: MV_DIST_ID_BYTES 384 (three communicators), mv_dist_shutdown, mv_dist_set_inplace_gather, MV_MAX_SHARDS; 3: mv_set_viewport, mv_dist_info, mv_dist_rccl_available, mv_host_wait_ms; 4: mv_config.frames_in_flight, MV_DIST_ID_BYTES 640 (up to five communicators), light march shared out over the ranks */
 uint32_t mv_abi_version(void);	/* == MV_ABI_VERSION of the header the library was built from */
 
 /* MultiRayCaster::Init (MultiRayCaster.cpp:79-166): creates volumes[S], lightMaps[V], cubeMaps/cubeDepths[V] (5 mips,
@@ -372,6 +375,11 @@ int mv_dist_init_callbacks(mv_ctx* ctx, mv_dist_allgather_fn allgather, mv_dist_
 /* The deal's rule as a function (tests, tools): the tiles of a cube face of tiles_x x tiles_x tiles of volume `volume` that rank shard_index of
  * shard_count marches, in its marching order, into tiles[0 .. capacity); returns how many there are.  Over the ranks: a partition of the face. */
 uint32_t mv_dealt_tiles(uint32_t tiles_x, uint32_t shard_index, uint32_t shard_count, uint32_t volume, uint32_t* tiles, uint32_t capacity);
+/* The light share-out's rule as a function (tests, tools; the arithmetic peerRebuildLightRole runs on the device): the z slices [out[0], out[1])
+ * of the relit light map that rank shard_index of shard_count marches and pushes -- a slab of ceil(B / shard_count) adjacent layers of four slices,
+ * B = ceil(L / 4); EMPTY, at L, for a rank beyond the last layer -- and the cells it rebuilds from the other ranks' texels: out[4] of them, cell k
+ * being cell k of the map for k < out[2], else cell k + out[3].  out[3] + out[4] == L^3.  MV_ERR_INVALID_ARG outside 2 <= L <= 640, 1 <= shard_count <= 64. */
+int mv_light_rebuild_range(uint32_t light_grid_size, uint32_t shard_index, uint32_t shard_count, uint32_t out[5]);
 /* A folded wait ends with a system-scope ACQUIRE by the wavefront that polled (`buffer_inv sc0 sc1`: invalidate, no write-back) in front of
  * the workgroup's plain loads of what the flags announce -- the default.  MV_DIST_PEER_NO_ACQUIRE leaves it out (round 4's form: it rested
  * on the rotation of the buffers alone), for A/B timing. */
@@ -403,11 +411,11 @@ int mv_dist_shutdown(mv_ctx* ctx);	/* detach the frame loop (drains it first); m
 int mv_dist_selftest(mv_ctx* ctx);	/* one all-gather (plain and in place) and one all-reduce per communicator, verified: call once after init on every rank */
 int mv_dist_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject, int with_composite);
 int mv_dist_flush(mv_ctx* ctx);	/* enqueue the exchange + composite of the last frame begun (then mv_synchronize / readbacks see it) */
-int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset);
+int mv_dist_exchanged_bytes(mv_ctx* ctx, uint64_t* bytes, int reset);	/* bytes this rank received through the collectives (peer stores: what the other ranks stored into its buffers, from the frames' own figures) */
 /* peer-store transport: out[8] = { waits folded, folded waits acquire, rows to rank 0 only, whole volumes per rank, bytes pushed per texel of a
  * rank's share of the relit light map, kind of memory the flag block lives in (2 uncached, 1 fine-grained, 0 plain), stale words and
  * wrong first reads of the last in-kernel coherence test }; all zero on the other transports */
-int mv_dist_peer_info(mv_ctx* ctx, uint32_t* out);	/* bytes this rank received through the collectives */
+int mv_dist_peer_info(mv_ctx* ctx, uint32_t* out);
 /* transport: 0 none, 1 RCCL, 2 caller-supplied collectives, 3 peer stores; ranks: the size of the communicator as RCCL reports it (ncclCommCount), or
  * shard_count for caller-supplied collectives; communicators: how many the loop keeps busy (3 with whole-frame chains, else 2) */
 int mv_dist_info(mv_ctx* ctx, uint32_t* transport, uint32_t* ranks, uint32_t* communicators);

@@ -78,6 +78,7 @@ _SZ = C.c_size_t
 ABI = {
     "mv_error_string": (C.c_char_p, [C.c_int]),
     "mv_last_error": (C.c_char_p, [_P]),
+    "mv_get_warning": (C.c_char_p, [_P]),
     "mv_abi_version": (_U32, []),
     "mv_create": (C.c_int, [C.POINTER(mv_config), C.POINTER(_P)]),
     "mv_destroy": (None, [_P]),
@@ -129,6 +130,7 @@ ABI = {
     "mv_dist_set_peer_timeout_ms": (C.c_int, [_P, _U32]),
     "mv_dist_peer_coherence": (C.c_int, [_P, _U32, C.POINTER(_U32), C.POINTER(_U32)]),
     "mv_dealt_tiles": (_U32, [_U32, _U32, _U32, _U32, C.POINTER(_U32), _U32]),
+    "mv_light_rebuild_range": (C.c_int, [_U32, _U32, _U32, C.POINTER(_U32)]),
     "mv_dist_selftest": (C.c_int, [_P]),
     "mv_dist_shutdown": (C.c_int, [_P]),
     "mv_dist_set_inplace_gather": (C.c_int, [_P, C.c_int]),

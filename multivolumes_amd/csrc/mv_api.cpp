@@ -26,6 +26,7 @@ const char* mv_error_string(int code)
 }
 
 const char* mv_last_error(const mv_ctx* ctx) { return ctx ? ctx->lastError.c_str() : ""; }
+const char* mv_get_warning(const mv_ctx* ctx) { return ctx ? ctx->warning.c_str() : ""; }
 uint32_t mv_abi_version(void) { return MV_ABI_VERSION; }
 uint64_t mv_cube_chain_texels(uint32_t N) { return mv::cubeChainTexels(N); }
 uint64_t mv_cube_mip_offset(uint32_t N, uint32_t mip) { return mv::cubeMipOffset(N, mip); }
@@ -93,7 +94,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 		// other: with three chains that is four streams; more chains need GPU_MAX_HW_QUEUES >= C + 1 in the environment before the HIP
 		// runtime starts -- the CALLER's job (bench.py does it): the library sets no environment variable.  A context that asks for more streams
 		// than the process has hardware queues still works, its frames share queues and wait for each other (profiles/r03_frames_in_flight.txt);
-		// mv_last_error says so after mv_create.
+		// mv_get_warning says so after mv_create.
 		if (cfg->flags & MV_FLAG_SINGLE_VIEW_STREAM)
 		{
 			if (hipStreamCreateWithPriority(&ctx->streamL, hipStreamNonBlocking, prHigh) != hipSuccess) return bail(MV_ERR_HIP);
@@ -334,7 +335,7 @@ int mv_create(const mv_config* cfg, mv_ctx** out)
 			char buf[256];
 			snprintf(buf, sizeof(buf), "warning: this context keeps %u streams busy and the process has %u hardware queues (GPU_MAX_HW_QUEUES%s): streams that share a queue wait for each other",
 				streams, queues, q ? "" : " is not set: the runtime's default of 4");
-			ctx->lastError = buf;
+			ctx->warning = buf;	// (not lastError: that is "" unless a call failed -- ADVICE r05)
 		}
 	}
 	*out = ctx;
@@ -1124,9 +1125,9 @@ int mv_set_latency_sampling(mv_ctx* ctx, uint32_t every_n_frames)
 {
 	if (!ctx) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	latencyHarvest(ctx);
+	if (ctx->latEvery) latencyHarvest(ctx, true);
 	for (uint32_t i = 0; i < kMaxFrameSlots; ++i) ctx->latOfSlot[i] = -1;
-	for (uint32_t i = 0; i < mv_ctx::kLatencyPool; ++i) ctx->lat[i].busy = false;
+	for (uint32_t i = 0; i < mv_ctx::kLatencyPool; ++i) { ctx->lat[i].busy = false; ctx->lat[i].open = false; }
 	ctx->latEvery = every_n_frames;
 	return MV_OK;
 }
@@ -1135,7 +1136,7 @@ int mv_get_latency(mv_ctx* ctx, double* mean_ms, double* max_ms, uint64_t* sampl
 {
 	if (!ctx || !mean_ms || !max_ms || !samples) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// (the frames in flight finish; the host functions behind them have run)
-	latencyHarvest(ctx);
+	latencyHarvest(ctx, true);
 	*samples = ctx->latCount; *mean_ms = ctx->latCount ? ctx->latSumMs / (double)ctx->latCount : 0.0; *max_ms = ctx->latMaxMs;
 	if (reset) { ctx->latSumMs = 0.0; ctx->latMaxMs = 0.0; ctx->latCount = 0; }
 	return MV_OK;

@@ -241,7 +241,10 @@ struct mv_ctx
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
 	// Frame latency, sampled (mv_set_latency_sampling): the host's clock when a frame's constants are handed over (mv_update_frame /
 	// mv_dist_frame) and when the last kernel of that frame has finished -- a host function behind the record of the frame's "done" event.
-	struct LatencySample { std::atomic<long long> startNs{0}, doneNs{0}; bool busy = false; };
+	// A frame is marked more than once (behind its march, behind its composite or tail): a sample counts when every mark the host enqueued for it
+	// has fired AND no further mark can come (its slot was handed to a newer frame, or everything was synchronised) -- round 5 counted a sample at its
+	// first mark and let the second one write into whichever frame had taken the sample over.
+	struct LatencySample { std::atomic<long long> startNs{0}, doneNs{0}; std::atomic<uint32_t> fired{0}; uint32_t enqueued = 0; bool busy = false, open = false; };
 	static constexpr uint32_t kLatencyPool = 64;	// samples in flight (a frame slot is reused by the HOST before the GPU is done with the frame it held: samples live apart from slots)
 	LatencySample lat[kLatencyPool];
 	int latOfSlot[kMaxFrameSlots];					// the sample of the frame a slot holds, or -1
@@ -256,6 +259,7 @@ struct mv_ctx
 	double msStage[4] = { 0, 0, 0, 0 };
 	uint64_t nStage[4] = { 0, 0, 0, 0 };
 	std::string lastError;
+	std::string warning;				// mv_get_warning: what a caller should know although the call succeeded (lastError stays the text of the last FAILURE)
 	DistState* dist = nullptr;
 	// Cross-stream ordering goes through evRecord / evWait below, which leave out the waits that are redundant: an event recorded on the
 	// very stream that is asked to wait for it (stream order already says so), and a wait the stream has already made for the same
@@ -490,29 +494,45 @@ hipError_t stageBBegin(mv_ctx* ctx)
 // stage of stream B finished being enqueued: the next user of this slot's buffers (ctx->numSlots frames on) and the light march two frames on wait for it
 // (latency sampling) behind a record of slot's "done" event on stream s: the host's clock at that point of the stream
 inline long long hostNowNs() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-inline void latencyDoneFn(void* p) { static_cast<mv_ctx::LatencySample*>(p)->doneNs.store(hostNowNs(), std::memory_order_release); }
-inline void latencyHarvest(mv_ctx* ctx)
+inline void latencyDoneFn(void* p)
+{
+	mv_ctx::LatencySample* l = static_cast<mv_ctx::LatencySample*>(p);
+	const long long now = hostNowNs();
+	long long seen = l->doneNs.load(std::memory_order_relaxed);
+	while (seen < now && !l->doneNs.compare_exchange_weak(seen, now, std::memory_order_relaxed)) {}	// (marks of one frame may sit on two streams: the later clock stands)
+	l->fired.fetch_add(1u, std::memory_order_release);
+}
+// all: everything enqueued has run (the caller synchronised), so the samples of frames still in their slots are complete too
+inline void latencyHarvest(mv_ctx* ctx, bool all = false)
 {
 	for (uint32_t i = 0; i < mv_ctx::kLatencyPool; ++i)
 	{
 		mv_ctx::LatencySample& l = ctx->lat[i];
-		const long long done = l.doneNs.load(std::memory_order_acquire);
-		if (!l.busy || !done) continue;
-		const double ms = (double)(done - l.startNs.load(std::memory_order_relaxed)) * 1e-6;
-		ctx->latSumMs += ms; ctx->latMaxMs = ms > ctx->latMaxMs ? ms : ctx->latMaxMs; ++ctx->latCount;
-		l.busy = false; l.doneNs.store(0, std::memory_order_relaxed);
+		if (!l.busy || (l.open && !all)) continue;
+		if (l.fired.load(std::memory_order_acquire) != l.enqueued) continue;	// a mark is still on its stream
+		if (l.enqueued)
+		{
+			const double ms = (double)(l.doneNs.load(std::memory_order_relaxed) - l.startNs.load(std::memory_order_relaxed)) * 1e-6;
+			ctx->latSumMs += ms; ctx->latMaxMs = ms > ctx->latMaxMs ? ms : ctx->latMaxMs; ++ctx->latCount;
+		}
+		l.busy = false; l.open = false;
+		for (uint32_t sl = 0; sl < kMaxFrameSlots; ++sl) if (ctx->latOfSlot[sl] == (int)i) ctx->latOfSlot[sl] = -1;	// (no later mark of that frame finds a sample that may be another frame's by then)
 	}
 }
 // a new frame in `slot`: every latEvery-th one is sampled, if a sample is free
 inline void latencyBegin(mv_ctx* ctx, uint32_t slot, uint64_t frame)
 {
+	if (!ctx->latEvery) { ctx->latOfSlot[slot] = -1; return; }	// (the table is only defined once mv_set_latency_sampling has run)
+	if (ctx->latOfSlot[slot] >= 0) ctx->lat[ctx->latOfSlot[slot]].open = false;	// the frame this slot held has been enqueued to its end: no more marks for it
 	ctx->latOfSlot[slot] = -1;
-	if (!ctx->latEvery || frame % ctx->latEvery != 0u) return;
+	if (frame % ctx->latEvery != 0u) return;
 	latencyHarvest(ctx);
 	for (uint32_t i = 0; i < mv_ctx::kLatencyPool; ++i)
 		if (!ctx->lat[i].busy)
 		{
-			ctx->lat[i].busy = true; ctx->lat[i].doneNs.store(0, std::memory_order_relaxed); ctx->lat[i].startNs.store(hostNowNs(), std::memory_order_relaxed);
+			mv_ctx::LatencySample& l = ctx->lat[i];
+			l.busy = true; l.open = true; l.enqueued = 0u; l.fired.store(0u, std::memory_order_relaxed);
+			l.doneNs.store(0, std::memory_order_relaxed); l.startNs.store(hostNowNs(), std::memory_order_relaxed);
 			ctx->latOfSlot[slot] = (int)i;
 			return;
 		}
@@ -520,7 +540,11 @@ inline void latencyBegin(mv_ctx* ctx, uint32_t slot, uint64_t frame)
 inline hipError_t latencyMark(mv_ctx* ctx, uint32_t slot, hipStream_t s)
 {
 	if (!ctx->latEvery || ctx->latOfSlot[slot] < 0) return hipSuccess;
-	return hipLaunchHostFunc(s, latencyDoneFn, &ctx->lat[ctx->latOfSlot[slot]]);	// (a frame may be marked twice -- behind its march and behind its composite: the later clock stands)
+	mv_ctx::LatencySample& l = ctx->lat[ctx->latOfSlot[slot]];
+	++l.enqueued;
+	const hipError_t e = hipLaunchHostFunc(s, latencyDoneFn, &l);
+	if (e != hipSuccess) --l.enqueued;
+	return e;
 }
 hipError_t stageBDone(mv_ctx* ctx)
 {

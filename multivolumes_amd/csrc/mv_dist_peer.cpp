@@ -229,6 +229,7 @@ int peerBeforeView(mv_ctx* ctx)
 			a.waitRow[a.nWait] = kStageLight * mv::kPeerMaxChains + chain; a.waitValue[a.nWait++] = d->peerFrame;
 			if (d->cullCrosscheck) a.checkChain = chain;
 			mv::launchPeerSync(streamB(ctx), a);
+			MV_HIP(ctx, hipGetLastError());
 			DeviceState sr = ctx->st;
 			foldBase(ctx, sr, kFoldRebuild, d->peerFrame, ctx->st.frameTag, ctx->slot);
 			sr.fold.rebuildRow = kStageRebuilt * mv::kPeerMaxChains + chain; sr.fold.rebuildValue = d->peerFrame;
@@ -407,6 +408,14 @@ uint32_t mv_dealt_tiles(uint32_t tiles_x, uint32_t shard_index, uint32_t shard_c
 	const uint32_t n = mv::dealtTilesOfFace(tiles_x * tiles_x, tiles_x, shard_index, shard_count, volume);
 	for (uint32_t k = 0; k < n && k < capacity && tiles; ++k) tiles[k] = mv::dealtTile(k, tiles_x, shard_index, shard_count, volume);
 	return n;
+}
+
+int mv_light_rebuild_range(uint32_t light_grid_size, uint32_t shard_index, uint32_t shard_count, uint32_t out[5])
+{
+	if (!out || light_grid_size < 2u || light_grid_size > 640u || !shard_count || shard_count > mv::kPeerMaxRanks || shard_index >= shard_count) return MV_ERR_INVALID_ARG;
+	const mv::LightRebuildRange r = mv::lightRebuildRange(light_grid_size, shard_index, shard_count);
+	out[0] = r.z0; out[1] = r.z1; out[2] = r.before; out[3] = r.skip; out[4] = r.total;
+	return MV_OK;
 }
 
 int mv_dist_peer_coherence(mv_ctx* ctx, uint32_t acquire, uint32_t* stale_words, uint32_t* first_read_bad)

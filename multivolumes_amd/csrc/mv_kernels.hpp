@@ -453,6 +453,24 @@ __host__ __device__ inline uint32_t lightLayerOfRank(uint32_t B, uint32_t rank, 
 	if (MV_LIGHT_LAYERS_INTERLEAVED) return rank + i * shardCount;
 	return rank * ((B + shardCount - 1u) / shardCount) + i;
 }
+// (plain light push) the cells a rank REBUILDS from the texels the other ranks pushed: all L^3 of the map but its own slab [z0, z1) of slices --
+// cell index k of `total` maps to cell k (k < before) or k + skip of the map.  A rank whose slab would start beyond the map (B layers over more
+// ranks than ceil(B / per) of them get one: L = 48 on 8 ranks, rank 7) owns the EMPTY range at L: round 5 computed [first * 4, L) there, whose
+// length wrapped -- 129 024 "cells" for a map of 110 592.  mv_light_rebuild_range states this through the C ABI for the CPU tests.
+struct LightRebuildRange { uint32_t z0, z1, before, skip, total; };
+__host__ __device__ inline LightRebuildRange lightRebuildRange(uint32_t L, uint32_t rank, uint32_t shardCount)
+{
+	LightRebuildRange r;
+	const uint32_t B = (L + 3u) >> 2, plane = L * L;
+	if (MV_LIGHT_LAYERS_INTERLEAVED) { r.z0 = r.z1 = 0u; r.before = 0u; r.skip = 0u; r.total = L * plane; return r; }	// (every cell is visited, a rank's own are left out one by one)
+	const uint32_t per = (B + shardCount - 1u) / shardCount, mine = lightLayersOfRank(B, rank, shardCount);
+	const uint64_t first = (uint64_t)rank * per;
+	const uint32_t z0 = first * 4u < L ? (uint32_t)(first * 4u) : L;
+	const uint32_t z1e = (first + mine) * 4u < L ? (uint32_t)((first + mine) * 4u) : L;
+	r.z0 = z0; r.z1 = z1e > z0 ? z1e : z0;
+	r.before = r.z0 * plane; r.skip = (r.z1 - r.z0) * plane; r.total = L * plane - r.skip;
+	return r;
+}
 constexpr uint32_t kFlagRotateAllLightMaps = 0x80000000u;	// DeviceState.flags (internal): every rank rotates the relit volume's light buffer, not only its owner
 
 // The 8-row tile rows of a screen rectangle [y0, y1] (pixel rows, y1 already clipped to the viewport) that this context marches and
@@ -640,19 +658,15 @@ __device__ __forceinline__ void peerRebuildLightRole(const DeviceState& st, size
 	const uint32_t count = st.counters[0];
 	const uint32_t volumeId = count ? st.visibleVolumes[frameIdx % count] : frameIdx % st.V;	// CSRayMarchL.hlsl:29-33
 	uint4* cells = st.lightTable[volumeId];
-	const uint32_t L = st.L, B = (L + 3u) >> 2;
-	const uint32_t per = (B + st.shardCount - 1u) / st.shardCount;
+	const uint32_t L = st.L;
 	const size_t plane = (size_t)L * L;
-	// (slabs: this rank's layers are [first, first + mine); everything else belongs to the others)
-	const uint32_t mine = lightLayersOfRank(B, st.shardIndex, st.shardCount), first = MV_LIGHT_LAYERS_INTERLEAVED ? 0u : st.shardIndex * per;
-	const uint32_t z0m = first * 4u, z1m = (first + mine) * 4u < L ? (first + mine) * 4u : L;
-	const size_t before = (size_t)(MV_LIGHT_LAYERS_INTERLEAVED ? 0u : z0m) * plane, total = (size_t)L * plane - (MV_LIGHT_LAYERS_INTERLEAVED ? 0u : (size_t)(z1m - z0m) * plane);
 	// Consecutive lanes take consecutive cells (every load and the 16-byte store of a wavefront are contiguous), four cells per thread and
 	// iteration with all sixteen loads in front of the four stores: vmcnt counts loads and stores in order, so a thread's next loads queue
 	// behind its stores -- one cell per iteration with write-through stores ran at a store acknowledgement per cell, 95 cells per thread
 	// (profiles/r05_plain_light_push.txt)
 	// (32-bit indices: L <= 640 keeps L^3 below 2^28, and a 64-bit division per cell cost more than the cell)
-	const uint32_t total32 = (uint32_t)total, before32 = (uint32_t)before, skip32 = (z1m - z0m) * (uint32_t)plane, plane32 = (uint32_t)plane, n32 = (uint32_t)n;
+	const LightRebuildRange rr = lightRebuildRange(L, st.shardIndex, st.shardCount);
+	const uint32_t total32 = rr.total, before32 = rr.before, skip32 = rr.skip, plane32 = (uint32_t)plane, n32 = (uint32_t)n;
 	for (uint32_t k = (uint32_t)t; k < total32; k += 4u * n32)
 	{
 		uint4 c[4];

@@ -148,6 +148,12 @@ class MultiRayCaster:
         if rc != 0:
             self._ctx = C.c_void_p()
             raise MVError(rc, "mv_create")
+        # what mv_create found worth saying although it succeeded (include/multivolumes.h mv_get_warning): a context with more chains than the
+        # process has hardware queues needs GPU_MAX_HW_QUEUES >= framesInFlight + 1 in the environment BEFORE torch / HIP start (bench.py sets 8)
+        self.warning = self._lib.mv_get_warning(self._ctx).decode()
+        if self.warning:
+            import warnings
+            warnings.warn(self.warning, RuntimeWarning, stacklevel=2)
         # host-side state of the reference class (MultiRayCaster.cpp:58-72)
         self.m_maxRaySamples, self.m_maxLightSamples = 256, 96
         self.m_lightPt = np.array([75.0, 75.0, -75.0], np.float32)

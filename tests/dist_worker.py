@@ -31,7 +31,10 @@ def test_config(world):
     name = os.environ.get("MV_TEST_CONFIG")
     if name:
         return dict(scene.CONFIGS[name])
-    return dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))
+    cfg = dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))
+    if os.environ.get("MV_TEST_L"):  # another light grid: how many block layers the ranks share out (idle ranks whose slab would start beyond the map)
+        cfg["L"] = int(os.environ["MV_TEST_L"])
+    return cfg
 
 
 def main():
@@ -124,6 +127,14 @@ def main():
         nbytes = c.DistExchangedBytes()
     cnt = torch.tensor([st[k] for k in ("view_samples", "lit_samples", "rays", "light_samples", "composite_samples")], dtype=torch.int64)
     dist.all_reduce(cnt)
+    if not diverge:
+        # EVERY rank holds every light map, current: rank 0's are compared with the single-GPU run by the test, the other ranks' with rank 0's
+        # here (a rank that rebuilds the others' layers wrongly corrupts its own maps only)
+        import zlib
+        crcs = torch.zeros(world, dtype=torch.int64)
+        crcs[rank] = zlib.crc32(lms.tobytes())
+        dist.all_reduce(crcs)
+        assert len(set(crcs.tolist())) == 1, f"the ranks' light maps differ: {crcs.tolist()}"
     if rank == 0:
         np.savez(out_path, imgs=np.stack(imgs), infos=np.stack(infos), counts=cnt.numpy(), lms=lms, nbytes=nbytes)
     dist.barrier()

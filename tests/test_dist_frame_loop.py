@@ -69,8 +69,12 @@ def single_gpu(world, frames, every, static_depth=False, all_frames=False):
                                                            (2, "peer-four", 3, False), (3, "peer-four", 13, True), (2, "peer-four", 26, True), (3, "chains-four", 13, True),
                                                            (3, "peer-root", 13, True), (3, "peer-tiles", 13, True), (2, "peer-tiles", 3, False), (3, "peer-x2-volumes", 13, True),
                                                            (2, "peer-x2", 3, False), (3, "peer-x2", 13, True), (2, "peer-x2", 26, True), (2, "peer-x3", 13, True), (3, "peer-x4", 7, True),
-                                                           (5, "peer-x4", 13, True)])
-def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static_depth):
+                                                           (5, "peer-x4", 13, True),
+                                                           # ranks that own NO layer of the light map and whose slab would start beyond it (B = 8 block layers,
+                                                           # two per rank: ranks 4.. idle, rank 5's slab "starts" at z = 40 > L = 32; round 5's ADVICE: the
+                                                           # rebuild's range wrapped there); L = 24 on five ranks: rank 4 at z = 32 > 24
+                                                           (6, "peer", 13, True), (7, "peer-x2", 13, True), (5, "peer-folded-L24", 13, True)])
+def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static_depth, monkeypatch):
     """Both schedules of the loop (include/multivolumes.h): whole frames on three view streams with a communicator each ("chains"),
     and one view stream with the exchange beside it ("single").  With `static_depth` nothing inside the sequence drains the frames
     in flight (a depth-map setter does), so up to three frames -- collectives included -- really overlap between checkpoints.
@@ -82,6 +86,10 @@ def test_dist_frame_loop_matches_single_gpu(tmp_path, world, mode, every, static
     frames = 26
     out = str(tmp_path / "dist.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if mode.endswith("-L24"):
+        mode = mode[:-len("-L24")]
+        env["MV_TEST_L"] = "24"
+        monkeypatch.setenv("MV_TEST_L", "24")  # (single_gpu() below reads the same config)
     if mode == "peer-root":  # the rows to rank 0 only (it is rank 0 whose frames the test compares)
         mode, env["MV_TEST_ROWS_TO_ROOT"] = "peer", "1"
     if mode == "peer-tiles":  # one frame per launch with every cube-map volume's tiles shared out (MV_DIST_PEER_DEAL_TILES; the default there: whole volumes per rank)

@@ -349,3 +349,41 @@ def test_tile_deal_is_a_partition_of_every_face():
                     runs = [buf[i] for i in range(0, n, 2 * tiles_x)]
                     assert all(r % (2 * tiles_x) == 0 for r in runs), (tiles_x, world, v)
     assert lib.mv_dealt_tiles(0, 0, 1, 0, buf, 16) == 0 and lib.mv_dealt_tiles(4, 3, 3, 0, buf, 16) == 0   # (nonsense in: nothing out)
+
+
+def test_light_rebuild_range_for_every_light_grid_and_world():
+    """Peer-store transport, plain light push: the range of cells a rank rebuilds from the other ranks' texels (csrc/mv_kernels.hpp
+    lightRebuildRange -- the arithmetic peerRebuildLightRole runs on the device -- through include/multivolumes.h mv_light_rebuild_range) for EVERY
+    light grid mv_create accepts and every world size up to 64: the ranks' slabs tile the map once and agree with the numpy restatement, a rank
+    rebuilds exactly the cells outside its slab, and no index it forms leaves the map.  Round 5's form wrapped for a rank whose slab would start
+    beyond the map (L = 48 on 8 ranks: 129 024 cells of a 110 592-cell map; T2 on 6 or 7 ranks, T1 on 5): those cases are named.
+    (Pure host arithmetic: runs without a GPU.)"""
+    import ctypes as C
+    from multivolumes_amd import _lib
+    lib = _lib.load()
+    out = (C.c_uint32 * 5)()
+    wrapped_in_round_5 = 0
+    for L in list(range(2, 131)) + [191, 192, 255, 256, 257, 383, 512, 639, 640]:
+        plane, B = L * L, (L + 3) // 4
+        for world in range(1, 65):
+            covered = 0
+            per = (B + world - 1) // world
+            for rank in range(world):
+                assert lib.mv_light_rebuild_range(L, rank, world, out) == 0
+                z0, z1, before, skip, total = (int(x) for x in out)
+                a, b = D.light_layers_of_rank(L, rank, world)
+                assert (z1 - z0) == (b - a) and (b == a or (z0, z1) == (a, b)), (L, world, rank)
+                assert 0 <= z0 <= z1 <= L and before == z0 * plane and skip == (z1 - z0) * plane and skip + total == L * plane, (L, world, rank)
+                # the last cell index the kernel forms: k = total - 1 -> k (if below `before`) or k + skip: inside the map, outside the slab
+                if total:
+                    last = total - 1 if total - 1 < before else total - 1 + skip
+                    assert last < L * plane and not (z0 * plane <= last < z1 * plane), (L, world, rank)
+                covered += z1 - z0
+                if rank * per * 4 > L:
+                    wrapped_in_round_5 += 1
+                    assert z0 == z1 == L and total == L * plane
+            assert covered == L, (L, world)
+    assert wrapped_in_round_5 > 1000
+    for L, world, rank in ((48, 8, 7), (32, 6, 5), (32, 7, 5), (32, 7, 6), (24, 5, 4), (64, 7, 6)):  # ADVICE r05's cases
+        assert lib.mv_light_rebuild_range(L, rank, world, out) == 0 and tuple(out) == (L, L, L ** 3, 0, L ** 3), (L, world, rank, tuple(out))
+    assert lib.mv_light_rebuild_range(1, 0, 1, out) != 0 and lib.mv_light_rebuild_range(96, 8, 8, out) != 0 and lib.mv_light_rebuild_range(96, 0, 65, out) != 0
