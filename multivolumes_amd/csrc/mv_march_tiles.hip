@@ -23,6 +23,9 @@ constexpr uint32_t kTileWaves = MV_TILE_WAVES;
 #ifndef MV_TILE_LUT
 #define MV_TILE_LUT 1	// per-axis address tables in LDS (N <= 256); 0 = compute every tap's offsets (A/B timing)
 #endif
+#ifndef MV_BATCH_COLOCATE
+#define MV_BATCH_COLOCATE 0	// several frames per launch: the same tile pair of every frame on the same XCD (round 6 experiment)
+#endif
 #ifndef MV_TILE_MIN_WAVES
 #define MV_TILE_MIN_WAVES 3	// occupancy bound given to the register allocator / scheduler. Measured at C3: 3 -> 0.360 ms, 5 -> 0.395, 6 -> 0.414,
 							// 7 -> 0.46, 8 -> 0.60 (spills); all of 1..5 allocate about 90 VGPRs, the looser bound schedules loads earlier
@@ -47,7 +50,7 @@ constexpr uint32_t kLutMaxN = 256;
 // IL: the rows of a sharded context are dealt by tile row (kFlagInterleaveRows) -- compile-time, see screenTileRowsT
 // (marchBlock: this workgroup's index among the workgroups that march)
 template <bool OVERFLOW, bool LUT, bool IL, bool PEER>
-__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis, uint32_t marchBlock);
+__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis, uint32_t marchBlock, const DeviceState& orderSt);
 
 // PEER: the peer-store transport's instantiation: a folded wait in front (mv_kernels.hpp peerFoldWait), every marched texel also stored
 // into the other ranks' cube maps, the last workgroup raises "cube faces landed" (peerFoldSignal); the others are untouched by it
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 		// inside the body, by the wavefronts whose tile reads the volume relit in this frame -- the others march at once, beside the push
 		// above and the other ranks')
 	}
-	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis, (PEER && !OVERFLOW) ? blockIdx.x - st.fold.pushBlocks - st.fold.rebuildBlocks : blockIdx.x);
+	marchTilesBody<OVERFLOW, LUT, IL, PEER>(st, firstSlot, sAxis, (PEER && !OVERFLOW) ? blockIdx.x - st.fold.pushBlocks - st.fold.rebuildBlocks : blockIdx.x, st);
 	if constexpr (PEER) peerFoldSignal(st);
 }
 
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 	{
 		const DeviceState& st = p.s[blockIdx.y];
 		const uint32_t first = blockIdx.y == 0u ? firstSlots.x : blockIdx.y == 1u ? firstSlots.y : blockIdx.y == 2u ? firstSlots.z : firstSlots.w;
-		if (first != 0xffffffffu) marchTilesBody<true, LUT, IL, true>(st, first, sAxis, blockIdx.x);
+		if (first != 0xffffffffu) marchTilesBody<true, LUT, IL, true>(st, first, sAxis, blockIdx.x, st);
 		peerFoldSignal(st);
 		return;
 	}
@@ -128,14 +131,23 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 		peerFoldSignal(st);
 		return;
 	}
-	const uint32_t m = blockIdx.x - pushAll - rebuildAll, marchBlock = m / n;
-	const DeviceState& st = p.s[m - marchBlock * n];
-	marchTilesBody<false, LUT, IL, true>(st, 0u, sAxis, marchBlock);
+	const uint32_t m = blockIdx.x - pushAll - rebuildAll;
+#if MV_BATCH_COLOCATE != 0
+	// Workgroups are dealt round-robin over the eight XCDs, each with an L2 of its own.  The frames of a launch march (nearly) the same tiles
+	// through the same volumes: eight consecutive workgroups -- one per XCD -- take eight consecutive tile pairs of ONE frame, the next eight
+	// the same pairs of the next frame, so the n marches of a tile pair run side by side on the SAME XCD and all but the first find the
+	// texels in its L2 (the grid is a multiple of 8 n workgroups: marchTilesBlocks rounds a frame's blocks up to a multiple of eight).
+	const uint32_t g = m / (8u * n), r = m - g * 8u * n, frame = r >> 3, marchBlock = g * 8u + (r & 7u);
+#else
+	const uint32_t marchBlock = m / n, frame = m - marchBlock * n;	// (frames interleaved workgroup by workgroup: a tile pair's n marches on n different XCDs)
+#endif
+	const DeviceState& st = p.s[frame];
+	marchTilesBody<false, LUT, IL, true>(st, 0u, sAxis, marchBlock, MV_BATCH_COLOCATE == 2 ? p.s[0] : st);	// (2: EXPERIMENT, identical work lists only -- every frame in frame 0's tile order)
 	peerFoldSignal(st);
 }
 
 template <bool OVERFLOW, bool LUT, bool IL, bool PEER>
-__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis, uint32_t marchBlock)
+__device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t firstSlot, u32x4* sAxis, uint32_t marchBlock, const DeviceState& orderSt)
 {
 	const uint32_t lane = threadIdx.x & 63u;
 	const uint32_t wave = threadIdx.x >> 6;
@@ -171,7 +183,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	const unsigned long long tileStart = wall_clock64();
 #endif
 	uint32_t costBin = kOrderBins;
-	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(st, __builtin_amdgcn_readfirstlane(orderSlot), &costBin));
+	const uint32_t tile = __builtin_amdgcn_readfirstlane(orderedTile(orderSt, __builtin_amdgcn_readfirstlane(orderSlot), &costBin));
 
 	// find the work entry that owns this tile (wave-uniform)
 	uint32_t entry = 0;
