@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on an MI355X box (run through gpurun from the repo root). Round tag in $1 (default r02).
-R=${1:-r05}
+R=${1:-r06}
 OUT=/root/repo/gpurun_out/profiles_$R
 rm -rf $OUT; mkdir -p $OUT
 cd /root/repo
