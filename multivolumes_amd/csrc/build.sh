@@ -19,6 +19,7 @@ $HIPCC $FLAGS -c mv_march.hip -o $OBJ/mv_march.o "$@" & pids+=($!)
 TILES=mv_march_tiles.hip
 case " $* " in *MV_TILE_STAGE*|*MV_TILE_SPECULATE_BELOW*|*MV_TILE_PRIORITY*) TILES=experiments/mv_march_tiles_experiments.hip;; esac
 case " $* " in *MV_EMPTY_REGIONS*|*MV_EMULATE_LIGHT_PAIRS*|*MV_TILE_LDS_PAD*|*MV_DIAG_ITER*|*MV_TILE_DIET*) TILES=experiments/mv_march_tiles_r05.hip;; esac	# (round 5's: profiles/r05_instruction_cuts.txt)
+TILES=${MV_TILES_SRC:-$TILES}	# (diagnostics: a patched copy of the tile march, e.g. scripts/r06_valu_pad.sh)
 $HIPCC $FLAGS -I. -c $TILES -o $OBJ/mv_march_tiles.o "$@" & pids+=($!)
 $HIPCC $FLAGS -c mv_peer.hip -o $OBJ/mv_peer.o "$@" & pids+=($!)
 NARROW=""
