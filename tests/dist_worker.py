@@ -34,6 +34,10 @@ def test_config(world):
     cfg = dict(scene.CONFIGS["T2"], W=int(os.environ.get("MV_TEST_W", "256")), H=int(os.environ.get("MV_TEST_H", "168" if world != 3 else "200")))
     if os.environ.get("MV_TEST_L"):  # another light grid: how many block layers the ranks share out (idle ranks whose slab would start beyond the map)
         cfg["L"] = int(os.environ["MV_TEST_L"])
+    # (tests/test_dist_fuzz.py: any of the config's sizes -- N = volume and cube-face edge, V volumes, ray / light sample caps)
+    for key, env in (("N", "MV_TEST_N"), ("V", "MV_TEST_V"), ("maxRay", "MV_TEST_MAXRAY"), ("maxLight", "MV_TEST_MAXLIGHT")):
+        if os.environ.get(env):
+            cfg[key] = int(os.environ[env])
     return cfg
 
 

@@ -1,0 +1,74 @@
+"""Fuzz of the multi-GPU frame loop (mv_dist_frame), round 6: a seeded random config (volume edge N, light grid L, volume count V, viewport, sample
+caps), world size and transport form against the single-GPU frames of the same config -- composites, VolumeInfo, every light map on EVERY rank, summed
+counters, bit for bit.  Round 5's review found a range that wrapped for light grids and world sizes no hand-picked case had combined (L = 48 on 8 ranks,
+T2 on 6 or 7): the hand-picked cases stay in tests/test_dist_frame_loop.py, this walks the space between them.  Ranks share cuda:0 (IPC mappings and
+gloo callbacks work between processes on one device).  MV_DIST_FUZZ=n runs n seeds (default 6: about a minute); MV_DIST_FUZZ_FIRST=k starts at seed k."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests.test_dist_frame_loop import ROOT, _free_port, run_group, single_gpu
+
+pytestmark = pytest.mark.gpu
+
+MODES = ["chains", "single", "peer", "peer-folded", "peer-four", "peer-root", "peer-tiles", "peer-x2", "peer-x3", "peer-x4", "peer-x2-volumes", "peer-x4-root", "peer-cells", "peer-x4-cells"]
+
+
+def draw(seed):
+    r = np.random.default_rng(1000 + seed)
+    world = int(r.choice([2, 3, 4, 5, 6, 7, 8]))
+    mode = MODES[int(r.integers(len(MODES)))]
+    cfg = dict(N=int(r.choice([16, 24, 32, 36, 40, 48, 56])), L=int(r.integers(6, 45)), V=int(r.choice([1, 2, 4, 4, 9, 16, 16])),
+               W=int(r.integers(64, 330)), H=int(r.integers(40, 250)), maxRay=int(r.choice([16, 32, 48, 64, 96])), maxLight=int(r.choice([8, 16, 24, 32])))
+    if world >= 6:  # (many processes on the one GPU: keep each small)
+        cfg["N"] = min(cfg["N"], 40)
+    frames = int(r.integers(8, 15))
+    every = int(r.choice([3, 5, 7, frames]))
+    static_depth = bool(r.integers(2))
+    return world, mode, cfg, frames, every, static_depth
+
+
+N_SEEDS = int(os.environ.get("MV_DIST_FUZZ", "6"))
+FIRST = int(os.environ.get("MV_DIST_FUZZ_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + N_SEEDS))
+def test_random_config_world_and_transport_match_single_gpu(tmp_path, seed, monkeypatch):
+    world, mode, cfg, frames, every, static_depth = draw(seed)
+    label = f"seed {seed}: world {world} {mode} {cfg} frames {frames} every {every} static_depth {static_depth}"
+    print(label)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for key, name in (("N", "MV_TEST_N"), ("L", "MV_TEST_L"), ("V", "MV_TEST_V"), ("W", "MV_TEST_W"), ("H", "MV_TEST_H"), ("maxRay", "MV_TEST_MAXRAY"), ("maxLight", "MV_TEST_MAXLIGHT")):
+        env[name] = str(cfg[key])
+        monkeypatch.setenv(name, str(cfg[key]))  # (single_gpu() below reads the same config)
+    if mode.endswith("-cells"):  # round 4's light push: whole cells instead of plain texels rebuilt by the receivers
+        mode, env["MV_TEST_PUSH_CELLS"] = mode[:-len("-cells")], "1"
+    if mode.endswith("-root"):
+        mode, env["MV_TEST_ROWS_TO_ROOT"] = mode[:-len("-root")], "1"
+    if mode == "peer-tiles":
+        mode, env["MV_TEST_DEAL_VOLUMES"] = "peer", "0"
+    if mode.endswith("-volumes"):
+        mode, env["MV_TEST_DEAL_VOLUMES"] = mode[:-len("-volumes")], "1"
+    if "-x" in mode:
+        env["MV_TEST_FRAMES_PER_LAUNCH"] = mode[-1]
+        mode, env["MV_TEST_FOUR_CHAINS"] = "peer-folded", "1"
+    if mode.endswith("-four"):
+        env["MV_TEST_FOUR_CHAINS"] = "1"
+        mode = mode[:-len("-four")]
+    if mode.startswith("peer"):
+        env["MV_TEST_PEER_FOLD"] = "1" if mode == "peer-folded" else "0"
+        mode, env["MV_TEST_TRANSPORT"] = "chains", "peer"
+    out = str(tmp_path / "dist.npz")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every), mode, "1" if static_depth else "0"]
+    r = run_group(cmd, 400, env)
+    assert r.returncode == 0, label + "\n" + r.stderr[-3000:]
+    d = np.load(out)
+    imgs, infos, counts, lms = single_gpu(world, frames, every, static_depth)
+    assert np.array_equal(d["infos"], infos), label
+    for i in range(len(imgs)):
+        assert np.array_equal(d["imgs"][i], imgs[i]), f"{label}: composite of checkpoint {i} differs ({(d['imgs'][i] != imgs[i]).sum()} halfs)"
+    assert np.array_equal(d["lms"], lms), label + ": light maps"
+    assert np.array_equal(d["counts"], counts), label + ": counters"
