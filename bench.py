@@ -671,7 +671,8 @@ def main():
                 "peer": caster.DistPeerInfo() if (world > 1 and exchange == "peer") else None,
                 "transport": exchange, "fallback_level": int(os.environ.get("MV_BENCH_LEVEL", "0")),
                 "transport_ladder": LEVELS if world > 1 else None,
-                "rccl_ranks": caster.DistInfo()["ranks"] if world > 1 else None,
+                "rccl_ranks": caster.DistInfo()["ranks"] if world > 1 else None,  # (the size of the transport's group as the library reports it: ncclCommCount on the RCCL rungs, the mapped peers on the peer-store rungs)
+                "transport_ranks": caster.DistInfo()["ranks"] if world > 1 else None,
                 "ms_per_step_per_rank": per_rank_ms, "ranks_hold_the_same_frame": ranks_agree,
                 "ranks_compared": ("every light map, the marched faces of every cube map" + (", every rank's own rows of the composite against rank 0's assembled frame" if (rows_to_root and exchange == "peer") else ", the composite")) if world > 1 else None,
             },
