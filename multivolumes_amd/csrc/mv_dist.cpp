@@ -393,6 +393,7 @@ static int distTailComposite(mv_ctx* ctx)
 		// chains: the copy-forward of this frame's unmarched faces ran on the stream of the frame before it
 		if (d->chains) MV_HIP(ctx, evWait(ctx, X, ctx->evCopy[slot]));
 		uint32_t launched = 0;
+		EventPair evt = { nullptr, nullptr, 0 };	// (profiling only: the composite's own time -- the bench line's kernel_ms.composite was 0 on this path until round 6)
 		if (d->transport == 3 && world > 1u)
 		{
 			// peer stores: the composite waits for every rank's cube faces itself (folded; else a kernel in front of it has) and stores every
@@ -404,9 +405,11 @@ static int distTailComposite(mv_ctx* ctx)
 			if (rc != MV_OK) return rc;
 			if (!d->peerFold) foldBase(ctx, stc, kFoldComposite, d->framePending, st.frameTag, slot);
 			stc.fold.stores = 1u; stc.fold.rowsRoot = d->peerRowsRoot ? 1u : 0u;
+			beginStage(ctx, 3, evt, X);
 			launched = mv::launchComposite(X, stc, st.bandRow0, st.bandRow1);
 		}
-		else launched = mv::launchComposite(X, st, st.bandRow0, st.bandRow1);
+		else { beginStage(ctx, 3, evt, X); launched = mv::launchComposite(X, st, st.bandRow0, st.bandRow1); }
+		endStage(ctx, evt, X);
 		compositeLaunched = launched != 0u;
 		MV_HIP(ctx, hipGetLastError());
 		if (d->transport == 3) d->bytes += (size_t)st.H * st.W * sizeof(uint2) / world * (d->peerRowsRoot ? (st.shardIndex ? 0u : world - 1u) : world - 1u);	// (rows pushed into this rank's frame buffer)

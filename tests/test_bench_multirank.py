@@ -57,6 +57,8 @@ def test_two_ranks_on_one_gpu(extra):
     # (latency has its own pass behind the timed frames: on ranks that share a GPU with gloo in between, either pass can hit a stall the other does not)
     assert d["latency_samples"] > 0 and d["latency_ms"] > 0 and d["latency_ms_max"] >= d["latency_ms"]
     assert d["steady_state_ms_per_step"] > 0 and d["steady_state_frames"] == 24
+    # every stage of rank 0's frame is timed, whichever path enqueued it (round 6: the composite of the loop's one-frame tail was not)
+    assert all(d["kernel_ms"][k] > 0 for k in ("cull", "march_light", "march_view", "composite")), d["kernel_ms"]
     if d["config"]["transport"] == "peer":
         c = d["config"]
         assert c["peer"]["rows_to_root"] and c["peer"]["acquire"] and c["peer"]["stale_words"] == 0
