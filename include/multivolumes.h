@@ -207,7 +207,10 @@ int mv_readback_shadow_map(mv_ctx* ctx, uint16_t* dst /* M x M */);
 int mv_cull(mv_ctx* ctx);
 /* rayMarchL (MultiRayCaster.cpp:1299-1327) = CSRayMarchL.hlsl:20-121: relights ONE volume, visible[FrameIdx % count].
  * On sharded contexts only the shard that owns that volume marches (the others return at once): the light maps evolve frame
- * by frame exactly as on one GPU. */
+ * by frame exactly as on one GPU.  A frame may leave it out (the reference then simply keeps its light maps): the frame -- whatever else it
+ * does, mv_cull alone included -- and the frames after it read the maps that were last written (round 6: a frame with no stage that reads
+ * light maps used to leave the relit volume's entry on an unwritten buffer; profiles/r06_api_fuzz.txt).  It must come before the frame's
+ * mv_march_view / mv_composite. */
 int mv_march_light(mv_ctx* ctx);
 /* rayMarchV (MultiRayCaster.cpp:1329-1368) = CSRayMarch.hlsl:77-158 with _LIGHT_PASS_ (CSRayMarchV.hlsl). */
 int mv_march_view(mv_ctx* ctx);
@@ -239,6 +242,9 @@ int mv_readback_light_map(mv_ctx* ctx, uint32_t volume, uint32_t* dst /* L^3 */)
 int mv_upload_light_map(mv_ctx* ctx, uint32_t volume, const uint32_t* src /* L^3 */);	/* test/exchange hook */
 int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* dst /* 6 x d x d x 4 */);
 int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* dst /* 6 x d x d */);
+/* (Contexts with frames in flight rotate output sets.  mv_readback_cube_map / _cube_depth / _composite read the CURRENT frame's set: what they return is
+ * defined behind a frame that marched / composited -- the set is then complete, every face the frame did not march brought forward -- and equals the
+ * one-stream context's; behind a frame that did neither it is that set's older content.) */
 int mv_readback_composite(mv_ctx* ctx, uint16_t* dst /* W x H x 4, rows in screen order (also inside the multi-GPU frame loop, where the device buffer MV_BUF_COMPOSITE keeps them rank-major by 8-row tile row: see mv_dist_frame) */);
 int mv_clear_cube_maps(mv_ctx* ctx);	/* zero every cube map / cube depth (creation state) */
 

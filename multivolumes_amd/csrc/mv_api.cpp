@@ -615,6 +615,12 @@ int mvi::keepLightTable(mv_ctx* ctx)
 int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 {
 	if (!ctx || !cbPerFrame || !perObject) return MV_ERR_INVALID_ARG;
+	// The frame that ends here may have had NO stage that reads light maps (mv_cull alone, or nothing at all): nobody has put the previous
+	// frame's light table back behind its cull's pre-rotation (keepLightTable), and this frame's cull derives its table from that one --
+	// the volume that frame would have relit then pointed at a buffer nobody wrote, until its next relight (round 6: tests/test_api_fuzz.py
+	// found it on the four-chain context, where an unwritten buffer is likeliest: a whole light map of zeros for up to V frames).
+	// (frameBegun, not haveFrame: a viewport change between the two frames forgets the frame in progress but not its slot's table)
+	if (ctx->frameBegun && !ctx->lightMarched && !ctx->lightTableKept && !ctx->batchExplicit) { const int rc = keepLightTable(ctx); if (rc != MV_OK) return rc; }
 	// a new frame: the next slot of constants / cull buffers (and the other parity's march outputs)
 	ctx->slot = (ctx->slot + 1u) % ctx->numSlots;
 	++ctx->frame;
@@ -675,7 +681,7 @@ int mv_update_frame(mv_ctx* ctx, const void* cbPerFrame, const void* perObject)
 	memcpy(s + 256, perObject, (size_t)ctx->st.V * MV_PER_OBJECT_BYTES);
 	if (!ctx->deferUpload) MV_HIP(ctx, hipMemcpyAsync(ctx->fb[ctx->slot].dCb, s, ctx->sliceBytes, hipMemcpyHostToDevice, ctx->streamA));	// (deferred: the multi-GPU loop uploads a group's slices together)
 	MV_HIP(ctx, stageADone(ctx, false));	// (a frame that never culls still marks its copy; inside the multi-GPU loop the cull's record follows at once)
-	ctx->haveFrame = true;
+	ctx->haveFrame = true; ctx->frameBegun = true;
 	ctx->haveCull = false;	// this frame's slot holds the cull outputs of four frames ago until mv_cull runs
 	ctx->lightMarched = false; ctx->lightTableKept = false; ctx->copiedForward = false; ctx->marchedThisFrame = false;
 	return MV_OK;
@@ -950,7 +956,8 @@ int mv_readback_volume(mv_ctx* ctx, uint32_t src, uint16_t* dst)
 
 static int currentLightBuffer(mv_ctx* ctx, uint32_t volume, uint4** out)
 {
-	if (ctx->lightTableFrame == ctx->frame)
+	// (unsettled: see below -- then this frame's table, also the copy mv_readback_cull brought back, is not the one to read)
+	if (ctx->lightTableFrame == ctx->frame && (ctx->lightMarched || ctx->lightTableKept))
 	{
 		// this frame's table came back with mv_readback_cull: no host synchronisation, the context's stream waits for the
 		// frame's light march instead (work the caller orders on that stream then sees the relit map)
@@ -960,7 +967,12 @@ static int currentLightBuffer(mv_ctx* ctx, uint32_t volume, uint4** out)
 		return MV_OK;
 	}
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
-	MV_HIP(ctx, hipMemcpy(out, ctx->st.lightTable + volume, sizeof(uint4*), hipMemcpyDeviceToHost));
+	// The frame in progress has neither relit a volume nor put the previous frame's table back (a cull alone so far, or not even that):
+	// its slot's table names, for the volume it would relight, a buffer nobody has written -- or is the table of numSlots frames ago.  The
+	// maps that were last written are the previous frame's (what keepLightTable would copy here).
+	const bool unsettled = ctx->frameBegun && !ctx->lightMarched && !ctx->lightTableKept;
+	uint4* const* table = unsettled ? ctx->fb[(ctx->slot + ctx->numSlots - 1u) % ctx->numSlots].lightTable : ctx->st.lightTable;
+	MV_HIP(ctx, hipMemcpy(out, table + volume, sizeof(uint4*), hipMemcpyDeviceToHost));
 	return MV_OK;
 }
 

@@ -239,6 +239,7 @@ struct mv_ctx
 	uint64_t lightTableFrame = ~0ull;	// frame whose light table (V device pointers) sits at the end of pinnedCull
 
 	bool haveDepth = false, haveShadow = false, haveFrame = false, haveCull = false;
+	bool frameBegun = false;			// some mv_update_frame has run on this context (unlike haveFrame, a viewport change does not clear it: the slot's light table still needs settling)
 	// Frame latency, sampled (mv_set_latency_sampling): the host's clock when a frame's constants are handed over (mv_update_frame /
 	// mv_dist_frame) and when the last kernel of that frame has finished -- a host function behind the record of the frame's "done" event.
 	// A frame is marked more than once (behind its march, behind its composite or tail): a sample counts when every mark the host enqueued for it
