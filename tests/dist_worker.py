@@ -41,6 +41,44 @@ def test_config(world):
     return cfg
 
 
+def setter_script(frames, every, cfg):
+    """(tests/test_dist_fuzz.py, MV_TEST_SETTER_SEED) per frame: the input setters in front of it -- collective inside the loop: every rank makes the same
+    calls -- and whether the frame composites (checkpoint frames always do: a readback shows the image of a frame that composited)."""
+    seed = os.environ.get("MV_TEST_SETTER_SEED")
+    if not seed:
+        return [([], True)] * frames
+    r = np.random.default_rng(int(seed))
+    out = []
+    for f in range(frames):
+        setters = []
+        if r.random() < 0.35:
+            what = ["sh", "max_samples", "light", "volume", "light_map", "shadow"][int(r.integers(6))]
+            arg = {"sh": bool(r.integers(2)), "max_samples": (int(r.choice([16, 32, 48, 64])), int(r.choice([8, 16, 24, 32]))),
+                   "light": (float(r.uniform(40, 90)), float(r.uniform(40, 90)), -float(r.uniform(40, 90))), "volume": (int(r.integers(cfg["V"])), int(r.integers(0, 40))),
+                   "light_map": (int(r.integers(cfg["V"])), int(r.integers(1 << 30))), "shadow": float(r.uniform(4.0, 12.0))}[what]
+            setters.append((what, arg))
+        checkpoint = f % every == every - 1 or f == frames - 1
+        out.append((setters, True if checkpoint else bool(r.random() < 0.75)))
+    return out
+
+
+def apply_setter(c, cfg, fr, what, arg):
+    from multivolumes_amd import raycaster as rc, scene
+    if what == "sh":
+        c.SetSH(scene.DEFAULT_SH if arg else None)
+    elif what == "max_samples":
+        c.SetMaxSamples(*arg)
+    elif what == "light":
+        c.SetLight(arg, scene.LIGHT_COLOR, scene.LIGHT_INTENSITY)
+    elif what == "volume":
+        c.LoadVolumeData(arg[0], rc.synth_volume(cfg["N"], arg[1]))
+    elif what == "light_map":
+        L = cfg["L"]
+        c.UploadLightMap(arg[0], np.random.default_rng(arg[1]).integers(0, 2 ** 32, size=(L, L, L), dtype=np.uint64).astype(np.uint32) & np.uint32(0x3BFFF7FF))
+    elif what == "shadow":
+        c.SetRenderTargets(shadowMap=rc.synth_sphere_shadow(64, fr["shadowVP"], (0, 0, 0), arg))
+
+
 def main():
     import torch
     import torch.distributed as dist
@@ -94,7 +132,10 @@ def main():
             info = c.DistInfo()
             assert info["transport"] == "rccl" and info["ranks"] == world and info["communicators"] == (2 if mode == "single" else 3), info
         imgs, infos = [], []
+        script = setter_script(frames, every, cfg)
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
+            for what, arg in script[f][0]:
+                apply_setter(c, cfg, fr, what, arg)
             if (not static_depth and not diverge) or f == 0:
                 # (inside the loop the setter first enqueues the pending tail of frame f - 1 -- its exchange, composite and row gather --
                 # so that frame is composited against ITS depth map, not this one; a collective call, made by every rank)
@@ -119,7 +160,7 @@ def main():
                     os._exit(0)  # nothing more can be exchanged; the ranks leave without a collective
                 assert f <= 5 + 2 * max(per_launch, 1) - 2, "a frame after the divergent one went through"
                 continue
-            c.DistFrame(vp, fr["shadowVP"], e)
+            c.DistFrame(vp, fr["shadowVP"], e, composite=script[f][1])
             if after_setter and f != frames - 1:
                 continue
             if f % every == every - 1 or f == frames - 1:

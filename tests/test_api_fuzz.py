@@ -55,7 +55,12 @@ def run_sequence(seed, disable=(), verbose=False, only_kinds=None, variants=None
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
     vols = [rc.synth_volume(N, k) for k in range(V)]
     if variants is None:
-        variants = [(0, 0), (_lib.MV_FLAG_PIPELINE_FRAMES, 0), (_lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_CULL_ON_VIEW_STREAM, 4)]
+        P, CV, RQ = _lib.MV_FLAG_PIPELINE_FRAMES, _lib.MV_FLAG_CULL_ON_VIEW_STREAM, _lib.MV_FLAG_RAY_QUEUE
+        variants = [(0, 0), (P, 0), (P | CV, 4)]
+        # every third seed also: the other forms of a context -- the ray-queue march (one stream and with frames in flight), list order instead of the
+        # cost-binned tile order, two and five frames in flight, the single view stream of the multi-GPU loop's other schedule
+        if seed % 3 == 0 or os.environ.get("MV_API_FUZZ_ALL_CONTEXTS") == "1":
+            variants += [(RQ, 0), (P | RQ, 0), (P | _lib.MV_FLAG_LIST_ORDER, 0), (P, 2), (P, 5), (P | CV, 3), (P | _lib.MV_FLAG_SINGLE_VIEW_STREAM, 0)]
     cs = [MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=f, framesInFlight=n) for f, n in variants]
     label = f"seed {seed}: {cfg}"
     print(label)

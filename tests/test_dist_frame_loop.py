@@ -42,18 +42,21 @@ def run_group(cmd, timeout, env=None):
 def single_gpu(world, frames, every, static_depth=False, all_frames=False):
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
-    from tests.dist_worker import camera_sequence, test_config
+    from tests.dist_worker import apply_setter, camera_sequence, setter_script, test_config
     cfg = test_config(world)
     V = cfg["V"]
     vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
     with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64) as c:
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         imgs, infos = [], []
+        script = setter_script(frames, every, cfg)  # (MV_TEST_SETTER_SEED: the setters the ranks make between their frames, frames without a composite)
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
+            for what, arg in script[f][0]:
+                apply_setter(c, cfg, fr, what, arg)
             if not static_depth or f == 0:
                 c.SetRenderTargets(rc.synth_sphere_depth(cfg["W"], cfg["H"], vp, (0, 0, 0), scene.SPHERE_RADIUS))
             c.UpdateFrame(vp, fr["shadowVP"], e)
-            c.Render(composite=True)
+            c.Render(composite=script[f][1])
             if all_frames or f % every == every - 1 or f == frames - 1:
                 imgs.append(c.ReadBackComposite())
                 infos.append(c.ReadBackVolumeInfo())

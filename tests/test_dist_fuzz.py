@@ -27,6 +27,7 @@ def draw(seed):
     frames = int(r.integers(8, 15))
     every = int(r.choice([3, 5, 7, frames]))
     static_depth = bool(r.integers(2))
+    cfg["setters"] = int(r.integers(1, 1 << 30)) if r.random() < 0.5 else 0  # (half of the seeds: setters between the frames, frames without a composite)
     return world, mode, cfg, frames, every, static_depth
 
 
@@ -75,6 +76,9 @@ def test_random_config_world_and_transport_match_single_gpu(tmp_path, seed, monk
     if mode.startswith("peer"):
         env["MV_TEST_PEER_FOLD"] = "1" if mode == "peer-folded" else "0"
         mode, env["MV_TEST_TRANSPORT"] = "chains", "peer"
+    if cfg.get("setters"):  # (tests/dist_worker.py setter_script: light probe, sample caps, light, volume / light-map uploads, shadow map; DistFrame(composite=False))
+        env["MV_TEST_SETTER_SEED"] = str(cfg["setters"])
+        monkeypatch.setenv("MV_TEST_SETTER_SEED", str(cfg["setters"]))
     out = str(tmp_path / "dist.npz")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), out, str(frames), str(every), mode, "1" if static_depth else "0"]
