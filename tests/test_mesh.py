@@ -121,3 +121,38 @@ def test_gpu_rasteriser_parity_and_use(oracle):
         c.Render(composite=True)
         b = (c.ReadBackComposite(), c.ReadBackLightMap(0))
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MV_RASTER_FUZZ", "6"))))
+def test_gpu_rasteriser_equals_the_oracle_on_random_triangle_soups(oracle, seed):
+    """Round 6 fuzz of the depth / shadow producer (csrc/mv_mesh.hip against mvo_raster_depth): triangle soups no modelling tool would make -- slivers, triangles
+    larger than the screen, triangles that cross the screen's edges, the eye plane and the far plane, duplicates at equal depth, zero-area triangles, vertices on
+    pixel centres -- at odd viewports, with and without the jitter.  Depth and D16 shadow maps bit for bit."""
+    from multivolumes_amd import MultiRayCaster
+    r = np.random.default_rng(500 + seed)
+    cfg = dict(scene.CONFIGS["T1"], W=int(r.integers(33, 400)), H=int(r.integers(17, 300)))
+    M = int(r.choice([64, 100, 256]))
+    eye, vp, wvp, shadow_wvp = mesh_matrices(cfg, scale=float(r.uniform(0.5, 2.0)), pos=(float(r.uniform(-5, 5)), float(r.uniform(-5, 5)), float(r.uniform(-5, 5))))
+    n = int(r.integers(50, 600))
+    centre = r.normal(0.0, 25.0, size=(n, 1, 3))
+    size = np.exp(r.uniform(np.log(0.01), np.log(80.0), size=(n, 1, 1)))
+    tri = (centre + r.normal(0.0, 1.0, size=(n, 3, 3)) * size).astype(np.float32)
+    k = n // 10
+    tri[:k, 2] = tri[:k, 1]                                   # zero area
+    tri[k:2 * k] = tri[2 * k:3 * k]                           # duplicates (equal depth: atomicMin either way)
+    tri[3 * k:4 * k, :, :] += np.array(eye, np.float32)       # around and behind the eye
+    tri[4 * k:5 * k] = np.round(tri[4 * k:5 * k])             # lattice positions
+    pos = tri.reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    bias = (0.0, 0.0) if seed % 2 else ((2 * float(r.random()) - 1) / cfg["W"], (2 * float(r.random()) - 1) / cfg["H"])
+    exp_d = oracle.raster_depth(pos, idx, rc.transpose_store(wvp), cfg["W"], cfg["H"], bias)
+    exp_s = oracle.depth_to_d16(oracle.raster_depth(pos, idx, rc.transpose_store(shadow_wvp), M, M))
+    with MultiRayCaster(cfg["N"], cfg["L"], cfg["V"], cfg["V"], (cfg["W"], cfg["H"]), shadowMapSize=M) as c:
+        c.SetMesh(pos, idx)
+        c.RenderMeshDepth(wvp, bias)
+        c.RenderMeshShadow(shadow_wvp)
+        got_d, got_s = c.ReadBackDepthMap(), c.ReadBackShadowMap()
+    assert (exp_d < 1).sum() > 50, "the soup must cover something"
+    assert np.array_equal(got_d, exp_d), f"seed {seed}: {(got_d != exp_d).sum()} depth pixels differ"
+    assert np.array_equal(got_s, exp_s), f"seed {seed}: {(got_s != exp_s).sum()} shadow texels differ"
