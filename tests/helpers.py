@@ -10,7 +10,7 @@ def default_descs(V, S, N):
     return np.array([(i % S) | (5 << 14) | (N << 18) for i in range(V)], np.uint32)
 
 
-def host_frame(cfg, frame_idx=0, eye=None, worlds=None):
+def host_frame(cfg, frame_idx=0, eye=None, worlds=None, light=None):
     """(eye, viewProj, shadowVP^T, cbPerFrame bytes, perObject bytes) for a config, reference defaults."""
     V = cfg["V"]
     lib = _lib.load()
@@ -24,24 +24,25 @@ def host_frame(cfg, frame_idx=0, eye=None, worlds=None):
     lc = np.array([*scene.LIGHT_COLOR, scene.LIGHT_INTENSITY], np.float32)
     am = np.array([*scene.AMBIENT_COLOR, scene.AMBIENT_INTENSITY], np.float32)
     lib.mvh_update_frame(V, rc._ptr(worlds), rc._ptr(rc._f32(vp, 16)), rc._ptr(rc._f32(svp, 16)), rc._ptr(eye),
-                         float(cfg["W"]), float(cfg["H"]), rc._ptr(rc._f32(scene.LIGHT_PT, 3)), rc._ptr(lc), rc._ptr(am),
+                         float(cfg["W"]), float(cfg["H"]), rc._ptr(rc._f32(scene.LIGHT_PT if light is None else light, 3)), rc._ptr(lc), rc._ptr(am),
                          frame_idx, rc._ptr(cb), rc._ptr(po))
     return eye, vp, svp, cb, po
 
 
-def oracle_pipeline(o, cfg, volumes, M, frames=None, sh=None, eye=None):
-    """cull -> marchL for `frames` consecutive frame indices (default: one per volume) -> marchV, all on the oracle."""
+def oracle_pipeline(o, cfg, volumes, M, frames=None, sh=None, eye=None, worlds=None, light=None):
+    """cull -> marchL for `frames` consecutive frame indices (default: one per volume) -> marchV, all on the oracle.
+    worlds: V x 12 floats (mvh_set_volume_world per volume) instead of the reference's grid; light: another light position."""
     V, N, L = cfg["V"], cfg["N"], cfg["L"]
     S = len(volumes)
     descs = default_descs(V, S, N)
-    eye_, vp, svp, cb, po = host_frame(cfg, 0, eye)
+    eye_, vp, svp, cb, po = host_frame(cfg, 0, eye, worlds, light)
     depth, shadow = scene.depth_and_shadow(cfg, vp, svp, M)
     info, vis, cube = o.cull(V, po, descs, cb, cfg["maxRay"])
     lms = None
     nls = 0
     frames = V if frames is None else frames
     for f in range(frames):
-        _, _, _, cb, po = host_frame(cfg, f, eye)
+        _, _, _, cb, po = host_frame(cfg, f, eye, worlds, light)
         _, lms, n = o.march_light(V, N, L, M, volumes, descs, po, cb, shadow, sh, vis, cfg["maxLight"], lms)
         nls += n
     cm, cd, st = o.march_view(V, N, L, cfg["W"], cfg["H"], volumes, lms, depth, po, cb, info, cube)

@@ -66,6 +66,72 @@ def test_random_scene(oracle, seed):
         assert st[k] == ref["stats"][k], (k, cfg, kinds, eye)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MV_RANDOM_PLACED_SEEDS", "8"))))
+def test_random_scene_with_volumes_placed_at_will(oracle, seed):
+    """What the reference's grid of equal cubes never shows: volumes of different sizes anywhere -- overlapping, nested, one containing the eye, far apart
+    (SetVolumeWorld per volume: MultiRayCaster.cpp:297-303 takes any size and position) --, fewer volume textures than volumes (VolTexId = i % S,
+    MultiRayCaster.cpp:471-479) and another light position.  Light rays cross several boxes at once, fragments of overlapping cubes interleave in the
+    K-buffer, cube maps of aliased sources differ only by their transforms.  Everything against the oracle, bit for bit."""
+    from multivolumes_amd import _lib
+    from tests.helpers import host_frame
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.choice([12, 17, 24, 30, 36]))
+    L = int(rng.choice([6, 9, 12, 16]))
+    V = int(rng.choice([2, 3, 5, 8]))
+    S = int(rng.integers(1, V + 1))
+    W, H = int(rng.choice([96, 130, 200])), int(rng.choice([64, 100, 160]))
+    cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([16, 40, 100])), maxLight=int(rng.choice([8, 20, 48])), mesh=bool(rng.integers(0, 2)))
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "sparse", "noise", "thin"], size=S)]
+    worlds = np.zeros((V, 12), np.float32)
+    lib = _lib.load()
+    placed = []
+    for i in range(V):
+        size = float(np.exp(rng.uniform(np.log(4.0), np.log(60.0))))
+        pos = rng.normal(0.0, 18.0, size=3).astype(np.float32)
+        if i and rng.random() < 0.4:  # on top of / inside an earlier one
+            pos = (placed[int(rng.integers(len(placed)))][1] + rng.normal(0.0, 3.0, size=3)).astype(np.float32)
+        placed.append((size, pos))
+        lib.mvh_set_volume_world(size, rc._ptr(rc._f32(pos, 3)), rc._ptr(worlds[i]))
+    r = rng.uniform(8, 140)
+    d = rng.normal(size=3)
+    eye = tuple((d / np.linalg.norm(d) * r).astype(np.float32))
+    if rng.random() < 0.25:  # inside one of the volumes
+        eye = tuple((placed[0][1] + rng.uniform(-0.3, 0.3, size=3) * placed[0][0]).astype(np.float32))
+    light = tuple(float(x) for x in rng.normal(0.0, 60.0, size=3) + np.array([0.0, 40.0, 0.0]))
+    use_sh = bool(rng.integers(0, 2))
+    M = 64
+    ref = oracle_pipeline(oracle, cfg, vols, M, sh=scene.DEFAULT_SH if use_sh else None, eye=eye, worlds=worlds, light=light)
+    with make_caster(cfg, M, S=S) as c:
+        fr = scene.setup_raycaster(c, cfg, vols, use_sh=use_sh, eye=eye)
+        for i, (size, pos) in enumerate(placed):
+            c.SetVolumeWorld(i, size, pos)
+        c.SetLight(light, scene.LIGHT_COLOR, scene.LIGHT_INTENSITY)
+        for f in range(V):
+            c.m_frameIdx = f
+            c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+            c.cullVolumes()
+            c.rayMarchL()
+        c.rayMarchV()
+        c.synchronize()
+        assert np.array_equal(np.frombuffer(c.perObject, np.uint8), np.frombuffer(ref["po"], np.uint8)), "the two sides were handed the same PerObject blobs"
+        assert np.array_equal(c.ReadBackVolumeInfo()[ref["vis"]], ref["info"][ref["vis"]]), "VolumeInfo of the visible volumes"
+        vis, cube = c.ReadBackVisibleLists()
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube, ref["cube"])
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        if len(ref["cube"]):
+            assert compare_cube(oracle, c, ref, cfg, tol=0.0)[1] == 0
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref)
+        c.composite()
+        got = c.ReadBackComposite()
+        gf, ef = got.view(np.float16), np.asarray(exp).view(np.float16)
+        assert np.array_equal(np.isnan(gf), np.isnan(ef))
+        assert np.array_equal(np.where(np.isnan(gf), 0, got), np.where(np.isnan(ef), 0, np.asarray(exp))), (cfg, placed, eye)
+        st = c.GetStats()
+    assert st["composite_samples"] == exp_samples
+    for k in ("rays", "view_samples", "lit_samples", "light_samples"):
+        assert st[k] == ref["stats"][k], (k, cfg, eye)
+
+
 def test_sixty_four_volumes(oracle):
     """V = 64 (eight cull workgroups + the ticket, an 8 x 8 grid of volumes): with a small viewport most volumes are on the
     screen-space scheme, more than the 32 whose RayCast joins the view-march launch, so the composite's inline fallback runs
