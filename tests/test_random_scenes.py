@@ -158,3 +158,34 @@ def test_sixty_four_volumes(oracle):
         assert np.array_equal(np.isnan(gf), np.isnan(ef))
         assert np.array_equal(np.where(np.isnan(gf), 0, got), np.where(np.isnan(ef), 0, np.asarray(exp)))
         assert c.GetStats()["composite_samples"] == exp_samples > 0
+
+
+@pytest.mark.parametrize("V,eye", [(256, (16.0, 64.0, -320.0)), (1024, (32.0, 128.0, -640.0)), (100, (10.0, 40.0, -200.0))])  # (the default eye x rowLength / 4, MultiVolumes.cpp:264-279)
+def test_many_volumes(oracle, V, eye):
+    """V = 256 and V = MV_MAX_VOLUMES = 1024 (a 16 x 16 and a 32 x 32 grid; V = 100: a 10 x 10 grid): 32 and 128 cull workgroups, volume indices beyond a
+    wavefront's 64 lanes everywhere they are ballots or bit masks (the light march's candidate words, the composite's per-tile skip, the work list), hundreds of
+    entries in the march's work list, far more screen-space volumes than RayCast slots.  Small volumes and a small viewport keep the oracle in seconds."""
+    cfg = dict(N=8, L=4, V=V, W=160, H=96, maxRay=16, maxLight=8, mesh=True)
+    vols = [rc.synth_volume(cfg["N"], k % 5) for k in range(8)]
+    M = 64
+    frames = 12
+    ref = oracle_pipeline(oracle, cfg, vols, M, frames=frames, eye=eye)
+    assert len(ref["vis"]) > V // 3, len(ref["vis"])
+    with make_caster(cfg, M, S=8) as c:
+        run_gpu(c, cfg, vols, frames=frames, eye=eye)
+        assert np.array_equal(c.ReadBackVolumeInfo()[ref["vis"]], ref["info"][ref["vis"]])
+        vis, cube = c.ReadBackVisibleLists()
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube, ref["cube"])
+        compare_light(oracle, c, ref, cfg, [v for v in ref["vis"] if ref["lightMaps"][v].any()], tol=0.0)
+        if len(ref["cube"]):
+            assert compare_cube(oracle, c, ref, cfg, tol=0.0)[1] == 0
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref)
+        c.composite()
+        got = c.ReadBackComposite()
+        gf, ef = got.view(np.float16), np.asarray(exp).view(np.float16)
+        assert np.array_equal(np.isnan(gf), np.isnan(ef))
+        assert np.array_equal(np.where(np.isnan(gf), 0, got), np.where(np.isnan(ef), 0, np.asarray(exp)))
+        st = c.GetStats()
+        assert st["composite_samples"] == exp_samples
+        for k in ("rays", "view_samples", "lit_samples", "light_samples"):
+            assert st[k] == ref["stats"][k], k
