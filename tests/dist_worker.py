@@ -133,7 +133,12 @@ def main():
             assert info["transport"] == "rccl" and info["ranks"] == world and info["communicators"] == (2 if mode == "single" else 3), info
         imgs, infos = [], []
         script = setter_script(frames, every, cfg)
+        # (MV_TEST_SKEW_SEED: the ranks' hosts stall at different frames for different times -- a rank runs groups ahead of another as far as the flags let it)
+        skew = np.random.default_rng(int(os.environ["MV_TEST_SKEW_SEED"]) * 64 + rank) if os.environ.get("MV_TEST_SKEW_SEED") else None
         for f, (e, vp) in enumerate(camera_sequence(cfg, frames)):
+            if skew is not None and skew.random() < 0.25:
+                import time
+                time.sleep(float(skew.uniform(0.0, 0.03)))
             for what, arg in script[f][0]:
                 apply_setter(c, cfg, fr, what, arg)
             if (not static_depth and not diverge) or f == 0:

@@ -76,6 +76,8 @@ def test_random_config_world_and_transport_match_single_gpu(tmp_path, seed, monk
     if mode.startswith("peer"):
         env["MV_TEST_PEER_FOLD"] = "1" if mode == "peer-folded" else "0"
         mode, env["MV_TEST_TRANSPORT"] = "chains", "peer"
+    if seed if isinstance(seed, str) else seed % 2:  # (every other seed, and the corners: the ranks' hosts stall at different frames for different times)
+        env["MV_TEST_SKEW_SEED"] = str(sum(map(ord, seed)) if isinstance(seed, str) else seed)
     if cfg.get("setters"):  # (tests/dist_worker.py setter_script: light probe, sample caps, light, volume / light-map uploads, shadow map; DistFrame(composite=False))
         env["MV_TEST_SETTER_SEED"] = str(cfg["setters"])
         monkeypatch.setenv("MV_TEST_SETTER_SEED", str(cfg["setters"]))
