@@ -586,10 +586,30 @@ def test_headline_config_c3_matches_oracle_at_full_size(oracle, c3_reference, fl
         assert (half_to_float(img[y0:y1])[..., 3] > 0).mean() > 0.2, "the band is covered"
 
 
-def test_large_grid_offsets(oracle):
-    """N = 512 (1 GiB of texels per volume): the 32-bit byte offsets and 24-bit stride multiplies of the bricked layout near
-    their upper range, against the oracle."""
-    cfg = dict(scene.CONFIGS["C1"], N=512, L=16, W=640, H=640, maxRay=40, maxLight=24)
+@pytest.mark.parametrize("L", [255, 320])
+def test_large_light_grids(oracle, L):
+    """Light grids far beyond the benchmark's 96 (an odd one and 320: 33 M voxels, 0.5 GB of cells per buffer): the voxel-block dispatch order, the
+    quad-replicated layout's 64-bit offsets and the light fetch's clamps at scale, every light map and the frame that reads them against the oracle."""
+    cfg = dict(scene.CONFIGS["T1"], N=24, L=L, V=2, W=128, H=96, maxRay=32, maxLight=12)
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    ref = oracle_pipeline(oracle, cfg, vols, 64)
+    with make_caster(cfg, 64) as c:
+        run_gpu(c, cfg, vols)
+        assert np.array_equal(c.ReadBackVolumeInfo()[ref["vis"]], ref["info"][ref["vis"]])
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        if len(ref["cube"]):
+            assert compare_cube(oracle, c, ref, cfg, tol=0.0)[1] == 0
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref)
+        c.composite()
+        assert np.array_equal(c.ReadBackComposite(), exp)
+        assert c.GetStats()["light_samples"] == ref["stats"]["light_samples"] > 0
+
+
+@pytest.mark.parametrize("N", [512, 640])
+def test_large_grid_offsets(oracle, N):
+    """N = 512 (1 GiB of texels per volume) and N = 640 (2 GiB: the largest grid mv_create accepts): the 32-bit byte offsets and 24-bit
+    stride multiplies of the bricked layout near and at the top of their range, against the oracle."""
+    cfg = dict(scene.CONFIGS["C1"], N=N, L=16, W=640 if N == 512 else 400, H=640 if N == 512 else 400, maxRay=40, maxLight=24)
     vols = [rc.synth_volume(cfg["N"], 1)]
     ref = oracle_pipeline(oracle, cfg, vols, 64)
     with make_caster(cfg, 64) as c:
