@@ -586,6 +586,37 @@ def test_headline_config_c3_matches_oracle_at_full_size(oracle, c3_reference, fl
         assert (half_to_float(img[y0:y1])[..., 3] > 0).mean() > 0.2, "the band is covered"
 
 
+@pytest.mark.parametrize("name,over", [("T2", dict(W=256, H=160)), ("T1", dict(N=40, W=200, H=200))])
+def test_stress_variant_against_the_oracle(oracle, name, over):
+    """MV_FLAG_FORCE_MIP0_ALL_FACES (SURVEY 8d's stress variant, `bench.py --stress`): the cull forces mip 0, all six faces, the cube-map scheme and the
+    whole sample cap for every visible volume.  Not a reference mode, so the oracle's cull is amended the same way here and its marches fed that VolumeInfo:
+    cube maps of all six faces (rays through the back faces too), depths, light maps, the composite and the counters, bit for bit."""
+    cfg = dict(scene.CONFIGS[name], **over)
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    M = 64
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    ref = oracle_pipeline(oracle, cfg, vols, M)   # cull + V light marches (the light marches do not read VolumeInfo)
+    info = ref["info"].copy()
+    for v in ref["vis"]:
+        info[v] = (0, cfg["maxRay"], 0x3f | 0x8000, info[v, 3])
+    cube = ref["vis"].copy()
+    cm, cd, st = oracle.march_view(V, N, L, cfg["W"], cfg["H"], vols, ref["lightMaps"], ref["depth"], ref["po"], ref["cb"], info, cube)
+    ref2 = dict(ref, info=info, cube=cube, cubeMaps=cm, cubeDepths=cd)
+    with make_caster(cfg, M, flags=_lib.MV_FLAG_FORCE_MIP0_ALL_FACES) as c:
+        run_gpu(c, cfg, vols)
+        assert np.array_equal(c.ReadBackVolumeInfo()[ref["vis"]], info[ref["vis"]])
+        vis, cube_g = c.ReadBackVisibleLists()
+        assert np.array_equal(vis, ref["vis"]) and np.array_equal(cube_g, cube)
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        worst, mism, total = compare_cube(oracle, c, ref2, cfg, tol=0.0)
+        assert mism == 0 and total >= len(cube) * 6 * N * N * 0.2
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref2)
+        c.composite()
+        assert np.array_equal(c.ReadBackComposite(), exp)
+        g = c.GetStats()
+        assert g["view_samples"] == st["view_samples"] > 0 and g["lit_samples"] == st["lit_samples"] and g["rays"] == st["rays"] and g["composite_samples"] == exp_samples
+
+
 @pytest.mark.parametrize("L", [255, 320])
 def test_large_light_grids(oracle, L):
     """Light grids far beyond the benchmark's 96 (an odd one and 320: 33 M voxels, 0.5 GB of cells per buffer): the voxel-block dispatch order, the
