@@ -60,8 +60,9 @@ def run_sequence(seed, disable=(), verbose=False, only_kinds=None, variants=None
         # every third seed also: the other forms of a context -- the ray-queue march (one stream and with frames in flight), list order instead of the
         # cost-binned tile order, two and five frames in flight, the single view stream of the multi-GPU loop's other schedule
         if seed % 3 == 0 or os.environ.get("MV_API_FUZZ_ALL_CONTEXTS") == "1":
-            variants += [(RQ, 0), (P | RQ, 0), (P | _lib.MV_FLAG_LIST_ORDER, 0), (P, 2), (P, 5), (P | CV, 3), (P | _lib.MV_FLAG_SINGLE_VIEW_STREAM, 0)]
-    cs = [MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=f, framesInFlight=n) for f, n in variants]
+            variants += [(RQ, 0), (P | RQ, 0), (P | _lib.MV_FLAG_LIST_ORDER, 0), (P, 2), (P, 5), (P | CV, 3), (P | _lib.MV_FLAG_SINGLE_VIEW_STREAM, 0),
+                         (P | CV, 4, 3), (P | CV, 4, 4)]  # (... and B = 3, 4 consecutive frames per view stream: mv_config.frames_per_launch outside the multi-GPU loop)
+    cs = [MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=v[0], framesInFlight=v[1], framesPerLaunch=v[2] if len(v) > 2 else 0) for v in variants]
     label = f"seed {seed}: {cfg}"
     print(label)
     try:
