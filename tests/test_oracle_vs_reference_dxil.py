@@ -303,7 +303,8 @@ def test_volumes_placed_at_will_against_the_compiled_shaders(oracle, seed):
     W, H = int(rng.choice([64, 96])), int(rng.choice([48, 64]))
     M = 32
     cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([16, 40])), maxLight=int(rng.choice([8, 20])), mesh=bool(rng.integers(0, 2)))
-    vols = [rc.synth_volume(N, int(rng.integers(0, 6))) for _ in range(S)]
+    from tests.test_random_scenes import random_volume   # (plain / sparse bricks / white noise in every channel / thin: the kinds the GPU sweep uses)
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "sparse", "noise", "thin"], size=S)]
     descs = default_descs(V, S, N)
     lib = _lib.load()
     worlds = np.zeros((V, 12), np.float32)
