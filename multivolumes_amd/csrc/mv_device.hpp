@@ -279,7 +279,8 @@ struct FootprintAddr
 {
 	uint32_t x0, x1, r00, r10, r01, r11;	// texel byte offsets: x taps and the four (y, z) rows
 	float fx, fy, fz;						// filter weights
-	float cx, cy, cz;						// weights for a CELL fetch: 0 where the two taps of an axis coincide (see fetchAlphaCell)
+	float cx, cy, cz;						// weights for a CELL fetch: 0 where the two taps of an axis coincide (the 16-byte and pair forms of fetchAlphaCell; experiments)
+	uint32_t mx, mz;						// 0 where the two taps of the x / z axis coincide, all ones otherwise (the quad form of fetchAlphaCell: it SELECTS the taps)
 	uint32_t ix, iy, iz;					// first tap of every axis (the footprint is {i, min(i + 1, N - 1)}^3)
 };
 
@@ -294,9 +295,13 @@ __device__ __forceinline__ FootprintAddr footprintAddr(uint32_t N, uint32_t stri
 	a.fx = tx.f; a.fy = ty.f; a.fz = tz.f;
 	a.ix = (uint32_t)tx.i0; a.iy = (uint32_t)ty.i0; a.iz = (uint32_t)tz.i0;
 	// A cell holds the clamped +1 neighbours of its own texel.  They are the sampler's second taps except when both
-	// taps of an axis are the SAME texel (coordinate below the first texel centre: taps (0,0) but the cell holds (0,1));
-	// there lerp(a, a, f) == a exactly, which is lerp(a, b, 0): zero the weight instead of fetching differently.
+	// taps of an axis are the SAME texel (coordinate below the first texel centre: taps (0,0) but the cell holds (0,1)).
+	// Rounds 1-5 zeroed the weight there (lerp(a, a, f) == a == lerp(a, b, 0)) -- true for FINITE b only: with b = inf or NaN
+	// 0 x (b - a) is NaN where the sampler, which reads a twice, returns a (round 6: found by the sweep with special halfs in
+	// the volumes, tests/test_random_scenes.py).  The quad form (the product's) therefore replaces the second taps by the
+	// first where mx / mz say so and keeps the true weights; cx / cy / cz remain for the other forms.
 	a.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; a.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; a.cz = tz.i1 == tz.i0 ? 0.0f : tz.f;
+	a.mx = tx.i1 == tx.i0 ? 0u : 0xffffffffu; a.mz = tz.i1 == tz.i0 ? 0u : 0xffffffffu;
 	return a;
 }
 
@@ -360,6 +365,9 @@ __device__ __forceinline__ uint32_t occupancyBit(uint32_t ix, uint32_t iy, uint3
 #ifndef MV_ALPHA_QUADS
 #define MV_ALPHA_QUADS 1
 #endif
+#ifndef MV_EXACT_COINCIDENT_TAPS
+#define MV_EXACT_COINCIDENT_TAPS 2	// 1: select the taps in every sample; 2: behind a scalar branch on the wavefront's ballot (the default: measured view march 0.2448 -> 0.2411-0.2426 ms alone, frame 0.318-0.33 -> 0.316; the results are the same)
+#endif
 #if MV_ALPHA_QUADS == 2
 // Pair form: the companion holds 4 bytes per texel -- {a(x,y,z), a(x+1,y,z)}, +1 clamped -- in the texels' own brick layout
 // (256 bytes per brick), and a footprint is the pairs of its four (y, z) rows: four aligned 4-byte loads, half the bytes of the quads.
@@ -395,14 +403,15 @@ __device__ __forceinline__ float resolveAlpha(const AlphaFootprint& f)
 // clamped -- in the texels' own brick layout, and a footprint is the quads of its two y rows (32 bytes apart inside one
 // 128-byte line three times out of four).  Half the bytes of the 16-byte cell form behind every sample: the light march
 // reads this structure almost completely every launch and is bound by HBM bandwidth (589 MB per launch with cells).
-struct AlphaFootprint { u32x2 row0, row1; float cx, cy, cz; };
+struct AlphaFootprint { u32x2 row0, row1; float cx, cy, cz; uint32_t mx, mz; };
 
 __device__ __forceinline__ AlphaFootprint fetchAlphaCell(const VolumeView& v, const FootprintAddr& a)
 {
 	AlphaFootprint f;
 	f.row0 = *(GlobalUint2)(v.cells + (a.r00 + a.x0));
 	f.row1 = *(GlobalUint2)(v.cells + (a.r10 + a.x0));
-	f.cx = a.cx; f.cy = a.fy; f.cz = a.cz;	// the y taps are the sampler's own: its own weight
+	f.cx = a.fx; f.cy = a.fy; f.cz = a.fz;	// the sampler's own weights on every axis (the y taps are its own rows; x and z: see resolveAlpha)
+	f.mx = a.mx; f.mz = a.mz;
 	return f;
 }
 
@@ -423,14 +432,28 @@ __device__ __forceinline__ float lerpRegisterHalves(uint32_t reg, float w)
 
 __device__ __forceinline__ float resolveAlpha(const AlphaFootprint& f)
 {
+	// Where the two x (z) taps are the same texel the sampler reads that texel twice; the quad holds its +1 neighbour instead: take the
+	// first tap for both -- v_perm_b32 duplicates the low half of a word (selector 0x01000100; 0x03020100 leaves it alone), a select copies
+	// the z words -- and lerp with the sampler's own weights, so that a NaN or an infinity in the neighbour stays out as it does in the
+	// reference (lerp(a, a, f) is a, or NaN for an infinite a: whatever the arithmetic says, on the same operands).
+	uint32_t r0x = f.row0.x, r1x = f.row1.x, r0y = f.row0.y, r1y = f.row1.y;
+#if MV_EXACT_COINCIDENT_TAPS == 2
+	if (__ballot(!f.mx || !f.mz))	// (only samples in the outermost half texel of the volume have such an axis: the other wavefronts skip this)
+#endif
+	{
+		const uint32_t sel = (f.mx & 0x02020000u) | 0x01000100u;
+		r0x = __builtin_amdgcn_perm(r0x, r0x, sel); r1x = __builtin_amdgcn_perm(r1x, r1x, sel);
+		r0y = __builtin_amdgcn_perm(r0y, r0y, sel); r1y = __builtin_amdgcn_perm(r1y, r1y, sel);
+		r0y = f.mz ? r0y : r0x; r1y = f.mz ? r1y : r1x;
+	}
 #if MV_FMA_MIX
 	// x taps are the two halves of each quad word: {a000,a100 | a001,a101} in row0, {a010,a110 | a011,a111} in row1
-	const float x00 = lerpRegisterHalves(f.row0.x, f.cx), x10 = lerpRegisterHalves(f.row1.x, f.cx);
-	const float x01 = lerpRegisterHalves(f.row0.y, f.cx), x11 = lerpRegisterHalves(f.row1.y, f.cx);
+	const float x00 = lerpRegisterHalves(r0x, f.cx), x10 = lerpRegisterHalves(r1x, f.cx);
+	const float x01 = lerpRegisterHalves(r0y, f.cx), x11 = lerpRegisterHalves(r1y, f.cx);
 	return lerpf(lerpf(x00, x10, f.cy), lerpf(x01, x11, f.cy), f.cz);
 #else
-	return trilerp(half_bits_to_float(f.row0.x & 0xffffu), half_bits_to_float(f.row0.x >> 16), half_bits_to_float(f.row1.x & 0xffffu), half_bits_to_float(f.row1.x >> 16),
-		half_bits_to_float(f.row0.y & 0xffffu), half_bits_to_float(f.row0.y >> 16), half_bits_to_float(f.row1.y & 0xffffu), half_bits_to_float(f.row1.y >> 16),
+	return trilerp(half_bits_to_float(r0x & 0xffffu), half_bits_to_float(r0x >> 16), half_bits_to_float(r1x & 0xffffu), half_bits_to_float(r1x >> 16),
+		half_bits_to_float(r0y & 0xffffu), half_bits_to_float(r0y >> 16), half_bits_to_float(r1y & 0xffffu), half_bits_to_float(r1y >> 16),
 		f.cx, f.cy, f.cz);
 #endif
 }
@@ -550,8 +573,9 @@ __device__ __forceinline__ float resolveAlphaFromTexels(const ColourFootprint& f
 // Light maps are stored QUAD-replicated: element (x,y,z) is a 16-byte cell {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)} of
 // slice z (+1 neighbours clamped), elements in plain [z][y][x] order.  Texture3D<float3>.SampleLevel(LINEAR_CLAMP)
 // (GetLight, Sh/RayMarch.hlsli:235-240) is then two aligned 16-byte loads (slices z0 and z1) instead of eight 4-byte
-// gathers.  The same coincident-tap rule as for alpha cells applies to x and y.  (Assumes finite light-map texels:
-// an 11/10-bit float only reaches inf above 65024, far beyond lightColor + ambient.)
+// gathers.  The same coincident-tap rule as for alpha cells applies to x and y: where both taps of an axis are the same texel the
+// cell's second member is replaced by its first (round 6; rounds 1-5 zeroed the weight, which assumed finite light-map texels -- an
+// infinite alpha in a volume makes a light texel NaN, and a light map may be uploaded).
 struct LightFootprint { u32x4 q0, q1; float cx, cy, fz; };
 
 // `pool` + `mapOff`: the light map starts mapOff bytes into a (wave-uniform) pool; mapOff may differ from lane to lane
@@ -564,7 +588,18 @@ __device__ __forceinline__ LightFootprint fetchLightFootprintAt(GlobalBytes pool
 	LightFootprint f;
 	f.q0 = *(GlobalUint4)(pool + (__umul24((uint32_t)tz.i0, slice) + row));
 	f.q1 = *(GlobalUint4)(pool + (__umul24((uint32_t)tz.i1, slice) + row));
-	f.cx = tx.i1 == tx.i0 ? 0.0f : tx.f; f.cy = ty.i1 == ty.i0 ? 0.0f : ty.f; f.fz = tz.f;
+	const bool sameX = tx.i1 == tx.i0, sameY = ty.i1 == ty.i0;
+	// cell = {t(x,y), t(x+1,y), t(x,y+1), t(x+1,y+1)}: the sampler's taps where an axis' two taps coincide are its first members.
+	// Only samples in the outermost half texel of the map have such an axis: a wavefront none of whose lanes has one skips the selects
+	// (a scalar branch on the lanes' ballot).
+#if MV_EXACT_COINCIDENT_TAPS == 2
+	if (__ballot(sameX || sameY))
+#endif
+	{
+		f.q0.y = sameX ? f.q0.x : f.q0.y; f.q0.w = sameX ? f.q0.z : f.q0.w; f.q1.y = sameX ? f.q1.x : f.q1.y; f.q1.w = sameX ? f.q1.z : f.q1.w;
+		f.q0.z = sameY ? f.q0.x : f.q0.z; f.q0.w = sameY ? f.q0.y : f.q0.w; f.q1.z = sameY ? f.q1.x : f.q1.z; f.q1.w = sameY ? f.q1.y : f.q1.w;
+	}
+	f.cx = tx.f; f.cy = ty.f; f.fz = tz.f;
 	return f;
 }
 

@@ -813,9 +813,10 @@ __device__ __forceinline__ FootprintAddr densityFootprint(const VolumeView& vol,
 	const u32x4 ez = axisTables[2u * TABLE_PITCH + axisTableIndex(uvw.z, vol.N, a.fz)];
 	a.x0 = ex.x; a.x1 = ex.y;
 	a.r00 = ey.x + ez.x; a.r10 = ey.y + ez.x; a.r01 = ey.x + ez.y; a.r11 = ey.y + ez.y;
-	a.cx = __uint_as_float(__float_as_uint(a.fx) & ex.w);	// weight 0 where both taps are the same texel
+	a.cx = __uint_as_float(__float_as_uint(a.fx) & ex.w);	// weight 0 where both taps are the same texel (the 16-byte and pair forms of the alpha companion)
 	a.cy = __uint_as_float(__float_as_uint(a.fy) & ey.w);
 	a.cz = __uint_as_float(__float_as_uint(a.fz) & ez.w);
+	a.mx = ex.w; a.mz = ez.w;	// (the quad form -- the product's -- selects the taps instead and keeps the true weights: mv_device.hpp resolveAlpha)
 	a.ix = a.iy = a.iz = 0u;	// (not needed by a cell fetch)
 	return a;
 }

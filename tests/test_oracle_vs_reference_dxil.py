@@ -304,7 +304,7 @@ def test_volumes_placed_at_will_against_the_compiled_shaders(oracle, seed):
     M = 32
     cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([16, 40])), maxLight=int(rng.choice([8, 20])), mesh=bool(rng.integers(0, 2)))
     from tests.test_random_scenes import random_volume   # (plain / sparse bricks / white noise in every channel / thin: the kinds the GPU sweep uses)
-    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "sparse", "noise", "thin"], size=S)]
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "sparse", "noise", "thin", "special"], size=S)]  # (special: +-inf, NaN, denormal ... halfs)
     descs = default_descs(V, S, N)
     lib = _lib.load()
     worlds = np.zeros((V, 12), np.float32)
@@ -345,13 +345,16 @@ def test_volumes_placed_at_will_against_the_compiled_shaders(oracle, seed):
             for sh_, m_ in ((0, 0x7ff), (11, 0x7ff), (22, 0x3ff)):
                 assert np.all(np.abs(((a >> sh_) & m_) - ((b >> sh_) & m_)) <= 1)
     cm, cd = oracle.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)[:2]
+    def same(a, b):  # (NaNs at the same halfs -- sign and payload of a NaN are not compared --, every other half equal)
+        fa, fb = np.asarray(a).view(np.float16), np.asarray(b).view(np.float16)
+        return np.array_equal(np.isnan(fa), np.isnan(fb)) and np.array_equal(np.where(np.isnan(fa), 0, np.asarray(a)), np.where(np.isnan(fb), 0, np.asarray(b)))
     if len(cube):
         cm1, cd1 = dxref.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)
-        assert np.array_equal(cm1, cm) and np.array_equal(cd1, cd), (seed, eye, int((cm1 != cm).sum()))
+        assert same(cm1, cm) and np.array_equal(cd1, cd), (seed, eye, int((cm1 != cm).sum()))
     args = (V, N, L, W, H, vols, lms, depth, po, cb, info, np.sort(vis), cm, cd)
     img = oracle.composite(*args)[0]
     got = dxref.composite(*args)
-    assert np.array_equal(got, img), (seed, eye, int((got != img).sum()))
+    assert same(got, img), (seed, eye, int((np.asarray(got) != np.asarray(img)).sum()))
 
 
 # ---- the two statements of the fixed-function stages, compared directly: oracle/mv_oracle.cpp (mvo_*) and oracle/dxil/d3d_sampler.c (d3ds_*) ----

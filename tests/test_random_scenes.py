@@ -25,6 +25,15 @@ def random_volume(rng, N, kind):
         v[..., :3] = rng.random((N, N, N, 3)).astype(np.float16)
     elif kind == "thin":
         v[..., 3] = np.where(rng.random((N, N, N)) < 0.02, np.float16(1.0), np.float16(0.004))
+    elif kind == "special":
+        # halfs no authoring tool would write, sprinkled over every channel: +-inf, NaNs, denormals, -0, +-65504, +-1, and the three halfs around ZERO_THRESHOLD
+        # (0x211f is the folded constant itself).  The reference's arithmetic decides what comes out (NaN-ignoring min / max, 0 x inf inside GetStep): both
+        # sides must agree texel for texel, NaNs at the same places.
+        special = np.array([0x7c00, 0xfc00, 0x7e00, 0xfe00, 0x0001, 0x8001, 0x03ff, 0x8000, 0x7bff, 0xfbff, 0x3c00, 0xbc00, 0x211f, 0x2120, 0x211e], np.uint16)
+        u = v.view(np.uint16)
+        n = int(rng.integers(1, max(2, N * N)))
+        idx = rng.integers(0, N, size=(n, 3))
+        u[idx[:, 0], idx[:, 1], idx[:, 2], rng.integers(0, 4, size=n)] = special[rng.integers(0, len(special), size=n)]
     return v.view(np.uint16)
 
 
@@ -36,7 +45,7 @@ def test_random_scene(oracle, seed):
     V = int(rng.choice([1, 2, 4, 9]))
     W, H = int(rng.choice([96, 130, 200])), int(rng.choice([64, 100, 160]))
     cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([16, 40, 100])), maxLight=int(rng.choice([8, 20, 48])), mesh=bool(rng.integers(0, 2)))
-    kinds = rng.choice(["plain", "sparse", "noise", "thin"], size=V)
+    kinds = rng.choice(["plain", "sparse", "noise", "thin"] + (["special"] if seed % 4 == 3 else []), size=V)  # (every fourth seed may draw the special halfs: the earlier seeds keep their scenes)
     vols = [random_volume(rng, N, k) for k in kinds]
     r = rng.uniform(8, 140)
     d = rng.normal(size=3)
@@ -81,7 +90,7 @@ def test_random_scene_with_volumes_placed_at_will(oracle, seed):
     S = int(rng.integers(1, V + 1))
     W, H = int(rng.choice([96, 130, 200])), int(rng.choice([64, 100, 160]))
     cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([16, 40, 100])), maxLight=int(rng.choice([8, 20, 48])), mesh=bool(rng.integers(0, 2)))
-    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "sparse", "noise", "thin"], size=S)]
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "sparse", "noise", "thin", "special"], size=S)]
     worlds = np.zeros((V, 12), np.float32)
     lib = _lib.load()
     placed = []
