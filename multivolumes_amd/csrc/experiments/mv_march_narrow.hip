@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64 * kNarrowWaves, MV_TILE_MIN_WAVES_NARROW) void m
 		size_t outIndex = 0;
 		if (!screenTile)
 		{
-			const uint32_t dims = st.N >> mipLevel;
+			const uint32_t dims = cubeMipDim(st.N, mipLevel);
 			const uint32_t tilesX = (dims + 7u) >> 3;
 			const uint32_t px = (localTile % tilesX) * 8u + ray, py = (localTile / tilesX) * 8u + wave;
 			if (px < dims && py < dims)

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * kTileWaves, MV_TILE_MIN_WAVES) void marchTiles
 	size_t outIndex = 0;
 	if (!screenTile)
 	{
-		const uint32_t dims = st.N >> mipLevel;
+		const uint32_t dims = cubeMipDim(st.N, mipLevel);
 		const uint32_t tilesX = (dims + 7u) >> 3;
 		const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
 		if (px < dims && py < dims)

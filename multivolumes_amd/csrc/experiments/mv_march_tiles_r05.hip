@@ -284,7 +284,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	{
 		if (!screenTile)
 		{
-			const uint32_t dims = st.N >> mipLevel;
+			const uint32_t dims = cubeMipDim(st.N, mipLevel);
 			const uint32_t tilesX = (dims + 7u) >> 3;
 			const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
 			return (size_t)st.cubeOffset[volumeId] + ((size_t)faceId * dims + py) * dims + px;
@@ -298,7 +298,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	};
 	if (!screenTile)
 	{
-		const uint32_t dims = st.N >> mipLevel;
+		const uint32_t dims = cubeMipDim(st.N, mipLevel);
 		const uint32_t tilesX = (dims + 7u) >> 3;
 		const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
 		float peerDepth = 0.0f;	// (PEER) what this lane stored into the cube depth

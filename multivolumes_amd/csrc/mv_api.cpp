@@ -1012,7 +1012,7 @@ int mv_readback_cube_map(mv_ctx* ctx, uint32_t volume, uint32_t mip, uint16_t* d
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the producing frame may have run on another stream
 	MV_REQUIRE(ctx, volume < ctx->st.V && mip < MV_NUM_CUBE_MIP, MV_ERR_RANGE, "volume / mip out of range");
-	const size_t d = ctx->st.N >> mip;
+	const size_t d = mv::cubeMipDim(ctx->st.N, mip);
 	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.cubeMaps + off, 6 * d * d * sizeof(uint2), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
@@ -1024,7 +1024,7 @@ int mv_readback_cube_depth(mv_ctx* ctx, uint32_t volume, uint32_t mip, float* ds
 	if (!ctx || !dst) return MV_ERR_INVALID_ARG;
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));	// the producing frame may have run on another stream
 	MV_REQUIRE(ctx, volume < ctx->st.V && mip < MV_NUM_CUBE_MIP, MV_ERR_RANGE, "volume / mip out of range");
-	const size_t d = ctx->st.N >> mip;
+	const size_t d = mv::cubeMipDim(ctx->st.N, mip);
 	const size_t off = (size_t)volume * mv::cubeChainTexels(ctx->st.N) + mv::cubeMipOffset(ctx->st.N, mip);
 	MV_HIP(ctx, hipMemcpyAsync(dst, ctx->st.cubeDepths + off, 6 * d * d * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));

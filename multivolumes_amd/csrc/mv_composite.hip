@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void exchangePackKernel(DeviceState st, uint32
 	const size_t slotTexels = (size_t)6 * slotDim * slotDim;
 	uint2* colour = reinterpret_cast<uint2*>(dst + (size_t)j * slotTexels * 12);
 	float* depth = reinterpret_cast<float*>(dst + (size_t)j * slotTexels * 12 + slotTexels * 8);
-	const uint32_t dv = st.N >> ((info >> 2) & 7u);
+	const uint32_t dv = cubeMipDim(st.N, (info >> 2) & 7u);
 	const size_t n = (info & 1u) ? (size_t)6 * dv * dv : 0;
 	const size_t off = (info & 1u) ? (size_t)st.cubeOffset[v] : 0;
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void exchangeUnpackKernel(DeviceState st, uint
 	const size_t slot = (size_t)r * perShard + j;
 	const uint2* colour = reinterpret_cast<const uint2*>(src + slot * slotTexels * 12);
 	const float* depth = reinterpret_cast<const float*>(src + slot * slotTexels * 12 + slotTexels * 8);
-	const uint32_t dv = st.N >> ((info >> 2) & 7u);
+	const uint32_t dv = cubeMipDim(st.N, (info >> 2) & 7u);
 	const size_t n = (size_t)6 * dv * dv;
 	const size_t off = (size_t)st.cubeOffset[v];
 	for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -77,7 +77,7 @@ void launchExchangeUnpack(hipStream_t s, const DeviceState& st, uint32_t slotDim
 __device__ __forceinline__ uint32_t exchangeFaceTexels(uint32_t info, uint32_t N)
 {
 	if ((info & 3u) != 3u) return 0u;	// visible and on the cube-map scheme
-	const uint32_t d = N >> ((info >> 2) & 7u);
+	const uint32_t d = cubeMipDim(N, (info >> 2) & 7u);
 	return (uint32_t)__popc((info >> 5) & 0x3fu) * d * d;
 }
 
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void exchangeCompactKernel(DeviceState st, uin
 	if (!n) return;
 	const uint32_t r = info >> 16;
 	if (PACK ? r != st.shardIndex : r == st.shardIndex) return;	// pack what this rank marched; unpack what the others did
-	const uint32_t d = st.N >> ((info >> 2) & 7u), mask = (info >> 5) & 0x3fu, face2 = d * d;
+	const uint32_t d = cubeMipDim(st.N, (info >> 2) & 7u), mask = (info >> 5) & 0x3fu, face2 = d * d;
 	uint8_t* shard = buf + (PACK ? 0 : (size_t)r * shardBytes) + (size_t)st.exchangeOff[v] * 12u;
 	uint2* colour = reinterpret_cast<uint2*>(shard);
 	float* depth = reinterpret_cast<float*>(shard + (size_t)n * 8u);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void copyForwardKernel(DeviceState st, const u
 	}
 	const uint32_t mine = st.faceStamps[idx], theirs = otherStamps[idx];
 	if ((int32_t)(theirs - mine) <= 0) return;
-	const uint32_t d = st.N >> mip;
+	const uint32_t d = cubeMipDim(st.N, mip);
 	const size_t base = (size_t)v * cubeChainTexels(st.N) + cubeMipOffset(st.N, mip) + (size_t)f * d * d;
 	for (uint32_t i = threadIdx.x; i < d * d; i += blockDim.x)
 	{
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void copyForwardBatchKernel(DeviceStateBatch p
 				const uint32_t mine = st.faceStamps[idx], theirs = srcStamps[idx];
 				if ((int32_t)(theirs - mine) > 0)
 				{
-					const uint32_t d = st.N >> mip;
+					const uint32_t d = cubeMipDim(st.N, mip);
 					const size_t base = (size_t)v * cubeChainTexels(st.N) + cubeMipOffset(st.N, mip) + (size_t)f * d * d;
 					for (uint32_t k = threadIdx.x; k < d * d; k += blockDim.x)
 					{
@@ -440,7 +440,7 @@ __device__ __forceinline__ void compositeBody(const DeviceState& st, uint32_t ro
 			uint2 layer;
 			if (vi.z & kCubeMapRayMarchBit)
 			{
-				const int dims = (int)(st.N >> vi.x);
+				const int dims = (int)cubeMipDim(st.N, vi.x);
 				const size_t off = (size_t)v * chain + cubeMipOffset(st.N, vi.x);
 				layer = packLayer(CubeCast(st.cubeMaps + off, st.cubeDepths + off, dims, depthPix, lpt, lpt - localSpaceEyePt));
 			}

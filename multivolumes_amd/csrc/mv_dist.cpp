@@ -43,7 +43,7 @@ int mv_exchange_layout(mv_ctx* ctx, uint32_t* slot_dim, size_t* slot_bytes, size
 	MV_HIP(ctx, hipMemcpyAsync(ctx->pinnedCounters, ctx->st.counters, kNumCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
 	MV_HIP(ctx, (hipError_t)syncAll(ctx));
 	const uint32_t minMip = ctx->pinnedCounters[5] < MV_NUM_CUBE_MIP ? ctx->pinnedCounters[5] : 0u;
-	const uint32_t d = ctx->st.N >> minMip;
+	const uint32_t d = mv::cubeMipDim(ctx->st.N, minMip);
 	*slot_dim = d;
 	*slot_bytes = (size_t)6 * d * d * (sizeof(uint2) + sizeof(float));
 	const uint32_t sc = ctx->st.shardCount ? ctx->st.shardCount : 1u;

@@ -494,7 +494,7 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 			uint32_t cost = 0;
 			if ((info & 3u) == 3u)
 			{
-				const uint32_t dims = st.N >> ((info >> 2) & 7u), tiles = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
+				const uint32_t dims = cubeMipDim(st.N, (info >> 2) & 7u), tiles = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
 				const unsigned long long infoBits = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(st.volumeInfo) + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				const uint32_t smp = (uint32_t)(infoBits >> 16) & 0xffffu;
 				const unsigned long long c = (unsigned long long)__popc((info >> 5) & 0x3fu) * tiles * (smp ? smp : 1u);
@@ -580,7 +580,7 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 			{
 				const uint32_t info = sInfo[v];
 				if ((info & 3u) != 3u || (info >> 16) != r0 + lane) continue;
-				const uint32_t d = st.N >> ((info >> 2) & 7u);
+				const uint32_t d = cubeMipDim(st.N, (info >> 2) & 7u);
 				st.exchangeOff[v] = run;
 				run += (uint32_t)__popc((info >> 5) & 0x3fu) * d * d;
 			}
@@ -622,7 +622,7 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 		if (vis && owned) st.ownedVisible[nOwned + __popcll(bOwn & lower)] = v;
 		nVis += __popcll(bVis); nCube += __popcll(bCube); nOwned += __popcll(bOwn);
 
-		const uint32_t dims = st.N >> mip;
+		const uint32_t dims = cubeMipDim(st.N, mip);
 		const uint32_t tilesOfFace = ((dims + 7u) >> 3) * ((dims + 7u) >> 3);
 		const uint32_t tilesPerFace = dealTiles ? dealtTilesOfFace(tilesOfFace, (dims + 7u) >> 3, st.shardIndex, shardCount, v) : tilesOfFace;	// (this rank's)
 		const uint32_t myFaces = (cube && marches && tilesPerFace) ? (uint32_t)__popc(mask) : 0u;
@@ -1259,7 +1259,7 @@ __device__ inline uint32_t tileBinOf(const DeviceState& st, const uint32_t* sSta
 		}
 		else
 		{
-			const uint32_t dims = st.N >> reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId].x;
+			const uint32_t dims = cubeMipDim(st.N, reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId].x);
 			tilesX = tilesY = (dims + 7u) >> 3;
 			stride = tilesX;
 		}

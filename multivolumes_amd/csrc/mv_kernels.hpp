@@ -419,10 +419,16 @@ __host__ __device__ inline uint32_t dealtTile(uint32_t k, uint32_t tilesX, uint3
 	const uint32_t G = dealtGroup(tilesX, shardCount);
 	return (dealtTileFirst(shardIndex, shardCount, v) + (k / G) * shardCount) * G + k % G;
 }
+// Edge of mip `mip` of a cube map of edge N, as D3D defines a mip chain (and as the reference's shaders learn it: GetDimensions of the mip's view,
+// CSRayMarch.hlsl:31, PSCube.hlsli:55): max(1, N >> mip).  Only differs from N >> mip for N < 16 (NumMips = 5), where round 1-5's `N >> mip` made the last
+// mips EMPTY -- a composite that selected one divided by an edge of zero and read out of bounds (round 6: tests/test_random_scenes.py, a 9 x 2 viewport).
+// (The cull's own `cubeMapSize >> mipLevel`, CSVolumeCull.hlsl:62, is the shader's arithmetic and stays.)
+__host__ __device__ inline uint32_t cubeMipDim(uint32_t N, uint32_t mip) { const uint32_t d = N >> mip; return d ? d : 1u; }
+
 __device__ __forceinline__ uint32_t cubeLocalTile(const DeviceState& st, uint32_t volumeId, uint32_t k)
 {
 	if (!(st.flags & kFlagDealTiles) || st.shardCount <= 1u) return k;
-	const uint32_t dims = st.N >> reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId].x;
+	const uint32_t dims = cubeMipDim(st.N, reinterpret_cast<const ushort4*>(st.volumeInfo)[volumeId].x);
 	return dealtTile(k, (dims + 7u) >> 3, st.shardIndex, st.shardCount, volumeId);
 }
 // Stable key of a tile in the per-tile cost table (tileCost): cube tiles by (volume, face, tile of the face), screen tiles by
@@ -575,14 +581,14 @@ __device__ __forceinline__ uint32_t orderedTile(const DeviceState& st, uint32_t 
 __host__ __device__ inline uint64_t cubeChainTexels(uint32_t N)
 {
 	uint64_t s = 0;
-	for (uint32_t m = 0; m < 5; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	for (uint32_t m = 0; m < 5; ++m) { const uint64_t d = cubeMipDim(N, m); s += 6 * d * d; }
 	return s;
 }
 
 __host__ __device__ inline uint64_t cubeMipOffset(uint32_t N, uint32_t mip)
 {
 	uint64_t s = 0;
-	for (uint32_t m = 0; m < mip; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	for (uint32_t m = 0; m < mip; ++m) { const uint64_t d = cubeMipDim(N, m); s += 6 * d * d; }
 	return s;
 }
 // ---- push roles (mv_peer.hip explains the transport): copy what this rank produced into every OTHER rank's buffers ----

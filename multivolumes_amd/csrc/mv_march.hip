@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64 * kSetupWaves) void raySetupKernel(DeviceState s
 		uint32_t out = kNoRay;
 		if (!screenTile)
 		{
-			const uint32_t dims = st.N >> mipLevel;
+			const uint32_t dims = cubeMipDim(st.N, mipLevel);
 			const uint32_t tilesX = (dims + 7u) >> 3;
 			const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
 			if (px < dims && py < dims)

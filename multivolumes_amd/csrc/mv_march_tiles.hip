@@ -235,7 +235,7 @@ __device__ __forceinline__ void marchTilesBody(const DeviceState& st, uint32_t f
 	uint2 peerColour; peerColour.x = peerColour.y = 0u;
 	if (!screenTile)
 	{
-		const uint32_t dims = st.N >> mipLevel;
+		const uint32_t dims = cubeMipDim(st.N, mipLevel);
 		const uint32_t tilesX = (dims + 7u) >> 3;
 		const uint32_t px = (localTile % tilesX) * 8u + (lane & 7u), py = (localTile / tilesX) * 8u + (lane >> 3);
 		if (px < dims && py < dims)

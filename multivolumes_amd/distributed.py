@@ -35,7 +35,7 @@ def exchange_layout(N, volume_info, visible, V, world):
     min_mip = min(mips) if mips else 0
     if min_mip >= NUM_CUBE_MIP:
         min_mip = 0
-    d = N >> min_mip
+    d = max(1, N >> min_mip)
     slot_bytes = 6 * d * d * (8 + 4)
     return d, slot_bytes, slot_bytes * slots_per_shard(V, world)
 
@@ -56,7 +56,7 @@ def pack_shard_numpy(N, V, rank, world, volume_info, visible, cube_maps, cube_de
         if v not in vis:
             continue
         mip = int(volume_info[v][0])
-        dv = N >> mip
+        dv = max(1, N >> mip)
         n = 6 * dv * dv
         off = mip_offset(N, mip)
         base = j * n_slot * 12
@@ -77,7 +77,7 @@ def unpack_gathered_numpy(N, V, rank, world, volume_info, visible, gathered, cub
             if v not in vis:
                 continue
             mip = int(volume_info[v][0])
-            dv = N >> mip
+            dv = max(1, N >> mip)
             n = 6 * dv * dv
             off = mip_offset(N, mip)
             base = (r * per + j) * n_slot * 12
@@ -102,7 +102,7 @@ def deal_cube_volumes(volume_info, visible, V, N, world):
         mask = int(volume_info[v, 2])
         if v not in vis or not (mask & 0x8000):
             continue
-        dims = N >> int(volume_info[v, 0])
+        dims = max(1, N >> int(volume_info[v, 0]))
         tiles = ((dims + 7) >> 3) ** 2
         c = bin(mask & 0x3F).count("1") * tiles * max(int(volume_info[v, 1]), 1)
         cost[v] = min(c + 1, 0xFFFFFFFF)
@@ -127,7 +127,7 @@ def compact_exchange_layout(volume_info, visible, owner, V, N, world):
         mask = int(volume_info[v, 2])
         if v not in vis or not (mask & 0x8000):
             continue
-        d = N >> int(volume_info[v, 0])
+        d = max(1, N >> int(volume_info[v, 0]))
         off[v] = run[owner[v]]
         run[owner[v]] += bin(mask & 0x3F).count("1") * d * d
     return off, int(run.max()) if world else 0

@@ -387,13 +387,13 @@ class MultiRayCaster:
         self._check(self._lib.mv_upload_light_map(self._ctx, volume, _ptr(a)), "mv_upload_light_map")
 
     def ReadBackCubeMap(self, volume, mip):
-        d = self.gridSize >> mip
+        d = max(1, self.gridSize >> mip)  # (a mip's edge as D3D defines it)
         out = np.empty((6, d, d, 4), np.uint16)
         self._check(self._lib.mv_readback_cube_map(self._ctx, volume, mip, _ptr(out)), "mv_readback_cube_map")
         return out
 
     def ReadBackCubeDepth(self, volume, mip):
-        d = self.gridSize >> mip
+        d = max(1, self.gridSize >> mip)  # (a mip's edge as D3D defines it)
         out = np.empty((6, d, d), np.float32)
         self._check(self._lib.mv_readback_cube_depth(self._ctx, volume, mip, _ptr(out)), "mv_readback_cube_depth")
         return out

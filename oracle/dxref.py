@@ -67,9 +67,7 @@ def _bind_cube_targets(N, V, cm, cd):
     """RWTexture2DArray g_rwCubeMaps[] / g_rwCubeDepths[] (u0.., space 0 / 1): descriptor 5 v + mip, six slices of (N >> mip)^2."""
     for v in range(V):
         for mip in range(O.MVO_NUM_CUBE_MIP if hasattr(O, "MVO_NUM_CUBE_MIP") else 5):
-            dim = N >> mip
-            if dim == 0:
-                continue
+            dim = max(1, N >> mip)   # (a mip's edge as D3D defines it: what GetDimensions answers)
             off = O.cube_mip_offset(N, mip)
             _bind(UAV, 0, 5 * v + mip, TEX2DARRAY, F_RGBA16F, cm[v][off:], dim, dim, 6)
             _bind(UAV, 1, 5 * v + mip, TEX2DARRAY, F_R32F, cd[v][off:], dim, dim, 6)
@@ -225,9 +223,7 @@ def lib_ray_march(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, descs,
     bind("g_smpPoint", 0, SAMPLER_KIND, F_NONE, None)
     for v in range(V):
         for mip in range(5):
-            dim = N >> mip
-            if dim == 0:
-                continue
+            dim = max(1, N >> mip)   # (a mip's edge as D3D defines it: what GetDimensions answers)
             off = O.cube_mip_offset(N, mip)
             bind("g_rwCubeMaps", 5 * v + mip, TEX2DARRAY, F_RGBA16F, cm[v][off:], dim, dim, 6)
             bind("g_rwCubeDepths", 5 * v + mip, TEX2DARRAY, F_R32F, cd[v][off:], dim, dim, 6)
@@ -321,11 +317,10 @@ def composite(V, N, L, W, H, volumes, lightMaps, depthMap, perObject, cbPerFrame
     for v in range(V):
         _bind(SRV, 0, 3 + v, TEX3D, F_R11G11B10F, lm[v], L, L, L)
         for mip in range(5):
-            dim = N >> mip
-            if dim:
-                off = O.cube_mip_offset(N, mip)
-                _bind(SRV, 4, 5 * v + mip, TEXCUBE, F_RGBA16F, cm[v][off:], dim, dim, 6)
-                _bind(SRV, 5, 5 * v + mip, TEXCUBE, F_R32F, cd[v][off:], dim, dim, 6)
+            dim = max(1, N >> mip)
+            off = O.cube_mip_offset(N, mip)
+            _bind(SRV, 4, 5 * v + mip, TEXCUBE, F_RGBA16F, cm[v][off:], dim, dim, 6)
+            _bind(SRV, 5, 5 * v + mip, TEXCUBE, F_R32F, cd[v][off:], dim, dim, 6)
     for i, g in enumerate(vols):
         _bind(SRV, 1, i, TEX3D, F_RGBA16F, g, N, N, N)
     _bind(SRV, 2, 0, TEX2D, F_R32F, dm, W, H, 1)

@@ -489,17 +489,20 @@ float3 GetLocalPos(float px, float py, uint32_t slice, float dims)
 	}
 }
 
+// edge of a cube map's mip as D3D defines it (what GetDimensions answers in CSRayMarch.hlsl:31 / PSCube.hlsli:55): max(1, N >> mip)
+inline uint32_t mipDim(uint32_t N, uint32_t mip) { const uint32_t d = N >> mip; return d ? d : 1u; }
+
 inline uint64_t chainTexels(uint32_t N)
 {
 	uint64_t s = 0;
-	for (uint32_t m = 0; m < MVO_NUM_CUBE_MIP; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	for (uint32_t m = 0; m < MVO_NUM_CUBE_MIP; ++m) { const uint64_t d = mipDim(N, m); s += 6 * d * d; }
 	return s;
 }
 
 inline uint64_t mipOffset(uint32_t N, uint32_t mip)
 {
 	uint64_t s = 0;
-	for (uint32_t m = 0; m < mip; ++m) { const uint64_t d = N >> m; s += 6 * d * d; }
+	for (uint32_t m = 0; m < mip; ++m) { const uint64_t d = mipDim(N, m); s += 6 * d * d; }
 	return s;
 }
 
@@ -980,7 +983,7 @@ void mvo_march_view(uint32_t V, uint32_t N, uint32_t L, uint32_t W, uint32_t H,
 	for (uint32_t g = 0; g < cubeMapCount; ++g)
 	{
 		const uint32_t volumeId = cubeMapVolumes[g];	// :80
-		const uint32_t dims = N >> volumeInfo[4 * volumeId + 0];
+		const uint32_t dims = mipDim(N, volumeInfo[4 * volumeId + 0]);	// rwCubeMap.GetDimensions (:31)
 		for (uint32_t faceId = 0; faceId < 6; ++faceId)
 			if (volumeInfo[4 * volumeId + 2] & (1u << faceId))	// :85
 			{
@@ -1358,7 +1361,7 @@ extern "C" void mvo_composite_over(uint32_t V, uint32_t N, uint32_t L, uint32_t 
 				}
 				else
 				{
-					const int32_t d = (int32_t)(N >> mipLevel);
+					const int32_t d = (int32_t)mipDim(N, mipLevel);	// txCubeMap.GetDimensions (PSCube.hlsli:55)
 					const size_t off = (size_t)v * chain + mipOffset(N, mipLevel);
 					color = CubeCast(cubeMaps + 4 * off, cubeDepths + off, d, depthPix, frags[k].lpt, rayDir);
 				}

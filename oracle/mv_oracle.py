@@ -216,7 +216,7 @@ def spread(a):
 
 def cube_face_view(chain_array, N, mip):
     """Slice mip `mip` out of a per-volume chain array: [chain, ...] -> [6, d, d, ...]."""
-    d = N >> mip
+    d = max(1, N >> mip)   # (a mip's edge as D3D defines it)
     off = cube_mip_offset(N, mip)
     a = chain_array[off:off + 6 * d * d]
     return a.reshape((6, d, d) + a.shape[1:])

@@ -163,7 +163,7 @@ def test_the_loops_work_deal_pure():
             visible = [v for v in range(V) if rng.random() < 0.8]
             owner = D.deal_cube_volumes(info, visible, V, N, world)
             cube = [v for v in visible if info[v, 2] & 0x8000]
-            cost = {v: bin(int(info[v, 2]) & 0x3F).count("1") * (((N >> int(info[v, 0])) + 7) // 8) ** 2 * int(info[v, 1]) + 1 for v in cube}
+            cost = {v: bin(int(info[v, 2]) & 0x3F).count("1") * (((max(1, N >> int(info[v, 0]))) + 7) // 8) ** 2 * int(info[v, 1]) + 1 for v in cube}
             load = [sum(cost[v] for v in cube if owner[v] == r) for r in range(world)]
             assert all(0 <= owner[v] < world for v in range(V))
             assert all(owner[v] == v % world for v in range(V) if v not in cube)
@@ -175,9 +175,9 @@ def test_the_loops_work_deal_pure():
                 run = 0
                 for v in mine:                                            # ascending, back to back
                     assert off[v] == run
-                    run += bin(int(info[v, 2]) & 0x3F).count("1") * (N >> int(info[v, 0])) ** 2
+                    run += bin(int(info[v, 2]) & 0x3F).count("1") * max(1, N >> int(info[v, 0])) ** 2
                 assert run <= biggest
-            assert biggest == max(sum(bin(int(info[v, 2]) & 0x3F).count("1") * (N >> int(info[v, 0])) ** 2 for v in cube if owner[v] == r) for r in range(world))
+            assert biggest == max(sum(bin(int(info[v, 2]) & 0x3F).count("1") * max(1, N >> int(info[v, 0])) ** 2 for v in cube if owner[v] == r) for r in range(world))
         for H in (80, 168, 200, 1024, 1):
             T = (H + 7) // 8
             rows = [D.tile_rows_of_rank(H, r, world) for r in range(world)]
@@ -245,7 +245,7 @@ def _worker_dealt(rank, world, port, out_path):
         chain_off = o.cube_mip_offset
 
         def faces(v):
-            d = N >> int(info[v, 0])
+            d = max(1, N >> int(info[v, 0]))
             return [f for f in range(6) if int(info[v, 2]) & (1 << f)], d
 
         for v in mine:

@@ -66,7 +66,7 @@ def test_gpu_matches_golden():
         from multivolumes_amd.raycaster import cube_mip_offset
         for v in cube:
             mip = int(g["info"][v, 0])
-            d = N >> mip
+            d = max(1, N >> mip)
             off = cube_mip_offset(N, mip)
             exp = half_to_float(g["cubeMaps"][v][off:off + 6 * d * d].reshape(6, d, d, 4))
             got = half_to_float(mc.ReadBackCubeMap(int(v), mip))
@@ -132,7 +132,7 @@ def test_gpu_matches_dxil_golden():
             assert np.array_equal(mc.ReadBackLightMap(int(v)), g["lightMaps"][v]), f"light map of volume {v}"
         for v in cube:
             mip = int(g["info"][v, 0])
-            d = N >> mip
+            d = max(1, N >> mip)
             off = cube_mip_offset(N, mip)
             assert np.array_equal(mc.ReadBackCubeMap(int(v), mip), g["cubeMaps"][v][off:off + 6 * d * d].reshape(6, d, d, 4)), f"cube map of volume {v}"
             assert np.array_equal(mc.ReadBackCubeDepth(int(v), mip), g["cubeDepths"][v][off:off + 6 * d * d].reshape(6, d, d))

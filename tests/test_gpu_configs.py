@@ -69,7 +69,7 @@ def test_c5_full_size_properties(oracle, flags):
             assert np.array_equal(c.ReadBackCubeMap(int(v), mip), cm) and np.array_equal(c.ReadBackCubeDepth(int(v), mip), cd)
             f = half_to_float(cm)
             assert np.all(np.isfinite(f)) and np.all((f[..., 3] >= 0) & (f[..., 3] <= 1.0))
-            d = N >> mip
+            d = max(1, N >> mip)
             expect_rays += bin(int(info[v, 2]) & 0x3F).count("1") * d * d
         for k in ("view_samples", "lit_samples", "rays", "composite_samples"):
             assert st1[k] == st2[k], k
@@ -117,7 +117,7 @@ def test_c5_full_size_properties(oracle, flags):
         cds = np.zeros((V, chain), np.float32)
         for u in cube:
             m = int(info[u, 0])
-            off, n = oracle.cube_mip_offset(N, m), 6 * (N >> m) ** 2
+            off, n = oracle.cube_mip_offset(N, m), 6 * max(1, N >> m) ** 2
             cms[u, off:off + n] = first[int(u)][0].reshape(n, 4)
             cds[u, off:off + n] = first[int(u)][1].reshape(n)
         y0, y1 = H // 2 - 16, H // 2 + 16

@@ -318,7 +318,7 @@ def test_config_c2_matches_oracle_at_full_size(oracle, flags):
             assert np.array_equal(c.ReadBackCubeMap(int(v), int(info[v, 0])), cm) and np.array_equal(c.ReadBackCubeDepth(int(v), int(info[v, 0])), cd), "marchV must be idempotent"
             a = half_to_float(cm)[..., 3]
             assert np.all((a >= 0) & (a <= 1.0)) and np.all(np.isfinite(half_to_float(cm)))
-            d = N >> int(info[v, 0])
+            d = max(1, N >> int(info[v, 0]))
             expect_rays += bin(int(info[v, 2]) & 0x3F).count("1") * d * d
         assert st2["rays"] == expect_rays  # every texel of a visible face of a volume the eye is outside of hits the box
         assert st2["view_samples"] == st1["view_samples"] and st2["lit_samples"] == st1["lit_samples"]
@@ -427,7 +427,7 @@ def test_sharded_contexts_reproduce_unsharded_frame(oracle):
             torch.cuda.synchronize()  # torch fills on ITS stream; the pack below runs on the context's
             c.ExchangePack(buf.data_ptr(), d)
             info2, vis2, cube2, min_mip = c.ReadBackCull()
-            assert np.array_equal(info2, info) and np.array_equal(vis2, vis) and np.array_equal(cube2, cube) and (N >> min_mip) == d
+            assert np.array_equal(info2, info) and np.array_equal(vis2, vis) and np.array_equal(cube2, cube) and max(1, N >> min_mip) == d
             c.synchronize()
             packed.append(buf)
             st = c.GetStats()
@@ -584,6 +584,30 @@ def test_headline_config_c3_matches_oracle_at_full_size(oracle, c3_reference, fl
                                   ref["cubeMaps"], ref["cubeDepths"], y0, y1)
         assert np.array_equal(exp[y0:y1], img[y0:y1]), "composite band differs from the oracle"
         assert (half_to_float(img[y0:y1])[..., 3] > 0).mean() > 0.2, "the band is covered"
+
+
+@pytest.mark.parametrize("N,W,H,eye", [(12, 9, 2, (30.0, 40.0, -200.0)), (8, 16, 8, (4.0, 16.0, -400.0)), (12, 32, 24, (4.0, 16.0, -400.0)), (4, 16, 8, (4.0, 16.0, -400.0)), (12, 16, 8, (20.0, 20.0, -120.0))])
+def test_one_texel_mips(oracle, N, W, H, eye):
+    """Cube maps smaller than 16 texels: their last mips are ONE texel (max(1, N >> mip), as D3D lays a mip chain out and GetDimensions tells the reference's
+    shaders), not empty.  Rounds 1-5 laid them out empty, and a composite that selected one divided by an edge of zero: a GPU memory fault at a 9 x 2 viewport
+    (round 6, found by tests/test_random_scenes.py).  Cull, the march into 1 x 1 faces, CubeCast from them and the image against the oracle -- which
+    tests/test_oracle_vs_reference_dxil.py::test_one_texel_mips_against_the_compiled_shaders holds against the reference's compiled shaders on these very scenes."""
+    cfg = dict(scene.CONFIGS["T1"], N=N, L=6, V=4, W=W, H=H, maxRay=16, maxLight=8)
+    M = 32
+    vols = [rc.synth_volume(N, k) for k in range(cfg["V"])]
+    ref = oracle_pipeline(oracle, cfg, vols, M, eye=eye)
+    assert len(ref["cube"]) and min(max(1, N >> int(ref["info"][v, 0])) for v in ref["cube"]) == 1
+    with make_caster(cfg, M) as c:
+        run_gpu(c, cfg, vols, eye=eye)
+        assert np.array_equal(c.ReadBackVolumeInfo()[ref["vis"]], ref["info"][ref["vis"]])
+        compare_light(oracle, c, ref, cfg, ref["vis"], tol=0.0)
+        worst, mism, total = compare_cube(oracle, c, ref, cfg, tol=0.0)
+        assert mism == 0 and total > 0
+        exp, exp_samples = oracle_composite(oracle, cfg, vols, ref)
+        c.composite()
+        assert np.array_equal(c.ReadBackComposite(), exp)
+        st = c.GetStats()
+        assert st["view_samples"] == ref["stats"]["view_samples"] and st["rays"] == ref["stats"]["rays"] > 0 and st["composite_samples"] == exp_samples
 
 
 @pytest.mark.parametrize("name,over", [("T2", dict(W=256, H=160)), ("T1", dict(N=40, W=200, H=200))])

@@ -357,6 +357,31 @@ def test_volumes_placed_at_will_against_the_compiled_shaders(oracle, seed):
     assert same(got, img), (seed, eye, int((np.asarray(got) != np.asarray(img)).sum()))
 
 
+@pytest.mark.parametrize("N,W,H,eye", [(12, 9, 2, (30.0, 40.0, -200.0)), (8, 16, 8, (4.0, 16.0, -400.0)), (12, 32, 24, (4.0, 16.0, -400.0)), (4, 16, 8, (4.0, 16.0, -400.0)), (12, 16, 8, (20.0, 20.0, -120.0))])
+def test_one_texel_mips_against_the_compiled_shaders(oracle, N, W, H, eye):
+    """Round 6: cube maps smaller than 16 texels have mips of ONE texel (D3D: max(1, N >> mip); the shaders learn the edge from GetDimensions,
+    CSRayMarch.hlsl:31, PSCube.hlsli:55) -- rounds 1-5 laid them out with N >> mip = 0 texels, and a composite that selected such a mip divided by an edge of
+    zero (a GPU memory fault at a 9 x 2 viewport).  Far cameras and tiny viewports select mips 3 and 4 here: cull, view march into a 1 x 1 face, CubeCast from it
+    and the image against the reference's compiled shaders, bit for bit."""
+    cfg = dict(scene.CONFIGS["T1"], N=N, L=6, V=4, W=W, H=H, maxRay=16, maxLight=8)
+    V, L, M = cfg["V"], cfg["L"], 32
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    descs = default_descs(V, V, N)
+    _, vp, svp, cb, po = host_frame(cfg, 0, eye)
+    depth, shadow = scene.depth_and_shadow(cfg, vp, svp, M)
+    info, vis, cube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+    i1, v1, c1 = dxref.cull(V, po, descs, cb, cfg["maxRay"])
+    assert np.array_equal(info, i1) and np.array_equal(np.sort(vis), np.sort(v1)) and np.array_equal(np.sort(cube), np.sort(c1))
+    assert len(cube) and max(int(info[v, 0]) for v in cube) >= 3 and min(max(1, N >> int(info[v, 0])) for v in cube) == 1, info[cube]
+    vid, lms, _ = oracle.march_light(V, N, L, M, vols, descs, po, cb, shadow, None, vis, cfg["maxLight"])
+    cm, cd = oracle.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)[:2]
+    cm1, cd1 = dxref.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)
+    assert np.array_equal(cm1, cm) and np.array_equal(cd1, cd)
+    assert any(oracle.cube_face_view(cm[v], N, int(info[v, 0])).any() for v in cube), "a one-texel face was marched"
+    args = (V, N, L, W, H, vols, lms, depth, po, cb, info, np.sort(vis), cm, cd)
+    assert np.array_equal(dxref.composite(*args), oracle.composite(*args)[0])
+
+
 # ---- the two statements of the fixed-function stages, compared directly: oracle/mv_oracle.cpp (mvo_*) and oracle/dxil/d3d_sampler.c (d3ds_*) ----
 import ctypes as C
 

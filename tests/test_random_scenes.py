@@ -198,3 +198,84 @@ def test_many_volumes(oracle, V, eye):
         assert st["composite_samples"] == exp_samples
         for k in ("rays", "view_samples", "lit_samples", "light_samples"):
             assert st[k] == ref["stats"][k], k
+
+
+def special_inputs(rng, cfg, M, vp):
+    """Inputs no tool would hand over (round 6): a depth map with NaN, +-inf, negatives and values beyond 1; uploaded light maps with the 11- / 10-bit patterns
+    of infinity and NaN, the largest finite value, denormals and zeros; a light probe with huge, negative and non-finite coefficients."""
+    W, H, L, V = cfg["W"], cfg["H"], cfg["L"], cfg["V"]
+    depth = rc.synth_sphere_depth(W, H, vp, (0, 0, 0), 8.0)
+    n = int(rng.integers(1, max(2, W * H // 4 + 1)))
+    ys, xs = rng.integers(0, H, size=n), rng.integers(0, W, size=n)
+    depth[ys, xs] = np.array([np.nan, np.inf, -np.inf, -0.5, 0.0, 1.0, 1.5, 0.999999, 1e-30, -0.0], np.float32)[rng.integers(0, 10, size=n)]
+    lms = rng.integers(0, 2 ** 32, size=(V, L, L, L), dtype=np.uint64).astype(np.uint32) & np.uint32(0x3BFFF7FF)   # finite 11/11/10-bit floats ...
+    k = int(rng.integers(1, L * L))
+    idx = rng.integers(0, L, size=(k, 3))
+    vsel = rng.integers(0, V, size=k)
+    special = np.array([0x7C0, 0x7FF, 0x7BF, 0x001, 0x03F, 0x000, 0x3C0], np.uint32)   # inf, NaN, largest finite, smallest denormal, largest denormal, 0, 1.0 (11-bit patterns)
+    r11, g11, b10 = special[rng.integers(0, 7, size=k)], special[rng.integers(0, 7, size=k)], special[rng.integers(0, 7, size=k)] >> 1
+    lms[vsel, idx[:, 0], idx[:, 1], idx[:, 2]] = r11 | (g11 << 11) | (b10 << 22)     # ... and these
+    sh = scene.DEFAULT_SH.copy()
+    sh[rng.integers(0, 27, size=4)] = np.array([1e30, -1e30, np.inf, np.nan], np.float32)[rng.integers(0, 4, size=4)]
+    return depth, lms, sh
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MV_SPECIAL_INPUT_SEEDS", "8"))))
+def test_special_inputs_against_the_oracle(oracle, seed):
+    """View march, composite and light march fed non-finite and extreme inputs (special_inputs above), extreme sample caps (1 and 65535) and viewports of a
+    few pixels: whatever the reference's arithmetic makes of them -- NaN-ignoring min / max, saturate(NaN) = 0, comparisons that are false -- both sides make the
+    same: NaNs at the same halfs, every other bit equal."""
+    from tests.helpers import host_frame
+    rng = np.random.default_rng(12000 + seed)
+    N = int(rng.choice([12, 17, 24, 32]))
+    L = int(rng.choice([4, 7, 12]))
+    V = int(rng.choice([1, 2, 4]))
+    W, H = ((int(rng.integers(1, 12)), int(rng.integers(1, 12))) if seed % 4 == 0 else (int(rng.choice([64, 130])), int(rng.choice([48, 100]))))
+    cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([1, 2, 40, 65535])), maxLight=int(rng.choice([1, 3, 20, 65535])), mesh=True)
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "noise", "special"], size=V)]
+    r = rng.uniform(8, 100)
+    d = rng.normal(size=3)
+    eye = tuple((d / np.linalg.norm(d) * r).astype(np.float32))
+    M = 64
+    descs = np.array([(i % V) | (5 << 14) | (N << 18) for i in range(V)], np.uint32)
+    eye_, vp, svp, cb, po = host_frame(cfg, 0, eye)
+    depth, lms, sh = special_inputs(rng, cfg, M, vp)
+    shadow = rc.synth_sphere_shadow(M, svp, (0, 0, 0), 8.0)
+    info, vis, cube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+    cm, cd, st = oracle.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)
+    img, comp_samples = oracle.composite(V, N, L, W, H, vols, lms, depth, po, cb, info, vis, cm, cd)
+    # the light march with the bad probe (its own frame: it overwrites one of the uploaded maps)
+    vid, lms2, nls = oracle.march_light(V, N, L, M, vols, descs, po, cb, shadow, sh, vis, cfg["maxLight"], lms.copy()) if len(vis) else (0, lms, 0)
+
+    def same(a, b, what):
+        fa, fb = np.asarray(a).view(np.float16), np.asarray(b).view(np.float16)
+        assert np.array_equal(np.isnan(fa), np.isnan(fb)), f"seed {seed}: NaNs of {what} at other places"
+        assert np.array_equal(np.where(np.isnan(fa), 0, np.asarray(a)), np.where(np.isnan(fb), 0, np.asarray(b))), f"seed {seed}: {what} differs"
+
+    with make_caster(cfg, M) as c:
+        fr = scene.setup_raycaster(c, cfg, vols, eye=eye)
+        c.SetRenderTargets(depth, shadow)
+        for v in range(V):
+            c.UploadLightMap(v, lms[v])
+        c.m_frameIdx = 0
+        c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        c.cullVolumes()
+        c.rayMarchV()
+        c.composite()
+        assert np.array_equal(c.ReadBackVolumeInfo()[vis], info[vis])
+        for v in cube:
+            mip = int(info[v, 0])
+            same(c.ReadBackCubeMap(int(v), mip), oracle.cube_face_view(cm[v], N, mip), f"cube map {v}")
+            gd, ed = c.ReadBackCubeDepth(int(v), mip), oracle.cube_face_view(cd[v], N, mip)
+            assert np.array_equal(np.isnan(gd), np.isnan(ed)) and np.array_equal(np.where(np.isnan(gd), 0, gd), np.where(np.isnan(ed), 0, ed)), f"seed {seed}: cube depth {v}"
+        same(c.ReadBackComposite(), img, "the composite")
+        g = c.GetStats()
+        assert (g["view_samples"], g["lit_samples"], g["rays"], g["composite_samples"]) == (st["view_samples"], st["lit_samples"], st["rays"], comp_samples)
+        if len(vis):
+            c.SetSH(sh)
+            c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+            c.cullVolumes()
+            c.rayMarchL()
+            c.synchronize()
+            assert np.array_equal(c.ReadBackLightMap(int(vid)), lms2[vid]), f"seed {seed}: light map {vid} with a non-finite probe"
+            assert c.GetStats()["light_samples"] == nls
