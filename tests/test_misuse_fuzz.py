@@ -126,3 +126,60 @@ def _only_history_differs(a, b):
     clears its cube maps): allowed to differ in a thin set of pixels along silhouettes, not in bulk."""
     d = (a != b).any(axis=2)
     return d.sum() <= 0.002 * d.size
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MV_GARBAGE_FUZZ", "4"))))
+def test_garbage_frame_constants_never_fault(seed):
+    """CBPerFrame / PerObject are the caller's bytes (mv_update_frame takes them raw, as the reference's upload heap does): NaNs, infinities, huge and denormal
+    values in them, or plain random bytes, may make a frame's RESULTS meaningless -- never its memory accesses.  Every float that becomes an index passes a clamp
+    first, every count derived from a projected rectangle is bounded: hundreds of frames of garbage on the one-stream and the four-chain context, the process lives,
+    and a proper frame afterwards equals a fresh context's.  (A GPU memory fault aborts the process: the test then dies instead of failing -- run it alone.)"""
+    r = np.random.default_rng(6000 + seed)
+    cfg = dict(scene.CONFIGS["T2"], N=int(r.choice([12, 24, 32])), L=int(r.integers(4, 16)), V=int(r.choice([1, 4, 9])), W=int(r.integers(8, 200)), H=int(r.integers(8, 150)), maxRay=32, maxLight=16)
+    V, N, L = cfg["V"], cfg["N"], cfg["L"]
+    vols = [rc.synth_volume(N, k) for k in range(V)]
+    flags, in_flight = ((0, 0), (_lib.MV_FLAG_PIPELINE_FRAMES | _lib.MV_FLAG_CULL_ON_VIEW_STREAM, 4))[seed % 2]
+    BAD = np.array([np.nan, np.inf, -np.inf, 1e38, -1e38, 1e-45, -1e-45, 0.0, -0.0, 3.4e38, 1e20, -1e20, 65536.0, -1.0], np.float32)
+
+    def proper(c):
+        fr = scene.setup_raycaster(c, cfg, vols)
+        c.ClearCubeMaps()   # (faces a frame does not march keep what earlier frames left -- here garbage: back to the creation state, as on the fresh context)
+        for f in range(V + 2):
+            c.m_frameIdx = f
+            c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+            c.Render(composite=True)
+        vis, _ = c.ReadBackVisibleLists()
+        return c.ReadBackComposite(), np.stack([c.ReadBackLightMap(int(v)) for v in vis] + [np.zeros((L, L, L), np.uint32)]), c.ReadBackVolumeInfo()[vis]
+
+    with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, framesInFlight=in_flight) as c:
+        fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
+        c.UpdateFrame(fr["viewProj"], fr["shadowVP"], fr["eye"])
+        good_cb, good_po = c.cbPerFrame.copy(), c.perObject.copy()
+        for k in range(150):
+            kind = int(r.integers(4))
+            cb, po = good_cb.copy(), good_po.copy()
+            if kind == 0:      # a few floats of the good constants replaced
+                for blob in (cb[:208].view(np.float32), po.view(np.float32)):
+                    n = int(r.integers(1, 6))
+                    blob[r.integers(0, blob.size, size=n)] = BAD[r.integers(0, len(BAD), size=n)]
+            elif kind == 1:    # every float of one of the two from the bad set
+                blob = (cb[:208].view(np.float32), po.view(np.float32))[int(r.integers(2))]
+                blob[:] = BAD[r.integers(0, len(BAD), size=blob.size)]
+            elif kind == 2:    # random bytes
+                cb[:] = r.integers(0, 256, size=cb.size, dtype=np.uint8)
+                po[:] = r.integers(0, 256, size=po.size, dtype=np.uint8)
+            else:              # good matrices scaled by wild factors (volumes of size 1e-20 .. 1e20, the eye at 1e30)
+                po.view(np.float32)[:] *= np.float32(10.0) ** r.integers(-25, 25)
+                cb[:16].view(np.float32)[:3] *= np.float32(10.0) ** r.integers(-20, 30)
+            cb[208:212].view(np.uint32)[0] = int(r.integers(0, 2 ** 32))   # FrameIdx: any
+            c.UpdateFrameRaw(cb, po)
+            c.Render(composite=bool(r.integers(2)))
+            if k % 25 == 24:
+                c.synchronize()
+                c.ReadBackComposite(); c.GetStats()
+        c.synchronize()
+        got = proper(c)
+    with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=64, flags=flags, framesInFlight=in_flight) as f:
+        exp = proper(f)
+    assert np.array_equal(got[2], exp[2]) and np.array_equal(got[1], exp[1])
+    assert np.array_equal(got[0], exp[0]), f"seed {seed}: {(got[0] != exp[0]).sum()} composite halfs differ after the garbage"
