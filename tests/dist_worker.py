@@ -41,6 +41,23 @@ def test_config(world):
     return cfg
 
 
+def test_volumes(cfg):
+    """The config's synthetic volumes; MV_TEST_SPECIAL_VOLUMES=seed sprinkles halfs no authoring tool writes over them (+-inf, NaNs, denormals, -0, +-65504, the
+    halfs around ZERO_THRESHOLD: tests/test_random_scenes.py random_volume "special"): every rank and the single-GPU run make the same ones."""
+    from multivolumes_amd import raycaster as rc
+    vols = [rc.synth_volume(cfg["N"], k) for k in range(cfg["V"])]
+    seed = os.environ.get("MV_TEST_SPECIAL_VOLUMES")
+    if seed:
+        r = np.random.default_rng(int(seed))
+        special = np.array([0x7c00, 0xfc00, 0x7e00, 0xfe00, 0x0001, 0x8001, 0x03ff, 0x8000, 0x7bff, 0xfbff, 0x3c00, 0xbc00, 0x211f, 0x2120, 0x211e], np.uint16)
+        N = cfg["N"]
+        for v in vols:
+            n = int(r.integers(1, N * N))
+            idx = r.integers(0, N, size=(n, 3))
+            v[idx[:, 0], idx[:, 1], idx[:, 2], r.integers(0, 4, size=n)] = special[r.integers(0, len(special), size=n)]
+    return vols
+
+
 def setter_script(frames, every, cfg):
     """(tests/test_dist_fuzz.py, MV_TEST_SETTER_SEED) per frame: the input setters in front of it -- collective inside the loop: every rank makes the same
     calls -- and whether the frame composites (checkpoint frames always do: a readback shows the image of a frame that composited)."""
@@ -103,7 +120,7 @@ def main():
         dist.init_process_group("gloo")
     cfg = test_config(world)
     V = cfg["V"]
-    vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+    vols = test_volumes(cfg)
     flags = _lib.MV_FLAG_PIPELINE_FRAMES | (_lib.MV_FLAG_SINGLE_VIEW_STREAM if mode == "single" else 0)
     four = os.environ.get("MV_TEST_FOUR_CHAINS") == "1"  # four whole frames in flight, upload + cull on the frames' own view streams
     if four:

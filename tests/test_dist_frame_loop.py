@@ -42,10 +42,10 @@ def run_group(cmd, timeout, env=None):
 def single_gpu(world, frames, every, static_depth=False, all_frames=False):
     from multivolumes_amd import MultiRayCaster, _lib, scene
     from multivolumes_amd import raycaster as rc
-    from tests.dist_worker import apply_setter, camera_sequence, setter_script, test_config
+    from tests.dist_worker import apply_setter, camera_sequence, setter_script, test_config, test_volumes
     cfg = test_config(world)
     V = cfg["V"]
-    vols = [rc.synth_volume(cfg["N"], k) for k in range(V)]
+    vols = test_volumes(cfg)
     with MultiRayCaster(cfg["N"], cfg["L"], V, V, (cfg["W"], cfg["H"]), shadowMapSize=64) as c:
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         imgs, infos = [], []

@@ -20,7 +20,7 @@ def draw(seed):
     r = np.random.default_rng(1000 + seed)
     world = int(r.choice([2, 3, 4, 5, 6, 7, 8]))
     mode = MODES[int(r.integers(len(MODES)))]
-    cfg = dict(N=int(r.choice([16, 24, 32, 36, 40, 48, 56])), L=int(r.integers(6, 45)), V=int(r.choice([1, 2, 4, 4, 9, 16, 16])),
+    cfg = dict(N=int(r.choice([16, 24, 32, 36, 40, 48, 56])), L=int(r.integers(6, 45)), V=int(r.choice([1, 2, 4, 4, 9, 16, 16])),  # (N = 12 with one-texel mips: the corners)
                W=int(r.integers(64, 330)), H=int(r.integers(40, 250)), maxRay=int(r.choice([16, 32, 48, 64, 96])), maxLight=int(r.choice([8, 16, 24, 32])))
     if world >= 6:  # (many processes on the one GPU: keep each small)
         cfg["N"] = min(cfg["N"], 40)
@@ -28,6 +28,7 @@ def draw(seed):
     every = int(r.choice([3, 5, 7, frames]))
     static_depth = bool(r.integers(2))
     cfg["setters"] = int(r.integers(1, 1 << 30)) if r.random() < 0.5 else 0  # (half of the seeds: setters between the frames, frames without a composite)
+    cfg["special"] = int(r.integers(1, 1 << 30)) if r.random() < 0.25 else 0  # (a quarter: +-inf, NaN, denormal ... halfs in the volumes)
     return world, mode, cfg, frames, every, static_depth
 
 
@@ -39,6 +40,8 @@ CORNERS = {
     "ragged-n-x4": (3, "peer-x4", dict(N=33, L=9, V=4, W=130, H=70, maxRay=32, maxLight=16), 9, 9, True),
     "one-tile-row": (8, "peer-x3-root", dict(N=24, L=10, V=4, W=200, H=8, maxRay=32, maxLight=8), 7, 7, True),
     "one-volume": (8, "peer-folded", dict(N=32, L=33, V=1, W=96, H=96, maxRay=48, maxLight=16), 8, 4, False),
+    "one-texel-mips": (4, "peer-x2", dict(N=12, L=7, V=4, W=24, H=16, maxRay=16, maxLight=8, special=77), 9, 3, True),
+    "special-halfs-x4": (3, "peer-x4-root", dict(N=24, L=11, V=9, W=150, H=90, maxRay=32, maxLight=16, special=78), 9, 9, True),
 }
 
 
@@ -78,6 +81,9 @@ def test_random_config_world_and_transport_match_single_gpu(tmp_path, seed, monk
         mode, env["MV_TEST_TRANSPORT"] = "chains", "peer"
     if seed if isinstance(seed, str) else seed % 2:  # (every other seed, and the corners: the ranks' hosts stall at different frames for different times)
         env["MV_TEST_SKEW_SEED"] = str(sum(map(ord, seed)) if isinstance(seed, str) else seed)
+    if cfg.get("special"):
+        env["MV_TEST_SPECIAL_VOLUMES"] = str(cfg["special"])
+        monkeypatch.setenv("MV_TEST_SPECIAL_VOLUMES", str(cfg["special"]))
     if cfg.get("setters"):  # (tests/dist_worker.py setter_script: light probe, sample caps, light, volume / light-map uploads, shadow map; DistFrame(composite=False))
         env["MV_TEST_SETTER_SEED"] = str(cfg["setters"])
         monkeypatch.setenv("MV_TEST_SETTER_SEED", str(cfg["setters"]))
