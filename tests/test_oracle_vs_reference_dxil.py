@@ -357,6 +357,57 @@ def test_volumes_placed_at_will_against_the_compiled_shaders(oracle, seed):
     assert same(got, img), (seed, eye, int((np.asarray(got) != np.asarray(img)).sum()))
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("MV_DXIL_SPECIAL_SEEDS", "6"))))
+def test_special_inputs_against_the_compiled_shaders(oracle, seed):
+    """Round 6: what the reference's arithmetic makes of inputs no tool hands over -- depth maps with NaN / +-inf / negatives / values beyond 1, uploaded light
+    maps with the 11- / 10-bit patterns of infinity, NaN, denormals, a light probe with huge and non-finite coefficients, special halfs in the volumes, sample
+    caps of 1 and 65535, viewports of a few pixels (tests/test_random_scenes.py special_inputs, the GPU's sweep against the oracle).  Which min / max ignore a
+    NaN, which comparisons are false, where a saturate turns NaN into 0 is the COMPILER's choice of operations, recorded in the shipped DXIL: the oracle follows
+    it -- cube maps / depths, image and the light map from the compiled shaders have NaNs at the same places and every other bit equal."""
+    from tests.test_random_scenes import random_volume, special_inputs
+    rng = np.random.default_rng(12000 + seed)  # (the scenes of the GPU's sweep, smaller)
+    N = int(rng.choice([12, 17, 24]))
+    L = int(rng.choice([4, 7, 12]))
+    V = int(rng.choice([1, 2, 4]))
+    W, H = ((int(rng.integers(1, 12)), int(rng.integers(1, 12))) if seed % 4 == 0 else (int(rng.choice([40, 66])), int(rng.choice([24, 50]))))
+    cfg = dict(N=N, L=L, V=V, W=W, H=H, maxRay=int(rng.choice([1, 2, 40, 65535])), maxLight=int(rng.choice([1, 3, 20, 65535])), mesh=True)
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "noise", "special"], size=V)]
+    r = rng.uniform(8, 100)
+    d = rng.normal(size=3)
+    eye = tuple((d / np.linalg.norm(d) * r).astype(np.float32))
+    M = 32
+    descs = default_descs(V, V, N)
+    _, vp, svp, cb, po = host_frame(cfg, 0, eye)
+    depth, lms, sh = special_inputs(rng, cfg, M, vp)
+    shadow = rc.synth_sphere_shadow(M, svp, (0, 0, 0), 8.0)
+    info, vis, cube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+    i1, v1, c1 = dxref.cull(V, po, descs, cb, cfg["maxRay"])
+    assert np.array_equal(info, i1) and np.array_equal(np.sort(vis), np.sort(v1)) and np.array_equal(np.sort(cube), np.sort(c1)), (seed, eye)
+
+    def same(a, b, what, halfs=True):
+        fa, fb = (np.asarray(a).view(np.float16), np.asarray(b).view(np.float16)) if halfs else (np.asarray(a), np.asarray(b))
+        assert np.array_equal(np.isnan(fa), np.isnan(fb)), f"seed {seed}: NaNs of {what} at other places"
+        assert np.array_equal(np.where(np.isnan(fa), 0, np.asarray(a)), np.where(np.isnan(fb), 0, np.asarray(b))), f"seed {seed}: {what} differs"
+
+    cm, cd = oracle.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)[:2]
+    if len(cube):
+        cm1, cd1 = dxref.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)
+        same(cm1, cm, "the cube maps")
+        same(cd1, cd, "the cube depths", halfs=False)
+    args = (V, N, L, W, H, vols, lms, depth, po, cb, info, np.sort(vis), cm, cd)
+    img = oracle.composite(*args)[0]
+    same(dxref.composite(*args), img, "the image")
+    print(f"seed {seed}: visible {len(vis)} cube-mapped {len(cube)} NaN halfs in the cube maps {int(np.isnan(np.asarray(cm).view(np.float16)).sum())} in the image {int(np.isnan(np.asarray(img).view(np.float16)).sum())} of {W}x{H}")
+    if len(vis):  # the light march with the bad probe, over one of the uploaded maps
+        vid, lms2, _ = oracle.march_light(V, N, L, M, vols, descs, po, cb, shadow, sh, vis, cfg["maxLight"], lms.copy())
+        lm = dxref.march_light(V, N, L, M, vols, descs, po, cb, shadow, sh, vis, cfg["maxLight"], lms.copy())
+        diff = lm[vid] != lms2[vid]
+        assert diff.sum() <= 3, (seed, int(diff.sum()))  # (the compiled SH sum is in the compiler's fast-math order: the neighbouring 11-bit value in a voxel or two)
+        a, b = lm[vid][diff].astype(np.int64), lms2[vid][diff].astype(np.int64)
+        for sh_, m_ in ((0, 0x7ff), (11, 0x7ff), (22, 0x3ff)):
+            assert np.all(np.abs(((a >> sh_) & m_) - ((b >> sh_) & m_)) <= 1)
+
+
 @pytest.mark.parametrize("N,W,H,eye", [(12, 9, 2, (30.0, 40.0, -200.0)), (8, 16, 8, (4.0, 16.0, -400.0)), (12, 32, 24, (4.0, 16.0, -400.0)), (4, 16, 8, (4.0, 16.0, -400.0)), (12, 16, 8, (20.0, 20.0, -120.0))])
 def test_one_texel_mips_against_the_compiled_shaders(oracle, N, W, H, eye):
     """Round 6: cube maps smaller than 16 texels have mips of ONE texel (D3D: max(1, N >> mip); the shaders learn the edge from GetDimensions,
