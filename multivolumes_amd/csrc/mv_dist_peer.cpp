@@ -112,19 +112,27 @@ int peerWaitStage(mv_ctx* ctx, hipStream_t s, int stage, uint64_t frame, uint32_
 int peerCheckReports(mv_ctx* ctx)
 {
 	DistState* d = ctx->dist;
+	// (timeouts first, in every slot: a wait that gave up goes on to compare its cull words with whatever the stalled rank's last frame left there,
+	// and "the culls disagree" would hide the stall -- round 6, tests/test_dist_frame_loop.py::test_a_stalled_rank_is_reported_soon_after_the_timeout)
+	// (and a wait for ANOTHER rank before a wait for a stage of this rank's own: the kernel that would have raised that one is itself waiting for the stalled rank)
+	unsigned long long t = 0ull;
+	for (uint32_t i = 0; i < kMaxFrameSlots; ++i)
+	{
+		const unsigned long long ti = *reinterpret_cast<volatile unsigned long long*>(d->reports + (size_t)i * 8u + 2u);
+		if (ti && (!t || ((t & 0xffu) == ctx->st.shardIndex && (ti & 0xffu) != ctx->st.shardIndex))) t = ti;
+	}
+	if (t)
+	{
+		char msg[320];
+		snprintf(msg, sizeof(msg), "peer-store transport: frame %u gave up waiting for rank %u (stage %u: 0 light share, 1 cube faces, 2 rows, 3 done, 4 this rank's own rebuild of the light cells) -- that rank is stalled, gone, or was handed other frames",
+			(unsigned)(t >> 32), (unsigned)(t & 0xffu), (unsigned)(((t >> 8) & 0xffffu) / mv::kPeerMaxChains));
+		return fail(ctx, MV_ERR_TIMEOUT, msg);
+	}
 	for (uint32_t i = 0; i < kMaxFrameSlots; ++i)
 	{
 		const unsigned long long c = *reinterpret_cast<volatile unsigned long long*>(d->reports + (size_t)i * 8u + 1u);
 		if (c && d->cullCrosscheck)
 			return fail(ctx, MV_ERR_INVALID_ARG, "the ranks' culls of a frame disagree (different frame constants on different ranks?): the ranks are not rendering the same frame");
-		const unsigned long long t = *reinterpret_cast<volatile unsigned long long*>(d->reports + (size_t)i * 8u + 2u);
-		if (t)
-		{
-			char msg[256];
-			snprintf(msg, sizeof(msg), "peer-store transport: frame %u gave up waiting for rank %u (stage %u: 0 light share, 1 cube faces, 2 rows, 3 done) -- that rank is stalled, gone, or was handed other frames",
-				(unsigned)(t >> 32), (unsigned)(t & 0xffu), (unsigned)(((t >> 8) & 0xffffu) / mv::kPeerMaxChains));
-			return fail(ctx, MV_ERR_TIMEOUT, msg);
-		}
 	}
 	return MV_OK;
 }

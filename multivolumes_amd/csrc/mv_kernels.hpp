@@ -244,6 +244,16 @@ __device__ __forceinline__ void peerFoldAcquire(const DeviceState& st)
 }
 // (firstRow / endRow: the rows of fold.waitRow to wait for -- the view march waits for its newest row only in the workgroups that read
 // the light map that row announces)
+// A wait of this frame slot has given up (its report is set): the workgroups dispatched behind it, and the slot's later launches, do not each wait
+// their own timeout for the same stalled rank; the host finds the report at its next call.  Looked at on the first unsuccessful poll and every
+// 1024th after it (pinned host memory).
+#ifndef MV_PEER_STICKY_GIVE_UP
+#define MV_PEER_STICKY_GIVE_UP 1	// (0: every workgroup waits its own timeout -- tests/test_dist_frame_loop.py's stalled-rank test then fails: its teeth)
+#endif
+__device__ __forceinline__ bool peerGaveUp(const DeviceState& st)
+{
+	return MV_PEER_STICKY_GIVE_UP && __hip_atomic_load(st.fold.report + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+}
 __device__ __forceinline__ void peerFoldWait(const DeviceState& st, uint32_t firstRow = 0u, uint32_t endRow = 0xffffffffu)
 {
 	if (endRow > st.fold.nWait) endRow = st.fold.nWait;
@@ -257,13 +267,18 @@ __device__ __forceinline__ void peerFoldWait(const DeviceState& st, uint32_t fir
 			const uint32_t r = firstRow + i / st.peerCount, p = i - (r - firstRow) * st.peerCount;
 			if (((st.fold.waitLocal >> r) & 1u) && p != st.shardIndex) continue;	// (a local row: this rank's own column is the only one ever raised)
 			const unsigned long long* flag = st.fold.myFlags + (size_t)st.fold.waitRow[r] * kPeerMaxRanks + p;
+			// (a local row is raised by a kernel of THIS rank, which may itself be waiting for a stalled rank: twice the patience, so that the
+			// report names that rank and not this one)
+			const unsigned long long patience = st.fold.timeoutTicks << ((st.fold.waitLocal >> r) & 1u);
+			uint32_t polls = 0u;
 			while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < st.fold.waitValue[r])
 			{
-				if (wall_clock64() - t0 > st.fold.timeoutTicks)
+				if (wall_clock64() - t0 > patience)
 				{
 					__hip_atomic_store(st.fold.report + 2, ((unsigned long long)st.fold.frameTag << 32) | ((unsigned long long)st.fold.waitRow[r] << 8) | p | 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					break;
 				}
+				if ((polls++ & 1023u) == 0u && peerGaveUp(st)) break;
 				__builtin_amdgcn_s_sleep(8);
 			}
 		}
@@ -307,13 +322,16 @@ __device__ __forceinline__ void peerFoldWaitWave(const DeviceState& st, uint32_t
 		const uint32_t r = firstRow + i / st.peerCount, p = i - (r - firstRow) * st.peerCount;
 		if (((st.fold.waitLocal >> r) & 1u) && p != st.shardIndex) continue;
 		const unsigned long long* flag = st.fold.myFlags + (size_t)st.fold.waitRow[r] * kPeerMaxRanks + p;
+		const unsigned long long patience = st.fold.timeoutTicks << ((st.fold.waitLocal >> r) & 1u);	// (as in peerFoldWait)
+		uint32_t polls = 0u;
 		while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < st.fold.waitValue[r])
 		{
-			if (wall_clock64() - t0 > st.fold.timeoutTicks)
+			if (wall_clock64() - t0 > patience)
 			{
 				__hip_atomic_store(st.fold.report + 2, ((unsigned long long)st.fold.frameTag << 32) | ((unsigned long long)st.fold.waitRow[r] << 8) | p | 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				break;
 			}
+			if ((polls++ & 1023u) == 0u && peerGaveUp(st)) break;
 			__builtin_amdgcn_s_sleep(8);
 		}
 	}

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(64) void peerSyncKernel(PeerSync a)
 	if (a.nWait)
 	{
 		const unsigned long long t0 = wall_clock64();
+		const unsigned long long patience = a.timeoutTicks << (a.waitLocal ? 1u : 0u);	// (a local row: mv_kernels.hpp peerFoldWait)
 		for (uint32_t i = 0; i < a.nWait; ++i)
 			for (uint32_t p = lane; p < a.world; p += 64u)
 			{
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(64) void peerSyncKernel(PeerSync a)
 				const unsigned long long* flag = a.myFlags + (size_t)a.waitRow[i] * kPeerMaxRanks + p;
 				while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.waitValue[i])
 				{
-					if (wall_clock64() - t0 > a.timeoutTicks)
+					if (wall_clock64() - t0 > patience)
 					{
 						__hip_atomic_store(a.report + 2, ((unsigned long long)a.frameTag << 32) | ((unsigned long long)a.waitRow[i] << 8) | p | 0x80000000ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 						break;

@@ -11,5 +11,5 @@ MV_TEST_PEER_FOLD=1 MV_TEST_FRAMES_PER_LAUNCH=4 MV_TEST_ROWS_TO_ROOT=1 MV_TEST_W
 MV_TEST_PEER_FOLD=1 MV_TEST_FRAMES_PER_LAUNCH=2 timeout 1500 python scripts/soak_dist.py 7 3000 233 chains
 MV_TEST_PEER_FOLD=1 MV_TEST_FRAMES_PER_LAUNCH=4 MV_TEST_L=24 MV_TEST_ROWS_TO_ROOT=1 timeout 1500 python scripts/soak_dist.py 5 4000 191 chains
 } 2>&1 | grep -v "^W\|warn" | tee $out/soak.txt
-MV_TEST_CONFIG=C3 MV_TEST_PEER_FOLD=1 MV_TEST_FRAMES_PER_LAUNCH=4 OMP_NUM_THREADS=4 timeout 1500 python scripts/soak_dist.py 2 2000 173 chains 2>&1 | grep -v "^W\|warn" | tee -a $out/soak.txt
+MV_TEST_CONFIG=C3 OMP_NUM_THREADS=4 timeout 1500 python scripts/soak_dist.py 2 2000 173 chains 2>&1 | grep -v "^W\|warn" | tee -a $out/soak.txt
 MV_SOAK_FOUR_CHAINS=1 timeout 1500 python scripts/soak.py 200000 10000 2>&1 | tail -8 | tee -a $out/soak.txt

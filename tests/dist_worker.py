@@ -106,6 +106,7 @@ def main():
     mode = sys.argv[4] if len(sys.argv) > 4 else "chains"           # "chains" (three view streams) or "single" (one view stream)
     static_depth = len(sys.argv) > 5 and sys.argv[5] == "1"          # no setter (= no drain of the frames in flight) inside the sequence
     diverge = len(sys.argv) > 5 and sys.argv[5] == "3"               # rank 1 is handed another camera in frame 5: the loop must REPORT it, not hang
+    stalled = len(sys.argv) > 5 and sys.argv[5] == "4"               # rank 1's host stops handing over frames behind frame 8: rank 0 must get MV_ERR_TIMEOUT soon after its timeout, not hang
     after_setter = len(sys.argv) > 5 and sys.argv[5] == "2"          # a new host depth map every frame and NO flush: frame f - 1 is read back right after the setter of frame f
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     rccl = os.environ.get("MV_TEST_RCCL") == "1"  # one GPU per rank and the library's own RCCL communicators (boxes with >= world GPUs)
@@ -131,7 +132,7 @@ def main():
         fr = scene.setup_raycaster(c, cfg, vols, use_sh=True)
         peer = os.environ.get("MV_TEST_TRANSPORT") == "peer"     # the peer-store transport: IPC mappings, works with every rank on one GPU
         fold = {"1": True, "0": False}.get(os.environ.get("MV_TEST_PEER_FOLD"))  # (None: the library decides -- ranks sharing a GPU keep the flag kernels)
-        kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=120000, peer_fold=fold, peer_rows_to_root=os.environ.get("MV_TEST_ROWS_TO_ROOT") == "1",
+        kind = D.init_frame_loop(c, prefer_peer=peer, peer_timeout_ms=int(os.environ.get("MV_TEST_PEER_TIMEOUT_MS", "120000")), peer_fold=fold, peer_rows_to_root=os.environ.get("MV_TEST_ROWS_TO_ROOT") == "1",
                                  peer_deal_volumes={"1": True, "0": False}.get(os.environ.get("MV_TEST_DEAL_VOLUMES")),  # (None: the library's choice)
                                  peer_push_cells=os.environ.get("MV_TEST_PUSH_CELLS") == "1")  # (round 4's light push: whole cells; the default is plain texels rebuilt by the receiver)
         assert kind == ("peer" if peer else "rccl" if rccl else "torch-callbacks"), kind
@@ -165,6 +166,24 @@ def main():
                 if after_setter and f > 0:
                     imgs.append(c.ReadBackComposite())
                     infos.append(c.ReadBackVolumeInfo())
+            if stalled:
+                import time
+                if rank == 1 and f == 8:
+                    c.synchronize()
+                    print("rank 1: stops here", flush=True)
+                    time.sleep(float(os.environ.get("MV_TEST_STALL_S", "40")))  # (alive, its buffers mapped, handing over nothing)
+                    os._exit(0)
+                if f == 8:
+                    t_stall = time.time()
+                try:
+                    c.DistFrame(vp, fr["shadowVP"], e)
+                    if f >= 8:
+                        c.synchronize()
+                except Exception as ex:
+                    assert f >= 8 and "gave up waiting for rank 1" in str(ex), (f, str(ex))
+                    print(f"rank {rank}: stall reported at frame {f} after {time.time() - t_stall:.1f} s: {ex}", flush=True)
+                    os._exit(0)
+                continue
             if diverge:
                 if f == 5 and rank == 1:
                     e = np.array([3.0, 9.0, -12.0], np.float32)  # inside the grid of volumes: another visible set, other shard sizes

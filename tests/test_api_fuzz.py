@@ -20,14 +20,27 @@ KINDS = ["full", "full", "full", "full_no_composite", "no_light", "no_march", "c
 SETTERS = ["depth_host", "depth_device", "shadow", "sh", "max_samples", "light", "volume", "light_map", "viewport", "readback"]
 
 
+# the second fuzz (later in round 6): the producers and the remaining setters between the frames -- the mesh rasterised into the context's own depth / shadow
+# map, a volume's world transform, the ambient term, the volume -> texture table, mv_clear_cube_maps, profiling on / off, mv_reset_stats -- and composites in
+# row bands or over a background
+KINDS_X = KINDS + ["bands", "bands", "over", "over_bands"]
+SETTERS_X = SETTERS + ["mesh_depth", "mesh_shadow", "world", "ambient", "descs", "clear_cube", "profiling", "reset_stats", "mesh"]
+
+
 @pytest.mark.parametrize("seed", range(FIRST, FIRST + N_SEEDS))
 def test_random_call_sequences_read_the_same_with_and_without_frames_in_flight(seed):
     run_sequence(seed)
 
 
-def make_script(seed):
+@pytest.mark.parametrize("seed", range(FIRST, FIRST + N_SEEDS))
+def test_random_call_sequences_with_the_producers_and_partial_composites(seed):
+    run_sequence(seed, extended=True)
+
+
+def make_script(seed, extended=False):
     """The whole sequence, drawn up front (so that leaving ops out by hand does not change the rest): (cfg, [(setters, kind, compare)] per frame)."""
-    r = np.random.default_rng(7000 + seed)
+    r = np.random.default_rng((7000 if not extended else 8000000) + seed)
+    SETTERS, KINDS = (SETTERS_X, KINDS_X) if extended else (globals()["SETTERS"], globals()["KINDS"])
     cfg = dict(scene.CONFIGS["T2"], N=int(r.choice([24, 32, 40, 48])), L=int(r.integers(8, 40)), V=int(r.choice([4, 9, 16])),
                W=int(r.integers(96, 300)), H=int(r.integers(64, 220)), maxRay=int(r.choice([32, 48, 64])), maxLight=int(r.choice([16, 24, 32])))
     frames = []
@@ -39,16 +52,29 @@ def make_script(seed):
                    "max_samples": (int(r.choice([16, 32, 48, 64, 96])), int(r.choice([8, 16, 24, 32]))),
                    "light": (float(r.uniform(40, 90)), float(r.uniform(40, 90)), -float(r.uniform(40, 90))),
                    "volume": (int(r.integers(cfg["V"])), int(r.integers(0, 40))), "light_map": (int(r.integers(cfg["V"])), int(r.integers(1 << 30))),
-                   "viewport": (int(r.integers(96, 300)), int(r.integers(64, 220))), "readback": int(r.integers(cfg["V"]))}[what]
+                   "viewport": (int(r.integers(96, 300)), int(r.integers(64, 220))), "readback": int(r.integers(cfg["V"])),
+                   "mesh_depth": (float(r.uniform(0.5, 3.0)), bool(r.integers(2))), "mesh_shadow": float(r.uniform(0.5, 3.0)), "mesh": int(r.integers(1 << 30)),
+                   "world": (int(r.integers(cfg["V"])), float(r.uniform(6.0, 30.0)), tuple(float(x) for x in r.normal(0.0, 14.0, size=3))),
+                   "ambient": (float(r.uniform(0.0, 1.0)), float(r.uniform(0.0, 1.0)), float(r.uniform(0.0, 1.0)), float(r.uniform(0.0, 2.0))),
+                   "descs": int(r.integers(1 << 30)), "clear_cube": None, "profiling": bool(r.integers(2)), "reset_stats": None}[what]
             setters.append((what, arg))
-        frames.append((setters, KINDS[int(r.integers(len(KINDS)))], bool(r.random() < 0.4)))
+        frames.append((setters, KINDS[int(r.integers(len(KINDS)))], bool(r.random() < 0.4), float(r.random())))
     return cfg, frames
 
 
-def run_sequence(seed, disable=(), verbose=False, only_kinds=None, variants=None, stop_after=None, script=None):
+def random_mesh(seed):
+    """A few dozen triangles around the origin (the rasteriser's own fuzz is tests/test_mesh.py): (positions, indices)."""
+    r = np.random.default_rng(seed)
+    n = int(r.integers(4, 60))
+    centres = r.normal(0.0, 5.0, size=(n, 1, 3))
+    pos = (centres + r.normal(0.0, 3.0, size=(n, 3, 3))).astype(np.float32).reshape(-1, 3)
+    return pos, np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+
+
+def run_sequence(seed, disable=(), verbose=False, only_kinds=None, variants=None, stop_after=None, script=None, extended=False):
     """(also driven by hand: python -c "from tests.test_api_fuzz import run_sequence; run_sequence(0, disable=('viewport',), verbose=True)")"""
     import torch
-    cfg, drawn = make_script(seed)
+    cfg, drawn = make_script(seed, extended)
     script = drawn if script is None else script
     if stop_after is not None:
         script = script[:stop_after]
@@ -70,8 +96,12 @@ def run_sequence(seed, disable=(), verbose=False, only_kinds=None, variants=None
         W, H = cfg["W"], cfg["H"]
         shadow_vp = frs[0]["shadowVP"]
         keep = []  # device tensors the contexts borrow: alive until the end
+        bg = None
         compared = 0
-        for f, (setters, kind, compare) in enumerate(script):
+        if extended:
+            for c in cs:
+                c.SetMesh(*random_mesh(seed))
+        for f, (setters, kind, compare, *rest) in enumerate(script):
             a = 0.05 * f + 0.3 * seed
             s = 1.0 - 0.5 * np.sin(0.21 * f) ** 2
             e = np.array([85.0 * s * np.sin(a), 16.0 + 14.0 * np.sin(0.37 * a), -85.0 * s * np.cos(a)], np.float32)
@@ -121,6 +151,36 @@ def run_sequence(seed, disable=(), verbose=False, only_kinds=None, variants=None
                     for c in cs:
                         c.SetViewport(W, H)
                         c.SetRenderTargets(d)
+                elif what == "mesh":
+                    for c in cs:
+                        c.SetMesh(*random_mesh(arg))
+                elif what == "mesh_depth":  # the context rasterises its own depth map (ObjectRenderer's depth pass), with or without the TAA jitter
+                    wvp = rc.multiply(rc.mesh_world(arg[0], (0.0, 0.0, 0.0)), vp)
+                    for c in cs:
+                        c.RenderMeshDepth(wvp, (0.25 / W, -0.4 / H) if arg[1] else None)
+                elif what == "mesh_shadow":
+                    swvp = rc.multiply(rc.mesh_world(arg, (0.0, 0.0, 0.0)), np.asarray(shadow_vp, np.float32).reshape(4, 4).T.copy())
+                    for c in cs:
+                        c.RenderMeshShadow(swvp)
+                elif what == "world":
+                    for c in cs:
+                        c.SetVolumeWorld(*arg)
+                elif what == "ambient":
+                    for c in cs:
+                        c.SetAmbient(arg[:3], arg[3])
+                elif what == "descs":  # another volume -> texture table (VolTexId = a random source each; mask bits and size as before)
+                    tex = np.random.default_rng(arg).integers(0, V, size=V)
+                    for c in cs:
+                        c.SetVolumeDescs(np.array([int(t) | (5 << 14) | (N << 18) for t in tex], np.uint32))
+                elif what == "clear_cube":
+                    for c in cs:
+                        c.ClearCubeMaps()
+                elif what == "profiling":
+                    for c in cs:
+                        c.SetProfiling(arg)
+                elif what == "reset_stats":
+                    for c in cs:
+                        c.ResetStats()
                 else:
                     got = [(c.ReadBackVolumeInfo(), c.ReadBackLightMap(arg)) for c in cs]
                     for g in got[1:]:
@@ -143,10 +203,25 @@ def run_sequence(seed, disable=(), verbose=False, only_kinds=None, variants=None
                         c.rayMarchV()
                     if kind in ("full", "no_light", "no_march", "composite_only"):
                         c.composite()
+                if kind in ("bands", "over", "over_bands"):  # (whole frames whose composite comes in row bands and / or over a colour target)
+                    c.rayMarchL()
+                    c.rayMarchV()
+                    if kind != "bands":
+                        if bg is None or tuple(bg.shape[:2]) != (H, W):
+                            bg = torch.from_numpy(np.random.default_rng(seed).random((H, W, 4), dtype=np.float32).astype(np.float16)).cuda()
+                            keep.append(bg)
+                    back = None if kind == "bands" else bg.data_ptr()
+                    if kind == "over":
+                        c.composite(backgroundDevice=back)
+                    else:
+                        cut = sorted({0, H, 1 + int(rest[0] * (H - 1)), 1 + int((rest[0] * 7.3 % 1.0) * (H - 1))})
+                        order = list(zip(cut[:-1], cut[1:]))
+                        for r0, r1 in (order[::-1] if f % 2 else order):
+                            c.composite(r0, r1, backgroundDevice=back)
                 c.m_frameIdx += 1
             # ---- compare at random points (a readback drains the frames in flight: most frames go by without one) ----
             # (behind a frame that composited: the image belongs to the frame's output set, include/multivolumes.h mv_readback_composite)
-            if kind in ("full", "no_light", "no_march", "composite_only", "composite_then_march") and compare:
+            if kind in ("full", "no_light", "no_march", "composite_only", "composite_then_march", "bands", "over", "over_bands") and compare:
                 imgs = [c.ReadBackComposite() for c in cs]
                 infos = [c.ReadBackVolumeInfo() for c in cs]
                 for i in range(1, len(cs)):

@@ -20,9 +20,10 @@ def _free_port():
     s.close()
     return p
 
-def run_group(cmd, timeout, env=None):
+def run_group(cmd, timeout, env=None, _retry=True):
     """subprocess.run in a process group of its own: on a timeout the whole group is killed (torchrun's workers would otherwise outlive
-    it and keep the GPU), and the failure carries what the ranks had printed."""
+    it and keep the GPU), and the failure carries what the ranks had printed.  A rendezvous port that was taken between _free_port() and
+    torchrun's bind (EADDRINUSE: seen once in some hundred launches) gets one more try on another port."""
     import signal
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
     try:
@@ -31,6 +32,10 @@ def run_group(cmd, timeout, env=None):
         os.killpg(p.pid, signal.SIGKILL)
         out, err = p.communicate()
         raise AssertionError(f"timed out after {timeout} s; stderr tail:\n{err[-3000:]}\nstdout tail:\n{out[-1000:]}")
+    if p.returncode != 0 and _retry and "EADDRINUSE" in err and "--master-port" in cmd:
+        cmd = list(cmd)
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        return run_group(cmd, timeout, env, _retry=False)
     return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 

@@ -21,9 +21,10 @@ def _free_port():
     s.close()
     return p
 
-def run_group(cmd, timeout, env=None):
+def run_group(cmd, timeout, env=None, _retry=True):
     """subprocess.run in a process group of its own: on a timeout the whole group is killed (torchrun's workers would otherwise outlive
-    it and keep the GPU), and the failure carries what the ranks had printed."""
+    it and keep the GPU), and the failure carries what the ranks had printed.  A rendezvous port that was taken between _free_port() and
+    torchrun's bind (EADDRINUSE: seen once in some hundred launches) gets one more try on another port."""
     import signal
     p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT, start_new_session=True)
     try:
@@ -35,6 +36,10 @@ def run_group(cmd, timeout, env=None):
         except subprocess.TimeoutExpired:  # (ranks stuck in a GPU kernel can take long to die: do not wait for their pipes)
             out, err = "", "(the killed ranks have not closed their pipes)"
         raise AssertionError(f"timed out after {timeout} s; stderr tail:\n{err[-3000:]}\nstdout tail:\n{out[-1000:]}")
+    if p.returncode != 0 and _retry and "EADDRINUSE" in err and "--master-port" in cmd:
+        cmd = list(cmd)
+        cmd[cmd.index("--master-port") + 1] = str(_free_port())
+        return run_group(cmd, timeout, env, _retry=False)
     return subprocess.CompletedProcess(cmd, p.returncode, out, err)
 
 
@@ -216,6 +221,30 @@ def test_ranks_that_were_handed_different_frames_get_an_error_not_a_hang(tmp_pat
     r = run_group(cmd, 300, env)
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.count("divergence reported at frame") == 2, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mode", ["peer", "peer-folded", "peer-x4"])
+def test_a_stalled_rank_is_reported_soon_after_the_timeout(tmp_path, mode):
+    """Rank 1's host stops handing over frames behind frame 8 (it stays alive, its buffers mapped).  Rank 0's waits -- a one-wavefront kernel, or
+    the prologue of EVERY workgroup of the consumer when the waits are folded -- give up after the transport's timeout (2 s here) and the next call
+    returns MV_ERR_TIMEOUT naming the rank.  Round 6 (first run of this test): the report said "the ranks' culls disagree" (a wait that gave up went on
+    to compare cull words the stalled rank never wrote; timeouts are now looked at first), or named rank 0 itself (a wait for this rank's own rebuild of
+    the light cells, whose kernel was waiting for rank 1: local rows now have twice the patience, and a report that names another rank comes first);
+    a give-up is also seen by the workgroups and launches of the slot dispatched behind it (mv_kernels.hpp peerGaveUp)."""
+    import re
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_TRANSPORT="peer", MV_TEST_PEER_TIMEOUT_MS="2000", MV_TEST_STALL_S="15", MV_TEST_W="1024", MV_TEST_H="1024")
+    if mode == "peer-x4":
+        env.update(MV_TEST_FRAMES_PER_LAUNCH="4", MV_TEST_FOUR_CHAINS="1", MV_TEST_PEER_FOLD="1")
+    elif mode == "peer-folded":
+        env.update(MV_TEST_FOUR_CHAINS="1", MV_TEST_PEER_FOLD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path / "unused.npz"), "40", "1", "chains", "4"]
+    r = run_group(cmd, 200, env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    m = re.search(r"rank 0: stall reported at frame (\d+) after ([0-9.]+) s", r.stdout)
+    assert m, r.stdout[-2000:] + r.stderr[-2000:]
+    print(m.group(0))
+    assert float(m.group(2)) < 15.0, m.group(0)  # (the timeout, plus the frames rank 0 could still finish, plus the groups in flight)
 
 
 @pytest.mark.parametrize("mode", ["chains", "single", "peer", "peer-x3"])
