@@ -233,7 +233,7 @@ def supervise(args, world, rank):
         while True:
             time.sleep(0.5 if proc.poll() is not None else 2.0)
             code = proc.poll()
-            stuck = code is None and time.monotonic() - state["since"] > PHASE_TIMEOUT_S.get(state["phase"], 240.0)
+            stuck = code is None and time.monotonic() - state["since"] > float(os.environ.get("MV_BENCH_PHASE_TIMEOUT_S", PHASE_TIMEOUT_S.get(state["phase"], 240.0)))
             mine = 0 if code == 0 else 2 if (stuck or (code is not None and code != 0)) else 1  # 0 done, 1 running, 2 failed
             seen = [None] * world
             dist.all_gather_object(seen, (mine, state["phase"]))
@@ -402,6 +402,15 @@ def main():
         print(f"bench.py: the peer-store transport could not be attached (got {exchange})", file=sys.stderr)
         return 3
     phase("warmup")
+    # (test hook, tests/test_bench_multirank.py: MV_BENCH_INJECT="fail:<rung>:<rank>" / "hang:<rung>:<rank>" -- that rank of that rung of the ladder leaves
+    # with an error / stops making progress here: the supervisors must move every rank to the next rung together)
+    for inj in filter(None, os.environ.get("MV_BENCH_INJECT", "").split(",")):
+        how, rung, who = inj.split(":")
+        if rung == os.environ.get("MV_BENCH_TRANSPORT", transport) and int(who) == rank:
+            print(f"bench.py: injected {how} on rank {rank} of rung {rung}", file=sys.stderr, flush=True)
+            if how == "fail":
+                return 5
+            time.sleep(3600.0)
     H, W = cfg["H"], cfg["W"]
     band = D.row_range(H, rank, world)
     assert band == caster.ShardRows()
