@@ -32,6 +32,24 @@ def test_abi_exports_every_declared_symbol(mvlib):
     assert mvlib.mv_error_string(_lib.MV_ERR_NO_DEVICE).decode().startswith("no usable gfx950")
 
 
+def test_the_headers_are_plain_c_and_link_against_the_library(tmp_path):
+    """The drop-in boundary is a C ABI: both headers compile as strict C99 (a cgo / JNI / N-API binding includes them as they are), and a C program that
+    uses nothing but them links against the library and reads the same struct sizes and ABI version as the ctypes mirror."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "multivolumes.h"\n#include "multivolumes_host.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%u %u %u %s\\n", (unsigned)sizeof(mv_config), (unsigned)sizeof(mv_stats), mv_abi_version(), mv_error_string(MV_ERR_TIMEOUT)); return 0; }\n')
+    libdir = os.path.join(ROOT, "multivolumes_amd")
+    exe = tmp_path / "abi.bin"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L" + libdir, "-lmultivolumes_amd", "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split(None, 3)
+    assert out[:3] == ["64", "128", "6"] and "timeout" in out[3]
+
+
 def test_no_gpu_means_failure_not_fallback(mvlib):
     """On a box without a GPU mv_create must fail loudly (the product has no CPU path)."""
     import torch
