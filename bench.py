@@ -233,7 +233,10 @@ def supervise(args, world, rank):
         while True:
             time.sleep(0.5 if proc.poll() is not None else 2.0)
             code = proc.poll()
-            stuck = code is None and time.monotonic() - state["since"] > float(os.environ.get("MV_BENCH_PHASE_TIMEOUT_S", PHASE_TIMEOUT_S.get(state["phase"], 240.0)))
+            limit = PHASE_TIMEOUT_S.get(state["phase"], 240.0)
+            if state["phase"] == "warmup" and os.environ.get("MV_BENCH_WARMUP_TIMEOUT_S"):  # (test hook: the injected hang sits in the warm-up)
+                limit = float(os.environ["MV_BENCH_WARMUP_TIMEOUT_S"])
+            stuck = code is None and time.monotonic() - state["since"] > limit
             mine = 0 if code == 0 else 2 if (stuck or (code is not None and code != 0)) else 1  # 0 done, 1 running, 2 failed
             seen = [None] * world
             dist.all_gather_object(seen, (mine, state["phase"]))
