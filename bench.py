@@ -234,8 +234,8 @@ def supervise(args, world, rank):
             time.sleep(0.5 if proc.poll() is not None else 2.0)
             code = proc.poll()
             limit = PHASE_TIMEOUT_S.get(state["phase"], 240.0)
-            if state["phase"] == "warmup" and os.environ.get("MV_BENCH_WARMUP_TIMEOUT_S"):  # (test hook: the injected hang sits in the warm-up)
-                limit = float(os.environ["MV_BENCH_WARMUP_TIMEOUT_S"])
+            if state["phase"] == "warmup" and os.environ.get("MV_BENCH_WARMUP_TIMEOUT_S") and f"hang:{transport}:" in os.environ.get("MV_BENCH_INJECT", ""):
+                limit = float(os.environ["MV_BENCH_WARMUP_TIMEOUT_S"])  # (test hook: the injected hang sits in this rung's warm-up; the other rungs keep their patience)
             stuck = code is None and time.monotonic() - state["since"] > limit
             mine = 0 if code == 0 else 2 if (stuck or (code is not None and code != 0)) else 1  # 0 done, 1 running, 2 failed
             seen = [None] * world

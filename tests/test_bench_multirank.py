@@ -104,7 +104,7 @@ def test_a_rung_that_fails_or_hangs_on_one_rank_moves_every_rank_to_the_next(how
     if how == "hang":
         env["MV_BENCH_WARMUP_TIMEOUT_S"] = "25"
     r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24", "--latency-frames", "24", "--no-cpu-baseline"], 400, env)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, "\n".join(l for l in r.stderr.splitlines() if l.startswith("bench.py") or "Error" in l)[-3000:]
     assert f"injected {how} on rank 1 of rung peer" in r.stderr and "transport 'peer' failed or stopped making progress" in r.stderr and "trying the next one" in r.stderr, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["config"]["fallback_level"] == 1 and d["config"]["transport"] == "torch-callbacks" and d["value"] > 0, d["config"]
