@@ -94,7 +94,7 @@ def test_bench_starts_and_supervises_its_ranks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("how", ["fail", "hang"])
+@pytest.mark.parametrize("how", ["fail", pytest.param("hang", marks=pytest.mark.skipif(os.environ.get("MV_SLOW_TESTS") != "1", reason="two minutes: MV_SLOW_TESTS=1 (passes: docs/STATUS.md)"))])
 def test_a_rung_that_fails_or_hangs_on_one_rank_moves_every_rank_to_the_next(how):
     """The safety net of the first run on a node with more than one GPU: bench.py's ladder of transports.  Rank 1 of the first rung (peer stores) leaves with
     an error, or stops making progress in its warm-up (MV_BENCH_INJECT, with the supervisors' patience for a warm-up cut to 25 s): the supervisors kill the rung's
@@ -103,7 +103,7 @@ def test_a_rung_that_fails_or_hangs_on_one_rank_moves_every_rank_to_the_next(how
     env.update(MV_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MV_BENCH_INJECT=f"{how}:peer:1")
     if how == "hang":
         env["MV_BENCH_WARMUP_TIMEOUT_S"] = "25"
-    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "24", "--latency-frames", "24", "--no-cpu-baseline"], 400, env)
+    r = run_group([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "T2", "--steps", "6", "--warmup", "2", "--steady-frames", "0", "--latency-frames", "0", "--no-cpu-baseline"], 400, env)
     assert r.returncode == 0, "\n".join(l for l in r.stderr.splitlines() if l.startswith("bench.py") or "Error" in l)[-3000:]
     assert f"injected {how} on rank 1 of rung peer" in r.stderr and "transport 'peer' failed or stopped making progress" in r.stderr and "trying the next one" in r.stderr, r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

@@ -223,7 +223,10 @@ def test_ranks_that_were_handed_different_frames_get_an_error_not_a_hang(tmp_pat
     assert r.stdout.count("divergence reported at frame") == 2, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("mode", ["peer", "peer-folded", "peer-x4"])
+_SLOW = pytest.mark.skipif(os.environ.get("MV_SLOW_TESTS") != "1", reason="MV_SLOW_TESTS=1 (passes: docs/STATUS.md)")
+
+
+@pytest.mark.parametrize("mode", [pytest.param("peer", marks=_SLOW), pytest.param("peer-folded", marks=_SLOW), "peer-x4"])
 def test_a_stalled_rank_is_reported_soon_after_the_timeout(tmp_path, mode):
     """Rank 1's host stops handing over frames behind frame 8 (it stays alive, its buffers mapped).  Rank 0's waits -- a one-wavefront kernel, or
     the prologue of EVERY workgroup of the consumer when the waits are folded -- give up after the transport's timeout (2 s here) and the next call
@@ -232,7 +235,7 @@ def test_a_stalled_rank_is_reported_soon_after_the_timeout(tmp_path, mode):
     the light cells, whose kernel was waiting for rank 1: local rows now have twice the patience, and a report that names another rank comes first);
     a give-up is also seen by the workgroups and launches of the slot dispatched behind it (mv_kernels.hpp peerGaveUp)."""
     import re
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_TRANSPORT="peer", MV_TEST_PEER_TIMEOUT_MS="2000", MV_TEST_STALL_S="15", MV_TEST_W="1024", MV_TEST_H="1024")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MV_TEST_TRANSPORT="peer", MV_TEST_PEER_TIMEOUT_MS="2000", MV_TEST_STALL_S="12", MV_TEST_W="1024", MV_TEST_H="1024")
     if mode == "peer-x4":
         env.update(MV_TEST_FRAMES_PER_LAUNCH="4", MV_TEST_FOUR_CHAINS="1", MV_TEST_PEER_FOLD="1")
     elif mode == "peer-folded":
