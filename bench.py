@@ -399,7 +399,7 @@ def main():
     # N > 1: the per-frame protocol runs inside the library (mv_dist_frame); torch.distributed only distributes the RCCL ids
     phase("dist-init")
     exchange = D.init_frame_loop(caster, prefer_rccl=transport in ("rccl", "rccl-single-stream"), prefer_peer=transport == "peer",
-                                 peer_timeout_ms=20000, peer_rows_to_root=rows_to_root, peer_fold=peer_fold, peer_acquire=not args.peer_no_acquire, peer_push_cells=args.peer_push_cells) if world > 1 else None
+                                 peer_timeout_ms=int(os.environ.get("MV_BENCH_PEER_TIMEOUT_MS", "20000")), peer_rows_to_root=rows_to_root, peer_fold=peer_fold, peer_acquire=not args.peer_no_acquire, peer_push_cells=args.peer_push_cells) if world > 1 else None
     if world > 1 and transport == "peer" and exchange != "peer":
         # (asked for by name or by the ladder: a rank that could not attach it leaves, and the supervisors move everybody to the next level)
         print(f"bench.py: the peer-store transport could not be attached (got {exchange})", file=sys.stderr)
