@@ -1135,11 +1135,13 @@ __device__ __forceinline__ void marchLightBody(const DeviceState& st, uint32_t* 
 		float shadow;
 		{
 			vec4 p; p.x = rayOrigin.x; p.y = rayOrigin.y; p.z = rayOrigin.z; p.w = 1.0f;
+			// in the compiled order (CSRayMarchL.cso; oracle/mv_oracle.cpp mvo_march_light): v = 0.5 - y * 0.5, reference depth = (row.w - 0.0027) + dot3
 			const vec4 ls = mul44(p, cb->shadowViewProj);
+			const float* m = cb->shadowViewProj;
 			const float su = ls.x * 0.5f + 0.5f;
-			float sv = ls.y * 0.5f + 0.5f;
-			sv = 1.0f - sv;
-			shadow = sampleCmpD16(st.shadowMap, st.M, su, sv, ls.z - 0.0027f);
+			const float sv = 0.5f - ls.y * 0.5f;
+			const float dz = p.x * m[8] + p.y * m[9] + p.z * m[10];
+			shadow = sampleCmpD16(st.shadowMap, st.M, su, sv, (m[11] + -0.0027f) + dz);
 		}
 
 		float ao = 1.0f;

@@ -893,12 +893,17 @@ uint32_t mvo_march_light(uint32_t V, uint32_t N, uint32_t L, uint32_t M,
 				// ShadowTest (RayMarch.hlsli:103-112): mul(float4(pos,1), g_shadowViewProj).xyz
 				float shadow;
 				{
+					// In the COMPILED order (CSRayMarchL.cso %109-%125; found in round 6 by reading the shader's fp32 `shadow` out through the light colour /
+					// ambient constants, tests/test_oracle_vs_reference_dxil.py::test_light_march_shadow_in_full_precision): v = 0.5 - y * 0.5 (ONE rounding; the
+					// source's 1 - (y * 0.5 + 0.5) has two), and the reference depth as (row.w - 0.0027) + dot3, not (dot3 + row.w) - 0.0027.
 					const float4 p = { rayOrigin.x, rayOrigin.y, rayOrigin.z, 1.0f };
 					const float4 ls = mul44(p, cb.shadowViewProj);
-					float su = ls.x * 0.5f + 0.5f;
-					float sv = ls.y * 0.5f + 0.5f;
-					sv = 1.0f - sv;
-					shadow = sampleCmpD16(shadowMap, M, su, sv, ls.z - 0.0027f);
+					const float* m = cb.shadowViewProj;
+					const float su = ls.x * 0.5f + 0.5f;
+					const float sv = 0.5f - ls.y * 0.5f;
+					const float dz = p.x * m[8] + p.y * m[9] + p.z * m[10];
+					const float ref = (m[11] + -0.0027f) + dz;
+					shadow = sampleCmpD16(shadowMap, M, su, sv, ref);
 				}
 
 				float ao = 1.0f;

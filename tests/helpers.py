@@ -71,3 +71,50 @@ def replicating_allgather(world):
                 return 1
         return 0
     return allgather
+
+
+def shadow_in_full_precision(light_map_of, cb, L):
+    """The fp32 value of CSRayMarchL's `shadow` for every voxel of a light map, read out through the frame constants (round 6).  The light map's
+    R11G11B10F texels keep six or five mantissa bits, so a last-bit difference in `shadow` shows in one voxel of some 10^5.  With light colour (1, 0, 0) x 1
+    and ambient (-c, 0, 0) x 1 the shader stores shadow * 1 + (-c): exact while c is near shadow, positive while c < shadow.  Bisecting c over the fp32
+    bit patterns until the stored red channel turns 0 gives shadow to the last bit (offset by the same packing threshold in every implementation).
+    light_map_of(cbPerFrame bytes) -> the light map of the volume marched [L, L, L] u32.  Returns [L^3] u32 bit patterns."""
+    n = L ** 3
+    res = np.zeros(n, np.uint32)
+    base = np.frombuffer(bytearray(np.asarray(cb).tobytes()), np.float32).copy()
+    base[44:48] = (1.0, 0.0, 0.0, 1.0)  # CBPerFrame: lightColor at float 44, ambient at float 48 (oracle/mv_oracle.cpp CBPerFrame)
+    top = int(np.float32(8.0).view(np.uint32))
+    for v in range(n):
+        lo, hi = 0, top
+        while lo < hi:
+            mid = (lo + hi + 1) // 2
+            base[48:52] = (-float(np.uint32(mid).view(np.float32)), 0.0, 0.0, 1.0)
+            if int(np.asarray(light_map_of(base.view(np.uint8))).reshape(-1)[v]) & 0x7ff:
+                lo = mid
+            else:
+                hi = mid - 1
+        res[v] = lo
+    return res
+
+
+def full_precision_light_scene(seed, L=2):
+    """A small random scene for shadow_in_full_precision: (cfg, volumes, descs, worlds, light, shadow map, M)."""
+    from tests.test_random_scenes import random_volume
+    rng = np.random.default_rng(31000 + seed)
+    N = int(rng.choice([8, 12, 16]))
+    V = int(rng.choice([1, 2, 3]))
+    M = 32
+    cfg = dict(N=N, L=L, V=V, W=32, H=32, maxRay=16, maxLight=int(rng.choice([4, 8, 20])), mesh=True)
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "noise"], size=V)]
+    lib = _lib.load()
+    worlds = np.zeros((V, 12), np.float32)
+    for i in range(V):
+        size = float(np.exp(rng.uniform(np.log(4.0), np.log(40.0))))
+        lib.mvh_set_volume_world(size, rc._ptr(rc._f32(rng.normal(0.0, 10.0, size=3), 3)), rc._ptr(worlds[i]))
+    light = tuple(float(x) for x in rng.normal(0.0, 60.0, size=3) + np.array([0.0, 40.0, 0.0]))
+    frame = int(rng.integers(0, 8))
+    svp = scene.shadow_vp(cfg)
+    shadow = rc.synth_sphere_shadow(M, svp, (0, 0, 0), 8.0)
+    if seed % 4:  # (most seeds: noise, so that the comparisons are mixed and the bilinear weights fractional everywhere)
+        shadow = rng.integers(0, 65536, size=(M, M)).astype(np.uint16)
+    return cfg, vols, worlds, light, frame, shadow, M

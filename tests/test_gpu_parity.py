@@ -4,6 +4,8 @@ Bar (BASELINE.json north_star): cull outputs bit-exact; marched buffers within 1
 with the outlier count reported.  Kernel and oracle share the numeric contract (fp32, explicit fma only in
 lerp / ray-point evaluation, -ffp-contract=off), so in practice almost every texel matches bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -678,3 +680,39 @@ def test_large_grid_offsets(oracle, N):
         assert np.array_equal(c.ReadBackComposite(), exp)
         st = c.GetStats()
         assert st["view_samples"] == ref["stats"]["view_samples"] > 0 and st["composite_samples"] == exp_samples
+
+
+@pytest.mark.gpu
+def test_light_march_shadow_in_full_precision_on_the_gpu(oracle):
+    """The light map keeps six mantissa bits; this reads the kernel's fp32 `shadow` out through the frame constants (tests/helpers.py
+    shadow_in_full_precision: light colour (1, 0, 0), ambient (-c, 0, 0), bisect c) and compares it with the oracle's, voxel by voxel, to the last bit --
+    ShadowTest in the compiled order (round 6) and the light ray through every volume behind it."""
+    from tests.helpers import default_descs, full_precision_light_scene, host_frame, shadow_in_full_precision
+    voxels = fractional = 0
+    for seed in range(int(os.environ.get("MV_GPU_PEEL_SEEDS", "12"))):
+        cfg, vols, worlds, light, frame, shadow, M = full_precision_light_scene(seed, L=4)
+        V, N, L = cfg["V"], cfg["N"], cfg["L"]
+        descs = default_descs(V, V, N)
+        _, vp, svp, cb, po = host_frame(cfg, frame, (30.0, 20.0, -60.0), worlds, light)
+        with MultiRayCaster(N, L, V, V, (cfg["W"], cfg["H"]), shadowMapSize=M) as c:
+            for i, v in enumerate(vols):
+                c.LoadVolumeData(i, v)
+            c.SetMaxSamples(cfg["maxRay"], cfg["maxLight"])
+            c.SetRenderTargets(np.ones((cfg["H"], cfg["W"]), np.float32), shadow)
+            c.UpdateFrameRaw(cb, po)
+            c.cullVolumes()
+            vis, _ = c.ReadBackVisibleLists()
+            vis = np.sort(np.asarray(vis, np.uint32))
+            vid = oracle.march_light(V, N, L, M, vols, descs, po, cb, shadow, None, vis, cfg["maxLight"])[0]
+
+            def on_gpu(cbb):
+                c.UpdateFrameRaw(cbb, po)
+                c.cullVolumes()
+                c.rayMarchL()
+                return c.ReadBackLightMap(int(vid))
+            a = shadow_in_full_precision(lambda cbb: oracle.march_light(V, N, L, M, vols, descs, po, cbb, shadow, None, vis, cfg["maxLight"])[1][vid], cb, L)
+            b = shadow_in_full_precision(on_gpu, cb, L)
+        assert np.array_equal(a, b), (seed, [hex(int(x)) for x in a[a != b]][:8], [hex(int(x)) for x in b[a != b]][:8])
+        voxels += len(a)
+        fractional += int(((a != 0) & (a != int(np.float32(1.0).view(np.uint32)))).sum())
+    assert fractional > voxels // 4, (fractional, voxels)
