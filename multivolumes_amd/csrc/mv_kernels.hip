@@ -339,8 +339,7 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 		p = mul44(p, po.wvp);
 		p.x /= p.w; p.y /= p.w; p.z /= p.w;
 		p.x = p.x * 0.5f + 0.5f;
-		p.y = p.y * 0.5f + 0.5f;
-		p.y = 1.0f - p.y;
+		p.y = 0.5f - p.y * 0.5f;	// (as compiled, CSVolumeCull.cso: one rounding where the source's 1 - (y * 0.5 + 0.5) has two; oracle/mv_oracle.cpp mvo_cull)
 		const float vx = p.x * vpW, vy = p.y * vpH, vz = p.z;
 
 		// CSVolumeCull.hlsl:32-38
@@ -430,7 +429,7 @@ __device__ __forceinline__ void cullBody(const DeviceState& st, bool chained)
 				const uint32_t cubeMapSize = volumeIn >> 18;
 				const uint32_t numMips = (volumeIn >> 14) & 0xfu;
 				float s = maxEdge / 2.0f;
-				float raySampleAmt = 2.0f * s / kSqrt3;
+				float raySampleAmt = 2.0f * s * __uint_as_float(0x3f13cd3au);	// (as compiled: times the constant 1 / sqrt(3) folded to fp32, not a division)
 				const uint32_t raySampleCnt = f2u_sat(__builtin_ceilf(raySampleAmt));
 				raySampleCount = raySampleCnt < raySampleCount ? raySampleCnt : raySampleCount;
 				raySampleAmt = __builtin_fminf(raySampleAmt, (float)raySampleCount);

@@ -752,9 +752,10 @@ void mvo_cull(uint32_t V, const void* perObjectBytes, const uint32_t* volumeDesc
 			p.w = 1.0f;
 			p = mul44(p, po.wvp);
 			p.x /= p.w; p.y /= p.w; p.z /= p.w;
+			// (as compiled, CSVolumeCull.cso %87-%92: y = 0.5 - y * 0.5 in ONE rounding -- the source's 1 - (y * 0.5 + 0.5) has two; found in round 6 by
+			// walking the cull's decision boundaries, tests/test_oracle_vs_reference_dxil.py::test_cull_agrees_at_its_decision_boundaries)
 			p.x = p.x * 0.5f + 0.5f;
-			p.y = p.y * 0.5f + 0.5f;
-			p.y = 1.0f - p.y;
+			p.y = 0.5f - p.y * 0.5f;
 			vx[i] = p.x * vpW; vy[i] = p.y * vpH; vz[i] = p.z;
 			// CSVolumeCull.hlsl:32
 			const bool isInView = (vx[i] <= vpW && vy[i] <= vpH && vx[i] >= 0.0f && vy[i] >= 0.0f) && vz[i] > 0.0f && vz[i] < 1.0f;
@@ -797,8 +798,9 @@ void mvo_cull(uint32_t V, const void* perObjectBytes, const uint32_t* volumeDesc
 		// EstimateCubeMapLOD (:267-294), upscale = 2, raySampleCountScale = 2
 		const uint32_t cubeMapSize = volumeIn >> 18;
 		const uint32_t numMips = (volumeIn >> 14) & 0xf;
+		// (as compiled, %216-%218: s * 2 TIMES the constant 1 / sqrt(3) folded to fp32, not a division by sqrt(3))
 		float s = maxEdge / 2.0f;
-		float raySampleAmt = 2.0f * s / kSqrt3;
+		float raySampleAmt = 2.0f * s * asfloat(0x3f13cd3au);
 		const uint32_t raySampleCnt = f2u(ceilf(raySampleAmt));
 		raySampleCount = std::min(raySampleCnt, raySampleCount);
 		raySampleAmt = fminf(raySampleAmt, (float)raySampleCount);

@@ -118,3 +118,58 @@ def full_precision_light_scene(seed, L=2):
     if seed % 4:  # (most seeds: noise, so that the comparisons are mixed and the bilinear weights fractional everywhere)
         shadow = rng.integers(0, 65536, size=(M, M)).astype(np.uint16)
     return cfg, vols, worlds, light, frame, shadow, M
+
+
+def cull_decision_boundaries(oracle, seed, trials=6):
+    """Round 6.  The cull's outputs are integers (mip, sample count, face mask, scheme bit, the lists): a last-bit difference in one of its float
+    intermediates moves a decision by ONE input float and shows in one scene of some 10^5.  This walks TO the decisions: take a random scene, pick one
+    float of the frame constants (eye, viewport) or of a volume's PerObject as a knob, step it until the oracle's output changes, bisect to the two
+    ADJACENT floats between which it changes.  Yields (cfg, descs, cbPerFrame bytes, perObject bytes) at those two floats and their outer neighbours:
+    another implementation must decide the same at all four."""
+    rng = np.random.default_rng(52000 + seed)
+    N = int(rng.choice([16, 64, 128, 256]))
+    V = int(rng.choice([1, 3, 4, 8]))
+    cfg = dict(N=N, L=8, V=V, W=int(rng.choice([64, 256, 1024])), H=int(rng.choice([48, 256, 1024])), maxRay=int(rng.choice([16, 128, 1000])), maxLight=8, mesh=False)
+    lib = _lib.load()
+    worlds = np.zeros((V, 12), np.float32)
+    for i in range(V):
+        size = float(np.exp(rng.uniform(np.log(4.0), np.log(60.0))))
+        lib.mvh_set_volume_world(size, rc._ptr(rc._f32(rng.normal(0.0, 18.0, size=3), 3)), rc._ptr(worlds[i]))
+    d = rng.normal(size=3)
+    eye = tuple((d / np.linalg.norm(d) * rng.uniform(8, 150)).astype(np.float32))
+    _, vp, svp, cb, po = host_frame(cfg, 0, eye, worlds, None)
+    descs = default_descs(V, V, N)
+
+    def key(res):
+        return (np.asarray(res[0]).tobytes(), np.sort(res[1]).tobytes(), np.sort(res[2]).tobytes())
+    for _ in range(trials):
+        if rng.random() < 0.3:
+            buf, idx = "cb", int(rng.choice([0, 1, 2, 4, 5]))                        # eye x / y / z, viewport width / height
+        else:
+            buf, idx = "po", int(rng.integers(V)) * 56 + int(rng.integers(0, 40))    # World, WorldI, WorldViewProj of a volume
+        v0 = int((np.asarray(cb) if buf == "cb" else np.asarray(po)).view(np.uint32)[idx])
+        span = int(rng.choice([1 << 12, 1 << 16, 1 << 20, 1 << 22]))
+        if (v0 & 0x7f800000) in (0, 0x7f800000):
+            continue
+
+        def at(bits):
+            c = np.frombuffer(bytearray(np.asarray(cb).tobytes()), np.uint32).copy()
+            p = np.frombuffer(bytearray(np.asarray(po).tobytes()), np.uint32).copy()
+            (c if buf == "cb" else p)[idx] = bits
+            return c.view(np.uint8), p.view(np.uint8)
+
+        def run(bits):
+            c, p = at(bits)
+            return key(oracle.cull(V, p, descs, c, cfg["maxRay"]))
+        lo, hi = v0, v0 + span   # (same sign, this binade or the next: the bit patterns are ordered like the magnitudes)
+        klo = run(lo)
+        if run(hi) == klo:
+            continue
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if run(mid) == klo:
+                lo = mid
+            else:
+                hi = mid
+        for bits in (lo - 1, lo, hi, hi + 1):
+            yield (cfg, descs) + at(bits)

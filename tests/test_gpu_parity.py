@@ -716,3 +716,33 @@ def test_light_march_shadow_in_full_precision_on_the_gpu(oracle):
         voxels += len(a)
         fractional += int(((a != 0) & (a != int(np.float32(1.0).view(np.uint32)))).sum())
     assert fractional > voxels // 4, (fractional, voxels)
+
+
+@pytest.mark.gpu
+def test_cull_agrees_with_the_oracle_at_its_decision_boundaries(oracle):
+    """The cull kernel at the adjacent input floats between which the oracle's cull changes a decision, and at their outer neighbours
+    (tests/helpers.py cull_decision_boundaries): VolumeInfo of the visible volumes and both lists equal -- the kernel's float intermediates are the
+    oracle's (and, through tests/test_oracle_vs_reference_dxil.py, the compiled shader's) to the last bit where it matters."""
+    from tests.helpers import cull_decision_boundaries
+    found = 0
+    casters = {}
+    try:
+        for seed in range(int(os.environ.get("MV_GPU_CULL_BOUNDARY_SEEDS", "150"))):
+            for cfg, descs, cb, po in cull_decision_boundaries(oracle, seed):
+                V, N = cfg["V"], cfg["N"]
+                k = (N, V, cfg["W"], cfg["H"], cfg["maxRay"])
+                if k not in casters:
+                    casters[k] = MultiRayCaster(N, 8, V, V, (cfg["W"], cfg["H"]), shadowMapSize=32)
+                    casters[k].SetMaxSamples(cfg["maxRay"], 8)
+                c = casters[k]
+                c.UpdateFrameRaw(cb, po)
+                c.cullVolumes()
+                info, vis, cube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+                gvis, gcube = c.ReadBackVisibleLists()
+                assert np.array_equal(np.sort(gvis), np.sort(vis)) and np.array_equal(np.sort(gcube), np.sort(cube)), (seed, cfg)
+                assert np.array_equal(c.ReadBackVolumeInfo()[np.sort(vis)], info[np.sort(vis)]), (seed, cfg, c.ReadBackVolumeInfo().tolist(), np.asarray(info).tolist())
+                found += 1
+    finally:
+        for c in casters.values():
+            c.close()
+    assert found >= 100, found

@@ -20,7 +20,7 @@ import pytest
 from multivolumes_amd import scene
 from multivolumes_amd import raycaster as rc
 from tests.conftest import half_to_float
-from tests.helpers import default_descs, host_frame, oracle_pipeline
+from tests.helpers import cull_decision_boundaries, default_descs, host_frame, oracle_pipeline
 
 dxref = pytest.importorskip("oracle.dxref")
 pytestmark = pytest.mark.skipif(not dxref.available(), reason="oracle/_ref/libmv_dxref.so not built (needs /root/reference/Bin/*.cso: make -C oracle ref)")
@@ -406,6 +406,21 @@ def test_special_inputs_against_the_compiled_shaders(oracle, seed):
         a, b = lm[vid][diff].astype(np.int64), lms2[vid][diff].astype(np.int64)
         for sh_, m_ in ((0, 0x7ff), (11, 0x7ff), (22, 0x3ff)):
             assert np.all(np.abs(((a >> sh_) & m_) - ((b >> sh_) & m_)) <= 1)
+
+
+def test_cull_agrees_at_its_decision_boundaries(oracle):
+    """Round 6 (tests/helpers.py cull_decision_boundaries): at the adjacent input floats between which the oracle's cull changes a decision -- sample count,
+    mip, a face bit, the scheme, visibility -- and at their outer neighbours, the reference's compiled cull decides the same.  The first walk disagreed at 2
+    of 7 boundaries: the compiled shader projects y as 0.5 - y * 0.5 (one rounding; the source's 1 - (y * 0.5 + 0.5) has two) and forms the sample count
+    from edge * (1 / sqrt(3) folded to fp32) instead of dividing by sqrt(3).  With the oracle (and the kernel) in that order: 1 976 boundaries, none."""
+    found = 0
+    for seed in range(int(os.environ.get("MV_DXIL_CULL_BOUNDARY_SEEDS", "150"))):
+        for cfg, descs, cb, po in cull_decision_boundaries(oracle, seed):
+            a = oracle.cull(cfg["V"], po, descs, cb, cfg["maxRay"])
+            b = dxref.cull(cfg["V"], po, descs, cb, cfg["maxRay"])
+            assert np.array_equal(a[0], b[0]) and np.array_equal(np.sort(a[1]), np.sort(b[1])) and np.array_equal(np.sort(a[2]), np.sort(b[2])), (seed, cfg, np.asarray(a[0]).tolist(), np.asarray(b[0]).tolist())
+            found += 1
+    assert found >= 100, found   # (four evaluations per boundary)
 
 
 def test_light_march_shadow_in_full_precision(oracle):
