@@ -173,3 +173,63 @@ def cull_decision_boundaries(oracle, seed, trials=6):
                 hi = mid
         for bits in (lo - 1, lo, hi, hi + 1):
             yield (cfg, descs) + at(bits)
+
+
+def small_march_scene(seed):
+    """A small random scene for the boundary walks of the view march and the composite (round 6): (cfg, volumes, descs, cb, po, depth map, light maps)."""
+    from tests.test_random_scenes import random_volume
+    rng = np.random.default_rng(77000 + seed)
+    N = int(rng.choice([8, 12, 16]))
+    L = int(rng.choice([4, 6]))
+    V = int(rng.choice([1, 2, 3]))
+    cfg = dict(N=N, L=L, V=V, W=48, H=32, maxRay=int(rng.choice([8, 24])), maxLight=8, mesh=bool(rng.integers(0, 2)))
+    vols = [random_volume(rng, N, k) for k in rng.choice(["plain", "noise"], size=V)]
+    lib = _lib.load()
+    worlds = np.zeros((V, 12), np.float32)
+    for i in range(V):
+        size = float(np.exp(rng.uniform(np.log(6.0), np.log(30.0))))
+        lib.mvh_set_volume_world(size, rc._ptr(rc._f32(rng.normal(0.0, 8.0, size=3), 3)), rc._ptr(worlds[i]))
+    d = rng.normal(size=3)
+    eye = tuple((d / np.linalg.norm(d) * rng.uniform(30, 90)).astype(np.float32))
+    _, vp, svp, cb, po = host_frame(cfg, 0, eye, worlds, None)
+    depth, _ = scene.depth_and_shadow(cfg, vp, svp, 32)
+    lms = rng.integers(0, 2 ** 32, size=(V, L, L, L), dtype=np.uint64).astype(np.uint32) & np.uint32(0x3BFFF7FF)  # (finite 11/11/10-bit floats)
+    return rng, cfg, vols, default_descs(V, V, N), cb, po, depth, lms
+
+
+def output_boundaries(rng, cb, po, volumes_of_interest, evaluate, trials=3, span=64):
+    """The adjacent floats of one input (a float of the eye position or of a volume's PerObject) between which evaluate(cb bytes, po bytes) -> bytes changes:
+    there some fp32 intermediate sits on a rounding boundary of a stored half, or on a decision (a sample more, a texel further, a layer matched), and a
+    last-bit difference between two implementations shows.  Yields (cb bytes, po bytes) at both floats."""
+    for _ in range(trials):
+        if rng.random() < 0.3:
+            buf, idx = "cb", int(rng.choice([0, 1, 2]))
+        else:
+            buf, idx = "po", int(rng.choice(volumes_of_interest)) * 56 + int(rng.integers(0, 56))
+        v0 = int((np.asarray(cb) if buf == "cb" else np.asarray(po)).view(np.uint32)[idx])
+        if (v0 & 0x7f800000) in (0, 0x7f800000):
+            continue
+
+        def at(bits):
+            c = np.frombuffer(bytearray(np.asarray(cb).tobytes()), np.uint32).copy()
+            p = np.frombuffer(bytearray(np.asarray(po).tobytes()), np.uint32).copy()
+            (c if buf == "cb" else p)[idx] = bits
+            return c.view(np.uint8), p.view(np.uint8)
+        lo, hi = v0, v0 + span
+        klo = evaluate(*at(lo))
+        if evaluate(*at(hi)) == klo:
+            continue
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            if evaluate(*at(mid)) == klo:
+                lo = mid
+            else:
+                hi = mid
+        yield at(lo)
+        yield at(hi)
+
+
+def halfs_without_nan_payloads(a):
+    a = np.asarray(a).copy().reshape(-1)
+    a[np.isnan(a.view(np.float16))] = 0x7e00   # (sign and payload of a NaN are not compared)
+    return a

@@ -20,7 +20,7 @@ import pytest
 from multivolumes_amd import scene
 from multivolumes_amd import raycaster as rc
 from tests.conftest import half_to_float
-from tests.helpers import cull_decision_boundaries, default_descs, host_frame, oracle_pipeline
+from tests.helpers import cull_decision_boundaries, default_descs, halfs_without_nan_payloads, host_frame, oracle_pipeline, output_boundaries, small_march_scene
 
 dxref = pytest.importorskip("oracle.dxref")
 pytestmark = pytest.mark.skipif(not dxref.available(), reason="oracle/_ref/libmv_dxref.so not built (needs /root/reference/Bin/*.cso: make -C oracle ref)")
@@ -444,6 +444,62 @@ def test_light_march_shadow_in_full_precision(oracle):
         voxels += len(a)
         fractional += int(((a != 0) & (a != int(np.float32(1.0).view(np.uint32)))).sum())
     assert fractional > voxels // 3, (fractional, voxels)
+
+
+def test_view_march_agrees_at_its_boundaries(oracle):
+    """Round 6 (tests/helpers.py output_boundaries): at the adjacent input floats between which the oracle's view march changes ANY stored half or cube depth --
+    an fp32 intermediate on a rounding boundary of the fp16 store, a sample more, another depth texel, the early-out -- the compiled CSRayMarchV stores the same.
+    10 000 knobs, 4 097 boundaries, none disagrees (the cull and the ShadowTest, where this kind of walk found one-rounding differences, have two roundings
+    where the bytecode has one; the view march has had the bytecode's form since round 2, when fp16 made it visible)."""
+    found = 0
+    for seed in range(int(os.environ.get("MV_DXIL_VIEW_BOUNDARY_SEEDS", "120"))):
+        rng, cfg, vols, descs, cb, po, depth, lms = small_march_scene(seed)
+        V, N, L, W, H = cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"]
+        info, vis, cube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+        if len(cube) == 0:
+            continue
+
+        def view(fn, c, p):   # (the cull's decisions held fixed: this walks the march)
+            r = fn(V, N, L, W, H, vols, lms, depth, p, c, info, cube)
+            return halfs_without_nan_payloads(r[0]).tobytes() + np.asarray(r[1]).tobytes()
+        for c, p in output_boundaries(rng, cb, po, cube, lambda c, p: view(oracle.march_view, c, p)):
+            assert view(oracle.march_view, c, p) == view(dxref.march_view, c, p), (seed, cfg)
+            found += 1
+    assert found >= 60, found
+
+
+def test_composite_agrees_at_its_boundaries(oracle):
+    """The same walk through the composite (PSDepthPeel -> PSCube with CubeCast or the screen-space RayCast -> PSResolveOIT, cube maps and cull held fixed):
+    4 386 boundaries; the compiled shaders store the same image, except where two fragments of a pixel have IDENTICAL depth bits (3 pixels in 4 000 scenes): the
+    reference's own result there depends on the order its fragments happen to run in (contract item 4)."""
+    import ctypes as C
+    from oracle import mv_oracle as O
+    olib = O.load()
+    olib.mvo_pixel_fragments.restype = C.c_uint32
+    olib.mvo_pixel_fragments.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 3
+    found = ties = 0
+    for seed in range(int(os.environ.get("MV_DXIL_COMPOSITE_BOUNDARY_SEEDS", "40"))):
+        rng, cfg, vols, descs, cb, po, depth, lms = small_march_scene(seed)
+        V, N, L, W, H = cfg["V"], cfg["N"], cfg["L"], cfg["W"], cfg["H"]
+        info, vis, cube = oracle.cull(V, po, descs, cb, cfg["maxRay"])
+        if len(vis) == 0:
+            continue
+        vis = np.sort(vis).astype(np.uint32)
+        cm, cd = oracle.march_view(V, N, L, W, H, vols, lms, depth, po, cb, info, cube)[:2]
+
+        def image(fn, c, p):
+            r = fn(V, N, L, W, H, vols, lms, depth, p, c, info, vis, cm, cd)
+            return halfs_without_nan_payloads(r[0] if isinstance(r, tuple) else r)
+        for c, p in output_boundaries(rng, cb, po, vis, lambda c, p: image(oracle.composite, c, p).tobytes()):
+            a, b = image(oracle.composite, c, p).reshape(H, W, 4), image(dxref.composite, c, p).reshape(H, W, 4)
+            for py, px in np.argwhere((a != b).any(-1)):
+                vol_buf, lpt_buf, z_buf = np.zeros(V, np.uint32), np.zeros((V, 3), np.float32), np.zeros(V, np.float32)
+                cc, pp = np.ascontiguousarray(c).copy(), np.ascontiguousarray(p).copy()
+                n = olib.mvo_pixel_fragments(W, H, int(px), int(py), pp.ctypes.data, cc.ctypes.data, vis.ctypes.data, len(vis), vol_buf.ctypes.data, lpt_buf.ctypes.data, z_buf.ctypes.data)
+                assert len(set(z_buf[:n].view(np.uint32).tolist())) < n, (seed, int(py), int(px), "differs without a tie of fragment depths")
+                ties += 1
+            found += 1
+    assert found >= 40, found
 
 
 def test_probe_path_at_its_rounding_boundaries(oracle):
