@@ -732,6 +732,8 @@ def test_cull_agrees_with_the_oracle_at_its_decision_boundaries(oracle):
                 V, N = cfg["V"], cfg["N"]
                 k = (N, V, cfg["W"], cfg["H"], cfg["maxRay"])
                 if k not in casters:
+                    if len(casters) >= 6:  # (a context of eight 256^3 volumes holds 2 GiB: a long sweep keeps a handful, not one per config)
+                        casters.pop(next(iter(casters))).close()
                     casters[k] = MultiRayCaster(N, 8, V, V, (cfg["W"], cfg["H"]), shadowMapSize=32)
                     casters[k].SetMaxSamples(cfg["maxRay"], 8)
                 c = casters[k]
