@@ -748,3 +748,14 @@ def test_cull_agrees_with_the_oracle_at_its_decision_boundaries(oracle):
         for c in casters.values():
             c.close()
     assert found >= 100, found
+
+
+@pytest.mark.gpu
+def test_view_march_agrees_with_the_oracle_at_its_boundaries():
+    """scripts/r06_gpu_view_walk.py: cull + view march on the GPU at the adjacent input floats between which any half or cube depth the ORACLE stores changes
+    (tests/helpers.py output_boundaries) -- VolumeInfo, every marched face and depth equal there too."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "r06_gpu_view_walk.py"), "40"], capture_output=True, text=True, cwd=root, timeout=300)
+    assert r.returncode == 0 and "GPU differs from the oracle at 0," in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
