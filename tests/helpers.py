@@ -233,3 +233,30 @@ def halfs_without_nan_payloads(a):
     a = np.asarray(a).copy().reshape(-1)
     a[np.isnan(a.view(np.float16))] = 0x7e00   # (sign and payload of a NaN are not compared)
     return a
+
+
+def pixels_with_tied_fragment_depths(W, H, V, po, cb, vis, pixels):
+    """Of `pixels` [(y, x)], those where two of the pixel's fragments have IDENTICAL depth bits: the K-buffer then holds that depth twice, both fragments match its
+    first layer, and what the reference shows depends on the order its fragments happen to run in (contract item 4) -- the compiled shaders run
+    in list order under oracle/dxref.py, the oracle breaks the tie by list index: such pixels are compared with nothing.  About one pixel in 3 000 small random scenes."""
+    import ctypes as C
+    from oracle import mv_oracle as O
+    olib = O.load()
+    olib.mvo_pixel_fragments.restype = C.c_uint32
+    olib.mvo_pixel_fragments.argtypes = [C.c_uint32] * 4 + [C.c_void_p] * 3 + [C.c_uint32] + [C.c_void_p] * 3
+    pp, cc = np.ascontiguousarray(po).view(np.uint8).copy(), np.ascontiguousarray(cb).view(np.uint8).copy()
+    vv = np.ascontiguousarray(np.sort(vis), np.uint32)
+    tied = []
+    for py, px in pixels:
+        vol_buf, lpt_buf, z_buf = np.zeros(max(V, 1), np.uint32), np.zeros((max(V, 1), 3), np.float32), np.zeros(max(V, 1), np.float32)
+        n = olib.mvo_pixel_fragments(W, H, int(px), int(py), pp.ctypes.data, cc.ctypes.data, vv.ctypes.data, len(vv), vol_buf.ctypes.data, lpt_buf.ctypes.data, z_buf.ctypes.data)
+        if len(set(z_buf[:n].view(np.uint32).tolist())) < n:
+            tied.append((int(py), int(px)))
+    return tied
+
+
+def images_equal_up_to_depth_ties(got, img, W, H, V, po, cb, vis):
+    """NaNs at the same halfs, every other half equal -- except in pixels whose fragments tie in depth (above)."""
+    a, b = halfs_without_nan_payloads(got).reshape(H, W, 4), halfs_without_nan_payloads(img).reshape(H, W, 4)
+    bad = [tuple(int(v) for v in yx) for yx in np.argwhere((a != b).any(-1))]
+    return not bad or len(bad) <= 2 and sorted(pixels_with_tied_fragment_depths(W, H, V, po, cb, vis, bad)) == sorted(bad)

